@@ -1,0 +1,153 @@
+"""ctypes binding of the C-ABI library ``libdva_hip.so`` (declared in ``include/dva.h``).
+
+This is the only place Python touches native code.  There is deliberately NO fallback: if the
+library is missing, or a tensor is not on a HIP device, the ops raise.  (The CPU oracle under
+``oracle/`` is test infrastructure and is never imported from this package.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdva_hip.so")
+
+DVA_F32, DVA_BF16 = 0, 1
+DVA_SUM, DVA_MEAN, DVA_MAX, DVA_MIN = 0, 1, 2, 3
+REDUCE_CODE = {"sum": DVA_SUM, "add": DVA_SUM, "mean": DVA_MEAN, "max": DVA_MAX, "min": DVA_MIN}
+CAMERA_CODE = {
+    "s3dis_equirectangular": 0,
+    "scannet": 1,
+    "kitti360_perspective": 2,
+    "kitti360_fisheye": 3,
+}
+
+_ERRORS = {
+    -1: "DVA_ERR_INVALID (bad argument)",
+    -2: "DVA_ERR_UNSUPPORTED",
+    -3: "DVA_ERR_LAUNCH (HIP runtime error)",
+    -4: "DVA_ERR_OVERFLOW (composite key does not fit int64)",
+}
+
+
+class DvaError(RuntimeError):
+    pass
+
+
+class DvaCamera(ctypes.Structure):
+    """Mirror of ``struct dva_camera`` (include/dva.h)."""
+    _fields_ = [
+        ("model", ctypes.c_int32),
+        ("img_w", ctypes.c_int32),
+        ("img_h", ctypes.c_int32),
+        ("crop_top", ctypes.c_int32),
+        ("crop_bottom", ctypes.c_int32),
+        ("r_min", ctypes.c_float),
+        ("r_max", ctypes.c_float),
+        ("img_xyz", ctypes.c_float * 3),
+        ("opk", ctypes.c_float * 3),
+        ("extrinsic", ctypes.c_float * 16),
+        ("intrinsic", ctypes.c_float * 16),
+        ("fisheye", ctypes.c_float * 7),
+        ("voxel", ctypes.c_float),
+        ("k_swell", ctypes.c_float),
+        ("d_swell", ctypes.c_double),
+        ("exact", ctypes.c_int32),
+    ]
+
+
+_vp, _i64, _i32, _f32, _f64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                               ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol include/dva.h declares must be listed here
+SIGNATURES = {
+    "dva_version": (ctypes.c_int, []),
+    "dva_device_count": (ctypes.c_int, []),
+    "dva_segment_csr_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dva_segment_csr_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dva_gather_csr": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "dva_segment_softmax_csr_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "dva_segment_softmax_csr_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "dva_pack_gather_index": (ctypes.c_int, [_vp, _vp, _vp, _i32, _f64, _i64, _i64, _vp, _vp]),
+    "dva_gather_nearest_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_gather_nearest_bwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_gather_bilinear_fwd": (ctypes.c_int,
+                                [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_gather_bilinear_bwd": (ctypes.c_int,
+                                [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_view_attention_fwd": (ctypes.c_int,
+                               [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
+                                _i32, _f32, _i32, _i32, _vp]),
+    "dva_view_attention_bwd": (ctypes.c_int,
+                               [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_lex_workspace_bytes": (ctypes.c_int64, [_i64]),
+    "dva_argsort_i64": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "dva_argunique_i64": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "dva_visibility_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(DvaCamera), _i64]),
+    "dva_visibility": (ctypes.c_int,
+                       [_vp, _i64, ctypes.POINTER(DvaCamera), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                        _vp, _i64, _vp]),
+    "dva_mapping_features": (ctypes.c_int,
+                             [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(DvaCamera),
+                              _i64, _vp, ctypes.POINTER(ctypes.c_int32), _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdva_hip.so (once) and attach the prototypes. Raises DvaError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DvaError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C deepviewagg_amd/csrc`). deepviewagg_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DvaError(f"{what} failed: {_ERRORS.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return DVA_F32
+    if t.dtype == torch.bfloat16:
+        return DVA_BF16
+    raise TypeError(f"deepviewagg_amd kernels take float32 or bfloat16 features, got {t.dtype}")
+
+
+def require_device(*tensors):
+    """The kernels only exist for HIP devices; refuse anything else loudly."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise DvaError(
+                "deepviewagg_amd ops run on a HIP device only (got a CPU tensor); "
+                "there is no CPU fallback in the product path")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise DvaError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev

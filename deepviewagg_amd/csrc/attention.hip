@@ -1,0 +1,523 @@
+// DeepViewAgg view attention for gfx950: segment softmax + attention-weighted segment sum +
+// rectified-tanh gating, forward and backward (reference: modules/multimodal/pooling.py:284-300,
+// :514-530, :690-715, :737-810).
+//
+// HBM-bound.  Algorithmic bytes per launch (s = bytes/element of val):
+//   fwd: V*(C*s + 2*G*4) + N*(C*s + 8 + 2*G*4)     (val, compat in, att out | out, ptr, gate+amax)
+//   bwd: V*(2*C*s + 4*G*4) + N*(C*s + 8 + 2*G*4)   (val in, grad_val out, compat/att in,
+//                                                   grad_compat written twice (scratch + final))
+//
+// Fused fast path ("team" kernels): a team of TS = LPR*R lanes owns one point; LPR lanes cover one
+// view row with 16-byte loads (VEC elements each), R rows are in flight per step, so a wavefront
+// issues 1 KiB of contiguous val per load instruction when R*LPR = 64.  Reductions over views are
+// per-lane fp32 accumulators + xor-shuffles across the R row slots; reductions over the channels of
+// a group are xor-shuffles inside a row.  No LDS, no atomics on the data path (gating-parameter
+// gradients: LDS partials per block, then one atomic per block).
+// The generic path (one thread per (point, channel)) covers every other shape.
+#include "dva_common.h"
+
+namespace dva {
+
+// ------------------------------------------------------------------------------------------------
+// generic path
+// ------------------------------------------------------------------------------------------------
+
+// one thread per (point, group): softmax over the point's views, gate, argmax
+__global__ __launch_bounds__(256) void att_scores_kernel(const float* __restrict__ compat,
+                                                          const int64_t* __restrict__ ptr,
+                                                          const float* __restrict__ gw,
+                                                          const float* __restrict__ gb,
+                                                          float* __restrict__ att,
+                                                          float* __restrict__ gate,
+                                                          int32_t* __restrict__ amax, int64_t N,
+                                                          int G, int scaling, float eps) {
+  const int64_t total = N * (int64_t)G;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / G;
+    const int g = (int)(t - p * G);
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    float m = 0.f;
+    int64_t am = -1;
+    for (int64_t r = beg; r < end; ++r) {
+      const float v = compat[r * G + g];
+      if (r == beg || v > m) {
+        m = v;
+        am = r;
+      }
+    }
+    if (end > beg) {
+      const float d = scaling ? sqrtf((float)(end - beg)) : 1.f;
+      float s = 0.f;
+      for (int64_t r = beg; r < end; ++r) s += expf((compat[r * G + g] - m) / d);
+      s += eps;
+      for (int64_t r = beg; r < end; ++r) att[r * G + g] = expf((compat[r * G + g] - m) / d) / s;
+    }
+    if (amax) amax[t] = (int32_t)am;
+    if (gate) {
+      float gt = 1.f;
+      if (gw) {
+        const float pre = gw[g] * m + gb[g];
+        gt = tanhf(fmaxf(pre, 0.f));
+      }
+      gate[t] = gt;
+    }
+  }
+}
+
+// one thread per (point, channel)
+template <typename T>
+__global__ __launch_bounds__(256) void att_wsum_kernel(const T* __restrict__ val,
+                                                        const float* __restrict__ att,
+                                                        const float* __restrict__ gate,
+                                                        const int64_t* __restrict__ ptr,
+                                                        T* __restrict__ out, int64_t N, int C,
+                                                        int G) {
+  const int64_t total = N * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t - p * C);
+    const int g = group_of_channel(c, C, G);
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    float acc = 0.f;
+    for (int64_t r = beg; r < end; ++r) acc += att[r * G + g] * Elt<T>::ld(val, r * C + c);
+    if (gate) acc *= gate[p * G + g];
+    Elt<T>::st(out, t, acc);
+  }
+}
+
+// backward, one thread per (point, group): d[v,g] = sum_{c in g} go[p,c]*val[v,c] (scratch in
+// gcompat), softmax backward, gating backward
+template <typename T>
+__global__ __launch_bounds__(256) void att_bwd_scores_kernel(
+    const T* __restrict__ gout, const T* __restrict__ val, const float* __restrict__ compat,
+    const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
+    const int64_t* __restrict__ ptr, const float* __restrict__ gw, float* __restrict__ gcompat,
+    float* __restrict__ gwb, int64_t N, int C, int G, int scaling) {
+  extern __shared__ float s_wb[];  // [2*G] block partials of d/dw, d/db
+  for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) s_wb[i] = 0.f;
+  __syncthreads();
+  const int64_t total = N * (int64_t)G;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / G;
+    const int g = (int)(t - p * G);
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    if (end <= beg) continue;
+    const int c0 = group_begin(g, C, G), c1 = group_begin(g + 1, C, G);
+    float sum_ad = 0.f;
+    for (int64_t r = beg; r < end; ++r) {
+      float d = 0.f;
+      for (int c = c0; c < c1; ++c) d += Elt<T>::ld(gout, p * C + c) * Elt<T>::ld(val, r * C + c);
+      gcompat[r * G + g] = d;
+      sum_ad += att[r * G + g] * d;
+    }
+    const float gt = gate ? gate[t] : 1.f;
+    const float dn = scaling ? sqrtf((float)(end - beg)) : 1.f;
+    float g_mx = 0.f;
+    const int64_t am = amax[t];
+    if (gw) {
+      const float g_pre = (gt > 0.f) ? sum_ad * (1.f - gt * gt) : 0.f;
+      const float mx = compat[am * G + g];
+      atomicAdd(&s_wb[g], g_pre * mx);
+      atomicAdd(&s_wb[G + g], g_pre);
+      g_mx = g_pre * gw[g];
+    }
+    const float tt = gt * sum_ad;
+    for (int64_t r = beg; r < end; ++r) {
+      const float d = gcompat[r * G + g];
+      float gc = att[r * G + g] * (gt * d - tt) / dn;
+      if (r == am) gc += g_mx;
+      gcompat[r * G + g] = gc;
+    }
+  }
+  __syncthreads();
+  if (gwb)
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x)
+      if (s_wb[i] != 0.f) atomicAdd(&gwb[i], s_wb[i]);
+}
+
+// backward, one thread per (point, channel): grad_val[v,c] = go[p,c]*gate[p,g]*att[v,g]
+template <typename T>
+__global__ __launch_bounds__(256) void att_bwd_val_kernel(const T* __restrict__ gout,
+                                                           const float* __restrict__ att,
+                                                           const float* __restrict__ gate,
+                                                           const int64_t* __restrict__ ptr,
+                                                           T* __restrict__ gval, int64_t N, int C,
+                                                           int G) {
+  const int64_t total = N * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t - p * C);
+    const int g = group_of_channel(c, C, G);
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    float go = Elt<T>::ld(gout, t);
+    if (gate) go *= gate[p * G + g];
+    for (int64_t r = beg; r < end; ++r) Elt<T>::st(gval, r * C + c, go * att[r * G + g]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused team path
+// ------------------------------------------------------------------------------------------------
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  typedef float4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+  }
+  static __device__ __forceinline__ raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <>
+struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  typedef uint4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ raw pack(const float* f) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    return r;
+  }
+};
+
+struct TeamGeom {
+  int lpr;      // lanes per view row (power of two, <= 64)
+  int rows;     // view rows in flight per team (power of two)
+  int ts;       // team size = lpr * rows (<= 64)
+  int lpg;      // lanes per group inside a row = lpr / G
+};
+
+// Forward.  Requirements (checked by the host): C % VEC == 0, C/VEC == lpr exactly (power of two),
+// C % G == 0, (C/G) % VEC == 0, G <= ts, G power of two.
+template <typename T>
+__global__ __launch_bounds__(256) void att_fwd_team_kernel(
+    const T* __restrict__ val, const float* __restrict__ compat, const int64_t* __restrict__ ptr,
+    const float* __restrict__ gw, const float* __restrict__ gb, T* __restrict__ out,
+    float* __restrict__ att, float* __restrict__ gate, int32_t* __restrict__ amax, int64_t N, int C,
+    int G, int scaling, float eps, TeamGeom tg) {
+  constexpr int VEC = Vec16<T>::N;
+  typedef typename Vec16<T>::raw raw_t;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (tg.ts - 1);        // lane in team
+  const int team_base = lane - li;          // first lane of the team inside the wave
+  const int lane_r = li & (tg.lpr - 1);     // position inside the row
+  const int row_slot = li / tg.lpr;         // which of the R rows in flight
+  const int g_lane = lane_r / tg.lpg;       // group of this lane's channels
+  const bool g_first = (lane_r % tg.lpg) == 0;
+  // softmax-statistics mapping: lane li <-> (view slot, group)
+  const int sg = li & (G - 1);
+  const int vslot = li / G;
+  const int VS = tg.ts / G;
+
+  const int teams_per_block = blockDim.x / tg.ts;
+  const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg.ts;
+  const int64_t team_stride = (int64_t)gridDim.x * teams_per_block;
+
+  for (int64_t p = team0; p < N; p += team_stride) {
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    const int n = (int)(end - beg);
+    // ---- per-group max (+ first arg) over the point's views
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int v = vslot; v < n; v += VS) {
+      const float c = compat[(beg + v) * G + sg];
+      if (c > m) {
+        m = c;
+        am = v;
+      }
+    }
+    for (int off = G; off < tg.ts; off <<= 1) {
+      const float m2 = __shfl_xor(m, off);
+      const int a2 = __shfl_xor(am, off);
+      if (m2 > m || (m2 == m && a2 < am)) {
+        m = m2;
+        am = a2;
+      }
+    }
+    if (n == 0) m = 0.f;
+    const float dn = scaling ? sqrtf((float)n) : 1.f;
+    float s = 0.f;
+    for (int v = vslot; v < n; v += VS) s += expf((compat[(beg + v) * G + sg] - m) / dn);
+    for (int off = G; off < tg.ts; off <<= 1) s += __shfl_xor(s, off);
+    s += eps;
+    float gt = 1.f;
+    if (gw) gt = tanhf(fmaxf(gw[sg] * m + gb[sg], 0.f));
+    if (vslot == 0) {
+      if (gate) gate[p * G + sg] = gt;
+      if (amax) amax[p * G + sg] = n > 0 ? (int32_t)(beg + am) : -1;
+    }
+    // broadcast the statistics of this lane's own channel group
+    const float m_l = __shfl(m, team_base + g_lane);
+    const float s_l = __shfl(s, team_base + g_lane);
+    const float gt_l = __shfl(gt, team_base + g_lane);
+
+    // ---- attention-weighted sum over views
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    const int64_t col = (int64_t)lane_r * VEC;
+#pragma unroll 2
+    for (int v = row_slot; v < n; v += tg.rows) {
+      const int64_t r = beg + v;
+      const raw_t x = *reinterpret_cast<const raw_t*>(val + r * C + col);
+      const float a = expf((compat[r * G + g_lane] - m_l) / dn) / s_l;
+      if (g_first) att[r * G + g_lane] = a;
+      float f[VEC];
+      Vec16<T>::unpack(x, f);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += a * f[k];
+    }
+    for (int off = tg.lpr; off < tg.ts; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+    }
+    if (row_slot == 0) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] *= gt_l;
+      *reinterpret_cast<raw_t*>(out + p * C + col) = Vec16<T>::pack(acc);
+    }
+  }
+}
+
+// Backward, same geometry.  gcompat doubles as scratch for d[v,g] between the two passes (each
+// (v,g) slot is written and re-read by the same lane).
+template <typename T>
+__global__ __launch_bounds__(256) void att_bwd_team_kernel(
+    const T* __restrict__ gout, const T* __restrict__ val, const float* __restrict__ compat,
+    const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
+    const int64_t* __restrict__ ptr, const float* __restrict__ gw, T* __restrict__ gval,
+    float* __restrict__ gcompat, float* __restrict__ gwb, int64_t N, int C, int G, int scaling,
+    TeamGeom tg) {
+  constexpr int VEC = Vec16<T>::N;
+  typedef typename Vec16<T>::raw raw_t;
+  __shared__ float s_wb[64];  // [2*G], G <= 32
+  if (threadIdx.x < 64) s_wb[threadIdx.x] = 0.f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (tg.ts - 1);
+  const int lane_r = li & (tg.lpr - 1);
+  const int row_slot = li / tg.lpr;
+  const int g_lane = lane_r / tg.lpg;
+  const bool g_first = (lane_r % tg.lpg) == 0;
+
+  const int teams_per_block = blockDim.x / tg.ts;
+  const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg.ts;
+  const int64_t team_stride = (int64_t)gridDim.x * teams_per_block;
+
+  for (int64_t p = team0; p < N; p += team_stride) {
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    const int n = (int)(end - beg);
+    if (n == 0) continue;
+    const int64_t col = (int64_t)lane_r * VEC;
+    float go[VEC];
+    Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(gout + p * C + col), go);
+    const float gt = gate ? gate[p * G + g_lane] : 1.f;
+
+    // ---- pass 1: d[v,g] = sum_{c in g} go[c]*val[v,c];  sum_ad[g] = sum_v att[v,g]*d[v,g]
+    float sum_ad = 0.f;
+#pragma unroll 2
+    for (int v = row_slot; v < n; v += tg.rows) {
+      const int64_t r = beg + v;
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + r * C + col), f);
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) d += go[k] * f[k];
+      for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
+      if (g_first) {
+        gcompat[r * G + g_lane] = d;
+        sum_ad += att[r * G + g_lane] * d;
+      }
+    }
+    // lanes of one column position in the R row slots hold partials of the same group
+    for (int off = tg.lpr; off < tg.ts; off <<= 1) sum_ad += __shfl_xor(sum_ad, off);
+    // make the group total visible to every lane of the group (only g_first lanes accumulated)
+    sum_ad = __shfl(sum_ad, lane - (lane_r % tg.lpg));
+
+    const float dn = scaling ? sqrtf((float)n) : 1.f;
+    float g_mx = 0.f;
+    const int64_t am = amax[p * G + g_lane];
+    if (gw) {
+      const float g_pre = (gt > 0.f) ? sum_ad * (1.f - gt * gt) : 0.f;
+      if (g_first && row_slot == 0) {
+        const float mx = compat[am * G + g_lane];
+        atomicAdd(&s_wb[g_lane], g_pre * mx);
+        atomicAdd(&s_wb[G + g_lane], g_pre);
+      }
+      g_mx = g_pre * gw[g_lane];
+    }
+    const float tt = gt * sum_ad;
+
+    // ---- pass 2: grad_compat, grad_val
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) go[k] *= gt;
+#pragma unroll 2
+    for (int v = row_slot; v < n; v += tg.rows) {
+      const int64_t r = beg + v;
+      const float a = att[r * G + g_lane];
+      if (g_first) {
+        const float d = gcompat[r * G + g_lane];
+        float gc = a * (gt * d - tt) / dn;
+        if (r == am) gc += g_mx;
+        gcompat[r * G + g_lane] = gc;
+      }
+      float f[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] = go[k] * a;
+      *reinterpret_cast<raw_t*>(gval + r * C + col) = Vec16<T>::pack(f);
+    }
+  }
+  __syncthreads();
+  if (gwb && threadIdx.x < 2 * G && s_wb[threadIdx.x] != 0.f)
+    atomicAdd(&gwb[threadIdx.x], s_wb[threadIdx.x]);
+}
+
+static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// Decide whether the fused team path applies and with which geometry.
+template <typename T>
+static bool team_geometry(int C, int G, int64_t N, int64_t V, TeamGeom* tg) {
+  constexpr int VEC = Vec16<T>::N;
+  if (C % VEC) return false;
+  const int lpr = C / VEC;
+  if (!is_pow2(lpr) || lpr > 64) return false;
+  if (!is_pow2(G) || G > 32 || C % G) return false;
+  if ((C / G) % VEC) return false;
+  int rows = 64 / lpr;  // default: a whole wavefront per point
+  // shrink the team for short segments so that lanes are not idle (avg views per point)
+  const double avg = N > 0 ? (double)V / (double)N : 0.0;
+  while (rows > 1 && (double)(rows / 2) >= avg && lpr * (rows / 2) >= G) rows >>= 1;
+  while (lpr * rows < G) rows <<= 1;
+  if (lpr * rows > 64) return false;
+  tg->lpr = lpr;
+  tg->rows = rows;
+  tg->ts = lpr * rows;
+  tg->lpg = lpr / G;
+  return tg->lpg >= 1;
+}
+
+static inline int grid_cap(int64_t blocks) {
+  const int64_t cap = 256 * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <typename T>
+static int fwd_impl(const void* val, const float* compat, const int64_t* ptr, const float* gw,
+                    const float* gb, void* out, float* att, float* gate, int32_t* amax, int64_t N,
+                    int64_t V_hint, int C, int G, int scaling, float eps, int algo, hipStream_t s) {
+  TeamGeom tg;
+  const bool team_ok = team_geometry<T>(C, G, N, V_hint, &tg);
+  if (algo == 2 && !team_ok) return DVA_ERR_UNSUPPORTED;
+  if (algo != 1 && team_ok) {
+    const int tpb = 256 / tg.ts;
+    const int grid = grid_cap((N + tpb - 1) / tpb);
+    hipLaunchKernelGGL((att_fwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)val, compat,
+                       ptr, gw, gb, (T*)out, att, gate, amax, N, C, G, scaling, eps, tg);
+    return DVA_OK;
+  }
+  hipLaunchKernelGGL(att_scores_kernel, dim3(grid_cap((N * G + 255) / 256)), dim3(256), 0, s, compat,
+                     ptr, gw, gb, att, gate, amax, N, G, scaling, eps);
+  hipLaunchKernelGGL((att_wsum_kernel<T>), dim3(grid_cap((N * C + 255) / 256)), dim3(256), 0, s,
+                     (const T*)val, att, gw ? gate : nullptr, ptr, (T*)out, N, C, G);
+  return DVA_OK;
+}
+
+template <typename T>
+static int bwd_impl(const void* gout, const void* val, const float* compat, const float* att,
+                    const float* gate, const int32_t* amax, const int64_t* ptr, const float* gw,
+                    void* gval, float* gcompat, float* gwb, int64_t N, int64_t V_hint, int C, int G,
+                    int scaling, int algo, hipStream_t s) {
+  TeamGeom tg;
+  const bool team_ok = team_geometry<T>(C, G, N, V_hint, &tg);
+  if (algo == 2 && !team_ok) return DVA_ERR_UNSUPPORTED;
+  if (algo != 1 && team_ok) {
+    const int tpb = 256 / tg.ts;
+    const int grid = grid_cap((N + tpb - 1) / tpb);
+    hipLaunchKernelGGL((att_bwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)gout,
+                       (const T*)val, compat, att, gw ? gate : nullptr, amax, ptr, gw, (T*)gval,
+                       gcompat, gwb, N, C, G, scaling, tg);
+    return DVA_OK;
+  }
+  hipLaunchKernelGGL((att_bwd_scores_kernel<T>), dim3(grid_cap((N * G + 255) / 256)), dim3(256),
+                     2 * G * sizeof(float), s, (const T*)gout, (const T*)val, compat, att,
+                     gw ? gate : nullptr, amax, ptr, gw, gcompat, gwb, N, C, G, scaling);
+  hipLaunchKernelGGL((att_bwd_val_kernel<T>), dim3(grid_cap((N * C + 255) / 256)), dim3(256), 0, s,
+                     (const T*)gout, att, gw ? gate : nullptr, ptr, (T*)gval, N, C, G);
+  return DVA_OK;
+}
+
+}  // namespace dva
+
+using namespace dva;
+
+extern "C" {
+
+int dva_view_attention_fwd(const void* val, const float* compat, const int64_t* ptr,
+                           const float* gate_w, const float* gate_b, void* out, float* att,
+                           float* gate, int32_t* amax, int64_t n_points, int64_t n_views, int32_t C,
+                           int32_t G, int32_t scaling, float eps, int32_t dtype, int32_t algo,
+                           void* stream) {
+  if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
+  if ((gate_w == nullptr) != (gate_b == nullptr)) return DVA_ERR_INVALID;
+  if (!out || !att || !gate || !amax) return DVA_ERR_INVALID;
+  if (algo < 0 || algo > 2) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  int rc;
+  if (dtype == DVA_F32)
+    rc = fwd_impl<float>(val, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points, n_views,
+                         C, G, scaling, eps, algo, (hipStream_t)stream);
+  else if (dtype == DVA_BF16)
+    rc = fwd_impl<bf16_t>(val, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points, n_views,
+                          C, G, scaling, eps, algo, (hipStream_t)stream);
+  else
+    return DVA_ERR_INVALID;
+  if (rc) return rc;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_view_attention_bwd(const void* grad_out, const void* val, const float* compat,
+                           const float* att, const float* gate, const int32_t* amax,
+                           const int64_t* ptr, const float* gate_w, const float* gate_b,
+                           void* grad_val, float* grad_compat, float* grad_gate_wb,
+                           int64_t n_points, int64_t n_views, int32_t C, int32_t G, int32_t scaling,
+                           int32_t dtype, int32_t algo, void* stream) {
+  (void)gate_b;
+  if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
+  if (!att || !gate || !amax || !grad_val || !grad_compat) return DVA_ERR_INVALID;
+  if (gate_w && !grad_gate_wb) return DVA_ERR_INVALID;
+  if (algo < 0 || algo > 2) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  int rc;
+  if (dtype == DVA_F32)
+    rc = bwd_impl<float>(grad_out, val, compat, att, gate, amax, ptr, gate_w, grad_val, grad_compat,
+                         grad_gate_wb, n_points, n_views, C, G, scaling, algo, (hipStream_t)stream);
+  else if (dtype == DVA_BF16)
+    rc = bwd_impl<bf16_t>(grad_out, val, compat, att, gate, amax, ptr, gate_w, grad_val,
+                          grad_compat, grad_gate_wb, n_points, n_views, C, G, scaling, algo,
+                          (hipStream_t)stream);
+  else
+    return DVA_ERR_INVALID;
+  if (rc) return rc;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

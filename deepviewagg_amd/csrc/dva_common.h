@@ -1,0 +1,69 @@
+// Internal helpers shared by the gfx950 kernels of libdva_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dva.h"
+
+#define DVA_WAVE 64
+
+#define DVA_CHECK_LAUNCH()                           \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return DVA_ERR_LAUNCH;    \
+  } while (0)
+
+namespace dva {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, NaN kept quiet (same rounding as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T>
+struct Elt;
+template <>
+struct Elt<float> {
+  static __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
+  static __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
+};
+template <>
+struct Elt<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p, int64_t i) { return bf2f(p[i]); }
+  static __device__ __forceinline__ void st(bf16_t* p, int64_t i, float v) { p[i] = f2bf(v); }
+};
+
+// expand_group_feat (pooling.py:737-755): the first (C mod G) groups own floor(C/G)+1 channels,
+// the others floor(C/G).  Returns the group of channel c.
+__host__ __device__ __forceinline__ int group_of_channel(int c, int C, int G) {
+  if (G <= 1) return 0;
+  if (G >= C) return c;
+  const int base = C / G, rem = C % G;
+  const int split = rem * (base + 1);
+  return c < split ? c / (base + 1) : rem + (c - split) / base;
+}
+// first channel of group g
+__host__ __device__ __forceinline__ int group_begin(int g, int C, int G) {
+  if (G <= 1) return 0;
+  if (G >= C) return g;
+  const int base = C / G, rem = C % G;
+  return g < rem ? g * (base + 1) : rem * (base + 1) + (g - rem) * base;
+}
+
+// 8-byte packed gather index of one atom: {int32 image, int16 x, int16 y}
+struct __attribute__((aligned(8))) PackedIdx {
+  int32_t img;
+  int16_t x;
+  int16_t y;
+};
+
+static inline int blocks_for(int64_t n, int threads) { return (int)((n + threads - 1) / threads); }
+
+}  // namespace dva

@@ -1,0 +1,290 @@
+// Multi-view feature gather / scatter for gfx950 (reference: core/multimodal/image.py:1262-1287,
+// :105-170, :1871-1885, :1916-1980).
+//
+// Feature maps are channels-last [B,H,W,C]: the C features of one mapped pixel are one contiguous
+// burst, so a group of C*s/16 lanes moves one atom with 16-byte accesses and a wavefront moves
+// 64*16 B = 1 KiB per instruction.  The maps themselves (tens of MB) live in L2 / Infinity Cache;
+// HBM traffic is the 8-byte packed index in and the [P,C] rows out:
+//   nearest fwd bytes = P*(8 + C*s [map read, cache] + C*s [write]);   bwd = P*(8 + C*s) + atomics.
+#include "dva_common.h"
+
+namespace dva {
+
+// torch.floor_divide on floats (c10::div_floor_floating): floor of the exact quotient a/b.
+__device__ __forceinline__ float floordiv_f32(float a, float b) {
+  const float mod = fmodf(a, b);
+  float div = __fdiv_rn(__fsub_rn(a, mod), b);
+  if (mod != 0.f && ((b < 0.f) != (mod < 0.f))) div = __fsub_rn(div, 1.f);
+  if (div != 0.f) {
+    float fl = floorf(div);
+    if (__fsub_rn(div, fl) > 0.5f) fl = __fadd_rn(fl, 1.f);
+    return fl;
+  }
+  return copysignf(0.f, __fdiv_rn(a, b));
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void pack_index_kernel(const int64_t* __restrict__ images,
+                                                          const int64_t* __restrict__ atom_ptr,
+                                                          const PIX* __restrict__ pixels,
+                                                          double ratio, int64_t n_views,
+                                                          PackedIdx* __restrict__ out) {
+  // one thread per view walks its atoms (P == V in exact mode, so usually one atom each)
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_views;
+       v += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t img = (int32_t)images[v];
+    for (int64_t a = atom_ptr[v]; a < atom_ptr[v + 1]; ++a) {
+      PackedIdx pi;
+      pi.img = img;
+      // image.py:1953-1954: (pix // ratio).long(); torch promotes the integer pixel to fp32 for a
+      // Python-float ratio and applies its Python-style floor division (true floor of the exact
+      // quotient), restated in floordiv_f32().
+      if (ratio == 1.0) {
+        pi.x = (int16_t)pixels[2 * a];
+        pi.y = (int16_t)pixels[2 * a + 1];
+      } else {
+        const float rf = (float)ratio;
+        pi.x = (int16_t)floordiv_f32((float)pixels[2 * a], rf);
+        pi.y = (int16_t)floordiv_f32((float)pixels[2 * a + 1], rf);
+      }
+      out[a] = pi;
+    }
+  }
+}
+
+// Nearest gather: pure byte movement in UNIT-byte units (16, 4 or 2).
+template <typename UNIT>
+__global__ __launch_bounds__(256) void gather_nearest_fwd_kernel(const UNIT* __restrict__ x,
+                                                                  const PackedIdx* __restrict__ idx,
+                                                                  UNIT* __restrict__ out,
+                                                                  int64_t n_atoms, int H, int W,
+                                                                  int units_per_row) {
+  const int64_t total = n_atoms * (int64_t)units_per_row;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / units_per_row;
+    const int u = (int)(t - p * units_per_row);
+    const PackedIdx pi = idx[p];
+    const int64_t pix = ((int64_t)pi.img * H + pi.y) * W + pi.x;
+    out[t] = x[pix * units_per_row + u];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_nearest_bwd_kernel(const T* __restrict__ gout,
+                                                                  const PackedIdx* __restrict__ idx,
+                                                                  float* __restrict__ gx,
+                                                                  int64_t n_atoms, int H, int W,
+                                                                  int C) {
+  const int64_t total = n_atoms * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t - p * C);
+    const PackedIdx pi = idx[p];
+    const int64_t pix = ((int64_t)pi.img * H + pi.y) * W + pi.x;
+    atomicAdd(&gx[pix * C + c], Elt<T>::ld(gout, t));
+  }
+}
+
+struct Taps {
+  int64_t tl, tr, bl, br;  // pixel offsets (in pixels) into [B,H,W]
+  float w_tl, w_tr, w_bl, w_br;
+};
+
+// image.py:138-165 with ReplicationPad2d(1): padded index i -> clamp(i-1, 0, size-1)
+__device__ __forceinline__ Taps bilinear_taps(const PackedIdx pi, float cy, float cx, int H, int W) {
+  const float qy = __fadd_rn(__fmul_rn(cy, (float)H), 0.5f);
+  const float qx = __fadd_rn(__fmul_rn(cx, (float)W), 0.5f);
+  const float top = floorf(qy), bottom = floorf(__fadd_rn(qy, 1.f));
+  const float left = floorf(qx), right = floorf(__fadd_rn(qx, 1.f));
+  Taps t;
+  t.w_tl = fabsf(__fmul_rn(__fsub_rn(qy, bottom), __fsub_rn(qx, right)));
+  t.w_tr = fabsf(__fmul_rn(__fsub_rn(qy, bottom), __fsub_rn(qx, left)));
+  t.w_bl = fabsf(__fmul_rn(__fsub_rn(qy, top), __fsub_rn(qx, right)));
+  t.w_br = fabsf(__fmul_rn(__fsub_rn(qy, top), __fsub_rn(qx, left)));
+  const int it = min(max((int)top - 1, 0), H - 1), ib = min(max((int)bottom - 1, 0), H - 1);
+  const int il = min(max((int)left - 1, 0), W - 1), ir = min(max((int)right - 1, 0), W - 1);
+  const int64_t base = (int64_t)pi.img * H;
+  t.tl = (base + it) * W + il;
+  t.tr = (base + it) * W + ir;
+  t.bl = (base + ib) * W + il;
+  t.br = (base + ib) * W + ir;
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bilinear_fwd_kernel(
+    const T* __restrict__ x, const PackedIdx* __restrict__ idx, const float* __restrict__ coords,
+    T* __restrict__ out, int64_t n_atoms, int H, int W, int C) {
+  const int64_t total = n_atoms * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t - p * C);
+    const Taps tp = bilinear_taps(idx[p], coords[2 * p], coords[2 * p + 1], H, W);
+    // reference evaluation order: ((w_tl*X_tl + w_tr*X_tr) + w_bl*X_bl) + w_br*X_br, no fma
+    float acc = __fmul_rn(tp.w_tl, Elt<T>::ld(x, tp.tl * C + c));
+    acc = __fadd_rn(acc, __fmul_rn(tp.w_tr, Elt<T>::ld(x, tp.tr * C + c)));
+    acc = __fadd_rn(acc, __fmul_rn(tp.w_bl, Elt<T>::ld(x, tp.bl * C + c)));
+    acc = __fadd_rn(acc, __fmul_rn(tp.w_br, Elt<T>::ld(x, tp.br * C + c)));
+    Elt<T>::st(out, t, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bilinear_bwd_kernel(
+    const T* __restrict__ gout, const PackedIdx* __restrict__ idx, const float* __restrict__ coords,
+    float* __restrict__ gx, int64_t n_atoms, int H, int W, int C) {
+  const int64_t total = n_atoms * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t - p * C);
+    const Taps tp = bilinear_taps(idx[p], coords[2 * p], coords[2 * p + 1], H, W);
+    const float g = Elt<T>::ld(gout, t);
+    atomicAdd(&gx[tp.tl * C + c], tp.w_tl * g);
+    atomicAdd(&gx[tp.tr * C + c], tp.w_tr * g);
+    atomicAdd(&gx[tp.bl * C + c], tp.w_bl * g);
+    atomicAdd(&gx[tp.br * C + c], tp.w_br * g);
+  }
+}
+
+static inline int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  const int64_t cap = 256 * 32;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace dva
+
+using namespace dva;
+
+extern "C" {
+
+int dva_pack_gather_index(const int64_t* images, const int64_t* atom_ptr, const void* pixels,
+                          int32_t pix_bytes, double ratio, int64_t n_views, int64_t n_atoms,
+                          void* packed_idx, void* stream) {
+  if (n_views < 0 || n_atoms < 0 || !(ratio >= 1.0)) return DVA_ERR_INVALID;
+  if (n_views == 0 || n_atoms == 0) return DVA_OK;
+  if (!images || !atom_ptr || !pixels || !packed_idx) return DVA_ERR_INVALID;
+  const int grid = grid_for(n_views);
+  hipStream_t s = (hipStream_t)stream;
+  PackedIdx* out = (PackedIdx*)packed_idx;
+  switch (pix_bytes) {
+    case 2:
+      hipLaunchKernelGGL((pack_index_kernel<int16_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
+                         (const int16_t*)pixels, ratio, n_views, out);
+      break;
+    case 4:
+      hipLaunchKernelGGL((pack_index_kernel<int32_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
+                         (const int32_t*)pixels, ratio, n_views, out);
+      break;
+    case 8:
+      hipLaunchKernelGGL((pack_index_kernel<int64_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
+                         (const int64_t*)pixels, ratio, n_views, out);
+      break;
+    default:
+      return DVA_ERR_INVALID;
+  }
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+static int check_map(int64_t n_atoms, int B, int H, int W, int C, int dtype) {
+  if (n_atoms < 0 || B < 0 || H < 0 || W < 0 || C < 0) return DVA_ERR_INVALID;
+  if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
+  if (H > 32767 || W > 32767) return DVA_ERR_UNSUPPORTED;
+  return DVA_OK;
+}
+
+int dva_gather_nearest_fwd(const void* x, const void* packed_idx, void* out, int64_t n_atoms,
+                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+  int rc = check_map(n_atoms, B, H, W, C, dtype);
+  if (rc) return rc;
+  if (n_atoms == 0 || C == 0) return DVA_OK;
+  if (!x || !packed_idx || !out) return DVA_ERR_INVALID;
+  const int64_t row_bytes = (int64_t)C * (dtype == DVA_F32 ? 4 : 2);
+  hipStream_t s = (hipStream_t)stream;
+  const PackedIdx* idx = (const PackedIdx*)packed_idx;
+  const bool al16 = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (row_bytes % 16 == 0 && al16) {
+    const int u = (int)(row_bytes / 16);
+    hipLaunchKernelGGL((gather_nearest_fwd_kernel<uint4>), dim3(grid_for(n_atoms * u)), dim3(256), 0,
+                       s, (const uint4*)x, idx, (uint4*)out, n_atoms, H, W, u);
+  } else if (row_bytes % 4 == 0) {
+    const int u = (int)(row_bytes / 4);
+    hipLaunchKernelGGL((gather_nearest_fwd_kernel<uint32_t>), dim3(grid_for(n_atoms * u)), dim3(256),
+                       0, s, (const uint32_t*)x, idx, (uint32_t*)out, n_atoms, H, W, u);
+  } else {
+    const int u = (int)(row_bytes / 2);
+    hipLaunchKernelGGL((gather_nearest_fwd_kernel<uint16_t>), dim3(grid_for(n_atoms * u)), dim3(256),
+                       0, s, (const uint16_t*)x, idx, (uint16_t*)out, n_atoms, H, W, u);
+  }
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_nearest_bwd(const void* grad_out, const void* packed_idx, float* grad_x,
+                           int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C,
+                           int32_t dtype, void* stream) {
+  int rc = check_map(n_atoms, B, H, W, C, dtype);
+  if (rc) return rc;
+  if (n_atoms == 0 || C == 0) return DVA_OK;
+  if (!grad_out || !packed_idx || !grad_x) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const PackedIdx* idx = (const PackedIdx*)packed_idx;
+  const int grid = grid_for(n_atoms * (int64_t)C);
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((gather_nearest_bwd_kernel<float>), dim3(grid), dim3(256), 0, s,
+                       (const float*)grad_out, idx, grad_x, n_atoms, H, W, C);
+  else
+    hipLaunchKernelGGL((gather_nearest_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s,
+                       (const bf16_t*)grad_out, idx, grad_x, n_atoms, H, W, C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_bilinear_fwd(const void* x, const void* packed_idx, const float* coords, void* out,
+                            int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C,
+                            int32_t dtype, void* stream) {
+  int rc = check_map(n_atoms, B, H, W, C, dtype);
+  if (rc) return rc;
+  if (n_atoms == 0 || C == 0) return DVA_OK;
+  if (!x || !packed_idx || !coords || !out) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const PackedIdx* idx = (const PackedIdx*)packed_idx;
+  const int grid = grid_for(n_atoms * (int64_t)C);
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((gather_bilinear_fwd_kernel<float>), dim3(grid), dim3(256), 0, s,
+                       (const float*)x, idx, coords, (float*)out, n_atoms, H, W, C);
+  else
+    hipLaunchKernelGGL((gather_bilinear_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s,
+                       (const bf16_t*)x, idx, coords, (bf16_t*)out, n_atoms, H, W, C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_bilinear_bwd(const void* grad_out, const void* packed_idx, const float* coords,
+                            float* grad_x, int64_t n_atoms, int32_t B, int32_t H, int32_t W,
+                            int32_t C, int32_t dtype, void* stream) {
+  int rc = check_map(n_atoms, B, H, W, C, dtype);
+  if (rc) return rc;
+  if (n_atoms == 0 || C == 0) return DVA_OK;
+  if (!grad_out || !packed_idx || !coords || !grad_x) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const PackedIdx* idx = (const PackedIdx*)packed_idx;
+  const int grid = grid_for(n_atoms * (int64_t)C);
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((gather_bilinear_bwd_kernel<float>), dim3(grid), dim3(256), 0, s,
+                       (const float*)grad_out, idx, coords, grad_x, n_atoms, H, W, C);
+  else
+    hipLaunchKernelGGL((gather_bilinear_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s,
+                       (const bf16_t*)grad_out, idx, coords, grad_x, n_atoms, H, W, C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,3 @@
+from .fusion import *  # noqa: F401,F403
+from .pooling import *  # noqa: F401,F403
+from .dropout import *  # noqa: F401,F403

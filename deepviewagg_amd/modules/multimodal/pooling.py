@@ -1,0 +1,412 @@
+"""Bimodal CSR pooling modules backed by the gfx950 kernels.
+
+Drop-in mirror of ``torch_points3d/modules/multimodal/pooling.py`` (reference): same class names,
+constructor keywords, ``forward(x_main, x_mod, x_map, csr_idx)`` contract, parameter/state-dict
+names and ``save_last`` attributes, so that ``ModalityFactory.get_module``
+(models/base_architectures/unet.py:69-101) resolves YAML ``module_name`` entries to these classes.
+
+What runs where:
+  * CSR reductions, segment softmax, attention-weighted sum and gating -> HIP kernels
+    (``deepviewagg_amd.ops``), hand-written forward AND backward;
+  * the small dense layers (Linear / BatchNorm1d / LeakyReLU of ``MLP``) -> PyTorch-ROCm
+    (rocBLAS/hipBLASLt GEMMs), as the north star prescribes for dense stages.
+
+The order of 3D points in the main modality must match the order of the groups in ``csr_idx``
+(reference docstring, pooling.py:30-33).
+"""
+import math
+import sys
+
+import torch
+import torch.nn as nn
+
+from ...core.common_modules import MLP
+from ... import ops
+from ...ops import (segment_csr, gather_csr, segment_gather_csr,  # noqa: F401 (re-exported)
+                    segment_softmax_csr)
+
+_local_modules = sys.modules[__name__]
+
+
+def _dense_index(csr_idx, device):
+    """Group id of every row covered by ``csr_idx`` (the reference's ``_last_idx``)."""
+    sizes = csr_idx[1:] - csr_idx[:-1]
+    return torch.arange(csr_idx.shape[0] - 1, device=device).repeat_interleave(sizes), sizes
+
+
+class _SaveLast:
+    """Shared bookkeeping of the optional ``save_last`` debugging outputs."""
+
+    def _init_save_last(self, save_last, extra=()):
+        self.save_last = save_last
+        for k in ('x_map', 'x_mod', 'idx', 'view_num') + tuple(extra):
+            setattr(self, f'_last_{k}', None)
+
+    def _save(self, x_map, x_mod, csr_idx, **extra):
+        if not self.save_last:
+            return
+        self._last_x_map = x_map
+        self._last_x_mod = x_mod
+        self._last_idx, self._last_view_num = _dense_index(csr_idx, x_mod.device)
+        for k, v in extra.items():
+            setattr(self, f'_last_{k}', v)
+
+
+class BimodalCSRPool(nn.Module, _SaveLast):
+    """max / mean / min / sum pooling of modality features over CSR groups
+    (reference pooling.py:14-71). Used for atomic-level (pixels -> view) and view-level
+    (views -> point) aggregation; empty groups receive zeros."""
+
+    _POOLING_MODES = ['max', 'mean', 'min', 'sum']
+
+    def __init__(self, mode='max', save_last=False, **kwargs):
+        super().__init__()
+        assert mode in self._POOLING_MODES, \
+            f"Unsupported mode '{mode}'. Expected one of: {self._POOLING_MODES}"
+        self._mode = mode
+        self._init_save_last(save_last)
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map] (unused), csr_idx [N+1]."""
+        x_pool = segment_csr(x_mod, csr_idx, reduce=self._mode)
+        self._save(x_map, x_mod, csr_idx)
+        return x_pool
+
+    def extra_repr(self) -> str:
+        return f'mode={self._mode}, save_last={self.save_last}'
+
+
+class HeuristicBimodalCSRPool(nn.Module, _SaveLast):
+    """Select, for each group, the row whose chosen mapping feature is max / min
+    (reference pooling.py:74-156). Unseen groups receive zeros."""
+
+    _MODES = ['max', 'min']
+    _FEATURES = [
+        'normalized_depth', 'linearity', 'planarity', 'scattering',
+        'orientation_to_the_surface', 'normalized_pixel_height', 'density', 'occlusion']
+
+    def __init__(self, mode='max', feat=0, save_last=False, **kwargs):
+        super().__init__()
+        assert mode in self._MODES, f"Unsupported mode '{mode}'. Expected one of: {self._MODES}."
+        self._mode = mode
+        feat = self._FEATURES.index(feat) if isinstance(feat, str) else feat
+        assert feat < len(self._FEATURES), \
+            f"Feat={feat} is too large. Expected feat<{len(self._FEATURES)}."
+        self._feat = feat
+        self._init_save_last(save_last)
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        # arg of the per-group extremum of the heuristic feature (first row on ties, -1 if unseen)
+        _, arg_idx = ops.segment_csr_arg(x_map[:, self._feat].float(), csr_idx, reduce=self._mode)
+        arg_idx = arg_idx.reshape(-1).long()
+        # unseen points index an appended zero row (pooling.py:140-143)
+        arg_idx = torch.where(arg_idx < 0, torch.full_like(arg_idx, x_mod.shape[0]), arg_idx)
+        x_mod_0 = torch.cat((x_mod, torch.zeros_like(x_mod[[0]])))
+        x_pool = x_mod_0[arg_idx]
+        self._save(x_map, x_mod, csr_idx)
+        return x_pool
+
+    def extra_repr(self) -> str:
+        return f'mode={self._mode}, feat={self._FEATURES[self._feat]}, save_last={self.save_last}'
+
+
+class Gating(nn.Module):
+    """Rectified-tanh gating with learnable affine correction: tanh(relu(w * x + b))
+    (reference pooling.py:690-715). Inside the pooling modules the gate is evaluated by the fused
+    view-attention kernel from ``weight`` / ``bias``; ``forward`` is the stand-alone form."""
+
+    def __init__(self, num_groups, weight=True, bias=True, activation='tanh+'):
+        super().__init__()
+        self.num_groups = num_groups
+        self.weight = nn.Parameter(torch.ones(1, num_groups)) if weight else None
+        self.bias = nn.Parameter(torch.zeros(1, num_groups)) if bias else None
+        if activation not in ('tanh+', 'sigmoid'):
+            raise ValueError(f"Activation '{activation}' not supported for Gating")
+        self._activation = activation
+
+    def forward(self, x):
+        if self.weight is not None:
+            x = x * self.weight
+        if self.bias is not None:
+            x = x + self.bias
+        # NB: like the reference (pooling.py:710-711), forward always applies tanh(relu(.))
+        return torch.tanh(torch.relu(x)).view(-1, self.num_groups).squeeze(1)
+
+    def extra_repr(self) -> str:
+        return f'num_groups={self.num_groups}, weight={self.weight is not None}, ' \
+               f'bias={self.bias is not None}'
+
+
+def _pool_with_attention(module, x_mod, compatibilities, csr_idx):
+    """softmax -> attention-weighted sum -> gating, one fused kernel (pooling.py:284-300)."""
+    G = module.G
+    x_pool, attentions, gating = ops.view_attention(
+        x_mod, compatibilities, csr_idx,
+        gate_w=G.weight if G is not None else None,
+        gate_b=G.bias if G is not None else None,
+        scaling=module.group_scaling)
+    if G is not None and module.num_groups == 1:
+        gating = gating.squeeze(1)
+    return x_pool, attentions, (gating if G is not None else None)
+
+
+class GroupBimodalCSRPool(nn.Module, _SaveLast):
+    """DeepViewAgg view pooling: attention over the views of each point, scores computed from the
+    mapping features only (optionally also from the modality features), one score per channel
+    group, optional gating (reference pooling.py:159-319).
+
+    Example (pooling.py:185-204)::
+
+        csr_idx = torch.LongTensor([0, 4, 4, 5, 10, 20]).cuda()
+        module = GroupBimodalCSRPool(in_map=3, in_mod=7, num_groups=2).cuda()
+        module(None, torch.rand(20, 7).cuda(), torch.rand(20, 3).cuda(), csr_idx)   # [5, 7]
+    """
+
+    def __init__(
+            self, in_map=None, in_mod=None, out_mod=None, num_groups=1,
+            use_mod=False, gating=True, group_scaling=True, save_last=False,
+            nc_inner=32, map_encoder='DeepSetFeat', **kwargs):
+        super().__init__()
+        self.nc_inner = nc_inner
+        self._init_save_last(save_last, extra=('C', 'A', 'G'))
+
+        assert 1 <= num_groups <= in_mod, \
+            f"Number of groups must be between 1 and in_mod={in_mod}."
+        out_mod = in_mod if out_mod is None else out_mod
+        self.in_mod = in_mod
+        self.out_mod = out_mod
+        self.use_mod = use_mod
+        self.num_groups = num_groups
+        self.group_scaling = group_scaling
+
+        # E_map: mapping features -> nc_inner;  E_mod: modality features -> values
+        self.E_map = getattr(_local_modules, map_encoder)(in_map, nc_inner, **kwargs)
+        self.E_mod = MLP([in_mod, out_mod, out_mod], bias=False)
+        if self.use_mod:
+            in_mix, out_mix = nc_inner + out_mod, nc_inner
+            mid_mix = nearest_power_of_2((in_mix + out_mix) / 2, out_mix * 2)
+            self.E_mix = MLP([in_mix, mid_mix, out_mix], bias=False)
+        self.E_score = nn.Linear(nc_inner, num_groups, bias=True)
+        self.G = Gating(num_groups, bias=True) if gating else None
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
+        x_map = self.E_map(x_map, csr_idx)
+        x_mod = self.E_mod(x_mod)
+        if self.use_mod:
+            compatibilities = self.E_score(self.E_mix(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
+        else:
+            compatibilities = self.E_score(x_map)
+        x_pool, attentions, gating = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
+        self._save(x_map, x_mod, csr_idx, C=compatibilities, A=attentions,
+                   **({'G': gating} if self.G is not None else {}))
+        return x_pool
+
+    def extra_repr(self) -> str:
+        return "\n".join(f'{a}={getattr(self, a)}'
+                         for a in ['num_groups', 'use_mod', 'group_scaling', 'save_last'])
+
+
+class QKVBimodalCSRPool(nn.Module, _SaveLast):
+    """Key-Query attention over views: queries from the main modality, keys from the mapping
+    features (optionally mixed with modality features), values from the modality
+    (reference pooling.py:322-551; named AttentiveBimodalCSRPool in stale configs)."""
+
+    def __init__(
+            self, in_main=None, in_map=None, in_mod=None, out_mod=None,
+            num_groups=1, use_mod_q=False, use_mod_k=False, nc_qk=8,
+            gating=True, dim_scaling=True, group_scaling=False, debug=False,
+            save_last=False, nc_inner=32, map_encoder='DeepSetFeat', **kwargs):
+        super().__init__()
+        self.nc_inner = nc_inner
+        self._init_save_last(save_last, extra=('Q', 'K', 'C', 'A', 'G'))
+        self.debug = debug
+        if debug:
+            group_scaling, dim_scaling, nc_qk, in_map, in_mod = False, True, 1, 1, None
+
+        assert 1 <= num_groups <= in_mod, \
+            f"Number of groups must be between 1 and in_mod={in_mod}."
+        out_mod = in_mod if out_mod is None else out_mod
+        self.in_mod = in_mod
+        self.out_mod = out_mod
+        self.nc_qk = nc_qk
+        self.use_mod_q = use_mod_q
+        self.use_mod_k = use_mod_k
+        self.num_groups = num_groups
+        self.dim_scaling = dim_scaling
+        self.group_scaling = group_scaling
+
+        self.E_main = MLP([in_main, nc_inner, nc_inner], bias=False)
+        self.E_map = getattr(_local_modules, map_encoder)(in_map, nc_inner, **kwargs)
+        self.E_mod = MLP([in_mod, out_mod, out_mod], bias=False)
+        if self.use_mod_q:
+            in_mix, out_mix = nc_inner + out_mod, nc_inner
+            mid_mix = nearest_power_of_2((in_mix + out_mix) / 2, out_mix * 2)
+            self.E_mix_Q = MLP([in_mix, mid_mix, out_mix], bias=False)
+        self.Q = nn.Linear(nc_inner, nc_qk * num_groups, bias=True)
+        if self.use_mod_k:
+            in_mix, out_mix = nc_inner + in_mod, nc_inner
+            mid_mix = nearest_power_of_2((in_mix + out_mix) / 2, out_mix * 2)
+            self.E_mix_K = MLP([in_mix, mid_mix, out_mix], bias=False)
+        self.K = nn.Linear(nc_inner, nc_qk * num_groups, bias=True)
+        self.G = Gating(num_groups, bias=True) if gating else None
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        if self.debug:
+            device = x_map.device
+            x_map = torch.rand((x_map.shape[0], 1), device=device)
+            idx_destroyed = torch.where(x_map < 0.3)[0]
+            x_mod[idx_destroyed] = torch.rand(
+                (idx_destroyed.shape[0], *(x_mod.shape[1:])), device=device)
+
+        n_views = x_mod.shape[0]
+        x_main = self.E_main(x_main)
+        x_map = self.E_map(x_map, csr_idx)
+        x_mod = self.E_mod(x_mod)
+
+        if self.use_mod_k:
+            keys = self.K(self.E_mix_K(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
+        else:
+            keys = self.K(x_map)
+
+        if self.use_mod_q:
+            # view-wise queries from the point features expanded to views
+            x_main_q = gather_csr(x_main, csr_idx, n_rows=n_views)
+            queries = self.Q(self.E_mix_Q(torch.cat([x_main_q, x_mod.to(x_main_q.dtype)], dim=1)))
+        else:
+            # point-wise queries expanded to views
+            queries = gather_csr(self.Q(x_main), csr_idx, n_rows=n_views)
+
+        compatibilities = (keys.reshape(n_views, self.num_groups, self.nc_qk)
+                           * queries.reshape(n_views, self.num_groups, self.nc_qk)).sum(dim=2)
+        if self.dim_scaling:
+            compatibilities = compatibilities / math.sqrt(self.nc_qk)
+
+        x_pool, attentions, gating = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
+        self._save(x_map, x_mod, csr_idx, K=keys, Q=queries, C=compatibilities, A=attentions,
+                   **({'G': gating} if self.G is not None else {}))
+        return x_pool
+
+    def extra_repr(self) -> str:
+        return "\n".join(f'{a}={getattr(self, a)}'
+                         for a in ['dim_scaling', 'group_scaling', 'save_last'])
+
+
+class MinMaxDiffSetFeat(nn.Module):
+    """Element-wise set features from difference-to-min / difference-to-max / set size
+    (reference pooling.py:554-601)."""
+
+    def __init__(self, d_in, d_out, use_min=True, use_max=True, use_num=False, **kwargs):
+        super().__init__()
+        self.d_in = d_in
+        self.d_out = d_out
+        self.use_min = use_min
+        self.use_max = use_max
+        self.use_num = use_num
+        in_mlp = d_in * (1 + self.use_min + self.use_max) + self.use_num
+        self.mlp = MLP([in_mlp, d_out, d_out], bias=False)
+
+    def forward(self, x, csr_idx):
+        feats = [x]
+        if self.use_min:
+            feats.append(x - segment_gather_csr(x, csr_idx, reduce='min'))
+        if self.use_max:
+            feats.append(x - segment_gather_csr(x, csr_idx, reduce='max'))
+        if self.use_num:
+            sizes = csr_idx[1:] - csr_idx[:-1]
+            num = torch.sqrt(1 / (sizes + 1e-3)).to(x.dtype)
+            feats.append(gather_csr(num.view(-1, 1), csr_idx, n_rows=x.shape[0]))
+        return self.mlp(torch.cat(feats, dim=1))
+
+    def extra_repr(self) -> str:
+        return "\n".join(f'{a}={getattr(self, a)}' for a in ['use_min', 'use_max', 'use_num'])
+
+
+class DeepSetFeat(nn.Module):
+    """DeepSets-style element features: elt MLP -> set pooling (+ set size) -> set MLP ->
+    redistribute -> fuse -> elt MLP (reference pooling.py:604-673)."""
+
+    _POOLING_MODES = ['max', 'mean', 'min', 'sum']
+    _FUSION_MODES = ['residual', 'concatenation', 'both']
+
+    def __init__(self, d_in, d_out, pool='max', fusion='concatenation', use_num=False, **kwargs):
+        super().__init__()
+        pool = pool.split('_')
+        assert all([p in self._POOLING_MODES for p in pool]), \
+            f"Unsupported pool='{pool}'. Expected elements of: {self._POOLING_MODES}"
+        self.pool = pool
+        if fusion not in self._FUSION_MODES:
+            raise NotImplementedError(
+                f"Unknown fusion='{fusion}'. Please choose among supported modes: "
+                f"{self._FUSION_MODES}.")
+        self.fusion = fusion
+        self.d_in = d_in
+        self.d_out = d_out
+        self.use_num = use_num
+        self.mlp_elt_1 = MLP([d_in, d_out, d_out], bias=False)
+        self.mlp_set = MLP([d_out * len(self.pool) + self.use_num, d_out, d_out], bias=False)
+        in_last_mlp = d_out if fusion == 'residual' else d_out * 2
+        self.mlp_elt_2 = MLP([in_last_mlp, d_out, d_out], bias=False)
+
+    def forward(self, x, csr_idx):
+        n_rows = x.shape[0]
+        x = self.mlp_elt_1(x)
+        x_set = torch.cat([segment_csr(x, csr_idx, reduce=p) for p in self.pool], dim=-1)
+        if self.use_num:
+            # heuristic normalisation of the set size to [0, 1] (pooling.py:661-664)
+            sizes = csr_idx[1:] - csr_idx[:-1]
+            set_num = torch.sqrt(1 / (sizes + 1e-3)).to(x_set.dtype)
+            x_set = torch.cat((x_set, set_num.view(-1, 1)), dim=1)
+        x_set = gather_csr(self.mlp_set(x_set), csr_idx, n_rows=n_rows)
+        if self.fusion == 'residual':
+            x_out = x + x_set
+        elif self.fusion == 'concatenation':
+            x_out = torch.cat((x, x_set), dim=-1)
+        else:
+            x_out = torch.cat((x, x + x_set), dim=-1)
+        return self.mlp_elt_2(x_out)
+
+    def extra_repr(self) -> str:
+        return "\n".join(f'{a}={getattr(self, a)}' for a in ['pool', 'fusion', 'use_num'])
+
+
+class MLPSetFeat(nn.Module):
+    """Element-wise features with a plain MLP (reference pooling.py:676-687)."""
+
+    def __init__(self, d_in, d_out, **kwargs):
+        super().__init__()
+        self.d_in = d_in
+        self.d_out = d_out
+        self.mlp = MLP([d_in, d_out, d_out], bias=False)
+
+    def forward(self, x, csr_idx):
+        return self.mlp(x)
+
+
+def nearest_power_of_2(x, min_power=16):
+    """Nearest power of two of x, not below ``min_power`` (reference pooling.py:718-734;
+    ties go to the larger power)."""
+    x = int(x)
+    if x < min_power:
+        return min_power
+    upper = 1 << (x - 1).bit_length()
+    lower = upper >> 1
+    return lower if x - lower < upper - x else upper
+
+
+def group_sizes(num_elements, num_groups):
+    """Sizes of ``num_groups`` near-equal groups partitioning ``num_elements`` channels
+    (reference pooling.py:737-745): the first ``num_elements % num_groups`` groups get one more."""
+    base, rem = divmod(num_elements, num_groups)
+    sizes = torch.full((num_groups,), base, dtype=torch.long)
+    sizes[:rem] += 1
+    return sizes
+
+
+def expand_group_feat(A, num_groups, num_channels):
+    """Repeat each group column over the channels of its group (reference pooling.py:748-755)."""
+    if num_groups == 1:
+        A = A.view(-1, 1)
+    elif num_groups < num_channels:
+        A = A.repeat_interleave(group_sizes(num_channels, num_groups).to(A.device), dim=1)
+    return A

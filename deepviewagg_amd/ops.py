@@ -1,0 +1,355 @@
+"""Autograd-aware Python entry points of the HIP kernels (through the C ABI, see ``_lib.py``).
+
+Each op mirrors a primitive the reference obtains from ``torch_scatter`` or composes from torch
+ops; names and argument meaning follow the reference call sites:
+
+=========================  ==========================================================
+``segment_csr``            torch_scatter.segment_csr  (pooling.py:63,289,295,628,787,807)
+``gather_csr``             pooling.py:813-841
+``segment_gather_csr``     pooling.py:844-856
+``segment_softmax_csr``    pooling.py:758-810
+``view_attention``         pooling.py:284-300 / :514-530 (softmax + weighted sum + gating)
+``gather_nearest``         core/multimodal/image.py:1285 (``x[feature_map_indexing]``)
+``gather_bilinear``        core/multimodal/image.py:105-170 (``sparse_interpolation``)
+=========================  ==========================================================
+
+All ops require tensors on a HIP device and raise otherwise (no CPU fallback).
+"""
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, ptr, require_device, stream_of
+
+# 0 = auto, 1 = generic kernels, 2 = fused wavefront-team kernels (tests flip this)
+ATTENTION_ALGO = 0
+
+
+def _as_2d(src):
+    if src.dim() == 1:
+        return src.reshape(-1, 1), True
+    if src.dim() != 2:
+        raise NotImplementedError("CSR ops take 1D or 2D source tensors")  # pooling.py:774-777
+    return src, False
+
+
+def _check_ptr(csr_idx):
+    if csr_idx.dim() != 1:
+        raise ValueError("CSR ops can only be computed over 1D CSR indices")  # pooling.py:771-773
+    if csr_idx.dtype != torch.int64:
+        raise TypeError(f"CSR pointers must be int64 (LongTensor), got {csr_idx.dtype}")
+    return csr_idx.contiguous()
+
+
+class _SegmentCSR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, csr_idx, reduce):
+        lib = _lib.load()
+        require_device(src, csr_idx)
+        src = src.contiguous()
+        n, C = csr_idx.shape[0] - 1, src.shape[1]
+        out = torch.empty((n, C), dtype=src.dtype, device=src.device)
+        arg = None
+        code = _lib.REDUCE_CODE[reduce]
+        if code in (_lib.DVA_MAX, _lib.DVA_MIN):
+            arg = torch.empty((n, C), dtype=torch.int32, device=src.device)
+        check(lib.dva_segment_csr_fwd(ptr(src), ptr(csr_idx), ptr(out), ptr(arg), n, C,
+                                      dtype_code(src), code, stream_of(src)), "dva_segment_csr_fwd")
+        ctx.save_for_backward(csr_idx, arg if arg is not None else csr_idx)
+        ctx.meta = (code, src.shape[0], C, arg is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        csr_idx, arg = ctx.saved_tensors
+        code, M, C, has_arg = ctx.meta
+        gout = gout.contiguous()
+        n = csr_idx.shape[0] - 1
+        # rows not covered by the pointers (none for a well-formed CSR) keep zero gradient
+        gsrc = torch.zeros((M, C), dtype=gout.dtype, device=gout.device)
+        check(lib.dva_segment_csr_bwd(ptr(gout), ptr(csr_idx), ptr(arg) if has_arg else None,
+                                      ptr(gsrc), n, C, dtype_code(gout), code, stream_of(gout)),
+              "dva_segment_csr_bwd")
+        return gsrc, None, None
+
+
+def segment_csr(src, csr_idx, out=None, reduce="sum"):
+    """``torch_scatter.segment_csr`` for 1D/2D ``src`` reduced along dim 0. Empty groups give 0."""
+    assert out is None, "out= is not supported"
+    if reduce not in _lib.REDUCE_CODE:
+        raise ValueError(f"Unknown reduce '{reduce}'")
+    csr_idx = _check_ptr(csr_idx)
+    src2, was_1d = _as_2d(src)
+    res = _SegmentCSR.apply(src2, csr_idx, reduce)
+    return res.reshape(-1) if was_1d else res
+
+
+def segment_csr_arg(src, csr_idx, reduce="max"):
+    """(values, arg) of a max/min CSR reduction; arg = winning row (int32, -1 for empty groups,
+    first row on ties). Not differentiable (used for index selection, pooling.py:135-143)."""
+    if reduce not in ("max", "min"):
+        raise ValueError("segment_csr_arg supports 'max' and 'min'")
+    lib = _lib.load()
+    csr_idx = _check_ptr(csr_idx)
+    src2, was_1d = _as_2d(src.detach())
+    require_device(src2, csr_idx)
+    src2 = src2.contiguous()
+    n, C = csr_idx.shape[0] - 1, src2.shape[1]
+    out = torch.empty((n, C), dtype=src2.dtype, device=src2.device)
+    arg = torch.empty((n, C), dtype=torch.int32, device=src2.device)
+    check(lib.dva_segment_csr_fwd(ptr(src2), ptr(csr_idx), ptr(out), ptr(arg), n, C,
+                                  dtype_code(src2), _lib.REDUCE_CODE[reduce], stream_of(src2)),
+          "dva_segment_csr_fwd")
+    if was_1d:
+        return out.reshape(-1), arg.reshape(-1)
+    return out, arg
+
+
+class _GatherCSR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, csr_idx, n_rows):
+        lib = _lib.load()
+        require_device(src, csr_idx)
+        src = src.contiguous()
+        n, C = csr_idx.shape[0] - 1, src.shape[1]
+        out = torch.empty((n_rows, C), dtype=src.dtype, device=src.device)
+        check(lib.dva_gather_csr(ptr(src), ptr(csr_idx), ptr(out), n, C, dtype_code(src),
+                                 stream_of(src)), "dva_gather_csr")
+        ctx.save_for_backward(csr_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (csr_idx,) = ctx.saved_tensors
+        return _SegmentCSR.apply(gout.contiguous(), csr_idx, "sum"), None, None
+
+
+def num_items(csr_idx):
+    """Number of rows a CSR pointer tensor covers (one host sync, like csr.py:140)."""
+    return int(csr_idx[-1].item()) if csr_idx.numel() > 0 else 0
+
+
+def gather_csr(src, csr_idx, n_rows=None):
+    """pooling.py:813-841: redistribute group-level rows to the group's elements."""
+    if not torch.is_floating_point(src):
+        raise ValueError("`gather_csr` can only be computed over tensors with floating point data types.")
+    csr_idx = _check_ptr(csr_idx)
+    src2, was_1d = _as_2d(src)
+    if n_rows is None:
+        n_rows = num_items(csr_idx)
+    res = _GatherCSR.apply(src2, csr_idx, n_rows)
+    return res.reshape(-1) if was_1d else res
+
+
+def segment_gather_csr(src, csr_idx, reduce="sum"):
+    """pooling.py:844-856."""
+    n_rows = src.shape[0]
+    return gather_csr(segment_csr(src, csr_idx, reduce=reduce), csr_idx, n_rows=n_rows)
+
+
+class _SegmentSoftmaxCSR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, csr_idx, eps, scaling):
+        lib = _lib.load()
+        require_device(src, csr_idx)
+        src = src.contiguous()
+        n, G = csr_idx.shape[0] - 1, src.shape[1]
+        out = torch.zeros_like(src)
+        check(lib.dva_segment_softmax_csr_fwd(ptr(src), ptr(csr_idx), ptr(out), n, G, int(scaling),
+                                              float(eps), stream_of(src)),
+              "dva_segment_softmax_csr_fwd")
+        ctx.save_for_backward(out, csr_idx)
+        ctx.scaling = int(scaling)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        out, csr_idx = ctx.saved_tensors
+        gout = gout.contiguous()
+        n, G = csr_idx.shape[0] - 1, out.shape[1]
+        gsrc = torch.zeros_like(out)
+        check(lib.dva_segment_softmax_csr_bwd(ptr(gout), ptr(out), ptr(csr_idx), ptr(gsrc), n, G,
+                                              ctx.scaling, stream_of(gout)),
+              "dva_segment_softmax_csr_bwd")
+        return gsrc, None, None, None
+
+
+def segment_softmax_csr(src, csr_idx, eps=1e-12, scaling=False):
+    """pooling.py:758-810 (same error behaviour)."""
+    if not torch.is_floating_point(src):
+        raise ValueError(
+            "`segment_csr_softmax` can only be computed over tensors with floating point data types.")
+    if csr_idx.dim() != 1:
+        raise ValueError("`segment_csr_softmax` can only be computed over 1D CSR indices.")
+    if src.dim() > 2:
+        raise NotImplementedError(
+            "`segment_csr_softmax` can only be computed over 1D or 2D source tensors.")
+    csr_idx = _check_ptr(csr_idx)
+    src2, was_1d = _as_2d(src)
+    res = _SegmentSoftmaxCSR.apply(src2.float(), csr_idx, eps, scaling).to(src.dtype)
+    return res.reshape(-1) if was_1d else res
+
+
+class _ViewAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, val, compat, csr_idx, gate_w, gate_b, scaling, eps):
+        lib = _lib.load()
+        require_device(val, compat, csr_idx, gate_w, gate_b)
+        val = val.contiguous()
+        compat = compat.contiguous()
+        N, (V, C), G = csr_idx.shape[0] - 1, val.shape, compat.shape[1]
+        gw = gate_w.detach().reshape(-1).float().contiguous() if gate_w is not None else None
+        gb = gate_b.detach().reshape(-1).float().contiguous() if gate_b is not None else None
+        if (gw is None) != (gb is None):
+            # Gating(weight=.., bias=..) with one of them disabled: neutral element for the other
+            gw = gw if gw is not None else torch.ones(G, device=val.device)
+            gb = gb if gb is not None else torch.zeros(G, device=val.device)
+        out = torch.empty((N, C), dtype=val.dtype, device=val.device)
+        att = torch.zeros((V, G), dtype=torch.float32, device=val.device)
+        gate = torch.empty((N, G), dtype=torch.float32, device=val.device)
+        amax = torch.empty((N, G), dtype=torch.int32, device=val.device)
+        check(lib.dva_view_attention_fwd(ptr(val), ptr(compat), ptr(csr_idx), ptr(gw), ptr(gb),
+                                         ptr(out), ptr(att), ptr(gate), ptr(amax), N, V, C, G,
+                                         int(scaling), float(eps), dtype_code(val), ATTENTION_ALGO,
+                                         stream_of(val)), "dva_view_attention_fwd")
+        ctx.save_for_backward(val, compat, csr_idx, att, gate, amax,
+                              gw if gw is not None else csr_idx, gb if gb is not None else csr_idx)
+        ctx.meta = (int(scaling), gw is not None,
+                    None if gate_w is None else gate_w.shape, None if gate_b is None else gate_b.shape)
+        ctx.mark_non_differentiable(att, gate)
+        return out, att, gate
+
+    @staticmethod
+    def backward(ctx, gout, _gatt, _ggate):
+        lib = _lib.load()
+        val, compat, csr_idx, att, gate, amax, gw, gb = ctx.saved_tensors
+        scaling, has_gate, w_shape, b_shape = ctx.meta
+        gout = gout.contiguous()
+        N, (V, C), G = csr_idx.shape[0] - 1, val.shape, compat.shape[1]
+        gval = torch.zeros_like(val)
+        gcompat = torch.zeros_like(compat)
+        gwb = torch.zeros(2 * G, dtype=torch.float32, device=val.device) if has_gate else None
+        check(lib.dva_view_attention_bwd(ptr(gout), ptr(val), ptr(compat), ptr(att), ptr(gate),
+                                         ptr(amax), ptr(csr_idx), ptr(gw) if has_gate else None,
+                                         ptr(gb) if has_gate else None, ptr(gval), ptr(gcompat),
+                                         ptr(gwb), N, V, C, G, scaling, dtype_code(val),
+                                         ATTENTION_ALGO, stream_of(val)), "dva_view_attention_bwd")
+        g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
+        g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
+        return gval, gcompat, None, g_w, g_b, None, None
+
+
+def view_attention(val, compat, csr_idx, gate_w=None, gate_b=None, scaling=False, eps=1e-12):
+    """Fused tail of GroupBimodalCSRPool / QKVBimodalCSRPool (pooling.py:284-300).
+
+    :param val: [V, C] values (fp32 or bf16)
+    :param compat: [V, G] compatibilities (computed in fp32)
+    :param csr_idx: LongTensor [N+1]
+    :param gate_w, gate_b: Gating parameters of shape [1, G] (both None -> no gating)
+    :return: (x_pool [N, C], attentions [V, G], gating [N, G])
+    """
+    csr_idx = _check_ptr(csr_idx)
+    if compat.dim() == 1:
+        compat = compat.reshape(-1, 1)
+    return _ViewAttention.apply(val, compat.float(), csr_idx, gate_w, gate_b, scaling, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# gather
+# ---------------------------------------------------------------------------------------------
+
+def pack_gather_index(images, atom_ptr, pixels, ratio=1.0):
+    """8-byte packed (image, x, y) index of every atom, at feature-map resolution.
+
+    images LongTensor [V], atom_ptr LongTensor [V+1], pixels int16/int32/int64 [P, 2] (w, h);
+    ``ratio`` is the mapping -> feature-map downscale (image.py:1916-1980).
+    """
+    lib = _lib.load()
+    require_device(images, atom_ptr, pixels)
+    images = images.contiguous()
+    atom_ptr = _check_ptr(atom_ptr)
+    pixels = pixels.contiguous()
+    if pixels.dtype not in (torch.int16, torch.int32, torch.int64):
+        raise TypeError(f"pixels must be int16/int32/int64, got {pixels.dtype}")
+    V, P = images.shape[0], pixels.shape[0]
+    packed = torch.empty(P, dtype=torch.int64, device=pixels.device)
+    check(lib.dva_pack_gather_index(ptr(images), ptr(atom_ptr), ptr(pixels), pixels.element_size(),
+                                    float(ratio), V, P, ptr(packed), stream_of(pixels)),
+          "dva_pack_gather_index")
+    return packed
+
+
+def _nhwc(x):
+    """[B,C,H,W] tensor -> contiguous [B,H,W,C] storage (free if x is channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+class _GatherNearest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, packed):
+        lib = _lib.load()
+        require_device(x, packed)
+        B, C, H, W = x.shape
+        xl = _nhwc(x)
+        P = packed.shape[0]
+        out = torch.empty((P, C), dtype=x.dtype, device=x.device)
+        check(lib.dva_gather_nearest_fwd(ptr(xl), ptr(packed), ptr(out), P, B, H, W, C,
+                                         dtype_code(x), stream_of(x)), "dva_gather_nearest_fwd")
+        ctx.save_for_backward(packed)
+        ctx.meta = (B, C, H, W, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (packed,) = ctx.saved_tensors
+        B, C, H, W, dt = ctx.meta
+        gout = gout.contiguous()
+        gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
+        check(lib.dva_gather_nearest_bwd(ptr(gout), ptr(packed), ptr(gx), packed.shape[0], B, H, W,
+                                         C, dtype_code(gout), stream_of(gout)),
+              "dva_gather_nearest_bwd")
+        return gx.permute(0, 3, 1, 2).to(dt), None
+
+
+def gather_nearest(x, packed_idx):
+    """``x[(batch, ..., h, w)]`` on a [B,C,H,W] map (image.py:1285) -> [P, C]."""
+    assert x.dim() == 4
+    return _GatherNearest.apply(x, packed_idx)
+
+
+class _GatherBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, packed, coords):
+        lib = _lib.load()
+        require_device(x, packed, coords)
+        B, C, H, W = x.shape
+        xl = _nhwc(x)
+        coords = coords.float().contiguous()
+        P = packed.shape[0]
+        out = torch.empty((P, C), dtype=x.dtype, device=x.device)
+        check(lib.dva_gather_bilinear_fwd(ptr(xl), ptr(packed), ptr(coords), ptr(out), P, B, H, W, C,
+                                          dtype_code(x), stream_of(x)), "dva_gather_bilinear_fwd")
+        ctx.save_for_backward(packed, coords)
+        ctx.meta = (B, C, H, W, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        packed, coords = ctx.saved_tensors
+        B, C, H, W, dt = ctx.meta
+        gout = gout.contiguous()
+        gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
+        check(lib.dva_gather_bilinear_bwd(ptr(gout), ptr(packed), ptr(coords), ptr(gx),
+                                          packed.shape[0], B, H, W, C, dtype_code(gout),
+                                          stream_of(gout)), "dva_gather_bilinear_bwd")
+        return gx.permute(0, 3, 1, 2).to(dt), None, None
+
+
+def gather_bilinear(x, packed_idx, coords):
+    """``sparse_interpolation(x, coords, batch)`` with border padding (image.py:105-170)."""
+    assert x.dim() == 4
+    assert coords.dim() == 2 and coords.shape[1] == 2
+    return _GatherBilinear.apply(x, packed_idx, coords)

@@ -1,0 +1,212 @@
+/*
+ * dva.h — C ABI of libdva_hip.so, the MI355X (gfx950) implementation of the DeepViewAgg
+ * multimodal hot path (mapping build -> multi-view gather -> view-attention pooling).
+ *
+ * Contract (SURVEY.md §8b "C-ABI to export"):
+ *   - plain C entry points, caller-owned DEVICE buffers (HBM pointers), sizes as integers;
+ *   - every function returns int: 0 = ok, <0 = DVA_ERR_*; no exceptions cross the ABI;
+ *   - the HIP stream is passed explicitly (as void* == hipStream_t); nothing synchronises the
+ *     device unless stated ("[syncs]"), no hidden global state, re-entrant;
+ *   - no torch types. The reference is 100 % Python, so "the reference interface each entry
+ *     replaces" is a Python call site, cited per function as file:line under /root/reference.
+ *
+ * Layouts: feature maps are channels-last x[B][H][W][C]; row matrices are row-major [rows][C];
+ * CSR pointers are int64 (reference: torch.LongTensor). dtype codes below select the element type
+ * of "feature" buffers (void*): fp32 or bf16; scores / mapping features / statistics are fp32.
+ */
+#ifndef DVA_H_
+#define DVA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVA_OK 0
+#define DVA_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, bad enum) */
+#define DVA_ERR_UNSUPPORTED (-2) /* valid request this build does not implement           */
+#define DVA_ERR_LAUNCH (-3)      /* HIP runtime reported a launch/runtime error           */
+#define DVA_ERR_OVERFLOW (-4)    /* composite key does not fit int64 (utils/multimodal.py:141) */
+
+#define DVA_F32 0
+#define DVA_BF16 1
+
+#define DVA_SUM 0
+#define DVA_MEAN 1
+#define DVA_MAX 2
+#define DVA_MIN 3
+
+/* camera models of core/multimodal/visibility.py:478-538 */
+#define DVA_CAM_EQUIRECT 0      /* 's3dis_equirectangular' */
+#define DVA_CAM_PINHOLE_SCANNET 1
+#define DVA_CAM_PINHOLE_KITTI 2 /* 'kitti360_perspective' */
+#define DVA_CAM_FISHEYE_KITTI 3 /* 'kitti360_fisheye' */
+
+/* library / device introspection ------------------------------------------------------------ */
+int dva_version(void);
+/* number of visible HIP devices, or <0 on runtime error. Does not create a context. */
+int dva_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ *
+ * CSR segment primitives.  Replace torch_scatter.segment_csr / gather_csr call sites:
+ *   modules/multimodal/pooling.py:63 (BimodalCSRPool), :289,:295 (weighted sum, gating max),
+ *   :628 (DeepSetFeat pool), :787,:807 (softmax), :813-841 (gather_csr);
+ *   core/multimodal/image.py:1767 (per-view mean of mapping features).
+ * Empty groups reduce to 0 (pooling.py:870); max/min ties -> first row of the group.
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[g, c] = reduce_{r in [ptr[g], ptr[g+1])} src[r, c].  arg (nullable) receives, for MAX/MIN,
+ * the winning row index (int32, -1 for empty groups); required later by the backward. */
+int dva_segment_csr_fwd(const void* src, const int64_t* ptr, void* out, int32_t* arg,
+                        int64_t n_groups, int32_t C, int32_t dtype, int32_t reduce, void* stream);
+
+/* grad_src[r, c] for r in every group (rows outside [ptr[0], ptr[n_groups]) are not touched).
+ * SUM: grad_out[g,c]; MEAN: grad_out[g,c]/n_g; MAX/MIN: grad_out[g,c] if r == arg[g,c] else 0. */
+int dva_segment_csr_bwd(const void* grad_out, const int64_t* ptr, const int32_t* arg,
+                        void* grad_src, int64_t n_groups, int32_t C, int32_t dtype,
+                        int32_t reduce, void* stream);
+
+/* out[r, c] = src[g(r), c]  (pooling.py:813-841 gather_csr). Backward = dva_segment_csr_fwd(SUM). */
+int dva_gather_csr(const void* src, const int64_t* ptr, void* out, int64_t n_groups, int32_t C,
+                   int32_t dtype, void* stream);
+
+/* Per-group softmax of fp32 scores src[V, G] (pooling.py:758-810 segment_softmax_csr):
+ * a = exp((s - max_g)/d) / (sum_g exp(.) + eps), d = sqrt(n_g) if scaling else 1. */
+int dva_segment_softmax_csr_fwd(const float* src, const int64_t* ptr, float* out,
+                                int64_t n_groups, int32_t G, int32_t scaling, float eps,
+                                void* stream);
+/* grad_src = a * (grad_a - sum_g(a * grad_a)) / d   (the eps term's O(1e-12) leak is dropped). */
+int dva_segment_softmax_csr_bwd(const float* grad_out, const float* out, const int64_t* ptr,
+                                float* grad_src, int64_t n_groups, int32_t G, int32_t scaling,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Multi-view feature gather.  Replaces SameSettingImageData.get_mapped_features
+ * (core/multimodal/image.py:1262-1287): nearest = x[feature_map_indexing] (:1285, indexing
+ * tuple built at :1871-1885 after downscale_images :1916-1980); bilinear = sparse_interpolation
+ * (:105-170).  Feature maps are channels-last [B,H,W,C] so one atom = one contiguous C-burst.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Build the packed 8-byte gather index of every atom (mapped pixel):
+ *   idx[p] = { int32 image, int16 x, int16 y } with x = floor(px / ratio), y = floor(py / ratio)
+ * image[p] = images[view(p)] expanded through atom_ptr (image.py:1879-1880 repeat_interleave).
+ * pixels: [P,2] (w,h) of pix_bytes-wide signed ints (2, 4 or 8: image.py:507-516 pixel_dtype).
+ * ratio >= 1 is the mapping->feature-map downscale (image.py:1953-1954, float floor-division). */
+int dva_pack_gather_index(const int64_t* images, const int64_t* atom_ptr, const void* pixels,
+                          int32_t pix_bytes, double ratio, int64_t n_views, int64_t n_atoms,
+                          void* packed_idx /* int64[P] */, void* stream);
+
+/* out[p, :] = x[img, y, x, :] */
+int dva_gather_nearest_fwd(const void* x, const void* packed_idx, void* out, int64_t n_atoms,
+                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* grad_x[img, y, x, :] += grad_out[p, :].  grad_x is fp32 [B,H,W,C], caller-zeroed
+ * (fp32 accumulation of bf16 gradients; atomics => run-to-run order may vary in the last ulp). */
+int dva_gather_nearest_bwd(const void* grad_out, const void* packed_idx, float* grad_x,
+                           int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C,
+                           int32_t dtype, void* stream);
+
+/* Bilinear gather with the reference's border-replicate semantics (image.py:105-170):
+ * q = coord * (H, W) + 0.5 in the 1-padded map; 4 taps floor(q), floor(q+1); weights |prod(q - opposite)|.
+ * coords fp32 [P,2] = (y, x) in [0,1]; the image of atom p comes from packed_idx (its x,y unused). */
+int dva_gather_bilinear_fwd(const void* x, const void* packed_idx, const float* coords, void* out,
+                            int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C,
+                            int32_t dtype, void* stream);
+int dva_gather_bilinear_bwd(const void* grad_out, const void* packed_idx, const float* coords,
+                            float* grad_x, int64_t n_atoms, int32_t B, int32_t H, int32_t W,
+                            int32_t C, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * DeepViewAgg view attention.  Replaces the tail of GroupBimodalCSRPool.forward /
+ * QKVBimodalCSRPool.forward (modules/multimodal/pooling.py:284-300, :514-530):
+ *   att  = segment_softmax_csr(compat, ptr, scaling)                       [V,G]
+ *   pool = segment_csr(val * expand_group_feat(att), ptr, 'sum')            [N,C]
+ *   gate = tanh(relu(w * segment_csr(compat, ptr, 'max') + b))  (Gating, pooling.py:690-715)
+ *   out  = pool * expand_group_feat(gate)
+ * expand_group_feat (pooling.py:737-755): group g owns floor(C/G) (+1 for the first C mod G) channels.
+ * gate_w / gate_b nullable together (gating=False): out = pool.
+ * Saved for backward / save_last: att [V,G], gate [N,G], amax int32 [N,G] (row of the group max,
+ * -1 for unseen points).  n_views = ptr[n_points] (used to size the launch geometry only).
+ * algo: 0 = auto, 1 = generic kernels (any C, G), 2 = fused wavefront-team kernels (needs
+ * C*s % 16 == 0 with C*s/16 a power of two <= 64, G a power of two dividing C with whole 16-byte
+ * lanes per group; DVA_ERR_UNSUPPORTED otherwise).
+ * ------------------------------------------------------------------------------------------ */
+int dva_view_attention_fwd(const void* val, const float* compat, const int64_t* ptr,
+                           const float* gate_w, const float* gate_b, void* out, float* att,
+                           float* gate, int32_t* amax, int64_t n_points, int64_t n_views, int32_t C,
+                           int32_t G, int32_t scaling, float eps, int32_t dtype, int32_t algo,
+                           void* stream);
+
+/* grad_val [V,C] (dtype), grad_compat [V,G] fp32, grad_gate_wb fp32[2*G] (caller-zeroed; atomically
+ * accumulated: first G = d/dw, last G = d/db; nullable when gating is off). */
+int dva_view_attention_bwd(const void* grad_out, const void* val, const float* compat,
+                           const float* att, const float* gate, const int32_t* amax,
+                           const int64_t* ptr, const float* gate_w, const float* gate_b,
+                           void* grad_val, float* grad_compat, float* grad_gate_wb,
+                           int64_t n_points, int64_t n_views, int32_t C, int32_t G, int32_t scaling,
+                           int32_t dtype, int32_t algo, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a
+ * composite int64 key, :97-179 CompositeTensor, :253-323 lex ops).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of temporary storage the two functions below need for n keys. */
+int64_t dva_lex_workspace_bytes(int64_t n);
+/* order[i] = index of the i-th smallest key; STABLE (ties keep input order), which is one of the
+ * orders numpy's unstable argsort (multimodal.py:316) may return. keys_sorted nullable. */
+int dva_argsort_i64(const int64_t* keys, int64_t n, int64_t* order, int64_t* keys_sorted,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+/* first[j] = smallest input index carrying the j-th smallest distinct key (numpy
+ * unique(return_index=True), multimodal.py:310); *n_unique written to device memory. */
+int dva_argunique_i64(const int64_t* keys, int64_t n, int64_t* first, int64_t* n_unique_dev,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Mapping build (point -> pixel visibility).  Replaces SplattingVisibility.__call__
+ * = camera_projection_cpu + visibility_from_splatting_cpu + postprocess_features
+ * (core/multimodal/visibility.py:478-538, :1073-1195, :1548-1582, glue :1699-1757).
+ * The CPU/numba path is the semantic reference (README.md:122-123).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dva_camera {
+  int32_t model;        /* DVA_CAM_* */
+  int32_t img_w, img_h; /* projection map size (proj_size) */
+  int32_t crop_top, crop_bottom;
+  float r_min, r_max;
+  float img_xyz[3];    /* camera centre */
+  float opk[3];        /* equirect pose (omega, phi, kappa) */
+  float extrinsic[16]; /* row-major 4x4 (pinhole / fisheye) */
+  float intrinsic[16]; /* row-major 4x4 pinhole intrinsic */
+  float fisheye[7];    /* xi, k1, k2, gamma1, gamma2, u0, v0 */
+  float voxel, k_swell;
+  double d_swell; /* int or float in the reference (np.log(d_swell)) */
+  int32_t exact;
+} dva_camera;
+
+/* Bytes of device workspace dva_visibility needs for n candidate points and this camera. */
+int64_t dva_visibility_workspace_bytes(const dva_camera* cam, int64_t n);
+
+/* One image.  xyz fp32 [n,3] candidate points IN CALLER ORDER (tie-breaks depend on it),
+ * mask nullable uint8 [img_w, img_h] (indexed [x][y], visibility.py:427-432).
+ * Outputs (capacity n each; *n_out_dev = q written on device), in the reference's output order
+ * (x-major, then y; visibility.py:1190-1195):
+ *   idx   int64[q] index into xyz          x_pix,y_pix int64[q]   depth fp32[q]
+ *   x_proj,y_proj fp64[q] float projection of the surviving points (for mapping features)
+ */
+int dva_visibility(const float* xyz, int64_t n, const dva_camera* cam, const uint8_t* mask,
+                   int64_t* idx, int64_t* x_pix, int64_t* y_pix, float* depth, double* x_proj,
+                   double* y_proj, int64_t* n_out_dev, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
+/* Mapping features of the q surviving points (visibility.py:1548-1582); nullable inputs drop
+ * their column exactly like the reference. features fp32 [q, n_cols], column order:
+ * depth, linearity, planarity, scattering, orientation, pixel height. Returns n_cols via *n_cols. */
+int dva_mapping_features(const float* xyz, const int64_t* idx, const float* depth,
+                         const double* y_proj, const float* linearity, const float* planarity,
+                         const float* scattering, const float* normals, const dva_camera* cam,
+                         int64_t q, float* features, int32_t* n_cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVA_H_ */

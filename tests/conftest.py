@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # gpu-marked tests are skipped (not failed) when collected on a box without a HIP device
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    """Committed golden vector produced by oracle/gen_golden.py from the reference's own source."""
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def t(a, device="cpu"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def state_dict_from(gold, prefix="sd/"):
+    return {k[len(prefix):]: torch.from_numpy(np.array(v)) for k, v in gold.items() if k.startswith(prefix)}
+
+
+@pytest.fixture
+def golden():
+    return load_golden

@@ -1,0 +1,144 @@
+"""The CPU oracle (oracle/pooling_oracle.py) pinned against the reference's own outputs.
+
+tests/golden/*.npz were produced by oracle/gen_golden.py, which imports and runs the reference's
+Python source (pooling.py, modules.py, image.py ...) in the build container.  Here the oracle's
+restatement must reproduce those outputs and gradients on the same inputs and weights.
+"""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t, state_dict_from
+from oracle import pooling_oracle as O
+
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+def close(a, b, **kw):
+    tol = dict(TOL)
+    tol.update(kw)
+    torch.testing.assert_close(a, t(b) if isinstance(b, np.ndarray) else b, **tol)
+
+
+def test_softmax_known_answers():
+    """pooling.py:913-921 docstring example; values quoted in SURVEY.md §4."""
+    g = load_golden("softmax_known")
+    src, csr = t(g["src"]), t(g["csr"])
+    out = O.segment_softmax_csr(src, csr)
+    close(out, g["out"])
+    close(out[:5, 0], torch.tensor([0.011656, 0.031685, 0.086129, 0.234122, 0.636409]), atol=1e-6, rtol=1e-4)
+    out_s = O.segment_softmax_csr(src, csr, scaling=True)
+    close(out_s, g["out_scaled"])
+    close(out_s[:5, 0], torch.tensor([0.067486, 0.105545, 0.165067, 0.258157, 0.403744]), atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("G", [1, 4])
+def test_softmax_random(G):
+    g = load_golden(f"softmax_random_G{G}")
+    csr, w = t(g["csr"]), t(g["w"])
+    for sc in (0, 1):
+        src = t(g["src"]).requires_grad_()
+        out = O.segment_softmax_csr(src, csr, scaling=bool(sc))
+        close(out, g[f"out_{sc}"])
+        (gr,) = torch.autograd.grad((out * w).sum(), src)
+        close(gr, g[f"grad_{sc}"])
+
+
+def test_segment_csr_and_gather():
+    g = load_golden("segment_csr")
+    csr = t(g["csr"])
+    for red in ("sum", "mean", "max", "min"):
+        src = t(g["src"]).requires_grad_()
+        out = O.segment_csr(src, csr, red)
+        close(out, g[f"out_{red}"])
+        (gr,) = torch.autograd.grad((out * t(g[f"w_{red}"])).sum(), src)
+        close(gr, g[f"grad_{red}"])
+    close(O.gather_csr(t(g["gather_src"]), csr), g["gather_out"])
+    # the loop definition and the vectorised arg agree (ties -> first row)
+    for red in ("max", "min"):
+        assert torch.equal(O.segment_arg(t(g["src"]), csr, red), O.segment_arg_fast(t(g["src"]), csr, red))
+
+
+POOL_CASES = ["pool_group_default_train", "pool_group_default_eval", "pool_group_docstring",
+              "pool_group_usemod_nogate", "pool_group_mlpset_g1", "pool_group_minmaxpool",
+              "pool_qkv_default", "pool_qkv_modqk"]
+
+
+def build_oracle_pool(name, g):
+    kwargs = ast.literal_eval(str(g["kwargs"]))
+    cls = O.QKVBimodalCSRPool if "qkv" in name else O.GroupBimodalCSRPool
+    m = cls(**kwargs)
+    m.load_state_dict(state_dict_from(g), strict=True)
+    m.train(bool(g["train"]))
+    return m, kwargs
+
+
+@pytest.mark.parametrize("name", POOL_CASES)
+def test_pool_modules(name):
+    g = load_golden(name)
+    m, _ = build_oracle_pool(name, g)
+    csr = t(g["csr"])
+    x_mod, x_map = t(g["x_mod"]).requires_grad_(), t(g["x_map"]).requires_grad_()
+    x_main = t(g["x_main"]).requires_grad_() if "x_main" in g else None
+    out = m(x_main, x_mod, x_map, csr)
+    close(out, g["out"], rtol=1e-4, atol=1e-5)
+    close(m.last_C, g["last_C"], rtol=1e-4, atol=1e-5)
+    close(m.last_A, g["last_A"], rtol=1e-4, atol=1e-5)
+    if m.G is not None:
+        close(m.last_G, g["last_G"], rtol=1e-4, atol=1e-5)
+    ins = [x_mod, x_map] + ([x_main] if x_main is not None else [])
+    names = [n for n, _ in m.named_parameters()]
+    grads = torch.autograd.grad((out * t(g["w"])).sum(), ins + list(m.parameters()), allow_unused=True)
+    close(grads[0], g["grad_x_mod"], rtol=1e-3, atol=1e-5)
+    close(grads[1], g["grad_x_map"], rtol=1e-3, atol=1e-5)
+    if x_main is not None:
+        close(grads[2], g["grad_x_main"], rtol=1e-3, atol=1e-5)
+    for n, gr in zip(names, grads[len(ins):]):
+        ref = t(g["gp/" + n])
+        gr = gr if gr is not None else torch.zeros_like(ref)
+        close(gr, ref, rtol=2e-3, atol=2e-5)
+    # BatchNorm running statistics after the forward
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g["sd_after/" + k], rtol=1e-4, atol=1e-6)
+
+
+def test_simple_pools_and_fusion():
+    g = load_golden("pool_simple")
+    csr, x_mod, x_map = t(g["csr"]), t(g["x_mod"]), t(g["x_map"])
+    for mode in ("max", "mean", "min", "sum"):
+        close(O.bimodal_csr_pool(x_mod, csr, mode), g[f"pool_{mode}"])
+    for mode in ("max", "min"):
+        close(O.heuristic_csr_pool(x_mod, x_map, csr, mode, 0), g[f"heur_{mode}_0"])
+        close(O.heuristic_csr_pool(x_mod, x_map, csr, mode, 7), g[f"heur_{mode}_occlusion"])
+    a, b = t(g["fusion_a"]), t(g["fusion_b"])
+    for mode in ("residual", "concatenation", "both", "modality"):
+        close(O.bimodal_fusion(a, b, mode), g[f"fusion_{mode}"])
+
+
+def images_per_atom(g):
+    sizes = t(g["atom_pointers"])[1:] - t(g["atom_pointers"])[:-1]
+    return t(g["images"]).repeat_interleave(sizes)
+
+
+def test_gather_nearest_and_bilinear():
+    g = load_golden("gather")
+    ipa, pix = images_per_atom(g), t(g["pixels"])
+    x = t(g["x"]).requires_grad_()
+    out = O.gather_nearest(x, ipa, pix, float(g["downscale"]))
+    assert torch.equal(out, t(g["out_nearest"]))
+    (gr,) = torch.autograd.grad((out * t(g["w_nearest"])).sum(), x)
+    close(gr, g["grad_x_nearest"])
+    out = O.gather_bilinear(x, ipa, pix, tuple(g["mapping_size"].tolist()))
+    close(out, g["out_bilinear"], rtol=1e-6, atol=1e-6)
+    (gr,) = torch.autograd.grad((out * t(g["w_bilinear"])).sum(), x)
+    close(gr, g["grad_x_bilinear"])
+
+
+def test_gather_multipixel_atomic_max():
+    g = load_golden("gather_multipixel")
+    out = O.gather_nearest(t(g["x"]), images_per_atom(g), t(g["pixels"]), float(g["downscale"]))
+    assert torch.equal(out, t(g["out_nearest"]))
+    close(O.segment_csr(out, t(g["atom_pointers"]), "max"), g["out_atomic_max"])
