@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void att_wsum_kernel(const T* __restrict__ val
     const int g = group_of_channel(c, C, G);
     const int64_t beg = ptr[p], end = ptr[p + 1];
     float acc = 0.f;
-    for (int64_t r = beg; r < end; ++r) acc += att[r * G + g] * Elt<T>::ld(val, r * C + c);
+    for (int64_t r = beg; r < end; ++r) acc = fmaf(att[r * G + g], Elt<T>::ld(val, r * C + c), acc);
     if (gate) acc *= gate[p * G + g];
     Elt<T>::st(out, t, acc);
   }
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       float f[VEC];
       Vec16<T>::unpack(x, f);
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] += a * f[k];
+      for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
     }
     for (int off = tg.lpr; off < tg.ts; off <<= 1) {
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
       Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + r * C + col), f);
       float d = 0.f;
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) d += go[k] * f[k];
+      for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
       for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
       if (g_first) {
         gcompat[r * G + g_lane] = d;

@@ -1,0 +1,262 @@
+"""-m gpu parity tests: HIP kernels (through the C ABI) vs the CPU oracle and the golden vectors.
+
+Tolerances: fp32 paths 1e-5 relative (sums are re-associated across lanes), bf16 paths 2e-2.
+Index outputs (argmax rows, packed gather index) are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t
+from oracle import pooling_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    if isinstance(b, np.ndarray):
+        b = t(b)
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+def random_csr(n, max_size, gen, p_empty=0.2):
+    sizes = torch.randint(1, max_size + 1, (n,), generator=gen)
+    sizes[torch.rand(n, generator=gen) < p_empty] = 0
+    return torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+
+
+def test_library_loads_and_sees_device():
+    from deepviewagg_amd import _lib
+    lib = _lib.load()
+    assert lib.dva_version() >= 100
+    assert lib.dva_device_count() >= 1
+
+
+def test_cpu_tensors_are_refused():
+    from deepviewagg_amd import ops, _lib
+    with pytest.raises(_lib.DvaError):
+        ops.segment_csr(torch.randn(4, 2), torch.tensor([0, 2, 4]))
+
+
+def test_segment_csr_golden():
+    from deepviewagg_amd import ops
+    g = load_golden("segment_csr")
+    csr = t(g["csr"], DEV)
+    for red in ("sum", "mean", "max", "min"):
+        src = t(g["src"], DEV).requires_grad_()
+        out = ops.segment_csr(src, csr, reduce=red)
+        close(out, g[f"out_{red}"])
+        (gr,) = torch.autograd.grad((out * t(g[f"w_{red}"], DEV)).sum(), src)
+        close(gr, g[f"grad_{red}"])
+    close(ops.gather_csr(t(g["gather_src"], DEV), csr), g["gather_out"], rtol=0, atol=0)
+    # arg: bit-exact vs the oracle's first-occurrence definition
+    _, arg = ops.segment_csr_arg(t(g["src"], DEV), csr, "max")
+    assert torch.equal(arg.cpu().long(), O.segment_arg(t(g["src"]), t(g["csr"]), "max"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [1, 3, 64, 130])
+def test_segment_csr_random(dtype, C):
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C)
+    csr = random_csr(300, 9, gen)
+    src = torch.randn(int(csr[-1]), C, generator=gen).to(dtype)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    for red in ("sum", "mean", "max", "min"):
+        s_dev = src.to(DEV).requires_grad_()
+        out = ops.segment_csr(s_dev, csr.to(DEV), reduce=red)
+        s_cpu = src.float().requires_grad_()
+        ref = O.segment_csr(s_cpu, csr, red)
+        close(out, ref, **tol)
+        w = torch.randn(ref.shape, generator=gen)
+        (g_dev,) = torch.autograd.grad((out.float() * w.to(DEV)).sum(), s_dev)
+        (g_cpu,) = torch.autograd.grad((ref * w).sum(), s_cpu)
+        close(g_dev, g_cpu, **tol)
+
+
+def test_segment_csr_edge_cases():
+    from deepviewagg_amd import ops
+    # all groups empty; single group; 1-D source
+    csr = torch.zeros(5, dtype=torch.long, device=DEV)
+    out = ops.segment_csr(torch.zeros(0, 3, device=DEV), csr, reduce="max")
+    assert out.shape == (4, 3) and float(out.abs().sum()) == 0
+    src = torch.arange(6, dtype=torch.float32, device=DEV)
+    out = ops.segment_csr(src, torch.tensor([0, 6], device=DEV), reduce="sum")
+    assert out.shape == (1,) and float(out[0]) == 15
+    with pytest.raises(ValueError):
+        ops.segment_csr(src, torch.tensor([[0, 6]], device=DEV))
+
+
+@pytest.mark.parametrize("G", [1, 4])
+def test_segment_softmax_golden(G):
+    from deepviewagg_amd import ops
+    g = load_golden(f"softmax_random_G{G}")
+    csr, w = t(g["csr"], DEV), t(g["w"], DEV)
+    for sc in (0, 1):
+        src = t(g["src"], DEV).requires_grad_()
+        out = ops.segment_softmax_csr(src, csr, scaling=bool(sc))
+        close(out, g[f"out_{sc}"])
+        (gr,) = torch.autograd.grad((out * w).sum(), src)
+        close(gr, g[f"grad_{sc}"], rtol=1e-4, atol=1e-6)
+    k = load_golden("softmax_known")
+    close(ops.segment_softmax_csr(t(k["src"], DEV), t(k["csr"], DEV)), k["out"])
+    close(ops.segment_softmax_csr(t(k["src"], DEV), t(k["csr"], DEV), scaling=True), k["out_scaled"])
+
+
+def attention_reference(val, compat, csr, gw, gb, scaling, C, G):
+    """oracle: pooling.py:284-300"""
+    class _G(torch.nn.Module):
+        def forward(self, x):
+            return torch.tanh(torch.relu(x * gw + gb)).view(-1, G).squeeze(1)
+    return O.attention_tail(val, compat, csr, _G() if gw is not None else None, G, C, scaling)
+
+
+ATT_SHAPES = [  # (C, G, max_views, dtype)
+    (64, 4, 40, torch.float32), (64, 4, 40, torch.bfloat16), (64, 4, 3, torch.bfloat16),
+    (512, 4, 8, torch.bfloat16), (256, 8, 8, torch.float32), (32, 1, 5, torch.float32),
+    (16, 16, 6, torch.float32), (128, 4, 70, torch.bfloat16),
+    (7, 2, 5, torch.float32), (20, 5, 4, torch.float32), (12, 4, 6, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("gating", [True, False])
+@pytest.mark.parametrize("C,G,max_views,dtype", ATT_SHAPES)
+def test_view_attention(C, G, max_views, dtype, gating, algo):
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C * 100 + G)
+    N = 257
+    csr = random_csr(N, max_views, gen)
+    V = int(csr[-1])
+    val = torch.randn(V, C, generator=gen).to(dtype)
+    compat = torch.randn(V, G, generator=gen) * 2
+    gw = (torch.randn(1, G, generator=gen)) if gating else None
+    gb = (torch.randn(1, G, generator=gen) * 0.5) if gating else None
+    w = torch.randn(N, C, generator=gen)
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+
+    # oracle in fp32 on the (rounded) inputs
+    val_c, compat_c = val.float().requires_grad_(), compat.clone().requires_grad_()
+    gw_c = gw.clone().requires_grad_() if gating else None
+    gb_c = gb.clone().requires_grad_() if gating else None
+    ref, att_ref, gate_ref = attention_reference(val_c, compat_c, csr, gw_c, gb_c, True, C, G)
+    ins_c = [val_c, compat_c] + ([gw_c, gb_c] if gating else [])
+    gref = torch.autograd.grad((ref * w).sum(), ins_c)
+
+    ops.ATTENTION_ALGO = algo
+    try:
+        val_d, compat_d = val.to(DEV).requires_grad_(), compat.to(DEV).requires_grad_()
+        gw_d = gw.to(DEV).requires_grad_() if gating else None
+        gb_d = gb.to(DEV).requires_grad_() if gating else None
+        out, att, gate = ops.view_attention(val_d, compat_d, csr.to(DEV), gw_d, gb_d, scaling=True)
+        ins_d = [val_d, compat_d] + ([gw_d, gb_d] if gating else [])
+        gdev = torch.autograd.grad((out.float() * w.to(DEV)).sum(), ins_d)
+    finally:
+        ops.ATTENTION_ALGO = 0
+    close(out, ref, **tol)
+    close(att, att_ref, rtol=1e-5, atol=1e-6)
+    if gating:
+        close(gate, gate_ref.view(N, G), rtol=1e-5, atol=1e-6)
+    close(gdev[0], gref[0], **tol)
+    gtol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=5e-2)
+    close(gdev[1], gref[1], **gtol)
+    if gating:
+        close(gdev[2], gref[2], rtol=gtol["rtol"], atol=gtol["atol"] * 20)
+        close(gdev[3], gref[3], rtol=gtol["rtol"], atol=gtol["atol"] * 20)
+
+
+def test_view_attention_team_equals_generic_bitwise_indices():
+    """Both code paths must select the same argmax rows (ties -> first row)."""
+    from deepviewagg_amd import ops, _lib
+    gen = torch.Generator().manual_seed(11)
+    N, C, G = 500, 64, 4
+    csr = random_csr(N, 12, gen)
+    V = int(csr[-1])
+    compat = torch.randint(-2, 3, (V, G), generator=gen).float()  # many ties
+    val = torch.randn(V, C, generator=gen)
+    lib = _lib.load()
+    res = []
+    for algo in (1, 2):
+        out = torch.empty(N, C, device=DEV)
+        att = torch.zeros(V, G, device=DEV)
+        gate = torch.empty(N, G, device=DEV)
+        amax = torch.empty(N, G, dtype=torch.int32, device=DEV)
+        gw, gb = torch.ones(G, device=DEV), torch.zeros(G, device=DEV)
+        rc = lib.dva_view_attention_fwd(
+            _lib.ptr(val.to(DEV)), _lib.ptr(compat.to(DEV)), _lib.ptr(csr.to(DEV)), _lib.ptr(gw), _lib.ptr(gb),
+            _lib.ptr(out), _lib.ptr(att), _lib.ptr(gate), _lib.ptr(amax), N, V, C, G, 1, 1e-12, 0, algo, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append((out.cpu(), amax.cpu()))
+    assert torch.equal(res[0][1], res[1][1])
+    ref_arg = O.segment_arg(compat, csr, "max")
+    assert torch.equal(res[0][1].long(), ref_arg)
+    close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5)
+
+
+def images_per_atom(g):
+    sizes = t(g["atom_pointers"])[1:] - t(g["atom_pointers"])[:-1]
+    return t(g["images"]).repeat_interleave(sizes)
+
+
+@pytest.mark.parametrize("name", ["gather", "gather_multipixel"])
+def test_gather_nearest_golden(name):
+    from deepviewagg_amd import ops
+    g = load_golden(name)
+    x = t(g["x"], DEV).requires_grad_()
+    packed = ops.pack_gather_index(t(g["images"], DEV), t(g["atom_pointers"], DEV), t(g["pixels"], DEV),
+                                   ratio=float(g["downscale"]))
+    out = ops.gather_nearest(x, packed)
+    assert torch.equal(out.cpu(), t(g["out_nearest"]))  # pure data movement: bit-exact
+    if "w_nearest" in g:
+        (gr,) = torch.autograd.grad((out * t(g["w_nearest"], DEV)).sum(), x)
+        close(gr, g["grad_x_nearest"])
+    else:
+        pooled = ops.segment_csr(out, t(g["atom_pointers"], DEV), reduce="max")
+        close(pooled, g["out_atomic_max"], rtol=0, atol=0)
+
+
+def test_gather_bilinear_golden():
+    from deepviewagg_amd import ops
+    g = load_golden("gather")
+    x = t(g["x"], DEV).requires_grad_()
+    packed = ops.pack_gather_index(t(g["images"], DEV), t(g["atom_pointers"], DEV), t(g["pixels"], DEV))
+    res = torch.tensor([g["mapping_size"].tolist()], dtype=torch.float32, device=DEV)
+    coords = (t(g["pixels"], DEV) / (res - 1))[:, [1, 0]]
+    out = ops.gather_bilinear(x, packed, coords)
+    close(out, g["out_bilinear"], rtol=1e-6, atol=1e-6)
+    (gr,) = torch.autograd.grad((out * t(g["w_bilinear"], DEV)).sum(), x)
+    close(gr, g["grad_x_bilinear"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [3, 6, 64])
+def test_gather_random_vs_oracle(dtype, C):
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C)
+    B, H, W, P = 5, 12, 20, 3000
+    x = torch.randn(B, C, H, W, generator=gen).to(dtype)
+    images = torch.randint(0, B, (P,), generator=gen)
+    pixels = torch.stack([torch.randint(0, W * 4, (P,), generator=gen),
+                          torch.randint(0, H * 4, (P,), generator=gen)], 1).short()
+    atom_ptr = torch.arange(P + 1)
+    packed = ops.pack_gather_index(images.to(DEV), atom_ptr.to(DEV), pixels.to(DEV), ratio=4.0)
+    x_d = x.to(DEV).requires_grad_()
+    out = ops.gather_nearest(x_d, packed)
+    ref = O.gather_nearest(x.float(), images, pixels, 4.0)
+    assert torch.equal(out.float().cpu(), ref)
+    w = torch.randn(P, C, generator=gen)
+    (gr,) = torch.autograd.grad((out.float() * w.to(DEV)).sum(), x_d)
+    x_c = x.float().requires_grad_()
+    (gr_ref,) = torch.autograd.grad((O.gather_nearest(x_c, images, pixels, 4.0) * w).sum(), x_c)
+    tol = dict(rtol=1e-5, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-1)
+    close(gr, gr_ref, **tol)
+    # bilinear at mapping resolution (W*4, H*4)
+    packed1 = ops.pack_gather_index(images.to(DEV), atom_ptr.to(DEV), pixels.to(DEV))
+    res = torch.tensor([[W * 4, H * 4]], dtype=torch.float32)
+    coords = (pixels / (res - 1))[:, [1, 0]]
+    out = ops.gather_bilinear(x.to(DEV), packed1, coords.to(DEV))
+    ref = O.sparse_interpolation(x.float(), coords, images)
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    close(out, ref, **tol)

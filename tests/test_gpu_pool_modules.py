@@ -1,0 +1,122 @@
+"""-m gpu: the drop-in pooling modules (HIP-backed) against the reference's golden outputs/gradients
+and against the CPU oracle at a larger random size."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t, state_dict_from
+from oracle import pooling_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+POOL_CASES = ["pool_group_default_train", "pool_group_default_eval", "pool_group_docstring",
+              "pool_group_usemod_nogate", "pool_group_mlpset_g1", "pool_group_minmaxpool",
+              "pool_qkv_default", "pool_qkv_modqk"]
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    if isinstance(b, np.ndarray):
+        b = t(b)
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", POOL_CASES)
+def test_pool_modules_match_reference(name):
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    g = load_golden(name)
+    kwargs = ast.literal_eval(str(g["kwargs"]))
+    cls = P.QKVBimodalCSRPool if "qkv" in name else P.GroupBimodalCSRPool
+    m = cls(save_last=True, **kwargs)
+    m.load_state_dict(state_dict_from(g), strict=True)   # reference state dict loads as is
+    m = m.to(DEV).train(bool(g["train"]))
+    csr = t(g["csr"], DEV)
+    x_mod, x_map = t(g["x_mod"], DEV).requires_grad_(), t(g["x_map"], DEV).requires_grad_()
+    x_main = t(g["x_main"], DEV).requires_grad_() if "x_main" in g else None
+    out = m(x_main, x_mod, x_map, csr)
+    close(out, g["out"])
+    close(m._last_C, g["last_C"])
+    close(m._last_A, g["last_A"])
+    if m.G is not None:
+        close(m._last_G, g["last_G"])
+    assert torch.equal(m._last_view_num.cpu(), t(g["csr"])[1:] - t(g["csr"])[:-1])
+    ins = [x_mod, x_map] + ([x_main] if x_main is not None else [])
+    names = [n for n, _ in m.named_parameters()]
+    grads = torch.autograd.grad((out * t(g["w"], DEV)).sum(), ins + list(m.parameters()), allow_unused=True)
+    close(grads[0], g["grad_x_mod"], rtol=1e-3, atol=1e-5)
+    close(grads[1], g["grad_x_map"], rtol=1e-3, atol=1e-5)
+    if x_main is not None:
+        close(grads[2], g["grad_x_main"], rtol=1e-3, atol=1e-5)
+    for n, gr in zip(names, grads[len(ins):]):
+        ref = t(g["gp/" + n])
+        gr = gr if gr is not None else torch.zeros_like(ref)
+        close(gr, ref, rtol=2e-3, atol=5e-5)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g["sd_after/" + k], rtol=1e-4, atol=1e-6)
+
+
+def test_simple_pools_and_fusion():
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd.modules.multimodal.fusion import BimodalFusion
+    g = load_golden("pool_simple")
+    csr, x_mod, x_map = t(g["csr"], DEV), t(g["x_mod"], DEV), t(g["x_map"], DEV)
+    for mode in ("max", "mean", "min", "sum"):
+        close(P.BimodalCSRPool(mode=mode)(None, x_mod, x_map, csr), g[f"pool_{mode}"], rtol=1e-5, atol=1e-6)
+    for mode in ("max", "min"):
+        for feat in (0, "occlusion"):
+            out = P.HeuristicBimodalCSRPool(mode=mode, feat=feat)(None, x_mod, x_map, csr)
+            assert torch.equal(out.cpu(), t(g[f"heur_{mode}_{feat}"]))
+    a, b = t(g["fusion_a"], DEV), t(g["fusion_b"], DEV)
+    for mode in BimodalFusion.MODES:
+        assert torch.equal(BimodalFusion(mode=mode)(a, b).cpu(), t(g[f"fusion_{mode}"]))
+    with pytest.raises(NotImplementedError):
+        BimodalFusion(mode="bogus")
+    with pytest.raises(AssertionError):
+        P.BimodalCSRPool(mode="median")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_group_pool_large_random_vs_oracle(dtype):
+    """N=20k points, up to 12 views, C=64: product module vs oracle module with the same weights."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    gen = torch.Generator().manual_seed(0)
+    N, C = 20000, 64
+    sizes = torch.randint(0, 13, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    kwargs = dict(in_map=8, in_mod=C, num_groups=4, use_mod=False, map_encoder='DeepSetFeat', use_num=True)
+    ref = O.GroupBimodalCSRPool(**kwargs)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+    m = P.GroupBimodalCSRPool(**kwargs)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.to(DEV)
+    x_mod = torch.randn(V, C, generator=gen)
+    x_map = torch.rand(V, 8, generator=gen)
+    w = torch.randn(N, C, generator=gen)
+    xr, mr = x_mod.clone().requires_grad_(), x_map.clone().requires_grad_()
+    out_ref = ref(None, xr, mr, csr)
+    g_ref = torch.autograd.grad((out_ref * w).sum(), [xr, mr] + list(ref.parameters()))
+    xd, md = x_mod.to(DEV).requires_grad_(), x_map.to(DEV).requires_grad_()
+    if dtype == torch.bfloat16:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(None, xd, md, csr.to(DEV))
+        tol = dict(rtol=5e-2, atol=5e-2)
+    else:
+        out = m(None, xd, md, csr.to(DEV))
+        tol = dict(rtol=1e-3, atol=1e-4)
+    g_dev = torch.autograd.grad((out.float() * w.to(DEV)).sum(), [xd, md] + list(m.parameters()))
+    close(out, out_ref, **tol)
+    if dtype == torch.float32:
+        close(g_dev[0], g_ref[0], rtol=1e-3, atol=1e-4)
+        close(g_dev[1], g_ref[1], rtol=5e-3, atol=1e-3)
+        for a, b in zip(g_dev[2:], g_ref[2:]):
+            close(a, b, rtol=5e-3, atol=5e-2)
+    else:
+        # bf16 autocast: compare the dominant gradient (values) loosely
+        rel = (g_dev[0].float().cpu() - g_ref[0]).norm() / g_ref[0].norm()
+        assert rel < 5e-2, rel
