@@ -43,12 +43,17 @@ class DvaCamera(ctypes.Structure):
         ("r_min", ctypes.c_float),
         ("r_max", ctypes.c_float),
         ("img_xyz", ctypes.c_float * 3),
-        ("opk", ctypes.c_float * 3),
-        ("extrinsic", ctypes.c_float * 16),
-        ("intrinsic", ctypes.c_float * 16),
+        ("rot", ctypes.c_float * 9),
+        ("trans", ctypes.c_float * 3),
+        ("fx", ctypes.c_float),
+        ("fy", ctypes.c_float),
+        ("mx", ctypes.c_float),
+        ("my", ctypes.c_float),
         ("fisheye", ctypes.c_float * 7),
-        ("voxel", ctypes.c_float),
-        ("k_swell", ctypes.c_float),
+        ("r_min_d", ctypes.c_double),
+        ("r_max_d", ctypes.c_double),
+        ("voxel", ctypes.c_double),
+        ("k_swell", ctypes.c_double),
         ("d_swell", ctypes.c_double),
         ("exact", ctypes.c_int32),
     ]

@@ -51,6 +51,7 @@ __host__ __device__ __forceinline__ int group_of_channel(int c, int C, int G) {
 }
 // first channel of group g
 __host__ __device__ __forceinline__ int group_begin(int g, int C, int G) {
+  if (g >= G) return C;
   if (G <= 1) return 0;
   if (G >= C) return g;
   const int base = C / G, rem = C % G;

@@ -172,14 +172,19 @@ typedef struct dva_camera {
   int32_t model;        /* DVA_CAM_* */
   int32_t img_w, img_h; /* projection map size (proj_size) */
   int32_t crop_top, crop_bottom;
-  float r_min, r_max;
-  float img_xyz[3];    /* camera centre */
-  float opk[3];        /* equirect pose (omega, phi, kappa) */
-  float extrinsic[16]; /* row-major 4x4 (pinhole / fisheye) */
-  float intrinsic[16]; /* row-major 4x4 pinhole intrinsic */
-  float fisheye[7];    /* xi, k1, k2, gamma1, gamma2, u0, v0 */
-  float voxel, k_swell;
-  double d_swell; /* int or float in the reference (np.log(d_swell)) */
+  float r_min, r_max;   /* informative copies; the range test uses r_min_d / r_max_d */
+  float img_xyz[3];     /* camera centre */
+  /* Row-major 3x3 / 3-vector the projection multiplies by, prepared by the host exactly like the
+   * reference does per image (scalar work): equirect: rot = M_o.M_p.M_k from opk
+   * (visibility.py:57-90), v = (xyz - img_xyz).rot^T; 'scannet': (rot, trans) =
+   * inv(extrinsic)[:3,:3|3] (:232-236), p = rot.xyz + trans; kitti perspective / fisheye:
+   * (rot, trans) = extrinsic[:3,:3|3] (:238-242, :304-308), p = rot^T.(xyz - trans). */
+  float rot[9];
+  float trans[3];
+  float fx, fy, mx, my; /* pinhole intrinsics [0][0], [1][1], [0][2], [1][2] */
+  float fisheye[7];     /* xi, k1, k2, gamma1, gamma2, u0, v0 */
+  double r_min_d, r_max_d; /* float64 scalars (numba promotes the float32 distances to compare) */
+  double voxel, k_swell, d_swell;
   int32_t exact;
 } dva_camera;
 

@@ -392,7 +392,7 @@ def gen_visibility():
     run_visibility("vis_equirect_bigsplat", 's3dis_equirectangular', xyz, cam, gen, True, (256, 128),
                    extra=dict(img_opk=torch.zeros(3)), voxel=0.15, k_swell=1.5, d_swell=1e6)
 
-    # pinhole, ScanNet convention: extrinsic = world->camera inverse (visibility.py:232-236)
+    # pinhole, ScanNet convention: extrinsic = camera-to-world pose, inverted at :232
     def look_at(eye, yaw):
         c, s = np.cos(yaw), np.sin(yaw)
         # camera looks along +z_cam = (c, s, 0) world, x_cam = (s, -c, 0), y_cam = (0, 0, -1)
@@ -405,8 +405,8 @@ def gen_visibility():
     K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 288.9, 289.4, 159.5, 119.5
     cam_to_world = look_at(np.array([2.0, 1.7, 1.2], dtype=np.float32), 0.4)
     run_visibility("vis_pinhole_scannet", 'scannet', xyz, cam_to_world[:3, 3].clone(), gen, True, (320, 240),
-                   extra=dict(img_extrinsic=torch.linalg.inv(cam_to_world).float().contiguous(),
-                              img_intrinsic_pinhole=K), r_min=0.1, r_max=8.0, voxel=0.03)
+                   extra=dict(img_extrinsic=cam_to_world, img_intrinsic_pinhole=K), r_min=0.1, r_max=8.0,
+                   voxel=0.03)
     K2 = torch.eye(4)
     K2[0, 0], K2[1, 1], K2[0, 2], K2[1, 2] = 552.55, 552.55, 682.05, 238.77
     run_visibility("vis_pinhole_kitti", 'kitti360_perspective', xyz, cam_to_world[:3, 3].clone(), gen, True,

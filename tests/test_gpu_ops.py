@@ -177,6 +177,7 @@ def test_view_attention_team_equals_generic_bitwise_indices():
     val = torch.randn(V, C, generator=gen)
     lib = _lib.load()
     res = []
+    val_d, compat_d, csr_d = val.to(DEV), compat.to(DEV), csr.to(DEV)  # keep alive across the raw calls
     for algo in (1, 2):
         out = torch.empty(N, C, device=DEV)
         att = torch.zeros(V, G, device=DEV)
@@ -184,7 +185,7 @@ def test_view_attention_team_equals_generic_bitwise_indices():
         amax = torch.empty(N, G, dtype=torch.int32, device=DEV)
         gw, gb = torch.ones(G, device=DEV), torch.zeros(G, device=DEV)
         rc = lib.dva_view_attention_fwd(
-            _lib.ptr(val.to(DEV)), _lib.ptr(compat.to(DEV)), _lib.ptr(csr.to(DEV)), _lib.ptr(gw), _lib.ptr(gb),
+            _lib.ptr(val_d), _lib.ptr(compat_d), _lib.ptr(csr_d), _lib.ptr(gw), _lib.ptr(gb),
             _lib.ptr(out), _lib.ptr(att), _lib.ptr(gate), _lib.ptr(amax), N, V, C, G, 1, 1e-12, 0, algo, None)
         assert rc == 0
         torch.cuda.synchronize()

@@ -52,7 +52,7 @@ def test_pool_modules_match_reference(name):
     for n, gr in zip(names, grads[len(ins):]):
         ref = t(g["gp/" + n])
         gr = gr if gr is not None else torch.zeros_like(ref)
-        close(gr, ref, rtol=2e-3, atol=5e-5)
+        close(gr, ref, rtol=2e-3, atol=3e-4)
     for k, v in m.state_dict().items():
         if "running" in k:
             close(v, g["sd_after/" + k], rtol=1e-4, atol=1e-6)
@@ -113,7 +113,7 @@ def test_group_pool_large_random_vs_oracle(dtype):
     close(out, out_ref, **tol)
     if dtype == torch.float32:
         close(g_dev[0], g_ref[0], rtol=1e-3, atol=1e-4)
-        close(g_dev[1], g_ref[1], rtol=5e-3, atol=1e-3)
+        close(g_dev[1], g_ref[1], rtol=5e-3, atol=5e-3)
         for a, b in zip(g_dev[2:], g_ref[2:]):
             close(a, b, rtol=5e-3, atol=5e-2)
     else:
