@@ -1,0 +1,176 @@
+"""Point -> pixel visibility models backed by the gfx950 mapping-build kernels.
+
+Drop-in mirror of the classes ``MapImages`` resolves by name with
+``getattr(visibility_module, self.method)`` (reference:
+torch_points3d/core/data_transform/multimodal/image.py:214-215) and calls as
+``visi_model(xyz, img_xyz, img_opk=..., img_intrinsic_pinhole=..., img_intrinsic_fisheye=...,
+img_extrinsic=..., img_mask=..., linearity=..., planarity=..., scattering=..., normals=...)``
+(:273-285).  Semantics follow the reference's CPU/numba path (core/multimodal/visibility.py:478-538,
+:630-953, :1073-1195, :1548-1582, :1699-1757), which its authors designate as the reliable one
+(README.md:122-123).  The computation itself runs on the HIP device through
+``dva_visibility`` / ``dva_mapping_features`` (include/dva.h); there is no CPU implementation here.
+
+Tie-breaks depend on the ORDER of the candidate points in ``xyz`` (first point wins a depth tie,
+highest index wins a shared centre pixel in exact mode), exactly as in the reference.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ..._lib import DvaCamera, check, ptr, stream_of
+
+CAMERAS = ('s3dis_equirectangular', 'scannet', 'kitti360_perspective', 'kitti360_fisheye')
+
+
+def _np32(x):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x, dtype=np.float32)
+
+
+def pose_to_rotation_matrix(opk):
+    """Inverse rotation matrix of an (omega, phi, kappa) pose, float32 like the reference
+    (visibility.py:57-90). Host-side scalar work done once per image."""
+    opk = _np32(opk)
+    co, so = np.cos(opk[0]), np.sin(opk[0])
+    cp, sp = np.cos(opk[1]), np.sin(opk[1])
+    ck, sk = np.cos(opk[2]), np.sin(opk[2])
+    m_o = np.array([[1.0, 0.0, 0.0], [0.0, co, -so], [0.0, so, co]], dtype=np.float32)
+    m_p = np.array([[cp, 0.0, sp], [0.0, 1.0, 0.0], [-sp, 0.0, cp]], dtype=np.float32)
+    m_k = np.array([[ck, -sk, 0.0], [sk, ck, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    return np.dot(m_o, np.dot(m_p, m_k))
+
+
+class VisibilityModel:
+    """Base class: camera description + the ``__call__`` contract (visibility.py:1677-1761)."""
+
+    def __init__(self, img_size=(1024, 512), crop_top=0, crop_bottom=0, r_max=30, r_min=0.5,
+                 camera='s3dis_equirectangular'):
+        self.img_size = img_size
+        self.crop_top = crop_top
+        self.crop_bottom = crop_bottom
+        self.r_max = r_max
+        self.r_min = r_min
+        self.camera = camera
+
+    # -- host-side per-image preparation -------------------------------------------------------
+    def _camera_struct(self, img_xyz, img_opk, img_intrinsic_pinhole, img_intrinsic_fisheye, img_extrinsic):
+        if self.camera not in CAMERAS:
+            raise ValueError(f"Unknown camera '{self.camera}'")  # visibility.py:526-527
+        c = DvaCamera()
+        c.model = _lib.CAMERA_CODE[self.camera]
+        c.img_w, c.img_h = int(self.img_size[0]), int(self.img_size[1])
+        c.crop_top, c.crop_bottom = int(self.crop_top), int(self.crop_bottom)
+        c.r_min, c.r_max = float(self.r_min), float(self.r_max)
+        c.r_min_d, c.r_max_d = float(self.r_min), float(self.r_max)
+        c.voxel = float(getattr(self, 'voxel', 0.1))
+        c.k_swell = float(getattr(self, 'k_swell', 1.0))
+        c.d_swell = float(getattr(self, 'd_swell', 1000))
+        c.exact = int(bool(getattr(self, 'exact', False)))
+        c.img_xyz[:] = _np32(img_xyz).reshape(3).tolist()
+        rot, trans = np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32)
+        if self.camera == 's3dis_equirectangular':
+            rot = pose_to_rotation_matrix(np.zeros(3) if img_opk is None else img_opk)
+        else:
+            ext = np.eye(4, dtype=np.float32) if img_extrinsic is None else _np32(img_extrinsic)
+            if self.camera == 'scannet':
+                # camera_to_world = inv(extrinsic) (visibility.py:232-236)
+                ext = np.linalg.inv(np.ascontiguousarray(ext))
+            rot, trans = ext[:3, :3].copy(), ext[:3, 3].copy()
+        c.rot[:] = rot.astype(np.float32).reshape(-1).tolist()
+        c.trans[:] = trans.astype(np.float32).tolist()
+        k = np.eye(4, dtype=np.float32) if img_intrinsic_pinhole is None else _np32(img_intrinsic_pinhole)
+        c.fx, c.fy, c.mx, c.my = float(k[0, 0]), float(k[1, 1]), float(k[0, 2]), float(k[1, 2])
+        fe = np.ones(7, dtype=np.float32) if img_intrinsic_fisheye is None else _np32(img_intrinsic_fisheye)
+        c.fisheye[:] = fe.reshape(7).tolist()
+        return c
+
+    def __call__(self, xyz, img_xyz, linearity=None, planarity=None, scattering=None, normals=None,
+                 img_opk=None, img_intrinsic_pinhole=None, img_intrinsic_fisheye=None, img_extrinsic=None,
+                 img_mask=None, **kwargs):
+        """Visibility of the point cloud ``xyz`` [n, 3] from one camera.
+
+        :return: dict(idx LongTensor[q] (index into xyz), x, y LongTensor[q] pixel coordinates in the
+          non-cropped projection map, depth FloatTensor[q], features FloatTensor[q, F])
+        """
+        lib = _lib.load()
+        in_device = xyz.device
+        if not torch.cuda.is_available():
+            raise _lib.DvaError("the mapping build runs on a HIP device; none is visible "
+                                "(deepviewagg_amd has no CPU fallback)")
+        dev = in_device if xyz.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        assert img_mask is None or tuple(img_mask.shape) == tuple(self.img_size), \
+            f'Expected img_mask to be a torch.BoolTensor of shape img_size={self.img_size} but got ' \
+            f'size={None if img_mask is None else tuple(img_mask.shape)}.'
+        cam = self._camera_struct(img_xyz, img_opk, img_intrinsic_pinhole, img_intrinsic_fisheye, img_extrinsic)
+
+        xyz_d = xyz.detach().to(dev, torch.float32).contiguous()
+        n = xyz_d.shape[0]
+        mask_d = None if img_mask is None else img_mask.to(dev).to(torch.uint8).contiguous()
+        hc = cam.img_h - cam.crop_top - cam.crop_bottom
+        cap = n if cam.exact else max(n, cam.img_w * hc)
+        cap = max(cap, 1)
+        idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        x_pix = torch.empty(cap, dtype=torch.int64, device=dev)
+        y_pix = torch.empty(cap, dtype=torch.int64, device=dev)
+        depth = torch.empty(cap, dtype=torch.float32, device=dev)
+        x_proj = torch.empty(cap, dtype=torch.float64, device=dev)
+        y_proj = torch.empty(cap, dtype=torch.float64, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws_bytes = lib.dva_visibility_workspace_bytes(ctypes.byref(cam), n)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "dva_visibility_workspace_bytes")
+        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        check(lib.dva_visibility(ptr(xyz_d), n, ctypes.byref(cam), ptr(mask_d), ptr(idx), ptr(x_pix),
+                                 ptr(y_pix), ptr(depth), ptr(x_proj), ptr(y_proj), ptr(n_out), ptr(ws),
+                                 int(ws_bytes), stream_of(xyz_d)), "dva_visibility")
+        q = int(n_out.item())   # one host sync per image, like the reference's numpy round trip
+
+        out = {}
+        if q == 0:
+            # visibility.py:1721-1729
+            out['idx'] = torch.empty((0,), dtype=torch.long, device=in_device)
+            out['x'] = torch.empty((0,), dtype=torch.long, device=in_device)
+            out['y'] = torch.empty((0,), dtype=torch.long, device=in_device)
+            out['depth'] = torch.empty((0,), dtype=torch.float, device=in_device)
+            out['features'] = torch.empty((0,), dtype=torch.float, device=in_device)
+            return out
+
+        def dev32(a):
+            return None if a is None else a.detach().to(dev, torch.float32).contiguous()
+        lin, pla, sca, nrm = dev32(linearity), dev32(planarity), dev32(scattering), dev32(normals)
+        ncol = 2 + sum(a is not None for a in (lin, pla, sca, nrm))
+        feats = torch.empty((q, ncol), dtype=torch.float32, device=dev)
+        got = ctypes.c_int32(0)
+        check(lib.dva_mapping_features(ptr(xyz_d), ptr(idx), ptr(depth), ptr(y_proj), ptr(lin), ptr(pla),
+                                       ptr(sca), ptr(nrm), ctypes.byref(cam), q, ptr(feats),
+                                       ctypes.byref(got), stream_of(xyz_d)), "dva_mapping_features")
+        assert got.value == ncol
+        out['idx'] = idx[:q].to(in_device)
+        out['x'] = x_pix[:q].to(in_device)
+        out['y'] = y_pix[:q].to(in_device)
+        out['depth'] = depth[:q].to(in_device)
+        out['features'] = feats.to(in_device)
+        # float projections of the mapped points (not in the reference's dict; used by parity tests)
+        out['x_proj'] = x_proj[:q].to(in_device)
+        out['y_proj'] = y_proj[:q].to(in_device)
+        return out
+
+    def __repr__(self):
+        attr_repr = ', '.join([f'{k}={v}' for k, v in self.__dict__.items()])
+        return f'{self.__class__.__name__}({attr_repr})'
+
+
+class SplattingVisibility(VisibilityModel):
+    """Z-buffered splatting visibility (visibility.py:1764-1776): every point is splatted as a box
+    whose size follows its voxel footprint and distance; the closest point wins each pixel; with
+    ``exact=True`` only the centre pixel of each winning point is kept."""
+
+    def __init__(self, voxel=0.1, k_swell=1.0, d_swell=1000, exact=False, **kwargs):
+        super().__init__(**kwargs)
+        self.voxel = voxel
+        self.k_swell = k_swell
+        self.d_swell = d_swell
+        self.exact = exact

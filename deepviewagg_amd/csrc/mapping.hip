@@ -1,14 +1,456 @@
-// placeholder until the mapping-build kernels land (same commit series)
+// Point -> pixel mapping build for gfx950 (reference: core/multimodal/visibility.py, the CPU/numba
+// path: camera_projection_cpu :478-538, *_splat_cpu :630-953, visibility_from_splatting_cpu
+// :1073-1195, postprocess_features :1548-1582).
+//
+// One image per call, candidates in CALLER ORDER (tie-breaks depend on it):
+//   project_kernel   range cull + projection + FoV/mask cull per candidate (float-width contract of
+//                    float32 geometry, float64 pixel arithmetic, correctly rounded
+//                    float32 atan2/acos through float64)
+//   exclusive scan + compact_kernel   order-preserving compaction -> local index j = list position
+//   splat_kernel     bounding box of every survivor's footprint (float64, round-half-even)
+//   zbuffer_kernel   one WAVEFRONT per point, lanes sweep the box pixels, 64-bit atomicMin of
+//                    (depth_bits << 32 | j): min depth wins, ties -> smallest j == the reference's
+//                    strict '<' in list order (:1157)
+//   exact mode       seen-flag pass, then atomicMax of j on the centre pixel: the largest seen j
+//                    survives == the reference's ascending overwrite (:1184-1187)
+//   flags + scan + emit_kernel   winners in (x-major, y) order (:1190-1195)
+// HBM-bound integer/atomic work; the 12-16 B/pixel maps (2048x1024 -> 33 MB) stay in L2/MALL.
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
 #include "dva_common.h"
+
+namespace dva {
+
+struct MapCounters {
+  int32_t m;  // candidates surviving projection
+  int32_t pad;
+};
+
+__device__ __forceinline__ double np_mod(double a, double b) {
+  double m = fmod(a, b);
+  if (m != 0.0 && ((b < 0) != (m < 0))) m += b;
+  return m;
+}
+
+__device__ __forceinline__ void fisheye_project(const float p0, const float p1, const float p2,
+                                                const float* fe, double* x, double* y, double* z) {
+  const float xi = fe[0], k1 = fe[1], k2 = fe[2], g1 = fe[3], g2 = fe[4], u0 = fe[5], v0 = fe[6];
+  const float norm = sqrtf((p0 * p0 + p1 * p1) + p2 * p2);
+  const float den = norm + 1e-4f;
+  float fx = p0 / den, fy = p1 / den;
+  const float fz = p2 / den;
+  fx = fx / (fz + xi);
+  fy = fy / (fz + xi);
+  const float r2 = fx * fx + fy * fy;
+  const float r4 = r2 * r2;
+  const float poly = (1.0f + k1 * r2) + k2 * r4;
+  *x = (double)((g1 * poly) * fx + u0);
+  *y = (double)((g2 * poly) * fy + v0);
+  *z = (double)((norm * p2) / fabsf(p2 + 1e-4f));
+}
+
+__device__ __forceinline__ void to_camera(const dva_camera& c, float q0, float q1, float q2, float* p) {
+  const float* R = c.rot;
+  if (c.model == DVA_CAM_PINHOLE_SCANNET) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      p[j] = fmaf(R[3 * j + 2], q2, fmaf(R[3 * j + 1], q1, R[3 * j] * q0)) + c.trans[j];
+  } else {
+    const float d0 = q0 - c.trans[0], d1 = q1 - c.trans[1], d2 = q2 - c.trans[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) p[j] = fmaf(R[6 + j], d2, fmaf(R[3 + j], d1, R[j] * d0));
+  }
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ xyz, int64_t n,
+                                                       const dva_camera c,
+                                                       const uint8_t* __restrict__ mask,
+                                                       int32_t* __restrict__ flag,
+                                                       float* __restrict__ dist_u,
+                                                       double* __restrict__ xp_u,
+                                                       double* __restrict__ yp_u) {
+  const int W = c.img_w, H = c.img_h;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float q0 = xyz[3 * i], q1 = xyz[3 * i + 1], q2 = xyz[3 * i + 2];
+    const float d0 = q0 - c.img_xyz[0], d1 = q1 - c.img_xyz[1], d2 = q2 - c.img_xyz[2];
+    const float dd = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    int keep = (c.r_min_d < (double)dd && (double)dd < c.r_max_d) ? 1 : 0;
+    double x = 0.0, y = 0.0, z = 1.0;
+    if (keep) {
+      if (c.model == DVA_CAM_EQUIRECT) {
+        const float* R = c.rot;
+        float v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = fmaf(d2, R[3 * j + 2], fmaf(d1, R[3 * j + 1], d0 * R[3 * j]));
+        const float t = (float)atan2((double)v[1], (double)v[0]);
+        const float p = (float)acos((double)(v[2] / dd));
+        x = np_mod((double)(W - 1) * (1.0 - (double)t / M_PI) / 2.0, (double)W);
+        y = np_mod((double)((float)(H - 1) * p) / M_PI, (double)H);
+        if (isnan(x)) x = 0.0;
+        if (isnan(y)) y = 0.0;
+      } else {
+        float p[3];
+        to_camera(c, q0, q1, q2, p);
+        if (c.model == DVA_CAM_FISHEYE_KITTI) {
+          fisheye_project(p[0], p[1], p[2], c.fisheye, &x, &y, &z);
+        } else {
+          x = (double)((p[0] * c.fx) / p[2] + c.mx);
+          y = (double)((p[1] * c.fy) / p[2] + c.my);
+          z = (double)p[2];
+        }
+      }
+      keep = (0.0 <= x && x < (double)W) && ((double)c.crop_top <= y && y < (double)(H - c.crop_bottom)) &&
+             (0.0 < z);
+      if (keep && mask) {
+        const uint32_t xi = (uint32_t)floor(x), yi = (uint32_t)floor(y);
+        keep = mask[(size_t)xi * H + yi] ? 1 : 0;
+      }
+    }
+    flag[i] = keep;
+    dist_u[i] = dd;
+    xp_u[i] = x;
+    yp_u[i] = y;
+  }
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(int64_t n, const int32_t* __restrict__ flag,
+                                                       const int32_t* __restrict__ pos,
+                                                       const float* __restrict__ dist_u,
+                                                       const double* __restrict__ xp_u,
+                                                       const double* __restrict__ yp_u,
+                                                       int32_t* __restrict__ idx1,
+                                                       float* __restrict__ dist,
+                                                       double* __restrict__ xp,
+                                                       double* __restrict__ yp,
+                                                       MapCounters* __restrict__ cnt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (flag[i]) {
+      const int32_t j = pos[i];
+      idx1[j] = (int32_t)i;
+      dist[j] = dist_u[i];
+      xp[j] = xp_u[i];
+      yp[j] = yp_u[i];
+    }
+    if (i == n - 1) cnt->m = pos[i] + flag[i];
+  }
+}
+
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) {
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// boxes in CROPPED coordinates (y shifted by -crop_top, :1138)
+__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ xyz,
+                                                     const int32_t* __restrict__ idx1,
+                                                     const float* __restrict__ dist,
+                                                     const double* __restrict__ xp,
+                                                     const double* __restrict__ yp, const dva_camera c,
+                                                     const MapCounters* __restrict__ cnt,
+                                                     int4* __restrict__ splat) {
+  const int W = c.img_w, H = c.img_h;
+  const double logd = log(c.d_swell);
+  const int m = cnt->m;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+    double wx, wy;
+    if (c.model == DVA_CAM_FISHEYE_KITTI) {
+      const int64_t i = idx1[j];
+      const float q0 = xyz[3 * i], q1 = xyz[3 * i + 1], q2 = xyz[3 * i + 2];
+      const float da = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
+      const double swell = 1.0 + c.k_swell * exp((double)(-da) / logd);
+      const float q2o = q2 + (float)(swell * c.voxel / 2.0);
+      float p[3];
+      double x2, y2, z2;
+      to_camera(c, q0 + 0.0f, q1 + 0.0f, q2o, p);
+      fisheye_project(p[0], p[1], p[2], c.fisheye, &x2, &y2, &z2);
+      const double ex = xp[j] - x2, ey = yp[j] - y2;
+      wx = wy = 2.0 * sqrt(ex * ex + ey * ey);
+    } else {
+      const double a = (1.0 + c.k_swell * exp((double)(-dist[j]) / logd)) * c.voxel / (double)dist[j];
+      if (c.model == DVA_CAM_EQUIRECT) {
+        wy = a * (double)H / M_PI;
+        wx = (a * (double)W / (2.0 * M_PI)) / (sin((M_PI / (double)H) * yp[j]) + 0.001);
+      } else {
+        wx = a * (double)c.fx;
+        wy = a * (double)c.fy;
+      }
+    }
+    const int32_t xa = (int32_t)(float)rint(xp[j] - wx / 2.0);
+    const int32_t xb = (int32_t)(float)rint(xp[j] + wx / 2.0 + 1.0);
+    const int32_t ya = (int32_t)(float)rint(yp[j] - wy / 2.0);
+    const int32_t yb = (int32_t)(float)rint(yp[j] + wy / 2.0 + 1.0);
+    const int32_t y_min = c.crop_top, y_max = H - c.crop_bottom;
+    int4 s;
+    s.x = clampi(xa, 0, W - 1);
+    s.y = clampi(xb, 1, W);
+    s.z = clampi(ya, y_min, y_max - 1) - c.crop_top;
+    s.w = clampi(yb, y_min + 1, y_max) - c.crop_top;
+    splat[j] = s;
+  }
+}
+
+// One wavefront per point; lanes sweep the box column-major like the map ([x][y], y fastest).
+__global__ __launch_bounds__(256) void zbuffer_kernel(const int4* __restrict__ splat,
+                                                       const float* __restrict__ dist,
+                                                       const MapCounters* __restrict__ cnt,
+                                                       unsigned long long* __restrict__ zbuf, int Hc) {
+  const int m = cnt->m;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int j = wave; j < m; j += n_waves) {
+    const int4 s = splat[j];
+    const int bw = s.y - s.x, bh = s.w - s.z;
+    const int area = bw * bh;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)j;
+    for (int t = lane; t < area; t += 64) {
+      const int bx = t / bh, by = t - bx * bh;
+      unsigned long long* cell = zbuf + (size_t)(s.x + bx) * Hc + (s.z + by);
+      if (key < *cell) atomicMin(cell, key);  // cheap pre-test; atomicMin decides
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void seen_kernel(const unsigned long long* __restrict__ zbuf,
+                                                    int64_t npix, uint8_t* __restrict__ seen) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < npix;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long z = zbuf[k];
+    if (z != ~0ull) seen[(uint32_t)z] = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void resplat_kernel(const uint8_t* __restrict__ seen,
+                                                       const double* __restrict__ xp,
+                                                       const double* __restrict__ yp,
+                                                       const MapCounters* __restrict__ cnt,
+                                                       int32_t* __restrict__ pixmap, int Hc,
+                                                       int crop_top) {
+  const int m = cnt->m;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+    if (!seen[j]) continue;
+    const int x = (int)xp[j], y = (int)yp[j] - crop_top;  // astype(np.int32): truncation (:1177-1178)
+    atomicMax(&pixmap[(size_t)x * Hc + y], j);
+  }
+}
+
+__global__ __launch_bounds__(256) void winners_kernel(const unsigned long long* __restrict__ zbuf,
+                                                       int64_t npix, int32_t* __restrict__ pixmap) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < npix;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long z = zbuf[k];
+    pixmap[k] = (z == ~0ull) ? -1 : (int32_t)(uint32_t)z;
+  }
+}
+
+__global__ __launch_bounds__(256) void pixflag_kernel(const int32_t* __restrict__ pixmap, int64_t npix,
+                                                       int32_t* __restrict__ pixflag) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < npix;
+       k += (int64_t)gridDim.x * blockDim.x)
+    pixflag[k] = pixmap[k] >= 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(
+    const int32_t* __restrict__ pixmap, const int32_t* __restrict__ pixflag,
+    const int32_t* __restrict__ pixpos, int64_t npix, int Hc, int crop_top,
+    const int32_t* __restrict__ idx1, const float* __restrict__ dist, const double* __restrict__ xp,
+    const double* __restrict__ yp, int64_t* __restrict__ idx, int64_t* __restrict__ x_pix,
+    int64_t* __restrict__ y_pix, float* __restrict__ depth, double* __restrict__ x_proj,
+    double* __restrict__ y_proj, int64_t* __restrict__ n_out) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < npix;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    if (pixflag[k]) {
+      const int32_t o = pixpos[k], j = pixmap[k];
+      idx[o] = idx1[j];
+      x_pix[o] = k / Hc;
+      y_pix[o] = k % Hc + crop_top;
+      depth[o] = dist[j];
+      x_proj[o] = xp[j];
+      y_proj[o] = yp[j];
+    }
+    if (k == npix - 1) *n_out = (int64_t)pixpos[k] + pixflag[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void features_kernel(
+    const float* __restrict__ xyz, const int64_t* __restrict__ idx, const float* __restrict__ depth,
+    const double* __restrict__ y_proj, const float* __restrict__ lin, const float* __restrict__ pla,
+    const float* __restrict__ sca, const float* __restrict__ nrm, const dva_camera c, int64_t q,
+    int ncol, float* __restrict__ out) {
+  const float rmin = (float)c.r_min_d;
+  const float den = (float)(c.r_max_d + 1e-4);
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < q;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx[k];
+    float* o = out + k * ncol;
+    int col = 0;
+    o[col++] = (depth[k] - rmin) / den;
+    if (lin) o[col++] = lin[i];
+    if (pla) o[col++] = pla[i];
+    if (sca) o[col++] = sca[i];
+    if (nrm) {
+      const float dd = depth[k] + 1e-4f;
+      const float u0 = (xyz[3 * i] - c.img_xyz[0]) / dd, u1 = (xyz[3 * i + 1] - c.img_xyz[1]) / dd,
+                  u2 = (xyz[3 * i + 2] - c.img_xyz[2]) / dd;
+      o[col++] = fabsf((u0 * nrm[3 * i] + u1 * nrm[3 * i + 1]) + u2 * nrm[3 * i + 2]);
+    }
+    o[col++] = (float)(y_proj[k] / (double)c.img_h);
+  }
+}
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct VisLayout {
+  size_t flag, pos, dist_u, xp_u, yp_u, idx1, dist, xp, yp, splat, seen, cnt, zbuf, pixmap, pixflag,
+      pixpos, temp, temp_bytes, total;
+};
+
+static int vis_layout(const dva_camera* c, int64_t n, VisLayout* L) {
+  const int64_t Hc = (int64_t)c->img_h - c->crop_top - c->crop_bottom;
+  if (c->img_w <= 0 || Hc <= 0) return DVA_ERR_INVALID;
+  const size_t npix = (size_t)c->img_w * (size_t)Hc;
+  const size_t big = (size_t)n > npix ? (size_t)n : npix;
+  size_t scan_tmp = 0;
+  int32_t* nul = nullptr;
+  if (rocprim::exclusive_scan(nullptr, scan_tmp, nul, nul, 0, big, rocprim::plus<int32_t>(),
+                              (hipStream_t)0) != hipSuccess)
+    return DVA_ERR_LAUNCH;
+  size_t o = 0;
+  L->flag = o;    o += al((size_t)n * 4);
+  L->pos = o;     o += al((size_t)n * 4);
+  L->dist_u = o;  o += al((size_t)n * 4);
+  L->xp_u = o;    o += al((size_t)n * 8);
+  L->yp_u = o;    o += al((size_t)n * 8);
+  L->idx1 = o;    o += al((size_t)n * 4);
+  L->dist = o;    o += al((size_t)n * 4);
+  L->xp = o;      o += al((size_t)n * 8);
+  L->yp = o;      o += al((size_t)n * 8);
+  L->splat = o;   o += al((size_t)n * 16);
+  L->seen = o;    o += al((size_t)n);
+  L->cnt = o;     o += al(sizeof(MapCounters));
+  L->zbuf = o;    o += al(npix * 8);
+  L->pixmap = o;  o += al(npix * 4);
+  L->pixflag = o; o += al(npix * 4);
+  L->pixpos = o;  o += al(npix * 4);
+  L->temp = o;
+  L->temp_bytes = scan_tmp;
+  o += al(scan_tmp);
+  L->total = o;
+  return DVA_OK;
+}
+
+static inline int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace dva
+
+using namespace dva;
+
 extern "C" {
-int64_t dva_visibility_workspace_bytes(const dva_camera*, int64_t) { return DVA_ERR_UNSUPPORTED; }
-int dva_visibility(const float*, int64_t, const dva_camera*, const uint8_t*, int64_t*, int64_t*,
-                   int64_t*, float*, double*, double*, int64_t*, void*, int64_t, void*) {
-  return DVA_ERR_UNSUPPORTED;
+
+int64_t dva_visibility_workspace_bytes(const dva_camera* cam, int64_t n) {
+  if (!cam || n < 0) return DVA_ERR_INVALID;
+  VisLayout L;
+  int rc = vis_layout(cam, n > 0 ? n : 1, &L);
+  if (rc) return rc;
+  return (int64_t)L.total;
 }
-int dva_mapping_features(const float*, const int64_t*, const float*, const double*, const float*,
-                         const float*, const float*, const float*, const dva_camera*, int64_t, float*,
-                         int32_t*, void*) {
-  return DVA_ERR_UNSUPPORTED;
+
+int dva_visibility(const float* xyz, int64_t n, const dva_camera* cam, const uint8_t* mask,
+                   int64_t* idx, int64_t* x_pix, int64_t* y_pix, float* depth, double* x_proj,
+                   double* y_proj, int64_t* n_out_dev, void* workspace, int64_t workspace_bytes,
+                   void* stream) {
+  if (!cam || n < 0 || !n_out_dev) return DVA_ERR_INVALID;
+  if (cam->model < DVA_CAM_EQUIRECT || cam->model > DVA_CAM_FISHEYE_KITTI) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), s) != hipSuccess) return DVA_ERR_LAUNCH;
+    return DVA_OK;
+  }
+  if (n > 0x7fffffff) return DVA_ERR_UNSUPPORTED;
+  if (!xyz || !idx || !x_pix || !y_pix || !depth || !x_proj || !y_proj || !workspace)
+    return DVA_ERR_INVALID;
+  VisLayout L;
+  int rc = vis_layout(cam, n, &L);
+  if (rc) return rc;
+  if ((int64_t)L.total > workspace_bytes) return DVA_ERR_INVALID;
+  char* ws = (char*)workspace;
+  const int Hc = cam->img_h - cam->crop_top - cam->crop_bottom;
+  const int64_t npix = (int64_t)cam->img_w * Hc;
+  int32_t* flag = (int32_t*)(ws + L.flag);
+  int32_t* pos = (int32_t*)(ws + L.pos);
+  float* dist_u = (float*)(ws + L.dist_u);
+  double* xp_u = (double*)(ws + L.xp_u);
+  double* yp_u = (double*)(ws + L.yp_u);
+  int32_t* idx1 = (int32_t*)(ws + L.idx1);
+  float* dist = (float*)(ws + L.dist);
+  double* xp = (double*)(ws + L.xp);
+  double* yp = (double*)(ws + L.yp);
+  int4* splat = (int4*)(ws + L.splat);
+  uint8_t* seen = (uint8_t*)(ws + L.seen);
+  MapCounters* cnt = (MapCounters*)(ws + L.cnt);
+  unsigned long long* zbuf = (unsigned long long*)(ws + L.zbuf);
+  int32_t* pixmap = (int32_t*)(ws + L.pixmap);
+  int32_t* pixflag = (int32_t*)(ws + L.pixflag);
+  int32_t* pixpos = (int32_t*)(ws + L.pixpos);
+
+  const dva_camera c = *cam;
+  hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(256), 0, s, xyz, n, c, mask, flag, dist_u,
+                     xp_u, yp_u);
+  size_t tmp = L.temp_bytes;
+  if (rocprim::exclusive_scan(ws + L.temp, tmp, flag, pos, 0, (size_t)n, rocprim::plus<int32_t>(), s) !=
+      hipSuccess)
+    return DVA_ERR_LAUNCH;
+  hipLaunchKernelGGL(compact_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, flag, pos, dist_u, xp_u, yp_u,
+                     idx1, dist, xp, yp, cnt);
+  hipLaunchKernelGGL(splat_kernel, dim3(grid_for(n)), dim3(256), 0, s, xyz, idx1, dist, xp, yp, c, cnt,
+                     splat);
+  if (hipMemsetAsync(zbuf, 0xFF, (size_t)npix * 8, s) != hipSuccess) return DVA_ERR_LAUNCH;
+  {
+    int64_t blocks = (n + 3) / 4;  // 4 wavefronts (points) per block
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(zbuffer_kernel, dim3((int)blocks), dim3(256), 0, s, splat, dist, cnt, zbuf, Hc);
+  }
+  if (c.exact) {
+    if (hipMemsetAsync(seen, 0, (size_t)n, s) != hipSuccess) return DVA_ERR_LAUNCH;
+    if (hipMemsetAsync(pixmap, 0xFF, (size_t)npix * 4, s) != hipSuccess) return DVA_ERR_LAUNCH;
+    hipLaunchKernelGGL(seen_kernel, dim3(grid_for(npix)), dim3(256), 0, s, zbuf, npix, seen);
+    hipLaunchKernelGGL(resplat_kernel, dim3(grid_for(n)), dim3(256), 0, s, seen, xp, yp, cnt, pixmap, Hc,
+                       c.crop_top);
+  } else {
+    hipLaunchKernelGGL(winners_kernel, dim3(grid_for(npix)), dim3(256), 0, s, zbuf, npix, pixmap);
+  }
+  hipLaunchKernelGGL(pixflag_kernel, dim3(grid_for(npix)), dim3(256), 0, s, pixmap, npix, pixflag);
+  tmp = L.temp_bytes;
+  if (rocprim::exclusive_scan(ws + L.temp, tmp, pixflag, pixpos, 0, (size_t)npix,
+                              rocprim::plus<int32_t>(), s) != hipSuccess)
+    return DVA_ERR_LAUNCH;
+  hipLaunchKernelGGL(emit_kernel, dim3(grid_for(npix)), dim3(256), 0, s, pixmap, pixflag, pixpos, npix, Hc,
+                     c.crop_top, idx1, dist, xp, yp, idx, x_pix, y_pix, depth, x_proj, y_proj, n_out_dev);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
 }
+
+int dva_mapping_features(const float* xyz, const int64_t* idx, const float* depth,
+                         const double* y_proj, const float* linearity, const float* planarity,
+                         const float* scattering, const float* normals, const dva_camera* cam,
+                         int64_t q, float* features, int32_t* n_cols, void* stream) {
+  if (!cam || q < 0) return DVA_ERR_INVALID;
+  const int ncol = 2 + (linearity != nullptr) + (planarity != nullptr) + (scattering != nullptr) +
+                   (normals != nullptr);
+  if (n_cols) *n_cols = ncol;
+  if (q == 0) return DVA_OK;
+  if (!xyz || !idx || !depth || !y_proj || !features) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(features_kernel, dim3(grid_for(q)), dim3(256), 0, (hipStream_t)stream, xyz, idx,
+                     depth, y_proj, linearity, planarity, scattering, normals, *cam, q, ncol, features);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
 }
+
+}  // extern "C"

@@ -193,7 +193,8 @@ int64_t dva_visibility_workspace_bytes(const dva_camera* cam, int64_t n);
 
 /* One image.  xyz fp32 [n,3] candidate points IN CALLER ORDER (tie-breaks depend on it),
  * mask nullable uint8 [img_w, img_h] (indexed [x][y], visibility.py:427-432).
- * Outputs (capacity n each; *n_out_dev = q written on device), in the reference's output order
+ * Outputs (capacity n each when cam->exact, else max(n, img_w * cropped_h) since every covered pixel is
+ * emitted; *n_out_dev = q written on device), in the reference's output order
  * (x-major, then y; visibility.py:1190-1195):
  *   idx   int64[q] index into xyz          x_pix,y_pix int64[q]   depth fp32[q]
  *   x_proj,y_proj fp64[q] float projection of the surviving points (for mapping features)

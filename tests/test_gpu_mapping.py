@@ -1,0 +1,117 @@
+"""-m gpu: the HIP mapping build (dva_visibility / dva_mapping_features / lex ops, through the C ABI)
+against the reference's golden vectors and against the C oracle at full projection-map size.
+
+Bit-exact: point indices, pixel coordinates, depths, lex orders.  Float projections: the GPU's
+float64 libm (OCML) vs glibc may differ in the last bit of a float64 intermediate -> compared at
+1e-9 px; mapping features at 2.5e-7.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t
+from oracle import mapping_oracle as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+VIS = ["vis_equirect_exact", "vis_equirect_dense", "vis_equirect_rot_crop_mask", "vis_equirect_bigsplat",
+       "vis_pinhole_scannet", "vis_pinhole_kitti", "vis_fisheye_kitti", "vis_equirect_empty"]
+
+
+def model_of(g):
+    from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
+    return SplattingVisibility(
+        img_size=tuple(int(v) for v in g["img_size"]), crop_top=int(g["crop"][0]), crop_bottom=int(g["crop"][1]),
+        r_max=float(g["r_max"]), r_min=float(g["r_min"]), camera=str(g["camera"]), voxel=float(g["voxel"]),
+        k_swell=float(g["k_swell"]), d_swell=float(g["d_swell"]), exact=bool(g["exact"]))
+
+
+def call_kwargs(g, dev):
+    kw = {k: t(g[k], dev) for k in ("img_opk", "img_extrinsic", "img_intrinsic_pinhole", "img_intrinsic_fisheye")
+          if k in g}
+    if "img_mask" in g:
+        kw["img_mask"] = t(g["img_mask"], dev)
+    return kw
+
+
+@pytest.mark.parametrize("name", VIS)
+def test_visibility_golden(name):
+    g = load_golden(name)
+    model = model_of(g)
+    out = model(t(g["xyz"], DEV), t(g["img_xyz"], DEV), linearity=t(g["linearity"], DEV),
+                planarity=t(g["planarity"], DEV), scattering=t(g["scattering"], DEV),
+                normals=t(g["normals"], DEV), **call_kwargs(g, DEV))
+    for k in ("idx", "x", "y"):
+        assert out[k].dtype == torch.int64
+        assert np.array_equal(out[k].cpu().numpy(), g[k]), k
+    assert np.array_equal(out["depth"].cpu().numpy(), g["depth"])
+    if len(g["idx"]):
+        np.testing.assert_allclose(out["features"].cpu().numpy(), g["features"], rtol=0, atol=2.5e-7)
+    else:
+        assert out["features"].shape == (0,)
+    # CPU inputs are accepted (uploaded, computed on the device, returned on the CPU) like the
+    # reference's use_cuda path
+    out2 = model(t(g["xyz"]), t(g["img_xyz"]), **call_kwargs(g, "cpu"))
+    assert out2["idx"].device.type == "cpu" and np.array_equal(out2["idx"].numpy(), g["idx"])
+
+
+def room_cloud(n, rng, size=(8.0, 6.0, 3.0)):
+    face = rng.integers(0, 6, n)
+    uvw = rng.random((n, 3))
+    uvw[np.arange(n), face // 2] = face % 2
+    return (uvw * np.array(size) + np.clip(rng.normal(0, 1e-3, (n, 3)), -0.05, 0.05)).astype(np.float32)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_visibility_full_size_vs_oracle(exact):
+    """S3DIS settings: 2048x1024 projection map, 200k candidates, voxel 2 cm."""
+    from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
+    rng = np.random.default_rng(0)
+    xyz = room_cloud(200_000, rng)
+    cam_xyz = np.array([3.1, 2.2, 1.4], dtype=np.float32)
+    opk = np.array([0.02, -0.01, 0.7], dtype=np.float32)
+    kw = dict(img_size=(2048, 1024), crop_top=0, crop_bottom=0, r_max=8.0, r_min=0.05, voxel=0.02,
+              k_swell=1.0, d_swell=1000, exact=exact)
+    cam = M.make_camera("s3dis_equirectangular", kw["img_size"], cam_xyz, r_min=kw["r_min"], r_max=kw["r_max"],
+                        voxel=kw["voxel"], k_swell=1.0, d_swell=1000, exact=exact, img_opk=opk)
+    ref = M.visibility(xyz, cam)
+    model = SplattingVisibility(camera="s3dis_equirectangular", **kw)
+    out = model(t(xyz, DEV), t(cam_xyz, DEV), img_opk=t(opk, DEV))
+    assert len(ref["idx"]) > 10000
+    for k in ("idx", "x", "y", "depth"):
+        assert np.array_equal(out[k].cpu().numpy(), ref[k]), k
+    np.testing.assert_allclose(out["x_proj"].cpu().numpy(), ref["x_proj"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["y_proj"].cpu().numpy(), ref["y_proj"], rtol=0, atol=1e-9)
+    # property: in exact mode every mapped pixel is unique and equals the truncated projection
+    if exact:
+        key = out["x"].cpu().numpy() * 1024 + out["y"].cpu().numpy()
+        assert len(np.unique(key)) == len(key)
+        assert np.array_equal(out["x"].cpu().numpy(), out["x_proj"].cpu().numpy().astype(np.int64))
+    # run-to-run determinism (atomics must not change the result)
+    out2 = model(t(xyz, DEV), t(cam_xyz, DEV), img_opk=t(opk, DEV))
+    assert torch.equal(out["idx"], out2["idx"]) and torch.equal(out["x"], out2["x"])
+
+
+def test_lex_ops_golden_and_random():
+    from deepviewagg_amd.utils import multimodal as U
+    g = load_golden("lex_csr")
+    a, b, c = t(g["a"], DEV), t(g["b"], DEV), t(g["c"], DEV)
+    assert np.array_equal(U.CompositeTensor(a, b, c).data.cpu().numpy(), g["composite"])
+    assert np.array_equal(U.lexargunique(a, b, c).cpu().numpy(), g["argunique"])
+    ua, ub, uc = U.lexunique(a, b, c)
+    assert np.array_equal(ua.cpu().numpy(), g["unique_a"]) and uc.dtype == torch.int16
+    assert np.array_equal(uc.cpu().numpy(), g["unique_c"])
+    sa, sb, sc = U.lexsort(a, b, c)
+    assert np.array_equal(sa.cpu().numpy(), g["sort_a"]) and np.array_equal(sc.cpu().numpy(), g["sort_c"])
+    order = U.lexargsort(a, b, c)
+    assert np.array_equal(g["composite"][order.cpu().numpy()], g["argsort_keys"])
+    # 2M random triples vs numpy (reference's own cross-check pattern, utils/multimodal.py:326-379)
+    rng = np.random.default_rng(1)
+    cols = [rng.integers(0, 1000, 2_000_000) for _ in range(3)]
+    dev_cols = [t(x, DEV) for x in cols]
+    key = M.composite(*cols)
+    assert np.array_equal(U.lexargunique(*dev_cols).cpu().numpy(), np.unique(key, return_index=True)[1])
+    assert np.array_equal(U.lexargsort(*dev_cols).cpu().numpy(), np.argsort(key, kind="stable"))
+    # empty input
+    e = torch.zeros(0, dtype=torch.long, device=DEV)
+    assert U.lexargunique(e, e).shape == (0,)
