@@ -24,6 +24,59 @@ from ._lib import check, dtype_code, ptr, require_device, stream_of
 ATTENTION_ALGO = 0
 
 
+class KernelTimer:
+    """Optional per-kernel timing with HIP events on the launch stream (bench.py sets
+    ``ops.TIMER = KernelTimer()``): records an event pair around every C-ABI launch together with the
+    algorithmic bytes of that launch; ``summary()`` synchronises once and aggregates."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, name, nbytes):
+        return _TimedLaunch(self, name, nbytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["bytes"] += nbytes
+        return agg
+
+
+class _TimedLaunch:
+    def __init__(self, timer, name, nbytes):
+        self.timer, self.name, self.nbytes = timer, name, nbytes
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        self.timer.records.append((self.name, self.nbytes, self.e0, self.e1))
+        return False
+
+
+class _NoTimer:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+TIMER = None
+
+
+def _timed(name, nbytes):
+    return TIMER.launch(name, int(nbytes)) if TIMER is not None else _NO_TIMER
+
+
 def _as_2d(src):
     if src.dim() == 1:
         return src.reshape(-1, 1), True
@@ -52,8 +105,10 @@ class _SegmentCSR(torch.autograd.Function):
         code = _lib.REDUCE_CODE[reduce]
         if code in (_lib.DVA_MAX, _lib.DVA_MIN):
             arg = torch.empty((n, C), dtype=torch.int32, device=src.device)
-        check(lib.dva_segment_csr_fwd(ptr(src), ptr(csr_idx), ptr(out), ptr(arg), n, C,
-                                      dtype_code(src), code, stream_of(src)), "dva_segment_csr_fwd")
+        with _timed("segment_csr_fwd", (src.shape[0] + n) * C * src.element_size() + n * 8
+                    + (n * C * 4 if arg is not None else 0)):
+            check(lib.dva_segment_csr_fwd(ptr(src), ptr(csr_idx), ptr(out), ptr(arg), n, C,
+                                          dtype_code(src), code, stream_of(src)), "dva_segment_csr_fwd")
         ctx.save_for_backward(csr_idx, arg if arg is not None else csr_idx)
         ctx.meta = (code, src.shape[0], C, arg is not None)
         return out
@@ -67,9 +122,11 @@ class _SegmentCSR(torch.autograd.Function):
         n = csr_idx.shape[0] - 1
         # rows not covered by the pointers (none for a well-formed CSR) keep zero gradient
         gsrc = torch.zeros((M, C), dtype=gout.dtype, device=gout.device)
-        check(lib.dva_segment_csr_bwd(ptr(gout), ptr(csr_idx), ptr(arg) if has_arg else None,
-                                      ptr(gsrc), n, C, dtype_code(gout), code, stream_of(gout)),
-              "dva_segment_csr_bwd")
+        with _timed("segment_csr_bwd", (M + n) * C * gout.element_size() + n * 8
+                    + (n * C * 4 if has_arg else 0)):
+            check(lib.dva_segment_csr_bwd(ptr(gout), ptr(csr_idx), ptr(arg) if has_arg else None,
+                                          ptr(gsrc), n, C, dtype_code(gout), code, stream_of(gout)),
+                  "dva_segment_csr_bwd")
         return gsrc, None, None
 
 
@@ -113,8 +170,9 @@ class _GatherCSR(torch.autograd.Function):
         src = src.contiguous()
         n, C = csr_idx.shape[0] - 1, src.shape[1]
         out = torch.empty((n_rows, C), dtype=src.dtype, device=src.device)
-        check(lib.dva_gather_csr(ptr(src), ptr(csr_idx), ptr(out), n, C, dtype_code(src),
-                                 stream_of(src)), "dva_gather_csr")
+        with _timed("gather_csr", (n_rows + n) * C * src.element_size() + n * 8):
+            check(lib.dva_gather_csr(ptr(src), ptr(csr_idx), ptr(out), n, C, dtype_code(src),
+                                     stream_of(src)), "dva_gather_csr")
         ctx.save_for_backward(csr_idx)
         return out
 
@@ -209,10 +267,12 @@ class _ViewAttention(torch.autograd.Function):
         att = torch.zeros((V, G), dtype=torch.float32, device=val.device)
         gate = torch.empty((N, G), dtype=torch.float32, device=val.device)
         amax = torch.empty((N, G), dtype=torch.int32, device=val.device)
-        check(lib.dva_view_attention_fwd(ptr(val), ptr(compat), ptr(csr_idx), ptr(gw), ptr(gb),
-                                         ptr(out), ptr(att), ptr(gate), ptr(amax), N, V, C, G,
-                                         int(scaling), float(eps), dtype_code(val), ATTENTION_ALGO,
-                                         stream_of(val)), "dva_view_attention_fwd")
+        es = val.element_size()
+        with _timed("view_attention_fwd", V * (C * es + 2 * G * 4) + N * (C * es + 8 + 2 * G * 4)):
+            check(lib.dva_view_attention_fwd(ptr(val), ptr(compat), ptr(csr_idx), ptr(gw), ptr(gb),
+                                             ptr(out), ptr(att), ptr(gate), ptr(amax), N, V, C, G,
+                                             int(scaling), float(eps), dtype_code(val), ATTENTION_ALGO,
+                                             stream_of(val)), "dva_view_attention_fwd")
         ctx.save_for_backward(val, compat, csr_idx, att, gate, amax,
                               gw if gw is not None else csr_idx, gb if gb is not None else csr_idx)
         ctx.meta = (int(scaling), gw is not None,
@@ -230,11 +290,13 @@ class _ViewAttention(torch.autograd.Function):
         gval = torch.zeros_like(val)
         gcompat = torch.zeros_like(compat)
         gwb = torch.zeros(2 * G, dtype=torch.float32, device=val.device) if has_gate else None
-        check(lib.dva_view_attention_bwd(ptr(gout), ptr(val), ptr(compat), ptr(att), ptr(gate),
-                                         ptr(amax), ptr(csr_idx), ptr(gw) if has_gate else None,
-                                         ptr(gb) if has_gate else None, ptr(gval), ptr(gcompat),
-                                         ptr(gwb), N, V, C, G, scaling, dtype_code(val),
-                                         ATTENTION_ALGO, stream_of(val)), "dva_view_attention_bwd")
+        es = val.element_size()
+        with _timed("view_attention_bwd", V * (2 * C * es + 2 * G * 4) + N * (C * es + 8 + 3 * G * 4)):
+            check(lib.dva_view_attention_bwd(ptr(gout), ptr(val), ptr(compat), ptr(att), ptr(gate),
+                                             ptr(amax), ptr(csr_idx), ptr(gw) if has_gate else None,
+                                             ptr(gb) if has_gate else None, ptr(gval), ptr(gcompat),
+                                             ptr(gwb), N, V, C, G, scaling, dtype_code(val),
+                                             ATTENTION_ALGO, stream_of(val)), "dva_view_attention_bwd")
         g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
         g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
         return gval, gcompat, None, g_w, g_b, None, None
@@ -294,8 +356,11 @@ class _GatherNearest(torch.autograd.Function):
         xl = _nhwc(x)
         P = packed.shape[0]
         out = torch.empty((P, C), dtype=x.dtype, device=x.device)
-        check(lib.dva_gather_nearest_fwd(ptr(xl), ptr(packed), ptr(out), P, B, H, W, C,
-                                         dtype_code(x), stream_of(x)), "dva_gather_nearest_fwd")
+        es = x.element_size()
+        # P*(g*C*s + idx) + P*C*s with g = 1
+        with _timed("gather_nearest_fwd", P * (2 * C * es + 8)):
+            check(lib.dva_gather_nearest_fwd(ptr(xl), ptr(packed), ptr(out), P, B, H, W, C,
+                                             dtype_code(x), stream_of(x)), "dva_gather_nearest_fwd")
         ctx.save_for_backward(packed)
         ctx.meta = (B, C, H, W, x.dtype)
         return out
@@ -307,9 +372,12 @@ class _GatherNearest(torch.autograd.Function):
         B, C, H, W, dt = ctx.meta
         gout = gout.contiguous()
         gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
-        check(lib.dva_gather_nearest_bwd(ptr(gout), ptr(packed), ptr(gx), packed.shape[0], B, H, W,
-                                         C, dtype_code(gout), stream_of(gout)),
-              "dva_gather_nearest_bwd")
+        P = packed.shape[0]
+        # P*(C*s + idx) + P*g*C*4*2 (read-modify-write of the fp32 gradient map)
+        with _timed("gather_nearest_bwd", P * (C * gout.element_size() + 8) + P * C * 4 * 2):
+            check(lib.dva_gather_nearest_bwd(ptr(gout), ptr(packed), ptr(gx), P, B, H, W,
+                                             C, dtype_code(gout), stream_of(gout)),
+                  "dva_gather_nearest_bwd")
         return gx.permute(0, 3, 1, 2).to(dt), None
 
 
