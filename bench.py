@@ -73,7 +73,7 @@ def build_modules(C, device):
     return BimodalCSRPool(mode='max'), view_pool, BimodalFusion(mode='concatenation')
 
 
-def step(scene, packed, mods, dtype):
+def step(scene, packed, mods, dtype, lazy=True):
     """One fused forward + backward of the hot path. Returns the scalar loss (device)."""
     from deepviewagg_amd import ops
     atomic_pool, view_pool, fusion = mods
@@ -81,12 +81,16 @@ def step(scene, packed, mods, dtype):
     x.grad = None
     for p in view_pool.parameters():
         p.grad = None
+    # mapping -> packed 8-byte gather index (image.py:1871-1885 + downscale), rebuilt every step
+    packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
-        x_mod = ops.gather_nearest(x, packed)                                  # [P, C]
-        if x_mod.shape[0] != scene["x_map"].shape[0]:
-            # P > V only for non-exact mappings; with one pixel per view (exact=True, every shipped
-            # data config) the atomic max-pool is the identity and is skipped
-            x_mod = atomic_pool(None, x_mod, None, scene["atom_ptr"])         # [V, C]
+        # nearest gather, lazy: the packed index is flattened to rows + per-row view counts (both are
+        # functions of the mapping only, but rebuilt every step like the reference's
+        # feature_map_indexing), E_mod then runs on the map rows and the gather is fused into the
+        # attention kernel (DESIGN.md "E_mod hoisting")
+        exact = scene["pixels"].shape[0] == scene["x_map"].shape[0]
+        x_mod = ops.lazy_gather_nearest(x, packed, exact=exact) if lazy else ops.gather_nearest(x, packed)
+        x_mod = atomic_pool(None, x_mod, None, scene["atom_ptr"])             # identity for exact mappings
         x_pool = view_pool(scene["x_3d"], x_mod, scene["x_map"], scene["csr"])  # [N, C]
         out = fusion(scene["x_3d"], x_pool.to(scene["x_3d"].dtype))           # [N, 4 + C]
     loss = out.float().square().mean()
@@ -162,8 +166,7 @@ def main():
     scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank)
     mods = build_modules(C, device)
     params = list(mods[1].parameters())
-    # the packed gather index is part of the mapping (built once per mapping, reused every step)
-    packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
+    packed = None  # built inside every step
 
     def barrier():
         torch.cuda.synchronize()

@@ -84,6 +84,13 @@ SIGNATURES = {
     "dva_view_attention_bwd": (ctypes.c_int,
                                [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                 _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_gather_row_index": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dva_view_gather_attention_fwd": (ctypes.c_int,
+                                      [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                       _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "dva_view_gather_attention_bwd": (ctypes.c_int,
+                                      [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dva_lex_workspace_bytes": (ctypes.c_int64, [_i64]),
     "dva_argsort_i64": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dva_argunique_i64": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(const float* __restrict
 // one thread per (point, channel)
 template <typename T>
 __global__ __launch_bounds__(256) void att_wsum_kernel(const T* __restrict__ val,
+                                                        const int32_t* __restrict__ row_idx,
                                                         const float* __restrict__ att,
                                                         const float* __restrict__ gate,
                                                         const int64_t* __restrict__ ptr,
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(256) void att_wsum_kernel(const T* __restrict__ val
     const int g = group_of_channel(c, C, G);
     const int64_t beg = ptr[p], end = ptr[p + 1];
     float acc = 0.f;
-    for (int64_t r = beg; r < end; ++r) acc = fmaf(att[r * G + g], Elt<T>::ld(val, r * C + c), acc);
+    for (int64_t r = beg; r < end; ++r) {
+      const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;
+      acc = fmaf(att[r * G + g], Elt<T>::ld(val, vr * C + c), acc);
+    }
     if (gate) acc *= gate[p * G + g];
     Elt<T>::st(out, t, acc);
   }
@@ -91,7 +95,8 @@ __global__ __launch_bounds__(256) void att_wsum_kernel(const T* __restrict__ val
 // gcompat), softmax backward, gating backward
 template <typename T>
 __global__ __launch_bounds__(256) void att_bwd_scores_kernel(
-    const T* __restrict__ gout, const T* __restrict__ val, const float* __restrict__ compat,
+    const T* __restrict__ gout, const T* __restrict__ val, const int32_t* __restrict__ row_idx,
+    const float* __restrict__ compat,
     const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
     const int64_t* __restrict__ ptr, const float* __restrict__ gw, float* __restrict__ gcompat,
     float* __restrict__ gwb, int64_t N, int C, int G, int scaling) {
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(256) void att_bwd_scores_kernel(
     float sum_ad = 0.f;
     for (int64_t r = beg; r < end; ++r) {
       float d = 0.f;
-      for (int c = c0; c < c1; ++c) d += Elt<T>::ld(gout, p * C + c) * Elt<T>::ld(val, r * C + c);
+      const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;
+      for (int c = c0; c < c1; ++c) d += Elt<T>::ld(gout, p * C + c) * Elt<T>::ld(val, vr * C + c);
       gcompat[r * G + g] = d;
       sum_ad += att[r * G + g] * d;
     }
@@ -141,6 +147,8 @@ __global__ __launch_bounds__(256) void att_bwd_scores_kernel(
 // backward, one thread per (point, channel): grad_val[v,c] = go[p,c]*gate[p,g]*att[v,g]
 template <typename T>
 __global__ __launch_bounds__(256) void att_bwd_val_kernel(const T* __restrict__ gout,
+                                                           const int32_t* __restrict__ row_idx,
+                                                           float* __restrict__ grows,
                                                            const float* __restrict__ att,
                                                            const float* __restrict__ gate,
                                                            const int64_t* __restrict__ ptr,
@@ -155,7 +163,12 @@ __global__ __launch_bounds__(256) void att_bwd_val_kernel(const T* __restrict__ 
     const int64_t beg = ptr[p], end = ptr[p + 1];
     float go = Elt<T>::ld(gout, t);
     if (gate) go *= gate[p * G + g];
-    for (int64_t r = beg; r < end; ++r) Elt<T>::st(gval, r * C + c, go * att[r * G + g]);
+    for (int64_t r = beg; r < end; ++r) {
+      if (row_idx)
+        atomicAdd(&grows[(int64_t)row_idx[r] * C + c], go * att[r * G + g]);
+      else
+        Elt<T>::st(gval, r * C + c, go * att[r * G + g]);
+    }
   }
 }
 
@@ -205,7 +218,8 @@ struct TeamGeom {
 // C % G == 0, (C/G) % VEC == 0, G <= ts, G power of two.
 template <typename T>
 __global__ __launch_bounds__(256) void att_fwd_team_kernel(
-    const T* __restrict__ val, const float* __restrict__ compat, const int64_t* __restrict__ ptr,
+    const T* __restrict__ val, const int32_t* __restrict__ row_idx, const float* __restrict__ compat,
+    const int64_t* __restrict__ ptr,
     const float* __restrict__ gw, const float* __restrict__ gb, T* __restrict__ out,
     float* __restrict__ att, float* __restrict__ gate, int32_t* __restrict__ amax, int64_t N, int C,
     int G, int scaling, float eps, TeamGeom tg) {
@@ -273,7 +287,8 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 #pragma unroll 2
     for (int v = row_slot; v < n; v += tg.rows) {
       const int64_t r = beg + v;
-      const raw_t x = *reinterpret_cast<const raw_t*>(val + r * C + col);
+      const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;  // fused view gather: row of the value map
+      const raw_t x = *reinterpret_cast<const raw_t*>(val + vr * C + col);
       const float a = expf((compat[r * G + g_lane] - m_l) / dn) / s_l;
       if (g_first) att[r * G + g_lane] = a;
       float f[VEC];
@@ -297,7 +312,8 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 // (v,g) slot is written and re-read by the same lane).
 template <typename T>
 __global__ __launch_bounds__(256) void att_bwd_team_kernel(
-    const T* __restrict__ gout, const T* __restrict__ val, const float* __restrict__ compat,
+    const T* __restrict__ gout, const T* __restrict__ val, const int32_t* __restrict__ row_idx,
+    float* __restrict__ grows, const float* __restrict__ compat,
     const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
     const int64_t* __restrict__ ptr, const float* __restrict__ gw, T* __restrict__ gval,
     float* __restrict__ gcompat, float* __restrict__ gwb, int64_t N, int C, int G, int scaling,
@@ -333,8 +349,9 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
 #pragma unroll 2
     for (int v = row_slot; v < n; v += tg.rows) {
       const int64_t r = beg + v;
+      const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;
       float f[VEC];
-      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + r * C + col), f);
+      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + vr * C + col), f);
       float d = 0.f;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
@@ -379,7 +396,14 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
       float f[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) f[k] = go[k] * a;
-      *reinterpret_cast<raw_t*>(gval + r * C + col) = Vec16<T>::pack(f);
+      if (row_idx) {
+        // scatter-add into the fp32 gradient of the value map (many views share a pixel)
+        float* dst = grows + (int64_t)row_idx[r] * C + col;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) atomicAdd(dst + k, f[k]);
+      } else {
+        *reinterpret_cast<raw_t*>(gval + r * C + col) = Vec16<T>::pack(f);
+      }
     }
   }
   __syncthreads();
@@ -419,7 +443,8 @@ static inline int grid_cap(int64_t blocks) {
 }
 
 template <typename T>
-static int fwd_impl(const void* val, const float* compat, const int64_t* ptr, const float* gw,
+static int fwd_impl(const void* val, const int32_t* row_idx, const float* compat, const int64_t* ptr,
+                    const float* gw,
                     const float* gb, void* out, float* att, float* gate, int32_t* amax, int64_t N,
                     int64_t V_hint, int C, int G, int scaling, float eps, int algo, hipStream_t s) {
   TeamGeom tg;
@@ -428,19 +453,20 @@ static int fwd_impl(const void* val, const float* compat, const int64_t* ptr, co
   if (algo != 1 && team_ok) {
     const int tpb = 256 / tg.ts;
     const int grid = grid_cap((N + tpb - 1) / tpb);
-    hipLaunchKernelGGL((att_fwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)val, compat,
-                       ptr, gw, gb, (T*)out, att, gate, amax, N, C, G, scaling, eps, tg);
+    hipLaunchKernelGGL((att_fwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)val, row_idx,
+                       compat, ptr, gw, gb, (T*)out, att, gate, amax, N, C, G, scaling, eps, tg);
     return DVA_OK;
   }
   hipLaunchKernelGGL(att_scores_kernel, dim3(grid_cap((N * G + 255) / 256)), dim3(256), 0, s, compat,
                      ptr, gw, gb, att, gate, amax, N, G, scaling, eps);
   hipLaunchKernelGGL((att_wsum_kernel<T>), dim3(grid_cap((N * C + 255) / 256)), dim3(256), 0, s,
-                     (const T*)val, att, gw ? gate : nullptr, ptr, (T*)out, N, C, G);
+                     (const T*)val, row_idx, att, gw ? gate : nullptr, ptr, (T*)out, N, C, G);
   return DVA_OK;
 }
 
 template <typename T>
-static int bwd_impl(const void* gout, const void* val, const float* compat, const float* att,
+static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, float* grows,
+                    const float* compat, const float* att,
                     const float* gate, const int32_t* amax, const int64_t* ptr, const float* gw,
                     void* gval, float* gcompat, float* gwb, int64_t N, int64_t V_hint, int C, int G,
                     int scaling, int algo, hipStream_t s) {
@@ -451,15 +477,15 @@ static int bwd_impl(const void* gout, const void* val, const float* compat, cons
     const int tpb = 256 / tg.ts;
     const int grid = grid_cap((N + tpb - 1) / tpb);
     hipLaunchKernelGGL((att_bwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)gout,
-                       (const T*)val, compat, att, gw ? gate : nullptr, amax, ptr, gw, (T*)gval,
-                       gcompat, gwb, N, C, G, scaling, tg);
+                       (const T*)val, row_idx, grows, compat, att, gw ? gate : nullptr, amax, ptr, gw,
+                       (T*)gval, gcompat, gwb, N, C, G, scaling, tg);
     return DVA_OK;
   }
   hipLaunchKernelGGL((att_bwd_scores_kernel<T>), dim3(grid_cap((N * G + 255) / 256)), dim3(256),
-                     2 * G * sizeof(float), s, (const T*)gout, (const T*)val, compat, att,
+                     2 * G * sizeof(float), s, (const T*)gout, (const T*)val, row_idx, compat, att,
                      gw ? gate : nullptr, amax, ptr, gw, gcompat, gwb, N, C, G, scaling);
   hipLaunchKernelGGL((att_bwd_val_kernel<T>), dim3(grid_cap((N * C + 255) / 256)), dim3(256), 0, s,
-                     (const T*)gout, att, gw ? gate : nullptr, ptr, (T*)gval, N, C, G);
+                     (const T*)gout, row_idx, grows, att, gw ? gate : nullptr, ptr, (T*)gval, N, C, G);
   return DVA_OK;
 }
 
@@ -469,11 +495,11 @@ using namespace dva;
 
 extern "C" {
 
-int dva_view_attention_fwd(const void* val, const float* compat, const int64_t* ptr,
-                           const float* gate_w, const float* gate_b, void* out, float* att,
-                           float* gate, int32_t* amax, int64_t n_points, int64_t n_views, int32_t C,
-                           int32_t G, int32_t scaling, float eps, int32_t dtype, int32_t algo,
-                           void* stream) {
+static int attention_fwd_entry(const void* val, const int32_t* row_idx, const float* compat,
+                               const int64_t* ptr, const float* gate_w, const float* gate_b, void* out,
+                               float* att, float* gate, int32_t* amax, int64_t n_points,
+                               int64_t n_views, int32_t C, int32_t G, int32_t scaling, float eps,
+                               int32_t dtype, int32_t algo, void* stream) {
   if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
   if ((gate_w == nullptr) != (gate_b == nullptr)) return DVA_ERR_INVALID;
   if (!out || !att || !gate || !amax) return DVA_ERR_INVALID;
@@ -481,16 +507,55 @@ int dva_view_attention_fwd(const void* val, const float* compat, const int64_t* 
   if (n_points == 0) return DVA_OK;
   int rc;
   if (dtype == DVA_F32)
-    rc = fwd_impl<float>(val, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points, n_views,
-                         C, G, scaling, eps, algo, (hipStream_t)stream);
+    rc = fwd_impl<float>(val, row_idx, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points,
+                         n_views, C, G, scaling, eps, algo, (hipStream_t)stream);
   else if (dtype == DVA_BF16)
-    rc = fwd_impl<bf16_t>(val, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points, n_views,
-                          C, G, scaling, eps, algo, (hipStream_t)stream);
+    rc = fwd_impl<bf16_t>(val, row_idx, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points,
+                          n_views, C, G, scaling, eps, algo, (hipStream_t)stream);
   else
     return DVA_ERR_INVALID;
   if (rc) return rc;
   DVA_CHECK_LAUNCH();
   return DVA_OK;
+}
+
+static int attention_bwd_entry(const void* grad_out, const void* val, const int32_t* row_idx,
+                               float* grad_rows, const float* compat, const float* att,
+                               const float* gate, const int32_t* amax, const int64_t* ptr,
+                               const float* gate_w, const float* gate_b, void* grad_val,
+                               float* grad_compat, float* grad_gate_wb, int64_t n_points,
+                               int64_t n_views, int32_t C, int32_t G, int32_t scaling, int32_t dtype,
+                               int32_t algo, void* stream) {
+  (void)gate_b;
+  if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
+  if (!att || !gate || !amax || !grad_compat) return DVA_ERR_INVALID;
+  if (row_idx ? !grad_rows : !grad_val) return DVA_ERR_INVALID;
+  if (gate_w && !grad_gate_wb) return DVA_ERR_INVALID;
+  if (algo < 0 || algo > 2) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  int rc;
+  if (dtype == DVA_F32)
+    rc = bwd_impl<float>(grad_out, val, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
+                         grad_val, grad_compat, grad_gate_wb, n_points, n_views, C, G, scaling, algo,
+                         (hipStream_t)stream);
+  else if (dtype == DVA_BF16)
+    rc = bwd_impl<bf16_t>(grad_out, val, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
+                          grad_val, grad_compat, grad_gate_wb, n_points, n_views, C, G, scaling, algo,
+                          (hipStream_t)stream);
+  else
+    return DVA_ERR_INVALID;
+  if (rc) return rc;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_view_attention_fwd(const void* val, const float* compat, const int64_t* ptr,
+                           const float* gate_w, const float* gate_b, void* out, float* att,
+                           float* gate, int32_t* amax, int64_t n_points, int64_t n_views, int32_t C,
+                           int32_t G, int32_t scaling, float eps, int32_t dtype, int32_t algo,
+                           void* stream) {
+  return attention_fwd_entry(val, nullptr, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points,
+                             n_views, C, G, scaling, eps, dtype, algo, stream);
 }
 
 int dva_view_attention_bwd(const void* grad_out, const void* val, const float* compat,
@@ -499,25 +564,33 @@ int dva_view_attention_bwd(const void* grad_out, const void* val, const float* c
                            void* grad_val, float* grad_compat, float* grad_gate_wb,
                            int64_t n_points, int64_t n_views, int32_t C, int32_t G, int32_t scaling,
                            int32_t dtype, int32_t algo, void* stream) {
-  (void)gate_b;
-  if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
-  if (!att || !gate || !amax || !grad_val || !grad_compat) return DVA_ERR_INVALID;
-  if (gate_w && !grad_gate_wb) return DVA_ERR_INVALID;
-  if (algo < 0 || algo > 2) return DVA_ERR_INVALID;
-  if (n_points == 0) return DVA_OK;
-  int rc;
-  if (dtype == DVA_F32)
-    rc = bwd_impl<float>(grad_out, val, compat, att, gate, amax, ptr, gate_w, grad_val, grad_compat,
-                         grad_gate_wb, n_points, n_views, C, G, scaling, algo, (hipStream_t)stream);
-  else if (dtype == DVA_BF16)
-    rc = bwd_impl<bf16_t>(grad_out, val, compat, att, gate, amax, ptr, gate_w, grad_val,
-                          grad_compat, grad_gate_wb, n_points, n_views, C, G, scaling, algo,
-                          (hipStream_t)stream);
-  else
-    return DVA_ERR_INVALID;
-  if (rc) return rc;
-  DVA_CHECK_LAUNCH();
-  return DVA_OK;
+  return attention_bwd_entry(grad_out, val, nullptr, nullptr, compat, att, gate, amax, ptr, gate_w,
+                             gate_b, grad_val, grad_compat, grad_gate_wb, n_points, n_views, C, G,
+                             scaling, dtype, algo, stream);
+}
+
+int dva_view_gather_attention_fwd(const void* rows, const int32_t* row_idx, const float* compat,
+                                  const int64_t* ptr, const float* gate_w, const float* gate_b,
+                                  void* out, float* att, float* gate, int32_t* amax,
+                                  int64_t n_points, int64_t n_views, int32_t C, int32_t G,
+                                  int32_t scaling, float eps, int32_t dtype, int32_t algo,
+                                  void* stream) {
+  if (!row_idx && n_views > 0) return DVA_ERR_INVALID;
+  return attention_fwd_entry(rows, row_idx, compat, ptr, gate_w, gate_b, out, att, gate, amax, n_points,
+                             n_views, C, G, scaling, eps, dtype, algo, stream);
+}
+
+int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const int32_t* row_idx,
+                                  const float* compat, const float* att, const float* gate,
+                                  const int32_t* amax, const int64_t* ptr, const float* gate_w,
+                                  const float* gate_b, float* grad_rows, float* grad_compat,
+                                  float* grad_gate_wb, int64_t n_points, int64_t n_views, int32_t C,
+                                  int32_t G, int32_t scaling, int32_t dtype, int32_t algo,
+                                  void* stream) {
+  if ((!row_idx || !grad_rows) && n_views > 0) return DVA_ERR_INVALID;
+  return attention_bwd_entry(grad_out, rows, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
+                             gate_b, nullptr, grad_compat, grad_gate_wb, n_points, n_views, C, G,
+                             scaling, dtype, algo, stream);
 }
 
 }  // extern "C"

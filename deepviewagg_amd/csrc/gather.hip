@@ -52,6 +52,23 @@ __global__ __launch_bounds__(256) void pack_index_kernel(const int64_t* __restri
   }
 }
 
+// Flat row index (img*H + y)*W + x of every atom into the [B*H*W, C] view of a channels-last map,
+// plus (optionally) the number of atoms that land on every row: the weights with which per-view
+// batch statistics can be evaluated at feature-map level (DESIGN.md "E_mod hoisting").
+__global__ __launch_bounds__(256) void row_index_kernel(const PackedIdx* __restrict__ idx,
+                                                         int64_t n_atoms, int H, int W,
+                                                         int32_t row_offset,
+                                                         int32_t* __restrict__ row_idx,
+                                                         int32_t* __restrict__ counts) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_atoms;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const PackedIdx pi = idx[p];
+    const int32_t r = (pi.img * H + pi.y) * W + pi.x;
+    row_idx[p] = r + row_offset;
+    if (counts) atomicAdd(&counts[r], 1);
+  }
+}
+
 // Nearest gather: pure byte movement in UNIT-byte units (16, 4 or 2).
 template <typename UNIT>
 __global__ __launch_bounds__(256) void gather_nearest_fwd_kernel(const UNIT* __restrict__ x,
@@ -189,6 +206,18 @@ int dva_pack_gather_index(const int64_t* images, const int64_t* atom_ptr, const 
     default:
       return DVA_ERR_INVALID;
   }
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_row_index(const void* packed_idx, int64_t n_atoms, int32_t B, int32_t H, int32_t W,
+                         int32_t row_offset, int32_t* row_idx, int32_t* counts, void* stream) {
+  if (n_atoms < 0 || B < 0 || H < 0 || W < 0) return DVA_ERR_INVALID;
+  if ((int64_t)B * H * W + row_offset > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_atoms == 0) return DVA_OK;
+  if (!packed_idx || !row_idx) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(row_index_kernel, dim3(grid_for(n_atoms)), dim3(256), 0, (hipStream_t)stream,
+                     (const PackedIdx*)packed_idx, n_atoms, H, W, row_offset, row_idx, counts);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -34,6 +34,46 @@ def _dense_index(csr_idx, device):
     return torch.arange(csr_idx.shape[0] - 1, device=device).repeat_interleave(sizes), sizes
 
 
+def _materialize(x_mod):
+    return x_mod.materialize() if isinstance(x_mod, ops.GatheredFeatures) else x_mod
+
+
+def mlp_on_gathered_rows(mlp, rows, counts):
+    """Evaluate ``mlp(rows[row_idx])`` WITHOUT gathering: returns ``out_rows`` such that
+    ``out_rows[row_idx] == mlp(rows[row_idx])`` row for row.
+
+    ``mlp`` is a Sequential of [Linear, FastBatchNorm1d, activation] blocks (MLP()).  Linear and the
+    activation act on each row independently, and the train-mode BatchNorm statistics over the P
+    gathered rows equal the statistics over the R map rows weighted by ``counts`` (how many atoms
+    gather each row).  P/R is ~128 on the headline workload, so the dense layers cost 1/128 of the
+    per-view evaluation of the reference (pooling.py:245,275) and no [P, C] tensor is materialised.
+    Backward is plain autograd over the [R, C] tensors.
+    """
+    w = counts.to(torch.float32).unsqueeze(1)
+    n = w.sum()
+    x = rows
+    for block in mlp:
+        lin, bn, act = block[0], block[1].batch_norm, block[2]
+        y = lin(x)
+        yf = y.float()
+        if bn.training or not bn.track_running_stats:
+            mean = (w * yf).sum(0) / n
+            var = (w * (yf - mean) ** 2).sum(0) / n
+            if bn.training and bn.track_running_stats:
+                with torch.no_grad():
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - m).add_(m * mean)
+                    bn.running_var.mul_(1 - m).add_(m * var * n / (n - 1))
+                    bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        z = (yf - mean) * torch.rsqrt(var + bn.eps)
+        if bn.affine:
+            z = z * bn.weight + bn.bias
+        x = act(z.to(y.dtype))
+    return x
+
+
 class _SaveLast:
     """Shared bookkeeping of the optional ``save_last`` debugging outputs."""
 
@@ -46,7 +86,7 @@ class _SaveLast:
         if not self.save_last:
             return
         self._last_x_map = x_map
-        self._last_x_mod = x_mod
+        self._last_x_mod = _materialize(x_mod)
         self._last_idx, self._last_view_num = _dense_index(csr_idx, x_mod.device)
         for k, v in extra.items():
             setattr(self, f'_last_{k}', v)
@@ -68,6 +108,13 @@ class BimodalCSRPool(nn.Module, _SaveLast):
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map] (unused), csr_idx [N+1]."""
+        if isinstance(x_mod, ops.GatheredFeatures):
+            if x_mod.exact and csr_idx.shape[0] - 1 == x_mod.shape[0]:
+                # atomic pooling of an exact mapping (one pixel per view): every group holds exactly
+                # one row, so max / min / mean / sum are all the identity -> stay lazy
+                self._save(x_map, x_mod, csr_idx)
+                return x_mod
+            x_mod = x_mod.materialize()
         x_pool = segment_csr(x_mod, csr_idx, reduce=self._mode)
         self._save(x_map, x_mod, csr_idx)
         return x_pool
@@ -96,6 +143,7 @@ class HeuristicBimodalCSRPool(nn.Module, _SaveLast):
         self._init_save_last(save_last)
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
+        x_mod = _materialize(x_mod)
         # arg of the per-group extremum of the heuristic feature (first row on ties, -1 if unseen)
         _, arg_idx = ops.segment_csr_arg(x_map[:, self._feat].float(), csr_idx, reduce=self._mode)
         arg_idx = arg_idx.reshape(-1).long()
@@ -140,11 +188,13 @@ class Gating(nn.Module):
 def _pool_with_attention(module, x_mod, compatibilities, csr_idx):
     """softmax -> attention-weighted sum -> gating, one fused kernel (pooling.py:284-300)."""
     G = module.G
-    x_pool, attentions, gating = ops.view_attention(
-        x_mod, compatibilities, csr_idx,
-        gate_w=G.weight if G is not None else None,
-        gate_b=G.bias if G is not None else None,
-        scaling=module.group_scaling)
+    kw = dict(gate_w=G.weight if G is not None else None, gate_b=G.bias if G is not None else None,
+              scaling=module.group_scaling)
+    if isinstance(x_mod, ops.GatheredFeatures):
+        x_pool, attentions, gating = ops.view_gather_attention(
+            x_mod.rows, x_mod.row_idx, compatibilities, csr_idx, **kw)
+    else:
+        x_pool, attentions, gating = ops.view_attention(x_mod, compatibilities, csr_idx, **kw)
     if G is not None and module.num_groups == 1:
         gating = gating.squeeze(1)
     return x_pool, attentions, (gating if G is not None else None)
@@ -192,11 +242,18 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
         x_map = self.E_map(x_map, csr_idx)
-        x_mod = self.E_mod(x_mod)
-        if self.use_mod:
-            compatibilities = self.E_score(self.E_mix(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
-        else:
+        if isinstance(x_mod, ops.GatheredFeatures) and not self.use_mod:
+            # lazy nearest gather: E_mod runs on the map rows, the gather is fused into the
+            # attention kernel (no [V, C] tensor exists on this path)
+            val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts)
             compatibilities = self.E_score(x_map)
+            x_mod = ops.GatheredFeatures(val_rows, x_mod.row_idx, x_mod.counts, x_mod.exact)
+        else:
+            x_mod = self.E_mod(_materialize(x_mod))
+            if self.use_mod:
+                compatibilities = self.E_score(self.E_mix(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
+            else:
+                compatibilities = self.E_score(x_map)
         x_pool, attentions, gating = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
         self._save(x_map, x_mod, csr_idx, C=compatibilities, A=attentions,
                    **({'G': gating} if self.G is not None else {}))
@@ -253,6 +310,7 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
         if self.debug:
+            x_mod = _materialize(x_mod)
             device = x_map.device
             x_map = torch.rand((x_map.shape[0], 1), device=device)
             idx_destroyed = torch.where(x_map < 0.3)[0]
@@ -262,7 +320,11 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
         n_views = x_mod.shape[0]
         x_main = self.E_main(x_main)
         x_map = self.E_map(x_map, csr_idx)
-        x_mod = self.E_mod(x_mod)
+        if isinstance(x_mod, ops.GatheredFeatures) and not (self.use_mod_k or self.use_mod_q or self.debug):
+            x_mod = ops.GatheredFeatures(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts),
+                                         x_mod.row_idx, x_mod.counts, x_mod.exact)
+        else:
+            x_mod = self.E_mod(_materialize(x_mod))
 
         if self.use_mod_k:
             keys = self.K(self.E_mix_K(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))

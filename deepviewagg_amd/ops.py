@@ -421,3 +421,164 @@ def gather_bilinear(x, packed_idx, coords):
     assert x.dim() == 4
     assert coords.dim() == 2 and coords.shape[1] == 2
     return _GatherBilinear.apply(x, packed_idx, coords)
+
+
+# ---------------------------------------------------------------------------------------------
+# lazy view gather + fused gather-attention  (DESIGN.md "E_mod hoisting")
+# ---------------------------------------------------------------------------------------------
+
+def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True):
+    """Flat row index of every atom into the [B*H*W, C] view of a channels-last map, and the number
+    of atoms per row (int32 [B*H*W]) if ``with_counts``."""
+    lib = _lib.load()
+    require_device(packed_idx)
+    P = packed_idx.shape[0]
+    row_idx = torch.empty(P, dtype=torch.int32, device=packed_idx.device)
+    counts = torch.zeros(B * H * W, dtype=torch.int32, device=packed_idx.device) if with_counts else None
+    with _timed("gather_row_index", P * 12):
+        check(lib.dva_gather_row_index(ptr(packed_idx), P, B, H, W, int(row_offset), ptr(row_idx),
+                                       ptr(counts), stream_of(packed_idx)), "dva_gather_row_index")
+    return row_idx, counts
+
+
+class GatheredFeatures:
+    """Result of a NEAREST view gather that has not been materialised: ``x_mod[p] = rows[row_idx[p]]``.
+
+    ``rows`` is the [R, C] row view of the channels-last feature map(s) (a differentiable function of
+    the 2D encoder output), ``row_idx`` int32 [P], ``counts`` int32 [R] = atoms per row.  Row-wise
+    modules (Linear / BatchNorm / activation) commute with the gather, so consumers that understand
+    this type apply them to ``rows`` (R << P) and hand ``row_idx`` to the fused gather-attention
+    kernel; everything else calls ``materialize()`` and gets the reference's [P, C] tensor.
+    ``exact`` tells that every view owns exactly one atom (P == V): the atomic pool is the identity.
+    """
+
+    def __init__(self, rows, row_idx, counts, exact):
+        self.rows, self.row_idx, self.counts, self.exact = rows, row_idx, counts, exact
+
+    @property
+    def shape(self):
+        return torch.Size((self.row_idx.shape[0], self.rows.shape[1]))
+
+    @property
+    def device(self):
+        return self.rows.device
+
+    @property
+    def dtype(self):
+        return self.rows.dtype
+
+    def dim(self):
+        return 2
+
+    def materialize(self):
+        return gather_rows(self.rows, self.row_idx)
+
+    @staticmethod
+    def cat(items, order=None):
+        """Concatenate lazily gathered features of several settings (rows are stacked, indices
+        offset) and optionally permute the atoms (UnimodalBranch view_cat_sorting)."""
+        offs, rows, idx, cnt = 0, [], [], []
+        for it in items:
+            rows.append(it.rows)
+            idx.append(it.row_idx + offs)
+            cnt.append(it.counts)
+            offs += it.rows.shape[0]
+        row_idx = torch.cat(idx)
+        if order is not None:
+            row_idx = row_idx[order]
+        return GatheredFeatures(torch.cat(rows, dim=0), row_idx.contiguous(), torch.cat(cnt),
+                                all(it.exact for it in items))
+
+
+def lazy_gather_nearest(x, packed_idx, exact):
+    """Lazy counterpart of ``gather_nearest``: no [P, C] tensor is produced."""
+    assert x.dim() == 4
+    B, C, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
+    row_idx, counts = gather_row_index(packed_idx, B, H, W)
+    return GatheredFeatures(rows, row_idx, counts, exact)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, row_idx):
+        ctx.save_for_backward(row_idx)
+        ctx.n_rows = rows.shape[0]
+        return rows.index_select(0, row_idx.long())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (row_idx,) = ctx.saved_tensors
+        g = torch.zeros((ctx.n_rows, gout.shape[1]), dtype=torch.float32, device=gout.device)
+        g.index_add_(0, row_idx.long(), gout.float())
+        return g.to(gout.dtype), None
+
+
+def gather_rows(rows, row_idx):
+    """Materialise ``rows[row_idx]`` (device library op; only used off the fused path)."""
+    require_device(rows, row_idx)
+    return _GatherRows.apply(rows, row_idx)
+
+
+class _ViewGatherAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, row_idx, compat, csr_idx, gate_w, gate_b, scaling, eps):
+        lib = _lib.load()
+        require_device(rows, row_idx, compat, csr_idx, gate_w, gate_b)
+        rows = rows.contiguous()
+        compat = compat.contiguous()
+        N, V, (R, C), G = csr_idx.shape[0] - 1, row_idx.shape[0], rows.shape, compat.shape[1]
+        gw = gate_w.detach().reshape(-1).float().contiguous() if gate_w is not None else None
+        gb = gate_b.detach().reshape(-1).float().contiguous() if gate_b is not None else None
+        if (gw is None) != (gb is None):
+            gw = gw if gw is not None else torch.ones(G, device=rows.device)
+            gb = gb if gb is not None else torch.zeros(G, device=rows.device)
+        out = torch.empty((N, C), dtype=rows.dtype, device=rows.device)
+        att = torch.zeros((V, G), dtype=torch.float32, device=rows.device)
+        gate = torch.empty((N, G), dtype=torch.float32, device=rows.device)
+        amax = torch.empty((N, G), dtype=torch.int32, device=rows.device)
+        es = rows.element_size()
+        # SURVEY.md 8(d) "fused view-gather+attention": V*(g*C*s + idx) + scores + N*(C*s + ptr)
+        with _timed("view_gather_attention_fwd", V * (C * es + 4 + 2 * G * 4) + N * (C * es + 8 + 2 * G * 4)):
+            check(lib.dva_view_gather_attention_fwd(
+                ptr(rows), ptr(row_idx), ptr(compat), ptr(csr_idx), ptr(gw), ptr(gb), ptr(out), ptr(att),
+                ptr(gate), ptr(amax), N, V, C, G, int(scaling), float(eps), dtype_code(rows),
+                ATTENTION_ALGO, stream_of(rows)), "dva_view_gather_attention_fwd")
+        ctx.save_for_backward(rows, row_idx, compat, csr_idx, att, gate, amax,
+                              gw if gw is not None else csr_idx, gb if gb is not None else csr_idx)
+        ctx.meta = (int(scaling), gw is not None,
+                    None if gate_w is None else gate_w.shape, None if gate_b is None else gate_b.shape)
+        ctx.mark_non_differentiable(att, gate)
+        return out, att, gate
+
+    @staticmethod
+    def backward(ctx, gout, _gatt, _ggate):
+        lib = _lib.load()
+        rows, row_idx, compat, csr_idx, att, gate, amax, gw, gb = ctx.saved_tensors
+        scaling, has_gate, w_shape, b_shape = ctx.meta
+        gout = gout.contiguous()
+        N, V, (R, C), G = csr_idx.shape[0] - 1, row_idx.shape[0], rows.shape, compat.shape[1]
+        grows = torch.zeros((R, C), dtype=torch.float32, device=rows.device)
+        gcompat = torch.zeros_like(compat)
+        gwb = torch.zeros(2 * G, dtype=torch.float32, device=rows.device) if has_gate else None
+        es = rows.element_size()
+        with _timed("view_gather_attention_bwd",
+                    V * (C * es + 4 + 2 * G * 4 + C * 4 * 2) + N * (C * es + 8 + 3 * G * 4)):
+            check(lib.dva_view_gather_attention_bwd(
+                ptr(gout), ptr(rows), ptr(row_idx), ptr(compat), ptr(att), ptr(gate), ptr(amax),
+                ptr(csr_idx), ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(grows),
+                ptr(gcompat), ptr(gwb), N, V, C, G, scaling, dtype_code(rows), ATTENTION_ALGO,
+                stream_of(rows)), "dva_view_gather_attention_bwd")
+        g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
+        g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
+        return grows.to(rows.dtype), None, gcompat, None, g_w, g_b, None, None
+
+
+def view_gather_attention(rows, row_idx, compat, csr_idx, gate_w=None, gate_b=None, scaling=False,
+                          eps=1e-12):
+    """``view_attention`` with the view gather fused in: the value of view v is ``rows[row_idx[v]]``."""
+    csr_idx = _check_ptr(csr_idx)
+    if compat.dim() == 1:
+        compat = compat.reshape(-1, 1)
+    return _ViewGatherAttention.apply(rows, row_idx.contiguous(), compat.float(), csr_idx, gate_w, gate_b,
+                                      scaling, eps)

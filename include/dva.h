@@ -97,6 +97,11 @@ int dva_pack_gather_index(const int64_t* images, const int64_t* atom_ptr, const 
                           int32_t pix_bytes, double ratio, int64_t n_views, int64_t n_atoms,
                           void* packed_idx /* int64[P] */, void* stream);
 
+/* row_idx[p] = row_offset + (img*H + y)*W + x : the atom's row in the [B*H*W, C] view of the map
+ * (image.py:1871-1885 flattened).  counts (nullable, caller-zeroed int32[B*H*W]) += 1 per atom. */
+int dva_gather_row_index(const void* packed_idx, int64_t n_atoms, int32_t B, int32_t H, int32_t W,
+                         int32_t row_offset, int32_t* row_idx, int32_t* counts, void* stream);
+
 /* out[p, :] = x[img, y, x, :] */
 int dva_gather_nearest_fwd(const void* x, const void* packed_idx, void* out, int64_t n_atoms,
                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
@@ -145,6 +150,24 @@ int dva_view_attention_bwd(const void* grad_out, const void* val, const float* c
                            void* grad_val, float* grad_compat, float* grad_gate_wb,
                            int64_t n_points, int64_t n_views, int32_t C, int32_t G, int32_t scaling,
                            int32_t dtype, int32_t algo, void* stream);
+
+/* Same maths with the view gather fused in: the value of view v is rows[row_idx[v], :]
+ * (rows = [R, C] value map, e.g. E_mod applied at feature-map level; DESIGN.md "E_mod hoisting").
+ * Replaces image.py:1285 + pooling.py:284-300 in one pass: no [V, C] tensor is materialised.
+ * Backward scatter-adds into grad_rows fp32 [R, C] (caller-zeroed, atomics). */
+int dva_view_gather_attention_fwd(const void* rows, const int32_t* row_idx, const float* compat,
+                                  const int64_t* ptr, const float* gate_w, const float* gate_b,
+                                  void* out, float* att, float* gate, int32_t* amax,
+                                  int64_t n_points, int64_t n_views, int32_t C, int32_t G,
+                                  int32_t scaling, float eps, int32_t dtype, int32_t algo,
+                                  void* stream);
+int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const int32_t* row_idx,
+                                  const float* compat, const float* att, const float* gate,
+                                  const int32_t* amax, const int64_t* ptr, const float* gate_w,
+                                  const float* gate_b, float* grad_rows, float* grad_compat,
+                                  float* grad_gate_wb, int64_t n_points, int64_t n_views, int32_t C,
+                                  int32_t G, int32_t scaling, int32_t dtype, int32_t algo,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a

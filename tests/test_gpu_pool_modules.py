@@ -120,3 +120,58 @@ def test_group_pool_large_random_vs_oracle(dtype):
         # bf16 autocast: compare the dominant gradient (values) loosely
         rel = (g_dev[0].float().cpu() - g_ref[0]).norm() / g_ref[0].norm()
         assert rel < 5e-2, rel
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("cls_name", ["GroupBimodalCSRPool", "QKVBimodalCSRPool"])
+def test_lazy_gather_path_matches_oracle(cls_name, train):
+    """E_mod hoisted to feature-map level + fused gather-attention == reference maths
+    (gather -> E_mod per view -> attention), forward, input/parameter gradients, running stats."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    N, C, B, H, W = 3000, 32, 3, 12, 20
+    sizes = torch.randint(0, 7, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    images = torch.randint(0, B, (V,), generator=gen)
+    pixels = torch.stack([torch.randint(0, W, (V,), generator=gen), torch.randint(0, H, (V,), generator=gen)], 1).short()
+    x = torch.randn(B, C, H, W, generator=gen)
+    x_map = torch.rand(V, 8, generator=gen)
+    x_main = torch.randn(N, 6, generator=gen)
+    w = torch.randn(N, C, generator=gen)
+    kwargs = dict(in_map=8, in_mod=C, num_groups=4, use_num=True)
+    if cls_name.startswith("QKV"):
+        kwargs.update(in_main=6, nc_qk=4)
+    ref = getattr(O, cls_name)(**kwargs)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.4)
+    ref.train(train)
+    m = getattr(P, cls_name)(**kwargs)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.to(DEV).train(train)
+
+    xr = x.clone().requires_grad_()
+    out_ref = ref(x_main, O.gather_nearest(xr, images, pixels), x_map, csr)
+    g_ref = torch.autograd.grad((out_ref * w).sum(), [xr] + list(ref.parameters()), allow_unused=True)
+
+    xd = x.to(DEV).requires_grad_()
+    packed = ops.pack_gather_index(images.to(DEV), torch.arange(V + 1, device=DEV), pixels.to(DEV))
+    lazy = ops.lazy_gather_nearest(xd, packed, exact=True)
+    assert torch.equal(lazy.materialize().cpu(), O.gather_nearest(x, images, pixels))
+    assert int(lazy.counts.sum()) == V
+    lazy = P.BimodalCSRPool(mode='max')(None, lazy, None, torch.arange(V + 1, device=DEV))
+    assert isinstance(lazy, ops.GatheredFeatures)        # atomic pool of an exact mapping stays lazy
+    out = m(x_main.to(DEV), lazy, x_map.to(DEV), csr.to(DEV))
+    g_dev = torch.autograd.grad((out * w.to(DEV)).sum(), [xd] + list(m.parameters()), allow_unused=True)
+    close(out, out_ref, rtol=1e-3, atol=1e-4)
+    close(g_dev[0], g_ref[0], rtol=1e-3, atol=1e-4)
+    for (n, _), a, b in zip(ref.named_parameters(), g_dev[1:], g_ref[1:]):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0, n
+            continue
+        close(a, b, rtol=5e-3, atol=2e-3)
+    for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
+        if "running" in k:
+            close(a, b, rtol=1e-4, atol=1e-5)
