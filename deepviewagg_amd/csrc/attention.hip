@@ -309,7 +309,10 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 }
 
 // Backward, same geometry.  gcompat doubles as scratch for d[v,g] between the two passes (each
-// (v,g) slot is written and re-read by the same lane).
+// (v,g) slot is written and re-read by the same lane).  With row_idx (fused view gather) the value
+// gradient is scatter-added into the fp32 value map: that phase switches to a channel-per-lane
+// layout so that one atomic instruction covers whole contiguous rows (2 cache lines per 64 atomics
+// instead of 16 with the 16-byte-per-lane layout: measured 8.7x on the first version).
 template <typename T>
 __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     const T* __restrict__ gout, const T* __restrict__ val, const int32_t* __restrict__ row_idx,
@@ -330,19 +333,26 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
   const int row_slot = li / tg.lpr;
   const int g_lane = lane_r / tg.lpg;
   const bool g_first = (lane_r % tg.lpg) == 0;
+  const int teams_per_wave = 64 / tg.ts;
+  const int team_in_wave = lane / tg.ts;
 
-  const int teams_per_block = blockDim.x / tg.ts;
-  const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg.ts;
-  const int64_t team_stride = (int64_t)gridDim.x * teams_per_block;
-
-  for (int64_t p = team0; p < N; p += team_stride) {
-    const int64_t beg = ptr[p], end = ptr[p + 1];
-    const int n = (int)(end - beg);
-    if (n == 0) continue;
+  // wave-uniform outer loop: the teams of one wavefront always iterate together
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t pw = wave * teams_per_wave; pw < N; pw += n_waves * teams_per_wave) {
+    const int64_t p = pw + team_in_wave;
+    const bool valid = p < N;
+    const int64_t beg = valid ? ptr[p] : 0;
+    const int n = valid ? (int)(ptr[p + 1] - beg) : 0;
     const int64_t col = (int64_t)lane_r * VEC;
     float go[VEC];
-    Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(gout + p * C + col), go);
-    const float gt = gate ? gate[p * G + g_lane] : 1.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) go[k] = 0.f;
+    float gt = 1.f;
+    if (n > 0) {
+      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(gout + p * C + col), go);
+      if (gate) gt = gate[p * G + g_lane];
+    }
 
     // ---- pass 1: d[v,g] = sum_{c in g} go[c]*val[v,c];  sum_ad[g] = sum_v att[v,g]*d[v,g]
     float sum_ad = 0.f;
@@ -366,10 +376,10 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     // make the group total visible to every lane of the group (only g_first lanes accumulated)
     sum_ad = __shfl(sum_ad, lane - (lane_r % tg.lpg));
 
-    const float dn = scaling ? sqrtf((float)n) : 1.f;
+    const float dn = scaling ? sqrtf((float)(n > 0 ? n : 1)) : 1.f;
     float g_mx = 0.f;
-    const int64_t am = amax[p * G + g_lane];
-    if (gw) {
+    const int64_t am = n > 0 ? amax[p * G + g_lane] : -1;
+    if (gw && n > 0) {
       const float g_pre = (gt > 0.f) ? sum_ad * (1.f - gt * gt) : 0.f;
       if (g_first && row_slot == 0) {
         const float mx = compat[am * G + g_lane];
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     }
     const float tt = gt * sum_ad;
 
-    // ---- pass 2: grad_compat, grad_val
+    // ---- pass 2a: grad_compat (and grad_val when it is a dense [V, C] tensor)
 #pragma unroll
     for (int k = 0; k < VEC; ++k) go[k] *= gt;
 #pragma unroll 2
@@ -393,16 +403,41 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
         if (r == am) gc += g_mx;
         gcompat[r * G + g_lane] = gc;
       }
-      float f[VEC];
+      if (!row_idx) {
+        float f[VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) f[k] = go[k] * a;
-      if (row_idx) {
-        // scatter-add into the fp32 gradient of the value map (many views share a pixel)
-        float* dst = grows + (int64_t)row_idx[r] * C + col;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) atomicAdd(dst + k, f[k]);
-      } else {
+        for (int k = 0; k < VEC; ++k) f[k] = go[k] * a;
         *reinterpret_cast<raw_t*>(gval + r * C + col) = Vec16<T>::pack(f);
+      }
+    }
+
+    // ---- pass 2b: fused-gather scatter: grows[row_idx[v], c] += go[p,c]*gate[p,g(c)]*att[v,g(c)]
+    if (row_idx) {
+      const int cpg = C / G;
+      for (int t = 0; t < teams_per_wave; ++t) {
+        const int src = t * tg.ts;
+        const int nb = __shfl(n, src);
+        if (nb == 0) continue;  // wave-uniform
+        const int64_t pp = pw + t;
+        const int64_t pb = __shfl((long long)beg, src);
+        if (C <= 64) {
+          const int c = lane & (C - 1), rsub = lane / C, rpi = 64 / C;
+          const int gc = c / cpg;
+          const float gq = Elt<T>::ld(gout, pp * C + c) * (gate ? gate[pp * G + gc] : 1.f);
+          for (int v = rsub; v < nb; v += rpi) {
+            const int64_t r = pb + v;
+            atomicAdd(&grows[(int64_t)row_idx[r] * C + c], gq * att[r * G + gc]);
+          }
+        } else {
+          for (int c = lane; c < C; c += 64) {
+            const int gc = c / cpg;
+            const float gq = Elt<T>::ld(gout, pp * C + c) * (gate ? gate[pp * G + gc] : 1.f);
+            for (int v = 0; v < nb; ++v) {
+              const int64_t r = pb + v;
+              atomicAdd(&grows[(int64_t)row_idx[r] * C + c], gq * att[r * G + gc]);
+            }
+          }
+        }
       }
     }
   }
