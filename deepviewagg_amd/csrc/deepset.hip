@@ -1,0 +1,691 @@
+// Fused DeepSetFeat + E_score chain for gfx950: the per-view mapping-feature encoder of
+// GroupBimodalCSRPool / QKVBimodalCSRPool (reference: modules/multimodal/pooling.py:604-673 DeepSetFeat
+// with pool='max', fusion='concatenation'; :258,:282 E_score; MLP / FastBatchNorm1d of
+// core/common_modules/base_modules.py:38-48,:131-156), forward AND backward, exact fp32.
+//
+// Why: the chain is six tiny Linear(<=64 -> 32) layers with train-mode BatchNorm between them over
+// V = tens of millions of views.  Library GEMM + BN + activation kernels move ~4 KB/view and the
+// skinny GEMMs run at <5 % of HBM speed; here every stage between two batch-statistics barriers is
+// ONE pass that reads the previous pre-BN activation (128 B/view), applies BN + LeakyReLU on load,
+// does the 32x32 product and writes the next pre-BN activation (128 B/view) while accumulating the
+// next layer's statistics.
+//
+// Layout ("row streaming"): lane = channel (32 channels, two rows per wavefront step), a wavefront
+// owns 32-row tiles.  Inputs of a row are broadcast to the 32 lanes through LDS (ds_read_b128 of a
+// row all lanes share = hardware broadcast), weights of lane n live in its registers, so a 32x32
+// layer is 32 v_fmac per row pair, column statistics / weight gradients are per-lane accumulators
+// (no cross-lane reduction in the loop), and every global access is a contiguous 128-B row.
+// VALU-bound part: V/2 * 32 fmac * 2 clk / 1024 SIMDs ~= 0.45 ms per layer pass at V = 33.5 M,
+// below the HBM time of the pass (8.6 GB ~= 1.4 ms), so the passes are HBM-bound.
+#include "dva_common.h"
+
+namespace dva {
+
+constexpr int D = 32;       // nc_inner of the fused path
+constexpr int TILE = 32;    // rows per wavefront tile
+constexpr float SLOPE = 0.2f;
+
+struct BNc {  // batch-norm constants of one channel
+  float mean, invstd, gamma, beta;
+};
+// bn arrays are [4][D] = mean | invstd | gamma | beta
+__device__ __forceinline__ BNc load_bn(const float* __restrict__ bn, int c) {
+  BNc b;
+  b.mean = bn[c]; b.invstd = bn[D + c]; b.gamma = bn[2 * D + c]; b.beta = bn[3 * D + c];
+  return b;
+}
+__device__ __forceinline__ float bn_hat(float a, const BNc& b) { return (a - b.mean) * b.invstd; }
+__device__ __forceinline__ float bn_z(float a, const BNc& b) { return bn_hat(a, b) * b.gamma + b.beta; }
+__device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : SLOPE * z; }
+__device__ __forceinline__ float dleaky(float z) { return z > 0.f ? 1.f : SLOPE; }
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum_k row[k] * w[k], k ascending, row broadcast from LDS
+template <int K>
+__device__ __forceinline__ float dot_row(const float* __restrict__ row, const float (&w)[K]) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k4 = 0; k4 < K / 4; ++k4) {
+    const float4 x = *reinterpret_cast<const float4*>(row + 4 * k4);
+    acc = fmaf(x.x, w[4 * k4], acc);
+    acc = fmaf(x.y, w[4 * k4 + 1], acc);
+    acc = fmaf(x.z, w[4 * k4 + 2], acc);
+    acc = fmaf(x.w, w[4 * k4 + 3], acc);
+  }
+  return acc;
+}
+
+// Add the two row-parity halves, then accumulate per-block partials into double accumulators.
+// vals[j] (j < NV) are per-lane partial sums of channel n; out[j*D + n] += total.
+template <int NV>
+__device__ __forceinline__ void flush_channel_sums(float (&vals)[NV], double* __restrict__ out,
+                                                   float* s_red /* [NV*D] */, int lane) {
+  const int n = lane & 31;
+  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float v = vals[j] + __shfl_xor(vals[j], 32);
+    if (lane < 32) atomicAdd(&s_red[j * D + n], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) atomicAdd(&out[i], (double)s_red[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+
+// x_map [V,F=8] -> a1 = x.Wa^T ; STATS_ONLY: statistics of a1.  Otherwise a1 -> BN1 -> leaky -> .Wb^T = a2,
+// written, with statistics of a2.
+template <bool STATS_ONLY>
+__global__ __launch_bounds__(256) void dsf_fwd_first_kernel(const float* __restrict__ x_map,
+                                                             const float* __restrict__ Wa,
+                                                             const float* __restrict__ bn1,
+                                                             const float* __restrict__ Wb,
+                                                             float* __restrict__ a2,
+                                                             double* __restrict__ stats, int64_t V) {
+  __shared__ __attribute__((aligned(16))) float s_x[4][TILE * 8];
+  __shared__ __attribute__((aligned(16))) float s_h[4][TILE * D];
+  __shared__ float s_red[2 * D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+  float wa[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) wa[k] = Wa[n * 8 + k];
+  float wb[D];
+  BNc b1 = {0.f, 1.f, 1.f, 0.f};
+  if (!STATS_ONLY) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) wb[k] = Wb[n * D + k];
+    b1 = load_bn(bn1, n);
+  }
+  float st[2] = {0.f, 0.f};
+  const int64_t tiles = (V + TILE - 1) / TILE;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = i * 64 + lane;
+      const int64_t g = row0 * 8 + e;
+      s_x[wv][e] = g < V * 8 ? x_map[g] : 0.f;
+    }
+    wave_sync();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const float a1 = dot_row<8>(&s_x[wv][(2 * i + h) * 8], wa);
+      if (STATS_ONLY) {
+        if (row0 + 2 * i + h < V) {
+          st[0] += a1;
+          st[1] += a1 * a1;
+        }
+      } else {
+        s_h[wv][(2 * i + h) * D + n] = leaky(bn_z(a1, b1));
+      }
+    }
+    if (!STATS_ONLY) {
+      wave_sync();
+#pragma unroll 2
+      for (int i = 0; i < 16; ++i) {
+        const int64_t r = row0 + 2 * i + h;
+        const float acc = dot_row<D>(&s_h[wv][(2 * i + h) * D], wb);
+        if (r < V) {
+          a2[r * D + n] = acc;
+          st[0] += acc;
+          st[1] += acc * acc;
+        }
+      }
+    }
+    wave_sync();
+  }
+  flush_channel_sums<2>(st, stats, s_red, lane);
+}
+
+// pooled[p, c] = max over the point's views of leaky(BN(a[v, c])) (first row on ties), arg = that row
+__global__ __launch_bounds__(256) void dsf_segmax_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ bn,
+                                                          const int64_t* __restrict__ ptr,
+                                                          float* __restrict__ pooled,
+                                                          int32_t* __restrict__ arg, int64_t N) {
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const BNc b = load_bn(bn, n);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p = wave * 2 + h; p < N; p += n_waves * 2) {
+    const int64_t beg = ptr[p], end = ptr[p + 1];
+    float m = 0.f;
+    int64_t am = -1;
+    for (int64_t r = beg; r < end; ++r) {
+      const float v = leaky(bn_z(a[r * D + n], b));
+      if (r == beg || v > m) {
+        m = v;
+        am = r;
+      }
+    }
+    pooled[p * D + n] = m;
+    arg[p * D + n] = (int32_t)am;
+  }
+}
+
+// a_out[v] = leaky(BN_in(a_in[v])) . W^T (+ addend[vp[v]]) ; statistics of a_out
+template <bool HAS_ADD>
+__global__ __launch_bounds__(256) void dsf_fwd_layer_kernel(
+    const float* __restrict__ a_in, const float* __restrict__ bn_in, const float* __restrict__ W,
+    const float* __restrict__ addend, const int32_t* __restrict__ vp, float* __restrict__ a_out,
+    double* __restrict__ stats, int64_t V) {
+  __shared__ __attribute__((aligned(16))) float s_in[4][TILE * D];
+  __shared__ float s_red[2 * D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+  const BNc b = load_bn(bn_in, n);
+  float w[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) w[k] = W[n * D + k];
+  float st[2] = {0.f, 0.f};
+  const int64_t tiles = (V + TILE - 1) / TILE;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * TILE;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = row0 + 2 * i + h;
+      s_in[wv][(2 * i + h) * D + n] = r < V ? leaky(bn_z(a_in[r * D + n], b)) : 0.f;
+    }
+    wave_sync();
+#pragma unroll 2
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = row0 + 2 * i + h;
+      float acc = dot_row<D>(&s_in[wv][(2 * i + h) * D], w);
+      if (r < V) {
+        if (HAS_ADD) acc += addend[(int64_t)vp[r] * D + n];
+        a_out[r * D + n] = acc;
+        st[0] += acc;
+        st[1] += acc * acc;
+      }
+    }
+    wave_sync();
+  }
+  flush_channel_sums<2>(st, stats, s_red, lane);
+}
+
+// compat[v, g] = leaky(BN(a[v])) . Ws[g] + bs[g],  G <= 32.  Lanes = (g, row-in-pass).
+__global__ __launch_bounds__(256) void dsf_fwd_score_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ bn,
+                                                             const float* __restrict__ Ws,
+                                                             const float* __restrict__ bs,
+                                                             float* __restrict__ compat, int64_t V,
+                                                             int G, int GP /* pow2 >= G */) {
+  __shared__ __attribute__((aligned(16))) float s_in[4][TILE * D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+  const BNc b = load_bn(bn, n);
+  const int g = lane & (GP - 1), rr = lane / GP, rpp = 64 / GP;
+  float w[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) w[k] = g < G ? Ws[g * D + k] : 0.f;
+  const float bias = g < G ? bs[g] : 0.f;
+  const int64_t tiles = (V + TILE - 1) / TILE;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * TILE;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = row0 + 2 * i + h;
+      s_in[wv][(2 * i + h) * D + n] = r < V ? leaky(bn_z(a[r * D + n], b)) : 0.f;
+    }
+    wave_sync();
+    for (int row = rr; row < TILE; row += rpp) {
+      const int64_t r = row0 + row;
+      const float acc = dot_row<D>(&s_in[wv][row * D], w) + bias;
+      if (r < V && g < G) compat[r * G + g] = acc;
+    }
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+
+// Score layer: dz[v,k] = (sum_g dc[v,g] Ws[g,k]) * leaky'(z[v,k]);  dWs, dbs;  S1 = sum dz, S2 = sum dz*a_hat
+template <int GMAX>
+__global__ __launch_bounds__(256) void dsf_bwd_score_kernel(
+    const float* __restrict__ dcompat, const float* __restrict__ a, const float* __restrict__ bn,
+    const float* __restrict__ Ws, float* __restrict__ dz, float* __restrict__ dWs,
+    float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G) {
+  __shared__ float s_red[(2 + GMAX) * D];
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const BNc b = load_bn(bn, n);
+  float ws[GMAX], acc[2 + GMAX], dbacc[GMAX];
+#pragma unroll
+  for (int g = 0; g < GMAX; ++g) {
+    ws[g] = g < G ? Ws[g * D + n] : 0.f;
+    dbacc[g] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 2 + GMAX; ++j) acc[j] = 0.f;
+  const int64_t pairs = (V + 1) / 2;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = wave; q < pairs; q += n_waves) {
+    const int64_t r = 2 * q + h;
+    if (r >= V) continue;
+    const float av = a[r * D + n];
+    const float ah = bn_hat(av, b);
+    const float z = ah * b.gamma + b.beta;
+    const float x = leaky(z);
+    float dx = 0.f;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+      if (g < G) {
+        const float dc = dcompat[r * G + g];
+        dx = fmaf(dc, ws[g], dx);
+        acc[2 + g] = fmaf(dc, x, acc[2 + g]);
+        dbacc[g] += dc;
+      }
+    }
+    const float d = dx * dleaky(z);
+    dz[r * D + n] = d;
+    acc[0] += d;
+    acc[1] = fmaf(d, ah, acc[1]);
+  }
+  // S1, S2 (double) and dWs (float) through the block reduction
+  const int nn = lane & 31;
+  for (int i = threadIdx.x; i < (2 + GMAX) * D; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2 + GMAX; ++j) {
+    const float v = acc[j] + __shfl_xor(acc[j], 32);
+    if (lane < 32) atomicAdd(&s_red[j * D + nn], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) atomicAdd(&st[i], (double)s_red[i]);
+  for (int i = threadIdx.x; i < G * D; i += blockDim.x) atomicAdd(&dWs[i], s_red[2 * D + i]);
+  // bias gradient: lanes n == 0 of both halves hold complete per-row sums
+  if (nn == 0) {
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+      if (g < G && dbacc[g] != 0.f) atomicAdd(&dbs[g], dbacc[g]);
+  }
+}
+
+// Generic layer backward.  Given dz_L (gradient w.r.t. the BN_L output), a_L, W_L and the layer input
+// x_L = leaky(BN_prev(a_prev)):
+//   da_L  = gamma_L*invstd_L*(dz_L - S1m_L - a_hat_L*S2m_L)          (S1m, S2m = S1/M, S2/M; 0 in eval)
+//   dW_L += da_L^T x_L ;   dx = da_L . W_L
+//   RAW_OUT: out = dx                       (concat layer: the max-pool path is added later)
+//   else   : out = dz_prev = dx*leaky'(z_prev), with S1_prev, S2_prev accumulated
+//   dt[vp[v]] += da_L[v]                    (gradient of the per-point addend, optional)
+// PREV_XMAP: a_prev is recomputed as x_map . Wa^T (first hidden layer).
+template <bool PREV_XMAP, bool RAW_OUT>
+__global__ __launch_bounds__(256) void dsf_bwd_layer_kernel(
+    const float* __restrict__ dz_L, const float* __restrict__ a_L, const float* __restrict__ bn_L,
+    const float* __restrict__ sm_L /* [2][D] S1/M | S2/M */, const float* __restrict__ W_L,
+    const float* __restrict__ a_prev /* [V,D] or x_map [V,8] */, const float* __restrict__ Wa,
+    const float* __restrict__ bn_prev, float* __restrict__ out, float* __restrict__ dW,
+    double* __restrict__ st_prev, float* __restrict__ dt, const int32_t* __restrict__ vp, int64_t V) {
+  __shared__ __attribute__((aligned(16))) float s_da[4][TILE * D];
+  __shared__ __attribute__((aligned(16))) float s_x[4][TILE * D];
+  __shared__ __attribute__((aligned(16))) float s_xm[4][TILE * 8];
+  __shared__ float s_ap[4][TILE * D];
+  __shared__ float s_red[D * D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+  const BNc bL = load_bn(bn_L, n), bp = load_bn(bn_prev, n);
+  const float s1m = sm_L[n], s2m = sm_L[D + n];
+  const float gsc = bL.gamma * bL.invstd;
+  float wt[D];  // column n of W_L: dx[k=n] = sum_n' da[n'] W_L[n'][n]
+#pragma unroll
+  for (int k = 0; k < D; ++k) wt[k] = W_L[k * D + n];
+  float wa[8];
+  if (PREV_XMAP) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wa[k] = Wa[n * 8 + k];
+  }
+  float dWacc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) dWacc[k] = 0.f;
+  float st[2] = {0.f, 0.f};
+  const int64_t tiles = (V + TILE - 1) / TILE;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * TILE;
+    if (PREV_XMAP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = i * 64 + lane;
+        const int64_t g = row0 * 8 + e;
+        s_xm[wv][e] = g < V * 8 ? a_prev[g] : 0.f;
+      }
+      wave_sync();
+    }
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int row = 2 * i + h;
+      const int64_t r = row0 + row;
+      float da = 0.f, ap = 0.f, x = 0.f;
+      if (r < V) {
+        const float ah = bn_hat(a_L[r * D + n], bL);
+        da = gsc * (dz_L[r * D + n] - s1m - ah * s2m);
+        ap = PREV_XMAP ? dot_row<8>(&s_xm[wv][row * 8], wa) : a_prev[r * D + n];
+        x = leaky(bn_z(ap, bp));
+      }
+      s_da[wv][row * D + n] = da;
+      s_x[wv][row * D + n] = x;
+      s_ap[wv][row * D + n] = ap;
+    }
+    wave_sync();
+    int32_t cur_p = -1;
+    float cur_s = 0.f;
+#pragma unroll 2
+    for (int i = 0; i < 16; ++i) {
+      const int row = 2 * i + h;
+      const int64_t r = row0 + row;
+      // dW[n][k] += da[v][n] * x[v][k]
+      const float da = s_da[wv][row * D + n];
+#pragma unroll
+      for (int k4 = 0; k4 < D / 4; ++k4) {
+        const float4 x = *reinterpret_cast<const float4*>(&s_x[wv][row * D + 4 * k4]);
+        dWacc[4 * k4] = fmaf(da, x.x, dWacc[4 * k4]);
+        dWacc[4 * k4 + 1] = fmaf(da, x.y, dWacc[4 * k4 + 1]);
+        dWacc[4 * k4 + 2] = fmaf(da, x.z, dWacc[4 * k4 + 2]);
+        dWacc[4 * k4 + 3] = fmaf(da, x.w, dWacc[4 * k4 + 3]);
+      }
+      // dx[v][n] = sum_n' da[v][n'] * W_L[n'][n]
+      const float dx = dot_row<D>(&s_da[wv][row * D], wt);
+      if (r < V) {
+        if (RAW_OUT) {
+          out[r * D + n] = dx;
+        } else {
+          const float ah = bn_hat(s_ap[wv][row * D + n], bp);
+          const float z = ah * bp.gamma + bp.beta;
+          const float d = dx * dleaky(z);
+          out[r * D + n] = d;
+          st[0] += d;
+          st[1] = fmaf(d, ah, st[1]);
+        }
+        if (dt) {
+          const int32_t p = vp[r];
+          if (p != cur_p) {
+            if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * D + n], cur_s);
+            cur_p = p;
+            cur_s = 0.f;
+          }
+          cur_s += da;
+        }
+      }
+    }
+    if (dt && cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * D + n], cur_s);
+    wave_sync();
+  }
+  // dW: add the two row-parity halves, reduce over the block in LDS, one atomic per element per block
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const float v = dWacc[k] + __shfl_xor(dWacc[k], 32);
+    if (lane < 32) atomicAdd(&s_red[n * D + k], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) atomicAdd(&dW[i], s_red[i]);
+  if (!RAW_OUT) {
+    __syncthreads();
+    flush_channel_sums<2>(st, st_prev, s_red, lane);
+  }
+}
+
+// dz2[v,c] = (dcat[v,c] + [arg[p,c]==v] dpooled[p,c]) * leaky'(z2[v,c]),  p = vp[v];  S1, S2 of BN2
+__global__ __launch_bounds__(256) void dsf_bwd_max_kernel(
+    const float* __restrict__ dcat, const float* __restrict__ a2, const float* __restrict__ bn2,
+    const int32_t* __restrict__ arg, const float* __restrict__ dpooled, const int32_t* __restrict__ vp,
+    float* __restrict__ dz2, double* __restrict__ st, int64_t V) {
+  __shared__ float s_red[2 * D];
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const BNc b = load_bn(bn2, n);
+  float acc[2] = {0.f, 0.f};
+  const int64_t pairs = (V + 1) / 2;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = wave; q < pairs; q += n_waves) {
+    const int64_t r = 2 * q + h;
+    if (r >= V) continue;
+    const int64_t p = vp[r];
+    float g = dcat[r * D + n];
+    if ((int64_t)arg[p * D + n] == r) g += dpooled[p * D + n];
+    const float ah = bn_hat(a2[r * D + n], b);
+    const float z = ah * b.gamma + b.beta;
+    const float d = g * dleaky(z);
+    dz2[r * D + n] = d;
+    acc[0] += d;
+    acc[1] = fmaf(d, ah, acc[1]);
+  }
+  flush_channel_sums<2>(acc, st, s_red, lane);
+}
+
+// First layer: a1 = x.Wa^T recomputed, da1 = BN-backward(dz1), dWa[n][j] += da1[v][n] x[v][j]
+__global__ __launch_bounds__(256) void dsf_bwd_first_kernel(
+    const float* __restrict__ dz1, const float* __restrict__ x_map, const float* __restrict__ Wa,
+    const float* __restrict__ bn1, const float* __restrict__ sm1, float* __restrict__ dWa, int64_t V) {
+  __shared__ __attribute__((aligned(16))) float s_x[4][TILE * 8];
+  __shared__ float s_red[D * 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+  const BNc b = load_bn(bn1, n);
+  const float s1m = sm1[n], s2m = sm1[D + n], gsc = b.gamma * b.invstd;
+  float wa[8], acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    wa[k] = Wa[n * 8 + k];
+    acc[k] = 0.f;
+  }
+  const int64_t tiles = (V + TILE - 1) / TILE;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = i * 64 + lane;
+      const int64_t g = row0 * 8 + e;
+      s_x[wv][e] = g < V * 8 ? x_map[g] : 0.f;
+    }
+    wave_sync();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int row = 2 * i + h;
+      const int64_t r = row0 + row;
+      if (r < V) {
+        const float a1 = dot_row<8>(&s_x[wv][row * 8], wa);
+        const float da = gsc * (dz1[r * D + n] - s1m - bn_hat(a1, b) * s2m);
+        const float4 x0 = *reinterpret_cast<const float4*>(&s_x[wv][row * 8]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&s_x[wv][row * 8 + 4]);
+        acc[0] = fmaf(da, x0.x, acc[0]); acc[1] = fmaf(da, x0.y, acc[1]);
+        acc[2] = fmaf(da, x0.z, acc[2]); acc[3] = fmaf(da, x0.w, acc[3]);
+        acc[4] = fmaf(da, x1.x, acc[4]); acc[5] = fmaf(da, x1.y, acc[5]);
+        acc[6] = fmaf(da, x1.z, acc[6]); acc[7] = fmaf(da, x1.w, acc[7]);
+      }
+    }
+    wave_sync();
+  }
+  for (int i = threadIdx.x; i < D * 8; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = acc[k] + __shfl_xor(acc[k], 32);
+    if (lane < 32) atomicAdd(&s_red[n * 8 + k], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * 8; i += blockDim.x) atomicAdd(&dWa[i], s_red[i]);
+}
+
+// view -> point index (dense expansion of the CSR pointers), one thread per point
+__global__ __launch_bounds__(256) void csr_expand_kernel(const int64_t* __restrict__ ptr, int64_t N,
+                                                          int32_t* __restrict__ vp) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N;
+       p += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t r = ptr[p]; r < ptr[p + 1]; ++r) vp[r] = (int32_t)p;
+}
+
+static inline int grid_rows(int64_t V) {
+  // one wavefront per 32-row tile, 4 wavefronts per block, capped at 8 blocks per CU
+  int64_t b = ((V + TILE - 1) / TILE + 3) / 4;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace dva
+
+using namespace dva;
+
+extern "C" {
+
+int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, void* stream) {
+  if (n_groups < 0 || !ptr) return DVA_ERR_INVALID;
+  if (n_groups == 0) return DVA_OK;
+  if (!group_of_row) return DVA_ERR_INVALID;
+  int64_t b = (n_groups + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(csr_expand_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, ptr, n_groups,
+                     group_of_row);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb,
+                          float* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
+                          void* stream) {
+  if (V < 0 || !stats) return DVA_ERR_INVALID;
+  if (F != 8) return DVA_ERR_UNSUPPORTED;
+  if (V == 0) return DVA_OK;
+  if (!x_map || !Wa) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (stats_only) {
+    hipLaunchKernelGGL((dsf_fwd_first_kernel<true>), dim3(grid_rows(V)), dim3(256), 0, s, x_map, Wa,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, stats, V);
+  } else {
+    if (!bn1 || !Wb || !a2) return DVA_ERR_INVALID;
+    hipLaunchKernelGGL((dsf_fwd_first_kernel<false>), dim3(grid_rows(V)), dim3(256), 0, s, x_map, Wa,
+                       bn1, Wb, a2, stats, V);
+  }
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, float* pooled,
+                       int32_t* arg, int64_t N, void* stream) {
+  if (N < 0) return DVA_ERR_INVALID;
+  if (N == 0) return DVA_OK;
+  if (!a || !bn || !ptr || !pooled || !arg) return DVA_ERR_INVALID;
+  int64_t b = (N + 7) / 8;
+  if (b > 256 * 8) b = 256 * 8;
+  hipLaunchKernelGGL(dsf_segmax_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, a, bn, ptr,
+                     pooled, arg, N);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
+                          const int32_t* group_of_row, float* a_out, double* stats, int64_t V,
+                          void* stream) {
+  if (V < 0 || !stats) return DVA_ERR_INVALID;
+  if (V == 0) return DVA_OK;
+  if (!a_in || !bn_in || !W || !a_out) return DVA_ERR_INVALID;
+  if (addend && !group_of_row) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (addend)
+    hipLaunchKernelGGL((dsf_fwd_layer_kernel<true>), dim3(grid_rows(V)), dim3(256), 0, s, a_in, bn_in, W,
+                       addend, group_of_row, a_out, stats, V);
+  else
+    hipLaunchKernelGGL((dsf_fwd_layer_kernel<false>), dim3(grid_rows(V)), dim3(256), 0, s, a_in, bn_in,
+                       W, (const float*)nullptr, (const int32_t*)nullptr, a_out, stats, V);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs,
+                          float* compat, int64_t V, int32_t G, void* stream) {
+  if (V < 0 || G <= 0 || G > 32) return DVA_ERR_INVALID;
+  if (V == 0) return DVA_OK;
+  if (!a || !bn || !Ws || !bs || !compat) return DVA_ERR_INVALID;
+  int GP = 1;
+  while (GP < G) GP <<= 1;
+  hipLaunchKernelGGL(dsf_fwd_score_kernel, dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream, a, bn,
+                     Ws, bs, compat, V, G, GP);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws,
+                          float* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
+                          void* stream) {
+  if (V < 0 || G <= 0) return DVA_ERR_INVALID;
+  if (G > 32) return DVA_ERR_UNSUPPORTED;
+  if (V == 0) return DVA_OK;
+  if (!dcompat || !a || !bn || !Ws || !dz || !dWs || !dbs || !st) return DVA_ERR_INVALID;
+  if (G <= 8)
+    hipLaunchKernelGGL((dsf_bwd_score_kernel<8>), dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream,
+                       dcompat, a, bn, Ws, dz, dWs, dbs, st, V, G);
+  else
+    hipLaunchKernelGGL((dsf_bwd_score_kernel<32>), dim3(grid_rows(V)), dim3(256), 0,
+                       (hipStream_t)stream, dcompat, a, bn, Ws, dz, dWs, dbs, st, V, G);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L, const float* sm_L,
+                          const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
+                          float* out, float* dW, double* st_prev, float* dt,
+                          const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
+                          int32_t raw_out, void* stream) {
+  if (V < 0) return DVA_ERR_INVALID;
+  if (V == 0) return DVA_OK;
+  if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || !bn_prev || !out || !dW)
+    return DVA_ERR_INVALID;
+  if (!raw_out && !st_prev) return DVA_ERR_INVALID;
+  if (prev_is_xmap && !Wa) return DVA_ERR_INVALID;
+  if (dt && !group_of_row) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(grid_rows(V)), block(256);
+#define DVA_L(P, R)                                                                                \
+  hipLaunchKernelGGL((dsf_bwd_layer_kernel<P, R>), grid, block, 0, s, dz_L, a_L, bn_L, sm_L, W_L,  \
+                     a_prev, Wa, bn_prev, out, dW, st_prev, dt, group_of_row, V)
+  if (prev_is_xmap && raw_out) DVA_L(true, true);
+  else if (prev_is_xmap) DVA_L(true, false);
+  else if (raw_out) DVA_L(false, true);
+  else DVA_L(false, false);
+#undef DVA_L
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
+                        const float* dpooled, const int32_t* group_of_row, float* dz2, double* st,
+                        int64_t V, void* stream) {
+  if (V < 0) return DVA_ERR_INVALID;
+  if (V == 0) return DVA_OK;
+  if (!dcat || !a2 || !bn2 || !arg || !dpooled || !group_of_row || !dz2 || !st) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(dsf_bwd_max_kernel, dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream, dcat, a2,
+                     bn2, arg, dpooled, group_of_row, dz2, st, V);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_deepset_bwd_first(const float* dz1, const float* x_map, const float* Wa, const float* bn1,
+                          const float* sm1, float* dWa, int64_t V, int32_t F, void* stream) {
+  if (V < 0) return DVA_ERR_INVALID;
+  if (F != 8) return DVA_ERR_UNSUPPORTED;
+  if (V == 0) return DVA_OK;
+  if (!dz1 || !x_map || !Wa || !bn1 || !sm1 || !dWa) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(dsf_bwd_first_kernel, dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream, dz1,
+                     x_map, Wa, bn1, sm1, dWa, V);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

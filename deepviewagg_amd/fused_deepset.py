@@ -1,0 +1,243 @@
+"""Fused DeepSetFeat (+ trailing Linear) over the views: one autograd.Function driving the row-streaming
+HIP kernels of ``csrc/deepset.hip`` (C ABI ``dva_deepset_*``), forward and hand-written backward.
+
+Computes exactly ``linear(E_map(x_map, csr_idx))`` of the reference
+(modules/multimodal/pooling.py:658-669 DeepSetFeat.forward followed by E_score :282 / K :484) for the
+shipped configuration: ``DeepSetFeat(d_in=8, d_out=32, pool='max', fusion='concatenation',
+use_num=*)``.  Train-mode BatchNorm uses batch statistics (accumulated in fp64 by the kernels) and
+updates the running statistics like nn.BatchNorm1d; eval mode uses the running statistics.
+
+Only the set branch (``mlp_set`` on N points, 1/32 of the rows) runs as ordinary PyTorch ops: it is
+evaluated under ``torch.enable_grad()`` inside the forward and differentiated with
+``torch.autograd.grad`` inside the backward.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import check, ptr, require_device, stream_of
+
+D = 32
+
+
+def _bn_of(block):
+    return block[1].batch_norm
+
+
+def applicable(e_map, linear, x_map):
+    """Can ``linear(e_map(x_map))`` take the fused path?"""
+    from .modules.multimodal import pooling as P
+    if not isinstance(e_map, P.DeepSetFeat) or not isinstance(linear, torch.nn.Linear):
+        return False
+    if e_map.d_out != D or e_map.d_in != 8 or e_map.pool != ['max'] or e_map.fusion != 'concatenation':
+        return False
+    if linear.in_features != D or linear.out_features > 32 or linear.bias is None:
+        return False
+    if not (x_map.is_cuda and x_map.dtype == torch.float32 and x_map.dim() == 2 and x_map.shape[1] == 8):
+        return False
+    if x_map.requires_grad and torch.is_grad_enabled():
+        return False  # gradient w.r.t. the raw mapping features is only produced by the generic path
+    for mlp in (e_map.mlp_elt_1, e_map.mlp_set, e_map.mlp_elt_2):
+        for block in mlp:
+            bn = _bn_of(block)
+            if block[0].bias is not None or not bn.affine or not bn.track_running_stats \
+                    or bn.momentum is None or getattr(block[2], 'negative_slope', None) != 0.2:
+                return False
+    return True
+
+
+def _bn_consts(stats, m, bn, training):
+    """[4, 32] fp32 = mean | invstd | gamma | beta from batch statistics (training) or running stats;
+    updates the running statistics in training (nn.BatchNorm1d semantics)."""
+    if training:
+        mean = stats[:D] / m
+        var = (stats[D:] / m - mean * mean).clamp_(min=0.0)
+        with torch.no_grad():
+            mom = bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mom * mean.float())
+            bn.running_var.mul_(1 - mom).add_(mom * (var * (m / max(m - 1, 1))).float())
+            bn.num_batches_tracked += 1
+        mean, var = mean.float(), var.float()
+    else:
+        mean, var = bn.running_mean.float(), bn.running_var.float()
+    invstd = torch.rsqrt(var + bn.eps)
+    return torch.stack([mean, invstd, bn.weight.detach().float(), bn.bias.detach().float()]).contiguous()
+
+
+class _DeepSetLinear(torch.autograd.Function):
+    """params: Wa, g1, b1, Wb, g2, b2, Wc, g3, b3, Wd, g4, b4, Ws, bs, then the mlp_set parameters."""
+
+    @staticmethod
+    def forward(ctx, x_map, csr_idx, e_map, linear, *params):
+        lib = _lib.load()
+        require_device(x_map, csr_idx)
+        x_map = x_map.contiguous()
+        dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
+        st = stream_of(x_map)
+        training = e_map.training
+        Wa = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
+        Wb = e_map.mlp_elt_1[1][0].weight.detach().contiguous()
+        Wc = e_map.mlp_elt_2[0][0].weight.detach()
+        WcA = Wc[:, :D].contiguous()
+        Wd = e_map.mlp_elt_2[1][0].weight.detach().contiguous()
+        Ws, bs = linear.weight.detach().contiguous(), linear.bias.detach().contiguous()
+        G = Ws.shape[0]
+        bns = [_bn_of(e_map.mlp_elt_1[0]), _bn_of(e_map.mlp_elt_1[1]),
+               _bn_of(e_map.mlp_elt_2[0]), _bn_of(e_map.mlp_elt_2[1])]
+
+        def zstats():
+            return torch.zeros(2 * D, dtype=torch.float64, device=dev)
+
+        # ---- elt MLP 1: x_map -> a1 -> a2
+        s1 = zstats()
+        if training:
+            with ops._timed("deepset_fwd_first_stats", V * 32):
+                check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), None, None, None, ptr(s1), V, 8, 1, st),
+                      "dva_deepset_fwd_first")
+        bn1 = _bn_consts(s1, V, bns[0], training)
+        a2 = torch.empty((V, D), dtype=torch.float32, device=dev)
+        s2 = zstats()
+        with ops._timed("deepset_fwd_first", V * (32 + 128)):
+            check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), ptr(bn1), ptr(Wb), ptr(a2), ptr(s2), V, 8, 0, st),
+                  "dva_deepset_fwd_first")
+        bn2 = _bn_consts(s2, V, bns[1], training)
+        # ---- set branch: max over views, set MLP on the N points, WcB product (PyTorch, N rows)
+        pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
+        arg = torch.empty((N, D), dtype=torch.int32, device=dev)
+        with ops._timed("deepset_segmax", V * 128 + N * (256 + 8)):
+            check(lib.dva_deepset_segmax(ptr(a2), ptr(bn2), ptr(csr_idx), ptr(pooled), ptr(arg), N, st),
+                  "dva_deepset_segmax")
+        with torch.enable_grad():
+            pooled_leaf = pooled.requires_grad_()
+            x_set = pooled_leaf
+            if e_map.use_num:
+                sizes = csr_idx[1:] - csr_idx[:-1]
+                x_set = torch.cat((x_set, torch.sqrt(1 / (sizes + 1e-3)).float().view(-1, 1)), dim=1)
+            with torch.autocast("cuda", enabled=False):
+                t_add = F.linear(e_map.mlp_set(x_set), e_map.mlp_elt_2[0][0].weight[:, D:])
+        vp = torch.empty(V, dtype=torch.int32, device=dev)
+        check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
+        # ---- elt MLP 2: cat(h1, set[p]) -> a3 -> a4
+        t_det = t_add.detach().contiguous()
+        a3 = torch.empty((V, D), dtype=torch.float32, device=dev)
+        s3 = zstats()
+        with ops._timed("deepset_fwd_layer", V * (128 + 4 + 128) + N * 128):
+            check(lib.dva_deepset_fwd_layer(ptr(a2), ptr(bn2), ptr(WcA), ptr(t_det), ptr(vp), ptr(a3), ptr(s3), V, st),
+                  "dva_deepset_fwd_layer")
+        bn3 = _bn_consts(s3, V, bns[2], training)
+        a4 = torch.empty((V, D), dtype=torch.float32, device=dev)
+        s4 = zstats()
+        with ops._timed("deepset_fwd_layer", V * (128 + 128)):
+            check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, st),
+                  "dva_deepset_fwd_layer")
+        bn4 = _bn_consts(s4, V, bns[3], training)
+        # ---- trailing Linear (E_score / K)
+        out = torch.empty((V, G), dtype=torch.float32, device=dev)
+        with ops._timed("deepset_fwd_score", V * (128 + 4 * G)):
+            check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, st),
+                  "dva_deepset_fwd_score")
+
+        ctx.save_for_backward(x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws)
+        ctx.inner = (t_add, pooled_leaf)
+        ctx.modules = (e_map, linear)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws = ctx.saved_tensors
+        e_map, linear = ctx.modules
+        t_add, pooled_leaf = ctx.inner
+        dev, V, N, G = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1, Ws.shape[0]
+        st = stream_of(x_map)
+        dout = dout.contiguous().float()
+        m = float(max(V, 1))
+
+        def zstats():
+            return torch.zeros(2 * D, dtype=torch.float64, device=dev)
+
+        def sm_of(stats):
+            # S1/M | S2/M of the batch-statistics BN backward; zero with running statistics (eval)
+            if not ctx.training:
+                return torch.zeros(2 * D, dtype=torch.float32, device=dev)
+            return (stats / m).float().contiguous()
+
+        def buf():
+            return torch.empty((V, D), dtype=torch.float32, device=dev)
+
+        # score layer
+        dz4, s4 = buf(), zstats()
+        dWs = torch.zeros_like(Ws)
+        dbs = torch.zeros(G, dtype=torch.float32, device=dev)
+        with ops._timed("deepset_bwd_score", V * (128 + 4 * G + 128)):
+            check(lib.dva_deepset_bwd_score(ptr(dout), ptr(a4), ptr(bn4), ptr(Ws), ptr(dz4), ptr(dWs), ptr(dbs),
+                                            ptr(s4), V, G, st), "dva_deepset_bwd_score")
+        # Wd layer (a3 -> a4)
+        dz3, s3, dWd = buf(), zstats(), torch.zeros_like(Wd)
+        sm4 = sm_of(s4)
+        with ops._timed("deepset_bwd_layer", V * 128 * 4):
+            check(lib.dva_deepset_bwd_layer(ptr(dz4), ptr(a4), ptr(bn4), ptr(sm4), ptr(Wd), ptr(a3), None, ptr(bn3),
+                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, V, 0, 0, st),
+                  "dva_deepset_bwd_layer")
+        del dz4
+        # Wc layer (cat(h1, set) -> a3): raw dx on the h1 half, per-point sum on the set half
+        dcat, dWcA = buf(), torch.zeros_like(WcA)
+        dt = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        sm3 = sm_of(s3)
+        with ops._timed("deepset_bwd_layer", V * (128 * 4 + 4) + N * 128):
+            check(lib.dva_deepset_bwd_layer(ptr(dz3), ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2), None, ptr(bn2),
+                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, st),
+                  "dva_deepset_bwd_layer")
+        del dz3
+        # set branch backward (PyTorch autograd over N rows)
+        set_params = [p for p in e_map.mlp_set.parameters()]
+        wc_param = e_map.mlp_elt_2[0][0].weight
+        inner = torch.autograd.grad(t_add, [pooled_leaf, wc_param] + set_params, grad_outputs=dt,
+                                    allow_unused=True)
+        dpooled = inner[0].contiguous()
+        dWc = inner[1].clone() if inner[1] is not None else torch.zeros_like(wc_param)
+        dWc[:, :D] += dWcA
+        d_set = list(inner[2:])
+        # join the max path, BN2 backward statistics
+        dz2, s2 = buf(), zstats()
+        with ops._timed("deepset_bwd_max", V * (128 * 3 + 4) + N * 256):
+            check(lib.dva_deepset_bwd_max(ptr(dcat), ptr(a2), ptr(bn2), ptr(arg), ptr(dpooled), ptr(vp), ptr(dz2),
+                                          ptr(s2), V, st), "dva_deepset_bwd_max")
+        del dcat
+        # Wb layer (a1 -> a2), a1 recomputed from x_map
+        dz1, s1, dWb = buf(), zstats(), torch.zeros_like(Wb)
+        sm2 = sm_of(s2)
+        with ops._timed("deepset_bwd_layer", V * (128 * 3 + 32)):
+            check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
+                                            ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, st),
+                  "dva_deepset_bwd_layer")
+        del dz2
+        dWa = torch.zeros_like(Wa)
+        sm1 = sm_of(s1)
+        with ops._timed("deepset_bwd_first", V * (128 + 32)):
+            check(lib.dva_deepset_bwd_first(ptr(dz1), ptr(x_map), ptr(Wa), ptr(bn1), ptr(sm1), ptr(dWa), V, 8, st),
+                  "dva_deepset_bwd_first")
+
+        def gb(stats):  # d gamma = S2, d beta = S1
+            return stats[D:].float(), stats[:D].float()
+        g1, b1 = gb(s1)
+        g2, b2 = gb(s2)
+        g3, b3 = gb(s3)
+        g4, b4 = gb(s4)
+        grads = [dWa, g1, b1, dWb, g2, b2, dWc, g3, b3, dWd, g4, b4, dWs, dbs] + d_set
+        ctx.inner = None
+        return (None, None, None, None) + tuple(grads)
+
+
+def deepset_linear(e_map, linear, x_map, csr_idx):
+    """``linear(e_map(x_map, csr_idx))`` through the fused kernels (check ``applicable`` first)."""
+    blocks = (e_map.mlp_elt_1[0], e_map.mlp_elt_1[1], e_map.mlp_elt_2[0], e_map.mlp_elt_2[1])
+    params = []
+    for blk in blocks:
+        bn = _bn_of(blk)
+        params += [blk[0].weight, bn.weight, bn.bias]
+    params += [linear.weight, linear.bias]
+    params += list(e_map.mlp_set.parameters())
+    csr_idx = ops._check_ptr(csr_idx)
+    return _DeepSetLinear.apply(x_map, csr_idx, e_map, linear, *params)

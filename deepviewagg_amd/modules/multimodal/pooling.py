@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from ...core.common_modules import MLP
 from ... import ops
+from ... import fused_deepset
 from ...ops import (segment_csr, gather_csr, segment_gather_csr,  # noqa: F401 (re-exported)
                     segment_softmax_csr)
 
@@ -241,18 +242,25 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
-        x_map = self.E_map(x_map, csr_idx)
+        fused_scores = (not self.use_mod and not self.save_last
+                        and fused_deepset.applicable(self.E_map, self.E_score, x_map))
+        if fused_scores:
+            # DeepSetFeat + E_score in the fused row-streaming kernels (fp32, hand-written backward)
+            compatibilities = fused_deepset.deepset_linear(self.E_map, self.E_score, x_map, csr_idx)
+        else:
+            x_map = self.E_map(x_map, csr_idx)
         if isinstance(x_mod, ops.GatheredFeatures) and not self.use_mod:
             # lazy nearest gather: E_mod runs on the map rows, the gather is fused into the
             # attention kernel (no [V, C] tensor exists on this path)
             val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts)
-            compatibilities = self.E_score(x_map)
+            if not fused_scores:
+                compatibilities = self.E_score(x_map)
             x_mod = ops.GatheredFeatures(val_rows, x_mod.row_idx, x_mod.counts, x_mod.exact)
         else:
             x_mod = self.E_mod(_materialize(x_mod))
             if self.use_mod:
                 compatibilities = self.E_score(self.E_mix(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
-            else:
+            elif not fused_scores:
                 compatibilities = self.E_score(x_map)
         x_pool, attentions, gating = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
         self._save(x_map, x_mod, csr_idx, C=compatibilities, A=attentions,
@@ -319,7 +327,12 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
 
         n_views = x_mod.shape[0]
         x_main = self.E_main(x_main)
-        x_map = self.E_map(x_map, csr_idx)
+        fused_keys = (not self.use_mod_k and not self.save_last and not self.debug
+                      and fused_deepset.applicable(self.E_map, self.K, x_map))
+        if fused_keys:
+            keys = fused_deepset.deepset_linear(self.E_map, self.K, x_map, csr_idx)
+        else:
+            x_map = self.E_map(x_map, csr_idx)
         if isinstance(x_mod, ops.GatheredFeatures) and not (self.use_mod_k or self.use_mod_q or self.debug):
             x_mod = ops.GatheredFeatures(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts),
                                          x_mod.row_idx, x_mod.counts, x_mod.exact)
@@ -328,7 +341,7 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
 
         if self.use_mod_k:
             keys = self.K(self.E_mix_K(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
-        else:
+        elif not fused_keys:
             keys = self.K(x_map)
 
         if self.use_mod_q:

@@ -175,3 +175,71 @@ def test_lazy_gather_path_matches_oracle(cls_name, train):
     for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
         if "running" in k:
             close(a, b, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["pool_group_default_train", "pool_group_default_eval", "pool_qkv_default"])
+def test_fused_deepset_matches_reference(name):
+    """Same golden cases, but through the fused DeepSetFeat kernels (x_map without grad, no save_last)."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import fused_deepset
+    g = load_golden(name)
+    kwargs = ast.literal_eval(str(g["kwargs"]))
+    cls = P.QKVBimodalCSRPool if "qkv" in name else P.GroupBimodalCSRPool
+    m = cls(**kwargs)
+    m.load_state_dict(state_dict_from(g), strict=True)
+    m = m.to(DEV).train(bool(g["train"]))
+    csr = t(g["csr"], DEV)
+    x_mod, x_map = t(g["x_mod"], DEV).requires_grad_(), t(g["x_map"], DEV)
+    x_main = t(g["x_main"], DEV).requires_grad_() if "x_main" in g else None
+    assert fused_deepset.applicable(m.E_map, m.K if "qkv" in name else m.E_score, x_map)
+    out = m(x_main, x_mod, x_map, csr)
+    close(out, g["out"])
+    ins = [x_mod] + ([x_main] if x_main is not None else [])
+    names = [n for n, _ in m.named_parameters()]
+    grads = torch.autograd.grad((out * t(g["w"], DEV)).sum(), ins + list(m.parameters()), allow_unused=True)
+    close(grads[0], g["grad_x_mod"], rtol=1e-3, atol=1e-5)
+    for n, gr in zip(names, grads[len(ins):]):
+        ref = t(g["gp/" + n])
+        gr = gr if gr is not None else torch.zeros_like(ref)
+        close(gr, ref, rtol=2e-3, atol=3e-4)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g["sd_after/" + k], rtol=1e-4, atol=1e-6)
+        if "num_batches_tracked" in k:
+            assert int(v) == int(g["sd_after/" + k])
+
+
+def test_fused_deepset_large_vs_generic():
+    """V ~ 300k views with ragged / empty segments: fused kernels vs the generic composition."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import fused_deepset
+    gen = torch.Generator().manual_seed(5)
+    N, C = 50000, 16
+    sizes = torch.randint(0, 13, (N,), generator=gen)
+    sizes[:100] = 150                      # long segments spanning several 32-row tiles
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    kwargs = dict(in_map=8, in_mod=C, num_groups=4, use_num=True)
+    m = P.GroupBimodalCSRPool(**kwargs).to(DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen).to(DEV) * 0.4)
+    import copy
+    m2 = copy.deepcopy(m)
+    m2.save_last = True                     # forces the generic (torch-composed) E_map path
+    x_mod = torch.randn(V, C, generator=gen).to(DEV)
+    x_map = torch.rand(V, 8, generator=gen).to(DEV)
+    w = torch.randn(N, C, generator=gen).to(DEV)
+    for train in (True, False):
+        m.train(train), m2.train(train)
+        out = m(None, x_mod, x_map, csr)
+        out2 = m2(None, x_mod, x_map, csr)
+        close(out, out2, rtol=1e-3, atol=1e-4)
+        g1 = torch.autograd.grad((out * w).sum(), list(m.parameters()))
+        g2 = torch.autograd.grad((out2 * w).sum(), list(m2.parameters()))
+        for (n, _), a, b in zip(m.named_parameters(), g1, g2):
+            scale = float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) / scale < 2e-3, (n, float((a - b).abs().max()), scale)
+    for (k, a), b in zip(m.state_dict().items(), m2.state_dict().values()):
+        if "running" in k:
+            close(a, b, rtol=1e-4, atol=1e-5)
