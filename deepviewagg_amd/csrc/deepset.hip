@@ -39,25 +39,35 @@ __device__ __forceinline__ float bn_z(float a, const BNc& b) { return bn_hat(a, 
 __device__ __forceinline__ float leaky(float z) { return z > 0.f ? z : SLOPE * z; }
 __device__ __forceinline__ float dleaky(float z) { return z > 0.f ? 1.f : SLOPE; }
 
+// Intra-wavefront LDS hand-off.  The DS instructions of one wavefront execute in program order, so
+// a later ds_read sees an earlier ds_write of another lane of the same wavefront; only the compiler
+// must be kept from reordering.  Deliberately NOT a memory fence: a release fence waits for
+// vmcnt(0), i.e. for the tile's global STORES to be acknowledged before the next tile's loads can
+// issue, which made the first version of these kernels latency-bound (17 us per tile per wave).
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // sum_k row[k] * w[k], k ascending, row broadcast from LDS
 template <int K>
 __device__ __forceinline__ float dot_row(const float* __restrict__ row, const float (&w)[K]) {
-  float acc = 0.f;
+  // two independent fma chains (even / odd float4 blocks) halve the dependent-latency exposure
+  float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-  for (int k4 = 0; k4 < K / 4; ++k4) {
+  for (int k4 = 0; k4 < K / 4; k4 += 2) {
     const float4 x = *reinterpret_cast<const float4*>(row + 4 * k4);
-    acc = fmaf(x.x, w[4 * k4], acc);
-    acc = fmaf(x.y, w[4 * k4 + 1], acc);
-    acc = fmaf(x.z, w[4 * k4 + 2], acc);
-    acc = fmaf(x.w, w[4 * k4 + 3], acc);
+    const float4 y = *reinterpret_cast<const float4*>(row + 4 * k4 + 4);
+    acc0 = fmaf(x.x, w[4 * k4], acc0);
+    acc1 = fmaf(y.x, w[4 * k4 + 4], acc1);
+    acc0 = fmaf(x.y, w[4 * k4 + 1], acc0);
+    acc1 = fmaf(y.y, w[4 * k4 + 5], acc1);
+    acc0 = fmaf(x.z, w[4 * k4 + 2], acc0);
+    acc1 = fmaf(y.z, w[4 * k4 + 6], acc1);
+    acc0 = fmaf(x.w, w[4 * k4 + 3], acc0);
+    acc1 = fmaf(y.w, w[4 * k4 + 7], acc1);
   }
-  return acc;
+  return acc0 + acc1;
 }
 
 // Add the two row-parity halves, then accumulate per-block partials into double accumulators.
