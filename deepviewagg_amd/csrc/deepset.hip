@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void dsf_fwd_layer_kernel(
     const float* __restrict__ addend, const int32_t* __restrict__ vp, float* __restrict__ a_out,
     double* __restrict__ stats, int64_t V) {
   __shared__ __attribute__((aligned(16))) float s_in[4][TILE * D];
+  __shared__ float s_add[HAS_ADD ? 4 : 1][HAS_ADD ? TILE * D : 1];
   __shared__ float s_red[2 * D];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
   const BNc b = load_bn(bn_in, n);
@@ -202,10 +203,24 @@ __global__ __launch_bounds__(256) void dsf_fwd_layer_kernel(
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t row0 = t * TILE;
+    // load phase: every global load of the tile is issued before the first use (the per-point
+    // addend is a dependent load through vp: two latencies per tile instead of one per row)
+    float av[16];
+    int32_t pv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t r = row0 + 2 * i + h;
-      s_in[wv][(2 * i + h) * D + n] = r < V ? leaky(bn_z(a_in[r * D + n], b)) : 0.f;
+      av[i] = r < V ? a_in[r * D + n] : 0.f;
+      if (HAS_ADD) pv[i] = r < V ? vp[r] : 0;
+    }
+    if (HAS_ADD) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_add[wv][(2 * i + h) * D + n] = addend[(int64_t)pv[i] * D + n];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = row0 + 2 * i + h;
+      s_in[wv][(2 * i + h) * D + n] = r < V ? leaky(bn_z(av[i], b)) : 0.f;
     }
     wave_sync();
 #pragma unroll 2
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(256) void dsf_fwd_layer_kernel(
       const int64_t r = row0 + 2 * i + h;
       float acc = dot_row<D>(&s_in[wv][(2 * i + h) * D], w);
       if (r < V) {
-        if (HAS_ADD) acc += addend[(int64_t)vp[r] * D + n];
+        if (HAS_ADD) acc += s_add[wv][(2 * i + h) * D + n];
         a_out[r * D + n] = acc;
         st[0] += acc;
         st[1] += acc * acc;
@@ -280,30 +295,39 @@ __global__ __launch_bounds__(256) void dsf_bwd_score_kernel(
   }
 #pragma unroll
   for (int j = 0; j < 2 + GMAX; ++j) acc[j] = 0.f;
-  const int64_t pairs = (V + 1) / 2;
+  constexpr int RP = GMAX <= 8 ? 8 : 1;  // row pairs per iteration (independent loads in flight)
+  const int64_t chunks = (V + 2 * RP - 1) / (2 * RP);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t q = wave; q < pairs; q += n_waves) {
-    const int64_t r = 2 * q + h;
-    if (r >= V) continue;
-    const float av = a[r * D + n];
-    const float ah = bn_hat(av, b);
-    const float z = ah * b.gamma + b.beta;
-    const float x = leaky(z);
-    float dx = 0.f;
+  for (int64_t q = wave; q < chunks; q += n_waves) {
+    float avs[RP], dcs[RP][GMAX];
 #pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-      if (g < G) {
-        const float dc = dcompat[r * G + g];
+    for (int j = 0; j < RP; ++j) {
+      const int64_t r = (q * RP + j) * 2 + h;
+      avs[j] = r < V ? a[r * D + n] : 0.f;
+#pragma unroll
+      for (int g = 0; g < GMAX; ++g) dcs[j][g] = (g < G && r < V) ? dcompat[r * G + g] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+      const int64_t r = (q * RP + j) * 2 + h;
+      if (r >= V) continue;
+      const float ah = bn_hat(avs[j], b);
+      const float z = ah * b.gamma + b.beta;
+      const float x = leaky(z);
+      float dx = 0.f;
+#pragma unroll
+      for (int g = 0; g < GMAX; ++g) {
+        const float dc = dcs[j][g];
         dx = fmaf(dc, ws[g], dx);
         acc[2 + g] = fmaf(dc, x, acc[2 + g]);
         dbacc[g] += dc;
       }
+      const float d = dx * dleaky(z);
+      dz[r * D + n] = d;
+      acc[0] += d;
+      acc[1] = fmaf(d, ah, acc[1]);
     }
-    const float d = dx * dleaky(z);
-    dz[r * D + n] = d;
-    acc[0] += d;
-    acc[1] = fmaf(d, ah, acc[1]);
   }
   // S1, S2 (double) and dWs (float) through the block reduction
   const int nn = lane & 31;
@@ -459,21 +483,39 @@ __global__ __launch_bounds__(256) void dsf_bwd_max_kernel(
   const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
   const BNc b = load_bn(bn2, n);
   float acc[2] = {0.f, 0.f};
-  const int64_t pairs = (V + 1) / 2;
+  const int64_t tiles = (V + TILE - 1) / TILE;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t q = wave; q < pairs; q += n_waves) {
-    const int64_t r = 2 * q + h;
-    if (r >= V) continue;
-    const int64_t p = vp[r];
-    float g = dcat[r * D + n];
-    if ((int64_t)arg[p * D + n] == r) g += dpooled[p * D + n];
-    const float ah = bn_hat(a2[r * D + n], b);
-    const float z = ah * b.gamma + b.beta;
-    const float d = g * dleaky(z);
-    dz2[r * D + n] = d;
-    acc[0] += d;
-    acc[1] = fmaf(d, ah, acc[1]);
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * TILE;
+    float gv[16], av[16], dp[16];
+    int32_t pv[16], ag[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = row0 + 2 * i + h;
+      const bool ok = r < V;
+      pv[i] = ok ? vp[r] : 0;
+      gv[i] = ok ? dcat[r * D + n] : 0.f;
+      av[i] = ok ? a2[r * D + n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ag[i] = arg[(int64_t)pv[i] * D + n];
+      dp[i] = dpooled[(int64_t)pv[i] * D + n];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = row0 + 2 * i + h;
+      if (r >= V) continue;
+      float g = gv[i];
+      if ((int64_t)ag[i] == r) g += dp[i];
+      const float ah = bn_hat(av[i], b);
+      const float z = ah * b.gamma + b.beta;
+      const float d = g * dleaky(z);
+      dz2[r * D + n] = d;
+      acc[0] += d;
+      acc[1] = fmaf(d, ah, acc[1]);
+    }
   }
   flush_channel_sums<2>(acc, st, s_red, lane);
 }

@@ -121,7 +121,7 @@ class _DeepSetLinear(torch.autograd.Function):
         t_det = t_add.detach().contiguous()
         a3 = torch.empty((V, D), dtype=torch.float32, device=dev)
         s3 = zstats()
-        with ops._timed("deepset_fwd_layer", V * (128 + 4 + 128) + N * 128):
+        with ops._timed("deepset_fwd_layer_add", V * (128 + 4 + 128) + N * 128):
             check(lib.dva_deepset_fwd_layer(ptr(a2), ptr(bn2), ptr(WcA), ptr(t_det), ptr(vp), ptr(a3), ptr(s3), V, st),
                   "dva_deepset_fwd_layer")
         bn3 = _bn_consts(s3, V, bns[2], training)
@@ -185,7 +185,7 @@ class _DeepSetLinear(torch.autograd.Function):
         dcat, dWcA = buf(), torch.zeros_like(WcA)
         dt = torch.zeros((N, D), dtype=torch.float32, device=dev)
         sm3 = sm_of(s3)
-        with ops._timed("deepset_bwd_layer", V * (128 * 4 + 4) + N * 128):
+        with ops._timed("deepset_bwd_layer_cat", V * (128 * 4 + 4) + N * 128):
             check(lib.dva_deepset_bwd_layer(ptr(dz3), ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2), None, ptr(bn2),
                                             ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, st),
                   "dva_deepset_bwd_layer")
@@ -208,7 +208,7 @@ class _DeepSetLinear(torch.autograd.Function):
         # Wb layer (a1 -> a2), a1 recomputed from x_map
         dz1, s1, dWb = buf(), zstats(), torch.zeros_like(Wb)
         sm2 = sm_of(s2)
-        with ops._timed("deepset_bwd_layer", V * (128 * 3 + 32)):
+        with ops._timed("deepset_bwd_layer_xmap", V * (128 * 3 + 32)):
             check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
                                             ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, st),
                   "dva_deepset_bwd_layer")
