@@ -1,0 +1,186 @@
+"""-m gpu: host data classes + orchestrator on the HIP device against the reference's golden vectors:
+ImageMapping.from_dense / select_points, SameSettingImageData.get_mapped_features, MapImages,
+UnimodalBranch forward + backward, ImageBatch round trip."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t, state_dict_from
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    if isinstance(b, np.ndarray):
+        b = t(b)
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+def eq(a, b):
+    assert np.array_equal(a.cpu().numpy(), b), (a.shape, b.shape)
+
+
+def mapping_equals(m, g, prefix=""):
+    eq(m.pointers, g[prefix + "pointers"])
+    eq(m.images, g[prefix + "images"])
+    eq(m.values[1].pointers, g[prefix + "atom_pointers"])
+    assert m.pixels.dtype == torch.int16
+    eq(m.pixels, g[prefix + "pixels"])
+    key = prefix + ("features" if (prefix + "features") in g else "map_features")
+    np.testing.assert_allclose(m.features.cpu().numpy(), g[key], rtol=0, atol=3e-7)
+    assert m.is_index_value.tolist() == [True, False, False]
+    m.debug()
+
+
+@pytest.mark.parametrize("name", ["gather", "gather_multipixel"])
+def test_from_dense_matches_reference(name):
+    from deepviewagg_amd.core.multimodal.image import ImageMapping
+    g = load_golden(name)
+    n_pts = len(g["pointers"]) - 1
+    m = ImageMapping.from_dense(t(g["point_ids"], DEV), t(g["image_ids"], DEV), t(g["pixels_dense"], DEV),
+                                t(g["map_features_dense"], DEV), num_points=n_pts)
+    mapping_equals(m, g)
+    # CPU inputs are uploaded, the mapping comes back on the CPU
+    m2 = ImageMapping.from_dense(t(g["point_ids"]), t(g["image_ids"]), t(g["pixels_dense"]),
+                                 t(g["map_features_dense"]), num_points=n_pts)
+    assert m2.device.type == "cpu" and torch.equal(m2.pointers, m.pointers.cpu())
+
+
+def test_select_points_pick_and_merge_match_reference():
+    from deepviewagg_amd.core.multimodal.image import ImageMapping
+    g = load_golden("mapping_build")
+    n_pts = len(g["pointers"]) - 1
+    m = ImageMapping.from_dense(t(g["dense_point_ids"], DEV), t(g["dense_image_ids"], DEV),
+                                t(g["dense_pixels"], DEV), t(g["dense_features"], DEV), num_points=n_pts)
+    mapping_equals(m, g)
+    mapping_equals(m.select_points(t(g["pick_idx"], DEV), mode="pick"), g, "pick_")
+    mapping_equals(m.select_points(t(g["merge_idx"], DEV), mode="merge"), g, "merge_")
+    # select_images keeps pointers length and renumbers
+    sub = m.select_images([2, 0])
+    assert sub.num_groups == m.num_groups and set(sub.images.unique().tolist()) <= {0, 1}
+    sub.debug()
+
+
+def make_image_data(g, prefix, x, ref_size, dev):
+    from deepviewagg_amd.core.multimodal.image import ImageMapping, SameSettingImageData
+    n_pts = len(g[prefix + "pointers"]) - 1
+    m = ImageMapping.from_dense(t(g[prefix + "point_ids"], dev), t(g[prefix + "image_ids"], dev),
+                                t(g[prefix + "pixels_dense"], dev), t(g[prefix + "map_features_dense"], dev),
+                                num_points=n_pts)
+    B = x.shape[0]
+    sd = SameSettingImageData(path=np.array([f"img_{i}" for i in range(B)]), pos=torch.zeros(B, 3, device=dev),
+                              opk=torch.zeros(B, 3, device=dev), ref_size=tuple(int(v) for v in ref_size),
+                              proj_upscale=1, mappings=m)
+    sd.x = x
+    return sd
+
+
+def test_get_mapped_features_matches_reference():
+    from deepviewagg_amd import ops
+    g = load_golden("gather")
+    x = t(g["x"], DEV).requires_grad_()
+    sd = make_image_data(g, "", x, g["mapping_size"], DEV)
+    assert float(sd.downscale) == float(g["downscale"]) and sd.img_size == (16, 8)
+    lazy = sd.get_mapped_features(interpolate=False)
+    assert isinstance(lazy, ops.GatheredFeatures) and lazy.exact
+    out = lazy.materialize()
+    assert torch.equal(out.cpu(), t(g["out_nearest"]))
+    (gr,) = torch.autograd.grad((out * t(g["w_nearest"], DEV)).sum(), x)
+    close(gr, g["grad_x_nearest"])
+    out = sd.get_mapped_features(interpolate=True)
+    close(out, g["out_bilinear"], rtol=1e-6, atol=1e-6)
+    # reference indexing tuple still available for user code
+    idx = sd.feature_map_indexing
+    assert idx[0].shape[0] == sd.mappings.num_atoms and idx[1] is Ellipsis
+
+
+class Conv(torch.nn.Module):
+    """same tiny 2D encoder as oracle/gen_golden.py::_RefConv"""
+
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(c_in, c_out, 3, stride=2, padding=1)
+
+    def forward(self, x, reset=True):
+        return torch.relu(self.conv(x))
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_unimodal_branch_matches_reference(mode):
+    from deepviewagg_amd.core.multimodal.image import ImageData
+    from deepviewagg_amd.modules.multimodal import (UnimodalBranch, BimodalCSRPool, GroupBimodalCSRPool,
+                                                    BimodalFusion)
+    g = load_golden(f"branch_{mode}")
+    n_set = int(g["n_settings"])
+    xs = [t(g[f"s{i}_x_img"], DEV).requires_grad_() for i in range(n_set)]
+    sds = [make_image_data(g, f"s{i}_", xs[i], g[f"s{i}_ref_size"], DEV) for i in range(n_set)]
+    conv = Conv(6, 8)
+    conv.load_state_dict(state_dict_from(g, "sd_conv/"))
+    pool = GroupBimodalCSRPool(in_map=8, in_mod=8, num_groups=4, use_num=True)
+    pool.load_state_dict(state_dict_from(g, "sd_pool/"))
+    branch = UnimodalBranch(conv, BimodalCSRPool(mode="max"), pool, BimodalFusion(mode="concatenation"),
+                            interpolate=(mode == "bilinear")).to(DEV).train()
+    x_3d = t(g["x_3d"], DEV).requires_grad_()
+    mm = {"x_3d": x_3d, "x_seen": None, "modalities": {"image": ImageData(sds)}}
+    out = branch(mm, "image")
+    y = out["x_3d"]
+    close(y, g["out"], rtol=1e-3, atol=1e-4)
+    eq(out["x_seen"], g["x_seen"])
+    grads = torch.autograd.grad((y * t(g["w"], DEV)).sum(), xs + [x_3d])
+    for i in range(n_set):
+        close(grads[i], g[f"s{i}_grad_x_img"], rtol=2e-3, atol=2e-4)
+    close(grads[-1], g["grad_x_3d"], rtol=1e-4, atol=1e-5)
+    assert branch.out_channels == y.shape[1]
+    # empty-modality contract (reference modules.py:314-365): x_3d is zero-padded to out_channels
+    empty = [sd[[]] for sd in sds]
+    for e, sd in zip(empty, sds):
+        e._x = torch.zeros((0,) + tuple(sd.x.shape[1:]), device=DEV)
+    mm2 = {"x_3d": t(g["x_3d"], DEV), "x_seen": None, "modalities": {"image": ImageData(empty)}}
+    y2 = branch(mm2, "image")["x_3d"]
+    assert y2.shape == y.shape and float(y2[:, 5:].abs().sum()) == 0
+
+
+def test_map_images_matches_reference():
+    """MapImages on the HIP device == the reference's per-image loop + from_dense (mapping_build.npz)."""
+    from deepviewagg_amd.core.data_transform.multimodal import MapImages
+    from deepviewagg_amd.core.multimodal.image import SameSettingImageData
+    g = load_golden("mapping_build")
+    n = g["xyz"].shape[0]
+    data = SimpleNamespace(pos=t(g["xyz"]), mapping_index=torch.arange(n), linearity=t(g["linearity"]),
+                           planarity=t(g["planarity"]), scattering=t(g["scattering"]), norm=t(g["normals"]))
+    cams = t(g["cams"])
+    images = SameSettingImageData(path=np.array([f"i{i}" for i in range(len(cams))]), pos=cams,
+                                  opk=torch.zeros(len(cams), 3), ref_size=tuple(int(v) for v in g["ref_size"]),
+                                  proj_upscale=int(g["proj_upscale"]))
+    tr = MapImages(method="SplattingVisibility", r_max=10.0, r_min=0.2, voxel=0.05, k_swell=1.0, d_swell=1000,
+                   exact=True)
+    _, out = tr(data, images)
+    assert out.num_views == len(g["seen_images"])          # the far-away camera sees nothing and is dropped
+    mapping_equals(out.mappings, g)
+    assert out.visibility.exact and out.mappings.device.type == "cpu"
+
+
+def test_image_batch_round_trip():
+    """The reference's own self-check (core/multimodal/image.py:2350-2390): batch -> unbatch == input."""
+    from deepviewagg_amd.core.multimodal.image import ImageBatch, ImageData
+    g = load_golden("branch_nearest")
+
+    def build(shift):
+        xs = [t(g[f"s{i}_x_img"], DEV) + shift for i in range(2)]
+        return ImageData([make_image_data(g, f"s{i}_", xs[i], g[f"s{i}_ref_size"], DEV) for i in range(2)])
+    items = [build(0.0), build(1.0), build(2.0)]
+    batch = ImageBatch.from_data_list(items)
+    assert batch.num_points == 3 * items[0].num_points and len(batch) == 2
+    for sd in batch:
+        sd.mappings.debug()
+    back = batch.to_data_list()
+    for a, b in zip(items, back):
+        for sa, sb in zip(a, b):
+            assert torch.equal(sa.x, sb.x)
+            assert torch.equal(sa.mappings.pointers, sb.mappings.pointers)
+            assert torch.equal(sa.mappings.images, sb.mappings.images)
+            assert torch.equal(sa.mappings.pixels, sb.mappings.pixels)
+            assert torch.equal(sa.mappings.features, sb.mappings.features)
