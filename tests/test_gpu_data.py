@@ -23,12 +23,24 @@ def eq(a, b):
     assert np.array_equal(a.cpu().numpy(), b), (a.shape, b.shape)
 
 
+def canonical_pixels(pixels, atom_ptr):
+    """Pixel order INSIDE a view is unspecified in the reference (unstable np.argsort on the
+    (point, image) key, utils/multimodal.py:316; SURVEY.md par. 7): compare views as sorted sets."""
+    pixels, atom_ptr = np.asarray(pixels).astype(np.int64), np.asarray(atom_ptr)
+    view = np.repeat(np.arange(len(atom_ptr) - 1), np.diff(atom_ptr))
+    order = np.lexsort((pixels[:, 1], pixels[:, 0], view))
+    return pixels[order]
+
+
 def mapping_equals(m, g, prefix=""):
     eq(m.pointers, g[prefix + "pointers"])
     eq(m.images, g[prefix + "images"])
     eq(m.values[1].pointers, g[prefix + "atom_pointers"])
     assert m.pixels.dtype == torch.int16
-    eq(m.pixels, g[prefix + "pixels"])
+    assert np.array_equal(canonical_pixels(m.pixels.cpu().numpy(), m.values[1].pointers.cpu().numpy()),
+                          canonical_pixels(g[prefix + "pixels"], g[prefix + "atom_pointers"]))
+    if m.is_exact:
+        eq(m.pixels, g[prefix + "pixels"])      # one pixel per view: order fully determined
     key = prefix + ("features" if (prefix + "features") in g else "map_features")
     np.testing.assert_allclose(m.features.cpu().numpy(), g[key], rtol=0, atol=3e-7)
     assert m.is_index_value.tolist() == [True, False, False]
