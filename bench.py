@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-points", type=int, default=14)
+    ap.add_argument("--cpu-log2-points", type=int, default=12)
     return ap.parse_args()
 
 
@@ -98,20 +98,6 @@ def step(scene, packed, mods, dtype, lazy=True):
     return loss
 
 
-def allreduce_grads(params, world):
-    """Data-parallel gradient reduction: one flat bucket, RCCL all-reduce (sum), average."""
-    if world == 1:
-        return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat)
-    flat /= world
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
-
-
 def cpu_baseline(log2_points, views, C, threads):
     """The oracle (plain PyTorch on the host cores) on a bounded sample of the same workload."""
     from oracle import pooling_oracle as O
@@ -137,7 +123,7 @@ def cpu_baseline(log2_points, views, C, threads):
         out.square().mean().backward()
     one()  # warm-up
     t0 = time.perf_counter()
-    reps = 2
+    reps = 1
     for _ in range(reps):
         one()
     dt = (time.perf_counter() - t0) / reps
@@ -165,7 +151,8 @@ def main():
     N, views, C, H, W = 1 << args.log2_points, args.views, args.channels, 64, 128
     scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank)
     mods = build_modules(C, device)
-    params = list(mods[1].parameters())
+    from deepviewagg_amd.parallel import GradientBucket
+    bucket = GradientBucket(mods[1].parameters())
     packed = None  # built inside every step
 
     def barrier():
@@ -176,13 +163,13 @@ def main():
 
     for _ in range(args.warmup):
         step(scene, packed, mods, dtype)
-        allreduce_grads(params, world)
+        bucket.reduce(average=True)
     barrier()
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(scene, packed, mods, dtype)
-        allreduce_grads(params, world)
+        bucket.reduce(average=True)
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
@@ -221,7 +208,7 @@ def main():
             "loss": float(loss.item()),
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, os.cpu_count() or 1)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

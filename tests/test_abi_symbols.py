@@ -1,0 +1,45 @@
+"""CPU test: libdva_hip.so loads (no GPU needed) and exports every entry point include/dva.h declares;
+the ctypes table in deepviewagg_amd/_lib.py covers exactly the same set.  No compute calls here."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from deepviewagg_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dva.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dva_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree():
+    names = declared_symbols()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in dva.h but not exported: {missing}"
+    assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
+
+
+def test_library_loads_and_reports_version_without_gpu():
+    lib = _lib.load()
+    assert lib.dva_version() >= 100
+    assert lib.dva_device_count() >= 0
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any HIP call (error codes, no exceptions across the ABI)."""
+    lib = _lib.load()
+    assert lib.dva_segment_csr_fwd(None, None, None, None, 4, 3, 0, 0, None) == -1      # null ptr
+    assert lib.dva_segment_csr_fwd(None, None, None, None, -1, 3, 0, 0, None) == -1     # negative size
+    assert lib.dva_deepset_fwd_first(None, None, None, None, None, None, 0, 5, 1, None) == -1
+    assert lib.dva_pack_gather_index(None, None, None, 2, 0.5, 1, 1, None, None) == -1  # ratio < 1
+
+
+def test_camera_struct_layout_matches_oracle():
+    """struct dva_camera (product) and struct dvo_camera (oracle) must stay byte-compatible."""
+    from oracle import mapping_oracle as M
+    assert ctypes.sizeof(_lib.DvaCamera) == ctypes.sizeof(M.Camera)
+    assert [f[0] for f in _lib.DvaCamera._fields_] == [f[0] for f in M.Camera._fields_]
