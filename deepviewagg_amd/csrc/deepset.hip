@@ -591,6 +591,17 @@ static inline int grid_rows(int64_t V) {
   return (int)b;
 }
 
+// fp32-MFMA generation of the layer kernels (deepset_mfma.hip)
+int dsm_launch_fwd_first(const float*, const float*, const float*, const float*, float*, double*, int64_t,
+                         int, hipStream_t);
+int dsm_launch_fwd_layer(const float*, const float*, const float*, const float*, const int32_t*, float*,
+                         double*, int64_t, hipStream_t);
+int dsm_launch_fwd_score(const float*, const float*, const float*, const float*, float*, int64_t, int,
+                         hipStream_t);
+int dsm_launch_bwd_layer(const float*, const float*, const float*, const float*, const float*, const float*,
+                         const float*, const float*, float*, float*, double*, float*, const int32_t*,
+                         int64_t, int, int, hipStream_t);
+
 }  // namespace dva
 
 using namespace dva;
@@ -611,12 +622,18 @@ int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, 
 
 int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb,
                           float* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
-                          void* stream) {
+                          int32_t algo, void* stream) {
   if (V < 0 || !stats) return DVA_ERR_INVALID;
   if (F != 8) return DVA_ERR_UNSUPPORTED;
   if (V == 0) return DVA_OK;
   if (!x_map || !Wa) return DVA_ERR_INVALID;
+  if (!stats_only && (!bn1 || !Wb || !a2)) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
+  if (algo != 1) {
+    dsm_launch_fwd_first(x_map, Wa, bn1, Wb, a2, stats, V, stats_only, s);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   if (stats_only) {
     hipLaunchKernelGGL((dsf_fwd_first_kernel<true>), dim3(grid_rows(V)), dim3(256), 0, s, x_map, Wa,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, stats, V);
@@ -644,12 +661,17 @@ int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, floa
 
 int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
                           const int32_t* group_of_row, float* a_out, double* stats, int64_t V,
-                          void* stream) {
+                          int32_t algo, void* stream) {
   if (V < 0 || !stats) return DVA_ERR_INVALID;
   if (V == 0) return DVA_OK;
   if (!a_in || !bn_in || !W || !a_out) return DVA_ERR_INVALID;
   if (addend && !group_of_row) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
+  if (algo != 1) {
+    dsm_launch_fwd_layer(a_in, bn_in, W, addend, group_of_row, a_out, stats, V, s);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   if (addend)
     hipLaunchKernelGGL((dsf_fwd_layer_kernel<true>), dim3(grid_rows(V)), dim3(256), 0, s, a_in, bn_in, W,
                        addend, group_of_row, a_out, stats, V);
@@ -661,10 +683,15 @@ int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W,
 }
 
 int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs,
-                          float* compat, int64_t V, int32_t G, void* stream) {
+                          float* compat, int64_t V, int32_t G, int32_t algo, void* stream) {
   if (V < 0 || G <= 0 || G > 32) return DVA_ERR_INVALID;
   if (V == 0) return DVA_OK;
   if (!a || !bn || !Ws || !bs || !compat) return DVA_ERR_INVALID;
+  if (algo != 1) {
+    dsm_launch_fwd_score(a, bn, Ws, bs, compat, V, G, (hipStream_t)stream);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   int GP = 1;
   while (GP < G) GP <<= 1;
   hipLaunchKernelGGL(dsf_fwd_score_kernel, dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream, a, bn,
@@ -694,7 +721,7 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
                           const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
                           float* out, float* dW, double* st_prev, float* dt,
                           const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
-                          int32_t raw_out, void* stream) {
+                          int32_t raw_out, int32_t algo, void* stream) {
   if (V < 0) return DVA_ERR_INVALID;
   if (V == 0) return DVA_OK;
   if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || !bn_prev || !out || !dW)
@@ -703,6 +730,12 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
   if (prev_is_xmap && !Wa) return DVA_ERR_INVALID;
   if (dt && !group_of_row) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
+  if (algo != 1) {
+    dsm_launch_bwd_layer(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt,
+                         group_of_row, V, prev_is_xmap, raw_out, s);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   const dim3 grid(grid_rows(V)), block(256);
 #define DVA_L(P, R)                                                                                \
   hipLaunchKernelGGL((dsf_bwd_layer_kernel<P, R>), grid, block, 0, s, dz_L, a_L, bn_L, sm_L, W_L,  \

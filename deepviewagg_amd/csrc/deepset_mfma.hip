@@ -1,0 +1,447 @@
+// DeepSetFeat layer kernels on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 fma chain).
+//
+// Second generation of the row-streaming kernels of deepset.hip.  The first generation broadcast the
+// inputs of a row to 32 lanes through LDS and spent 32 v_fmac + 8 ds_read_b128 per row pair: rocprofv3
+// showed ~1000-1600 VALU and ~150-350 LDS instructions per 32-row tile, i.e. LDS/VALU-bound at ~2 TB/s
+// of HBM traffic.  Here one wavefront owns a 32-view tile and every 32x32 product is 16 MFMA
+// instructions whose operands are the registers the global loads landed in:
+//
+//   D[i][j] += sum_{kk<2} A[i][kk] * B[kk][j];  lane l supplies A[i=l&31][kk=l>>5], B[kk=l>>5][j=l&31];
+//   lane l holds D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31] in register r (r < 16).
+//
+// view-major products (forward, dx):  j = view, i = output channel, k-step s pairs input channels
+//   (s, s+16): lane (v, h) loads ITS half row X[v][16h .. 16h+16) as 4 float4 (BN + LeakyReLU applied in
+//   registers) and lane (n, h) holds W[n][16h + s].  The result lands as 4 groups of 4 consecutive
+//   channels per lane -> float4 stores.  Chaining a second layer needs no data movement: k-step r of
+//   the next product pairs channels (n(r,0), n(r,1)), which is exactly register r of the two half-waves.
+// channel-major product (weight gradient): i = n, j = k, k-step s pairs views (2s, 2s+1): plain
+//   coalesced row loads, the 16 accumulators live across all tiles of the wavefront.
+// No LDS on the data path; the matrix pipe needs 1024 cycles per product and tile, well below the HBM
+// time of a pass, so these kernels are HBM-bound.
+#include "dva_common.h"
+
+namespace dva {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DM = 32;
+constexpr float SLOPE_M = 0.2f;
+
+__device__ __forceinline__ float leaky_m(float z) { return z > 0.f ? z : SLOPE_M * z; }
+__device__ __forceinline__ float dleaky_m(float z) { return z > 0.f ? 1.f : SLOPE_M; }
+__device__ __forceinline__ int acc_chan(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// bn arrays are [4][32] = mean | invstd | gamma | beta.  Constants of the 16 channels of a half row
+// (c = 16h + s) or of the accumulator layout (c = acc_chan(r, h)).
+struct BN16 {
+  float mean[16], invstd[16], gamma[16], beta[16];
+};
+__device__ __forceinline__ void load_bn_half(const float* __restrict__ bn, int h, BN16& b) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int c = 16 * h + s;
+    b.mean[s] = bn[c]; b.invstd[s] = bn[DM + c]; b.gamma[s] = bn[2 * DM + c]; b.beta[s] = bn[3 * DM + c];
+  }
+}
+__device__ __forceinline__ void load_bn_acc(const float* __restrict__ bn, int h, BN16& b) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = acc_chan(r, h);
+    b.mean[r] = bn[c]; b.invstd[r] = bn[DM + c]; b.gamma[r] = bn[2 * DM + c]; b.beta[r] = bn[3 * DM + c];
+  }
+}
+
+__device__ __forceinline__ void load16(const float* __restrict__ p, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+  }
+}
+// accumulator layout <-> memory: 4 float4 at channels 8q + 4h
+__device__ __forceinline__ void load_acc_layout(const float* __restrict__ row, int h, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(row + 8 * q + 4 * h);
+    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void store_acc_layout(float* __restrict__ row, int h, const f32x16& a) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(row + 8 * q + 4 * h) =
+        make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
+// Sum vals[r] over the 32 lanes of a half-wave; lanes 0 / 32 then add channel acc_chan(r,h) to s_red.
+__device__ __forceinline__ void reduce_acc_channels(float (&vals)[16], float* s_red, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = vals[r];
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+    if ((lane & 31) == 0) atomicAdd(&s_red[acc_chan(r, lane >> 5)], v);
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restrict__ out, float* s_red,
+                                            int lane) {
+  for (int i = threadIdx.x; i < NV * DM; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) reduce_acc_channels(st[j], s_red + j * DM, lane);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * DM; i += blockDim.x) atomicAdd(&out[i], (double)s_red[i]);
+}
+
+#define DVA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+
+// x_map [V,8] -> a1 (stats only) or -> a1 -> BN1 -> leaky -> a2 (written, with stats)
+template <bool STATS_ONLY>
+__global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restrict__ x_map,
+                                                             const float* __restrict__ Wa,
+                                                             const float* __restrict__ bn1,
+                                                             const float* __restrict__ Wb,
+                                                             float* __restrict__ a2,
+                                                             double* __restrict__ stats, int64_t V) {
+  __shared__ float s_red[2 * DM];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  float wa[4];  // Wa[n=j][4h + s]
+#pragma unroll
+  for (int s = 0; s < 4; ++s) wa[s] = Wa[j * 8 + 4 * h + s];
+  float wb[16];  // Wb[n2=j][acc_chan(r,h)]
+  BN16 b1;
+  if (!STATS_ONLY) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wb[r] = Wb[j * DM + acc_chan(r, h)];
+    load_bn_acc(bn1, h, b1);
+  }
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  const int64_t tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t v = t * 32 + j;
+    const bool ok = v < V;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) x = *reinterpret_cast<const float4*>(x_map + v * 8 + 4 * h);
+    f32x16 acc = {0};
+    acc = DVA_MFMA(wa[0], x.x, acc);
+    acc = DVA_MFMA(wa[1], x.y, acc);
+    acc = DVA_MFMA(wa[2], x.z, acc);
+    acc = DVA_MFMA(wa[3], x.w, acc);
+    if (STATS_ONLY) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[0][r] += acc[r];            // rows beyond V are exact zeros
+        st[1][r] = fmaf(acc[r], acc[r], st[1][r]);
+      }
+    } else {
+      f32x16 acc2 = {0};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float z = (acc[r] - b1.mean[r]) * b1.invstd[r] * b1.gamma[r] + b1.beta[r];
+        const float tv = ok ? leaky_m(z) : 0.f;
+        acc2 = DVA_MFMA(wb[r], tv, acc2);
+      }
+      if (ok) store_acc_layout(a2 + v * DM, h, acc2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[0][r] += acc2[r];
+        st[1][r] = fmaf(acc2[r], acc2[r], st[1][r]);
+      }
+    }
+  }
+  flush_stats<2>(st, stats, s_red, lane);
+}
+
+// a_out[v] = leaky(BN_in(a_in[v])) . W^T (+ addend[vp[v]]) ; statistics of a_out.
+// SCORE: W has G <= 32 valid rows (others zero), bias added, only columns < G stored, no statistics.
+template <bool HAS_ADD, bool SCORE>
+__global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
+    const float* __restrict__ a_in, const float* __restrict__ bn_in, const float* __restrict__ W,
+    const float* __restrict__ addend, const int32_t* __restrict__ vp, const float* __restrict__ bias,
+    float* __restrict__ a_out, double* __restrict__ stats, int64_t V, int G) {
+  __shared__ float s_red[2 * DM];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  BN16 b;
+  load_bn_half(bn_in, h, b);
+  float w[16];  // W[n=j][16h + s]
+#pragma unroll
+  for (int s = 0; s < 16; ++s) w[s] = (!SCORE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
+  float bia[16];
+  if (SCORE) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bia[r] = acc_chan(r, h) < G ? bias[acc_chan(r, h)] : 0.f;
+  }
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  const int64_t tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t v = t * 32 + j;
+    const bool ok = v < V;
+    float x[16];
+    if (ok) {
+      load16(a_in + v * DM + 16 * h, x);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) x[s] = 0.f;
+    }
+    float ad[16];
+    if (HAS_ADD) {
+      const int64_t p = ok ? (int64_t)vp[v] : 0;
+      load_acc_layout(addend + p * DM, h, ad);
+    }
+    f32x16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float z = (x[s] - b.mean[s]) * b.invstd[s] * b.gamma[s] + b.beta[s];
+      acc = DVA_MFMA(w[s], ok ? leaky_m(z) : 0.f, acc);
+    }
+    if (SCORE) {
+      if (ok) {
+        if (G == 4) {
+          if (h == 0)
+            *reinterpret_cast<float4*>(a_out + v * 4) =
+                make_float4(acc[0] + bia[0], acc[1] + bia[1], acc[2] + bia[2], acc[3] + bia[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (acc_chan(r, h) < G) a_out[v * G + acc_chan(r, h)] = acc[r] + bia[r];
+        }
+      }
+    } else {
+      if (ok) {
+        if (HAS_ADD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] += ad[r];
+        }
+        store_acc_layout(a_out + v * DM, h, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[0][r] += acc[r];
+          st[1][r] = fmaf(acc[r], acc[r], st[1][r]);
+        }
+      }
+    }
+  }
+  if (!SCORE) flush_stats<2>(st, stats, s_red, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (same contract as dsf_bwd_layer_kernel in deepset.hip)
+// ------------------------------------------------------------------------------------------------
+template <bool PREV_XMAP, bool RAW_OUT>
+__global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
+    const float* __restrict__ dz_L, const float* __restrict__ a_L, const float* __restrict__ bn_L,
+    const float* __restrict__ sm_L, const float* __restrict__ W_L, const float* __restrict__ a_prev,
+    const float* __restrict__ Wa, const float* __restrict__ bn_prev, float* __restrict__ out,
+    float* __restrict__ dW, double* __restrict__ st_prev, float* __restrict__ dt,
+    const int32_t* __restrict__ vp, int64_t V) {
+  __shared__ float s_red[DM * DM];
+  __shared__ float s_c[5][DM];  // BN_L constants by channel: gsc | mean | invstd | S1/M | S2/M
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  if (threadIdx.x < DM) {
+    const int c = threadIdx.x;
+    s_c[0][c] = bn_L[2 * DM + c] * bn_L[DM + c];
+    s_c[1][c] = bn_L[c];
+    s_c[2][c] = bn_L[DM + c];
+    s_c[3][c] = sm_L[c];
+    s_c[4][c] = sm_L[DM + c];
+  }
+  __syncthreads();
+  // own-channel constants (channel-major phase): channel j of BN_L and of BN_prev
+  const float cg = s_c[0][j], cm = s_c[1][j], ci = s_c[2][j], c1 = s_c[3][j], c2 = s_c[4][j];
+  const float pm = bn_prev[j], pi = bn_prev[DM + j], pg = bn_prev[2 * DM + j], pb = bn_prev[3 * DM + j];
+  BN16 bp;  // BN_prev constants in accumulator layout (view-major phase)
+  load_bn_acc(bn_prev, h, bp);
+  float wt[16];  // W_L[n = 16h + s][k = j]
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
+  float wa4[4], wa8[8];
+  if (PREV_XMAP) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wa4[s] = Wa[j * 8 + 4 * h + s];  // view-major recompute of a1
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wa8[s] = Wa[j * 8 + s];          // channel-major recompute of a1[., j]
+  }
+  f32x16 accW = {0};
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+
+  const int64_t tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * 32;
+    // ---------------- view-major: dx = da . W_L, then dz_prev
+    {
+      const int64_t v = row0 + j;
+      const bool ok = v < V;
+      float dzv[16], alv[16];
+      if (ok) {
+        load16(dz_L + v * DM + 16 * h, dzv);
+        load16(a_L + v * DM + 16 * h, alv);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dzv[s] = alv[s] = 0.f;
+      }
+      f32x16 accx = {0};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int c = 16 * h + s;
+        const float ah = (alv[s] - s_c[1][c]) * s_c[2][c];
+        const float da = ok ? s_c[0][c] * (dzv[s] - s_c[3][c] - ah * s_c[4][c]) : 0.f;
+        accx = DVA_MFMA(wt[s], da, accx);
+      }
+      if (RAW_OUT) {
+        if (ok) store_acc_layout(out + v * DM, h, accx);
+      } else {
+        float ap[16];
+        if (PREV_XMAP) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) x = *reinterpret_cast<const float4*>(a_prev + v * 8 + 4 * h);
+          f32x16 a1 = {0};
+          a1 = DVA_MFMA(wa4[0], x.x, a1);
+          a1 = DVA_MFMA(wa4[1], x.y, a1);
+          a1 = DVA_MFMA(wa4[2], x.z, a1);
+          a1 = DVA_MFMA(wa4[3], x.w, a1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ap[r] = a1[r];
+        } else if (ok) {
+          load_acc_layout(a_prev + v * DM, h, ap);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ap[r] = 0.f;
+        }
+        if (ok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float ah = (ap[r] - bp.mean[r]) * bp.invstd[r];
+            const float z = ah * bp.gamma[r] + bp.beta[r];
+            const float d = accx[r] * dleaky_m(z);
+            accx[r] = d;
+            st[0][r] += d;
+            st[1][r] = fmaf(d, ah, st[1][r]);
+          }
+          store_acc_layout(out + v * DM, h, accx);
+        }
+      }
+    }
+    // ---------------- channel-major: dW_L[n][k] += sum_v da[v][n] * x_L[v][k]; dt[p][n] += da[v][n]
+    {
+      int32_t cur_p = -1;
+      float cur_s = 0.f;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int64_t r = row0 + 2 * s + h;
+        float da = 0.f, x = 0.f;
+        if (r < V) {
+          const float ah = (a_L[r * DM + j] - cm) * ci;
+          da = cg * (dz_L[r * DM + j] - c1 - ah * c2);
+          float ap;
+          if (PREV_XMAP) {
+            const float4 x0 = *reinterpret_cast<const float4*>(a_prev + r * 8);
+            const float4 x1 = *reinterpret_cast<const float4*>(a_prev + r * 8 + 4);
+            ap = x0.x * wa8[0];
+            ap = fmaf(x0.y, wa8[1], ap); ap = fmaf(x0.z, wa8[2], ap); ap = fmaf(x0.w, wa8[3], ap);
+            ap = fmaf(x1.x, wa8[4], ap); ap = fmaf(x1.y, wa8[5], ap); ap = fmaf(x1.z, wa8[6], ap);
+            ap = fmaf(x1.w, wa8[7], ap);
+          } else {
+            ap = a_prev[r * DM + j];
+          }
+          x = leaky_m((ap - pm) * pi * pg + pb);
+          if (dt) {
+            const int32_t p = vp[r];
+            if (p != cur_p) {
+              if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
+              cur_p = p;
+              cur_s = 0.f;
+            }
+            cur_s += da;
+          }
+        }
+        accW = DVA_MFMA(da, x, accW);
+      }
+      if (dt && cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
+    }
+  }
+  // dW: accW[r] = dW[n = acc_chan(r,h)][k = j]; block reduction in LDS, one atomic per element per block
+  for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) atomicAdd(&s_red[acc_chan(r, h) * DM + j], accW[r]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) atomicAdd(&dW[i], s_red[i]);
+  if (!RAW_OUT) {
+    __syncthreads();
+    flush_stats<2>(st, st_prev, s_red, lane);
+  }
+}
+
+static inline int grid_tiles(int64_t V) {
+  int64_t b = ((V + 31) / 32 + 3) / 4;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// launchers used by the C entry points in deepset.hip
+int dsm_launch_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb, float* a2,
+                         double* stats, int64_t V, int stats_only, hipStream_t s) {
+  if (stats_only)
+    hipLaunchKernelGGL((dsm_fwd_first_kernel<true>), dim3(grid_tiles(V)), dim3(256), 0, s, x_map, Wa,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, stats, V);
+  else
+    hipLaunchKernelGGL((dsm_fwd_first_kernel<false>), dim3(grid_tiles(V)), dim3(256), 0, s, x_map, Wa, bn1,
+                       Wb, a2, stats, V);
+  return 0;
+}
+
+int dsm_launch_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
+                         const int32_t* vp, float* a_out, double* stats, int64_t V, hipStream_t s) {
+  if (addend)
+    hipLaunchKernelGGL((dsm_fwd_layer_kernel<true, false>), dim3(grid_tiles(V)), dim3(256), 0, s, a_in,
+                       bn_in, W, addend, vp, (const float*)nullptr, a_out, stats, V, 32);
+  else
+    hipLaunchKernelGGL((dsm_fwd_layer_kernel<false, false>), dim3(grid_tiles(V)), dim3(256), 0, s, a_in,
+                       bn_in, W, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
+                       a_out, stats, V, 32);
+  return 0;
+}
+
+int dsm_launch_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs, float* compat,
+                         int64_t V, int G, hipStream_t s) {
+  hipLaunchKernelGGL((dsm_fwd_layer_kernel<false, true>), dim3(grid_tiles(V)), dim3(256), 0, s, a, bn, Ws,
+                     (const float*)nullptr, (const int32_t*)nullptr, bs, compat, (double*)nullptr, V, G);
+  return 0;
+}
+
+int dsm_launch_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L, const float* sm_L,
+                         const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
+                         float* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
+                         int prev_is_xmap, int raw_out, hipStream_t s) {
+  const dim3 grid(grid_tiles(V)), block(256);
+#define DVA_L(P, R)                                                                               \
+  hipLaunchKernelGGL((dsm_bwd_layer_kernel<P, R>), grid, block, 0, s, dz_L, a_L, bn_L, sm_L, W_L, \
+                     a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp, V)
+  if (prev_is_xmap && raw_out) DVA_L(true, true);
+  else if (prev_is_xmap) DVA_L(true, false);
+  else if (raw_out) DVA_L(false, true);
+  else DVA_L(false, false);
+#undef DVA_L
+  return 0;
+}
+
+}  // namespace dva

@@ -18,6 +18,8 @@ from . import _lib, ops
 from ._lib import check, ptr, require_device, stream_of
 
 D = 32
+# layer-kernel generation: 0 = fp32 matrix cores, 1 = VALU + LDS broadcast (tests flip this)
+ALGO = 0
 
 
 def _bn_of(block):
@@ -92,13 +94,13 @@ class _DeepSetLinear(torch.autograd.Function):
         s1 = zstats()
         if training:
             with ops._timed("deepset_fwd_first_stats", V * 32):
-                check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), None, None, None, ptr(s1), V, 8, 1, st),
+                check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), None, None, None, ptr(s1), V, 8, 1, ALGO, st),
                       "dva_deepset_fwd_first")
         bn1 = _bn_consts(s1, V, bns[0], training)
         a2 = torch.empty((V, D), dtype=torch.float32, device=dev)
         s2 = zstats()
         with ops._timed("deepset_fwd_first", V * (32 + 128)):
-            check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), ptr(bn1), ptr(Wb), ptr(a2), ptr(s2), V, 8, 0, st),
+            check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), ptr(bn1), ptr(Wb), ptr(a2), ptr(s2), V, 8, 0, ALGO, st),
                   "dva_deepset_fwd_first")
         bn2 = _bn_consts(s2, V, bns[1], training)
         # ---- set branch: max over views, set MLP on the N points, WcB product (PyTorch, N rows)
@@ -122,19 +124,19 @@ class _DeepSetLinear(torch.autograd.Function):
         a3 = torch.empty((V, D), dtype=torch.float32, device=dev)
         s3 = zstats()
         with ops._timed("deepset_fwd_layer_add", V * (128 + 4 + 128) + N * 128):
-            check(lib.dva_deepset_fwd_layer(ptr(a2), ptr(bn2), ptr(WcA), ptr(t_det), ptr(vp), ptr(a3), ptr(s3), V, st),
+            check(lib.dva_deepset_fwd_layer(ptr(a2), ptr(bn2), ptr(WcA), ptr(t_det), ptr(vp), ptr(a3), ptr(s3), V, ALGO, st),
                   "dva_deepset_fwd_layer")
         bn3 = _bn_consts(s3, V, bns[2], training)
         a4 = torch.empty((V, D), dtype=torch.float32, device=dev)
         s4 = zstats()
         with ops._timed("deepset_fwd_layer", V * (128 + 128)):
-            check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, st),
+            check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, ALGO, st),
                   "dva_deepset_fwd_layer")
         bn4 = _bn_consts(s4, V, bns[3], training)
         # ---- trailing Linear (E_score / K)
         out = torch.empty((V, G), dtype=torch.float32, device=dev)
         with ops._timed("deepset_fwd_score", V * (128 + 4 * G)):
-            check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, st),
+            check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, ALGO, st),
                   "dva_deepset_fwd_score")
 
         ctx.save_for_backward(x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws)
@@ -178,7 +180,7 @@ class _DeepSetLinear(torch.autograd.Function):
         sm4 = sm_of(s4)
         with ops._timed("deepset_bwd_layer", V * 128 * 4):
             check(lib.dva_deepset_bwd_layer(ptr(dz4), ptr(a4), ptr(bn4), ptr(sm4), ptr(Wd), ptr(a3), None, ptr(bn3),
-                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, V, 0, 0, st),
+                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, V, 0, 0, ALGO, st),
                   "dva_deepset_bwd_layer")
         del dz4
         # Wc layer (cat(h1, set) -> a3): raw dx on the h1 half, per-point sum on the set half
@@ -187,7 +189,7 @@ class _DeepSetLinear(torch.autograd.Function):
         sm3 = sm_of(s3)
         with ops._timed("deepset_bwd_layer_cat", V * (128 * 4 + 4) + N * 128):
             check(lib.dva_deepset_bwd_layer(ptr(dz3), ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2), None, ptr(bn2),
-                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, st),
+                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, ALGO, st),
                   "dva_deepset_bwd_layer")
         del dz3
         # set branch backward (PyTorch autograd over N rows)
@@ -210,7 +212,7 @@ class _DeepSetLinear(torch.autograd.Function):
         sm2 = sm_of(s2)
         with ops._timed("deepset_bwd_layer_xmap", V * (128 * 3 + 32)):
             check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
-                                            ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, st),
+                                            ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, ALGO, st),
                   "dva_deepset_bwd_layer")
         del dz2
         dWa = torch.zeros_like(Wa)

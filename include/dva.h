@@ -178,6 +178,8 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
  * activations [V,32] fp32, "bn" arrays are fp32 [4][32] = mean | invstd | gamma | beta,
  * "stats" are caller-zeroed double[64] = per-channel sum | sum of squares (forward) or
  * S1 = sum dz | S2 = sum dz*a_hat (backward), "sm" are fp32 [2][32] = S1/M | S2/M (zeros in eval).
+ * algo (layer kernels): 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32, operands from registers),
+ * 1 = first-generation VALU + LDS-broadcast kernels (kept for A/B checks).
  * ------------------------------------------------------------------------------------------ */
 /* group_of_row[r] = g for ptr[g] <= r < ptr[g+1] (dense expansion of CSR pointers, int32). */
 int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, void* stream);
@@ -185,7 +187,7 @@ int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, 
  * with its statistics (mlp_elt_1, pooling.py:649-650). */
 int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb,
                           float* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
-                          void* stream);
+                          int32_t algo, void* stream);
 /* pooled[p] = max_v leaky(BN(a[v])) over the point's views (first row on ties; 0 / arg -1 for
  * unseen points): segment_csr(x, csr, 'max') of pooling.py:660,:628. */
 int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, float* pooled,
@@ -195,10 +197,10 @@ int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, floa
  * (pooling.py:666-668). */
 int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
                           const int32_t* group_of_row, float* a_out, double* stats, int64_t V,
-                          void* stream);
+                          int32_t algo, void* stream);
 /* out[v, g] = leaky(BN(a[v])).Ws[g] + bs[g], G <= 32 (E_score, pooling.py:258,:282; also Q/K). */
 int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs,
-                          float* compat, int64_t V, int32_t G, void* stream);
+                          float* compat, int64_t V, int32_t G, int32_t algo, void* stream);
 int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws,
                           float* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
                           void* stream);
@@ -210,7 +212,7 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
                           const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
                           float* out, float* dW, double* st_prev, float* dt,
                           const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
-                          int32_t raw_out, void* stream);
+                          int32_t raw_out, int32_t algo, void* stream);
 /* dz2 = (dcat + [arg[p]==v] dpooled[p]) * leaky'(BN2(a2)): joins the max-pool path (segment max
  * backward routes to the arg row only) with the direct path; S1/S2 of BN2 in st. */
 int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,

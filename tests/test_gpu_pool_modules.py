@@ -243,3 +243,34 @@ def test_fused_deepset_large_vs_generic():
     for (k, a), b in zip(m.state_dict().items(), m2.state_dict().values()):
         if "running" in k:
             close(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_deepset_mfma_equals_valu_generation():
+    """The fp32-MFMA layer kernels (algo 0) against the first-generation VALU kernels (algo 1): both are
+    exact fp32 fma chains, only the summation order differs."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import fused_deepset
+    gen = torch.Generator().manual_seed(9)
+    N, C = 20001, 16
+    sizes = torch.randint(0, 9, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    m = P.GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=4, use_num=True).to(DEV).train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen).to(DEV) * 0.4)
+    x_mod = torch.randn(V, C, generator=gen).to(DEV)
+    x_map = torch.rand(V, 8, generator=gen).to(DEV)
+    w = torch.randn(N, C, generator=gen).to(DEV)
+    res = {}
+    for algo in (0, 1):
+        fused_deepset.ALGO = algo
+        try:
+            out = m(None, x_mod, x_map, csr)
+            res[algo] = (out, torch.autograd.grad((out * w).sum(), list(m.parameters())))
+        finally:
+            fused_deepset.ALGO = 0
+    close(res[0][0], res[1][0], rtol=1e-4, atol=1e-5)
+    for (n, _), a, b in zip(m.named_parameters(), res[0][1], res[1][1]):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) / scale < 2e-3, (n, float((a - b).abs().max()), scale)
