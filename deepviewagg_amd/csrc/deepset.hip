@@ -664,8 +664,9 @@ int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W,
                           int32_t algo, void* stream) {
   if (V < 0 || !stats) return DVA_ERR_INVALID;
   if (V == 0) return DVA_OK;
-  if (!a_in || !bn_in || !W || !a_out) return DVA_ERR_INVALID;
+  if (!a_in || !W || !a_out) return DVA_ERR_INVALID;
   if (addend && !group_of_row) return DVA_ERR_INVALID;
+  if (!bn_in && algo == 1) return DVA_ERR_UNSUPPORTED;  // raw-input layers only in the MFMA generation
   hipStream_t s = (hipStream_t)stream;
   if (algo != 1) {
     dsm_launch_fwd_layer(a_in, bn_in, W, addend, group_of_row, a_out, stats, V, s);
@@ -724,8 +725,8 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
                           int32_t raw_out, int32_t algo, void* stream) {
   if (V < 0) return DVA_ERR_INVALID;
   if (V == 0) return DVA_OK;
-  if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || !bn_prev || !out || !dW)
-    return DVA_ERR_INVALID;
+  if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || !out || !dW) return DVA_ERR_INVALID;
+  if (!bn_prev && (!raw_out || algo == 1 || prev_is_xmap)) return DVA_ERR_UNSUPPORTED;
   if (!raw_out && !st_prev) return DVA_ERR_INVALID;
   if (prev_is_xmap && !Wa) return DVA_ERR_INVALID;
   if (dt && !group_of_row) return DVA_ERR_INVALID;

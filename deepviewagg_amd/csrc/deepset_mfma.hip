@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
     float* __restrict__ a_out, double* __restrict__ stats, int64_t V, int G) {
   __shared__ float s_red[2 * DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const bool ident = bn_in == nullptr;  // raw input (no BatchNorm / activation), e.g. pooled set features
   BN16 b;
-  load_bn_half(bn_in, h, b);
+  if (!ident) load_bn_half(bn_in, h, b);
   float w[16];  // W[n=j][16h + s]
 #pragma unroll
   for (int s = 0; s < 16; ++s) w[s] = (!SCORE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
@@ -205,8 +206,9 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
     f32x16 acc = {0};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float z = (x[s] - b.mean[s]) * b.invstd[s] * b.gamma[s] + b.beta[s];
-      acc = DVA_MFMA(w[s], ok ? leaky_m(z) : 0.f, acc);
+      float xin = x[s];
+      if (!ident) xin = leaky_m((x[s] - b.mean[s]) * b.invstd[s] * b.gamma[s] + b.beta[s]);
+      acc = DVA_MFMA(w[s], ok ? xin : 0.f, acc);
     }
     if (SCORE) {
       if (ok) {
@@ -262,9 +264,13 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   __syncthreads();
   // own-channel constants (channel-major phase): channel j of BN_L and of BN_prev
   const float cg = s_c[0][j], cm = s_c[1][j], ci = s_c[2][j], c1 = s_c[3][j], c2 = s_c[4][j];
-  const float pm = bn_prev[j], pi = bn_prev[DM + j], pg = bn_prev[2 * DM + j], pb = bn_prev[3 * DM + j];
+  const bool pident = bn_prev == nullptr;  // the layer input is raw (only valid with RAW_OUT)
+  float pm = 0.f, pi = 1.f, pg = 1.f, pb = 0.f;
   BN16 bp;  // BN_prev constants in accumulator layout (view-major phase)
-  load_bn_acc(bn_prev, h, bp);
+  if (!pident) {
+    pm = bn_prev[j]; pi = bn_prev[DM + j]; pg = bn_prev[2 * DM + j]; pb = bn_prev[3 * DM + j];
+    load_bn_acc(bn_prev, h, bp);
+  }
   float wt[16];  // W_L[n = 16h + s][k = j]
 #pragma unroll
   for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
           } else {
             ap = a_prev[r * DM + j];
           }
-          x = leaky_m((ap - pm) * pi * pg + pb);
+          x = pident ? ap : leaky_m((ap - pm) * pi * pg + pb);
           if (dt) {
             const int32_t p = vp[r];
             if (p != cur_p) {

@@ -7,9 +7,8 @@ shipped configuration: ``DeepSetFeat(d_in=8, d_out=32, pool='max', fusion='conca
 use_num=*)``.  Train-mode BatchNorm uses batch statistics (accumulated in fp64 by the kernels) and
 updates the running statistics like nn.BatchNorm1d; eval mode uses the running statistics.
 
-Only the set branch (``mlp_set`` on N points, 1/32 of the rows) runs as ordinary PyTorch ops: it is
-evaluated under ``torch.enable_grad()`` inside the forward and differentiated with
-``torch.autograd.grad`` inside the backward.
+The set branch (``mlp_set`` on the N points) goes through the same layer kernels with raw (un-normalised)
+input; the set-size column of ``use_num`` is a rank-1 per-row addend.
 """
 import torch
 import torch.nn.functional as F
@@ -109,18 +108,35 @@ class _DeepSetLinear(torch.autograd.Function):
         with ops._timed("deepset_segmax", V * 128 + N * (256 + 8)):
             check(lib.dva_deepset_segmax(ptr(a2), ptr(bn2), ptr(csr_idx), ptr(pooled), ptr(arg), N, st),
                   "dva_deepset_segmax")
-        with torch.enable_grad():
-            pooled_leaf = pooled.requires_grad_()
-            x_set = pooled_leaf
-            if e_map.use_num:
-                sizes = csr_idx[1:] - csr_idx[:-1]
-                x_set = torch.cat((x_set, torch.sqrt(1 / (sizes + 1e-3)).float().view(-1, 1)), dim=1)
-            with torch.autocast("cuda", enabled=False):
-                t_add = F.linear(e_map.mlp_set(x_set), e_map.mlp_elt_2[0][0].weight[:, D:])
+        # set MLP on the N points with the same layer kernels (raw input, the set-size column of
+        # use_num enters as a rank-1 per-row addend), then the WcB half of the concatenation layer
+        mlp_set = e_map.mlp_set
+        Wsa_full = mlp_set[0][0].weight.detach()
+        WsaP = Wsa_full[:, :D].contiguous()
+        Wsb = mlp_set[1][0].weight.detach().contiguous()
+        WcB = Wc[:, D:].contiguous()
+        set_bns = [_bn_of(mlp_set[0]), _bn_of(mlp_set[1])]
+        num = add1 = ident_idx = None
+        if e_map.use_num:
+            sizes = csr_idx[1:] - csr_idx[:-1]
+            num = torch.sqrt(1 / (sizes + 1e-3)).float()
+            add1 = (num.view(-1, 1) * Wsa_full[:, D].view(1, -1)).contiguous()
+            ident_idx = torch.arange(N, dtype=torch.int32, device=dev)
+        u1, su1 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
+        check(lib.dva_deepset_fwd_layer(ptr(pooled), None, ptr(WsaP), ptr(add1), ptr(ident_idx), ptr(u1), ptr(su1),
+                                        N, 0, st), "dva_deepset_fwd_layer")
+        bns1 = _bn_consts(su1, N, set_bns[0], training)
+        u2, su2 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
+        check(lib.dva_deepset_fwd_layer(ptr(u1), ptr(bns1), ptr(Wsb), None, None, ptr(u2), ptr(su2), N, 0, st),
+              "dva_deepset_fwd_layer")
+        bns2 = _bn_consts(su2, N, set_bns[1], training)
+        t_add, su3 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
+        check(lib.dva_deepset_fwd_layer(ptr(u2), ptr(bns2), ptr(WcB), None, None, ptr(t_add), ptr(su3), N, 0, st),
+              "dva_deepset_fwd_layer")
         vp = torch.empty(V, dtype=torch.int32, device=dev)
         check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
         # ---- elt MLP 2: cat(h1, set[p]) -> a3 -> a4
-        t_det = t_add.detach().contiguous()
+        t_det = t_add
         a3 = torch.empty((V, D), dtype=torch.float32, device=dev)
         s3 = zstats()
         with ops._timed("deepset_fwd_layer_add", V * (128 + 4 + 128) + N * 128):
@@ -140,7 +156,7 @@ class _DeepSetLinear(torch.autograd.Function):
                   "dva_deepset_fwd_score")
 
         ctx.save_for_backward(x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws)
-        ctx.inner = (t_add, pooled_leaf)
+        ctx.set_branch = (pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx)
         ctx.modules = (e_map, linear)
         ctx.training = training
         return out
@@ -150,7 +166,7 @@ class _DeepSetLinear(torch.autograd.Function):
         lib = _lib.load()
         x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws = ctx.saved_tensors
         e_map, linear = ctx.modules
-        t_add, pooled_leaf = ctx.inner
+        pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx = ctx.set_branch
         dev, V, N, G = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1, Ws.shape[0]
         st = stream_of(x_map)
         dout = dout.contiguous().float()
@@ -159,14 +175,14 @@ class _DeepSetLinear(torch.autograd.Function):
         def zstats():
             return torch.zeros(2 * D, dtype=torch.float64, device=dev)
 
-        def sm_of(stats):
+        def sm_of(stats, rows=m):
             # S1/M | S2/M of the batch-statistics BN backward; zero with running statistics (eval)
             if not ctx.training:
                 return torch.zeros(2 * D, dtype=torch.float32, device=dev)
-            return (stats / m).float().contiguous()
+            return (stats / rows).float().contiguous()
 
-        def buf():
-            return torch.empty((V, D), dtype=torch.float32, device=dev)
+        def buf(rows=V):
+            return torch.empty((rows, D), dtype=torch.float32, device=dev)
 
         # score layer
         dz4, s4 = buf(), zstats()
@@ -192,15 +208,34 @@ class _DeepSetLinear(torch.autograd.Function):
                                             ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, ALGO, st),
                   "dva_deepset_bwd_layer")
         del dz3
-        # set branch backward (PyTorch autograd over N rows)
-        set_params = [p for p in e_map.mlp_set.parameters()]
-        wc_param = e_map.mlp_elt_2[0][0].weight
-        inner = torch.autograd.grad(t_add, [pooled_leaf, wc_param] + set_params, grad_outputs=dt,
-                                    allow_unused=True)
-        dpooled = inner[0].contiguous()
-        dWc = inner[1].clone() if inner[1] is not None else torch.zeros_like(wc_param)
-        dWc[:, :D] += dWcA
-        d_set = list(inner[2:])
+        # set branch backward with the same layer kernels over the N points
+        n_rows = float(max(N, 1))
+        ident_bn = torch.tensor([0.0, 1.0, 1.0, 0.0], device=dev).repeat_interleave(D).contiguous()
+        zero_sm = torch.zeros(2 * D, dtype=torch.float32, device=dev)
+        dWcB = torch.zeros_like(WcB)
+        dzs2, ss2 = buf(N), zstats()
+        check(lib.dva_deepset_bwd_layer(ptr(dt), ptr(t_add), ptr(ident_bn), ptr(zero_sm), ptr(WcB), ptr(u2), None,
+                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, N, 0, 0, 0, st),
+              "dva_deepset_bwd_layer")
+        dWsb = torch.zeros_like(Wsb)
+        dzs1, ss1 = buf(N), zstats()
+        sms2 = sm_of(ss2, n_rows)
+        check(lib.dva_deepset_bwd_layer(ptr(dzs2), ptr(u2), ptr(bns2), ptr(sms2), ptr(Wsb), ptr(u1), None,
+                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, N, 0, 0, 0, st),
+              "dva_deepset_bwd_layer")
+        dWsaP = torch.zeros_like(WsaP)
+        dpooled = buf(N)
+        da1 = torch.zeros((N, D), dtype=torch.float32, device=dev) if num is not None else None
+        sms1 = sm_of(ss1, n_rows)
+        check(lib.dva_deepset_bwd_layer(ptr(dzs1), ptr(u1), ptr(bns1), ptr(sms1), ptr(WsaP), ptr(pooled), None,
+                                        None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), N, 0, 1, 0,
+                                        st), "dva_deepset_bwd_layer")
+        if num is not None:
+            dWsa = torch.cat([dWsaP, (da1 * num.view(-1, 1)).sum(0).view(-1, 1)], dim=1)
+        else:
+            dWsa = dWsaP
+        dWc = torch.cat([dWcA, dWcB], dim=1)
+        d_set = [dWsa, ss1[D:].float(), ss1[:D].float(), dWsb, ss2[D:].float(), ss2[:D].float()]
         # join the max path, BN2 backward statistics
         dz2, s2 = buf(), zstats()
         with ops._timed("deepset_bwd_max", V * (128 * 3 + 4) + N * 256):
@@ -228,7 +263,7 @@ class _DeepSetLinear(torch.autograd.Function):
         g3, b3 = gb(s3)
         g4, b4 = gb(s4)
         grads = [dWa, g1, b1, dWb, g2, b2, dWc, g3, b3, dWd, g4, b4, dWs, dbs] + d_set
-        ctx.inner = None
+        ctx.set_branch = None
         return (None, None, None, None) + tuple(grads)
 
 

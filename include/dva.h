@@ -194,7 +194,7 @@ int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, floa
                        int32_t* arg, int64_t N, void* stream);
 /* a_out[v] = leaky(BN_in(a_in[v])).W^T (+ addend[group_of_row[v]]) with statistics of a_out.
  * The addend carries the set half of the concatenation: cat(x, x_set).Wc^T = x.WcA^T + (x_set.WcB^T)[p]
- * (pooling.py:666-668). */
+ * (pooling.py:666-668).  bn_in == NULL: the input is used raw (set MLP on the pooled features). */
 int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
                           const int32_t* group_of_row, float* a_out, double* stats, int64_t V,
                           int32_t algo, void* stream);
@@ -207,7 +207,8 @@ int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn,
 /* Backward of one layer: da_L = BN-backward(dz_L), dW_L += da_L^T x_L, dx = da_L.W_L;
  * out = dx (raw_out) or dz_prev = dx*leaky'(BN_prev(a_prev)) with S1/S2 of BN_prev in st_prev;
  * dt[group_of_row[v]] += da_L[v] (nullable). prev_is_xmap: a_prev is x_map [V,8] and the previous
- * activation is recomputed as x_map.Wa^T. dW / dt are caller-zeroed fp32, atomically accumulated. */
+ * activation is recomputed as x_map.Wa^T. dW / dt are caller-zeroed fp32, atomically accumulated.
+ * bn_prev == NULL (with raw_out): the layer input is a_prev itself (no BatchNorm / activation). */
 int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L, const float* sm_L,
                           const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
                           float* out, float* dW, double* st_prev, float* dt,
