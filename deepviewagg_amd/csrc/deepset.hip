@@ -602,6 +602,11 @@ int dsm_launch_bwd_layer(const float*, const float*, const float*, const float*,
                          const float*, const float*, float*, float*, double*, float*, const int32_t*,
                          int64_t, int, int, hipStream_t);
 
+int dsm_launch_bwd_max(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*,
+                       float*, double*, int64_t, hipStream_t);
+int dsm_launch_bwd_score(const float*, const float*, const float*, const float*, float*, float*, float*,
+                         double*, int64_t, int, hipStream_t);
+
 }  // namespace dva
 
 using namespace dva;
@@ -703,11 +708,16 @@ int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, cons
 
 int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws,
                           float* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
-                          void* stream) {
+                          int32_t algo, void* stream) {
   if (V < 0 || G <= 0) return DVA_ERR_INVALID;
   if (G > 32) return DVA_ERR_UNSUPPORTED;
   if (V == 0) return DVA_OK;
   if (!dcompat || !a || !bn || !Ws || !dz || !dWs || !dbs || !st) return DVA_ERR_INVALID;
+  if (algo != 1) {
+    dsm_launch_bwd_score(dcompat, a, bn, Ws, dz, dWs, dbs, st, V, G, (hipStream_t)stream);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   if (G <= 8)
     hipLaunchKernelGGL((dsf_bwd_score_kernel<8>), dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream,
                        dcompat, a, bn, Ws, dz, dWs, dbs, st, V, G);
@@ -752,10 +762,15 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
 
 int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
                         const float* dpooled, const int32_t* group_of_row, float* dz2, double* st,
-                        int64_t V, void* stream) {
+                        int64_t V, int32_t algo, void* stream) {
   if (V < 0) return DVA_ERR_INVALID;
   if (V == 0) return DVA_OK;
   if (!dcat || !a2 || !bn2 || !arg || !dpooled || !group_of_row || !dz2 || !st) return DVA_ERR_INVALID;
+  if (algo != 1) {
+    dsm_launch_bwd_max(dcat, a2, bn2, arg, dpooled, group_of_row, dz2, st, V, (hipStream_t)stream);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   hipLaunchKernelGGL(dsf_bwd_max_kernel, dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream, dcat, a2,
                      bn2, arg, dpooled, group_of_row, dz2, st, V);
   DVA_CHECK_LAUNCH();

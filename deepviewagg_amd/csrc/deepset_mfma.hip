@@ -396,6 +396,143 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   }
 }
 
+
+// Sum vals[s] over the 32 lanes of a half-wave; channel of register s is 16h + s (half-row layout).
+__device__ __forceinline__ void reduce_half_channels(float (&vals)[16], float* s_red, int lane) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    float v = vals[s];
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+    if ((lane & 31) == 0) atomicAdd(&s_red[16 * (lane >> 5) + s], v);
+  }
+}
+
+// dz2[v,c] = (dcat[v,c] + [arg[p,c]==v] dpooled[p,c]) * leaky'(BN2(a2[v,c])), p = vp[v]; S1, S2 of BN2.
+// View-major, 16 channels per lane, 16-byte accesses only.
+__global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
+    const float* __restrict__ dcat, const float* __restrict__ a2, const float* __restrict__ bn2,
+    const int32_t* __restrict__ arg, const float* __restrict__ dpooled, const int32_t* __restrict__ vp,
+    float* __restrict__ dz2, double* __restrict__ st, int64_t V) {
+  __shared__ float s_red[2 * DM];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  BN16 b;
+  load_bn_half(bn2, h, b);
+  float acc[2][16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc[0][s] = acc[1][s] = 0.f;
+  const int64_t tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t v = t * 32 + j;
+    if (v >= V) continue;
+    const int64_t p = vp[v];
+    float g[16], a[16], dp[16];
+    load16(dcat + v * DM + 16 * h, g);
+    load16(a2 + v * DM + 16 * h, a);
+    load16(dpooled + p * DM + 16 * h, dp);
+    int32_t ag[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 w = *reinterpret_cast<const int4*>(arg + p * DM + 16 * h + 4 * q);
+      ag[4 * q] = w.x; ag[4 * q + 1] = w.y; ag[4 * q + 2] = w.z; ag[4 * q + 3] = w.w;
+    }
+    float d[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float gg = g[s] + ((int64_t)ag[s] == v ? dp[s] : 0.f);
+      const float ah = (a[s] - b.mean[s]) * b.invstd[s];
+      const float z = ah * b.gamma[s] + b.beta[s];
+      d[s] = gg * dleaky_m(z);
+      acc[0][s] += d[s];
+      acc[1][s] = fmaf(d[s], ah, acc[1][s]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(dz2 + v * DM + 16 * h + 4 * q) =
+          make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+  }
+  for (int i = threadIdx.x; i < 2 * DM; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+  reduce_half_channels(acc[0], s_red, lane);
+  reduce_half_channels(acc[1], s_red + DM, lane);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * DM; i += blockDim.x) atomicAdd(&st[i], (double)s_red[i]);
+}
+
+// Score layer backward on the matrix cores: out = f(a4).Ws^T + bs with f = leaky(BN4(.)).
+//   dz4[v,k] = (sum_g dc[v,g] Ws[g,k]) * leaky'(z4[v,k])   (view-major, ceil(G/2) k-steps)
+//   dWs[g,k] = sum_v dc[v,g] f(a4)[v,k],  dbs[g] = sum_v dc[v,g]   (channel-major, 16 k-steps)
+__global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
+    const float* __restrict__ dcompat, const float* __restrict__ a, const float* __restrict__ bn,
+    const float* __restrict__ Ws, float* __restrict__ dz, float* __restrict__ dWs,
+    float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G) {
+  __shared__ float s_red[DM * DM];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int GH = (G + 1) / 2;  // k-step s pairs score columns (s, s + GH)
+  BN16 bp;
+  load_bn_acc(bn, h, bp);
+  const float pm = bn[j], pi = bn[DM + j], pg = bn[2 * DM + j], pb = bn[3 * DM + j];
+  f32x16 accW = {0};
+  float db = 0.f;
+  float stv[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stv[0][r] = stv[1][r] = 0.f;
+  const int64_t tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) {
+    const int64_t row0 = t * 32;
+    {
+      const int64_t v = row0 + j;
+      const bool ok = v < V;
+      f32x16 accx = {0};
+      for (int s = 0; s < GH; ++s) {
+        const int g = s + GH * h;
+        const float wv = g < G ? Ws[g * DM + j] : 0.f;                   // A[i = k = j][kk = h]
+        const float dc = (ok && g < G) ? dcompat[v * G + g] : 0.f;       // B[kk = h][j = v]
+        accx = DVA_MFMA(wv, dc, accx);
+      }
+      if (ok) {
+        float ap[16];
+        load_acc_layout(a + v * DM, h, ap);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ah = (ap[r] - bp.mean[r]) * bp.invstd[r];
+          const float z = ah * bp.gamma[r] + bp.beta[r];
+          const float d = accx[r] * dleaky_m(z);
+          accx[r] = d;
+          stv[0][r] += d;
+          stv[1][r] = fmaf(d, ah, stv[1][r]);
+        }
+        store_acc_layout(dz + v * DM, h, accx);
+      }
+    }
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int64_t r = row0 + 2 * s + h;
+      float dc = 0.f, x = 0.f;
+      if (r < V) {
+        if (j < G) dc = dcompat[r * G + j];                              // A[i = g = j][kk = h]
+        x = leaky_m((a[r * DM + j] - pm) * pi * pg + pb);                // B[kk = h][j = k]
+        db += dc;
+      }
+      accW = DVA_MFMA(dc, x, accW);
+    }
+  }
+  for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (acc_chan(r, h) < G) atomicAdd(&s_red[acc_chan(r, h) * DM + j], accW[r]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * DM; i += blockDim.x) atomicAdd(&dWs[i], s_red[i]);
+  __syncthreads();
+  if (j < G && db != 0.f) atomicAdd(&dbs[j], db);
+  flush_stats<2>(stv, st, s_red, lane);
+}
+
 static inline int grid_tiles(int64_t V) {
   int64_t b = ((V + 31) / 32 + 3) / 4;
   if (b > 256 * 8) b = 256 * 8;
@@ -447,6 +584,21 @@ int dsm_launch_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L,
   else if (raw_out) DVA_L(false, true);
   else DVA_L(false, false);
 #undef DVA_L
+  return 0;
+}
+
+int dsm_launch_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
+                       const float* dpooled, const int32_t* vp, float* dz2, double* st, int64_t V,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(dsm_bwd_max_kernel, dim3(grid_tiles(V)), dim3(256), 0, s, dcat, a2, bn2, arg, dpooled,
+                     vp, dz2, st, V);
+  return 0;
+}
+
+int dsm_launch_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws, float* dz,
+                         float* dWs, float* dbs, double* st, int64_t V, int G, hipStream_t s) {
+  hipLaunchKernelGGL(dsm_bwd_score_kernel, dim3(grid_tiles(V)), dim3(256), 0, s, dcompat, a, bn, Ws, dz, dWs,
+                     dbs, st, V, G);
   return 0;
 }
 

@@ -190,7 +190,7 @@ class _DeepSetLinear(torch.autograd.Function):
         dbs = torch.zeros(G, dtype=torch.float32, device=dev)
         with ops._timed("deepset_bwd_score", V * (128 + 4 * G + 128)):
             check(lib.dva_deepset_bwd_score(ptr(dout), ptr(a4), ptr(bn4), ptr(Ws), ptr(dz4), ptr(dWs), ptr(dbs),
-                                            ptr(s4), V, G, st), "dva_deepset_bwd_score")
+                                            ptr(s4), V, G, ALGO, st), "dva_deepset_bwd_score")
         # Wd layer (a3 -> a4)
         dz3, s3, dWd = buf(), zstats(), torch.zeros_like(Wd)
         sm4 = sm_of(s4)
@@ -240,7 +240,7 @@ class _DeepSetLinear(torch.autograd.Function):
         dz2, s2 = buf(), zstats()
         with ops._timed("deepset_bwd_max", V * (128 * 3 + 4) + N * 256):
             check(lib.dva_deepset_bwd_max(ptr(dcat), ptr(a2), ptr(bn2), ptr(arg), ptr(dpooled), ptr(vp), ptr(dz2),
-                                          ptr(s2), V, st), "dva_deepset_bwd_max")
+                                          ptr(s2), V, ALGO, st), "dva_deepset_bwd_max")
         del dcat
         # Wb layer (a1 -> a2), a1 recomputed from x_map
         dz1, s1, dWb = buf(), zstats(), torch.zeros_like(Wb)

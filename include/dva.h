@@ -203,7 +203,7 @@ int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, cons
                           float* compat, int64_t V, int32_t G, int32_t algo, void* stream);
 int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws,
                           float* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
-                          void* stream);
+                          int32_t algo, void* stream);
 /* Backward of one layer: da_L = BN-backward(dz_L), dW_L += da_L^T x_L, dx = da_L.W_L;
  * out = dx (raw_out) or dz_prev = dx*leaky'(BN_prev(a_prev)) with S1/S2 of BN_prev in st_prev;
  * dt[group_of_row[v]] += da_L[v] (nullable). prev_is_xmap: a_prev is x_map [V,8] and the previous
@@ -218,7 +218,7 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
  * backward routes to the arg row only) with the direct path; S1/S2 of BN2 in st. */
 int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
                         const float* dpooled, const int32_t* group_of_row, float* dz2, double* st,
-                        int64_t V, void* stream);
+                        int64_t V, int32_t algo, void* stream);
 /* dWa[n][j] += sum_v BN1-backward(dz1)[v][n] * x_map[v][j]. */
 int dva_deepset_bwd_first(const float* dz1, const float* x_map, const float* Wa, const float* bn1,
                           const float* sm1, float* dWa, int64_t V, int32_t F, void* stream);
