@@ -97,6 +97,29 @@ __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restr
 
 #define DVA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// BatchNorm constants as an LDS table [4][32] (mean | invstd | gamma | beta): 16 ds_read_b128 per tile
+// instead of 64 live registers per lane (occupancy).  `base` = first channel of each group of 4:
+// half-row layout 16h + 4q, accumulator layout 8q + 4h.
+__device__ __forceinline__ void stage_bn(float (*t)[DM], const float* __restrict__ bn) {
+  for (int i = threadIdx.x; i < 4 * DM; i += blockDim.x) t[i / DM][i % DM] = bn ? bn[i] : ((i / DM) == 1 || (i / DM) == 2 ? 1.f : 0.f);
+}
+template <bool ACC_LAYOUT>
+__device__ __forceinline__ void bn_norm16(const float (*t)[DM], int h, const float (&x)[16], float (&ah)[16],
+                                          float (&z)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int base = ACC_LAYOUT ? 8 * q + 4 * h : 16 * h + 4 * q;
+    const float4 m = *reinterpret_cast<const float4*>(&t[0][base]);
+    const float4 iv = *reinterpret_cast<const float4*>(&t[1][base]);
+    const float4 g = *reinterpret_cast<const float4*>(&t[2][base]);
+    const float4 b = *reinterpret_cast<const float4*>(&t[3][base]);
+    ah[4 * q] = (x[4 * q] - m.x) * iv.x;         z[4 * q] = ah[4 * q] * g.x + b.x;
+    ah[4 * q + 1] = (x[4 * q + 1] - m.y) * iv.y; z[4 * q + 1] = ah[4 * q + 1] * g.y + b.y;
+    ah[4 * q + 2] = (x[4 * q + 2] - m.z) * iv.z; z[4 * q + 2] = ah[4 * q + 2] * g.z + b.z;
+    ah[4 * q + 3] = (x[4 * q + 3] - m.w) * iv.w; z[4 * q + 3] = ah[4 * q + 3] * g.w + b.w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -110,16 +133,17 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
                                                              float* __restrict__ a2,
                                                              double* __restrict__ stats, int64_t V) {
   __shared__ float s_red[2 * DM];
+  __shared__ __attribute__((aligned(16))) float s_bn[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   float wa[4];  // Wa[n=j][4h + s]
 #pragma unroll
   for (int s = 0; s < 4; ++s) wa[s] = Wa[j * 8 + 4 * h + s];
   float wb[16];  // Wb[n2=j][acc_chan(r,h)]
-  BN16 b1;
   if (!STATS_ONLY) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) wb[r] = Wb[j * DM + acc_chan(r, h)];
-    load_bn_acc(bn1, h, b1);
+    stage_bn(s_bn, bn1);
+    __syncthreads();
   }
   float st[2][16];
 #pragma unroll
@@ -145,12 +169,12 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
       }
     } else {
       f32x16 acc2 = {0};
+      float a1v[16], ah1[16], z1[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float z = (acc[r] - b1.mean[r]) * b1.invstd[r] * b1.gamma[r] + b1.beta[r];
-        const float tv = ok ? leaky_m(z) : 0.f;
-        acc2 = DVA_MFMA(wb[r], tv, acc2);
-      }
+      for (int r = 0; r < 16; ++r) a1v[r] = acc[r];
+      bn_norm16<true>(s_bn, h, a1v, ah1, z1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = DVA_MFMA(wb[r], ok ? leaky_m(z1[r]) : 0.f, acc2);
       if (ok) store_acc_layout(a2 + v * DM, h, acc2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -170,10 +194,11 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
     const float* __restrict__ addend, const int32_t* __restrict__ vp, const float* __restrict__ bias,
     float* __restrict__ a_out, double* __restrict__ stats, int64_t V, int G) {
   __shared__ float s_red[2 * DM];
+  __shared__ __attribute__((aligned(16))) float s_bn[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const bool ident = bn_in == nullptr;  // raw input (no BatchNorm / activation), e.g. pooled set features
-  BN16 b;
-  if (!ident) load_bn_half(bn_in, h, b);
+  stage_bn(s_bn, bn_in);
+  __syncthreads();
   float w[16];  // W[n=j][16h + s]
 #pragma unroll
   for (int s = 0; s < 16; ++s) w[s] = (!SCORE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
@@ -204,10 +229,11 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
       load_acc_layout(addend + p * DM, h, ad);
     }
     f32x16 acc = {0};
+    float ahx[16], zx[16];
+    bn_norm16<false>(s_bn, h, x, ahx, zx);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      float xin = x[s];
-      if (!ident) xin = leaky_m((x[s] - b.mean[s]) * b.invstd[s] * b.gamma[s] + b.beta[s]);
+      const float xin = ident ? x[s] : leaky_m(zx[s]);
       acc = DVA_MFMA(w[s], ok ? xin : 0.f, acc);
     }
     if (SCORE) {
@@ -251,7 +277,8 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     float* __restrict__ dW, double* __restrict__ st_prev, float* __restrict__ dt,
     const int32_t* __restrict__ vp, int64_t V) {
   __shared__ float s_red[DM * DM];
-  __shared__ float s_c[5][DM];  // BN_L constants by channel: gsc | mean | invstd | S1/M | S2/M
+  __shared__ __attribute__((aligned(16))) float s_c[5][DM];  // BN_L: gsc | mean | invstd | S1/M | S2/M
+  __shared__ __attribute__((aligned(16))) float s_p[4][DM];  // BN_prev table
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   if (threadIdx.x < DM) {
     const int c = threadIdx.x;
@@ -261,16 +288,12 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     s_c[3][c] = sm_L[c];
     s_c[4][c] = sm_L[DM + c];
   }
+  stage_bn(s_p, bn_prev);
   __syncthreads();
+  const bool pident = bn_prev == nullptr;  // the layer input is raw (only valid with RAW_OUT)
   // own-channel constants (channel-major phase): channel j of BN_L and of BN_prev
   const float cg = s_c[0][j], cm = s_c[1][j], ci = s_c[2][j], c1 = s_c[3][j], c2 = s_c[4][j];
-  const bool pident = bn_prev == nullptr;  // the layer input is raw (only valid with RAW_OUT)
-  float pm = 0.f, pi = 1.f, pg = 1.f, pb = 0.f;
-  BN16 bp;  // BN_prev constants in accumulator layout (view-major phase)
-  if (!pident) {
-    pm = bn_prev[j]; pi = bn_prev[DM + j]; pg = bn_prev[2 * DM + j]; pb = bn_prev[3 * DM + j];
-    load_bn_acc(bn_prev, h, bp);
-  }
+  const float pm = s_p[0][j], pi = s_p[1][j], pg = s_p[2][j], pb = s_p[3][j];
   float wt[16];  // W_L[n = 16h + s][k = j]
 #pragma unroll
   for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
@@ -291,55 +314,81 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t row0 = t * 32;
-    // ---------------- view-major: dx = da . W_L, then dz_prev
-    {
-      const int64_t v = row0 + j;
-      const bool ok = v < V;
-      float dzv[16], alv[16];
-      if (ok) {
-        load16(dz_L + v * DM + 16 * h, dzv);
-        load16(a_L + v * DM + 16 * h, alv);
+    const int64_t v = row0 + j;
+    const bool ok = v < V;
+    // ---- issue every load of the tile up front (both layouts): the channel-major rows are in flight
+    //      while the view-major product runs
+    float dzv[16], alv[16], ap[16];
+    if (ok) {
+      load16(dz_L + v * DM + 16 * h, dzv);
+      load16(a_L + v * DM + 16 * h, alv);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dzv[s] = alv[s] = 0.f;
+    }
+    float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!RAW_OUT) {
+      if (PREV_XMAP) {
+        if (ok) xm = *reinterpret_cast<const float4*>(a_prev + v * 8 + 4 * h);
+      } else if (ok) {
+        load_acc_layout(a_prev + v * DM, h, ap);
       } else {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) dzv[s] = alv[s] = 0.f;
+        for (int r = 0; r < 16; ++r) ap[r] = 0.f;
       }
+    }
+    float dzr[16], alr[16], apr[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int64_t r = row0 + 2 * s + h;
+      const bool okr = r < V;
+      dzr[s] = okr ? dz_L[r * DM + j] : 0.f;
+      alr[s] = okr ? a_L[r * DM + j] : 0.f;
+      if (!PREV_XMAP) apr[s] = okr ? a_prev[r * DM + j] : 0.f;
+    }
+    // ---------------- view-major: dx = da . W_L, then dz_prev
+    {
       f32x16 accx = {0};
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int c = 16 * h + s;
-        const float ah = (alv[s] - s_c[1][c]) * s_c[2][c];
-        const float da = ok ? s_c[0][c] * (dzv[s] - s_c[3][c] - ah * s_c[4][c]) : 0.f;
-        accx = DVA_MFMA(wt[s], da, accx);
+      for (int q = 0; q < 4; ++q) {
+        const int base = 16 * h + 4 * q;
+        const float4 g4 = *reinterpret_cast<const float4*>(&s_c[0][base]);
+        const float4 m4 = *reinterpret_cast<const float4*>(&s_c[1][base]);
+        const float4 i4 = *reinterpret_cast<const float4*>(&s_c[2][base]);
+        const float4 a4 = *reinterpret_cast<const float4*>(&s_c[3][base]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&s_c[4][base]);
+        const float gs[4] = {g4.x, g4.y, g4.z, g4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+        const float is[4] = {i4.x, i4.y, i4.z, i4.w}, s1[4] = {a4.x, a4.y, a4.z, a4.w};
+        const float s2[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = 4 * q + e;
+          const float ah = (alv[s] - ms[e]) * is[e];
+          const float da = ok ? gs[e] * (dzv[s] - s1[e] - ah * s2[e]) : 0.f;
+          accx = DVA_MFMA(wt[s], da, accx);
+        }
       }
       if (RAW_OUT) {
         if (ok) store_acc_layout(out + v * DM, h, accx);
       } else {
-        float ap[16];
         if (PREV_XMAP) {
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok) x = *reinterpret_cast<const float4*>(a_prev + v * 8 + 4 * h);
           f32x16 a1 = {0};
-          a1 = DVA_MFMA(wa4[0], x.x, a1);
-          a1 = DVA_MFMA(wa4[1], x.y, a1);
-          a1 = DVA_MFMA(wa4[2], x.z, a1);
-          a1 = DVA_MFMA(wa4[3], x.w, a1);
+          a1 = DVA_MFMA(wa4[0], xm.x, a1);
+          a1 = DVA_MFMA(wa4[1], xm.y, a1);
+          a1 = DVA_MFMA(wa4[2], xm.z, a1);
+          a1 = DVA_MFMA(wa4[3], xm.w, a1);
 #pragma unroll
           for (int r = 0; r < 16; ++r) ap[r] = a1[r];
-        } else if (ok) {
-          load_acc_layout(a_prev + v * DM, h, ap);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ap[r] = 0.f;
         }
         if (ok) {
+          float ahp[16], zp[16];
+          bn_norm16<true>(s_p, h, ap, ahp, zp);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float ah = (ap[r] - bp.mean[r]) * bp.invstd[r];
-            const float z = ah * bp.gamma[r] + bp.beta[r];
-            const float d = accx[r] * dleaky_m(z);
+            const float d = accx[r] * dleaky_m(zp[r]);
             accx[r] = d;
             st[0][r] += d;
-            st[1][r] = fmaf(d, ah, st[1][r]);
+            st[1][r] = fmaf(d, ahp[r], st[1][r]);
           }
           store_acc_layout(out + v * DM, h, accx);
         }
@@ -349,25 +398,25 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     {
       int32_t cur_p = -1;
       float cur_s = 0.f;
-#pragma unroll 4
+#pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int64_t r = row0 + 2 * s + h;
         float da = 0.f, x = 0.f;
         if (r < V) {
-          const float ah = (a_L[r * DM + j] - cm) * ci;
-          da = cg * (dz_L[r * DM + j] - c1 - ah * c2);
-          float ap;
+          const float ah = (alr[s] - cm) * ci;
+          da = cg * (dzr[s] - c1 - ah * c2);
+          float apv;
           if (PREV_XMAP) {
             const float4 x0 = *reinterpret_cast<const float4*>(a_prev + r * 8);
             const float4 x1 = *reinterpret_cast<const float4*>(a_prev + r * 8 + 4);
-            ap = x0.x * wa8[0];
-            ap = fmaf(x0.y, wa8[1], ap); ap = fmaf(x0.z, wa8[2], ap); ap = fmaf(x0.w, wa8[3], ap);
-            ap = fmaf(x1.x, wa8[4], ap); ap = fmaf(x1.y, wa8[5], ap); ap = fmaf(x1.z, wa8[6], ap);
-            ap = fmaf(x1.w, wa8[7], ap);
+            apv = x0.x * wa8[0];
+            apv = fmaf(x0.y, wa8[1], apv); apv = fmaf(x0.z, wa8[2], apv); apv = fmaf(x0.w, wa8[3], apv);
+            apv = fmaf(x1.x, wa8[4], apv); apv = fmaf(x1.y, wa8[5], apv); apv = fmaf(x1.z, wa8[6], apv);
+            apv = fmaf(x1.w, wa8[7], apv);
           } else {
-            ap = a_prev[r * DM + j];
+            apv = apr[s];
           }
-          x = pident ? ap : leaky_m((ap - pm) * pi * pg + pb);
+          x = pident ? apv : leaky_m((apv - pm) * pi * pg + pb);
           if (dt) {
             const int32_t p = vp[r];
             if (p != cur_p) {
@@ -396,7 +445,6 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   }
 }
 
-
 // Sum vals[s] over the 32 lanes of a half-wave; channel of register s is 16h + s (half-row layout).
 __device__ __forceinline__ void reduce_half_channels(float (&vals)[16], float* s_red, int lane) {
 #pragma unroll
@@ -415,9 +463,10 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
     const int32_t* __restrict__ arg, const float* __restrict__ dpooled, const int32_t* __restrict__ vp,
     float* __restrict__ dz2, double* __restrict__ st, int64_t V) {
   __shared__ float s_red[2 * DM];
+  __shared__ __attribute__((aligned(16))) float s_p[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  BN16 b;
-  load_bn_half(bn2, h, b);
+  stage_bn(s_p, bn2);
+  __syncthreads();
   float acc[2][16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) acc[0][s] = acc[1][s] = 0.f;
@@ -438,15 +487,14 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
       const int4 w = *reinterpret_cast<const int4*>(arg + p * DM + 16 * h + 4 * q);
       ag[4 * q] = w.x; ag[4 * q + 1] = w.y; ag[4 * q + 2] = w.z; ag[4 * q + 3] = w.w;
     }
-    float d[16];
+    float d[16], ahv[16], zv[16];
+    bn_norm16<false>(s_p, h, a, ahv, zv);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const float gg = g[s] + ((int64_t)ag[s] == v ? dp[s] : 0.f);
-      const float ah = (a[s] - b.mean[s]) * b.invstd[s];
-      const float z = ah * b.gamma[s] + b.beta[s];
-      d[s] = gg * dleaky_m(z);
+      d[s] = gg * dleaky_m(zv[s]);
       acc[0][s] += d[s];
-      acc[1][s] = fmaf(d[s], ah, acc[1][s]);
+      acc[1][s] = fmaf(d[s], ahv[s], acc[1][s]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -469,11 +517,12 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
     const float* __restrict__ Ws, float* __restrict__ dz, float* __restrict__ dWs,
     float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G) {
   __shared__ float s_red[DM * DM];
+  __shared__ __attribute__((aligned(16))) float s_p[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int GH = (G + 1) / 2;  // k-step s pairs score columns (s, s + GH)
-  BN16 bp;
-  load_bn_acc(bn, h, bp);
-  const float pm = bn[j], pi = bn[DM + j], pg = bn[2 * DM + j], pb = bn[3 * DM + j];
+  stage_bn(s_p, bn);
+  __syncthreads();
+  const float pm = s_p[0][j], pi = s_p[1][j], pg = s_p[2][j], pb = s_p[3][j];
   f32x16 accW = {0};
   float db = 0.f;
   float stv[2][16];
@@ -484,9 +533,25 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t row0 = t * 32;
+    const int64_t v = row0 + j;
+    const bool ok = v < V;
+    // all loads of the tile first
+    float ap[16];
+    if (ok) {
+      load_acc_layout(a + v * DM, h, ap);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ap[r] = 0.f;
+    }
+    float ar[16], dcr[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int64_t r = row0 + 2 * s + h;
+      const bool okr = r < V;
+      ar[s] = okr ? a[r * DM + j] : 0.f;
+      dcr[s] = (okr && j < G) ? dcompat[r * G + j] : 0.f;                // A[i = g = j][kk = h]
+    }
     {
-      const int64_t v = row0 + j;
-      const bool ok = v < V;
       f32x16 accx = {0};
       for (int s = 0; s < GH; ++s) {
         const int g = s + GH * h;
@@ -495,30 +560,27 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
         accx = DVA_MFMA(wv, dc, accx);
       }
       if (ok) {
-        float ap[16];
-        load_acc_layout(a + v * DM, h, ap);
+        float ahp[16], zp[16];
+        bn_norm16<true>(s_p, h, ap, ahp, zp);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float ah = (ap[r] - bp.mean[r]) * bp.invstd[r];
-          const float z = ah * bp.gamma[r] + bp.beta[r];
-          const float d = accx[r] * dleaky_m(z);
+          const float d = accx[r] * dleaky_m(zp[r]);
           accx[r] = d;
           stv[0][r] += d;
-          stv[1][r] = fmaf(d, ah, stv[1][r]);
+          stv[1][r] = fmaf(d, ahp[r], stv[1][r]);
         }
         store_acc_layout(dz + v * DM, h, accx);
       }
     }
-#pragma unroll 4
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int64_t r = row0 + 2 * s + h;
-      float dc = 0.f, x = 0.f;
+      float x = 0.f;
       if (r < V) {
-        if (j < G) dc = dcompat[r * G + j];                              // A[i = g = j][kk = h]
-        x = leaky_m((a[r * DM + j] - pm) * pi * pg + pb);                // B[kk = h][j = k]
-        db += dc;
+        x = leaky_m((ar[s] - pm) * pi * pg + pb);                        // B[kk = h][j = k]
+        db += dcr[s];
       }
-      accW = DVA_MFMA(dc, x, accW);
+      accW = DVA_MFMA(dcr[s], x, accW);
     }
   }
   for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
