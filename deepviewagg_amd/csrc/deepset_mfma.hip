@@ -97,6 +97,22 @@ __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restr
 
 #define DVA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Tile loop: every full 32-row tile runs a body instantiated with TAIL = false (no predication at all:
+// the first versions predicated each load / store, which made hipcc (a) branch around every access and
+// (b) lose count of the outstanding accesses and fall back to s_waitcnt vmcnt(0) -- i.e. wait for the
+// tile's STORES before touching the prefetched rows).  The one partial tile runs the TAIL = true body.
+struct TailNo { static constexpr bool value = false; };
+struct TailYes { static constexpr bool value = true; };
+template <typename Body>
+__device__ __forceinline__ void for_each_tile(int64_t V, Body&& body) {
+  // (a two-body variant -- unpredicated full tiles + a predicated tail body -- doubled the register
+  // footprint; one body with clamped row indices costs a v_min per address and keeps loads branch-free)
+  const int64_t tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < tiles; t += n_waves) body(t, TailYes());
+}
+
 // BatchNorm constants as an LDS table [4][32] (mean | invstd | gamma | beta): 16 ds_read_b128 per tile
 // instead of 64 live registers per lane (occupancy).  `base` = first channel of each group of 4:
 // half-row layout 16h + 4q, accumulator layout 8q + 4h.
@@ -148,14 +164,13 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  const int64_t tiles = (V + 31) / 32;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t t = wave; t < tiles; t += n_waves) {
+  for_each_tile(V, [&](int64_t t, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     const int64_t v = t * 32 + j;
-    const bool ok = v < V;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) x = *reinterpret_cast<const float4*>(x_map + v * 8 + 4 * h);
+    const bool ok = !TAIL || v < V;
+    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
+    float4 x = *reinterpret_cast<const float4*>(x_map + vc * 8 + 4 * h);
+    if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
     f32x16 acc = {0};
     acc = DVA_MFMA(wa[0], x.x, acc);
     acc = DVA_MFMA(wa[1], x.y, acc);
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
         st[1][r] = fmaf(acc2[r], acc2[r], st[1][r]);
       }
     }
-  }
+  });
   flush_stats<2>(st, stats, s_red, lane);
 }
 
@@ -210,24 +225,15 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  const int64_t tiles = (V + 31) / 32;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t t = wave; t < tiles; t += n_waves) {
+  for_each_tile(V, [&](int64_t t, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     const int64_t v = t * 32 + j;
-    const bool ok = v < V;
+    const bool ok = !TAIL || v < V;
+    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;   // clamped row: loads are unconditional
     float x[16];
-    if (ok) {
-      load16(a_in + v * DM + 16 * h, x);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) x[s] = 0.f;
-    }
+    load16(a_in + vc * DM + 16 * h, x);
     float ad[16];
-    if (HAS_ADD) {
-      const int64_t p = ok ? (int64_t)vp[v] : 0;
-      load_acc_layout(addend + p * DM, h, ad);
-    }
+    if (HAS_ADD) load_acc_layout(addend + (int64_t)vp[vc] * DM, h, ad);
     f32x16 acc = {0};
     float ahx[16], zx[16];
     bn_norm16<false>(s_bn, h, x, ahx, zx);
@@ -249,11 +255,11 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
         }
       }
     } else {
-      if (ok) {
-        if (HAS_ADD) {
+      if (HAS_ADD) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] += ad[r];
-        }
+        for (int r = 0; r < 16; ++r) acc[r] += ad[r];
+      }
+      if (ok) {
         store_acc_layout(a_out + v * DM, h, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
         }
       }
     }
-  }
+  });
   if (!SCORE) flush_stats<2>(st, stats, s_red, lane);
 }
 
@@ -309,129 +315,102 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
 
-  const int64_t tiles = (V + 31) / 32;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t t = wave; t < tiles; t += n_waves) {
+  for_each_tile(V, [&](int64_t t, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     const int64_t row0 = t * 32;
     const int64_t v = row0 + j;
-    const bool ok = v < V;
-    // ---- issue every load of the tile up front (both layouts): the channel-major rows are in flight
-    //      while the view-major product runs
+    const bool ok = !TAIL || v < V;
+    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
+    // ---- every load of the tile is issued up front, unconditionally (clamped rows), in both layouts:
+    //      the channel-major rows are in flight while the view-major product runs
     float dzv[16], alv[16], ap[16];
-    if (ok) {
-      load16(dz_L + v * DM + 16 * h, dzv);
-      load16(a_L + v * DM + 16 * h, alv);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) dzv[s] = alv[s] = 0.f;
-    }
+    load16(dz_L + vc * DM + 16 * h, dzv);
+    load16(a_L + vc * DM + 16 * h, alv);
     float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!RAW_OUT) {
+      if (PREV_XMAP) xm = *reinterpret_cast<const float4*>(a_prev + vc * 8 + 4 * h);
+      else load_acc_layout(a_prev + vc * DM, h, ap);
+    }
+    // ---------------- view-major: dx = da . W_L, then dz_prev (kept in registers, stored last)
+    f32x16 accx = {0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int base = 16 * h + 4 * q;
+      const float4 g4 = *reinterpret_cast<const float4*>(&s_c[0][base]);
+      const float4 m4 = *reinterpret_cast<const float4*>(&s_c[1][base]);
+      const float4 i4 = *reinterpret_cast<const float4*>(&s_c[2][base]);
+      const float4 a4 = *reinterpret_cast<const float4*>(&s_c[3][base]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&s_c[4][base]);
+      const float gs[4] = {g4.x, g4.y, g4.z, g4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
+      const float is[4] = {i4.x, i4.y, i4.z, i4.w}, s1[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float s2[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * q + e;
+        const float ah = (alv[s] - ms[e]) * is[e];
+        const float da = ok ? gs[e] * (dzv[s] - s1[e] - ah * s2[e]) : 0.f;
+        accx = DVA_MFMA(wt[s], da, accx);
+      }
+    }
+    if (!RAW_OUT) {
       if (PREV_XMAP) {
-        if (ok) xm = *reinterpret_cast<const float4*>(a_prev + v * 8 + 4 * h);
-      } else if (ok) {
-        load_acc_layout(a_prev + v * DM, h, ap);
-      } else {
+        f32x16 a1 = {0};
+        a1 = DVA_MFMA(wa4[0], xm.x, a1);
+        a1 = DVA_MFMA(wa4[1], xm.y, a1);
+        a1 = DVA_MFMA(wa4[2], xm.z, a1);
+        a1 = DVA_MFMA(wa4[3], xm.w, a1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ap[r] = 0.f;
+        for (int r = 0; r < 16; ++r) ap[r] = a1[r];
       }
-    }
-    float dzr[16], alr[16], apr[16];
+      float ahp[16], zp[16];
+      bn_norm16<true>(s_p, h, ap, ahp, zp);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int64_t r = row0 + 2 * s + h;
-      const bool okr = r < V;
-      dzr[s] = okr ? dz_L[r * DM + j] : 0.f;
-      alr[s] = okr ? a_L[r * DM + j] : 0.f;
-      if (!PREV_XMAP) apr[s] = okr ? a_prev[r * DM + j] : 0.f;
-    }
-    // ---------------- view-major: dx = da . W_L, then dz_prev
-    {
-      f32x16 accx = {0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int base = 16 * h + 4 * q;
-        const float4 g4 = *reinterpret_cast<const float4*>(&s_c[0][base]);
-        const float4 m4 = *reinterpret_cast<const float4*>(&s_c[1][base]);
-        const float4 i4 = *reinterpret_cast<const float4*>(&s_c[2][base]);
-        const float4 a4 = *reinterpret_cast<const float4*>(&s_c[3][base]);
-        const float4 b4 = *reinterpret_cast<const float4*>(&s_c[4][base]);
-        const float gs[4] = {g4.x, g4.y, g4.z, g4.w}, ms[4] = {m4.x, m4.y, m4.z, m4.w};
-        const float is[4] = {i4.x, i4.y, i4.z, i4.w}, s1[4] = {a4.x, a4.y, a4.z, a4.w};
-        const float s2[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int s = 4 * q + e;
-          const float ah = (alv[s] - ms[e]) * is[e];
-          const float da = ok ? gs[e] * (dzv[s] - s1[e] - ah * s2[e]) : 0.f;
-          accx = DVA_MFMA(wt[s], da, accx);
-        }
-      }
-      if (RAW_OUT) {
-        if (ok) store_acc_layout(out + v * DM, h, accx);
-      } else {
-        if (PREV_XMAP) {
-          f32x16 a1 = {0};
-          a1 = DVA_MFMA(wa4[0], xm.x, a1);
-          a1 = DVA_MFMA(wa4[1], xm.y, a1);
-          a1 = DVA_MFMA(wa4[2], xm.z, a1);
-          a1 = DVA_MFMA(wa4[3], xm.w, a1);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ap[r] = a1[r];
-        }
-        if (ok) {
-          float ahp[16], zp[16];
-          bn_norm16<true>(s_p, h, ap, ahp, zp);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = accx[r] * dleaky_m(zp[r]);
-            accx[r] = d;
-            st[0][r] += d;
-            st[1][r] = fmaf(d, ahp[r], st[1][r]);
-          }
-          store_acc_layout(out + v * DM, h, accx);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float d = ok ? accx[r] * dleaky_m(zp[r]) : 0.f;
+        accx[r] = d;
+        st[0][r] += d;
+        st[1][r] = fmaf(d, ahp[r], st[1][r]);
       }
     }
     // ---------------- channel-major: dW_L[n][k] += sum_v da[v][n] * x_L[v][k]; dt[p][n] += da[v][n]
     {
       int32_t cur_p = -1;
       float cur_s = 0.f;
-#pragma unroll
+#pragma unroll 8
       for (int s = 0; s < 16; ++s) {
         const int64_t r = row0 + 2 * s + h;
-        float da = 0.f, x = 0.f;
-        if (r < V) {
-          const float ah = (alr[s] - cm) * ci;
-          da = cg * (dzr[s] - c1 - ah * c2);
-          float apv;
-          if (PREV_XMAP) {
-            const float4 x0 = *reinterpret_cast<const float4*>(a_prev + r * 8);
-            const float4 x1 = *reinterpret_cast<const float4*>(a_prev + r * 8 + 4);
-            apv = x0.x * wa8[0];
-            apv = fmaf(x0.y, wa8[1], apv); apv = fmaf(x0.z, wa8[2], apv); apv = fmaf(x0.w, wa8[3], apv);
-            apv = fmaf(x1.x, wa8[4], apv); apv = fmaf(x1.y, wa8[5], apv); apv = fmaf(x1.z, wa8[6], apv);
-            apv = fmaf(x1.w, wa8[7], apv);
-          } else {
-            apv = apr[s];
+        const bool okr = !TAIL || r < V;
+        const int64_t rc = TAIL ? (r < V ? r : V - 1) : r;
+        const float ah = (a_L[rc * DM + j] - cm) * ci;
+        const float da = okr ? cg * (dz_L[rc * DM + j] - c1 - ah * c2) : 0.f;
+        float apv;
+        if (PREV_XMAP) {
+          const float4 x0 = *reinterpret_cast<const float4*>(a_prev + rc * 8);
+          const float4 x1 = *reinterpret_cast<const float4*>(a_prev + rc * 8 + 4);
+          apv = x0.x * wa8[0];
+          apv = fmaf(x0.y, wa8[1], apv); apv = fmaf(x0.z, wa8[2], apv); apv = fmaf(x0.w, wa8[3], apv);
+          apv = fmaf(x1.x, wa8[4], apv); apv = fmaf(x1.y, wa8[5], apv); apv = fmaf(x1.z, wa8[6], apv);
+          apv = fmaf(x1.w, wa8[7], apv);
+        } else {
+          apv = a_prev[rc * DM + j];
+        }
+        const float x = okr ? (pident ? apv : leaky_m((apv - pm) * pi * pg + pb)) : 0.f;
+        if (dt && okr) {
+          const int32_t p = vp[rc];
+          if (p != cur_p) {
+            if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
+            cur_p = p;
+            cur_s = 0.f;
           }
-          x = pident ? apv : leaky_m((apv - pm) * pi * pg + pb);
-          if (dt) {
-            const int32_t p = vp[r];
-            if (p != cur_p) {
-              if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
-              cur_p = p;
-              cur_s = 0.f;
-            }
-            cur_s += da;
-          }
+          cur_s += da;
         }
         accW = DVA_MFMA(da, x, accW);
       }
       if (dt && cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
     }
-  }
+    // ---------------- the tile's only stores, last: nothing in this iteration waits for them
+    if (ok) store_acc_layout(out + v * DM, h, accx);
+  });
   // dW: accW[r] = dW[n = acc_chan(r,h)][k = j]; block reduction in LDS, one atomic per element per block
   for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
   __syncthreads();
@@ -470,16 +449,15 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
   float acc[2][16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) acc[0][s] = acc[1][s] = 0.f;
-  const int64_t tiles = (V + 31) / 32;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t t = wave; t < tiles; t += n_waves) {
+  for_each_tile(V, [&](int64_t t, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     const int64_t v = t * 32 + j;
-    if (v >= V) continue;
-    const int64_t p = vp[v];
+    const bool ok = !TAIL || v < V;
+    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
+    const int64_t p = vp[vc];
     float g[16], a[16], dp[16];
-    load16(dcat + v * DM + 16 * h, g);
-    load16(a2 + v * DM + 16 * h, a);
+    load16(dcat + vc * DM + 16 * h, g);
+    load16(a2 + vc * DM + 16 * h, a);
     load16(dpooled + p * DM + 16 * h, dp);
     int32_t ag[16];
 #pragma unroll
@@ -492,15 +470,17 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const float gg = g[s] + ((int64_t)ag[s] == v ? dp[s] : 0.f);
-      d[s] = gg * dleaky_m(zv[s]);
+      d[s] = ok ? gg * dleaky_m(zv[s]) : 0.f;
       acc[0][s] += d[s];
       acc[1][s] = fmaf(d[s], ahv[s], acc[1][s]);
     }
+    if (ok) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(dz2 + v * DM + 16 * h + 4 * q) =
-          make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-  }
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(dz2 + v * DM + 16 * h + 4 * q) =
+            make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+    }
+  });
   for (int i = threadIdx.x; i < 2 * DM; i += blockDim.x) s_red[i] = 0.f;
   __syncthreads();
   reduce_half_channels(acc[0], s_red, lane);
@@ -528,61 +508,60 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
   float stv[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) stv[0][r] = stv[1][r] = 0.f;
-  const int64_t tiles = (V + 31) / 32;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t t = wave; t < tiles; t += n_waves) {
+  float wsv[16];  // Ws[g = s + GH*h][k = j] for the (at most 16) view-major k-steps
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wsv[s] = (s < GH && s + GH * h < G) ? Ws[(s + GH * h) * DM + j] : 0.f;
+  for_each_tile(V, [&](int64_t t, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     const int64_t row0 = t * 32;
     const int64_t v = row0 + j;
-    const bool ok = v < V;
-    // all loads of the tile first
+    const bool ok = !TAIL || v < V;
+    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
+    // all loads of the tile first, unconditional
     float ap[16];
-    if (ok) {
-      load_acc_layout(a + v * DM, h, ap);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ap[r] = 0.f;
-    }
+    load_acc_layout(a + vc * DM, h, ap);
     float ar[16], dcr[16];
+    const int jc = j < G ? j : 0;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int64_t r = row0 + 2 * s + h;
-      const bool okr = r < V;
-      ar[s] = okr ? a[r * DM + j] : 0.f;
-      dcr[s] = (okr && j < G) ? dcompat[r * G + j] : 0.f;                // A[i = g = j][kk = h]
+      const int64_t rc = TAIL ? (r < V ? r : V - 1) : r;
+      ar[s] = a[rc * DM + j];
+      dcr[s] = dcompat[rc * G + jc];                                     // A[i = g = j][kk = h]
     }
-    {
-      f32x16 accx = {0};
+    f32x16 accx = {0};
+    if (G == 4) {
+      const float2 dc2 = *reinterpret_cast<const float2*>(dcompat + vc * 4 + 2 * h);
+      accx = DVA_MFMA(wsv[0], ok ? dc2.x : 0.f, accx);
+      accx = DVA_MFMA(wsv[1], ok ? dc2.y : 0.f, accx);
+    } else {
       for (int s = 0; s < GH; ++s) {
         const int g = s + GH * h;
         const float wv = g < G ? Ws[g * DM + j] : 0.f;                   // A[i = k = j][kk = h]
-        const float dc = (ok && g < G) ? dcompat[v * G + g] : 0.f;       // B[kk = h][j = v]
+        const float dc = (ok && g < G) ? dcompat[vc * G + g] : 0.f;      // B[kk = h][j = v]
         accx = DVA_MFMA(wv, dc, accx);
       }
-      if (ok) {
-        float ahp[16], zp[16];
-        bn_norm16<true>(s_p, h, ap, ahp, zp);
+    }
+    float ahp[16], zp[16];
+    bn_norm16<true>(s_p, h, ap, ahp, zp);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = accx[r] * dleaky_m(zp[r]);
-          accx[r] = d;
-          stv[0][r] += d;
-          stv[1][r] = fmaf(d, ahp[r], stv[1][r]);
-        }
-        store_acc_layout(dz + v * DM, h, accx);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float d = ok ? accx[r] * dleaky_m(zp[r]) : 0.f;
+      accx[r] = d;
+      stv[0][r] += d;
+      stv[1][r] = fmaf(d, ahp[r], stv[1][r]);
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int64_t r = row0 + 2 * s + h;
-      float x = 0.f;
-      if (r < V) {
-        x = leaky_m((ar[s] - pm) * pi * pg + pb);                        // B[kk = h][j = k]
-        db += dcr[s];
-      }
-      accW = DVA_MFMA(dcr[s], x, accW);
+      const bool okr = !TAIL || r < V;
+      const float dc = (okr && j < G) ? dcr[s] : 0.f;
+      const float x = okr ? leaky_m((ar[s] - pm) * pi * pg + pb) : 0.f;  // B[kk = h][j = k]
+      db += dc;
+      accW = DVA_MFMA(dc, x, accW);
     }
-  }
+    if (ok) store_acc_layout(dz + v * DM, h, accx);
+  });
   for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
   __syncthreads();
 #pragma unroll
