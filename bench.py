@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-points", type=int, default=12)
+    ap.add_argument("--cpu-log2-points", type=int, default=15)
+    ap.add_argument("--no-mapping-build", action="store_true")
     return ap.parse_args()
 
 
@@ -132,6 +133,44 @@ def cpu_baseline(log2_points, views, C, threads):
                        f"C={C}, {reps} fwd+bwd steps, {dt:.2f} s/step")
 
 
+def mapping_build_bench(device, n_images=4, n_points=200_000):
+    """Secondary measurement: mapping build at the S3DIS settings (2048x1024
+    projection map, voxel 2 cm, r_max 8 m, exact=True): images/s on the GPU and for the C oracle on
+    one host core, with a bit-exactness check of the indices."""
+    import numpy as np
+    from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
+    from oracle import mapping_oracle as M
+    rng = np.random.default_rng(0)
+    face = rng.integers(0, 6, n_points)
+    uvw = rng.random((n_points, 3))
+    uvw[np.arange(n_points), face // 2] = face % 2
+    xyz = (uvw * np.array([8.0, 6.0, 3.0])).astype(np.float32)
+    cams = np.array([[3.1, 2.2, 1.4], [5.0, 3.0, 1.2], [2.0, 4.5, 1.6], [6.5, 1.5, 1.5]], dtype=np.float32)[:n_images]
+    kw = dict(img_size=(2048, 1024), r_max=8.0, r_min=0.05, voxel=0.02, k_swell=1.0, d_swell=1000, exact=True)
+    model = SplattingVisibility(camera="s3dis_equirectangular", **kw)
+    xyz_d = torch.from_numpy(xyz).to(device)
+    opk = torch.zeros(3, device=device)
+    outs = [model(xyz_d, torch.from_numpy(c).to(device), img_opk=opk) for c in cams]  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        outs = [model(xyz_d, torch.from_numpy(c).to(device), img_opk=opk) for c in cams]
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / (reps * len(cams))
+    cam0 = M.make_camera("s3dis_equirectangular", kw["img_size"], cams[0], r_min=kw["r_min"], r_max=kw["r_max"],
+                         voxel=kw["voxel"], k_swell=1.0, d_swell=1000, exact=True, img_opk=np.zeros(3))
+    t0 = time.perf_counter()
+    ref = M.visibility(xyz, cam0)
+    cpu_s = time.perf_counter() - t0
+    exact = bool(np.array_equal(outs[0]["idx"].cpu().numpy(), ref["idx"])
+                 and np.array_equal(outs[0]["x"].cpu().numpy(), ref["x"])
+                 and np.array_equal(outs[0]["y"].cpu().numpy(), ref["y"]))
+    return {"images_per_s": 1.0 / gpu_s, "ms_per_image": gpu_s * 1e3, "candidates_per_image": n_points,
+            "proj_map": [2048, 1024], "mapped_points_image0": int(ref["idx"].shape[0]),
+            "cpu_oracle_ms_per_image_1core": cpu_s * 1e3, "indices_bit_exact_vs_oracle": exact}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,6 +246,8 @@ def main():
             "gather_GBps": None if gk is None else (gk["bytes"] / gk["launches"]) / (gk["ms"] / gk["launches"] * 1e-3) / 1e9,
             "loss": float(loss.item()),
         }
+        if world == 1 and not args.no_mapping_build:
+            res["mapping_build"] = mapping_build_bench(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
         print(json.dumps(res))

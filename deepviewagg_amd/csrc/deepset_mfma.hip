@@ -97,6 +97,28 @@ __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restr
 
 #define DVA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Intra-wavefront LDS hand-off (DS ops of one wavefront execute in order; see deepset.hip).
+__device__ __forceinline__ void wave_sync_m() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+// 32x32 fp32 tile staged per wavefront for the view-major -> channel-major transposition.
+// Row stride 36 floats: 16-byte aligned rows, float4 writes of 8 consecutive lanes hit 32 distinct
+// banks, and the column reads (lane = channel) are conflict free.
+constexpr int TS = 36;
+__device__ __forceinline__ void tile_put_half(float* tile, int v, int h, const float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(tile + v * TS + 16 * h + 4 * q) =
+        make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+__device__ __forceinline__ void tile_put_acc(float* tile, int v, int h, const float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(tile + v * TS + 8 * q + 4 * h) =
+        make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
 // Tile loop: every full 32-row tile runs a body instantiated with TAIL = false (no predication at all:
 // the first versions predicated each load / store, which made hipcc (a) branch around every access and
 // (b) lose count of the outstanding accesses and fall back to s_waitcnt vmcnt(0) -- i.e. wait for the
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward (same contract as dsf_bwd_layer_kernel in deepset.hip)
 // ------------------------------------------------------------------------------------------------
-template <bool PREV_XMAP, bool RAW_OUT>
+template <bool PREV_XMAP, bool RAW_OUT, bool HAS_DT>
 __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     const float* __restrict__ dz_L, const float* __restrict__ a_L, const float* __restrict__ bn_L,
     const float* __restrict__ sm_L, const float* __restrict__ W_L, const float* __restrict__ a_prev,
@@ -285,7 +307,9 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   __shared__ float s_red[DM * DM];
   __shared__ __attribute__((aligned(16))) float s_c[5][DM];  // BN_L: gsc | mean | invstd | S1/M | S2/M
   __shared__ __attribute__((aligned(16))) float s_p[4][DM];  // BN_prev table
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float s_da[4][32 * TS];  // per-wavefront da tile
+  __shared__ __attribute__((aligned(16))) float s_x[4][32 * TS];   // per-wavefront x_L tile
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (threadIdx.x < DM) {
     const int c = threadIdx.x;
     s_c[0][c] = bn_L[2 * DM + c] * bn_L[DM + c];
@@ -297,41 +321,38 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   stage_bn(s_p, bn_prev);
   __syncthreads();
   const bool pident = bn_prev == nullptr;  // the layer input is raw (only valid with RAW_OUT)
-  // own-channel constants (channel-major phase): channel j of BN_L and of BN_prev
-  const float cg = s_c[0][j], cm = s_c[1][j], ci = s_c[2][j], c1 = s_c[3][j], c2 = s_c[4][j];
-  const float pm = s_p[0][j], pi = s_p[1][j], pg = s_p[2][j], pb = s_p[3][j];
   float wt[16];  // W_L[n = 16h + s][k = j]
 #pragma unroll
   for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
-  float wa4[4], wa8[8];
+  float wa4[4];
   if (PREV_XMAP) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) wa4[s] = Wa[j * 8 + 4 * h + s];  // view-major recompute of a1
-#pragma unroll
-    for (int s = 0; s < 8; ++s) wa8[s] = Wa[j * 8 + s];          // channel-major recompute of a1[., j]
   }
   f32x16 accW = {0};
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  float* tda = s_da[wv];
+  float* tx = s_x[wv];
 
   for_each_tile(V, [&](int64_t t, auto tail) {
-    constexpr bool TAIL = decltype(tail)::value;
     const int64_t row0 = t * 32;
     const int64_t v = row0 + j;
-    const bool ok = !TAIL || v < V;
-    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
-    // ---- every load of the tile is issued up front, unconditionally (clamped rows), in both layouts:
-    //      the channel-major rows are in flight while the view-major product runs
+    const bool ok = v < V;
+    const int64_t vc = ok ? v : V - 1;  // clamped: loads are unconditional
+    // ---- the tile is read ONCE, view-major (each lane: half a row of dz_L, a_L; a_prev in the
+    //      accumulator layout); the channel-major operands of the weight gradient come from LDS
     float dzv[16], alv[16], ap[16];
     load16(dz_L + vc * DM + 16 * h, dzv);
     load16(a_L + vc * DM + 16 * h, alv);
     float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!RAW_OUT) {
-      if (PREV_XMAP) xm = *reinterpret_cast<const float4*>(a_prev + vc * 8 + 4 * h);
-      else load_acc_layout(a_prev + vc * DM, h, ap);
-    }
-    // ---------------- view-major: dx = da . W_L, then dz_prev (kept in registers, stored last)
+    if (PREV_XMAP) xm = *reinterpret_cast<const float4*>(a_prev + vc * 8 + 4 * h);
+    else load_acc_layout(a_prev + vc * DM, h, ap);
+    int32_t pnt = 0;
+    if (HAS_DT) pnt = vp[vc];
+    // ---------------- da = BN_L-backward(dz_L); view-major product dx = da . W_L
+    float da[16];
     f32x16 accx = {0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -348,22 +369,27 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
       for (int e = 0; e < 4; ++e) {
         const int s = 4 * q + e;
         const float ah = (alv[s] - ms[e]) * is[e];
-        const float da = ok ? gs[e] * (dzv[s] - s1[e] - ah * s2[e]) : 0.f;
-        accx = DVA_MFMA(wt[s], da, accx);
+        da[s] = ok ? gs[e] * (dzv[s] - s1[e] - ah * s2[e]) : 0.f;
+        accx = DVA_MFMA(wt[s], da[s], accx);
       }
     }
-    if (!RAW_OUT) {
-      if (PREV_XMAP) {
-        f32x16 a1 = {0};
-        a1 = DVA_MFMA(wa4[0], xm.x, a1);
-        a1 = DVA_MFMA(wa4[1], xm.y, a1);
-        a1 = DVA_MFMA(wa4[2], xm.z, a1);
-        a1 = DVA_MFMA(wa4[3], xm.w, a1);
+    tile_put_half(tda, j, h, da);
+    // ---------------- x_L = leaky(BN_prev(a_prev)) in the accumulator layout -> LDS; dz_prev
+    if (PREV_XMAP) {
+      f32x16 a1 = {0};
+      a1 = DVA_MFMA(wa4[0], xm.x, a1);
+      a1 = DVA_MFMA(wa4[1], xm.y, a1);
+      a1 = DVA_MFMA(wa4[2], xm.z, a1);
+      a1 = DVA_MFMA(wa4[3], xm.w, a1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ap[r] = a1[r];
-      }
-      float ahp[16], zp[16];
-      bn_norm16<true>(s_p, h, ap, ahp, zp);
+      for (int r = 0; r < 16; ++r) ap[r] = a1[r];
+    }
+    float ahp[16], zp[16], xl[16];
+    bn_norm16<true>(s_p, h, ap, ahp, zp);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xl[r] = ok ? (pident ? ap[r] : leaky_m(zp[r])) : 0.f;
+    tile_put_acc(tx, j, h, xl);
+    if (!RAW_OUT) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float d = ok ? accx[r] * dleaky_m(zp[r]) : 0.f;
@@ -372,44 +398,36 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
         st[1][r] = fmaf(d, ahp[r], st[1][r]);
       }
     }
-    // ---------------- channel-major: dW_L[n][k] += sum_v da[v][n] * x_L[v][k]; dt[p][n] += da[v][n]
-    {
+    wave_sync_m();
+    // ---------------- channel-major: dW_L[n][k] += sum_v da[v][n] * x_L[v][k]  (operands from LDS)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * s + h;
+      accW = DVA_MFMA(tda[row * TS + j], tx[row * TS + j], accW);
+    }
+    // ---------------- dt[p][n] += da[v][n]: run-length sum over the tile's rows, lane = channel
+    if (HAS_DT) {
+      // point id of row (2s + h) lives in lane (2s + h) of either half: fetch with a shuffle
       int32_t cur_p = -1;
       float cur_s = 0.f;
-#pragma unroll 8
+#pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const int64_t r = row0 + 2 * s + h;
-        const bool okr = !TAIL || r < V;
-        const int64_t rc = TAIL ? (r < V ? r : V - 1) : r;
-        const float ah = (a_L[rc * DM + j] - cm) * ci;
-        const float da = okr ? cg * (dz_L[rc * DM + j] - c1 - ah * c2) : 0.f;
-        float apv;
-        if (PREV_XMAP) {
-          const float4 x0 = *reinterpret_cast<const float4*>(a_prev + rc * 8);
-          const float4 x1 = *reinterpret_cast<const float4*>(a_prev + rc * 8 + 4);
-          apv = x0.x * wa8[0];
-          apv = fmaf(x0.y, wa8[1], apv); apv = fmaf(x0.z, wa8[2], apv); apv = fmaf(x0.w, wa8[3], apv);
-          apv = fmaf(x1.x, wa8[4], apv); apv = fmaf(x1.y, wa8[5], apv); apv = fmaf(x1.z, wa8[6], apv);
-          apv = fmaf(x1.w, wa8[7], apv);
-        } else {
-          apv = a_prev[rc * DM + j];
-        }
-        const float x = okr ? (pident ? apv : leaky_m((apv - pm) * pi * pg + pb)) : 0.f;
-        if (dt && okr) {
-          const int32_t p = vp[rc];
+        const int row = 2 * s + h;
+        const int32_t p = __shfl(pnt, row);
+        if (row0 + row < V) {
           if (p != cur_p) {
             if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
             cur_p = p;
             cur_s = 0.f;
           }
-          cur_s += da;
+          cur_s += tda[row * TS + j];
         }
-        accW = DVA_MFMA(da, x, accW);
       }
-      if (dt && cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
+      if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
     }
     // ---------------- the tile's only stores, last: nothing in this iteration waits for them
     if (ok) store_acc_layout(out + v * DM, h, accx);
+    wave_sync_m();
   });
   // dW: accW[r] = dW[n = acc_chan(r,h)][k = j]; block reduction in LDS, one atomic per element per block
   for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
@@ -498,11 +516,12 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
     float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G) {
   __shared__ float s_red[DM * DM];
   __shared__ __attribute__((aligned(16))) float s_p[4][DM];
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float s_x[4][32 * TS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const int GH = (G + 1) / 2;  // k-step s pairs score columns (s, s + GH)
   stage_bn(s_p, bn);
   __syncthreads();
-  const float pm = s_p[0][j], pi = s_p[1][j], pg = s_p[2][j], pb = s_p[3][j];
+  float* tx = s_x[wv];
   f32x16 accW = {0};
   float db = 0.f;
   float stv[2][16];
@@ -520,13 +539,12 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
     // all loads of the tile first, unconditional
     float ap[16];
     load_acc_layout(a + vc * DM, h, ap);
-    float ar[16], dcr[16];
+    float dcr[16];
     const int jc = j < G ? j : 0;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int64_t r = row0 + 2 * s + h;
       const int64_t rc = TAIL ? (r < V ? r : V - 1) : r;
-      ar[s] = a[rc * DM + j];
       dcr[s] = dcompat[rc * G + jc];                                     // A[i = g = j][kk = h]
     }
     f32x16 accx = {0};
@@ -542,25 +560,28 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
         accx = DVA_MFMA(wv, dc, accx);
       }
     }
-    float ahp[16], zp[16];
+    float ahp[16], zp[16], xl[16];
     bn_norm16<true>(s_p, h, ap, ahp, zp);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      xl[r] = ok ? leaky_m(zp[r]) : 0.f;
       const float d = ok ? accx[r] * dleaky_m(zp[r]) : 0.f;
       accx[r] = d;
       stv[0][r] += d;
       stv[1][r] = fmaf(d, ahp[r], stv[1][r]);
     }
+    tile_put_acc(tx, j, h, xl);
+    wave_sync_m();
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int64_t r = row0 + 2 * s + h;
       const bool okr = !TAIL || r < V;
       const float dc = (okr && j < G) ? dcr[s] : 0.f;
-      const float x = okr ? leaky_m((ar[s] - pm) * pi * pg + pb) : 0.f;  // B[kk = h][j = k]
       db += dc;
-      accW = DVA_MFMA(dc, x, accW);
+      accW = DVA_MFMA(dc, tx[(2 * s + h) * TS + j], accW);              // B[kk = h][j = k] from LDS
     }
     if (ok) store_acc_layout(dz + v * DM, h, accx);
+    wave_sync_m();
   });
   for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;
   __syncthreads();
@@ -617,13 +638,15 @@ int dsm_launch_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L,
                          float* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
                          int prev_is_xmap, int raw_out, hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
-#define DVA_L(P, R)                                                                               \
-  hipLaunchKernelGGL((dsm_bwd_layer_kernel<P, R>), grid, block, 0, s, dz_L, a_L, bn_L, sm_L, W_L, \
+#define DVA_L(P, R, T)                                                                               \
+  hipLaunchKernelGGL((dsm_bwd_layer_kernel<P, R, T>), grid, block, 0, s, dz_L, a_L, bn_L, sm_L, W_L, \
                      a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp, V)
-  if (prev_is_xmap && raw_out) DVA_L(true, true);
-  else if (prev_is_xmap) DVA_L(true, false);
-  else if (raw_out) DVA_L(false, true);
-  else DVA_L(false, false);
+  if (prev_is_xmap && raw_out) DVA_L(true, true, false);
+  else if (prev_is_xmap) DVA_L(true, false, false);
+  else if (raw_out && dt) DVA_L(false, true, true);
+  else if (raw_out) DVA_L(false, true, false);
+  else if (dt) DVA_L(false, false, true);
+  else DVA_L(false, false, false);
 #undef DVA_L
   return 0;
 }
