@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     }
 
     // ---- pass 2b: fused-gather scatter: grows[row_idx[v], c] += go[p,c]*gate[p,g(c)]*att[v,g(c)]
-    if (row_idx) {
+    if (row_idx && grows) {
       const int cpg = C / G;
       for (int t = 0; t < teams_per_wave; ++t) {
         const int src = t * tg.ts;
@@ -519,8 +519,119 @@ static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, f
   hipLaunchKernelGGL((att_bwd_scores_kernel<T>), dim3(grid_cap((N * G + 255) / 256)), dim3(256),
                      2 * G * sizeof(float), s, (const T*)gout, (const T*)val, row_idx, compat, att,
                      gw ? gate : nullptr, amax, ptr, gw, gcompat, gwb, N, C, G, scaling);
-  hipLaunchKernelGGL((att_bwd_val_kernel<T>), dim3(grid_cap((N * C + 255) / 256)), dim3(256), 0, s,
-                     (const T*)gout, row_idx, grows, att, gw ? gate : nullptr, ptr, (T*)gval, N, C, G);
+  if (!row_idx || grows)
+    hipLaunchKernelGGL((att_bwd_val_kernel<T>), dim3(grid_cap((N * C + 255) / 256)), dim3(256), 0, s,
+                       (const T*)gout, row_idx, grows, att, gw ? gate : nullptr, ptr, (T*)gval, N, C, G);
+  return DVA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows gradient of the fused gather as a segmented reduction (no atomics, deterministic):
+//   grows[r, c] = sum_{i in [row_ptr[r], row_ptr[r+1])} gout[p, c] * gate[p, g(c)] * att[v, g(c)],
+//   v = perm[i], p = view_point[v].  (perm, row_ptr) = dva_row_plan of the row index.
+// One wavefront per feature-map row, 64/lpr views in flight, 4 loads deep: the dependent chain
+// perm -> view_point -> gout row is issued for 4 views before the first use.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rows_grad_team_kernel(
+    const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
+    const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ row_ptr, float* __restrict__ grows, int64_t R, int C, int G, int lpr,
+    int lpg) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int U = 4;
+  typedef typename Vec16<T>::raw raw_t;
+  const int lane = threadIdx.x & 63;
+  const int lane_r = lane & (lpr - 1);
+  const int slot = lane / lpr;
+  const int slots = 64 / lpr;
+  const int g_lane = lane_r / lpg;
+  const int64_t col = (int64_t)lane_r * VEC;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < R; r += n_waves) {
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int i0 = beg; i0 < end; i0 += slots * U) {
+      int v[U], p[U];
+      bool ok[U];
+      float sc[U];
+      raw_t raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * slots + slot;
+        ok[u] = i < end;
+        v[u] = perm[ok[u] ? i : beg];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u] = vp[v[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)p[u] * C + col);
+        const float a = att[(int64_t)v[u] * G + g_lane];
+        const float gt = gate ? gate[(int64_t)p[u] * G + g_lane] : 1.f;
+        sc[u] = ok[u] ? a * gt : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[VEC];
+        Vec16<T>::unpack(raw[u], f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(f[k], sc[u], acc[k]);
+      }
+    }
+    for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+    }
+    if (slot == 0) {
+      float* dst = grows + r * C + col;
+#pragma unroll
+      for (int k = 0; k < VEC; k += 4)
+        *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+    }
+  }
+}
+
+// any C / G: one thread per (row, channel)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_grad_generic_kernel(
+    const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
+    const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ row_ptr, float* __restrict__ grows, int64_t R, int C, int G) {
+  const int64_t total = R * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    const int g = group_of_channel(c, C, G);
+    float acc = 0.f;
+    for (int i = row_ptr[r]; i < row_ptr[r + 1]; ++i) {
+      const int64_t v = perm[i], p = vp[v];
+      const float s = att[v * G + g] * (gate ? gate[p * G + g] : 1.f);
+      acc = fmaf(Elt<T>::ld(gout, p * C + c), s, acc);
+    }
+    grows[t] = acc;
+  }
+}
+
+template <typename T>
+static int rows_grad_impl(const void* gout, const float* att, const float* gate, const int32_t* vp,
+                          const int32_t* perm, const int32_t* row_ptr, float* grows, int64_t R, int C,
+                          int G, hipStream_t s) {
+  constexpr int VEC = Vec16<T>::N;
+  const int lpr = C / VEC;
+  const bool team_ok = (C % VEC) == 0 && is_pow2(lpr) && lpr <= 64 && is_pow2(G) && C % G == 0 &&
+                       (C / G) % VEC == 0 && ((uintptr_t)gout % 16 == 0) && ((uintptr_t)grows % 16 == 0);
+  if (team_ok) {
+    hipLaunchKernelGGL((rows_grad_team_kernel<T>), dim3(grid_cap((R + 3) / 4)), dim3(256), 0, s,
+                       (const T*)gout, att, gate, vp, perm, row_ptr, grows, R, C, G, lpr, lpr / G);
+  } else {
+    hipLaunchKernelGGL((rows_grad_generic_kernel<T>), dim3(grid_cap((R * C + 255) / 256)), dim3(256),
+                       0, s, (const T*)gout, att, gate, vp, perm, row_ptr, grows, R, C, G);
+  }
   return DVA_OK;
 }
 
@@ -564,7 +675,7 @@ static int attention_bwd_entry(const void* grad_out, const void* val, const int3
   (void)gate_b;
   if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
   if (!att || !gate || !amax || !grad_compat) return DVA_ERR_INVALID;
-  if (row_idx ? !grad_rows : !grad_val) return DVA_ERR_INVALID;
+  if (!row_idx && !grad_val) return DVA_ERR_INVALID;
   if (gate_w && !grad_gate_wb) return DVA_ERR_INVALID;
   if (algo < 0 || algo > 2) return DVA_ERR_INVALID;
   if (n_points == 0) return DVA_OK;
@@ -622,10 +733,33 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
                                   float* grad_gate_wb, int64_t n_points, int64_t n_views, int32_t C,
                                   int32_t G, int32_t scaling, int32_t dtype, int32_t algo,
                                   void* stream) {
-  if ((!row_idx || !grad_rows) && n_views > 0) return DVA_ERR_INVALID;
+  if (!row_idx && n_views > 0) return DVA_ERR_INVALID;
   return attention_bwd_entry(grad_out, rows, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
                              gate_b, nullptr, grad_compat, grad_gate_wb, n_points, n_views, C, G,
                              scaling, dtype, algo, stream);
+}
+
+int dva_view_gather_rows_grad(const void* grad_out, const float* att, const float* gate,
+                              const int32_t* view_point, const int32_t* perm, const int32_t* row_ptr,
+                              float* grad_rows, int64_t n_rows, int64_t n_views, int32_t C, int32_t G,
+                              int32_t dtype, void* stream) {
+  if (n_rows < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C) return DVA_ERR_INVALID;
+  if (n_views > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_rows == 0) return DVA_OK;
+  if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
+  if (n_views > 0 && (!grad_out || !att || !view_point || !perm)) return DVA_ERR_INVALID;
+  int rc;
+  if (dtype == DVA_F32)
+    rc = rows_grad_impl<float>(grad_out, att, gate, view_point, perm, row_ptr, grad_rows, n_rows, C, G,
+                               (hipStream_t)stream);
+  else if (dtype == DVA_BF16)
+    rc = rows_grad_impl<bf16_t>(grad_out, att, gate, view_point, perm, row_ptr, grad_rows, n_rows, C, G,
+                                (hipStream_t)stream);
+  else
+    return DVA_ERR_INVALID;
+  if (rc) return rc;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
 }
 
 }  // extern "C"

@@ -54,6 +54,60 @@ static int lex_layout(int64_t n, LexLayout* L) {
   return DVA_OK;
 }
 
+
+__global__ __launch_bounds__(256) void iota32_kernel(int32_t* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int32_t)i;
+}
+
+// Sorted row keys -> CSR pointers over ALL rows (rows nobody maps to get empty segments):
+// row_ptr[r] = first position whose key is >= r.  One extra thread (i == n) closes the tail.
+__global__ __launch_bounds__(256) void row_ptr_kernel(const uint32_t* __restrict__ sorted, int64_t n,
+                                                       int64_t n_rows, int32_t* __restrict__ row_ptr) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lo = i == 0 ? 0 : (int64_t)sorted[i - 1] + 1;
+    int64_t hi = i == n ? n_rows : (int64_t)sorted[i];
+    if (hi > n_rows) hi = n_rows;  // contract: keys < n_rows
+    for (int64_t r = lo; r <= hi; ++r) row_ptr[r] = (int32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void ptr_diff_kernel(const int32_t* __restrict__ row_ptr,
+                                                        int64_t n_rows, int32_t* __restrict__ counts) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows;
+       r += (int64_t)gridDim.x * blockDim.x)
+    counts[r] = row_ptr[r + 1] - row_ptr[r];
+}
+
+struct PlanLayout {
+  size_t off_iota, off_keys, off_temp, temp_bytes, total;
+};
+
+static int key_bits(int64_t n_rows) {
+  int b = 1;
+  while (b < 32 && ((int64_t)1 << b) < n_rows) ++b;
+  return b;
+}
+
+static int plan_layout(int64_t n, int bits, PlanLayout* L) {
+  size_t tmp = 0;
+  uint32_t* nk = nullptr;
+  int32_t* nv = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, tmp, nk, nk, nv, nv, (size_t)n, 0, bits, (hipStream_t)0) !=
+      hipSuccess)
+    return DVA_ERR_LAUNCH;
+  size_t off = 0;
+  L->off_iota = off;  off += align256((size_t)n * 4);
+  L->off_keys = off;  off += align256((size_t)n * 4);
+  L->off_temp = off;
+  L->temp_bytes = tmp;
+  off += align256(tmp);
+  L->total = off;
+  return DVA_OK;
+}
+
 static inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 8192) b = 8192;
@@ -126,6 +180,51 @@ int dva_argunique_i64(const int64_t* keys, int64_t n, int64_t* first, int64_t* n
   if (rocprim::select(ws + L.off_temp, tmp, vout, flags, first, n_unique_dev, (size_t)n, s) !=
       hipSuccess)
     return DVA_ERR_LAUNCH;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int64_t dva_row_plan_workspace_bytes(int64_t n_views, int64_t n_rows) {
+  if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
+  if (n_views > 0x7fffffffLL || n_rows > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_views == 0) return 256;
+  PlanLayout L;
+  int rc = plan_layout(n_views, key_bits(n_rows), &L);
+  if (rc) return rc;
+  return (int64_t)L.total;
+}
+
+int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_t* perm,
+                 int32_t* row_ptr, int32_t* counts, void* workspace, int64_t workspace_bytes,
+                 void* stream) {
+  if (n_views < 0 || n_rows < 0 || !row_ptr) return DVA_ERR_INVALID;
+  if (n_views > 0x7fffffffLL || n_rows > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_views == 0) {
+    if (hipMemsetAsync(row_ptr, 0, (size_t)(n_rows + 1) * 4, s) != hipSuccess) return DVA_ERR_LAUNCH;
+    if (counts && n_rows && hipMemsetAsync(counts, 0, (size_t)n_rows * 4, s) != hipSuccess)
+      return DVA_ERR_LAUNCH;
+    return DVA_OK;
+  }
+  if (!row_idx || !perm || !workspace) return DVA_ERR_INVALID;
+  PlanLayout L;
+  const int bits = key_bits(n_rows);
+  int rc = plan_layout(n_views, bits, &L);
+  if (rc) return rc;
+  if ((int64_t)L.total > workspace_bytes) return DVA_ERR_INVALID;
+  char* ws = (char*)workspace;
+  int32_t* iota = (int32_t*)(ws + L.off_iota);
+  uint32_t* kout = (uint32_t*)(ws + L.off_keys);
+  hipLaunchKernelGGL(iota32_kernel, dim3(grid_for(n_views)), dim3(256), 0, s, iota, n_views);
+  size_t tmp = L.temp_bytes;
+  if (rocprim::radix_sort_pairs(ws + L.off_temp, tmp, (const uint32_t*)row_idx, kout, iota, perm,
+                                (size_t)n_views, 0, bits, s) != hipSuccess)
+    return DVA_ERR_LAUNCH;
+  hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(n_views + 1)), dim3(256), 0, s, kout, n_views,
+                     n_rows, row_ptr);
+  if (counts)
+    hipLaunchKernelGGL(ptr_diff_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, row_ptr, n_rows,
+                       counts);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -193,7 +193,7 @@ def _pool_with_attention(module, x_mod, compatibilities, csr_idx):
               scaling=module.group_scaling)
     if isinstance(x_mod, ops.GatheredFeatures):
         x_pool, attentions, gating = ops.view_gather_attention(
-            x_mod.rows, x_mod.row_idx, compatibilities, csr_idx, **kw)
+            x_mod.rows, x_mod.row_idx, compatibilities, csr_idx, plan=x_mod.plan, **kw)
     else:
         x_pool, attentions, gating = ops.view_attention(x_mod, compatibilities, csr_idx, **kw)
     if G is not None and module.num_groups == 1:
@@ -255,7 +255,7 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
             val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts)
             if not fused_scores:
                 compatibilities = self.E_score(x_map)
-            x_mod = ops.GatheredFeatures(val_rows, x_mod.row_idx, x_mod.counts, x_mod.exact)
+            x_mod = x_mod.with_rows(val_rows)
         else:
             x_mod = self.E_mod(_materialize(x_mod))
             if self.use_mod:
@@ -334,8 +334,7 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
         else:
             x_map = self.E_map(x_map, csr_idx)
         if isinstance(x_mod, ops.GatheredFeatures) and not (self.use_mod_k or self.use_mod_q or self.debug):
-            x_mod = ops.GatheredFeatures(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts),
-                                         x_mod.row_idx, x_mod.counts, x_mod.exact)
+            x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts))
         else:
             x_mod = self.E_mod(_materialize(x_mod))
 

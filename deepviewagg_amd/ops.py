@@ -21,6 +21,7 @@ from . import _lib
 from ._lib import check, dtype_code, ptr, require_device, stream_of
 
 # 0 = auto, 1 = generic kernels, 2 = fused wavefront-team kernels (tests flip this)
+ROWS_GRAD_ALGO = 0    # 0: segmented reduction over the row plan; 1: fp32 atomics
 ATTENTION_ALGO = 0
 
 
@@ -427,17 +428,53 @@ def gather_bilinear(x, packed_idx, coords):
 # lazy view gather + fused gather-attention  (DESIGN.md "E_mod hoisting")
 # ---------------------------------------------------------------------------------------------
 
-def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True):
+def row_plan(row_idx, n_rows, with_counts=True):
+    """Views grouped by the feature-map row they read: ``(perm, row_ptr)`` int32 (+ ``counts`` int32
+    [n_rows]).  Stable, so the order of the views inside a row (and with it every sum over them) is
+    deterministic."""
+    lib = _lib.load()
+    require_device(row_idx)
+    V, dev = row_idx.shape[0], row_idx.device
+    perm = torch.empty(V, dtype=torch.int32, device=dev)
+    row_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    counts = torch.empty(n_rows, dtype=torch.int32, device=dev) if with_counts else None
+    nbytes = lib.dva_row_plan_workspace_bytes(V, n_rows)
+    if nbytes < 0:
+        raise _lib.DvaError("dva_row_plan_workspace_bytes", int(nbytes))
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    with _timed("row_plan", V * 16):
+        check(lib.dva_row_plan(ptr(row_idx), V, n_rows, ptr(perm), ptr(row_ptr), ptr(counts), ptr(ws),
+                               int(nbytes), stream_of(row_idx)), "dva_row_plan")
+    return (perm, row_ptr), counts
+
+
+def csr_expand(csr_idx, n_views):
+    """int32 [V]: the point (segment) of every view -- the dense form of the CSR pointers."""
+    lib = _lib.load()
+    require_device(csr_idx)
+    vp = torch.empty(n_views, dtype=torch.int32, device=csr_idx.device)
+    check(lib.dva_csr_expand(ptr(csr_idx), csr_idx.shape[0] - 1, ptr(vp), stream_of(csr_idx)),
+          "dva_csr_expand")
+    return vp
+
+
+def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True, with_plan=False):
     """Flat row index of every atom into the [B*H*W, C] view of a channels-last map, and the number
-    of atoms per row (int32 [B*H*W]) if ``with_counts``."""
+    of atoms per row (int32 [B*H*W]) if ``with_counts``.  ``with_plan``: also return the row plan
+    (``row_plan``); the counts then come from the plan instead of a histogram with atomics."""
     lib = _lib.load()
     require_device(packed_idx)
     P = packed_idx.shape[0]
     row_idx = torch.empty(P, dtype=torch.int32, device=packed_idx.device)
-    counts = torch.zeros(B * H * W, dtype=torch.int32, device=packed_idx.device) if with_counts else None
+    hist = with_counts and not with_plan
+    counts = torch.zeros(B * H * W, dtype=torch.int32, device=packed_idx.device) if hist else None
     with _timed("gather_row_index", P * 12):
         check(lib.dva_gather_row_index(ptr(packed_idx), P, B, H, W, int(row_offset), ptr(row_idx),
                                        ptr(counts), stream_of(packed_idx)), "dva_gather_row_index")
+    if with_plan:
+        assert row_offset == 0, "a plan is built over the rows of one map"
+        plan, counts = row_plan(row_idx, B * H * W, with_counts)
+        return row_idx, counts, plan
     return row_idx, counts
 
 
@@ -452,8 +489,14 @@ class GatheredFeatures:
     ``exact`` tells that every view owns exactly one atom (P == V): the atomic pool is the identity.
     """
 
-    def __init__(self, rows, row_idx, counts, exact):
+    def __init__(self, rows, row_idx, counts, exact, plan=None):
         self.rows, self.row_idx, self.counts, self.exact = rows, row_idx, counts, exact
+        self.plan = plan    # (perm, row_ptr) of row_idx, or None: built on demand in backward
+
+    def with_rows(self, rows):
+        """Same gather applied to another [R, C'] row tensor (e.g. E_mod(rows))."""
+        assert rows.shape[0] == self.rows.shape[0]
+        return GatheredFeatures(rows, self.row_idx, self.counts, self.exact, self.plan)
 
     @property
     def shape(self):
@@ -483,6 +526,8 @@ class GatheredFeatures:
             idx.append(it.row_idx + offs)
             cnt.append(it.counts)
             offs += it.rows.shape[0]
+        if len(items) == 1 and order is None:
+            return items[0]
         row_idx = torch.cat(idx)
         if order is not None:
             row_idx = row_idx[order]
@@ -495,8 +540,8 @@ def lazy_gather_nearest(x, packed_idx, exact):
     assert x.dim() == 4
     B, C, H, W = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
-    row_idx, counts = gather_row_index(packed_idx, B, H, W)
-    return GatheredFeatures(rows, row_idx, counts, exact)
+    row_idx, counts, plan = gather_row_index(packed_idx, B, H, W, with_plan=True)
+    return GatheredFeatures(rows, row_idx, counts, exact, plan)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -522,9 +567,10 @@ def gather_rows(rows, row_idx):
 
 class _ViewGatherAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rows, row_idx, compat, csr_idx, gate_w, gate_b, scaling, eps):
+    def forward(ctx, rows, row_idx, compat, csr_idx, gate_w, gate_b, scaling, eps, plan):
         lib = _lib.load()
         require_device(rows, row_idx, compat, csr_idx, gate_w, gate_b)
+        ctx.plan = plan
         rows = rows.contiguous()
         compat = compat.contiguous()
         N, V, (R, C), G = csr_idx.shape[0] - 1, row_idx.shape[0], rows.shape, compat.shape[1]
@@ -558,27 +604,46 @@ class _ViewGatherAttention(torch.autograd.Function):
         scaling, has_gate, w_shape, b_shape = ctx.meta
         gout = gout.contiguous()
         N, V, (R, C), G = csr_idx.shape[0] - 1, row_idx.shape[0], rows.shape, compat.shape[1]
-        grows = torch.zeros((R, C), dtype=torch.float32, device=rows.device)
         gcompat = torch.zeros_like(compat)
         gwb = torch.zeros(2 * G, dtype=torch.float32, device=rows.device) if has_gate else None
         es = rows.element_size()
+        need_rows = ctx.needs_input_grad[0]
+        use_plan = need_rows and ROWS_GRAD_ALGO == 0
+        if need_rows and not use_plan:
+            grows = torch.zeros((R, C), dtype=torch.float32, device=rows.device)
+        else:
+            grows = None
         with _timed("view_gather_attention_bwd",
-                    V * (C * es + 4 + 2 * G * 4 + C * 4 * 2) + N * (C * es + 8 + 3 * G * 4)):
+                    V * (C * es + 4 + 2 * G * 4 + (C * 4 * 2 if grows is not None else 0))
+                    + N * (C * es + 8 + 3 * G * 4)):
             check(lib.dva_view_gather_attention_bwd(
                 ptr(gout), ptr(rows), ptr(row_idx), ptr(compat), ptr(att), ptr(gate), ptr(amax),
                 ptr(csr_idx), ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(grows),
                 ptr(gcompat), ptr(gwb), N, V, C, G, scaling, dtype_code(rows), ATTENTION_ALGO,
                 stream_of(rows)), "dva_view_gather_attention_bwd")
+        if use_plan:
+            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
+            perm, row_ptr = plan
+            vp = csr_expand(csr_idx, V)
+            grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
+            # per view: perm + view_point + grad_out row + att/gate scores; per row: fp32 row written
+            with _timed("view_gather_rows_grad", V * (8 + C * es + 2 * G * 4) + R * (C * 4 + 4)):
+                check(lib.dva_view_gather_rows_grad(
+                    ptr(gout), ptr(att), ptr(gate) if has_gate else None, ptr(vp), ptr(perm), ptr(row_ptr),
+                    ptr(grows), R, V, C, G, dtype_code(rows), stream_of(rows)),
+                    "dva_view_gather_rows_grad")
         g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
         g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
-        return grows.to(rows.dtype), None, gcompat, None, g_w, g_b, None, None
+        return (grows.to(rows.dtype) if grows is not None else None), None, gcompat, None, g_w, g_b, \
+            None, None, None
 
 
 def view_gather_attention(rows, row_idx, compat, csr_idx, gate_w=None, gate_b=None, scaling=False,
-                          eps=1e-12):
-    """``view_attention`` with the view gather fused in: the value of view v is ``rows[row_idx[v]]``."""
+                          eps=1e-12, plan=None):
+    """``view_attention`` with the view gather fused in: the value of view v is ``rows[row_idx[v]]``.
+    ``plan`` = ``row_plan(row_idx, R)[0]`` if the caller already has it (else built in backward)."""
     csr_idx = _check_ptr(csr_idx)
     if compat.dim() == 1:
         compat = compat.reshape(-1, 1)
     return _ViewGatherAttention.apply(rows, row_idx.contiguous(), compat.float(), csr_idx, gate_w, gate_b,
-                                      scaling, eps)
+                                      scaling, eps, plan)

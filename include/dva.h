@@ -154,7 +154,9 @@ int dva_view_attention_bwd(const void* grad_out, const void* val, const float* c
 /* Same maths with the view gather fused in: the value of view v is rows[row_idx[v], :]
  * (rows = [R, C] value map, e.g. E_mod applied at feature-map level; DESIGN.md "E_mod hoisting").
  * Replaces image.py:1285 + pooling.py:284-300 in one pass: no [V, C] tensor is materialised.
- * Backward scatter-adds into grad_rows fp32 [R, C] (caller-zeroed, atomics). */
+ * Backward: grad_rows fp32 [R, C] non-NULL = scatter-add with atomics (caller-zeroed);
+ * grad_rows NULL = only grad_compat / grad_gate_wb are produced and the caller obtains the rows
+ * gradient from dva_view_gather_rows_grad (segmented reduction, deterministic, faster). */
 int dva_view_gather_attention_fwd(const void* rows, const int32_t* row_idx, const float* compat,
                                   const int64_t* ptr, const float* gate_w, const float* gate_b,
                                   void* out, float* att, float* gate, int32_t* amax,
@@ -168,6 +170,24 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
                                   float* grad_gate_wb, int64_t n_points, int64_t n_views, int32_t C,
                                   int32_t G, int32_t scaling, int32_t dtype, int32_t algo,
                                   void* stream);
+
+/* Transposed view of a row index (views grouped by the feature-map row they read): the backward of
+ * the gather in image.py:1285 (index_select -> index_add) as a CSR over rows.
+ * row_idx int32 [n_views] with values in [0, n_rows).  Outputs: perm int32 [n_views] (view ids
+ * ordered by row, original order inside a row: stable radix sort), row_ptr int32 [n_rows+1],
+ * counts int32 [n_rows] (nullable) = views per row.  n_views, n_rows < 2^31. */
+int64_t dva_row_plan_workspace_bytes(int64_t n_views, int64_t n_rows);
+int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_t* perm,
+                 int32_t* row_ptr, int32_t* counts, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+/* grad_rows[r, c] = sum over the views v of row r of grad_out[p(v), c] * gate[p(v), g(c)] *
+ * att[v, g(c)]  (written, not accumulated; fp32 [n_rows, C]).  view_point int32 [n_views] = point of
+ * every view (dva_csr_expand); gate nullable (no gating); grad_out [n_points, C] in dtype. */
+int dva_view_gather_rows_grad(const void* grad_out, const float* att, const float* gate,
+                              const int32_t* view_point, const int32_t* perm, const int32_t* row_ptr,
+                              float* grad_rows, int64_t n_rows, int64_t n_views, int32_t C, int32_t G,
+                              int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Fused DeepSetFeat (+ score Linear) chain over the V views, exact fp32, forward and backward.

@@ -261,3 +261,76 @@ def test_gather_random_vs_oracle(dtype, C):
     ref = O.sparse_interpolation(x.float(), coords, images)
     tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
     close(out, ref, **tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# row plan (views grouped by feature-map row) and the rows gradient as a segmented reduction
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("V,R", [(0, 5), (1, 1), (1000, 7), (50000, 4096), (300000, 1 << 18)])
+def test_row_plan_is_a_stable_sort(V, R):
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(V + R)
+    row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    if V > 10:
+        row_idx[row_idx == 3] = 4                     # an empty row in the middle
+    (perm, row_ptr), counts = ops.row_plan(row_idx.to(DEV), R)
+    ref_perm = torch.sort(row_idx.long(), stable=True).indices
+    ref_counts = torch.bincount(row_idx.long(), minlength=R)
+    assert torch.equal(perm.cpu().long(), ref_perm)
+    assert torch.equal(counts.cpu().long(), ref_counts)
+    assert torch.equal(row_ptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), ref_counts.cumsum(0)]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,G,gating", [(64, 4, True), (32, 1, False), (24, 3, True), (128, 8, True)])
+def test_rows_grad_plan_equals_atomics(C, G, gating, dtype):
+    """grad wrt the feature-map rows: segmented reduction over the plan == fp32 atomics == torch."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C * G)
+    N, R = 2000, 300
+    sizes = torch.randint(0, 9, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    row_idx = torch.randint(0, R - 20, (V,), generator=gen, dtype=torch.int32)   # last rows unused
+    rows = torch.randn(R, C, generator=gen).to(dtype)
+    compat = torch.randn(V, G, generator=gen)
+    gw = torch.randn(G, generator=gen) if gating else None
+    gb = torch.randn(G, generator=gen) if gating else None
+    w = torch.randn(N, C, generator=gen)
+
+    def run(algo, plan):
+        old, ops.ROWS_GRAD_ALGO = ops.ROWS_GRAD_ALGO, algo
+        try:
+            rd = rows.to(DEV).requires_grad_()
+            cd = compat.to(DEV).requires_grad_()
+            gwd = gw.to(DEV).requires_grad_() if gating else None
+            gbd = gb.to(DEV).requires_grad_() if gating else None
+            out, _, _ = ops.view_gather_attention(rd, row_idx.to(DEV), cd, csr.to(DEV), gwd, gbd, plan=plan)
+            ins = [rd, cd] + ([gwd, gbd] if gating else [])
+            return [out] + list(torch.autograd.grad((out.float() * w.to(DEV)).sum(), ins))
+        finally:
+            ops.ROWS_GRAD_ALGO = old
+
+    plan = ops.row_plan(row_idx.to(DEV), R, with_counts=False)[0]
+    a = run(1, None)
+    b = run(0, None)          # plan built on demand in backward
+    c = run(0, plan)
+    for x, y in zip(b[:3], c[:3]):      # out, grad rows, grad compat: deterministic, bit-identical
+        assert torch.equal(x, y)
+    for x, y in zip(b[3:], c[3:]):      # gate parameters: atomically accumulated sums
+        close(x, y, rtol=1e-5, atol=1e-5)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    for x, y in zip(a, b):
+        close(x, y, **tol)
+    assert float(b[1][R - 20:].abs().max()) == 0.0
+    # torch reference on the materialised gather
+    rr = rows.float().requires_grad_()
+    x_mod = rr[row_idx.long()]
+    att = O.segment_softmax_csr(compat, csr, scaling=False)
+    xp = O.segment_csr(x_mod * O.expand_group_feat(att, G, C), csr, 'sum')
+    if gating:
+        mx = O.segment_csr(compat, csr, 'max')
+        xp = xp * O.expand_group_feat(torch.tanh(torch.relu(mx * gw + gb)), G, C)
+    g_ref = torch.autograd.grad((xp * w).sum(), rr)[0]
+    close(b[1], g_ref, **(dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)))
