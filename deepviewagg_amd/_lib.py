@@ -96,15 +96,16 @@ SIGNATURES = {
     "dva_view_gather_rows_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
                                                  _i32, _vp]),
     "dva_csr_expand": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
-    "dva_deepset_fwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "dva_deepset_fwd_layer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "dva_deepset_fwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "dva_deepset_bwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "dva_deepset_fwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "dva_deepset_fwd_layer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "dva_deepset_fwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "dva_deepset_bwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
+                                             _vp]),
     "dva_deepset_bwd_layer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                             _vp, _i64, _i32, _i32, _i32, _vp]),
-    "dva_deepset_bwd_max": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "dva_deepset_bwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+                                             _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "dva_deepset_bwd_max": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "dva_deepset_bwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "dva_lex_workspace_bytes": (ctypes.c_int64, [_i64]),
     "dva_argsort_i64": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dva_argunique_i64": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void dsf_fwd_first_kernel(const float* __restr
 }
 
 // pooled[p, c] = max over the point's views of leaky(BN(a[v, c])) (first row on ties), arg = that row
-__global__ __launch_bounds__(256) void dsf_segmax_kernel(const float* __restrict__ a,
+template <typename AT>
+__global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ a,
                                                           const float* __restrict__ bn,
                                                           const int64_t* __restrict__ ptr,
                                                           float* __restrict__ pooled,
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void dsf_segmax_kernel(const float* __restrict
     float m = 0.f;
     int64_t am = -1;
     for (int64_t r = beg; r < end; ++r) {
-      const float v = leaky(bn_z(a[r * D + n], b));
+      const float v = leaky(bn_z(Elt<AT>::ld(a, r * D + n), b));
       if (r == beg || v > m) {
         m = v;
         am = r;
@@ -521,8 +522,9 @@ __global__ __launch_bounds__(256) void dsf_bwd_max_kernel(
 }
 
 // First layer: a1 = x.Wa^T recomputed, da1 = BN-backward(dz1), dWa[n][j] += da1[v][n] x[v][j]
+template <typename AT>
 __global__ __launch_bounds__(256) void dsf_bwd_first_kernel(
-    const float* __restrict__ dz1, const float* __restrict__ x_map, const float* __restrict__ Wa,
+    const AT* __restrict__ dz1, const float* __restrict__ x_map, const float* __restrict__ Wa,
     const float* __restrict__ bn1, const float* __restrict__ sm1, float* __restrict__ dWa, int64_t V) {
   __shared__ __attribute__((aligned(16))) float s_x[4][TILE * 8];
   __shared__ float s_red[D * 8];
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void dsf_bwd_first_kernel(
       const int64_t r = row0 + row;
       if (r < V) {
         const float a1 = dot_row<8>(&s_x[wv][row * 8], wa);
-        const float da = gsc * (dz1[r * D + n] - s1m - bn_hat(a1, b) * s2m);
+        const float da = gsc * (Elt<AT>::ld(dz1, r * D + n) - s1m - bn_hat(a1, b) * s2m);
         const float4 x0 = *reinterpret_cast<const float4*>(&s_x[wv][row * 8]);
         const float4 x1 = *reinterpret_cast<const float4*>(&s_x[wv][row * 8 + 4]);
         acc[0] = fmaf(da, x0.x, acc[0]); acc[1] = fmaf(da, x0.y, acc[1]);
@@ -591,21 +593,25 @@ static inline int grid_rows(int64_t V) {
   return (int)b;
 }
 
-// fp32-MFMA generation of the layer kernels (deepset_mfma.hip)
-int dsm_launch_fwd_first(const float*, const float*, const float*, const float*, float*, double*, int64_t,
-                         int, hipStream_t);
-int dsm_launch_fwd_layer(const float*, const float*, const float*, const float*, const int32_t*, float*,
-                         double*, int64_t, hipStream_t);
-int dsm_launch_fwd_score(const float*, const float*, const float*, const float*, float*, int64_t, int,
-                         hipStream_t);
-int dsm_launch_bwd_layer(const float*, const float*, const float*, const float*, const float*, const float*,
-                         const float*, const float*, float*, float*, double*, float*, const int32_t*,
-                         int64_t, int, int, hipStream_t);
-
-int dsm_launch_bwd_max(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*,
-                       float*, double*, int64_t, hipStream_t);
-int dsm_launch_bwd_score(const float*, const float*, const float*, const float*, float*, float*, float*,
+// fp32-MFMA generation of the layer kernels (deepset_mfma.hip); bf = bf16 activation storage
+int dsm_launch_fwd_first(const float*, const float*, const float*, const float*, void*, double*, int64_t,
+                         int, int, hipStream_t);
+int dsm_launch_fwd_layer(const void*, const float*, const float*, const float*, const int32_t*, void*,
                          double*, int64_t, int, hipStream_t);
+int dsm_launch_fwd_score(const void*, const float*, const float*, const float*, float*, int64_t, int, int,
+                         hipStream_t);
+int dsm_launch_bwd_layer(const void*, const void*, const float*, const float*, const float*, const void*,
+                         const float*, const float*, void*, float*, double*, float*, const int32_t*,
+                         int64_t, int, int, int, hipStream_t);
+int dsm_launch_bwd_max(const void*, const void*, const float*, const int32_t*, const float*, const int32_t*,
+                       void*, double*, int64_t, int, hipStream_t);
+int dsm_launch_bwd_score(const float*, const void*, const float*, const float*, void*, float*, float*,
+                         double*, int64_t, int, int, hipStream_t);
+
+// activation storage code of the C ABI -> 0 (fp32) / 1 (bf16) / -1 (invalid)
+static inline int act_bf(int32_t act_dtype) {
+  return act_dtype == DVA_F32 ? 0 : act_dtype == DVA_BF16 ? 1 : -1;
+}
 
 }  // namespace dva
 
@@ -626,16 +632,19 @@ int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, 
 }
 
 int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb,
-                          float* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
-                          int32_t algo, void* stream) {
-  if (V < 0 || !stats) return DVA_ERR_INVALID;
+                          void* a2_, double* stats, int64_t V, int32_t F, int32_t stats_only,
+                          int32_t algo, int32_t act_dtype, void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || !stats || bf < 0) return DVA_ERR_INVALID;
+  if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;  // bf16 storage only in the MFMA generation
+  float* a2 = (float*)a2_;
   if (F != 8) return DVA_ERR_UNSUPPORTED;
   if (V == 0) return DVA_OK;
   if (!x_map || !Wa) return DVA_ERR_INVALID;
   if (!stats_only && (!bn1 || !Wb || !a2)) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   if (algo != 1) {
-    dsm_launch_fwd_first(x_map, Wa, bn1, Wb, a2, stats, V, stats_only, s);
+    dsm_launch_fwd_first(x_map, Wa, bn1, Wb, a2_, stats, V, stats_only, bf, s);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -651,30 +660,39 @@ int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1,
   return DVA_OK;
 }
 
-int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, float* pooled,
-                       int32_t* arg, int64_t N, void* stream) {
-  if (N < 0) return DVA_ERR_INVALID;
+int dva_deepset_segmax(const void* a, const float* bn, const int64_t* ptr, float* pooled,
+                       int32_t* arg, int64_t N, int32_t act_dtype, void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (N < 0 || bf < 0) return DVA_ERR_INVALID;
   if (N == 0) return DVA_OK;
   if (!a || !bn || !ptr || !pooled || !arg) return DVA_ERR_INVALID;
   int64_t b = (N + 7) / 8;
   if (b > 256 * 8) b = 256 * 8;
-  hipLaunchKernelGGL(dsf_segmax_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, a, bn, ptr,
-                     pooled, arg, N);
+  if (bf)
+    hipLaunchKernelGGL((dsf_segmax_kernel<bf16_t>), dim3((int)b), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)a, bn, ptr, pooled, arg, N);
+  else
+    hipLaunchKernelGGL((dsf_segmax_kernel<float>), dim3((int)b), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)a, bn, ptr, pooled, arg, N);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
 
-int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
-                          const int32_t* group_of_row, float* a_out, double* stats, int64_t V,
-                          int32_t algo, void* stream) {
-  if (V < 0 || !stats) return DVA_ERR_INVALID;
+int dva_deepset_fwd_layer(const void* a_in_, const float* bn_in, const float* W, const float* addend,
+                          const int32_t* group_of_row, void* a_out_, double* stats, int64_t V,
+                          int32_t algo, int32_t act_dtype, void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || !stats || bf < 0) return DVA_ERR_INVALID;
+  if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  const float* a_in = (const float*)a_in_;
+  float* a_out = (float*)a_out_;
   if (V == 0) return DVA_OK;
   if (!a_in || !W || !a_out) return DVA_ERR_INVALID;
   if (addend && !group_of_row) return DVA_ERR_INVALID;
   if (!bn_in && algo == 1) return DVA_ERR_UNSUPPORTED;  // raw-input layers only in the MFMA generation
   hipStream_t s = (hipStream_t)stream;
   if (algo != 1) {
-    dsm_launch_fwd_layer(a_in, bn_in, W, addend, group_of_row, a_out, stats, V, s);
+    dsm_launch_fwd_layer(a_in_, bn_in, W, addend, group_of_row, a_out_, stats, V, bf, s);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -688,13 +706,17 @@ int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W,
   return DVA_OK;
 }
 
-int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs,
-                          float* compat, int64_t V, int32_t G, int32_t algo, void* stream) {
-  if (V < 0 || G <= 0 || G > 32) return DVA_ERR_INVALID;
+int dva_deepset_fwd_score(const void* a_, const float* bn, const float* Ws, const float* bs,
+                          float* compat, int64_t V, int32_t G, int32_t algo, int32_t act_dtype,
+                          void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || G <= 0 || G > 32 || bf < 0) return DVA_ERR_INVALID;
+  if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  const float* a = (const float*)a_;
   if (V == 0) return DVA_OK;
   if (!a || !bn || !Ws || !bs || !compat) return DVA_ERR_INVALID;
   if (algo != 1) {
-    dsm_launch_fwd_score(a, bn, Ws, bs, compat, V, G, (hipStream_t)stream);
+    dsm_launch_fwd_score(a_, bn, Ws, bs, compat, V, G, bf, (hipStream_t)stream);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -706,15 +728,19 @@ int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, cons
   return DVA_OK;
 }
 
-int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws,
-                          float* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
-                          int32_t algo, void* stream) {
-  if (V < 0 || G <= 0) return DVA_ERR_INVALID;
+int dva_deepset_bwd_score(const float* dcompat, const void* a_, const float* bn, const float* Ws,
+                          void* dz_, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
+                          int32_t algo, int32_t act_dtype, void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || G <= 0 || bf < 0) return DVA_ERR_INVALID;
+  if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  const float* a = (const float*)a_;
+  float* dz = (float*)dz_;
   if (G > 32) return DVA_ERR_UNSUPPORTED;
   if (V == 0) return DVA_OK;
   if (!dcompat || !a || !bn || !Ws || !dz || !dWs || !dbs || !st) return DVA_ERR_INVALID;
   if (algo != 1) {
-    dsm_launch_bwd_score(dcompat, a, bn, Ws, dz, dWs, dbs, st, V, G, (hipStream_t)stream);
+    dsm_launch_bwd_score(dcompat, a_, bn, Ws, dz_, dWs, dbs, st, V, G, bf, (hipStream_t)stream);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -728,12 +754,16 @@ int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn,
   return DVA_OK;
 }
 
-int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L, const float* sm_L,
-                          const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
-                          float* out, float* dW, double* st_prev, float* dt,
+int dva_deepset_bwd_layer(const void* dz_L_, const void* a_L_, const float* bn_L, const float* sm_L,
+                          const float* W_L, const void* a_prev_, const float* Wa, const float* bn_prev,
+                          void* out_, float* dW, double* st_prev, float* dt,
                           const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
-                          int32_t raw_out, int32_t algo, void* stream) {
-  if (V < 0) return DVA_ERR_INVALID;
+                          int32_t raw_out, int32_t algo, int32_t act_dtype, void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || bf < 0) return DVA_ERR_INVALID;
+  if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  const float *dz_L = (const float*)dz_L_, *a_L = (const float*)a_L_, *a_prev = (const float*)a_prev_;
+  float* out = (float*)out_;
   if (V == 0) return DVA_OK;
   if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || !out || !dW) return DVA_ERR_INVALID;
   if (!bn_prev && (!raw_out || algo == 1 || prev_is_xmap)) return DVA_ERR_UNSUPPORTED;
@@ -742,8 +772,8 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
   if (dt && !group_of_row) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   if (algo != 1) {
-    dsm_launch_bwd_layer(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt,
-                         group_of_row, V, prev_is_xmap, raw_out, s);
+    dsm_launch_bwd_layer(dz_L_, a_L_, bn_L, sm_L, W_L, a_prev_, Wa, bn_prev, out_, dW, st_prev, dt,
+                         group_of_row, V, prev_is_xmap, raw_out, bf, s);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -760,14 +790,18 @@ int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L
   return DVA_OK;
 }
 
-int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
-                        const float* dpooled, const int32_t* group_of_row, float* dz2, double* st,
-                        int64_t V, int32_t algo, void* stream) {
-  if (V < 0) return DVA_ERR_INVALID;
+int dva_deepset_bwd_max(const void* dcat_, const void* a2_, const float* bn2, const int32_t* arg,
+                        const float* dpooled, const int32_t* group_of_row, void* dz2_, double* st,
+                        int64_t V, int32_t algo, int32_t act_dtype, void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || bf < 0) return DVA_ERR_INVALID;
+  if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  const float *dcat = (const float*)dcat_, *a2 = (const float*)a2_;
+  float* dz2 = (float*)dz2_;
   if (V == 0) return DVA_OK;
   if (!dcat || !a2 || !bn2 || !arg || !dpooled || !group_of_row || !dz2 || !st) return DVA_ERR_INVALID;
   if (algo != 1) {
-    dsm_launch_bwd_max(dcat, a2, bn2, arg, dpooled, group_of_row, dz2, st, V, (hipStream_t)stream);
+    dsm_launch_bwd_max(dcat_, a2_, bn2, arg, dpooled, group_of_row, dz2_, st, V, bf, (hipStream_t)stream);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -777,14 +811,20 @@ int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, co
   return DVA_OK;
 }
 
-int dva_deepset_bwd_first(const float* dz1, const float* x_map, const float* Wa, const float* bn1,
-                          const float* sm1, float* dWa, int64_t V, int32_t F, void* stream) {
-  if (V < 0) return DVA_ERR_INVALID;
+int dva_deepset_bwd_first(const void* dz1, const float* x_map, const float* Wa, const float* bn1,
+                          const float* sm1, float* dWa, int64_t V, int32_t F, int32_t act_dtype,
+                          void* stream) {
+  const int bf = act_bf(act_dtype);
+  if (V < 0 || bf < 0) return DVA_ERR_INVALID;
   if (F != 8) return DVA_ERR_UNSUPPORTED;
   if (V == 0) return DVA_OK;
   if (!dz1 || !x_map || !Wa || !bn1 || !sm1 || !dWa) return DVA_ERR_INVALID;
-  hipLaunchKernelGGL(dsf_bwd_first_kernel, dim3(grid_rows(V)), dim3(256), 0, (hipStream_t)stream, dz1,
-                     x_map, Wa, bn1, sm1, dWa, V);
+  if (bf)
+    hipLaunchKernelGGL((dsf_bwd_first_kernel<bf16_t>), dim3(grid_rows(V)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)dz1, x_map, Wa, bn1, sm1, dWa, V);
+  else
+    hipLaunchKernelGGL((dsf_bwd_first_kernel<float>), dim3(grid_rows(V)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)dz1, x_map, Wa, bn1, sm1, dWa, V);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

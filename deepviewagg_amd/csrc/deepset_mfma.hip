@@ -73,6 +73,53 @@ __device__ __forceinline__ void store_acc_layout(float* __restrict__ row, int h,
         make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
 }
 
+__device__ __forceinline__ void store16(float* __restrict__ p, const float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(p + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
+// bf16 storage of the [V, 32] activation / gradient tensors (arithmetic stays fp32): a half row is
+// 32 bytes (2 x 16-byte accesses), a group of 4 accumulator channels 8 bytes.
+__device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) {
+  lo = __uint_as_float(u << 16);
+  hi = __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void load16(const bf16_t* __restrict__ p, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p + 8 * q);
+    unpack_bf16x2(v.x, x[8 * q], x[8 * q + 1]);
+    unpack_bf16x2(v.y, x[8 * q + 2], x[8 * q + 3]);
+    unpack_bf16x2(v.z, x[8 * q + 4], x[8 * q + 5]);
+    unpack_bf16x2(v.w, x[8 * q + 6], x[8 * q + 7]);
+  }
+}
+__device__ __forceinline__ void store16(bf16_t* __restrict__ p, const float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    *reinterpret_cast<uint4*>(p + 8 * q) =
+        make_uint4(pack_bf16x2(x[8 * q], x[8 * q + 1]), pack_bf16x2(x[8 * q + 2], x[8 * q + 3]),
+                   pack_bf16x2(x[8 * q + 4], x[8 * q + 5]), pack_bf16x2(x[8 * q + 6], x[8 * q + 7]));
+}
+__device__ __forceinline__ void load_acc_layout(const bf16_t* __restrict__ row, int h, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint2 v = *reinterpret_cast<const uint2*>(row + 8 * q + 4 * h);
+    unpack_bf16x2(v.x, x[4 * q], x[4 * q + 1]);
+    unpack_bf16x2(v.y, x[4 * q + 2], x[4 * q + 3]);
+  }
+}
+__device__ __forceinline__ void store_acc_layout(bf16_t* __restrict__ row, int h, const f32x16& a) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<uint2*>(row + 8 * q + 4 * h) =
+        make_uint2(pack_bf16x2(a[4 * q], a[4 * q + 1]), pack_bf16x2(a[4 * q + 2], a[4 * q + 3]));
+}
+
 // Sum vals[r] over the 32 lanes of a half-wave; lanes 0 / 32 then add channel acc_chan(r,h) to s_red.
 __device__ __forceinline__ void reduce_acc_channels(float (&vals)[16], float* s_red, int lane) {
 #pragma unroll
@@ -163,12 +210,12 @@ __device__ __forceinline__ void bn_norm16(const float (*t)[DM], int h, const flo
 // ------------------------------------------------------------------------------------------------
 
 // x_map [V,8] -> a1 (stats only) or -> a1 -> BN1 -> leaky -> a2 (written, with stats)
-template <bool STATS_ONLY>
+template <typename AT, bool STATS_ONLY>
 __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restrict__ x_map,
                                                              const float* __restrict__ Wa,
                                                              const float* __restrict__ bn1,
                                                              const float* __restrict__ Wb,
-                                                             float* __restrict__ a2,
+                                                             AT* __restrict__ a2,
                                                              double* __restrict__ stats, int64_t V) {
   __shared__ float s_red[2 * DM];
   __shared__ __attribute__((aligned(16))) float s_bn[4][DM];
@@ -225,11 +272,14 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
 
 // a_out[v] = leaky(BN_in(a_in[v])) . W^T (+ addend[vp[v]]) ; statistics of a_out.
 // SCORE: W has G <= 32 valid rows (others zero), bias added, only columns < G stored, no statistics.
-template <bool HAS_ADD, bool SCORE>
+template <typename AT, bool HAS_ADD, bool SCORE>
 __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
-    const float* __restrict__ a_in, const float* __restrict__ bn_in, const float* __restrict__ W,
+    const AT* __restrict__ a_in, const float* __restrict__ bn_in, const float* __restrict__ W,
     const float* __restrict__ addend, const int32_t* __restrict__ vp, const float* __restrict__ bias,
-    float* __restrict__ a_out, double* __restrict__ stats, int64_t V, int G) {
+    void* __restrict__ a_out_, double* __restrict__ stats, int64_t V, int G) {
+  // SCORE writes the fp32 compatibilities [V, G]; layers write activations in the storage type
+  float* __restrict__ c_out = reinterpret_cast<float*>(a_out_);
+  AT* __restrict__ a_out = reinterpret_cast<AT*>(a_out_);
   __shared__ float s_red[2 * DM];
   __shared__ __attribute__((aligned(16))) float s_bn[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -268,12 +318,12 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
       if (ok) {
         if (G == 4) {
           if (h == 0)
-            *reinterpret_cast<float4*>(a_out + v * 4) =
+            *reinterpret_cast<float4*>(c_out + v * 4) =
                 make_float4(acc[0] + bia[0], acc[1] + bia[1], acc[2] + bia[2], acc[3] + bia[3]);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (acc_chan(r, h) < G) a_out[v * G + acc_chan(r, h)] = acc[r] + bia[r];
+            if (acc_chan(r, h) < G) c_out[v * G + acc_chan(r, h)] = acc[r] + bia[r];
         }
       }
     } else {
@@ -297,13 +347,16 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward (same contract as dsf_bwd_layer_kernel in deepset.hip)
 // ------------------------------------------------------------------------------------------------
-template <bool PREV_XMAP, bool RAW_OUT, bool HAS_DT>
+template <typename AT, bool PREV_XMAP, bool RAW_OUT, bool HAS_DT>
 __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
-    const float* __restrict__ dz_L, const float* __restrict__ a_L, const float* __restrict__ bn_L,
-    const float* __restrict__ sm_L, const float* __restrict__ W_L, const float* __restrict__ a_prev,
-    const float* __restrict__ Wa, const float* __restrict__ bn_prev, float* __restrict__ out,
+    const AT* __restrict__ dz_L, const AT* __restrict__ a_L, const float* __restrict__ bn_L,
+    const float* __restrict__ sm_L, const float* __restrict__ W_L, const void* __restrict__ a_prev_,
+    const float* __restrict__ Wa, const float* __restrict__ bn_prev, AT* __restrict__ out,
     float* __restrict__ dW, double* __restrict__ st_prev, float* __restrict__ dt,
     const int32_t* __restrict__ vp, int64_t V) {
+  // the layer input: raw x_map rows (fp32 [V, 8]) or activations in the storage type
+  const float* __restrict__ x_prev = reinterpret_cast<const float*>(a_prev_);
+  const AT* __restrict__ a_prev = reinterpret_cast<const AT*>(a_prev_);
   __shared__ float s_red[DM * DM];
   __shared__ __attribute__((aligned(16))) float s_c[5][DM];  // BN_L: gsc | mean | invstd | S1/M | S2/M
   __shared__ __attribute__((aligned(16))) float s_p[4][DM];  // BN_prev table
@@ -347,7 +400,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     load16(dz_L + vc * DM + 16 * h, dzv);
     load16(a_L + vc * DM + 16 * h, alv);
     float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PREV_XMAP) xm = *reinterpret_cast<const float4*>(a_prev + vc * 8 + 4 * h);
+    if (PREV_XMAP) xm = *reinterpret_cast<const float4*>(x_prev + vc * 8 + 4 * h);
     else load_acc_layout(a_prev + vc * DM, h, ap);
     int32_t pnt = 0;
     if (HAS_DT) pnt = vp[vc];
@@ -455,10 +508,11 @@ __device__ __forceinline__ void reduce_half_channels(float (&vals)[16], float* s
 
 // dz2[v,c] = (dcat[v,c] + [arg[p,c]==v] dpooled[p,c]) * leaky'(BN2(a2[v,c])), p = vp[v]; S1, S2 of BN2.
 // View-major, 16 channels per lane, 16-byte accesses only.
+template <typename AT>
 __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
-    const float* __restrict__ dcat, const float* __restrict__ a2, const float* __restrict__ bn2,
+    const AT* __restrict__ dcat, const AT* __restrict__ a2, const float* __restrict__ bn2,
     const int32_t* __restrict__ arg, const float* __restrict__ dpooled, const int32_t* __restrict__ vp,
-    float* __restrict__ dz2, double* __restrict__ st, int64_t V) {
+    AT* __restrict__ dz2, double* __restrict__ st, int64_t V) {
   __shared__ float s_red[2 * DM];
   __shared__ __attribute__((aligned(16))) float s_p[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -492,12 +546,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
       acc[0][s] += d[s];
       acc[1][s] = fmaf(d[s], ahv[s], acc[1][s]);
     }
-    if (ok) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(dz2 + v * DM + 16 * h + 4 * q) =
-            make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-    }
+    if (ok) store16(dz2 + v * DM + 16 * h, d);
   });
   for (int i = threadIdx.x; i < 2 * DM; i += blockDim.x) s_red[i] = 0.f;
   __syncthreads();
@@ -510,9 +559,10 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
 // Score layer backward on the matrix cores: out = f(a4).Ws^T + bs with f = leaky(BN4(.)).
 //   dz4[v,k] = (sum_g dc[v,g] Ws[g,k]) * leaky'(z4[v,k])   (view-major, ceil(G/2) k-steps)
 //   dWs[g,k] = sum_v dc[v,g] f(a4)[v,k],  dbs[g] = sum_v dc[v,g]   (channel-major, 16 k-steps)
+template <typename AT>
 __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
-    const float* __restrict__ dcompat, const float* __restrict__ a, const float* __restrict__ bn,
-    const float* __restrict__ Ws, float* __restrict__ dz, float* __restrict__ dWs,
+    const float* __restrict__ dcompat, const AT* __restrict__ a, const float* __restrict__ bn,
+    const float* __restrict__ Ws, AT* __restrict__ dz, float* __restrict__ dWs,
     float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G) {
   __shared__ float s_red[DM * DM];
   __shared__ __attribute__((aligned(16))) float s_p[4][DM];
@@ -602,45 +652,70 @@ static inline int grid_tiles(int64_t V) {
   return (int)b;
 }
 
-// launchers used by the C entry points in deepset.hip
-int dsm_launch_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb, float* a2,
-                         double* stats, int64_t V, int stats_only, hipStream_t s) {
+// launchers used by the C entry points in deepset.hip; `bf` = the [V, 32] activation / gradient tensors
+// are stored as bf16 (else fp32)
+#define DVA_ACT(bf, CALL_F, CALL_B) \
+  do {                              \
+    if (bf) { CALL_B; } else { CALL_F; } \
+  } while (0)
+
+int dsm_launch_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb, void* a2,
+                         double* stats, int64_t V, int stats_only, int bf, hipStream_t s) {
+  const dim3 grid(grid_tiles(V)), block(256);
   if (stats_only)
-    hipLaunchKernelGGL((dsm_fwd_first_kernel<true>), dim3(grid_tiles(V)), dim3(256), 0, s, x_map, Wa,
+    hipLaunchKernelGGL((dsm_fwd_first_kernel<float, true>), grid, block, 0, s, x_map, Wa,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, stats, V);
   else
-    hipLaunchKernelGGL((dsm_fwd_first_kernel<false>), dim3(grid_tiles(V)), dim3(256), 0, s, x_map, Wa, bn1,
-                       Wb, a2, stats, V);
+    DVA_ACT(bf,
+            hipLaunchKernelGGL((dsm_fwd_first_kernel<float, false>), grid, block, 0, s, x_map, Wa, bn1, Wb,
+                               (float*)a2, stats, V),
+            hipLaunchKernelGGL((dsm_fwd_first_kernel<bf16_t, false>), grid, block, 0, s, x_map, Wa, bn1, Wb,
+                               (bf16_t*)a2, stats, V));
   return 0;
 }
 
-int dsm_launch_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
-                         const int32_t* vp, float* a_out, double* stats, int64_t V, hipStream_t s) {
+template <typename AT>
+static void launch_fwd_layer(const void* a_in, const float* bn_in, const float* W, const float* addend,
+                             const int32_t* vp, void* a_out, double* stats, int64_t V, hipStream_t s) {
+  const dim3 grid(grid_tiles(V)), block(256);
   if (addend)
-    hipLaunchKernelGGL((dsm_fwd_layer_kernel<true, false>), dim3(grid_tiles(V)), dim3(256), 0, s, a_in,
-                       bn_in, W, addend, vp, (const float*)nullptr, a_out, stats, V, 32);
+    hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, true, false>), grid, block, 0, s, (const AT*)a_in, bn_in, W,
+                       addend, vp, (const float*)nullptr, a_out, stats, V, 32);
   else
-    hipLaunchKernelGGL((dsm_fwd_layer_kernel<false, false>), dim3(grid_tiles(V)), dim3(256), 0, s, a_in,
-                       bn_in, W, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,
-                       a_out, stats, V, 32);
+    hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, false, false>), grid, block, 0, s, (const AT*)a_in, bn_in,
+                       W, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, a_out,
+                       stats, V, 32);
+}
+int dsm_launch_fwd_layer(const void* a_in, const float* bn_in, const float* W, const float* addend,
+                         const int32_t* vp, void* a_out, double* stats, int64_t V, int bf, hipStream_t s) {
+  DVA_ACT(bf, launch_fwd_layer<float>(a_in, bn_in, W, addend, vp, a_out, stats, V, s),
+          launch_fwd_layer<bf16_t>(a_in, bn_in, W, addend, vp, a_out, stats, V, s));
   return 0;
 }
 
-int dsm_launch_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs, float* compat,
-                         int64_t V, int G, hipStream_t s) {
-  hipLaunchKernelGGL((dsm_fwd_layer_kernel<false, true>), dim3(grid_tiles(V)), dim3(256), 0, s, a, bn, Ws,
-                     (const float*)nullptr, (const int32_t*)nullptr, bs, compat, (double*)nullptr, V, G);
+int dsm_launch_fwd_score(const void* a, const float* bn, const float* Ws, const float* bs, float* compat,
+                         int64_t V, int G, int bf, hipStream_t s) {
+  const dim3 grid(grid_tiles(V)), block(256);
+  DVA_ACT(bf,
+          hipLaunchKernelGGL((dsm_fwd_layer_kernel<float, false, true>), grid, block, 0, s, (const float*)a,
+                             bn, Ws, (const float*)nullptr, (const int32_t*)nullptr, bs, (void*)compat,
+                             (double*)nullptr, V, G),
+          hipLaunchKernelGGL((dsm_fwd_layer_kernel<bf16_t, false, true>), grid, block, 0, s,
+                             (const bf16_t*)a, bn, Ws, (const float*)nullptr, (const int32_t*)nullptr, bs,
+                             (void*)compat, (double*)nullptr, V, G));
   return 0;
 }
 
-int dsm_launch_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L, const float* sm_L,
-                         const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
-                         float* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
-                         int prev_is_xmap, int raw_out, hipStream_t s) {
+template <typename AT>
+static void launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
+                             const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
+                             void* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
+                             int prev_is_xmap, int raw_out, hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
 #define DVA_L(P, R, T)                                                                               \
-  hipLaunchKernelGGL((dsm_bwd_layer_kernel<P, R, T>), grid, block, 0, s, dz_L, a_L, bn_L, sm_L, W_L, \
-                     a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp, V)
+  hipLaunchKernelGGL((dsm_bwd_layer_kernel<AT, P, R, T>), grid, block, 0, s, (const AT*)dz_L,        \
+                     (const AT*)a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, (AT*)out, dW, st_prev, dt, \
+                     vp, V)
   if (prev_is_xmap && raw_out) DVA_L(true, true, false);
   else if (prev_is_xmap) DVA_L(true, false, false);
   else if (raw_out && dt) DVA_L(false, true, true);
@@ -648,21 +723,39 @@ int dsm_launch_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L,
   else if (dt) DVA_L(false, false, true);
   else DVA_L(false, false, false);
 #undef DVA_L
+}
+int dsm_launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
+                         const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
+                         void* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
+                         int prev_is_xmap, int raw_out, int bf, hipStream_t s) {
+  DVA_ACT(bf,
+          launch_bwd_layer<float>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp,
+                                  V, prev_is_xmap, raw_out, s),
+          launch_bwd_layer<bf16_t>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt,
+                                   vp, V, prev_is_xmap, raw_out, s));
   return 0;
 }
 
-int dsm_launch_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
-                       const float* dpooled, const int32_t* vp, float* dz2, double* st, int64_t V,
+int dsm_launch_bwd_max(const void* dcat, const void* a2, const float* bn2, const int32_t* arg,
+                       const float* dpooled, const int32_t* vp, void* dz2, double* st, int64_t V, int bf,
                        hipStream_t s) {
-  hipLaunchKernelGGL(dsm_bwd_max_kernel, dim3(grid_tiles(V)), dim3(256), 0, s, dcat, a2, bn2, arg, dpooled,
-                     vp, dz2, st, V);
+  const dim3 grid(grid_tiles(V)), block(256);
+  DVA_ACT(bf,
+          hipLaunchKernelGGL((dsm_bwd_max_kernel<float>), grid, block, 0, s, (const float*)dcat,
+                             (const float*)a2, bn2, arg, dpooled, vp, (float*)dz2, st, V),
+          hipLaunchKernelGGL((dsm_bwd_max_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dcat,
+                             (const bf16_t*)a2, bn2, arg, dpooled, vp, (bf16_t*)dz2, st, V));
   return 0;
 }
 
-int dsm_launch_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws, float* dz,
-                         float* dWs, float* dbs, double* st, int64_t V, int G, hipStream_t s) {
-  hipLaunchKernelGGL(dsm_bwd_score_kernel, dim3(grid_tiles(V)), dim3(256), 0, s, dcompat, a, bn, Ws, dz, dWs,
-                     dbs, st, V, G);
+int dsm_launch_bwd_score(const float* dcompat, const void* a, const float* bn, const float* Ws, void* dz,
+                         float* dWs, float* dbs, double* st, int64_t V, int G, int bf, hipStream_t s) {
+  const dim3 grid(grid_tiles(V)), block(256);
+  DVA_ACT(bf,
+          hipLaunchKernelGGL((dsm_bwd_score_kernel<float>), grid, block, 0, s, dcompat, (const float*)a, bn,
+                             Ws, (float*)dz, dWs, dbs, st, V, G),
+          hipLaunchKernelGGL((dsm_bwd_score_kernel<bf16_t>), grid, block, 0, s, dcompat, (const bf16_t*)a,
+                             bn, Ws, (bf16_t*)dz, dWs, dbs, st, V, G));
   return 0;
 }
 

@@ -19,6 +19,18 @@ from ._lib import check, ptr, require_device, stream_of
 D = 32
 # layer-kernel generation: 0 = fp32 matrix cores, 1 = VALU + LDS broadcast (tests flip this)
 ALGO = 0
+# storage type of the [V, 32] activation / gradient tensors between the kernels.  None = auto: bf16 inside
+# torch.autocast(bfloat16) (what the reference's autocast keeps for these tensors; arithmetic, statistics
+# and parameters stay fp32 here), fp32 otherwise.  Tests pin it.
+ACT_DTYPE = None
+
+
+def _act_dtype():
+    if ACT_DTYPE is not None:
+        return ACT_DTYPE
+    if ALGO == 0 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        return torch.bfloat16
+    return torch.float32
 
 
 def _bn_of(block):
@@ -76,6 +88,9 @@ class _DeepSetLinear(torch.autograd.Function):
         dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
         st = stream_of(x_map)
         training = e_map.training
+        act = _act_dtype()
+        AC, F32C = (_lib.DVA_BF16 if act == torch.bfloat16 else _lib.DVA_F32), _lib.DVA_F32
+        RB = D * (2 if act == torch.bfloat16 else 4)      # bytes of one stored activation row
         Wa = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
         Wb = e_map.mlp_elt_1[1][0].weight.detach().contiguous()
         Wc = e_map.mlp_elt_2[0][0].weight.detach()
@@ -93,20 +108,20 @@ class _DeepSetLinear(torch.autograd.Function):
         s1 = zstats()
         if training:
             with ops._timed("deepset_fwd_first_stats", V * 32):
-                check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), None, None, None, ptr(s1), V, 8, 1, ALGO, st),
+                check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), None, None, None, ptr(s1), V, 8, 1, ALGO, AC, st),
                       "dva_deepset_fwd_first")
         bn1 = _bn_consts(s1, V, bns[0], training)
-        a2 = torch.empty((V, D), dtype=torch.float32, device=dev)
+        a2 = torch.empty((V, D), dtype=act, device=dev)
         s2 = zstats()
-        with ops._timed("deepset_fwd_first", V * (32 + 128)):
-            check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), ptr(bn1), ptr(Wb), ptr(a2), ptr(s2), V, 8, 0, ALGO, st),
+        with ops._timed("deepset_fwd_first", V * (32 + RB)):
+            check(lib.dva_deepset_fwd_first(ptr(x_map), ptr(Wa), ptr(bn1), ptr(Wb), ptr(a2), ptr(s2), V, 8, 0, ALGO, AC, st),
                   "dva_deepset_fwd_first")
         bn2 = _bn_consts(s2, V, bns[1], training)
         # ---- set branch: max over views, set MLP on the N points, WcB product (PyTorch, N rows)
         pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
         arg = torch.empty((N, D), dtype=torch.int32, device=dev)
-        with ops._timed("deepset_segmax", V * 128 + N * (256 + 8)):
-            check(lib.dva_deepset_segmax(ptr(a2), ptr(bn2), ptr(csr_idx), ptr(pooled), ptr(arg), N, st),
+        with ops._timed("deepset_segmax", V * RB + N * (256 + 8)):
+            check(lib.dva_deepset_segmax(ptr(a2), ptr(bn2), ptr(csr_idx), ptr(pooled), ptr(arg), N, AC, st),
                   "dva_deepset_segmax")
         # set MLP on the N points with the same layer kernels (raw input, the set-size column of
         # use_num enters as a rank-1 per-row addend), then the WcB half of the concatenation layer
@@ -124,41 +139,43 @@ class _DeepSetLinear(torch.autograd.Function):
             ident_idx = torch.arange(N, dtype=torch.int32, device=dev)
         u1, su1 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
         check(lib.dva_deepset_fwd_layer(ptr(pooled), None, ptr(WsaP), ptr(add1), ptr(ident_idx), ptr(u1), ptr(su1),
-                                        N, 0, st), "dva_deepset_fwd_layer")
+                                        N, 0, F32C, st), "dva_deepset_fwd_layer")
         bns1 = _bn_consts(su1, N, set_bns[0], training)
         u2, su2 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
-        check(lib.dva_deepset_fwd_layer(ptr(u1), ptr(bns1), ptr(Wsb), None, None, ptr(u2), ptr(su2), N, 0, st),
+        check(lib.dva_deepset_fwd_layer(ptr(u1), ptr(bns1), ptr(Wsb), None, None, ptr(u2), ptr(su2), N, 0, F32C, st),
               "dva_deepset_fwd_layer")
         bns2 = _bn_consts(su2, N, set_bns[1], training)
         t_add, su3 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
-        check(lib.dva_deepset_fwd_layer(ptr(u2), ptr(bns2), ptr(WcB), None, None, ptr(t_add), ptr(su3), N, 0, st),
+        check(lib.dva_deepset_fwd_layer(ptr(u2), ptr(bns2), ptr(WcB), None, None, ptr(t_add), ptr(su3), N, 0, F32C, st),
               "dva_deepset_fwd_layer")
         vp = torch.empty(V, dtype=torch.int32, device=dev)
         check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
         # ---- elt MLP 2: cat(h1, set[p]) -> a3 -> a4
         t_det = t_add
-        a3 = torch.empty((V, D), dtype=torch.float32, device=dev)
+        a3 = torch.empty((V, D), dtype=act, device=dev)
         s3 = zstats()
-        with ops._timed("deepset_fwd_layer_add", V * (128 + 4 + 128) + N * 128):
-            check(lib.dva_deepset_fwd_layer(ptr(a2), ptr(bn2), ptr(WcA), ptr(t_det), ptr(vp), ptr(a3), ptr(s3), V, ALGO, st),
+        with ops._timed("deepset_fwd_layer_add", V * (2 * RB + 4) + N * 128):
+            check(lib.dva_deepset_fwd_layer(ptr(a2), ptr(bn2), ptr(WcA), ptr(t_det), ptr(vp), ptr(a3), ptr(s3), V, ALGO,
+                                            AC, st),
                   "dva_deepset_fwd_layer")
         bn3 = _bn_consts(s3, V, bns[2], training)
-        a4 = torch.empty((V, D), dtype=torch.float32, device=dev)
+        a4 = torch.empty((V, D), dtype=act, device=dev)
         s4 = zstats()
-        with ops._timed("deepset_fwd_layer", V * (128 + 128)):
-            check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, ALGO, st),
+        with ops._timed("deepset_fwd_layer", V * 2 * RB):
+            check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, ALGO, AC, st),
                   "dva_deepset_fwd_layer")
         bn4 = _bn_consts(s4, V, bns[3], training)
         # ---- trailing Linear (E_score / K)
         out = torch.empty((V, G), dtype=torch.float32, device=dev)
-        with ops._timed("deepset_fwd_score", V * (128 + 4 * G)):
-            check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, ALGO, st),
+        with ops._timed("deepset_fwd_score", V * (RB + 4 * G)):
+            check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, ALGO, AC, st),
                   "dva_deepset_fwd_score")
 
         ctx.save_for_backward(x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws)
         ctx.set_branch = (pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx)
         ctx.modules = (e_map, linear)
         ctx.training = training
+        ctx.act = act
         return out
 
     @staticmethod
@@ -171,6 +188,9 @@ class _DeepSetLinear(torch.autograd.Function):
         st = stream_of(x_map)
         dout = dout.contiguous().float()
         m = float(max(V, 1))
+        act = ctx.act
+        AC, F32C = (_lib.DVA_BF16 if act == torch.bfloat16 else _lib.DVA_F32), _lib.DVA_F32
+        RB = D * (2 if act == torch.bfloat16 else 4)
 
         def zstats():
             return torch.zeros(2 * D, dtype=torch.float64, device=dev)
@@ -181,31 +201,31 @@ class _DeepSetLinear(torch.autograd.Function):
                 return torch.zeros(2 * D, dtype=torch.float32, device=dev)
             return (stats / rows).float().contiguous()
 
-        def buf(rows=V):
-            return torch.empty((rows, D), dtype=torch.float32, device=dev)
+        def buf(rows=V, dtype=None):
+            return torch.empty((rows, D), dtype=act if dtype is None else dtype, device=dev)
 
         # score layer
         dz4, s4 = buf(), zstats()
         dWs = torch.zeros_like(Ws)
         dbs = torch.zeros(G, dtype=torch.float32, device=dev)
-        with ops._timed("deepset_bwd_score", V * (128 + 4 * G + 128)):
+        with ops._timed("deepset_bwd_score", V * (2 * RB + 4 * G)):
             check(lib.dva_deepset_bwd_score(ptr(dout), ptr(a4), ptr(bn4), ptr(Ws), ptr(dz4), ptr(dWs), ptr(dbs),
-                                            ptr(s4), V, G, ALGO, st), "dva_deepset_bwd_score")
+                                            ptr(s4), V, G, ALGO, AC, st), "dva_deepset_bwd_score")
         # Wd layer (a3 -> a4)
         dz3, s3, dWd = buf(), zstats(), torch.zeros_like(Wd)
         sm4 = sm_of(s4)
-        with ops._timed("deepset_bwd_layer", V * 128 * 4):
+        with ops._timed("deepset_bwd_layer", V * RB * 4):
             check(lib.dva_deepset_bwd_layer(ptr(dz4), ptr(a4), ptr(bn4), ptr(sm4), ptr(Wd), ptr(a3), None, ptr(bn3),
-                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, V, 0, 0, ALGO, st),
+                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, V, 0, 0, ALGO, AC, st),
                   "dva_deepset_bwd_layer")
         del dz4
         # Wc layer (cat(h1, set) -> a3): raw dx on the h1 half, per-point sum on the set half
         dcat, dWcA = buf(), torch.zeros_like(WcA)
         dt = torch.zeros((N, D), dtype=torch.float32, device=dev)
         sm3 = sm_of(s3)
-        with ops._timed("deepset_bwd_layer_cat", V * (128 * 4 + 4) + N * 128):
+        with ops._timed("deepset_bwd_layer_cat", V * (RB * 4 + 4) + N * 128):
             check(lib.dva_deepset_bwd_layer(ptr(dz3), ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2), None, ptr(bn2),
-                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, ALGO, st),
+                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, ALGO, AC, st),
                   "dva_deepset_bwd_layer")
         del dz3
         # set branch backward with the same layer kernels over the N points
@@ -213,23 +233,23 @@ class _DeepSetLinear(torch.autograd.Function):
         ident_bn = torch.tensor([0.0, 1.0, 1.0, 0.0], device=dev).repeat_interleave(D).contiguous()
         zero_sm = torch.zeros(2 * D, dtype=torch.float32, device=dev)
         dWcB = torch.zeros_like(WcB)
-        dzs2, ss2 = buf(N), zstats()
+        dzs2, ss2 = buf(N, torch.float32), zstats()
         check(lib.dva_deepset_bwd_layer(ptr(dt), ptr(t_add), ptr(ident_bn), ptr(zero_sm), ptr(WcB), ptr(u2), None,
-                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, N, 0, 0, 0, st),
+                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, N, 0, 0, 0, F32C, st),
               "dva_deepset_bwd_layer")
         dWsb = torch.zeros_like(Wsb)
-        dzs1, ss1 = buf(N), zstats()
+        dzs1, ss1 = buf(N, torch.float32), zstats()
         sms2 = sm_of(ss2, n_rows)
         check(lib.dva_deepset_bwd_layer(ptr(dzs2), ptr(u2), ptr(bns2), ptr(sms2), ptr(Wsb), ptr(u1), None,
-                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, N, 0, 0, 0, st),
+                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, N, 0, 0, 0, F32C, st),
               "dva_deepset_bwd_layer")
         dWsaP = torch.zeros_like(WsaP)
-        dpooled = buf(N)
+        dpooled = buf(N, torch.float32)
         da1 = torch.zeros((N, D), dtype=torch.float32, device=dev) if num is not None else None
         sms1 = sm_of(ss1, n_rows)
         check(lib.dva_deepset_bwd_layer(ptr(dzs1), ptr(u1), ptr(bns1), ptr(sms1), ptr(WsaP), ptr(pooled), None,
                                         None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), N, 0, 1, 0,
-                                        st), "dva_deepset_bwd_layer")
+                                        F32C, st), "dva_deepset_bwd_layer")
         if num is not None:
             dWsa = torch.cat([dWsaP, (da1 * num.view(-1, 1)).sum(0).view(-1, 1)], dim=1)
         else:
@@ -238,22 +258,22 @@ class _DeepSetLinear(torch.autograd.Function):
         d_set = [dWsa, ss1[D:].float(), ss1[:D].float(), dWsb, ss2[D:].float(), ss2[:D].float()]
         # join the max path, BN2 backward statistics
         dz2, s2 = buf(), zstats()
-        with ops._timed("deepset_bwd_max", V * (128 * 3 + 4) + N * 256):
+        with ops._timed("deepset_bwd_max", V * (RB * 3 + 4) + N * 256):
             check(lib.dva_deepset_bwd_max(ptr(dcat), ptr(a2), ptr(bn2), ptr(arg), ptr(dpooled), ptr(vp), ptr(dz2),
-                                          ptr(s2), V, ALGO, st), "dva_deepset_bwd_max")
+                                          ptr(s2), V, ALGO, AC, st), "dva_deepset_bwd_max")
         del dcat
         # Wb layer (a1 -> a2), a1 recomputed from x_map
         dz1, s1, dWb = buf(), zstats(), torch.zeros_like(Wb)
         sm2 = sm_of(s2)
-        with ops._timed("deepset_bwd_layer_xmap", V * (128 * 3 + 32)):
+        with ops._timed("deepset_bwd_layer_xmap", V * (RB * 3 + 32)):
             check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
-                                            ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, ALGO, st),
+                                            ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, ALGO, AC, st),
                   "dva_deepset_bwd_layer")
         del dz2
         dWa = torch.zeros_like(Wa)
         sm1 = sm_of(s1)
-        with ops._timed("deepset_bwd_first", V * (128 + 32)):
-            check(lib.dva_deepset_bwd_first(ptr(dz1), ptr(x_map), ptr(Wa), ptr(bn1), ptr(sm1), ptr(dWa), V, 8, st),
+        with ops._timed("deepset_bwd_first", V * (RB + 32)):
+            check(lib.dva_deepset_bwd_first(ptr(dz1), ptr(x_map), ptr(Wa), ptr(bn1), ptr(sm1), ptr(dWa), V, 8, AC, st),
                   "dva_deepset_bwd_first")
 
         def gb(stats):  # d gamma = S2, d beta = S1

@@ -200,48 +200,53 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
  * S1 = sum dz | S2 = sum dz*a_hat (backward), "sm" are fp32 [2][32] = S1/M | S2/M (zeros in eval).
  * algo (layer kernels): 0 = fp32 matrix cores (v_mfma_f32_32x32x2_f32, operands from registers),
  * 1 = first-generation VALU + LDS-broadcast kernels (kept for A/B checks).
+ * act_dtype = STORAGE type of the [V,32] activation / gradient tensors (the `void*` arguments):
+ * DVA_F32, or DVA_BF16 (what the reference keeps under torch.autocast; algo 0 only).  Arithmetic,
+ * weights, statistics, per-point tensors (addend, pooled, dpooled, dt) and the scores stay fp32.
  * ------------------------------------------------------------------------------------------ */
 /* group_of_row[r] = g for ptr[g] <= r < ptr[g+1] (dense expansion of CSR pointers, int32). */
 int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, void* stream);
 /* a1 = x_map.Wa^T (F = 8). stats_only: statistics of a1; else a2 = leaky(BN1(a1)).Wb^T written
  * with its statistics (mlp_elt_1, pooling.py:649-650). */
 int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1, const float* Wb,
-                          float* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
-                          int32_t algo, void* stream);
+                          void* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
+                          int32_t algo, int32_t act_dtype, void* stream);
 /* pooled[p] = max_v leaky(BN(a[v])) over the point's views (first row on ties; 0 / arg -1 for
  * unseen points): segment_csr(x, csr, 'max') of pooling.py:660,:628. */
-int dva_deepset_segmax(const float* a, const float* bn, const int64_t* ptr, float* pooled,
-                       int32_t* arg, int64_t N, void* stream);
+int dva_deepset_segmax(const void* a, const float* bn, const int64_t* ptr, float* pooled,
+                       int32_t* arg, int64_t N, int32_t act_dtype, void* stream);
 /* a_out[v] = leaky(BN_in(a_in[v])).W^T (+ addend[group_of_row[v]]) with statistics of a_out.
  * The addend carries the set half of the concatenation: cat(x, x_set).Wc^T = x.WcA^T + (x_set.WcB^T)[p]
  * (pooling.py:666-668).  bn_in == NULL: the input is used raw (set MLP on the pooled features). */
-int dva_deepset_fwd_layer(const float* a_in, const float* bn_in, const float* W, const float* addend,
-                          const int32_t* group_of_row, float* a_out, double* stats, int64_t V,
-                          int32_t algo, void* stream);
+int dva_deepset_fwd_layer(const void* a_in, const float* bn_in, const float* W, const float* addend,
+                          const int32_t* group_of_row, void* a_out, double* stats, int64_t V,
+                          int32_t algo, int32_t act_dtype, void* stream);
 /* out[v, g] = leaky(BN(a[v])).Ws[g] + bs[g], G <= 32 (E_score, pooling.py:258,:282; also Q/K). */
-int dva_deepset_fwd_score(const float* a, const float* bn, const float* Ws, const float* bs,
-                          float* compat, int64_t V, int32_t G, int32_t algo, void* stream);
-int dva_deepset_bwd_score(const float* dcompat, const float* a, const float* bn, const float* Ws,
-                          float* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
-                          int32_t algo, void* stream);
+int dva_deepset_fwd_score(const void* a, const float* bn, const float* Ws, const float* bs,
+                          float* compat, int64_t V, int32_t G, int32_t algo, int32_t act_dtype,
+                          void* stream);
+int dva_deepset_bwd_score(const float* dcompat, const void* a, const float* bn, const float* Ws,
+                          void* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
+                          int32_t algo, int32_t act_dtype, void* stream);
 /* Backward of one layer: da_L = BN-backward(dz_L), dW_L += da_L^T x_L, dx = da_L.W_L;
  * out = dx (raw_out) or dz_prev = dx*leaky'(BN_prev(a_prev)) with S1/S2 of BN_prev in st_prev;
  * dt[group_of_row[v]] += da_L[v] (nullable). prev_is_xmap: a_prev is x_map [V,8] and the previous
  * activation is recomputed as x_map.Wa^T. dW / dt are caller-zeroed fp32, atomically accumulated.
  * bn_prev == NULL (with raw_out): the layer input is a_prev itself (no BatchNorm / activation). */
-int dva_deepset_bwd_layer(const float* dz_L, const float* a_L, const float* bn_L, const float* sm_L,
-                          const float* W_L, const float* a_prev, const float* Wa, const float* bn_prev,
-                          float* out, float* dW, double* st_prev, float* dt,
+int dva_deepset_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
+                          const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
+                          void* out, float* dW, double* st_prev, float* dt,
                           const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
-                          int32_t raw_out, int32_t algo, void* stream);
+                          int32_t raw_out, int32_t algo, int32_t act_dtype, void* stream);
 /* dz2 = (dcat + [arg[p]==v] dpooled[p]) * leaky'(BN2(a2)): joins the max-pool path (segment max
  * backward routes to the arg row only) with the direct path; S1/S2 of BN2 in st. */
-int dva_deepset_bwd_max(const float* dcat, const float* a2, const float* bn2, const int32_t* arg,
-                        const float* dpooled, const int32_t* group_of_row, float* dz2, double* st,
-                        int64_t V, int32_t algo, void* stream);
+int dva_deepset_bwd_max(const void* dcat, const void* a2, const float* bn2, const int32_t* arg,
+                        const float* dpooled, const int32_t* group_of_row, void* dz2, double* st,
+                        int64_t V, int32_t algo, int32_t act_dtype, void* stream);
 /* dWa[n][j] += sum_v BN1-backward(dz1)[v][n] * x_map[v][j]. */
-int dva_deepset_bwd_first(const float* dz1, const float* x_map, const float* Wa, const float* bn1,
-                          const float* sm1, float* dWa, int64_t V, int32_t F, void* stream);
+int dva_deepset_bwd_first(const void* dz1, const float* x_map, const float* Wa, const float* bn1,
+                          const float* sm1, float* dWa, int64_t V, int32_t F, int32_t act_dtype,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a

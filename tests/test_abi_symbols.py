@@ -34,7 +34,10 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.dva_segment_csr_fwd(None, None, None, None, 4, 3, 0, 0, None) == -1      # null ptr
     assert lib.dva_segment_csr_fwd(None, None, None, None, -1, 3, 0, 0, None) == -1     # negative size
-    assert lib.dva_deepset_fwd_first(None, None, None, None, None, None, 0, 5, 1, 0, None) == -1
+    assert lib.dva_deepset_fwd_first(None, None, None, None, None, None, 0, 5, 1, 0, 0, None) == -1
+    assert lib.dva_deepset_fwd_layer(None, None, None, None, None, None, None, 0, 0, 7, None) == -1   # bad act_dtype
+    assert lib.dva_row_plan(None, -1, 4, None, None, None, None, 0, None) == -1
+    assert lib.dva_row_plan_workspace_bytes(1 << 33, 4) == -2
     assert lib.dva_pack_gather_index(None, None, None, 2, 0.5, 1, 1, None, None) == -1  # ratio < 1
 
 

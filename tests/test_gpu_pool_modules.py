@@ -274,3 +274,60 @@ def test_deepset_mfma_equals_valu_generation():
     for (n, _), a, b in zip(m.named_parameters(), res[0][1], res[1][1]):
         scale = float(b.abs().max()) + 1e-6
         assert float((a - b).abs().max()) / scale < 2e-3, (n, float((a - b).abs().max()), scale)
+
+
+def test_deepset_bf16_activation_storage():
+    """bf16 STORAGE of the [V, 32] activations / gradients between the DeepSet kernels (what the fused path
+    selects inside torch.autocast(bfloat16)); arithmetic, statistics and parameters stay fp32.
+    Tolerance: the error against the fp32 reference maths must not exceed the error of the reference maths
+    itself under torch.autocast(bfloat16) (oracle on the CPU, same inputs): per parameter gradient,
+    relative L2 error <= max(1.25 x reference-autocast error, 2e-2); output: 1e-2."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import fused_deepset
+    gen = torch.Generator().manual_seed(11)
+    N, C = 30011, 32
+    sizes = torch.randint(0, 9, (N,), generator=gen)
+    sizes[:50] = 100
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    kwargs = dict(in_map=8, in_mod=C, num_groups=4, use_num=True)
+    ref = O.GroupBimodalCSRPool(**kwargs).train()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.4)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    x_mod = torch.randn(V, C, generator=gen)
+    x_map = torch.rand(V, 8, generator=gen)
+    w = torch.randn(N, C, generator=gen)
+
+    def rel(a, b):
+        return float((a.detach().float().cpu() - b.detach()).norm() / (b.detach().norm() + 1e-6))
+
+    out_ref = ref(None, x_mod, x_map, csr)
+    g_ref = torch.autograd.grad((out_ref * w).sum(), list(ref.parameters()))
+    ref.load_state_dict(sd)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out_amp = ref(None, x_mod, x_map, csr)
+    g_amp = torch.autograd.grad((out_amp.float() * w).sum(), list(ref.parameters()))
+
+    m = P.GroupBimodalCSRPool(**kwargs)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    fused_deepset.ACT_DTYPE = torch.bfloat16
+    try:
+        out = m(None, x_mod.to(DEV), x_map.to(DEV), csr.to(DEV))
+        g = torch.autograd.grad((out * w.to(DEV)).sum(), list(m.parameters()))
+    finally:
+        fused_deepset.ACT_DTYPE = None
+    assert rel(out, out_ref) < 1e-2, rel(out, out_ref)
+    report = []
+    for (n, _), a, b, c in zip(ref.named_parameters(), g, g_ref, g_amp):
+        ours, amp = rel(a, b), rel(c, b)
+        report.append((n, round(ours, 4), round(amp, 4)))
+    bad = [r for r in report if r[1] > max(1.25 * r[2], 2e-2)]
+    assert not bad, (bad, report)
+    # auto mode: bf16 storage is selected inside autocast(bfloat16) only
+    assert fused_deepset._act_dtype() == torch.float32
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert fused_deepset._act_dtype() == torch.bfloat16
+    print("bf16-storage error vs reference-autocast error per parameter:", report)
