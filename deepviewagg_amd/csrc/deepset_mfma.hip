@@ -27,7 +27,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DM = 32;
 constexpr float SLOPE_M = 0.2f;
 
-__device__ __forceinline__ float leaky_m(float z) { return z > 0.f ? z : SLOPE_M * z; }
+// slope < 1: leaky(z) = max(z, slope*z) -- one v_mul + one v_max, no compare / select
+__device__ __forceinline__ float leaky_m(float z) { return fmaxf(z, SLOPE_M * z); }
 __device__ __forceinline__ float dleaky_m(float z) { return z > 0.f ? 1.f : SLOPE_M; }
 __device__ __forceinline__ int acc_chan(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -84,9 +85,6 @@ __device__ __forceinline__ void store16(float* __restrict__ p, const float (&x)[
 __device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) {
   lo = __uint_as_float(u << 16);
   hi = __uint_as_float(u & 0xffff0000u);
-}
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 __device__ __forceinline__ void load16(const bf16_t* __restrict__ p, float (&x)[16]) {
 #pragma unroll
@@ -182,6 +180,193 @@ __device__ __forceinline__ void for_each_tile(int64_t V, Body&& body) {
   for (int64_t t = wave; t < tiles; t += n_waves) body(t, TailYes());
 }
 
+// Raw (not yet converted) registers of half a row / of a row in the accumulator layout, so that the loads
+// of the NEXT tile can be in flight while the current one is computed (for_each_tile_pf).
+template <typename AT> struct HalfRow;
+template <> struct HalfRow<float> { float4 q[4]; };
+template <> struct HalfRow<bf16_t> { uint4 q[2]; };
+template <typename AT> struct AccRow;
+template <> struct AccRow<float> { float4 q[4]; };
+template <> struct AccRow<bf16_t> { uint4 q[2]; };  // raw half row; half-waves exchange at unpack
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The <= 32 rows [row0, row0 + 32) of a row-major array with `row_bytes` per row, as a raw buffer
+// resource (row0 is wave-uniform: the descriptor lives in SGPRs).  The hardware bounds check replaces
+// every predicate of the partial last tile: loads past the last row return 0, stores are dropped.  That
+// matters beyond the saved compares -- a store inside an `if (row < V)` branch makes hipcc lose count of
+// the outstanding memory operations and emit s_waitcnt vmcnt(0), which also waits for the prefetch of
+// the next tile.
+struct RowTile {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ RowTile(const void* base, int64_t row0, int64_t V, int row_bytes) {
+    int64_t rows = V - row0;
+    rows = rows > 32 ? 32 : (rows < 0 ? 0 : rows);
+    // readfirstlane: tell the compiler the descriptor is wave-uniform (else every access is wrapped in
+    // a waterfall loop)
+    const uint64_t addr = (uint64_t)base + (uint64_t)(row0 * row_bytes);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)rows * row_bytes);
+    r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+  }
+  __device__ __forceinline__ uint32_t b32(int off) const { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+  __device__ __forceinline__ u32x2 b64(int off) const { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+  __device__ __forceinline__ u32x4 b128(int off) const { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+  __device__ __forceinline__ void st64(int off, u32x2 v) const { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0); }
+  __device__ __forceinline__ void st128(int off, u32x4 v) const { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0); }
+};
+__device__ __forceinline__ float4 as_f4(u32x4 v) { return __builtin_bit_cast(float4, v); }
+__device__ __forceinline__ u32x4 as_u4(float a, float b, float c, float d) {
+  const float4 f = make_float4(a, b, c, d);
+  return __builtin_bit_cast(u32x4, f);
+}
+constexpr int OOB = 0x7ffffff0;  // byte offset no tile reaches: a store there is dropped (branch-free masking)
+
+template <typename AT> __device__ __forceinline__ HalfRow<AT> tile_load_half(const RowTile& T, int j, int h);
+template <> __device__ __forceinline__ HalfRow<float> tile_load_half<float>(const RowTile& T, int j, int h) {
+  HalfRow<float> r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r.q[q] = as_f4(T.b128(j * 128 + h * 64 + 16 * q));
+  return r;
+}
+template <> __device__ __forceinline__ HalfRow<bf16_t> tile_load_half<bf16_t>(const RowTile& T, int j, int h) {
+  HalfRow<bf16_t> r;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) r.q[q] = __builtin_bit_cast(uint4, T.b128(j * 64 + h * 32 + 16 * q));
+  return r;
+}
+template <typename AT> __device__ __forceinline__ AccRow<AT> tile_load_acc(const RowTile& T, int j, int h);
+template <> __device__ __forceinline__ AccRow<float> tile_load_acc<float>(const RowTile& T, int j, int h) {
+  AccRow<float> r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r.q[q] = as_f4(T.b128(j * 128 + (8 * q + 4 * h) * 4));
+  return r;
+}
+// bf16 rows are 64 bytes: in the accumulator layout a lane owns 4 groups of 4 channels = 4 x 8 bytes with
+// a 16-byte stride, and 8-byte accesses cost twice the issue slots of 16-byte ones.  Instead every lane
+// moves its contiguous HALF row (2 x 16 bytes) and the two half-waves trade two groups with
+// v_permlane32_swap (lanes [32,64) of the first operand <-> lanes [0,32) of the second):
+//   half row of (j, h=0) = channels 0..15 = own q0 | partner q0 | own q1 | partner q1
+//   half row of (j, h=1) = channels 16..31 = partner q2 | own q2 | partner q3 | own q3
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r.x;
+  b = r.y;
+}
+template <> __device__ __forceinline__ AccRow<bf16_t> tile_load_acc<bf16_t>(const RowTile& T, int j, int h) {
+  AccRow<bf16_t> r;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) r.q[q] = __builtin_bit_cast(uint4, T.b128(j * 64 + h * 32 + 16 * q));
+  return r;
+}
+template <typename AT> __device__ __forceinline__ void tile_store_acc(const RowTile& T, int j, int h, const f32x16& a);
+template <> __device__ __forceinline__ void tile_store_acc<float>(const RowTile& T, int j, int h, const f32x16& a) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    T.st128(j * 128 + (8 * q + 4 * h) * 4, as_u4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]));
+}
+template <> __device__ __forceinline__ void tile_store_acc<bf16_t>(const RowTile& T, int j, int h, const f32x16& a) {
+  uint32_t p[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    p[q][0] = pack_bf16x2(a[4 * q], a[4 * q + 1]);
+    p[q][1] = pack_bf16x2(a[4 * q + 2], a[4 * q + 3]);
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    swap_halves(p[0][d], p[2][d]);
+    swap_halves(p[1][d], p[3][d]);
+  }
+  const u32x4 v0 = {p[0][0], p[0][1], p[2][0], p[2][1]};
+  const u32x4 v1 = {p[1][0], p[1][1], p[3][0], p[3][1]};
+  T.st128(j * 64 + h * 32, v0);
+  T.st128(j * 64 + h * 32 + 16, v1);
+}
+template <typename AT> __device__ __forceinline__ void tile_store_half(const RowTile& T, int j, int h, const float (&x)[16]);
+template <> __device__ __forceinline__ void tile_store_half<float>(const RowTile& T, int j, int h, const float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    T.st128(j * 128 + h * 64 + 16 * q, as_u4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
+}
+template <> __device__ __forceinline__ void tile_store_half<bf16_t>(const RowTile& T, int j, int h, const float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const u32x4 v = {pack_bf16x2(x[8 * q], x[8 * q + 1]), pack_bf16x2(x[8 * q + 2], x[8 * q + 3]),
+                     pack_bf16x2(x[8 * q + 4], x[8 * q + 5]), pack_bf16x2(x[8 * q + 6], x[8 * q + 7])};
+    T.st128(j * 64 + h * 32 + 16 * q, v);
+  }
+}
+__device__ __forceinline__ void unpack(const HalfRow<float>& r, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    x[4 * q] = r.q[q].x; x[4 * q + 1] = r.q[q].y; x[4 * q + 2] = r.q[q].z; x[4 * q + 3] = r.q[q].w;
+  }
+}
+__device__ __forceinline__ void unpack(const HalfRow<bf16_t>& r, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    unpack_bf16x2(r.q[q].x, x[8 * q], x[8 * q + 1]);
+    unpack_bf16x2(r.q[q].y, x[8 * q + 2], x[8 * q + 3]);
+    unpack_bf16x2(r.q[q].z, x[8 * q + 4], x[8 * q + 5]);
+    unpack_bf16x2(r.q[q].w, x[8 * q + 6], x[8 * q + 7]);
+  }
+}
+__device__ __forceinline__ void unpack(const AccRow<float>& r, float (&x)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    x[4 * q] = r.q[q].x; x[4 * q + 1] = r.q[q].y; x[4 * q + 2] = r.q[q].z; x[4 * q + 3] = r.q[q].w;
+  }
+}
+__device__ __forceinline__ void unpack(const AccRow<bf16_t>& r, float (&x)[16]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // (A, B) = the two 8-byte groups of 16 bytes: after the swap A = group q = i, B = group q = i + 2
+    uint32_t a0 = r.q[i].x, a1 = r.q[i].y, b0 = r.q[i].z, b1 = r.q[i].w;
+    swap_halves(a0, b0);
+    swap_halves(a1, b1);
+    unpack_bf16x2(a0, x[4 * i], x[4 * i + 1]);
+    unpack_bf16x2(a1, x[4 * i + 2], x[4 * i + 3]);
+    unpack_bf16x2(b0, x[4 * (i + 2)], x[4 * (i + 2) + 1]);
+    unpack_bf16x2(b1, x[4 * (i + 2) + 2], x[4 * (i + 2) + 3]);
+  }
+}
+
+// Software-pipelined tile loop: load(t) issues the global loads of tile t and returns the raw registers,
+// compute(t, raw) consumes them.  The loads of the wavefront's next tile are issued before the current
+// tile is computed, so one memory latency per tile is hidden behind the MFMA / VALU work of the previous
+// one (3 wavefronts per SIMD do not hide it on their own).  Past the last tile the prefetch re-reads the
+// last tile (valid memory, result unused).
+template <typename Load, typename Compute>
+__device__ __forceinline__ void for_each_tile_pf(int64_t V, Load&& load, Compute&& compute) {
+  const int64_t tiles = (V + 31) / 32;
+  // readfirstlane: the tile index must be provably wave-uniform (buffer descriptors live in SGPRs)
+  const int64_t wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t last = tiles - 1;
+  if (wave < tiles) {
+    // Two register sets in ping-pong (a rotating `cur = nxt` copy would make the loop wait for the
+    // prefetch it has just issued: the copy reads the registers the loads are landing in).  The first
+    // tile is peeled so that the loop is ENTERED in the same memory state as it is RE-ENTERED (one
+    // prefetch in flight, then the stores of a tile): hipcc's s_waitcnt insertion merges the two paths
+    // conservatively, and with a plain prologue it waited for the previous tile's stores at the loop top.
+    auto a = load(wave);
+    int64_t t = wave + n_waves;
+    auto b = load(t < tiles ? t : last);
+    compute(wave, a);
+    while (t < tiles) {
+      a = load(t + n_waves < tiles ? t + n_waves : last);
+      compute(t, b);
+      t += n_waves;
+      if (t >= tiles) break;
+      b = load(t + n_waves < tiles ? t + n_waves : last);
+      compute(t, a);
+      t += n_waves;
+    }
+  }
+}
+
 // BatchNorm constants as an LDS table [4][32] (mean | invstd | gamma | beta): 16 ds_read_b128 per tile
 // instead of 64 live registers per lane (occupancy).  `base` = first channel of each group of 4:
 // half-row layout 16h + 4q, accumulator layout 8q + 4h.
@@ -233,13 +418,10 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  for_each_tile(V, [&](int64_t t, auto tail) {
-    constexpr bool TAIL = decltype(tail)::value;
-    const int64_t v = t * 32 + j;
-    const bool ok = !TAIL || v < V;
-    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
-    float4 x = *reinterpret_cast<const float4*>(x_map + vc * 8 + 4 * h);
-    if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+  for_each_tile_pf(V, [&](int64_t t) {
+    return as_f4(RowTile(x_map, t * 32, V, 32).b128(j * 32 + h * 16));   // rows beyond V read as zeros
+  }, [&](int64_t t, float4 x) {
+    const bool ok = t * 32 + j < V;
     f32x16 acc = {0};
     acc = DVA_MFMA(wa[0], x.x, acc);
     acc = DVA_MFMA(wa[1], x.y, acc);
@@ -259,7 +441,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
       bn_norm16<true>(s_bn, h, a1v, ah1, z1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2 = DVA_MFMA(wb[r], ok ? leaky_m(z1[r]) : 0.f, acc2);
-      if (ok) store_acc_layout(a2 + v * DM, h, acc2);
+      tile_store_acc<AT>(RowTile(a2, t * 32, V, DM * (int)sizeof(AT)), j, h, acc2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         st[0][r] += acc2[r];
@@ -297,15 +479,23 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  for_each_tile(V, [&](int64_t t, auto tail) {
-    constexpr bool TAIL = decltype(tail)::value;
-    const int64_t v = t * 32 + j;
-    const bool ok = !TAIL || v < V;
-    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;   // clamped row: loads are unconditional
+  struct Raw {
+    HalfRow<AT> x;
+    int32_t p;
+  };
+  constexpr int RB = DM * (int)sizeof(AT);
+  for_each_tile_pf(V, [&](int64_t t) {
+    Raw r;
+    r.x = tile_load_half<AT>(RowTile(a_in, t * 32, V, RB), j, h);
+    r.p = HAS_ADD ? (int32_t)RowTile(vp, t * 32, V, 4).b32(j * 4) : 0;
+    return r;
+  }, [&](int64_t t, const Raw& raw) {
+    const bool ok = t * 32 + j < V;
     float x[16];
-    load16(a_in + vc * DM + 16 * h, x);
+    unpack(raw.x, x);
+    // the addend row is shared by the views of a point (mostly one point per tile): L2 hit
     float ad[16];
-    if (HAS_ADD) load_acc_layout(addend + (int64_t)vp[vc] * DM, h, ad);
+    if (HAS_ADD) load_acc_layout(addend + (int64_t)raw.p * DM, h, ad);
     f32x16 acc = {0};
     float ahx[16], zx[16];
     bn_norm16<false>(s_bn, h, x, ahx, zx);
@@ -315,15 +505,16 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
       acc = DVA_MFMA(w[s], ok ? xin : 0.f, acc);
     }
     if (SCORE) {
-      if (ok) {
-        if (G == 4) {
-          if (h == 0)
-            *reinterpret_cast<float4*>(c_out + v * 4) =
-                make_float4(acc[0] + bia[0], acc[1] + bia[1], acc[2] + bia[2], acc[3] + bia[3]);
-        } else {
+      // scores [V, G] fp32; lanes / registers without a score column store out of bounds (dropped)
+      const RowTile C(c_out, t * 32, V, G * 4);
+      if (G == 4) {
+        C.st128(h == 0 ? j * 16 : OOB, as_u4(acc[0] + bia[0], acc[1] + bia[1], acc[2] + bia[2], acc[3] + bia[3]));
+      } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (acc_chan(r, h) < G) c_out[v * G + acc_chan(r, h)] = acc[r] + bia[r];
+        for (int r = 0; r < 16; ++r) {
+          const int c = acc_chan(r, h);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r] + bia[r]), C.r,
+                                                c < G ? (j * G + c) * 4 : OOB, 0, 0);
         }
       }
     } else {
@@ -331,8 +522,8 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += ad[r];
       }
+      tile_store_acc<AT>(RowTile(a_out, t * 32, V, RB), j, h, acc);
       if (ok) {
-        store_acc_layout(a_out + v * DM, h, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           st[0][r] += acc[r];
@@ -389,21 +580,33 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   float* tda = s_da[wv];
   float* tx = s_x[wv];
 
-  for_each_tile(V, [&](int64_t t, auto tail) {
+  struct Raw {
+    HalfRow<AT> dz, al;
+    AccRow<AT> ap;
+    float4 xm;
+    int32_t pnt;
+  };
+  constexpr int RB = DM * (int)sizeof(AT);
+  for_each_tile_pf(V, [&](int64_t t) {
+    // ---- the tile is read ONCE, view-major (each lane: half a row of dz_L, a_L; a_prev in the
+    //      accumulator layout); the channel-major operands of the weight gradient come from LDS
+    Raw r;
+    r.dz = tile_load_half<AT>(RowTile(dz_L, t * 32, V, RB), j, h);
+    r.al = tile_load_half<AT>(RowTile(a_L, t * 32, V, RB), j, h);
+    if (PREV_XMAP) r.xm = as_f4(RowTile(x_prev, t * 32, V, 32).b128(j * 32 + h * 16));
+    else r.ap = tile_load_acc<AT>(RowTile(a_prev, t * 32, V, RB), j, h);
+    r.pnt = HAS_DT ? (int32_t)RowTile(vp, t * 32, V, 4).b32(j * 4) : 0;
+    return r;
+  }, [&](int64_t t, const Raw& raw) {
     const int64_t row0 = t * 32;
     const int64_t v = row0 + j;
     const bool ok = v < V;
-    const int64_t vc = ok ? v : V - 1;  // clamped: loads are unconditional
-    // ---- the tile is read ONCE, view-major (each lane: half a row of dz_L, a_L; a_prev in the
-    //      accumulator layout); the channel-major operands of the weight gradient come from LDS
     float dzv[16], alv[16], ap[16];
-    load16(dz_L + vc * DM + 16 * h, dzv);
-    load16(a_L + vc * DM + 16 * h, alv);
-    float4 xm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PREV_XMAP) xm = *reinterpret_cast<const float4*>(x_prev + vc * 8 + 4 * h);
-    else load_acc_layout(a_prev + vc * DM, h, ap);
-    int32_t pnt = 0;
-    if (HAS_DT) pnt = vp[vc];
+    unpack(raw.dz, dzv);
+    unpack(raw.al, alv);
+    if (!PREV_XMAP) unpack(raw.ap, ap);
+    const float4 xm = raw.xm;
+    const int32_t pnt = raw.pnt;
     // ---------------- da = BN_L-backward(dz_L); view-major product dx = da . W_L
     float da[16];
     f32x16 accx = {0};
@@ -479,7 +682,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
       if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
     }
     // ---------------- the tile's only stores, last: nothing in this iteration waits for them
-    if (ok) store_acc_layout(out + v * DM, h, accx);
+    tile_store_acc<AT>(RowTile(out, row0, V, RB), j, h, accx);
     wave_sync_m();
   });
   // dW: accW[r] = dW[n = acc_chan(r,h)][k = j]; block reduction in LDS, one atomic per element per block
@@ -521,16 +724,25 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
   float acc[2][16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) acc[0][s] = acc[1][s] = 0.f;
-  for_each_tile(V, [&](int64_t t, auto tail) {
-    constexpr bool TAIL = decltype(tail)::value;
+  struct Raw {
+    HalfRow<AT> g, a;
+    int32_t p;
+  };
+  constexpr int RB = DM * (int)sizeof(AT);
+  for_each_tile_pf(V, [&](int64_t t) {
+    Raw r;
+    r.g = tile_load_half<AT>(RowTile(dcat, t * 32, V, RB), j, h);
+    r.a = tile_load_half<AT>(RowTile(a2, t * 32, V, RB), j, h);
+    r.p = (int32_t)RowTile(vp, t * 32, V, 4).b32(j * 4);
+    return r;
+  }, [&](int64_t t, const Raw& raw) {
     const int64_t v = t * 32 + j;
-    const bool ok = !TAIL || v < V;
-    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
-    const int64_t p = vp[vc];
+    const bool ok = v < V;
+    const int64_t p = raw.p;
     float g[16], a[16], dp[16];
-    load16(dcat + vc * DM + 16 * h, g);
-    load16(a2 + vc * DM + 16 * h, a);
-    load16(dpooled + p * DM + 16 * h, dp);
+    load16(dpooled + p * DM + 16 * h, dp);   // per-point rows: shared by the views of a point (L2)
+    unpack(raw.g, g);
+    unpack(raw.a, a);
     int32_t ag[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -546,7 +758,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
       acc[0][s] += d[s];
       acc[1][s] = fmaf(d[s], ahv[s], acc[1][s]);
     }
-    if (ok) store16(dz2 + v * DM + 16 * h, d);
+    tile_store_half<AT>(RowTile(dz2, t * 32, V, RB), j, h, d);
   });
   for (int i = threadIdx.x; i < 2 * DM; i += blockDim.x) s_red[i] = 0.f;
   __syncthreads();
@@ -580,26 +792,33 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
   float wsv[16];  // Ws[g = s + GH*h][k = j] for the (at most 16) view-major k-steps
 #pragma unroll
   for (int s = 0; s < 16; ++s) wsv[s] = (s < GH && s + GH * h < G) ? Ws[(s + GH * h) * DM + j] : 0.f;
-  for_each_tile(V, [&](int64_t t, auto tail) {
-    constexpr bool TAIL = decltype(tail)::value;
+  constexpr bool TAIL = true;
+  struct Raw {
+    AccRow<AT> ap;
+    float dcr[16];
+    float2 dc2;
+  };
+  const int jc = j < G ? j : 0;
+  constexpr int RB = DM * (int)sizeof(AT);
+  for_each_tile_pf(V, [&](int64_t t) {
+    Raw r;
+    r.ap = tile_load_acc<AT>(RowTile(a, t * 32, V, RB), j, h);
+    const RowTile D(dcompat, t * 32, V, G * 4);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) r.dcr[s] = __uint_as_float(D.b32(((2 * s + h) * G + jc) * 4));  // A[i = g = j][kk = h]
+    if (G == 4) r.dc2 = __builtin_bit_cast(float2, D.b64(j * 16 + h * 8));
+    return r;
+  }, [&](int64_t t, const Raw& raw) {
     const int64_t row0 = t * 32;
     const int64_t v = row0 + j;
-    const bool ok = !TAIL || v < V;
-    const int64_t vc = TAIL ? (v < V ? v : V - 1) : v;
-    // all loads of the tile first, unconditional
+    const bool ok = v < V;
+    const int64_t vc = ok ? v : V - 1;
     float ap[16];
-    load_acc_layout(a + vc * DM, h, ap);
-    float dcr[16];
-    const int jc = j < G ? j : 0;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int64_t r = row0 + 2 * s + h;
-      const int64_t rc = TAIL ? (r < V ? r : V - 1) : r;
-      dcr[s] = dcompat[rc * G + jc];                                     // A[i = g = j][kk = h]
-    }
+    unpack(raw.ap, ap);
+    const float (&dcr)[16] = raw.dcr;
     f32x16 accx = {0};
     if (G == 4) {
-      const float2 dc2 = *reinterpret_cast<const float2*>(dcompat + vc * 4 + 2 * h);
+      const float2 dc2 = raw.dc2;
       accx = DVA_MFMA(wsv[0], ok ? dc2.x : 0.f, accx);
       accx = DVA_MFMA(wsv[1], ok ? dc2.y : 0.f, accx);
     } else {
@@ -630,7 +849,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
       db += dc;
       accW = DVA_MFMA(dc, tx[(2 * s + h) * TS + j], accW);              // B[kk = h][j = k] from LDS
     }
-    if (ok) store_acc_layout(dz + v * DM, h, accx);
+    tile_store_acc<AT>(RowTile(dz, row0, V, RB), j, h, accx);
     wave_sync_m();
   });
   for (int i = threadIdx.x; i < DM * DM; i += blockDim.x) s_red[i] = 0.f;

@@ -19,13 +19,16 @@ typedef uint16_t bf16_t;  // raw bfloat16 bits
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even, NaN kept quiet (same rounding as torch's float -> bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// float -> bfloat16, round-to-nearest-even (same rounding as torch): gfx950 has the packed hardware
+// conversion v_cvt_pk_bf16_f32 (one instruction per pair, NaN stays NaN).
+typedef __bf16 dva_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dva_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const dva_f32x2 v = {lo, hi};
+  const dva_bf16x2 b = __builtin_convertvector(v, dva_bf16x2);
+  return __builtin_bit_cast(uint32_t, b);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T>
 struct Elt;
