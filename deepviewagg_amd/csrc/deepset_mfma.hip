@@ -142,6 +142,99 @@ __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restr
 
 #define DVA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// bf16 matrix cores for the bf16-storage instantiations.  v_mfma_f32_32x32x16_bf16 does 8x the work of the
+// fp32 instruction in half the cycles; rocprofv3 (profiles/r01d_sq_counters.txt) showed the fp32 chain as
+// the limiter once the traffic was halved: 55-68 % of the wave cycles were MFMA issue stalls.  fp32
+// accuracy is kept with the split  x = hi + lo  (hi = bf16(x), lo = bf16(x - hi)) and three products
+// hi*hi + lo*hi + hi*lo (the dropped lo*lo term is < 2^-16 relative).  Lane l supplies the 8 k-slots
+// 8*(l>>5) .. +7 of row / column l & 31; the accumulator layout is that of the fp32 instruction.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define DVA_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void split8(const float* x, bf16x8& hi, bf16x8& lo) {
+  uint32_t H[4], L[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    H[p] = pack_bf16x2(x[2 * p], x[2 * p + 1]);
+    const float h0 = __uint_as_float(H[p] << 16), h1 = __uint_as_float(H[p] & 0xffff0000u);
+    L[p] = pack_bf16x2(x[2 * p] - h0, x[2 * p + 1] - h1);
+  }
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 hv = {H[0], H[1], H[2], H[3]}, lv = {L[0], L[1], L[2], L[3]};
+  hi = __builtin_bit_cast(bf16x8, hv);
+  lo = __builtin_bit_cast(bf16x8, lv);
+}
+__device__ __forceinline__ bf16x8 round8(const float* x) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const u4 v = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
+                pack_bf16x2(x[6], x[7])};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// View-major 32x32 product  D[n][view] += sum_c W[n][c] X[c][view]:  lane (j, h) holds w[s] = W[n = j][c(s,h)]
+// and x[s] = X[c(s,h)][view = j] for the same 16 channels c(s, h) (half-row or accumulator layout).
+template <typename AT> struct ViewProd;
+template <> struct ViewProd<float> {
+  float w[16];
+  __device__ __forceinline__ void prep(const float (&wf)[16]) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w[s] = wf[s];
+  }
+  __device__ __forceinline__ f32x16 mul(const float (&x)[16], f32x16 acc) const {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = DVA_MFMA(w[s], x[s], acc);
+    return acc;
+  }
+};
+template <> struct ViewProd<bf16_t> {
+  bf16x8 hi[2], lo[2];
+  __device__ __forceinline__ void prep(const float (&wf)[16]) {
+    split8(&wf[0], hi[0], lo[0]);
+    split8(&wf[8], hi[1], lo[1]);
+  }
+  __device__ __forceinline__ f32x16 mul(const float (&x)[16], f32x16 acc) const {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x8 xh, xl;
+      split8(&x[8 * m], xh, xl);
+      acc = DVA_MFMA_BF16(hi[m], xh, acc);
+      acc = DVA_MFMA_BF16(lo[m], xh, acc);
+      acc = DVA_MFMA_BF16(hi[m], xl, acc);
+    }
+    return acc;
+  }
+};
+// The same with 4 channels per lane (x_map rows: 8 features).
+template <typename AT> struct ViewProd4;
+template <> struct ViewProd4<float> {
+  float w[4];
+  __device__ __forceinline__ void prep(const float (&wf)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = wf[s];
+  }
+  __device__ __forceinline__ f32x16 mul(const float4& x, f32x16 acc) const {
+    acc = DVA_MFMA(w[0], x.x, acc);
+    acc = DVA_MFMA(w[1], x.y, acc);
+    acc = DVA_MFMA(w[2], x.z, acc);
+    return DVA_MFMA(w[3], x.w, acc);
+  }
+};
+template <> struct ViewProd4<bf16_t> {
+  bf16x8 hi, lo;
+  __device__ __forceinline__ void prep(const float (&wf)[4]) {
+    const float w8[8] = {wf[0], wf[1], wf[2], wf[3], 0.f, 0.f, 0.f, 0.f};
+    split8(w8, hi, lo);
+  }
+  __device__ __forceinline__ f32x16 mul(const float4& x, f32x16 acc) const {
+    const float x8[8] = {x.x, x.y, x.z, x.w, 0.f, 0.f, 0.f, 0.f};
+    bf16x8 xh, xl;
+    split8(x8, xh, xl);
+    acc = DVA_MFMA_BF16(hi, xh, acc);
+    acc = DVA_MFMA_BF16(lo, xh, acc);
+    return DVA_MFMA_BF16(hi, xl, acc);
+  }
+};
+
 // Intra-wavefront LDS hand-off (DS ops of one wavefront execute in order; see deepset.hip).
 __device__ __forceinline__ void wave_sync_m() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -162,6 +255,29 @@ __device__ __forceinline__ void tile_put_acc(float* tile, int v, int h, const fl
   for (int q = 0; q < 4; ++q)
     *reinterpret_cast<float4*>(tile + v * TS + 8 * q + 4 * h) =
         make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
+// bf16 instantiations: the tile is staged TRANSPOSED ([channel][view], bf16, row stride 40 = 80 bytes) so
+// that the 8 consecutive views a lane feeds to v_mfma_f32_32x32x16_bf16 are one ds_read_b128.  The weight
+// gradient takes the operands rounded to bf16 (no split): it is a sum over all V views, the rounding
+// errors are unbiased and average out (the reference under autocast rounds the same operands).
+constexpr int TSB = 40;
+__device__ __forceinline__ void tileT_put(bf16_t* tile, int c0, int c1, int v, float x0, float x1) {
+  const uint32_t d = pack_bf16x2(x0, x1);
+  tile[c0 * TSB + v] = (bf16_t)(d & 0xffffu);
+  tile[c1 * TSB + v] = (bf16_t)(d >> 16);
+}
+__device__ __forceinline__ void tileT_put_half(bf16_t* tile, int v, int h, const float (&x)[16]) {
+#pragma unroll
+  for (int s = 0; s < 16; s += 2) tileT_put(tile, 16 * h + s, 16 * h + s + 1, v, x[s], x[s + 1]);
+}
+__device__ __forceinline__ void tileT_put_acc(bf16_t* tile, int v, int h, const float (&x)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) tileT_put(tile, acc_chan(r, h), acc_chan(r + 1, h), v, x[r], x[r + 1]);
+}
+// views 16m + 8h .. +7 of channel c: the 8 k-slots of lane (c, h) in MFMA m
+__device__ __forceinline__ bf16x8 tileT_get(const bf16_t* tile, int c, int h, int m) {
+  return *reinterpret_cast<const bf16x8*>(tile + c * TSB + 16 * m + 8 * h);
 }
 
 // Tile loop: every full 32-row tile runs a body instantiated with TAIL = false (no predication at all:
@@ -338,13 +454,19 @@ __device__ __forceinline__ void unpack(const AccRow<bf16_t>& r, float (&x)[16]) 
 // tile is computed, so one memory latency per tile is hidden behind the MFMA / VALU work of the previous
 // one (3 wavefronts per SIMD do not hide it on their own).  Past the last tile the prefetch re-reads the
 // last tile (valid memory, result unused).
-template <typename Load, typename Compute>
+template <bool PIPE = true, typename Load, typename Compute>
 __device__ __forceinline__ void for_each_tile_pf(int64_t V, Load&& load, Compute&& compute) {
   const int64_t tiles = (V + 31) / 32;
   // readfirstlane: the tile index must be provably wave-uniform (buffer descriptors live in SGPRs)
   const int64_t wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t last = tiles - 1;
+  if (!PIPE) {
+    // plain loop for bodies with memory operations under divergent control flow (run-length atomics):
+    // hipcc waits with vmcnt(0) there anyway, a second register set would only cost occupancy
+    for (int64_t t = wave; t < tiles; t += n_waves) compute(t, load(t));
+    return;
+  }
   if (wave < tiles) {
     // Two register sets in ping-pong (a rotating `cur = nxt` copy would make the loop wait for the
     // prefetch it has just issued: the copy reads the registers the loads are landing in).  The first
@@ -405,28 +527,31 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
   __shared__ float s_red[2 * DM];
   __shared__ __attribute__((aligned(16))) float s_bn[4][DM];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  float wa[4];  // Wa[n=j][4h + s]
+  ViewProd4<AT> pa;  // Wa[n=j][4h + s]
+  {
+    float wa[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) wa[s] = Wa[j * 8 + 4 * h + s];
-  float wb[16];  // Wb[n2=j][acc_chan(r,h)]
+    for (int s = 0; s < 4; ++s) wa[s] = Wa[j * 8 + 4 * h + s];
+    pa.prep(wa);
+  }
+  ViewProd<AT> pb;  // Wb[n2=j][acc_chan(r,h)]
   if (!STATS_ONLY) {
+    float wb[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) wb[r] = Wb[j * DM + acc_chan(r, h)];
+    pb.prep(wb);
     stage_bn(s_bn, bn1);
     __syncthreads();
   }
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  for_each_tile_pf(V, [&](int64_t t) {
+  for_each_tile_pf<sizeof(AT) == 2>(V, [&](int64_t t) {
     return as_f4(RowTile(x_map, t * 32, V, 32).b128(j * 32 + h * 16));   // rows beyond V read as zeros
   }, [&](int64_t t, float4 x) {
     const bool ok = t * 32 + j < V;
     f32x16 acc = {0};
-    acc = DVA_MFMA(wa[0], x.x, acc);
-    acc = DVA_MFMA(wa[1], x.y, acc);
-    acc = DVA_MFMA(wa[2], x.z, acc);
-    acc = DVA_MFMA(wa[3], x.w, acc);
+    acc = pa.mul(x, acc);
     if (STATS_ONLY) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -439,8 +564,10 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1v[r] = acc[r];
       bn_norm16<true>(s_bn, h, a1v, ah1, z1);
+      float xin[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2 = DVA_MFMA(wb[r], ok ? leaky_m(z1[r]) : 0.f, acc2);
+      for (int r = 0; r < 16; ++r) xin[r] = ok ? leaky_m(z1[r]) : 0.f;
+      acc2 = pb.mul(xin, acc2);
       tile_store_acc<AT>(RowTile(a2, t * 32, V, DM * (int)sizeof(AT)), j, h, acc2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -468,9 +595,13 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
   const bool ident = bn_in == nullptr;  // raw input (no BatchNorm / activation), e.g. pooled set features
   stage_bn(s_bn, bn_in);
   __syncthreads();
-  float w[16];  // W[n=j][16h + s]
+  ViewProd<AT> pw;  // W[n=j][16h + s]
+  {
+    float w[16];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) w[s] = (!SCORE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
+    for (int s = 0; s < 16; ++s) w[s] = (!SCORE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
+    pw.prep(w);
+  }
   float bia[16];
   if (SCORE) {
 #pragma unroll
@@ -484,7 +615,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
     int32_t p;
   };
   constexpr int RB = DM * (int)sizeof(AT);
-  for_each_tile_pf(V, [&](int64_t t) {
+  for_each_tile_pf<sizeof(AT) == 2>(V, [&](int64_t t) {
     Raw r;
     r.x = tile_load_half<AT>(RowTile(a_in, t * 32, V, RB), j, h);
     r.p = HAS_ADD ? (int32_t)RowTile(vp, t * 32, V, 4).b32(j * 4) : 0;
@@ -499,11 +630,10 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
     f32x16 acc = {0};
     float ahx[16], zx[16];
     bn_norm16<false>(s_bn, h, x, ahx, zx);
+    float xin[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float xin = ident ? x[s] : leaky_m(zx[s]);
-      acc = DVA_MFMA(w[s], ok ? xin : 0.f, acc);
-    }
+    for (int s = 0; s < 16; ++s) xin[s] = ok ? (ident ? x[s] : leaky_m(zx[s])) : 0.f;
+    acc = pw.mul(xin, acc);
     if (SCORE) {
       // scores [V, G] fp32; lanes / registers without a score column store out of bounds (dropped)
       const RowTile C(c_out, t * 32, V, G * 4);
@@ -539,7 +669,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
 // backward (same contract as dsf_bwd_layer_kernel in deepset.hip)
 // ------------------------------------------------------------------------------------------------
 template <typename AT, bool PREV_XMAP, bool RAW_OUT, bool HAS_DT>
-__global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
+__global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
     const AT* __restrict__ dz_L, const AT* __restrict__ a_L, const float* __restrict__ bn_L,
     const float* __restrict__ sm_L, const float* __restrict__ W_L, const void* __restrict__ a_prev_,
     const float* __restrict__ Wa, const float* __restrict__ bn_prev, AT* __restrict__ out,
@@ -565,13 +695,20 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
   stage_bn(s_p, bn_prev);
   __syncthreads();
   const bool pident = bn_prev == nullptr;  // the layer input is raw (only valid with RAW_OUT)
-  float wt[16];  // W_L[n = 16h + s][k = j]
+  constexpr bool BF = sizeof(AT) == 2;
+  ViewProd<AT> pt;  // W_L[n = 16h + s][k = j]
+  {
+    float wt[16];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
-  float wa4[4];
+    for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
+    pt.prep(wt);
+  }
+  ViewProd4<AT> p4;
   if (PREV_XMAP) {
+    float wa4[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) wa4[s] = Wa[j * 8 + 4 * h + s];  // view-major recompute of a1
+    p4.prep(wa4);
   }
   f32x16 accW = {0};
   float st[2][16];
@@ -587,7 +724,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     int32_t pnt;
   };
   constexpr int RB = DM * (int)sizeof(AT);
-  for_each_tile_pf(V, [&](int64_t t) {
+  for_each_tile_pf<(sizeof(AT) == 2) && !HAS_DT>(V, [&](int64_t t) {
     // ---- the tile is read ONCE, view-major (each lane: half a row of dz_L, a_L; a_prev in the
     //      accumulator layout); the channel-major operands of the weight gradient come from LDS
     Raw r;
@@ -626,17 +763,15 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
         const int s = 4 * q + e;
         const float ah = (alv[s] - ms[e]) * is[e];
         da[s] = ok ? gs[e] * (dzv[s] - s1[e] - ah * s2[e]) : 0.f;
-        accx = DVA_MFMA(wt[s], da[s], accx);
       }
     }
-    tile_put_half(tda, j, h, da);
+    accx = pt.mul(da, accx);
+    if (BF) tileT_put_half(reinterpret_cast<bf16_t*>(tda), j, h, da);
+    else tile_put_half(tda, j, h, da);
     // ---------------- x_L = leaky(BN_prev(a_prev)) in the accumulator layout -> LDS; dz_prev
     if (PREV_XMAP) {
       f32x16 a1 = {0};
-      a1 = DVA_MFMA(wa4[0], xm.x, a1);
-      a1 = DVA_MFMA(wa4[1], xm.y, a1);
-      a1 = DVA_MFMA(wa4[2], xm.z, a1);
-      a1 = DVA_MFMA(wa4[3], xm.w, a1);
+      a1 = p4.mul(xm, a1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) ap[r] = a1[r];
     }
@@ -644,7 +779,8 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     bn_norm16<true>(s_p, h, ap, ahp, zp);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xl[r] = ok ? (pident ? ap[r] : leaky_m(zp[r])) : 0.f;
-    tile_put_acc(tx, j, h, xl);
+    if (BF) tileT_put_acc(reinterpret_cast<bf16_t*>(tx), j, h, xl);
+    else tile_put_acc(tx, j, h, xl);
     if (!RAW_OUT) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -656,10 +792,17 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
     }
     wave_sync_m();
     // ---------------- channel-major: dW_L[n][k] += sum_v da[v][n] * x_L[v][k]  (operands from LDS)
+    if (BF) {
+      const bf16_t* ta = reinterpret_cast<const bf16_t*>(tda);
+      const bf16_t* tb = reinterpret_cast<const bf16_t*>(tx);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int row = 2 * s + h;
-      accW = DVA_MFMA(tda[row * TS + j], tx[row * TS + j], accW);
+      for (int m = 0; m < 2; ++m) accW = DVA_MFMA_BF16(tileT_get(ta, j, h, m), tileT_get(tb, j, h, m), accW);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int row = 2 * s + h;
+        accW = DVA_MFMA(tda[row * TS + j], tx[row * TS + j], accW);
+      }
     }
     // ---------------- dt[p][n] += da[v][n]: run-length sum over the tile's rows, lane = channel
     if (HAS_DT) {
@@ -676,7 +819,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_layer_kernel(
             cur_p = p;
             cur_s = 0.f;
           }
-          cur_s += tda[row * TS + j];
+          cur_s += BF ? bf2f(reinterpret_cast<const bf16_t*>(tda)[j * TSB + row]) : tda[row * TS + j];
         }
       }
       if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
@@ -729,7 +872,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
     int32_t p;
   };
   constexpr int RB = DM * (int)sizeof(AT);
-  for_each_tile_pf(V, [&](int64_t t) {
+  for_each_tile_pf<sizeof(AT) == 2>(V, [&](int64_t t) {
     Raw r;
     r.g = tile_load_half<AT>(RowTile(dcat, t * 32, V, RB), j, h);
     r.a = tile_load_half<AT>(RowTile(a2, t * 32, V, RB), j, h);
@@ -792,7 +935,6 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
   float wsv[16];  // Ws[g = s + GH*h][k = j] for the (at most 16) view-major k-steps
 #pragma unroll
   for (int s = 0; s < 16; ++s) wsv[s] = (s < GH && s + GH * h < G) ? Ws[(s + GH * h) * DM + j] : 0.f;
-  constexpr bool TAIL = true;
   struct Raw {
     AccRow<AT> ap;
     float dcr[16];
@@ -800,12 +942,18 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
   };
   const int jc = j < G ? j : 0;
   constexpr int RB = DM * (int)sizeof(AT);
-  for_each_tile_pf(V, [&](int64_t t) {
+  constexpr bool BF = sizeof(AT) == 2;
+  for_each_tile_pf<sizeof(AT) == 2>(V, [&](int64_t t) {
     Raw r;
     r.ap = tile_load_acc<AT>(RowTile(a, t * 32, V, RB), j, h);
     const RowTile D(dcompat, t * 32, V, G * 4);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) r.dcr[s] = __uint_as_float(D.b32(((2 * s + h) * G + jc) * 4));  // A[i = g = j][kk = h]
+    for (int s = 0; s < 16; ++s) {
+      // score gradient of column g = j: fp32 k-step s takes rows (2s, 2s+1); bf16 MFMA m = s / 8 takes
+      // rows 16m + 8h + (s & 7).  Rows beyond V read as zeros.
+      const int row = BF ? 16 * (s >> 3) + 8 * h + (s & 7) : 2 * s + h;
+      r.dcr[s] = __uint_as_float(D.b32((row * G + jc) * 4));
+    }
     if (G == 4) r.dc2 = __builtin_bit_cast(float2, D.b64(j * 16 + h * 8));
     return r;
   }, [&](int64_t t, const Raw& raw) {
@@ -839,15 +987,22 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
       stv[0][r] += d;
       stv[1][r] = fmaf(d, ahp[r], stv[1][r]);
     }
-    tile_put_acc(tx, j, h, xl);
+    if (BF) tileT_put_acc(reinterpret_cast<bf16_t*>(tx), j, h, xl);
+    else tile_put_acc(tx, j, h, xl);
     wave_sync_m();
+    float dcm[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int64_t r = row0 + 2 * s + h;
-      const bool okr = !TAIL || r < V;
-      const float dc = (okr && j < G) ? dcr[s] : 0.f;
-      db += dc;
-      accW = DVA_MFMA(dc, tx[(2 * s + h) * TS + j], accW);              // B[kk = h][j = k] from LDS
+      dcm[s] = j < G ? dcr[s] : 0.f;      // rows beyond V were read as zeros
+      db += dcm[s];
+    }
+    if (BF) {
+      const bf16_t* tb = reinterpret_cast<const bf16_t*>(tx);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) accW = DVA_MFMA_BF16(round8(&dcm[8 * m]), tileT_get(tb, j, h, m), accW);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) accW = DVA_MFMA(dcm[s], tx[(2 * s + h) * TS + j], accW);  // B[kk = h][j = k]
     }
     tile_store_acc<AT>(RowTile(dz, row0, V, RB), j, h, accx);
     wave_sync_m();
