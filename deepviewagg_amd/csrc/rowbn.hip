@@ -1,0 +1,196 @@
+// Weighted BatchNorm + LeakyReLU over the R rows of a feature map ("E_mod hoisting").
+//
+// The reference applies E_mod = [Linear -> BatchNorm1d -> LeakyReLU] x 2 to the V gathered view features
+// (modules/multimodal/pooling.py:245,275; MLP blocks core/common_modules/base_modules.py:38-48).  With an
+// exact nearest mapping those V rows are copies of the R feature-map rows, row r appearing counts[r]
+// times, so the train-mode batch statistics over the views are the statistics over the map rows weighted
+// by counts, and the whole block runs on R << V rows:
+//     mean = sum_r w_r y_r / n,  var = sum_r w_r (y_r - mean)^2 / n,  n = sum_r w_r = V
+//     out_r = leaky(gamma (y_r - mean) / sqrt(var + eps) + beta)
+// backward (gout_r already holds the sum of the gradients of the views of row r):
+//     dz_r = gout_r leaky'(z_r);  S1 = sum_r dz_r;  S2 = sum_r dz_r a_r   (a = normalised y)
+//     dy_r = gamma invstd (dz_r - w_r S1 / n - w_r a_r S2 / n);  dgamma = S2;  dbeta = S1
+// Four row-streaming passes (statistics / apply, forward and backward): lanes over channels (coalesced
+// rows), fp32 partial sums per thread, LDS per block, fp64 atomics per block.
+#include "dva_common.h"
+
+namespace dva {
+
+constexpr int RB_ROWS = 4;  // rows per block iteration (blockDim = 64 x 4)
+
+// sums[0..C) += sum_r w_r f1, sums[C..2C) += sum_r w_r f2 with (f1, f2) produced per element by `F`
+template <typename T, typename F>
+__device__ __forceinline__ void row_sums(int64_t R, int C, double* __restrict__ sums, float* s_red, F&& f) {
+  for (int i = threadIdx.y * 64 + threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 64) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * RB_ROWS + threadIdx.y; r < R; r += (int64_t)gridDim.x * RB_ROWS) {
+      float f1, f2;
+      f(r, c, f1, f2);
+      a0 += f1;
+      a1 += f2;
+    }
+    atomicAdd(&s_red[c], a0);
+    atomicAdd(&s_red[C + c], a1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.y * 64 + threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], (double)s_red[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowbn_stats_kernel(const T* __restrict__ y,
+                                                           const int32_t* __restrict__ counts,
+                                                           double* __restrict__ sums, int64_t R, int C) {
+  extern __shared__ float s_red[];
+  row_sums<T>(R, C, sums, s_red, [&](int64_t r, int c, float& f1, float& f2) {
+    const float w = (float)counts[r], v = Elt<T>::ld(y, r * C + c);
+    f1 = w * v;
+    f2 = w * v * v;
+  });
+}
+
+// bn = [4][C] fp32: mean | invstd | gamma | beta
+template <typename T>
+__global__ __launch_bounds__(256) void rowbn_apply_kernel(const T* __restrict__ y,
+                                                           const float* __restrict__ bn,
+                                                           T* __restrict__ out, int64_t R, int C,
+                                                           float slope) {
+  const int64_t total = R * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const float a = (Elt<T>::ld(y, t) - bn[c]) * bn[C + c];
+    const float z = a * bn[2 * C + c] + bn[3 * C + c];
+    Elt<T>::st(out, t, z > 0.f ? z : slope * z);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowbn_bwd_stats_kernel(const T* __restrict__ gout,
+                                                               const T* __restrict__ y,
+                                                               const float* __restrict__ bn,
+                                                               double* __restrict__ sums, int64_t R,
+                                                               int C, float slope) {
+  extern __shared__ float s_red[];
+  row_sums<T>(R, C, sums, s_red, [&](int64_t r, int c, float& f1, float& f2) {
+    const float a = (Elt<T>::ld(y, r * C + c) - bn[c]) * bn[C + c];
+    const float z = a * bn[2 * C + c] + bn[3 * C + c];
+    const float dz = Elt<T>::ld(gout, r * C + c) * (z > 0.f ? 1.f : slope);
+    f1 = dz;
+    f2 = dz * a;
+  });
+}
+
+// sm = [2][C] fp32: S1/n | S2/n (zeros when the statistics are not batch statistics)
+template <typename T>
+__global__ __launch_bounds__(256) void rowbn_bwd_apply_kernel(
+    const T* __restrict__ gout, const T* __restrict__ y, const int32_t* __restrict__ counts,
+    const float* __restrict__ bn, const float* __restrict__ sm, T* __restrict__ dy, int64_t R, int C,
+    float slope) {
+  const int64_t total = R * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    const float a = (Elt<T>::ld(y, t) - bn[c]) * bn[C + c];
+    const float z = a * bn[2 * C + c] + bn[3 * C + c];
+    const float dz = Elt<T>::ld(gout, t) * (z > 0.f ? 1.f : slope);
+    const float w = (float)counts[r];
+    Elt<T>::st(dy, t, bn[2 * C + c] * bn[C + c] * (dz - w * sm[c] - w * a * sm[C + c]));
+  }
+}
+
+static inline int rows_grid(int64_t R) {
+  int64_t b = (R + RB_ROWS - 1) / RB_ROWS;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+static inline int elems_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace dva
+
+using namespace dva;
+
+extern "C" {
+
+int dva_rowbn_stats(const void* y, const int32_t* counts, double* sums, int64_t R, int32_t C,
+                    int32_t dtype, void* stream) {
+  if (R < 0 || C <= 0 || C > 4096 || !sums) return DVA_ERR_INVALID;
+  if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
+  if (R == 0) return DVA_OK;
+  if (!y || !counts) return DVA_ERR_INVALID;
+  const dim3 block(64, 4);
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((rowbn_stats_kernel<float>), dim3(rows_grid(R)), block, lds, (hipStream_t)stream,
+                       (const float*)y, counts, sums, R, C);
+  else
+    hipLaunchKernelGGL((rowbn_stats_kernel<bf16_t>), dim3(rows_grid(R)), block, lds, (hipStream_t)stream,
+                       (const bf16_t*)y, counts, sums, R, C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_rowbn_apply(const void* y, const float* bn, void* out, int64_t R, int32_t C, float slope,
+                    int32_t dtype, void* stream) {
+  if (R < 0 || C <= 0) return DVA_ERR_INVALID;
+  if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
+  if (R == 0) return DVA_OK;
+  if (!y || !bn || !out) return DVA_ERR_INVALID;
+  const dim3 grid(elems_grid(R * C));
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((rowbn_apply_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)y, bn, (float*)out, R, C, slope);
+  else
+    hipLaunchKernelGGL((rowbn_apply_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)y, bn, (bf16_t*)out, R, C, slope);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_rowbn_bwd_stats(const void* grad_out, const void* y, const float* bn, double* sums, int64_t R,
+                        int32_t C, float slope, int32_t dtype, void* stream) {
+  if (R < 0 || C <= 0 || C > 4096 || !sums) return DVA_ERR_INVALID;
+  if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
+  if (R == 0) return DVA_OK;
+  if (!grad_out || !y || !bn) return DVA_ERR_INVALID;
+  const dim3 block(64, 4);
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((rowbn_bwd_stats_kernel<float>), dim3(rows_grid(R)), block, lds,
+                       (hipStream_t)stream, (const float*)grad_out, (const float*)y, bn, sums, R, C, slope);
+  else
+    hipLaunchKernelGGL((rowbn_bwd_stats_kernel<bf16_t>), dim3(rows_grid(R)), block, lds,
+                       (hipStream_t)stream, (const bf16_t*)grad_out, (const bf16_t*)y, bn, sums, R, C,
+                       slope);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_rowbn_bwd_apply(const void* grad_out, const void* y, const int32_t* counts, const float* bn,
+                        const float* sm, void* grad_y, int64_t R, int32_t C, float slope, int32_t dtype,
+                        void* stream) {
+  if (R < 0 || C <= 0) return DVA_ERR_INVALID;
+  if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
+  if (R == 0) return DVA_OK;
+  if (!grad_out || !y || !counts || !bn || !sm || !grad_y) return DVA_ERR_INVALID;
+  const dim3 grid(elems_grid(R * C));
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((rowbn_bwd_apply_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)grad_out, (const float*)y, counts, bn, sm, (float*)grad_y, R, C, slope);
+  else
+    hipLaunchKernelGGL((rowbn_bwd_apply_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)grad_out, (const bf16_t*)y, counts, bn, sm, (bf16_t*)grad_y, R, C,
+                       slope);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

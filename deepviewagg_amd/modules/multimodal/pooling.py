@@ -39,7 +39,7 @@ def _materialize(x_mod):
     return x_mod.materialize() if isinstance(x_mod, ops.GatheredFeatures) else x_mod
 
 
-def mlp_on_gathered_rows(mlp, rows, counts):
+def mlp_on_gathered_rows(mlp, rows, counts, n_views=None):
     """Evaluate ``mlp(rows[row_idx])`` WITHOUT gathering: returns ``out_rows`` such that
     ``out_rows[row_idx] == mlp(rows[row_idx])`` row for row.
 
@@ -50,6 +50,48 @@ def mlp_on_gathered_rows(mlp, rows, counts):
     per-view evaluation of the reference (pooling.py:245,275) and no [P, C] tensor is materialised.
     Backward is plain autograd over the [R, C] tensors.
     """
+    x = rows
+    n = None
+    for block in mlp:
+        lin, bn, act = block[0], block[1].batch_norm, block[2]
+        slope = _leaky_slope(act)
+        if slope is None or x.dtype not in (torch.float32, torch.bfloat16):
+            return _mlp_on_gathered_rows_torch(mlp, rows, counts)
+        y = ops.tall_linear(x, lin.weight, lin.bias)
+        batch_stats = bn.training or not bn.track_running_stats
+        if n is None:
+            # number of gathered rows (views); callers pass it to avoid a device synchronisation
+            n = float(n_views if n_views is not None else counts.sum()) if batch_stats else 1.0
+        if batch_stats:
+            s1, s2 = ops.rowbn_stats(y, counts)
+            mean = s1 / n
+            var = (s2 / n - mean * mean).clamp_(min=0.0)
+            if bn.training and bn.track_running_stats:
+                with torch.no_grad():
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - m).add_(m * mean.float())
+                    bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1.0, 1.0))).float())
+                    bn.num_batches_tracked += 1
+            mean, var = mean.float(), var.float()
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        invstd = torch.rsqrt(var + bn.eps)
+        x = ops.rowbn_act(y, counts, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                          mean, invstd, n, batch_stats, slope)
+    return x
+
+
+def _leaky_slope(act):
+    """Negative slope of the activations the fused row kernels cover, else None."""
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    return None
+
+
+def _mlp_on_gathered_rows_torch(mlp, rows, counts):
+    """Generic composition of ``mlp_on_gathered_rows`` for activations without a fused kernel."""
     w = counts.to(torch.float32).unsqueeze(1)
     n = w.sum()
     x = rows
@@ -252,7 +294,7 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
         if isinstance(x_mod, ops.GatheredFeatures) and not self.use_mod:
             # lazy nearest gather: E_mod runs on the map rows, the gather is fused into the
             # attention kernel (no [V, C] tensor exists on this path)
-            val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts)
+            val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0])
             if not fused_scores:
                 compatibilities = self.E_score(x_map)
             x_mod = x_mod.with_rows(val_rows)
@@ -334,7 +376,7 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
         else:
             x_map = self.E_map(x_map, csr_idx)
         if isinstance(x_mod, ops.GatheredFeatures) and not (self.use_mod_k or self.use_mod_q or self.debug):
-            x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts))
+            x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0]))
         else:
             x_mod = self.E_mod(_materialize(x_mod))
 

@@ -647,3 +647,104 @@ def view_gather_attention(rows, row_idx, compat, csr_idx, gate_w=None, gate_b=No
         compat = compat.reshape(-1, 1)
     return _ViewGatherAttention.apply(rows, row_idx.contiguous(), compat.float(), csr_idx, gate_w, gate_b,
                                       scaling, eps, plan)
+
+
+# ---------------------------------------------------------------------------------------------
+# E_mod on the feature-map rows: tall-skinny Linear + weighted BatchNorm + LeakyReLU
+# ---------------------------------------------------------------------------------------------
+
+def _xty_splitk(a, b, splits=64):
+    """``a.T @ b`` for tall operands [R, O], [R, I] -> fp32 [O, I].  A plain GEMM call runs this
+    K = R reduction in ONE 64x64 tile (one workgroup, 0.5 ms at R = 262144); ``splits`` batched
+    products of R / splits rows fill the device, the partial sums are added in fp32."""
+    R = a.shape[0]
+    if R < 8192 or R % splits:
+        return a.float().t() @ b.float()
+    part = torch.bmm(a.view(splits, R // splits, -1).transpose(1, 2), b.view(splits, R // splits, -1))
+    return part.float().sum(0)
+
+
+class _TallLinear(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is a split-K product (same forward, same autocast rule)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else x.dtype
+        xc, wc = x.to(dt), weight.to(dt)
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return torch.nn.functional.linear(xc, wc, None if bias is None else bias.to(dt))
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc = ctx.saved_tensors
+        x_dt, w_dt, b_dt = ctx.meta
+        gy = gy.contiguous()
+        gx = (gy @ wc).to(x_dt) if ctx.needs_input_grad[0] else None
+        gw = _xty_splitk(gy, xc).to(w_dt) if ctx.needs_input_grad[1] else None
+        gb = gy.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def tall_linear(x, weight, bias=None):
+    return _TallLinear.apply(x, weight, bias)
+
+
+class _RowBNAct(torch.autograd.Function):
+    """``leaky(BatchNorm(y))`` on map rows with the statistics weighted by ``counts`` (views per row).
+    ``mean`` / ``invstd`` are given (batch statistics from ``rowbn_stats`` or running statistics);
+    with ``batch_stats`` the backward includes the statistics terms."""
+
+    @staticmethod
+    def forward(ctx, y, counts, gamma, beta, mean, invstd, n, batch_stats, slope):
+        lib = _lib.load()
+        require_device(y, counts)
+        y = y.contiguous()
+        R, C = y.shape
+        g = gamma.detach().float() if gamma is not None else torch.ones(C, device=y.device)
+        b = beta.detach().float() if beta is not None else torch.zeros(C, device=y.device)
+        bn = torch.stack([mean.float(), invstd.float(), g, b]).contiguous()
+        out = torch.empty_like(y)
+        with _timed("rowbn_apply", R * C * 2 * y.element_size()):
+            check(lib.dva_rowbn_apply(ptr(y), ptr(bn), ptr(out), R, C, float(slope), dtype_code(y),
+                                      stream_of(y)), "dva_rowbn_apply")
+        ctx.save_for_backward(y, counts, bn)
+        ctx.meta = (float(n), bool(batch_stats), float(slope), gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        y, counts, bn = ctx.saved_tensors
+        n, batch_stats, slope, has_g, has_b = ctx.meta
+        R, C = y.shape
+        gout = gout.contiguous().to(y.dtype)
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=y.device)
+        with _timed("rowbn_bwd_stats", R * C * 2 * y.element_size()):
+            check(lib.dva_rowbn_bwd_stats(ptr(gout), ptr(y), ptr(bn), ptr(sums), R, C, slope, dtype_code(y),
+                                          stream_of(y)), "dva_rowbn_bwd_stats")
+        sm = (sums / n).float().contiguous() if batch_stats else torch.zeros(2 * C, device=y.device)
+        dy = torch.empty_like(y)
+        with _timed("rowbn_bwd_apply", R * C * 3 * y.element_size()):
+            check(lib.dva_rowbn_bwd_apply(ptr(gout), ptr(y), ptr(counts), ptr(bn), ptr(sm), ptr(dy), R, C, slope,
+                                          dtype_code(y), stream_of(y)), "dva_rowbn_bwd_apply")
+        dg = sums[C:].float() if has_g else None
+        db = sums[:C].float() if has_b else None
+        return dy, None, dg, db, None, None, None, None, None
+
+
+def rowbn_stats(y, counts):
+    """(sum_r counts_r y_r, sum_r counts_r y_r^2) as float64 [C] each."""
+    lib = _lib.load()
+    require_device(y, counts)
+    y = y.contiguous()
+    R, C = y.shape
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=y.device)
+    with _timed("rowbn_stats", R * (C * y.element_size() + 4)):
+        check(lib.dva_rowbn_stats(ptr(y), ptr(counts), ptr(sums), R, C, dtype_code(y), stream_of(y)),
+              "dva_rowbn_stats")
+    return sums[:C], sums[C:]
+
+
+def rowbn_act(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope):
+    return _RowBNAct.apply(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope)

@@ -249,6 +249,29 @@ int dva_deepset_bwd_first(const void* dz1, const float* x_map, const float* Wa, 
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * Weighted BatchNorm1d + LeakyReLU over the R rows of a feature map: one MLP block of E_mod
+ * (pooling.py:245,275; core/common_modules/base_modules.py:38-48) evaluated on the map rows instead of
+ * the V gathered views.  counts int32 [R] = views per row (dva_row_plan / dva_gather_row_index): the
+ * batch statistics over the views are the statistics over the rows weighted by counts.
+ * y / out / grad_* are [R, C] in dtype; sums = caller-zeroed double[2*C]; bn = fp32 [4][C] =
+ * mean | invstd | gamma | beta; sm = fp32 [2][C] = S1/n | S2/n (zeros when running statistics are used).
+ * ------------------------------------------------------------------------------------------ */
+/* sums = sum_r counts_r y_r | sum_r counts_r y_r^2 */
+int dva_rowbn_stats(const void* y, const int32_t* counts, double* sums, int64_t R, int32_t C,
+                    int32_t dtype, void* stream);
+/* out = leaky(gamma (y - mean) invstd + beta), negative slope `slope` */
+int dva_rowbn_apply(const void* y, const float* bn, void* out, int64_t R, int32_t C, float slope,
+                    int32_t dtype, void* stream);
+/* sums = S1 | S2 with dz = grad_out leaky'(z): S1 = sum_r dz_r, S2 = sum_r dz_r a_r (a = normalised y);
+ * also d beta = S1, d gamma = S2. */
+int dva_rowbn_bwd_stats(const void* grad_out, const void* y, const float* bn, double* sums, int64_t R,
+                        int32_t C, float slope, int32_t dtype, void* stream);
+/* grad_y = gamma invstd (dz - counts (S1/n) - counts a (S2/n)) */
+int dva_rowbn_bwd_apply(const void* grad_out, const void* y, const int32_t* counts, const float* bn,
+                        const float* sm, void* grad_y, int64_t R, int32_t C, float slope, int32_t dtype,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a
  * composite int64 key, :97-179 CompositeTensor, :253-323 lex ops).
  * ------------------------------------------------------------------------------------------ */

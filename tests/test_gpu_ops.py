@@ -334,3 +334,44 @@ def test_rows_grad_plan_equals_atomics(C, G, gating, dtype):
         xp = xp * O.expand_group_feat(torch.tanh(torch.relu(mx * gw + gb)), G, C)
     g_ref = torch.autograd.grad((xp * w).sum(), rr)[0]
     close(b[1], g_ref, **(dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C,slope", [(1000, 64, 0.2), (8192 * 2, 32, 0.2), (777, 48, 0.0)])
+def test_rowbn_and_tall_linear_match_torch(R, C, slope, dtype):
+    """Linear + weighted BatchNorm + LeakyReLU on map rows (C ABI dva_rowbn_*) against the plain torch
+    composition on the materialised per-view rows, forward and all gradients."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(R + C)
+    counts = torch.randint(0, 5, (R,), generator=gen, dtype=torch.int32)
+    n = float(counts.sum())
+    x = torch.randn(R, C, generator=gen)
+    W = torch.randn(C, C, generator=gen) * 0.3
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    gw = torch.randn(R, C, generator=gen)
+    # reference: every row repeated counts times (the gathered views), standard batch norm over them
+    idx = torch.repeat_interleave(torch.arange(R), counts.long())
+    xr, Wr, gr, br = [t.clone().requires_grad_() for t in (x, W, gamma, beta)]
+    yv = torch.nn.functional.linear(xr[idx], Wr)
+    zv = torch.nn.functional.batch_norm(yv, None, None, gr, br, True, 0.1, 1e-5)
+    ov = torch.nn.functional.leaky_relu(zv, slope)
+    ref_grads = torch.autograd.grad((ov * gw[idx]).sum(), [xr, Wr, gr, br])
+    # device
+    xd, Wd, gd, bd = [t.to(DEV).requires_grad_() for t in (x, W, gamma, beta)]
+    cd = counts.to(DEV)
+    y = ops.tall_linear(xd.to(dtype), Wd.to(dtype))
+    s1, s2 = ops.rowbn_stats(y, cd)
+    mean = s1 / n
+    var = (s2 / n - mean * mean).clamp_(min=0)
+    out = ops.rowbn_act(y, cd, gd, bd, mean.float(), torch.rsqrt(var.float() + 1e-5), n, True, slope)
+    # the loss over the views = sum over rows of counts * (row term)
+    grads = torch.autograd.grad((out.float() * (gw.to(DEV) * cd.unsqueeze(1))).sum(), [xd, Wd, gd, bd])
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=6e-2, atol=6e-2)
+    seen = counts > 0
+    first = (counts.long().cumsum(0) - counts.long())[seen]      # first view of every row that is seen
+    close(out[seen.to(DEV)], ov.detach()[first], **tol)
+    for a, b in zip(grads, ref_grads):
+        if dtype == torch.float32:
+            close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
+        else:
+            assert float((a.float().cpu() - b).norm() / b.norm()) < 5e-2
