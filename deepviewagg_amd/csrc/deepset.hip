@@ -601,7 +601,7 @@ int dsm_launch_fwd_layer(const void*, const float*, const float*, const float*, 
 int dsm_launch_fwd_score(const void*, const float*, const float*, const float*, float*, int64_t, int, int,
                          hipStream_t);
 int dsm_launch_bwd_layer(const void*, const void*, const float*, const float*, const float*, const void*,
-                         const float*, const float*, void*, float*, double*, float*, const int32_t*,
+                         const float*, const float*, void*, float*, double*, float*, const int32_t*, float*,
                          int64_t, int, int, int, hipStream_t);
 int dsm_launch_bwd_max(const void*, const void*, const float*, const int32_t*, const float*, const int32_t*,
                        void*, double*, int64_t, int, hipStream_t);
@@ -757,15 +757,19 @@ int dva_deepset_bwd_score(const float* dcompat, const void* a_, const float* bn,
 int dva_deepset_bwd_layer(const void* dz_L_, const void* a_L_, const float* bn_L, const float* sm_L,
                           const float* W_L, const void* a_prev_, const float* Wa, const float* bn_prev,
                           void* out_, float* dW, double* st_prev, float* dt,
-                          const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
-                          int32_t raw_out, int32_t algo, int32_t act_dtype, void* stream) {
+                          const int32_t* group_of_row, float* first_grad, int64_t V,
+                          int32_t prev_is_xmap, int32_t raw_out, int32_t algo, int32_t act_dtype,
+                          void* stream) {
   const int bf = act_bf(act_dtype);
   if (V < 0 || bf < 0) return DVA_ERR_INVALID;
   if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  // fused first-layer gradient: bf16 storage, x_map input, batch-norm output, no per-point sum
+  if (first_grad && (!bf || !prev_is_xmap || raw_out || dt)) return DVA_ERR_UNSUPPORTED;
   const float *dz_L = (const float*)dz_L_, *a_L = (const float*)a_L_, *a_prev = (const float*)a_prev_;
   float* out = (float*)out_;
   if (V == 0) return DVA_OK;
-  if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || !out || !dW) return DVA_ERR_INVALID;
+  if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || (!out && !first_grad) || !dW)
+    return DVA_ERR_INVALID;
   if (!bn_prev && (!raw_out || algo == 1 || prev_is_xmap)) return DVA_ERR_UNSUPPORTED;
   if (!raw_out && !st_prev) return DVA_ERR_INVALID;
   if (prev_is_xmap && !Wa) return DVA_ERR_INVALID;
@@ -773,7 +777,7 @@ int dva_deepset_bwd_layer(const void* dz_L_, const void* a_L_, const float* bn_L
   hipStream_t s = (hipStream_t)stream;
   if (algo != 1) {
     dsm_launch_bwd_layer(dz_L_, a_L_, bn_L, sm_L, W_L, a_prev_, Wa, bn_prev, out_, dW, st_prev, dt,
-                         group_of_row, V, prev_is_xmap, raw_out, bf, s);
+                         group_of_row, first_grad, V, prev_is_xmap, raw_out, bf, s);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }

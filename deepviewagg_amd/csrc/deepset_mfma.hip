@@ -498,6 +498,9 @@ __device__ __forceinline__ void stage_bn(float (*t)[DM], const float* __restrict
 template <bool ACC_LAYOUT>
 __device__ __forceinline__ void bn_norm16(const float (*t)[DM], int h, const float (&x)[16], float (&ah)[16],
                                           float (&z)[16]) {
+  // keep the table in LDS: without the barrier hipcc hoists the 64 constants of a lane out of the tile
+  // loop into registers, which costs a whole occupancy step (16 ds_read_b128 per tile are nothing)
+  asm volatile("" ::: "memory");
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int base = ACC_LAYOUT ? 8 * q + 4 * h : 16 * h + 4 * q;
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
 // a_out[v] = leaky(BN_in(a_in[v])) . W^T (+ addend[vp[v]]) ; statistics of a_out.
 // SCORE: W has G <= 32 valid rows (others zero), bias added, only columns < G stored, no statistics.
 template <typename AT, bool HAS_ADD, bool SCORE>
-__global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
+__global__ __launch_bounds__(256, (HAS_ADD ? 2 : 3)) void dsm_fwd_layer_kernel(
     const AT* __restrict__ a_in, const float* __restrict__ bn_in, const float* __restrict__ W,
     const float* __restrict__ addend, const int32_t* __restrict__ vp, const float* __restrict__ bias,
     void* __restrict__ a_out_, double* __restrict__ stats, int64_t V, int G) {
@@ -668,13 +671,23 @@ __global__ __launch_bounds__(256) void dsm_fwd_layer_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward (same contract as dsf_bwd_layer_kernel in deepset.hip)
 // ------------------------------------------------------------------------------------------------
-template <typename AT, bool PREV_XMAP, bool RAW_OUT, bool HAS_DT>
+// FUSE1 (bf16 storage, PREV_XMAP): the first layer's weight gradient is folded in.  BN1-backward needs the
+// statistics this very pass produces, but it is linear in them:
+//   dWa[n][f] = sum_v da1[v][n] x[v][f],  da1 = gsc (dz1 - S1/M - a1_hat S2/M)
+//             = gsc[n] (P[n][f] - (S1/M)[n] SX[f] - (S2/M)[n] Q[n][f])
+//   P = sum_v dz1 x^T,  Q = sum_v a1_hat x^T,  SX = sum_v x     (first = P[32][8] | Q[32][8] | SX[8])
+// so P, Q, SX are accumulated here (two more channel-major bf16 products per tile) and dz1 is never
+// written: saves the dva_deepset_bwd_first pass and 2 x V x 64 bytes of traffic.
+template <typename AT, bool PREV_XMAP, bool RAW_OUT, bool HAS_DT, bool FUSE1 = false>
 __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
     const AT* __restrict__ dz_L, const AT* __restrict__ a_L, const float* __restrict__ bn_L,
     const float* __restrict__ sm_L, const float* __restrict__ W_L, const void* __restrict__ a_prev_,
     const float* __restrict__ Wa, const float* __restrict__ bn_prev, AT* __restrict__ out,
     float* __restrict__ dW, double* __restrict__ st_prev, float* __restrict__ dt,
-    const int32_t* __restrict__ vp, int64_t V) {
+    const int32_t* __restrict__ vp, float* __restrict__ first, int64_t V) {
+  static_assert(!FUSE1 || (PREV_XMAP && !RAW_OUT && !HAS_DT && sizeof(AT) == 2), "FUSE1 variant");
+  // per-wavefront transposed bf16 tiles of the fused first-layer products: dz1 | a1_hat | x (32 rows each)
+  __shared__ __attribute__((aligned(16))) bf16_t s_f1[FUSE1 ? 4 : 1][FUSE1 ? 96 * TSB : 8];
   // the layer input: raw x_map rows (fp32 [V, 8]) or activations in the storage type
   const float* __restrict__ x_prev = reinterpret_cast<const float*>(a_prev_);
   const AT* __restrict__ a_prev = reinterpret_cast<const AT*>(a_prev_);
@@ -711,11 +724,20 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
     p4.prep(wa4);
   }
   f32x16 accW = {0};
+  f32x16 accP = {0}, accQ = {0};
+  float4 sx4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
   float* tda = s_da[wv];
   float* tx = s_x[wv];
+  bf16_t* f1 = s_f1[FUSE1 ? wv : 0];
+  if (FUSE1) {
+    // x^T tile: only the 8 feature rows are rewritten per tile, rows 8..31 stay zero
+    uint32_t* z = reinterpret_cast<uint32_t*>(f1 + 64 * TSB);
+    for (int i = lane; i < 32 * TSB / 2; i += 64) z[i] = 0u;
+    wave_sync_m();
+  }
 
   struct Raw {
     HalfRow<AT> dz, al;
@@ -724,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
     int32_t pnt;
   };
   constexpr int RB = DM * (int)sizeof(AT);
-  for_each_tile_pf<(sizeof(AT) == 2) && !HAS_DT>(V, [&](int64_t t) {
+  for_each_tile_pf<(sizeof(AT) == 2) && !HAS_DT && !FUSE1>(V, [&](int64_t t) {
     // ---- the tile is read ONCE, view-major (each lane: half a row of dz_L, a_L; a_prev in the
     //      accumulator layout); the channel-major operands of the weight gradient come from LDS
     Raw r;
@@ -790,6 +812,19 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
         st[1][r] = fmaf(d, ahp[r], st[1][r]);
       }
     }
+    if (FUSE1) {
+      float d1[16], ah1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d1[r] = accx[r];                 // dz1, already zero for rows beyond V
+        ah1[r] = ok ? ahp[r] : 0.f;
+      }
+      tileT_put_acc(f1, j, h, d1);
+      tileT_put_acc(f1 + 32 * TSB, j, h, ah1);
+      tileT_put(f1 + 64 * TSB, 4 * h, 4 * h + 1, j, xm.x, xm.y);     // rows beyond V read as zeros
+      tileT_put(f1 + 64 * TSB, 4 * h + 2, 4 * h + 3, j, xm.z, xm.w);
+      sx4.x += xm.x; sx4.y += xm.y; sx4.z += xm.z; sx4.w += xm.w;
+    }
     wave_sync_m();
     // ---------------- channel-major: dW_L[n][k] += sum_v da[v][n] * x_L[v][k]  (operands from LDS)
     if (BF) {
@@ -797,6 +832,14 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
       const bf16_t* tb = reinterpret_cast<const bf16_t*>(tx);
 #pragma unroll
       for (int m = 0; m < 2; ++m) accW = DVA_MFMA_BF16(tileT_get(ta, j, h, m), tileT_get(tb, j, h, m), accW);
+      if (FUSE1) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x8 bx = tileT_get(f1 + 64 * TSB, j, h, m);      // x[view][f = j] (zero for j >= 8)
+          accP = DVA_MFMA_BF16(tileT_get(f1, j, h, m), bx, accP);
+          accQ = DVA_MFMA_BF16(tileT_get(f1 + 32 * TSB, j, h, m), bx, accQ);
+        }
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -825,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
       if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
     }
     // ---------------- the tile's only stores, last: nothing in this iteration waits for them
-    tile_store_acc<AT>(RowTile(out, row0, V, RB), j, h, accx);
+    if (!FUSE1) tile_store_acc<AT>(RowTile(out, row0, V, RB), j, h, accx);
     wave_sync_m();
   });
   // dW: accW[r] = dW[n = acc_chan(r,h)][k = j]; block reduction in LDS, one atomic per element per block
@@ -838,6 +881,28 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
   if (!RAW_OUT) {
     __syncthreads();
     flush_stats<2>(st, st_prev, s_red, lane);
+  }
+  if (FUSE1) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 520; i += blockDim.x) s_red[i] = 0.f;
+    __syncthreads();
+    if (j < 8) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        atomicAdd(&s_red[acc_chan(r, h) * 8 + j], accP[r]);
+        atomicAdd(&s_red[256 + acc_chan(r, h) * 8 + j], accQ[r]);
+      }
+    }
+    float sx[4] = {sx4.x, sx4.y, sx4.z, sx4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = sx[e];
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+      if (j == 0) atomicAdd(&s_red[512 + 4 * h + e], v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 520; i += blockDim.x) atomicAdd(&first[i], s_red[i]);
   }
 }
 
@@ -1083,13 +1148,21 @@ int dsm_launch_fwd_score(const void* a, const float* bn, const float* Ws, const 
 template <typename AT>
 static void launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
                              const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
-                             void* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
-                             int prev_is_xmap, int raw_out, hipStream_t s) {
+                             void* out, float* dW, double* st_prev, float* dt, const int32_t* vp,
+                             float* first, int64_t V, int prev_is_xmap, int raw_out, hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
 #define DVA_L(P, R, T)                                                                               \
   hipLaunchKernelGGL((dsm_bwd_layer_kernel<AT, P, R, T>), grid, block, 0, s, (const AT*)dz_L,        \
                      (const AT*)a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, (AT*)out, dW, st_prev, dt, \
-                     vp, V)
+                     vp, (float*)nullptr, V)
+  if constexpr (sizeof(AT) == 2) {
+    if (first) {
+      hipLaunchKernelGGL((dsm_bwd_layer_kernel<AT, true, false, false, true>), grid, block, 0, s,
+                         (const AT*)dz_L, (const AT*)a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, (AT*)out, dW,
+                         st_prev, dt, vp, first, V);
+      return;
+    }
+  }
   if (prev_is_xmap && raw_out) DVA_L(true, true, false);
   else if (prev_is_xmap) DVA_L(true, false, false);
   else if (raw_out && dt) DVA_L(false, true, true);
@@ -1100,13 +1173,13 @@ static void launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_
 }
 int dsm_launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
                          const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
-                         void* out, float* dW, double* st_prev, float* dt, const int32_t* vp, int64_t V,
-                         int prev_is_xmap, int raw_out, int bf, hipStream_t s) {
+                         void* out, float* dW, double* st_prev, float* dt, const int32_t* vp, float* first,
+                         int64_t V, int prev_is_xmap, int raw_out, int bf, hipStream_t s) {
   DVA_ACT(bf,
           launch_bwd_layer<float>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp,
-                                  V, prev_is_xmap, raw_out, s),
+                                  first, V, prev_is_xmap, raw_out, s),
           launch_bwd_layer<bf16_t>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt,
-                                   vp, V, prev_is_xmap, raw_out, s));
+                                   vp, first, V, prev_is_xmap, raw_out, s));
   return 0;
 }
 

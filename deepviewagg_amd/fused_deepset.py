@@ -216,7 +216,7 @@ class _DeepSetLinear(torch.autograd.Function):
         sm4 = sm_of(s4)
         with ops._timed("deepset_bwd_layer", V * RB * 4):
             check(lib.dva_deepset_bwd_layer(ptr(dz4), ptr(a4), ptr(bn4), ptr(sm4), ptr(Wd), ptr(a3), None, ptr(bn3),
-                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, V, 0, 0, ALGO, AC, st),
+                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, None, V, 0, 0, ALGO, AC, st),
                   "dva_deepset_bwd_layer")
         del dz4
         # Wc layer (cat(h1, set) -> a3): raw dx on the h1 half, per-point sum on the set half
@@ -225,7 +225,7 @@ class _DeepSetLinear(torch.autograd.Function):
         sm3 = sm_of(s3)
         with ops._timed("deepset_bwd_layer_cat", V * (RB * 4 + 4) + N * 128):
             check(lib.dva_deepset_bwd_layer(ptr(dz3), ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2), None, ptr(bn2),
-                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), V, 0, 1, ALGO, AC, st),
+                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), None, V, 0, 1, ALGO, AC, st),
                   "dva_deepset_bwd_layer")
         del dz3
         # set branch backward with the same layer kernels over the N points
@@ -235,21 +235,21 @@ class _DeepSetLinear(torch.autograd.Function):
         dWcB = torch.zeros_like(WcB)
         dzs2, ss2 = buf(N, torch.float32), zstats()
         check(lib.dva_deepset_bwd_layer(ptr(dt), ptr(t_add), ptr(ident_bn), ptr(zero_sm), ptr(WcB), ptr(u2), None,
-                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, N, 0, 0, 0, F32C, st),
+                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, None, N, 0, 0, 0, F32C, st),
               "dva_deepset_bwd_layer")
         dWsb = torch.zeros_like(Wsb)
         dzs1, ss1 = buf(N, torch.float32), zstats()
         sms2 = sm_of(ss2, n_rows)
         check(lib.dva_deepset_bwd_layer(ptr(dzs2), ptr(u2), ptr(bns2), ptr(sms2), ptr(Wsb), ptr(u1), None,
-                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, N, 0, 0, 0, F32C, st),
+                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, None, N, 0, 0, 0, F32C, st),
               "dva_deepset_bwd_layer")
         dWsaP = torch.zeros_like(WsaP)
         dpooled = buf(N, torch.float32)
         da1 = torch.zeros((N, D), dtype=torch.float32, device=dev) if num is not None else None
         sms1 = sm_of(ss1, n_rows)
         check(lib.dva_deepset_bwd_layer(ptr(dzs1), ptr(u1), ptr(bns1), ptr(sms1), ptr(WsaP), ptr(pooled), None,
-                                        None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), N, 0, 1, 0,
-                                        F32C, st), "dva_deepset_bwd_layer")
+                                        None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), None, N, 0, 1,
+                                        0, F32C, st), "dva_deepset_bwd_layer")
         if num is not None:
             dWsa = torch.cat([dWsaP, (da1 * num.view(-1, 1)).sum(0).view(-1, 1)], dim=1)
         else:
@@ -263,18 +263,33 @@ class _DeepSetLinear(torch.autograd.Function):
                                           ptr(s2), V, ALGO, AC, st), "dva_deepset_bwd_max")
         del dcat
         # Wb layer (a1 -> a2), a1 recomputed from x_map
-        dz1, s1, dWb = buf(), zstats(), torch.zeros_like(Wb)
+        s1, dWb = zstats(), torch.zeros_like(Wb)
         sm2 = sm_of(s2)
-        with ops._timed("deepset_bwd_layer_xmap", V * (RB * 3 + 32)):
-            check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
-                                            ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, V, 1, 0, ALGO, AC, st),
-                  "dva_deepset_bwd_layer")
-        del dz2
-        dWa = torch.zeros_like(Wa)
-        sm1 = sm_of(s1)
-        with ops._timed("deepset_bwd_first", V * (RB + 32)):
-            check(lib.dva_deepset_bwd_first(ptr(dz1), ptr(x_map), ptr(Wa), ptr(bn1), ptr(sm1), ptr(dWa), V, 8, AC, st),
-                  "dva_deepset_bwd_first")
+        if act == torch.bfloat16 and ALGO == 0:
+            # first layer folded in: the pass also accumulates P | Q | SX (BN1-backward is linear in the
+            # statistics it produces), dz1 is never written and there is no bwd_first pass
+            first = torch.zeros(520, dtype=torch.float32, device=dev)
+            with ops._timed("deepset_bwd_layer_xmap_first", V * (RB * 2 + 32)):
+                check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
+                                                ptr(bn1), None, ptr(dWb), ptr(s1), None, None, ptr(first), V, 1, 0,
+                                                ALGO, AC, st), "dva_deepset_bwd_layer")
+            del dz2
+            sm1 = sm_of(s1)
+            P, Q, SX = first[:256].view(D, 8), first[256:512].view(D, 8), first[512:]
+            gsc = (bn1[2] * bn1[1]).view(D, 1)
+            dWa = gsc * (P - sm1[:D].view(D, 1) * SX.view(1, 8) - sm1[D:].view(D, 1) * Q)
+        else:
+            dz1 = buf()
+            with ops._timed("deepset_bwd_layer_xmap", V * (RB * 3 + 32)):
+                check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
+                                                ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, None, V, 1, 0,
+                                                ALGO, AC, st), "dva_deepset_bwd_layer")
+            del dz2
+            dWa = torch.zeros_like(Wa)
+            sm1 = sm_of(s1)
+            with ops._timed("deepset_bwd_first", V * (RB + 32)):
+                check(lib.dva_deepset_bwd_first(ptr(dz1), ptr(x_map), ptr(Wa), ptr(bn1), ptr(sm1), ptr(dWa), V, 8, AC,
+                                                st), "dva_deepset_bwd_first")
 
         def gb(stats):  # d gamma = S2, d beta = S1
             return stats[D:].float(), stats[:D].float()

@@ -232,12 +232,18 @@ int dva_deepset_bwd_score(const float* dcompat, const void* a, const float* bn, 
  * out = dx (raw_out) or dz_prev = dx*leaky'(BN_prev(a_prev)) with S1/S2 of BN_prev in st_prev;
  * dt[group_of_row[v]] += da_L[v] (nullable). prev_is_xmap: a_prev is x_map [V,8] and the previous
  * activation is recomputed as x_map.Wa^T. dW / dt are caller-zeroed fp32, atomically accumulated.
- * bn_prev == NULL (with raw_out): the layer input is a_prev itself (no BatchNorm / activation). */
+ * bn_prev == NULL (with raw_out): the layer input is a_prev itself (no BatchNorm / activation).
+ * first_grad (nullable; DVA_BF16 storage, prev_is_xmap, !raw_out, dt NULL): caller-zeroed fp32[520] =
+ * P[32][8] | Q[32][8] | SX[8] with P = sum_v dz_prev x^T, Q = sum_v a_prev_hat x^T, SX = sum_v x, from
+ * which the first layer's weight gradient follows without another pass (BN-backward is linear in the
+ * statistics): dWa[n][f] = gamma invstd (P - (S1/M)[n] SX[f] - (S2/M)[n] Q)[n][f].  `out` is then not
+ * written (may be NULL) and dva_deepset_bwd_first is not needed. */
 int dva_deepset_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
                           const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
                           void* out, float* dW, double* st_prev, float* dt,
-                          const int32_t* group_of_row, int64_t V, int32_t prev_is_xmap,
-                          int32_t raw_out, int32_t algo, int32_t act_dtype, void* stream);
+                          const int32_t* group_of_row, float* first_grad, int64_t V,
+                          int32_t prev_is_xmap, int32_t raw_out, int32_t algo, int32_t act_dtype,
+                          void* stream);
 /* dz2 = (dcat + [arg[p]==v] dpooled[p]) * leaky'(BN2(a2)): joins the max-pool path (segment max
  * backward routes to the arg row only) with the direct path; S1/S2 of BN2 in st. */
 int dva_deepset_bwd_max(const void* dcat, const void* a2, const float* bn2, const int32_t* arg,
