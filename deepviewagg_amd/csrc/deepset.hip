@@ -157,30 +157,105 @@ __global__ __launch_bounds__(256) void dsf_fwd_first_kernel(const float* __restr
   flush_channel_sums<2>(st, stats, s_red, lane);
 }
 
-// pooled[p, c] = max over the point's views of leaky(BN(a[v, c])) (first row on ties), arg = that row
+// pooled[p, c] = max over the point's views of leaky(BN(a[v, c])) (first row on ties), arg = that row.
+// One half-wave per point: every lane reads 16 bytes (VEC channels) of a row, 32/LPR rows are in flight
+// per half-wave and four row loads per lane are issued before the first is used; the row slots are then
+// merged with xor-shuffles (value, row) -- larger value wins, smaller row on ties.
+template <typename AT>
+struct SegVec;
+template <>
+struct SegVec<float> {
+  static constexpr int VEC = 4;
+  typedef float4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+};
+template <>
+struct SegVec<bf16_t> {
+  static constexpr int VEC = 8;
+  typedef uint4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = __uint_as_float(w[e] << 16);
+      f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+  }
+};
+
 template <typename AT>
 __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ a,
                                                           const float* __restrict__ bn,
                                                           const int64_t* __restrict__ ptr,
                                                           float* __restrict__ pooled,
                                                           int32_t* __restrict__ arg, int64_t N) {
-  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
-  const BNc b = load_bn(bn, n);
+  constexpr int VEC = SegVec<AT>::VEC, LPR = D / VEC, SLOTS = 32 / LPR, U = 4;
+  typedef typename SegVec<AT>::raw raw_t;
+  const int lane = threadIdx.x & 63, hl = lane & 31, h = lane >> 5;
+  const int cl = hl % LPR, slot = hl / LPR, c0 = cl * VEC;
+  BNc b[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) b[k] = load_bn(bn, c0 + k);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t p = wave * 2 + h; p < N; p += n_waves * 2) {
-    const int64_t beg = ptr[p], end = ptr[p + 1];
-    float m = 0.f;
-    int64_t am = -1;
-    for (int64_t r = beg; r < end; ++r) {
-      const float v = leaky(bn_z(Elt<AT>::ld(a, r * D + n), b));
-      if (r == beg || v > m) {
-        m = v;
-        am = r;
+  for (int64_t p2 = wave * 2; p2 < N; p2 += n_waves * 2) {
+    const int64_t p = p2 + h;
+    const bool valid = p < N;
+    const int64_t beg = valid ? ptr[p] : 0;
+    const int64_t end = valid ? ptr[p + 1] : 0;
+    float m[VEC];
+    int64_t am[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      m[k] = -INFINITY;
+      am[k] = -1;
+    }
+    // both half-waves iterate together (shuffles below need every lane)
+    const int64_t n_max = max(end - beg, __shfl_xor(end - beg, 32));
+    for (int64_t i0 = 0; i0 < n_max; i0 += SLOTS * U) {
+      raw_t raw[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = beg + i0 + u * SLOTS + slot;
+        ok[u] = r < end;
+        raw[u] = *reinterpret_cast<const raw_t*>(a + (ok[u] ? r : (end > beg ? beg : 0)) * D + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[VEC];
+        SegVec<AT>::unpack(raw[u], f);
+        const int64_t r = beg + i0 + u * SLOTS + slot;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float v = leaky(bn_z(f[k], b[k]));
+          if (ok[u] && v > m[k]) {   // rows ascend within a lane: strict > keeps the first row on ties
+            m[k] = v;
+            am[k] = r;
+          }
+        }
       }
     }
-    pooled[p * D + n] = m;
-    arg[p * D + n] = (int32_t)am;
+    // merge the row slots: lanes hl, hl ^ off hold the same channels for different rows
+#pragma unroll
+    for (int off = LPR; off < 32; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const float ov = __shfl_xor(m[k], off);
+        const int64_t oa = __shfl_xor(am[k], off);
+        if (oa >= 0 && (am[k] < 0 || ov > m[k] || (ov == m[k] && oa < am[k]))) {
+          m[k] = ov;
+          am[k] = oa;
+        }
+      }
+    }
+    if (valid && slot == 0) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        pooled[p * D + c0 + k] = am[k] >= 0 ? m[k] : 0.f;
+        arg[p * D + c0 + k] = (int32_t)am[k];
+      }
+    }
   }
 }
 

@@ -849,23 +849,43 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
     }
     // ---------------- dt[p][n] += da[v][n]: run-length sum over the tile's rows, lane = channel
     if (HAS_DT) {
-      // point id of row (2s + h) lives in lane (2s + h) of either half: fetch with a shuffle
-      int32_t cur_p = -1;
-      float cur_s = 0.f;
+      const int64_t left = V - row0;
+      const int nvalid = left < 32 ? (int)left : 32;
+      const int32_t p_first = __shfl(pnt, 0), p_last = __shfl(pnt, nvalid - 1);
+      if (BF && p_first == p_last) {
+        // all the tile's views belong to one point (rows are sorted by point; the usual case with tens
+        // of views per point): column sums of the transposed tile.  Lane (c = j, h) owns the 16 views
+        // 8h..8h+7, 16+8h..16+8h+7 (rows beyond V hold zeros).
+        const bf16_t* ta = reinterpret_cast<const bf16_t*>(tda);
+        float sum = 0.f;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int row = 2 * s + h;
-        const int32_t p = __shfl(pnt, row);
-        if (row0 + row < V) {
-          if (p != cur_p) {
-            if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
-            cur_p = p;
-            cur_s = 0.f;
-          }
-          cur_s += BF ? bf2f(reinterpret_cast<const bf16_t*>(tda)[j * TSB + row]) : tda[row * TS + j];
+        for (int m = 0; m < 2; ++m) {
+          const uint4 q = *reinterpret_cast<const uint4*>(ta + j * TSB + 16 * m + 8 * h);
+          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
         }
+        sum += __shfl_xor(sum, 32);
+        if (h == 0) atomicAdd(&dt[(int64_t)p_first * DM + j], sum);
+      } else {
+        // point id of row (2s + h) lives in lane (2s + h) of either half: fetch with a shuffle
+        int32_t cur_p = -1;
+        float cur_s = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int row = 2 * s + h;
+          const int32_t p = __shfl(pnt, row);
+          if (row0 + row < V) {
+            if (p != cur_p) {
+              if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
+              cur_p = p;
+              cur_s = 0.f;
+            }
+            cur_s += BF ? bf2f(reinterpret_cast<const bf16_t*>(tda)[j * TSB + row]) : tda[row * TS + j];
+          }
+        }
+        if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
       }
-      if (cur_p >= 0) atomicAdd(&dt[(int64_t)cur_p * DM + j], cur_s);
     }
     // ---------------- the tile's only stores, last: nothing in this iteration waits for them
     if (!FUSE1) tile_store_acc<AT>(RowTile(out, row0, V, RB), j, h, accx);
