@@ -90,11 +90,11 @@ SIGNATURES = {
                                        _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "dva_view_gather_attention_bwd": (ctypes.c_int,
                                       [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+                                       _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dva_row_plan_workspace_bytes": (ctypes.c_int64, [_i64, _i64]),
     "dva_row_plan": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "dva_view_gather_rows_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32,
-                                                 _i32, _vp]),
+    "dva_view_gather_rows_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64,
+                                                 _i32, _i32, _i32, _vp]),
     "dva_csr_expand": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "dva_deepset_fwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),

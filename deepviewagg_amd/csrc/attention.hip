@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     float* __restrict__ grows, const float* __restrict__ compat,
     const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
     const int64_t* __restrict__ ptr, const float* __restrict__ gw, T* __restrict__ gval,
-    float* __restrict__ gcompat, float* __restrict__ gwb, int64_t N, int C, int G, int scaling,
-    TeamGeom tg) {
+    float* __restrict__ gcompat, float* __restrict__ gwb, float* __restrict__ rec, int rs, int64_t N,
+    int C, int G, int scaling, TeamGeom tg) {
   constexpr int VEC = Vec16<T>::N;
   typedef typename Vec16<T>::raw raw_t;
   __shared__ float s_wb[64];  // [2*G], G <= 32
@@ -402,6 +402,12 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
         float gc = a * (gt * d - tt) / dn;
         if (r == am) gc += g_mx;
         gcompat[r * G + g_lane] = gc;
+        if (rec) {
+          // view record for dva_view_gather_rows_grad: point id | gate * attention per group, one
+          // 32-byte sector per view instead of three scattered reads (view_point, att, gate)
+          rec[r * rs + 1 + g_lane] = a * gt;
+          if (g_lane == 0) rec[r * rs] = __int_as_float((int)p);
+        }
       }
       if (!row_idx) {
         float f[VEC];
@@ -503,17 +509,18 @@ template <typename T>
 static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, float* grows,
                     const float* compat, const float* att,
                     const float* gate, const int32_t* amax, const int64_t* ptr, const float* gw,
-                    void* gval, float* gcompat, float* gwb, int64_t N, int64_t V_hint, int C, int G,
-                    int scaling, int algo, hipStream_t s) {
+                    void* gval, float* gcompat, float* gwb, float* rec, int rs, int64_t N, int64_t V_hint,
+                    int C, int G, int scaling, int algo, hipStream_t s) {
   TeamGeom tg;
   const bool team_ok = team_geometry<T>(C, G, N, V_hint, &tg);
   if (algo == 2 && !team_ok) return DVA_ERR_UNSUPPORTED;
+  if (rec && !(algo != 1 && team_ok)) return DVA_ERR_UNSUPPORTED;  // records come from the team kernel
   if (algo != 1 && team_ok) {
     const int tpb = 256 / tg.ts;
     const int grid = grid_cap((N + tpb - 1) / tpb);
     hipLaunchKernelGGL((att_bwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)gout,
                        (const T*)val, row_idx, grows, compat, att, gw ? gate : nullptr, amax, ptr, gw,
-                       (T*)gval, gcompat, gwb, N, C, G, scaling, tg);
+                       (T*)gval, gcompat, gwb, rec, rs, N, C, G, scaling, tg);
     return DVA_OK;
   }
   hipLaunchKernelGGL((att_bwd_scores_kernel<T>), dim3(grid_cap((N * G + 255) / 256)), dim3(256),
@@ -536,8 +543,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void rows_grad_team_kernel(
     const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
     const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
-    const int32_t* __restrict__ row_ptr, float* __restrict__ grows, int64_t R, int C, int G, int lpr,
-    int lpg) {
+    const int32_t* __restrict__ row_ptr, const float* __restrict__ rec, int rs,
+    float* __restrict__ grows, int64_t R, int C, int G, int lpr, int lpg) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int U = 4;
   typedef typename Vec16<T>::raw raw_t;
@@ -565,14 +572,26 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
         ok[u] = i < end;
         v[u] = perm[ok[u] ? i : beg];
       }
+      if (rec) {
+        // one 32-byte record per view: point id | gate * attention per group
 #pragma unroll
-      for (int u = 0; u < U; ++u) p[u] = vp[v[u]];
+        for (int u = 0; u < U; ++u) {
+          const float* rv = rec + (int64_t)v[u] * rs;
+          p[u] = __float_as_int(rv[0]);
+          sc[u] = ok[u] ? rv[1 + g_lane] : 0.f;
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)p[u] * C + col);
-        const float a = att[(int64_t)v[u] * G + g_lane];
-        const float gt = gate ? gate[(int64_t)p[u] * G + g_lane] : 1.f;
-        sc[u] = ok[u] ? a * gt : 0.f;
+        for (int u = 0; u < U; ++u) raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)p[u] * C + col);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = vp[v[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)p[u] * C + col);
+          const float a = att[(int64_t)v[u] * G + g_lane];
+          const float gt = gate ? gate[(int64_t)p[u] * G + g_lane] : 1.f;
+          sc[u] = ok[u] ? a * gt : 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -600,7 +619,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void rows_grad_generic_kernel(
     const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
     const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
-    const int32_t* __restrict__ row_ptr, float* __restrict__ grows, int64_t R, int C, int G) {
+    const int32_t* __restrict__ row_ptr, const float* __restrict__ rec, int rs,
+    float* __restrict__ grows, int64_t R, int C, int G) {
   const int64_t total = R * (int64_t)C;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -609,8 +629,9 @@ __global__ __launch_bounds__(256) void rows_grad_generic_kernel(
     const int g = group_of_channel(c, C, G);
     float acc = 0.f;
     for (int i = row_ptr[r]; i < row_ptr[r + 1]; ++i) {
-      const int64_t v = perm[i], p = vp[v];
-      const float s = att[v * G + g] * (gate ? gate[p * G + g] : 1.f);
+      const int64_t v = perm[i];
+      const int64_t p = rec ? (int64_t)__float_as_int(rec[v * rs]) : (int64_t)vp[v];
+      const float s = rec ? rec[v * rs + 1 + g] : att[v * G + g] * (gate ? gate[p * G + g] : 1.f);
       acc = fmaf(Elt<T>::ld(gout, p * C + c), s, acc);
     }
     grows[t] = acc;
@@ -619,18 +640,18 @@ __global__ __launch_bounds__(256) void rows_grad_generic_kernel(
 
 template <typename T>
 static int rows_grad_impl(const void* gout, const float* att, const float* gate, const int32_t* vp,
-                          const int32_t* perm, const int32_t* row_ptr, float* grows, int64_t R, int C,
-                          int G, hipStream_t s) {
+                          const int32_t* perm, const int32_t* row_ptr, const float* rec, int rs,
+                          float* grows, int64_t R, int C, int G, hipStream_t s) {
   constexpr int VEC = Vec16<T>::N;
   const int lpr = C / VEC;
   const bool team_ok = (C % VEC) == 0 && is_pow2(lpr) && lpr <= 64 && is_pow2(G) && C % G == 0 &&
                        (C / G) % VEC == 0 && ((uintptr_t)gout % 16 == 0) && ((uintptr_t)grows % 16 == 0);
   if (team_ok) {
     hipLaunchKernelGGL((rows_grad_team_kernel<T>), dim3(grid_cap((R + 3) / 4)), dim3(256), 0, s,
-                       (const T*)gout, att, gate, vp, perm, row_ptr, grows, R, C, G, lpr, lpr / G);
+                       (const T*)gout, att, gate, vp, perm, row_ptr, rec, rs, grows, R, C, G, lpr, lpr / G);
   } else {
     hipLaunchKernelGGL((rows_grad_generic_kernel<T>), dim3(grid_cap((R * C + 255) / 256)), dim3(256),
-                       0, s, (const T*)gout, att, gate, vp, perm, row_ptr, grows, R, C, G);
+                       0, s, (const T*)gout, att, gate, vp, perm, row_ptr, rec, rs, grows, R, C, G);
   }
   return DVA_OK;
 }
@@ -669,10 +690,11 @@ static int attention_bwd_entry(const void* grad_out, const void* val, const int3
                                float* grad_rows, const float* compat, const float* att,
                                const float* gate, const int32_t* amax, const int64_t* ptr,
                                const float* gate_w, const float* gate_b, void* grad_val,
-                               float* grad_compat, float* grad_gate_wb, int64_t n_points,
-                               int64_t n_views, int32_t C, int32_t G, int32_t scaling, int32_t dtype,
-                               int32_t algo, void* stream) {
+                               float* grad_compat, float* grad_gate_wb, float* view_rec,
+                               int32_t rec_stride, int64_t n_points, int64_t n_views, int32_t C,
+                               int32_t G, int32_t scaling, int32_t dtype, int32_t algo, void* stream) {
   (void)gate_b;
+  if (view_rec && rec_stride < G + 1) return DVA_ERR_INVALID;
   if (n_points < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C || !ptr) return DVA_ERR_INVALID;
   if (!att || !gate || !amax || !grad_compat) return DVA_ERR_INVALID;
   if (!row_idx && !grad_val) return DVA_ERR_INVALID;
@@ -682,12 +704,12 @@ static int attention_bwd_entry(const void* grad_out, const void* val, const int3
   int rc;
   if (dtype == DVA_F32)
     rc = bwd_impl<float>(grad_out, val, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
-                         grad_val, grad_compat, grad_gate_wb, n_points, n_views, C, G, scaling, algo,
-                         (hipStream_t)stream);
+                         grad_val, grad_compat, grad_gate_wb, view_rec, rec_stride, n_points, n_views, C, G,
+                         scaling, algo, (hipStream_t)stream);
   else if (dtype == DVA_BF16)
     rc = bwd_impl<bf16_t>(grad_out, val, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
-                          grad_val, grad_compat, grad_gate_wb, n_points, n_views, C, G, scaling, algo,
-                          (hipStream_t)stream);
+                          grad_val, grad_compat, grad_gate_wb, view_rec, rec_stride, n_points, n_views, C, G,
+                          scaling, algo, (hipStream_t)stream);
   else
     return DVA_ERR_INVALID;
   if (rc) return rc;
@@ -711,8 +733,8 @@ int dva_view_attention_bwd(const void* grad_out, const void* val, const float* c
                            int64_t n_points, int64_t n_views, int32_t C, int32_t G, int32_t scaling,
                            int32_t dtype, int32_t algo, void* stream) {
   return attention_bwd_entry(grad_out, val, nullptr, nullptr, compat, att, gate, amax, ptr, gate_w,
-                             gate_b, grad_val, grad_compat, grad_gate_wb, n_points, n_views, C, G,
-                             scaling, dtype, algo, stream);
+                             gate_b, grad_val, grad_compat, grad_gate_wb, nullptr, 0, n_points, n_views, C,
+                             G, scaling, dtype, algo, stream);
 }
 
 int dva_view_gather_attention_fwd(const void* rows, const int32_t* row_idx, const float* compat,
@@ -730,31 +752,34 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
                                   const float* compat, const float* att, const float* gate,
                                   const int32_t* amax, const int64_t* ptr, const float* gate_w,
                                   const float* gate_b, float* grad_rows, float* grad_compat,
-                                  float* grad_gate_wb, int64_t n_points, int64_t n_views, int32_t C,
-                                  int32_t G, int32_t scaling, int32_t dtype, int32_t algo,
-                                  void* stream) {
+                                  float* grad_gate_wb, float* view_rec, int32_t rec_stride,
+                                  int64_t n_points, int64_t n_views, int32_t C, int32_t G,
+                                  int32_t scaling, int32_t dtype, int32_t algo, void* stream) {
   if (!row_idx && n_views > 0) return DVA_ERR_INVALID;
   return attention_bwd_entry(grad_out, rows, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
-                             gate_b, nullptr, grad_compat, grad_gate_wb, n_points, n_views, C, G,
-                             scaling, dtype, algo, stream);
+                             gate_b, nullptr, grad_compat, grad_gate_wb, view_rec, rec_stride, n_points,
+                             n_views, C, G, scaling, dtype, algo, stream);
 }
 
 int dva_view_gather_rows_grad(const void* grad_out, const float* att, const float* gate,
                               const int32_t* view_point, const int32_t* perm, const int32_t* row_ptr,
-                              float* grad_rows, int64_t n_rows, int64_t n_views, int32_t C, int32_t G,
-                              int32_t dtype, void* stream) {
+                              const float* view_rec, int32_t rec_stride, float* grad_rows,
+                              int64_t n_rows, int64_t n_views, int32_t C, int32_t G, int32_t dtype,
+                              void* stream) {
   if (n_rows < 0 || n_views < 0 || C <= 0 || G <= 0 || G > C) return DVA_ERR_INVALID;
   if (n_views > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
   if (n_rows == 0) return DVA_OK;
   if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
-  if (n_views > 0 && (!grad_out || !att || !view_point || !perm)) return DVA_ERR_INVALID;
+  if (view_rec && rec_stride < G + 1) return DVA_ERR_INVALID;
+  if (n_views > 0 && (!grad_out || !perm)) return DVA_ERR_INVALID;
+  if (n_views > 0 && !view_rec && (!att || !view_point)) return DVA_ERR_INVALID;
   int rc;
   if (dtype == DVA_F32)
-    rc = rows_grad_impl<float>(grad_out, att, gate, view_point, perm, row_ptr, grad_rows, n_rows, C, G,
-                               (hipStream_t)stream);
+    rc = rows_grad_impl<float>(grad_out, att, gate, view_point, perm, row_ptr, view_rec, rec_stride,
+                               grad_rows, n_rows, C, G, (hipStream_t)stream);
   else if (dtype == DVA_BF16)
-    rc = rows_grad_impl<bf16_t>(grad_out, att, gate, view_point, perm, row_ptr, grad_rows, n_rows, C, G,
-                                (hipStream_t)stream);
+    rc = rows_grad_impl<bf16_t>(grad_out, att, gate, view_point, perm, row_ptr, view_rec, rec_stride,
+                                grad_rows, n_rows, C, G, (hipStream_t)stream);
   else
     return DVA_ERR_INVALID;
   if (rc) return rc;

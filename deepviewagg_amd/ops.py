@@ -565,6 +565,17 @@ def gather_rows(rows, row_idx):
     return _GatherRows.apply(rows, row_idx)
 
 
+def _team_records_ok(C, G, dtype):
+    """Mirror of team_geometry() in csrc/attention.hip: the view records are produced by the wavefront-team
+    backward kernel only."""
+    vec = 4 if dtype == torch.float32 else 8
+    if C % vec:
+        return False
+    lpr = C // vec
+    pow2 = lambda x: x > 0 and (x & (x - 1)) == 0
+    return pow2(lpr) and lpr <= 64 and pow2(G) and G <= 32 and C % G == 0 and (C // G) % vec == 0
+
+
 class _ViewGatherAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, row_idx, compat, csr_idx, gate_w, gate_b, scaling, eps, plan):
@@ -613,24 +624,32 @@ class _ViewGatherAttention(torch.autograd.Function):
             grows = torch.zeros((R, C), dtype=torch.float32, device=rows.device)
         else:
             grows = None
+        # per-view records (point id | gate * attention per group) for the rows-gradient pass: one 32-byte
+        # sector per view instead of scattered reads of view_point, att and gate
+        rs = ((G + 1 + 7) // 8) * 8
+        rec = None
+        if use_plan and ATTENTION_ALGO != 1 and _team_records_ok(C, G, rows.dtype):
+            rec = torch.empty((V, rs), dtype=torch.float32, device=rows.device)
         with _timed("view_gather_attention_bwd",
-                    V * (C * es + 4 + 2 * G * 4 + (C * 4 * 2 if grows is not None else 0))
+                    V * (C * es + 4 + 2 * G * 4 + (C * 4 * 2 if grows is not None else 0)
+                         + (rs * 4 if rec is not None else 0))
                     + N * (C * es + 8 + 3 * G * 4)):
             check(lib.dva_view_gather_attention_bwd(
                 ptr(gout), ptr(rows), ptr(row_idx), ptr(compat), ptr(att), ptr(gate), ptr(amax),
                 ptr(csr_idx), ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(grows),
-                ptr(gcompat), ptr(gwb), N, V, C, G, scaling, dtype_code(rows), ATTENTION_ALGO,
+                ptr(gcompat), ptr(gwb), ptr(rec), rs, N, V, C, G, scaling, dtype_code(rows), ATTENTION_ALGO,
                 stream_of(rows)), "dva_view_gather_attention_bwd")
         if use_plan:
             plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
             perm, row_ptr = plan
-            vp = csr_expand(csr_idx, V)
+            vp = csr_expand(csr_idx, V) if rec is None else None
             grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
-            # per view: perm + view_point + grad_out row + att/gate scores; per row: fp32 row written
-            with _timed("view_gather_rows_grad", V * (8 + C * es + 2 * G * 4) + R * (C * 4 + 4)):
+            # per view: perm + record (or view_point + scores) + grad_out row; per row: fp32 row written
+            with _timed("view_gather_rows_grad", V * (4 + (rs * 4 if rec is not None else 4 + 2 * G * 4) + C * es)
+                        + R * (C * 4 + 4)):
                 check(lib.dva_view_gather_rows_grad(
                     ptr(gout), ptr(att), ptr(gate) if has_gate else None, ptr(vp), ptr(perm), ptr(row_ptr),
-                    ptr(grows), R, V, C, G, dtype_code(rows), stream_of(rows)),
+                    ptr(rec), rs, ptr(grows), R, V, C, G, dtype_code(rows), stream_of(rows)),
                     "dva_view_gather_rows_grad")
         g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
         g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None

@@ -156,7 +156,10 @@ int dva_view_attention_bwd(const void* grad_out, const void* val, const float* c
  * Replaces image.py:1285 + pooling.py:284-300 in one pass: no [V, C] tensor is materialised.
  * Backward: grad_rows fp32 [R, C] non-NULL = scatter-add with atomics (caller-zeroed);
  * grad_rows NULL = only grad_compat / grad_gate_wb are produced and the caller obtains the rows
- * gradient from dva_view_gather_rows_grad (segmented reduction, deterministic, faster). */
+ * gradient from dva_view_gather_rows_grad (segmented reduction, deterministic, faster).
+ * view_rec (nullable, fp32 [n_views, rec_stride], rec_stride >= G + 1, a multiple of 8 keeps one record
+ * per 32-byte sector): per view, word 0 = point id (int32 bits), words 1..G = gate * attention per
+ * group -- everything dva_view_gather_rows_grad needs about a view in one place. */
 int dva_view_gather_attention_fwd(const void* rows, const int32_t* row_idx, const float* compat,
                                   const int64_t* ptr, const float* gate_w, const float* gate_b,
                                   void* out, float* att, float* gate, int32_t* amax,
@@ -167,9 +170,9 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
                                   const float* compat, const float* att, const float* gate,
                                   const int32_t* amax, const int64_t* ptr, const float* gate_w,
                                   const float* gate_b, float* grad_rows, float* grad_compat,
-                                  float* grad_gate_wb, int64_t n_points, int64_t n_views, int32_t C,
-                                  int32_t G, int32_t scaling, int32_t dtype, int32_t algo,
-                                  void* stream);
+                                  float* grad_gate_wb, float* view_rec, int32_t rec_stride,
+                                  int64_t n_points, int64_t n_views, int32_t C, int32_t G,
+                                  int32_t scaling, int32_t dtype, int32_t algo, void* stream);
 
 /* Transposed view of a row index (views grouped by the feature-map row they read): the backward of
  * the gather in image.py:1285 (index_select -> index_add) as a CSR over rows.
@@ -183,11 +186,13 @@ int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_
 
 /* grad_rows[r, c] = sum over the views v of row r of grad_out[p(v), c] * gate[p(v), g(c)] *
  * att[v, g(c)]  (written, not accumulated; fp32 [n_rows, C]).  view_point int32 [n_views] = point of
- * every view (dva_csr_expand); gate nullable (no gating); grad_out [n_points, C] in dtype. */
+ * every view (dva_csr_expand); gate nullable (no gating); grad_out [n_points, C] in dtype.
+ * With view_rec (from dva_view_gather_attention_bwd) att / gate / view_point are not read. */
 int dva_view_gather_rows_grad(const void* grad_out, const float* att, const float* gate,
                               const int32_t* view_point, const int32_t* perm, const int32_t* row_ptr,
-                              float* grad_rows, int64_t n_rows, int64_t n_views, int32_t C, int32_t G,
-                              int32_t dtype, void* stream);
+                              const float* view_rec, int32_t rec_stride, float* grad_rows,
+                              int64_t n_rows, int64_t n_views, int32_t C, int32_t G, int32_t dtype,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Fused DeepSetFeat (+ score Linear) chain over the V views, exact fp32, forward and backward.
