@@ -74,6 +74,37 @@ def build_modules(C, device):
     return BimodalCSRPool(mode='max'), view_pool, BimodalFusion(mode='concatenation')
 
 
+# HIP-event timer name -> kernel symbol in the rocprofv3 outputs (bf16 headline workload)
+KERNEL_SYMBOL = {
+    "view_gather_attention_fwd": "att_fwd_team_kernel<unsigned short>",
+    "view_gather_attention_bwd": "att_bwd_team_kernel<unsigned short>",
+    "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short>",
+    "deepset_fwd_first": "dsm_fwd_first_kernel<unsigned short, false>",
+    "deepset_fwd_layer": "dsm_fwd_layer_kernel<unsigned short, false, false>",
+    "deepset_fwd_layer_add": "dsm_fwd_layer_kernel<unsigned short, true, false>",
+    "deepset_fwd_score": "dsm_fwd_layer_kernel<unsigned short, false, true>",
+    "deepset_segmax": "dsf_segmax_kernel<unsigned short>",
+    "deepset_bwd_score": "dsm_bwd_score_kernel<unsigned short>",
+    "deepset_bwd_layer": "dsm_bwd_layer_kernel<unsigned short, false, false, false, false>",
+    "deepset_bwd_layer_cat": "dsm_bwd_layer_kernel<unsigned short, false, true, true, false>",
+    "deepset_bwd_layer_xmap_first": "dsm_bwd_layer_kernel<unsigned short, true, false, false, true>",
+    "deepset_bwd_max": "dsm_bwd_max_kernel<unsigned short>",
+}
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
+
+
+def pmc_traffic(timer_name, default_workload):
+    """HBM bytes per launch of the kernel from the committed rocprofv3 PMC passes of this same command
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes;
+    tools/gpu_evidence.sh + profiles/summarize_pmc.py).  Counters cannot be read from inside the process,
+    so this is only reported for the default workload the passes were taken on; None otherwise."""
+    if not default_workload or timer_name not in KERNEL_SYMBOL or not os.path.exists(PMC_TRAFFIC_FILE):
+        return None
+    table = json.load(open(PMC_TRAFFIC_FILE))
+    entry = table.get(KERNEL_SYMBOL[timer_name])
+    return None if entry is None else entry["hbm_bytes"]
+
+
 def step(scene, packed, mods, dtype, lazy=True):
     """One fused forward + backward of the hot path. Returns the scalar loss (device)."""
     from deepviewagg_amd import ops
@@ -226,6 +257,8 @@ def main():
         avg_ms = k["ms"] / k["launches"]
         achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
         gk = kern.get("gather_nearest_fwd")
+        default_workload = (args.log2_points == 20 and args.dtype == "bf16")
+        traffic = pmc_traffic(name, default_workload)
         res = {
             "metric": "points/sec fused fwd+bwd (1M pts, 32 views)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,7 +270,10 @@ def main():
                                    f"one scene per GPU",
                        "points_per_gpu": N, "views_per_point": views, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         "profiles/pmc_traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                         "command, bytes per launch, FETCH_SIZE x2 (gfx950 correction)",
                          "avg_launch_ms": avg_ms, "launches": k["launches"],
                          "algorithmic_bytes_per_launch": k["bytes"] / k["launches"]},
             "kernels": {n: {"avg_ms": v["ms"] / v["launches"], "launches": v["launches"],

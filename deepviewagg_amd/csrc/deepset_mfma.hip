@@ -143,7 +143,7 @@ __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restr
 #define DVA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // bf16 matrix cores for the bf16-storage instantiations.  v_mfma_f32_32x32x16_bf16 does 8x the work of the
-// fp32 instruction in half the cycles; rocprofv3 (profiles/r01d_sq_counters.txt) showed the fp32 chain as
+// fp32 instruction in half the cycles; rocprofv3 (profiles/r01c_sq_counters_fp32_mfma.txt) showed the fp32 chain as
 // the limiter once the traffic was halved: 55-68 % of the wave cycles were MFMA issue stalls.  fp32
 // accuracy is kept with the split  x = hi + lo  (hi = bf16(x), lo = bf16(x - hi)) and three products
 // hi*hi + lo*hi + hi*lo (the dropped lo*lo term is < 2^-16 relative).  Lane l supplies the 8 k-slots
