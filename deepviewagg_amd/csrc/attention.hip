@@ -244,6 +244,84 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
   for (int64_t p = team0; p < N; p += team_stride) {
     const int64_t beg = ptr[p], end = ptr[p + 1];
     const int n = (int)(end - beg);
+    if (n > 0 && n <= 4 * tg.rows) {
+      // ---- short segments (the common case): every load of the point -- row indices, scores, value rows
+      //      -- is issued before the first use (3 dependent latencies per point instead of ~6), and each
+      //      lane derives the softmax statistics of ITS channel group from the scores it needs anyway
+      constexpr int U = 4;
+      const int64_t col = (int64_t)lane_r * VEC;
+      bool ok[U];
+      int64_t rr[U], ri[U];
+      float cg[U];
+      raw_t x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int v = row_slot + u * tg.rows;
+        ok[u] = v < n;
+        rr[u] = beg + (ok[u] ? v : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ri[u] = row_idx ? (int64_t)row_idx[rr[u]] : rr[u];
+        cg[u] = compat[rr[u] * G + g_lane];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
+      float m = -INFINITY;
+      int am = 0x7fffffff;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u] && cg[u] > m) {     // views ascend with u inside a lane: strict > keeps the first
+          m = cg[u];
+          am = row_slot + u * tg.rows;
+        }
+      }
+      for (int off = tg.lpr; off < tg.ts; off <<= 1) {
+        const float m2 = __shfl_xor(m, off);
+        const int a2 = __shfl_xor(am, off);
+        if (m2 > m || (m2 == m && a2 < am)) {
+          m = m2;
+          am = a2;
+        }
+      }
+      const float dn = scaling ? sqrtf((float)n) : 1.f;
+      float e[U], s = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        e[u] = ok[u] ? expf((cg[u] - m) / dn) : 0.f;
+        s += e[u];
+      }
+      for (int off = tg.lpr; off < tg.ts; off <<= 1) s += __shfl_xor(s, off);
+      s += eps;
+      float gt = 1.f;
+      if (gw) gt = tanhf(fmaxf(gw[g_lane] * m + gb[g_lane], 0.f));
+      if (row_slot == 0 && g_first) {
+        if (gate) gate[p * G + g_lane] = gt;
+        if (amax) amax[p * G + g_lane] = (int32_t)(beg + am);
+      }
+      float acc[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float a = e[u] / s;
+        if (ok[u] && g_first) att[rr[u] * G + g_lane] = a;
+        float f[VEC];
+        Vec16<T>::unpack(x[u], f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
+      }
+      for (int off = tg.lpr; off < tg.ts; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+      }
+      if (row_slot == 0) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] *= gt;
+        *reinterpret_cast<raw_t*>(out + p * C + col) = Vec16<T>::pack(acc);
+      }
+      continue;
+    }
     // ---- per-group max (+ first arg) over the point's views
     float m = -INFINITY;
     int am = 0x7fffffff;
@@ -356,19 +434,57 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
 
     // ---- pass 1: d[v,g] = sum_{c in g} go[c]*val[v,c];  sum_ad[g] = sum_v att[v,g]*d[v,g]
     float sum_ad = 0.f;
-#pragma unroll 2
-    for (int v = row_slot; v < n; v += tg.rows) {
-      const int64_t r = beg + v;
-      const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;
-      float f[VEC];
-      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + vr * C + col), f);
-      float d = 0.f;
+    // short segments (the common case): row indices, value rows and attentions of the whole point are
+    // loaded before the first use and d stays in registers (no round trip through grad_compat)
+    constexpr int U = 4;
+    const bool small = n <= U * tg.rows;
+    float dreg[U], areg[U];
+    bool okr[U];
+    if (small) {
+      int64_t rr[U], ri[U];
+      raw_t x[U];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
-      for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
-      if (g_first) {
-        gcompat[r * G + g_lane] = d;
-        sum_ad += att[r * G + g_lane] * d;
+      for (int u = 0; u < U; ++u) {
+        const int v = row_slot + u * tg.rows;
+        okr[u] = v < n;
+        rr[u] = beg + (okr[u] ? v : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ri[u] = (row_idx && n > 0) ? (int64_t)row_idx[rr[u]] : rr[u];
+        areg[u] = n > 0 ? att[rr[u] * G + g_lane] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (n > 0) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
+        else x[u] = raw_t();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[VEC];
+        Vec16<T>::unpack(x[u], f);
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
+        for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
+        dreg[u] = d;
+        if (g_first && okr[u]) sum_ad += areg[u] * d;
+      }
+    } else {
+#pragma unroll 2
+      for (int v = row_slot; v < n; v += tg.rows) {
+        const int64_t r = beg + v;
+        const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;
+        float f[VEC];
+        Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + vr * C + col), f);
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
+        for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
+        if (g_first) {
+          gcompat[r * G + g_lane] = d;
+          sum_ad += att[r * G + g_lane] * d;
+        }
       }
     }
     // lanes of one column position in the R row slots hold partials of the same group
@@ -393,12 +509,8 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     // ---- pass 2a: grad_compat (and grad_val when it is a dense [V, C] tensor)
 #pragma unroll
     for (int k = 0; k < VEC; ++k) go[k] *= gt;
-#pragma unroll 2
-    for (int v = row_slot; v < n; v += tg.rows) {
-      const int64_t r = beg + v;
-      const float a = att[r * G + g_lane];
+    auto emit = [&](int64_t r, float a, float d) {
       if (g_first) {
-        const float d = gcompat[r * G + g_lane];
         float gc = a * (gt * d - tt) / dn;
         if (r == am) gc += g_mx;
         gcompat[r * G + g_lane] = gc;
@@ -414,6 +526,17 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
 #pragma unroll
         for (int k = 0; k < VEC; ++k) f[k] = go[k] * a;
         *reinterpret_cast<raw_t*>(gval + r * C + col) = Vec16<T>::pack(f);
+      }
+    };
+    if (small) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (okr[u]) emit(beg + row_slot + u * tg.rows, areg[u], dreg[u]);
+    } else {
+#pragma unroll 2
+      for (int v = row_slot; v < n; v += tg.rows) {
+        const int64_t r = beg + v;
+        emit(r, att[r * G + g_lane], g_first ? gcompat[r * G + g_lane] : 0.f);
       }
     }
 
