@@ -194,3 +194,70 @@ int dva_rowbn_bwd_apply(const void* grad_out, const void* y, const int32_t* coun
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping between two passes of the DeepSet / rowbn kernels, one launch instead of ~18
+// tiny library kernels: batch statistics -> constants table, running statistics update
+// (nn.BatchNorm1d semantics: biased variance for the normalisation, unbiased for running_var).
+// ------------------------------------------------------------------------------------------------
+namespace dva {
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double m, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float momentum, float eps, int training, int C,
+                                   float* __restrict__ bn) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mean, var;
+    if (training) {
+      const double mu = sums[c] / m;
+      double v = sums[C + c] / m - mu * mu;
+      if (v < 0.0) v = 0.0;
+      mean = (float)mu;
+      var = (float)v;
+      if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(v * (m / (m > 1.0 ? m - 1.0 : 1.0)));
+      }
+    } else {
+      mean = rmean[c];
+      var = rvar[c];
+    }
+    bn[c] = mean;
+    bn[C + c] = rsqrtf(var + eps);
+    bn[2 * C + c] = gamma ? gamma[c] : 1.f;
+    bn[3 * C + c] = beta ? beta[c] : 0.f;
+  }
+  if (training && nbt && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void scale_f64_kernel(const double* __restrict__ in, double scale, float* __restrict__ out, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (float)(in[i] * scale);
+}
+
+}  // namespace dva
+
+extern "C" {
+
+int dva_bn_finalize(const double* sums, double m, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, const float* gamma, const float* beta, float momentum,
+                    float eps, int32_t training, int32_t C, float* bn, void* stream) {
+  if (C <= 0 || !bn) return DVA_ERR_INVALID;
+  if (training ? (!sums || m <= 0.0) : (!running_mean || !running_var)) return DVA_ERR_INVALID;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(dva::bn_finalize_kernel, dim3(1), dim3(C < 256 ? 64 * ((C + 63) / 64) : 256), 0,
+                     (hipStream_t)stream, sums, m, running_mean, running_var, num_batches_tracked, gamma,
+                     beta, momentum, eps, training, C, bn);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!in || !out))) return DVA_ERR_INVALID;
+  if (n == 0) return DVA_OK;
+  hipLaunchKernelGGL(dva::scale_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, scale, out, n);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

@@ -28,7 +28,7 @@ ACT_DTYPE = None
 def _act_dtype():
     if ACT_DTYPE is not None:
         return ACT_DTYPE
-    if ALGO == 0 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+    if ALGO == 0 and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
         return torch.bfloat16
     return torch.float32
 
@@ -61,20 +61,14 @@ def applicable(e_map, linear, x_map):
 
 def _bn_consts(stats, m, bn, training):
     """[4, 32] fp32 = mean | invstd | gamma | beta from batch statistics (training) or running stats;
-    updates the running statistics in training (nn.BatchNorm1d semantics)."""
-    if training:
-        mean = stats[:D] / m
-        var = (stats[D:] / m - mean * mean).clamp_(min=0.0)
-        with torch.no_grad():
-            mom = bn.momentum
-            bn.running_mean.mul_(1 - mom).add_(mom * mean.float())
-            bn.running_var.mul_(1 - mom).add_(mom * (var * (m / max(m - 1, 1))).float())
-            bn.num_batches_tracked += 1
-        mean, var = mean.float(), var.float()
-    else:
-        mean, var = bn.running_mean.float(), bn.running_var.float()
-    invstd = torch.rsqrt(var + bn.eps)
-    return torch.stack([mean, invstd, bn.weight.detach().float(), bn.bias.detach().float()]).contiguous()
+    updates the running statistics in training (nn.BatchNorm1d semantics).  One kernel launch."""
+    lib = _lib.load()
+    out = torch.empty((4, D), dtype=torch.float32, device=stats.device)
+    check(lib.dva_bn_finalize(ptr(stats), float(max(m, 1)), ptr(bn.running_mean), ptr(bn.running_var),
+                              ptr(bn.num_batches_tracked), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                              float(bn.momentum), float(bn.eps), 1 if training else 0, D, ptr(out),
+                              stream_of(stats)), "dva_bn_finalize")
+    return out
 
 
 class _DeepSetLinear(torch.autograd.Function):
@@ -101,8 +95,10 @@ class _DeepSetLinear(torch.autograd.Function):
         bns = [_bn_of(e_map.mlp_elt_1[0]), _bn_of(e_map.mlp_elt_1[1]),
                _bn_of(e_map.mlp_elt_2[0]), _bn_of(e_map.mlp_elt_2[1])]
 
+        zpool = iter(torch.zeros((8, 2 * D), dtype=torch.float64, device=dev))
+
         def zstats():
-            return torch.zeros(2 * D, dtype=torch.float64, device=dev)
+            return next(zpool)
 
         # ---- elt MLP 1: x_map -> a1 -> a2
         s1 = zstats()
@@ -192,14 +188,18 @@ class _DeepSetLinear(torch.autograd.Function):
         AC, F32C = (_lib.DVA_BF16 if act == torch.bfloat16 else _lib.DVA_F32), _lib.DVA_F32
         RB = D * (2 if act == torch.bfloat16 else 4)
 
+        zpool = iter(torch.zeros((8, 2 * D), dtype=torch.float64, device=dev))
+
         def zstats():
-            return torch.zeros(2 * D, dtype=torch.float64, device=dev)
+            return next(zpool)
 
         def sm_of(stats, rows=m):
             # S1/M | S2/M of the batch-statistics BN backward; zero with running statistics (eval)
             if not ctx.training:
                 return torch.zeros(2 * D, dtype=torch.float32, device=dev)
-            return (stats / rows).float().contiguous()
+            out = torch.empty(2 * D, dtype=torch.float32, device=dev)
+            check(lib.dva_scale_f64(ptr(stats), 1.0 / rows, ptr(out), 2 * D, st), "dva_scale_f64")
+            return out
 
         def buf(rows=V, dtype=None):
             return torch.empty((rows, D), dtype=act if dtype is None else dtype, device=dev)

@@ -591,7 +591,7 @@ class _ViewGatherAttention(torch.autograd.Function):
             gw = gw if gw is not None else torch.ones(G, device=rows.device)
             gb = gb if gb is not None else torch.zeros(G, device=rows.device)
         out = torch.empty((N, C), dtype=rows.dtype, device=rows.device)
-        att = torch.zeros((V, G), dtype=torch.float32, device=rows.device)
+        att = torch.empty((V, G), dtype=torch.float32, device=rows.device)   # every view belongs to a point
         gate = torch.empty((N, G), dtype=torch.float32, device=rows.device)
         amax = torch.empty((N, G), dtype=torch.int32, device=rows.device)
         es = rows.element_size()
@@ -615,7 +615,7 @@ class _ViewGatherAttention(torch.autograd.Function):
         scaling, has_gate, w_shape, b_shape = ctx.meta
         gout = gout.contiguous()
         N, V, (R, C), G = csr_idx.shape[0] - 1, row_idx.shape[0], rows.shape, compat.shape[1]
-        gcompat = torch.zeros_like(compat)
+        gcompat = torch.empty_like(compat)             # every view is written (it belongs to a point)
         gwb = torch.zeros(2 * G, dtype=torch.float32, device=rows.device) if has_gate else None
         es = rows.element_size()
         need_rows = ctx.needs_input_grad[0]

@@ -282,6 +282,17 @@ int dva_rowbn_bwd_apply(const void* grad_out, const void* y, const int32_t* coun
                         const float* sm, void* grad_y, int64_t R, int32_t C, float slope, int32_t dtype,
                         void* stream);
 
+/* BatchNorm1d bookkeeping between two passes (one launch): sums = double[2*C] (sum | sum of squares over m
+ * rows) -> bn = fp32 [4][C] = mean | invstd | gamma | beta.  training: batch statistics (biased variance),
+ * running_mean / running_var (nullable pair) updated with `momentum` using the unbiased variance,
+ * *num_batches_tracked += 1 (nullable); else the running statistics are used.  gamma / beta nullable
+ * (no affine).  nn.BatchNorm1d as wrapped by FastBatchNorm1d (base_modules.py:131-156). */
+int dva_bn_finalize(const double* sums, double m, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, const float* gamma, const float* beta, float momentum,
+                    float eps, int32_t training, int32_t C, float* bn, void* stream);
+/* out[i] = (float)(in[i] * scale): S1/M | S2/M tables of the BatchNorm backward. */
+int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a
  * composite int64 key, :97-179 CompositeTensor, :253-323 lex ops).
