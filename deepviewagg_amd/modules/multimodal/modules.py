@@ -11,15 +11,115 @@ Same constructor, ``forward(mm_data_dict, modality)`` contract and empty-modalit
 reference; the gather / pooling steps run on the HIP kernels of this package.  In nearest mode the
 gather is lazy (``ops.GatheredFeatures``): an exact mapping's atomic pool is the identity, E_mod runs on
 the feature-map rows and the gather is fused into the attention kernel.
-``MultimodalBlockDown`` (strided sparse 3D convolutions around the branch) belongs to the sparse
-backbone and is outside this package's scope.
+``MultimodalBlockDown`` wraps the 3D blocks around the branches and keeps the mappings consistent when a
+3D block changes the point set (reference modules.py:21-236): sampler-based blocks pick points, strided
+sparse convolutions MERGE the mappings of the input voxels onto their parent voxels.  The sparse
+convolution itself (torchsparse / MinkowskiEngine) is not part of this package: any block that maps a
+voxel tensor exposing ``C`` (int32 [N, 4] coordinates, batch index in the last column), ``s`` (stride) and
+``coord_maps`` (stride -> coordinates), i.e. the torchsparse 1.1 SparseTensor interface, can be plugged in;
+the parent index is a HIP hash query (``ops.voxel_parent_index``).
 """
 import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
 from ... import ops
+from ...core.common_modules.base_modules import Identity
 from .dropout import ModalityDropout
+
+MODALITY_NAMES = ['image']      # core/multimodal/data.py:10
+
+
+class SparseVoxels:
+    """Minimal voxel tensor with the torchsparse 1.1 ``SparseTensor`` fields the multimodal blocks read
+    (``F`` features, ``C`` int32 [N, 4] = x, y, z, batch, ``s`` stride, ``coord_maps`` stride -> coords).
+    Lets a ROCm sparse-convolution block (or a test double) sit between the multimodal branches."""
+
+    def __init__(self, F, C, s=1, coord_maps=None):
+        self.F, self.C, self.s = F, C, s
+        self.coord_maps = coord_maps if coord_maps is not None else {}
+        self.coord_maps.setdefault(s, C)
+
+
+def _is_voxel_tensor(x):
+    return all(hasattr(x, a) for a in ('C', 's', 'coord_maps'))
+
+
+class MultimodalBlockDown(nn.Module):
+    """ -- 3D Conv ---- Merge i -- 3D Conv --   with one UnimodalBranch per modality in between
+    (reference modules.py:21-236).  Built from already-instantiated modules."""
+
+    def __init__(self, block_1, block_2, **kwargs):
+        super().__init__()
+        self.block_1 = block_1 if block_1 is not None else Identity()
+        self.block_2 = block_2 if block_2 is not None else Identity()
+        self._modalities = []
+        for m, branch in kwargs.items():
+            assert m in MODALITY_NAMES, f"Invalid kwarg modality '{m}', expected one of {MODALITY_NAMES}."
+            assert isinstance(branch, (UnimodalBranch, IdentityBranch)), \
+                f"Expected a UnimodalBranch module for '{m}' modality but got {type(branch)} instead."
+            setattr(self, m, branch)
+            self._modalities.append(m)
+        self.sampler = [getattr(self.block_1, "sampler", None), getattr(self.block_2, "sampler", None)]
+
+    @property
+    def modalities(self):
+        return self._modalities
+
+    def forward(self, mm_data_dict):
+        mm_data_dict = self.forward_3d_block_down(mm_data_dict, self.block_1)
+        for m in self.modalities:
+            mm_data_dict = getattr(self, m)(mm_data_dict, m)
+        return self.forward_3d_block_down(mm_data_dict, self.block_2)
+
+    @staticmethod
+    def forward_3d_block_down(mm_data_dict, block):
+        """Run a 3D block and re-index ``x_seen`` and every modality's mappings if the block changed the
+        point set: i -> idx[i] (reference modules.py:101-236)."""
+        if isinstance(block, Identity):
+            return mm_data_dict
+        x_3d, x_seen = mm_data_dict['x_3d'], mm_data_dict['x_seen']
+        idx, mode = None, 'pick'
+        if isinstance(x_3d, torch.Tensor):
+            # dense features + sampler: the sampler reports which input points were kept
+            block.sampler.last_idx = None
+            n_in = x_3d.shape[0]
+            x_3d = block(x_3d)
+            idx_sample = block.sampler.last_idx
+            same = idx_sample is not None and idx_sample.shape[0] == n_in and bool(
+                (idx_sample == torch.arange(n_in, device=idx_sample.device)).all())
+            idx = None if same else idx_sample
+        elif _is_voxel_tensor(x_3d):
+            mode = 'merge'
+            stride_in = x_3d.s
+            x_3d = block(x_3d)
+            stride_out = x_3d.s
+            if stride_in != stride_out:
+                assert x_3d.C.shape[1] == 4, \
+                    f"Sparse coordinates are expected to have shape (N x 4), with batch indices in the last " \
+                    f"column and 3D spatial coordinates in the first ones. Yet, received coordinates tensor " \
+                    f"with shape {x_3d.C.shape} instead."
+                idx = ops.voxel_parent_index(x_3d.coord_maps[stride_in], x_3d.coord_maps[stride_out],
+                                             int(stride_out), batch_col=3)
+        else:
+            raise NotImplementedError(
+                f"Unsupported format for x_3d: {type(x_3d)}. Expected a dense feature tensor or a voxel tensor "
+                f"with the torchsparse SparseTensor fields (C, s, coord_maps).")
+        if x_seen is not None and idx is not None:
+            if mode == 'pick':
+                x_seen = x_seen[idx]
+            else:
+                n_out = x_3d.C.shape[0]
+                x_seen = torch.zeros(n_out, dtype=torch.int32, device=x_seen.device).index_add_(
+                    0, idx, x_seen.to(torch.int32)).to(x_seen.dtype)
+        mm_data_dict['x_3d'], mm_data_dict['x_seen'] = x_3d, x_seen
+        for m in mm_data_dict['modalities'].keys():
+            mm_data_dict['modalities'][m] = mm_data_dict['modalities'][m].select_points(idx, mode=mode)
+        return mm_data_dict
+
+
+class MultimodalBlockUp(nn.Module):
+    """Placeholder of the reference's (empty) up block (modules.py:239-246)."""
 
 
 class UnimodalBranch(nn.Module):

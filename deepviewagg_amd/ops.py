@@ -767,3 +767,27 @@ def rowbn_stats(y, counts):
 
 def rowbn_act(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope):
     return _RowBNAct.apply(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope)
+
+
+# ---------------------------------------------------------------------------------------------
+# voxel parent index after a strided sparse 3D convolution (modules.py:176-198)
+# ---------------------------------------------------------------------------------------------
+
+def voxel_parent_index(in_coords, out_coords, stride_out, batch_col=3):
+    """``idx[i] = j`` with ``out_coords[j] == floor_to_stride(in_coords[i])`` (batch column untouched),
+    ``-1`` when absent: the torchsparse ``sphashquery(sphash(in), sphash(out))`` of the reference."""
+    lib = _lib.load()
+    require_device(in_coords, out_coords)
+    assert in_coords.dim() == 2 and in_coords.shape[1] == 4 and out_coords.dim() == 2 and out_coords.shape[1] == 4
+    ic = in_coords.to(torch.int32).contiguous()
+    oc = out_coords.to(torch.int32).contiguous()
+    n_in, n_out = ic.shape[0], oc.shape[0]
+    idx = torch.empty(n_in, dtype=torch.int64, device=ic.device)
+    nbytes = lib.dva_voxel_parent_workspace_bytes(n_out)
+    if nbytes < 0:
+        raise _lib.DvaError("dva_voxel_parent_workspace_bytes", int(nbytes))
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=ic.device)
+    with _timed("voxel_parent_index", n_in * 24 + n_out * 24):
+        check(lib.dva_voxel_parent_index(ptr(ic), n_in, ptr(oc), n_out, int(stride_out), int(batch_col), ptr(idx),
+                                         ptr(ws), int(nbytes), stream_of(ic)), "dva_voxel_parent_index")
+    return idx

@@ -294,6 +294,21 @@ int dva_bn_finalize(const double* sums, double m, float* running_mean, float* ru
 int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * Voxel parent index after a strided sparse 3D convolution.  Replaces the torchsparse (v1.1.0, not in the
+ * reference tree) `sphashquery(sphash(in_coords), sphash(out_coords))` call of
+ * modules/multimodal/modules.py:176-198 together with the flooring of the spatial columns:
+ * idx[i] = j such that out_coords[j] == in_coords[i] with every column except batch_col floored to a
+ * multiple of stride_out (floor towards -inf), or -1 when no output voxel has these coordinates.
+ * in_coords int32 [n_in, 4], out_coords int32 [n_out, 4] (16-byte aligned; torchsparse layout: x, y, z,
+ * batch => batch_col = 3; batch_col = -1 floors all four columns), idx int64 [n_in].  Exact (full
+ * coordinate compare in an open-addressing table), deterministic; duplicate out rows -> smallest j.
+ * ------------------------------------------------------------------------------------------ */
+int64_t dva_voxel_parent_workspace_bytes(int64_t n_out);
+int dva_voxel_parent_index(const int32_t* in_coords, int64_t n_in, const int32_t* out_coords, int64_t n_out,
+                           int32_t stride_out, int32_t batch_col, int64_t* idx, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a
  * composite int64 key, :97-179 CompositeTensor, :253-323 lex ops).
  * ------------------------------------------------------------------------------------------ */
