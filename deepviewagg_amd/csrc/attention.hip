@@ -362,17 +362,35 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
     const int64_t col = (int64_t)lane_r * VEC;
-#pragma unroll 2
-    for (int v = row_slot; v < n; v += tg.rows) {
-      const int64_t r = beg + v;
-      const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;  // fused view gather: row of the value map
-      const raw_t x = *reinterpret_cast<const raw_t*>(val + vr * C + col);
-      const float a = expf((compat[r * G + g_lane] - m_l) / dn) / s_l;
-      if (g_first) att[r * G + g_lane] = a;
-      float f[VEC];
-      Vec16<T>::unpack(x, f);
+    // chunks of 4 rows per lane: row indices + scores, then the value rows, are issued before the first use
+    for (int v0 = 0; v0 < n; v0 += 4 * tg.rows) {
+      constexpr int U = 4;
+      bool ok[U];
+      int64_t rr[U], ri[U];
+      float cg[U];
+      raw_t x[U];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
+      for (int u = 0; u < U; ++u) {
+        const int v = v0 + row_slot + u * tg.rows;
+        ok[u] = v < n;
+        rr[u] = beg + (ok[u] ? v : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ri[u] = row_idx ? (int64_t)row_idx[rr[u]] : rr[u];  // fused view gather: row of the value map
+        cg[u] = compat[rr[u] * G + g_lane];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float a = ok[u] ? expf((cg[u] - m_l) / dn) / s_l : 0.f;
+        if (ok[u] && g_first) att[rr[u] * G + g_lane] = a;
+        float f[VEC];
+        Vec16<T>::unpack(x[u], f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
+      }
     }
     for (int off = tg.lpr; off < tg.ts; off <<= 1) {
 #pragma unroll
@@ -471,19 +489,37 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
         if (g_first && okr[u]) sum_ad += areg[u] * d;
       }
     } else {
-#pragma unroll 2
-      for (int v = row_slot; v < n; v += tg.rows) {
-        const int64_t r = beg + v;
-        const int64_t vr = row_idx ? (int64_t)row_idx[r] : r;
-        float f[VEC];
-        Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(val + vr * C + col), f);
-        float d = 0.f;
+      // long segments: same load-first chunks, d goes through grad_compat (re-read by the same lane in 2a)
+      for (int v0 = 0; v0 < n; v0 += U * tg.rows) {
+        bool ok[U];
+        int64_t rr[U], ri[U];
+        float av[U];
+        raw_t x[U];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
-        for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
-        if (g_first) {
-          gcompat[r * G + g_lane] = d;
-          sum_ad += att[r * G + g_lane] * d;
+        for (int u = 0; u < U; ++u) {
+          const int v = v0 + row_slot + u * tg.rows;
+          ok[u] = v < n;
+          rr[u] = beg + (ok[u] ? v : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ri[u] = row_idx ? (int64_t)row_idx[rr[u]] : rr[u];
+          av[u] = att[rr[u] * G + g_lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float f[VEC];
+          Vec16<T>::unpack(x[u], f);
+          float d = 0.f;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
+          for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
+          if (g_first && ok[u]) {
+            gcompat[rr[u] * G + g_lane] = d;
+            sum_ad += av[u] * d;
+          }
         }
       }
     }

@@ -318,8 +318,8 @@ def test_rows_grad_plan_equals_atomics(C, G, gating, dtype):
     c = run(0, plan)
     for x, y in zip(b[:3], c[:3]):      # out, grad rows, grad compat: deterministic, bit-identical
         assert torch.equal(x, y)
-    for x, y in zip(b[3:], c[3:]):      # gate parameters: atomically accumulated sums
-        close(x, y, rtol=1e-5, atol=1e-5)
+    for x, y in zip(b[3:], c[3:]):      # gate parameters: fp32 sums accumulated atomically (order varies)
+        close(x, y, rtol=1e-4, atol=1e-4)
     tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
     for x, y in zip(a, b):
         close(x, y, **tol)
