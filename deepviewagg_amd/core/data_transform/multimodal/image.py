@@ -105,3 +105,57 @@ class MapImages:
     def __repr__(self):
         return f"{self.__class__.__name__}(method={self.method}, ref_size={self.ref_size}, " \
                f"proj_upscale={self.proj_upscale}, kwargs={self.kwargs})"
+
+
+class NeighborhoodBasedMappingFeatures:
+    """Append neighbourhood-based mapping features to ``images.mappings.features`` (reference
+    core/data_transform/multimodal/image.py:431-612): per k in ``k`` a *density* column (surface density
+    from the distance to the k-th neighbour, normalised by ``voxel``) and an *occlusion* column (ratio of
+    the k nearest neighbours seen by the same image).  Same constructor as the reference; the K-NN search
+    is the exact HIP grid search of ``ops.knn`` (the reference's KeOps path is exact too; its FAISS path is
+    approximate), so ``use_cuda / use_faiss / ncells / nprobes`` are accepted and ignored."""
+
+    def __init__(self, k=20, voxel=None, density=True, occlusion=True, use_cuda=False, use_faiss=True, ncells=None,
+                 nprobes=10, verbose=False):
+        self.k_list = sorted(k) if isinstance(k, list) else [k]
+        self.voxel = voxel if voxel is not None else 1
+        self.compute_density = density
+        self.compute_occlusion = occlusion
+        self.verbose = verbose
+        assert density or occlusion, "At least one of `density` or `occlusion` must be True."
+
+    def __call__(self, data, images):
+        return self._process(data, images)
+
+    def _process(self, data, images):
+        from .... import ops
+        assert images.mappings is not None
+        in_device = images.device
+        device = torch.device('cuda', torch.cuda.current_device())
+        xyz = data.pos.float().to(device)
+        mappings = images.mappings
+        pointers = mappings.pointers.to(device)
+        neighbors, _ = ops.knn(xyz, self.k_list[-1])
+        new = []
+        if self.compute_density:
+            cols = []
+            for k in self.k_list:
+                # farthest neighbour of the k-neighbourhood, surface density of the disk of that radius
+                # (:522-531: same expressions, same constants)
+                d2_max = ((xyz - xyz[neighbors[:, k - 1].long()]) ** 2).sum(dim=1)
+                v_sphere = 3.1416 * d2_max
+                density = ((k + 1) / v_sphere) / (1 / self.voxel ** 2)
+                density[torch.where(density.isnan())] = 1
+                cols.append(density.view(-1, 1))
+            dens = torch.cat(cols, dim=1)
+            new.append(dens.repeat_interleave(pointers[1:] - pointers[:-1], 0))
+        if self.compute_occlusion:
+            image_ids = mappings.images.to(device)
+            n_images = int(image_ids.max()) + 1 if image_ids.numel() > 0 else 1
+            new.append(ops.view_occlusion(pointers, image_ids, neighbors, self.k_list, n_images))
+        new = torch.cat(new, dim=1).to(in_device)
+        if not mappings.has_features:
+            mappings.features = new
+        else:
+            mappings.features = torch.cat([mappings.features, new], dim=1)
+        return data, images

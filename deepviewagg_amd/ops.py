@@ -791,3 +791,64 @@ def voxel_parent_index(in_coords, out_coords, stride_out, batch_col=3):
         check(lib.dva_voxel_parent_index(ptr(ic), n_in, ptr(oc), n_out, int(stride_out), int(batch_col), ptr(idx),
                                          ptr(ws), int(nbytes), stream_of(ic)), "dva_voxel_parent_index")
     return idx
+
+
+# ---------------------------------------------------------------------------------------------
+# neighbourhood-based mapping features (data_transform/multimodal/image.py:431-612)
+# ---------------------------------------------------------------------------------------------
+
+def knn(xyz, k, cell=None):
+    """Exact k nearest neighbours of every point among all points (itself first): ``(neighbors int32 [n, k],
+    dist2 fp32 [n, k])``, ascending by (squared fp32 distance, index)."""
+    lib = _lib.load()
+    require_device(xyz)
+    xyz = xyz.float().contiguous()
+    n = xyz.shape[0]
+    assert xyz.dim() == 2 and xyz.shape[1] == 3 and 0 < k <= 64
+    nbr = torch.empty((n, k), dtype=torch.int32, device=xyz.device)
+    d2 = torch.empty((n, k), dtype=torch.float32, device=xyz.device)
+    if n == 0:
+        return nbr, d2
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    bbox = torch.cat([lo, hi]).contiguous()
+    ext = float((hi - lo).max())                   # host sync: this is a preprocessing transform
+    if cell is None:
+        # a cell that holds a few points of a surface-like cloud: mean spacing x (k/4)^(1/3)
+        vol = float((hi - lo).clamp(min=1e-6).prod())
+        cell = (vol / n) ** (1 / 3) * max(1.0, (k / 4) ** (1 / 3))
+    cell = max(float(cell), ext / (1 << 19), 1e-12)
+    nbytes = lib.dva_knn_workspace_bytes(n)
+    if nbytes < 0:
+        raise _lib.DvaError("dva_knn_workspace_bytes", int(nbytes))
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=xyz.device)
+    done = torch.zeros(n, dtype=torch.uint8, device=xyz.device)
+    # levels: a query that is not provably complete within 2 shells of cells (sparse region, outlier) is
+    # retried on a 4x coarser grid; the last level covers the whole cloud
+    shells = 2
+    with _timed("knn", n * (12 + k * 8)):
+        while True:
+            last = cell * shells >= ext + cell
+            check(lib.dva_knn(ptr(xyz), n, ptr(bbox), float(cell), int(k), (1 << 30) if last else shells, ptr(done),
+                              ptr(nbr), ptr(d2), ptr(ws), int(nbytes), stream_of(xyz)), "dva_knn")
+            if last:
+                break
+            cell *= 4.0
+    return nbr, d2
+
+
+def view_occlusion(csr_idx, images, neighbors, k_list, n_images):
+    """fp32 [V, len(k_list)]: ratio of the k nearest neighbours (and the point itself) seen by the view's image."""
+    lib = _lib.load()
+    require_device(csr_idx, images, neighbors)
+    V, N, k = images.shape[0], csr_idx.shape[0] - 1, neighbors.shape[1]
+    kl = torch.tensor(sorted(int(x) for x in k_list), dtype=torch.int32, device=images.device)
+    assert int(kl[-1]) <= k
+    out = torch.empty((V, kl.shape[0]), dtype=torch.float32, device=images.device)
+    if V == 0:
+        return out
+    vp = csr_expand(csr_idx, V)
+    bits = torch.empty(N * ((n_images + 63) // 64), dtype=torch.int64, device=images.device)
+    check(lib.dva_view_occlusion(ptr(vp), ptr(images.contiguous()), V, N, int(n_images), ptr(neighbors.contiguous()),
+                                 k, ptr(kl), kl.shape[0], ptr(bits), ptr(out), stream_of(images)),
+          "dva_view_occlusion")
+    return out

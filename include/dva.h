@@ -309,6 +309,30 @@ int dva_voxel_parent_index(const int32_t* in_coords, int64_t n_in, const int32_t
                            int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * Neighbourhood-based mapping features (core/data_transform/multimodal/image.py:431-612): exact k nearest
+ * neighbours of every point among all points (replaces KeOps `((x_i - x_j)**2).sum(2).argKmin(k, dim=1)`,
+ * :506-507; pykeops 1.4.2 is not in the reference tree) and the per-view occlusion counts (:560-599).
+ * ------------------------------------------------------------------------------------------ */
+/* neighbors int32 [n, k] (k <= 64), dist2 fp32 [n, k] (nullable): ascending by (d2, index) with
+ * d2 = ((dx*dx + dy*dy) + dz*dz) in fp32; the point itself is its own first neighbour; -1 / inf when
+ * n < k.  bbox = fp32[6] device array (min xyz | max xyz of the cloud); cell = grid cell size;
+ * (max - min) / cell must stay below 2^20 per axis.  One call searches at most max_shell Chebyshev shells
+ * of cells around each query and finishes every query whose k-th distance is provably final within them
+ * (or all queries, when the shells cover the whole cloud); `done` (uint8 [n], nullable) is read to skip
+ * finished queries and set for those finished here, so sparse regions are handled by calling again with
+ * a coarser cell (host: deepviewagg_amd.ops.knn, cell x4 per level).  The result is exact for any cell. */
+int64_t dva_knn_workspace_bytes(int64_t n);
+int dva_knn(const float* xyz, int64_t n, const float* bbox, float cell, int32_t k, int32_t max_shell,
+            uint8_t* done, int32_t* neighbors, float* dist2, void* workspace, int64_t workspace_bytes,
+            void* stream);
+/* out fp32 [n_views, n_k]: (1 + #{i < k_list[c] : neighbors[p(v), i] is seen by image(v)}) / (k_list[c] + 1)
+ * (k_list ascending, last <= k).  view_point int32 [n_views] (dva_csr_expand), images int64 [n_views],
+ * bits = scratch uint64 [n_points * ceil(n_images / 64)]. */
+int dva_view_occlusion(const int32_t* view_point, const int64_t* images, int64_t n_views, int64_t n_points,
+                       int32_t n_images, const int32_t* neighbors, int32_t k, const int32_t* k_list,
+                       int32_t n_k, uint64_t* bits, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * Lexicographic integer keys.  Replace utils/multimodal.py:36-94 (lexargsort / lexargunique on a
  * composite int64 key, :97-179 CompositeTensor, :253-323 lex ops).
  * ------------------------------------------------------------------------------------------ */
