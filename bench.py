@@ -202,6 +202,46 @@ def mapping_build_bench(device, n_images=4, n_points=200_000):
             "cpu_oracle_ms_per_image_1core": cpu_s * 1e3, "indices_bit_exact_vs_oracle": exact}
 
 
+def neighborhood_bench(device, n_points=1 << 20, k=50, n_images=32, views_per_point=8):
+    """Secondary measurement: K-NN (k = 50, the S3DIS setting) over a 1M-point
+    surface cloud + per-view occlusion, next to an exact KD-tree (scipy, 1 host core) on a 2^15-point sample
+    of the same cloud."""
+    import numpy as np
+    from deepviewagg_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    face = torch.randint(0, 3, (n_points,), generator=g)
+    xyz = torch.rand(n_points, 3, generator=g) * torch.tensor([8.0, 6.0, 3.0])
+    lim = torch.tensor([8.0, 6.0, 3.0])[face]
+    xyz[torch.arange(n_points), face] = torch.randint(0, 2, (n_points,), generator=g).float() * lim
+    xyz = (xyz + torch.randn(n_points, 3, generator=g) * 1e-3).to(device)
+    ops.knn(xyz[:4096], k)                                   # warm-up (rocPRIM kernels, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbr, d2 = ops.knn(xyz, k)
+    torch.cuda.synchronize()
+    knn_s = time.perf_counter() - t0
+    V = n_points * views_per_point
+    csr = torch.arange(0, V + 1, views_per_point, device=device)
+    images = torch.randint(0, n_images, (V,), generator=g).to(device)
+    ops.view_occlusion(csr, images, nbr, [k], n_images)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.view_occlusion(csr, images, nbr, [k], n_images)
+    torch.cuda.synchronize()
+    occ_s = time.perf_counter() - t0
+    from scipy.spatial import cKDTree
+    sample = xyz[: 1 << 15].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    dist, _ = cKDTree(sample).query(sample, k=k)
+    cpu_s = time.perf_counter() - t0
+    nb_s, d2_s = ops.knn(xyz[: 1 << 15], k)
+    same = bool(np.allclose(np.sqrt(d2_s.cpu().numpy().astype(np.float64)), dist, rtol=1e-4, atol=1e-6))
+    return {"points": n_points, "k": k, "knn_ms": knn_s * 1e3, "knn_points_per_s": n_points / knn_s,
+            "occlusion_views": V, "occlusion_ms": occ_s * 1e3,
+            "cpu_kdtree_points_per_s_1core": (1 << 15) / cpu_s, "cpu_sample": "scipy cKDTree, 2^15 points, k=50",
+            "kth_distances_match_kdtree": same}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,6 +324,8 @@ def main():
         }
         if world == 1 and not args.no_mapping_build:
             res["mapping_build"] = mapping_build_bench(device)
+        if world == 1 and not args.no_mapping_build:
+            res["neighborhood_features"] = neighborhood_bench(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
         print(json.dumps(res))
