@@ -241,32 +241,65 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
   const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg.ts;
   const int64_t team_stride = (int64_t)gridDim.x * teams_per_block;
 
-  for (int64_t p = team0; p < N; p += team_stride) {
-    const int64_t beg = ptr[p], end = ptr[p + 1];
-    const int n = (int)(end - beg);
-    if (n > 0 && n <= 4 * tg.rows) {
-      // ---- short segments (the common case): every load of the point -- row indices, scores, value rows
-      //      -- is issued before the first use (3 dependent latencies per point instead of ~6), and each
-      //      lane derives the softmax statistics of ITS channel group from the scores it needs anyway
-      constexpr int U = 4;
+  // Software pipeline over the points of a team, three stages deep, so that the three dependent loads of
+  // a point (CSR pointers -> row indices + scores -> value rows) of three consecutive points are in flight
+  // together: one memory latency per point instead of three.
+  constexpr int U = 4;
+  struct StageB {          // row indices and scores of a short segment (n <= U * rows): 8 registers
+    int32_t ri[U];
+    float cg[U];
+  };
+  auto is_small = [&](int n) { return n > 0 && n <= U * tg.rows; };
+  auto load_a = [&](int64_t p, int64_t& beg, int& n) {
+    beg = 0;
+    n = 0;
+    if (p < N) {
+      beg = ptr[p];
+      n = (int)(ptr[p + 1] - beg);
+    }
+  };
+  auto load_b = [&](int64_t beg, int n, StageB& b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      b.ri[u] = 0;
+      b.cg[u] = 0.f;
+    }
+    if (is_small(n)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int v = row_slot + u * tg.rows;
+        const int64_t r = beg + (v < n ? v : 0);
+        if (row_idx) b.ri[u] = row_idx[r];
+        b.cg[u] = compat[r * G + g_lane];
+      }
+    }
+  };
+  int64_t p = team0, p1 = team0 + team_stride, p2 = team0 + 2 * team_stride;
+  int64_t beg, beg1, beg2;
+  int n, n1, n2;
+  StageB sb, sb1;
+  load_a(p, beg, n);
+  load_a(p1, beg1, n1);
+  load_b(beg, n, sb);
+  for (; p < N; p = p1, beg = beg1, n = n1, sb = sb1, p1 = p2, beg1 = beg2, n1 = n2, p2 += team_stride) {
+    load_b(beg1, n1, sb1);      // next point: row indices + scores (its pointers came one iteration ago)
+    load_a(p2, beg2, n2);       // the point after: CSR pointers
+    if (is_small(n)) {
+      // ---- short segments (the common case): every lane derives the softmax statistics of ITS channel
+      //      group from the scores it needs anyway; the value rows are the only loads left to issue
       const int64_t col = (int64_t)lane_r * VEC;
       bool ok[U];
-      int64_t rr[U], ri[U];
-      float cg[U];
+      int64_t rr[U];
+      const float (&cg)[U] = sb.cg;
       raw_t x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int v = row_slot + u * tg.rows;
         ok[u] = v < n;
         rr[u] = beg + (ok[u] ? v : 0);
+        const int64_t ri = row_idx ? (int64_t)sb.ri[u] : rr[u];
+        x[u] = *reinterpret_cast<const raw_t*>(val + ri * C + col);
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ri[u] = row_idx ? (int64_t)row_idx[rr[u]] : rr[u];
-        cg[u] = compat[rr[u] * G + g_lane];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
       float m = -INFINITY;
       int am = 0x7fffffff;
 #pragma unroll
