@@ -468,46 +468,80 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
   // wave-uniform outer loop: the teams of one wavefront always iterate together
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t pw = wave * teams_per_wave; pw < N; pw += n_waves * teams_per_wave) {
+  // Three-stage software pipeline over the points of a team (same scheme as the forward kernel): CSR
+  // pointers of point i+2, row indices / attentions / grad_out row / gate of point i+1 and the value rows of
+  // point i are in flight together.
+  constexpr int U = 4;
+  struct StageB {
+    int32_t ri[U];
+    float av[U];
+    typename Vec16<T>::raw go;
+    float gt;
+  };
+  auto load_a = [&](int64_t p, int64_t& beg, int& n) {
+    beg = 0;
+    n = 0;
+    if (p < N) {
+      beg = ptr[p];
+      n = (int)(ptr[p + 1] - beg);
+    }
+  };
+  auto load_b = [&](int64_t p, int64_t beg, int n, StageB& b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      b.ri[u] = 0;
+      b.av[u] = 0.f;
+    }
+    b.go = raw_t();
+    b.gt = 1.f;
+    if (n > 0) {
+      b.go = *reinterpret_cast<const raw_t*>(gout + p * C + (int64_t)lane_r * VEC);
+      if (gate) b.gt = gate[p * G + g_lane];
+      if (n <= U * tg.rows) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = row_slot + u * tg.rows;
+          const int64_t r = beg + (v < n ? v : 0);
+          if (row_idx) b.ri[u] = row_idx[r];
+          b.av[u] = att[r * G + g_lane];
+        }
+      }
+    }
+  };
+  const int64_t pstep = n_waves * teams_per_wave;
+  int64_t pw = wave * teams_per_wave;
+  int64_t beg, beg1, beg2;
+  int n, n1, n2;
+  StageB sb, sb1;
+  load_a(pw + team_in_wave, beg, n);
+  load_a(pw + pstep + team_in_wave, beg1, n1);
+  load_b(pw + team_in_wave, beg, n, sb);
+  for (; pw < N; pw += pstep, beg = beg1, n = n1, sb = sb1, beg1 = beg2, n1 = n2) {
     const int64_t p = pw + team_in_wave;
-    const bool valid = p < N;
-    const int64_t beg = valid ? ptr[p] : 0;
-    const int n = valid ? (int)(ptr[p + 1] - beg) : 0;
+    load_b(p + pstep, beg1, n1, sb1);
+    load_a(p + 2 * pstep, beg2, n2);
     const int64_t col = (int64_t)lane_r * VEC;
     float go[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) go[k] = 0.f;
-    float gt = 1.f;
-    if (n > 0) {
-      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(gout + p * C + col), go);
-      if (gate) gt = gate[p * G + g_lane];
-    }
+    Vec16<T>::unpack(sb.go, go);
+    const float gt = sb.gt;
 
     // ---- pass 1: d[v,g] = sum_{c in g} go[c]*val[v,c];  sum_ad[g] = sum_v att[v,g]*d[v,g]
     float sum_ad = 0.f;
     // short segments (the common case): row indices, value rows and attentions of the whole point are
     // loaded before the first use and d stays in registers (no round trip through grad_compat)
-    constexpr int U = 4;
     const bool small = n <= U * tg.rows;
     float dreg[U], areg[U];
     bool okr[U];
     if (small) {
-      int64_t rr[U], ri[U];
       raw_t x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int v = row_slot + u * tg.rows;
         okr[u] = v < n;
-        rr[u] = beg + (okr[u] ? v : 0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ri[u] = (row_idx && n > 0) ? (int64_t)row_idx[rr[u]] : rr[u];
-        areg[u] = n > 0 ? att[rr[u] * G + g_lane] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (n > 0) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
+        areg[u] = sb.av[u];
+        const int64_t rr = beg + (okr[u] ? v : 0);
+        const int64_t ri = row_idx ? (int64_t)sb.ri[u] : rr;
+        if (n > 0) x[u] = *reinterpret_cast<const raw_t*>(val + ri * C + col);
         else x[u] = raw_t();
       }
 #pragma unroll
