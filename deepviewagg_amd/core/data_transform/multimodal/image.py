@@ -159,3 +159,245 @@ class NeighborhoodBasedMappingFeatures:
         else:
             mappings.features = torch.cat([mappings.features, new], dim=1)
         return data, images
+
+
+# ---------------------------------------------------------------------------------------------------
+# Online mapping-selection transforms (reference core/data_transform/multimodal/image.py:615-959).
+# Same constructors and `_process(data, images)` contract; the index work stays on the device the mappings
+# live on (the reference runs them in CPU DataLoader workers).  `data` is any object with the reference's
+# Data fields (`pos`, the MAPPING_KEY attribute, `num_nodes`), accessed as attributes or items.
+# ---------------------------------------------------------------------------------------------------
+
+def _get(data, key):
+    return data[key] if isinstance(data, dict) else getattr(data, key)
+
+
+def _set(data, key, value):
+    if isinstance(data, dict):
+        data[key] = value
+    else:
+        setattr(data, key, value)
+
+
+def _num_nodes(data):
+    n = data.get('num_nodes') if isinstance(data, dict) else getattr(data, 'num_nodes', None)
+    return int(n) if n is not None else int(_get(data, 'pos').shape[0])
+
+
+class ImageTransform:
+    """Transforms on ``(data, images)``; ``images`` may be an ``ImageData`` (list of settings), in which case
+    the transform is applied to every ``SameSettingImageData`` (reference :28-63) unless
+    ``_PROCESS_IMAGE_DATA``."""
+    _PROCESS_IMAGE_DATA = False
+
+    def __call__(self, data, images):
+        from ...multimodal.image import ImageData
+        if isinstance(images, ImageData) and not self._PROCESS_IMAGE_DATA:
+            out = []
+            for im in images:
+                data, im = self._process(data, im)
+                out.append(im)
+            return data, ImageData(out)
+        return self._process(data, images)
+
+    def __repr__(self):
+        attr = ', '.join(f'{k}={v}' for k, v in self.__dict__.items())
+        return f'{self.__class__.__name__}({attr})'
+
+
+class SelectMappingFromPointId(ImageTransform):
+    """Keep the mappings of the points listed in ``data[MAPPING_KEY]`` and renumber them 0..n-1 (:615-644)."""
+
+    def __init__(self):
+        self.key = MAPPING_KEY
+
+    def _process(self, data, images):
+        assert images.mappings is not None
+        images = images.select_points(_get(data, self.key).to(images.device), mode='pick')
+        _set(data, self.key, torch.arange(_num_nodes(data), device=images.device))
+        return data, images
+
+
+class DropImagesOutsideDataBoundingBox(ImageTransform):
+    """Drop the images whose position is outside the bounding box of the points (:647-667)."""
+
+    def __init__(self, margin=0, ignore_z=False):
+        self.margin = margin
+        self.ignore_z = ignore_z
+
+    def _process(self, data, images):
+        pos = _get(data, 'pos').to(images.device)
+        b_min = pos.min(dim=0).values - self.margin / 2
+        b_max = pos.max(dim=0).values + self.margin / 2
+        mask = torch.logical_and(b_min < images.pos, images.pos < b_max)
+        mask = mask[:, 0] * mask[:, 1] if self.ignore_z else mask[:, 0] * mask[:, 1] * mask[:, 2]
+        return data, images[mask]
+
+
+class PickKImages(ImageTransform):
+    """K random images, or one image out of K in their order (:689-710)."""
+
+    def __init__(self, k, random=False, replace=False):
+        self.k = k
+        self.random = random
+        self.replace = replace
+
+    def _process(self, data, images):
+        if self.random:
+            import numpy as np
+            idx = torch.from_numpy(np.random.choice(range(images.num_views), size=self.k, replace=self.replace))
+        else:
+            idx = slice(0, images.num_views, self.k)
+        return data, images[idx]
+
+
+class PickImagesFromMappingArea(ImageTransform):
+    """Keep the (at most n_max) images whose mappings cover more than ``area_ratio`` of the image, largest
+    first (:713-762)."""
+
+    def __init__(self, area_ratio=0.02, n_max=None, n_min=0, use_bbox=False):
+        self.area_ratio = area_ratio
+        self.n_max = n_max if n_max is not None and n_max >= 1 else None
+        self.n_min = n_min if n_max is not None and n_min >= 0 else 0
+        self.use_bbox = use_bbox
+
+    def _process(self, data, images):
+        assert images.mappings is not None, "No mappings found in images."
+        m = images.mappings
+        threshold = images.img_size[0] * images.img_size[1] * self.area_ratio
+        atom_ptr = m.values[1].pointers
+        pixel_idx = m.images.repeat_interleave(atom_ptr[1:] - atom_ptr[:-1])
+        B = images.num_views
+        if not self.use_bbox:
+            areas = torch.zeros(B, device=pixel_idx.device).index_add_(
+                0, pixel_idx, torch.ones(pixel_idx.shape[0], device=pixel_idx.device))
+        else:
+            pix = m.pixels.int()
+            big = torch.iinfo(torch.int32).max
+            lo = torch.full((B, 2), big, dtype=torch.int32, device=pix.device)
+            hi = torch.full((B, 2), -big, dtype=torch.int32, device=pix.device)
+            lo.scatter_reduce_(0, pixel_idx.view(-1, 1).expand(-1, 2), pix, 'amin')
+            hi.scatter_reduce_(0, pixel_idx.view(-1, 1).expand(-1, 2), pix, 'amax')
+            empty = lo[:, 0] == big                       # torch_scatter leaves 0 for images without pixels
+            areas = ((hi[:, 0] - lo[:, 0]) * (hi[:, 1] - lo[:, 1])).masked_fill(empty, 0)
+        n_max = images.num_views if self.n_max is None else self.n_max
+        idx = areas.argsort().flip(0)
+        idx = idx[areas[idx] > threshold][:n_max]
+        if idx.shape[0] == 0 and images.num_views > 0 and self.n_min > 0:
+            idx = idx[:self.n_min]
+        return data, images[idx]
+
+
+class PickMappingsFromMappingFeatures(ImageTransform):
+    """Drop the views whose mapping features are outside (lower, upper) bounds (:877-931)."""
+
+    def __init__(self, feat=None, lower=None, upper=None):
+        self.feat = self.sanitize(feat)
+        self.lower = self.sanitize(lower)
+        self.upper = self.sanitize(upper)
+        if len(self.lower) == 0:
+            self.lower = [None] * len(self.feat)
+        if len(self.upper) == 0:
+            self.upper = [None] * len(self.feat)
+        for x in [self.lower, self.upper]:
+            assert len(x) == len(self.feat), f"{x} has {len(x)} elements but {len(self.feat)} were expected."
+
+    @staticmethod
+    def sanitize(x):
+        if x is None:
+            return []
+        return list(x) if isinstance(x, (list, tuple)) else [x]
+
+    def _process(self, data, images):
+        if images.mappings is None or not images.mappings.has_features or len(self.feat) == 0:
+            return data, images
+        m = images.mappings
+        assert max(self.feat) == 0 or max(self.feat) < m.features.shape[1], \
+            f"Out of bounds feature id {max(self.feat)}."
+        features = m.features.view(m.num_items, -1)
+        view_mask = torch.ones(m.num_items, dtype=torch.bool, device=features.device)
+        for i_feat, lower, upper in zip(self.feat, self.lower, self.upper):
+            if lower is not None:
+                view_mask = view_mask & (features[:, i_feat] > lower)
+            if upper is not None:
+                view_mask = view_mask & (features[:, i_feat] < upper)
+        return data, images.select_views(view_mask)
+
+
+class JitterMappingFeatures(ImageTransform):
+    """Clamped gaussian noise on the mapping features (:934-959)."""
+
+    def __init__(self, sigma=0.02, clip=0.03):
+        self.sigma = sigma
+        self.clip = clip
+
+    def _process(self, data, images):
+        if images.mappings is None or not images.mappings.has_features:
+            return data, images
+        f = images.mappings.features
+        noise = (self.sigma * torch.randn(f.shape, device=f.device)).clamp(-self.clip, self.clip)
+        images.mappings.features = f + noise
+        return data, images
+
+
+class PickImagesFromMemoryCredit(ImageTransform):
+    """Cherry-pick images of an ``ImageData`` under a pixel-memory credit, optionally favouring images that
+    see yet-unseen points (:765-874).  Same sequential sampling (``np.random.choice``) as the reference."""
+    _PROCESS_IMAGE_DATA = True
+
+    def __init__(self, credit=None, img_size=[], k_coverage=0, n_img=0):
+        if credit is not None:
+            self.credit = credit
+        elif len(img_size) == 2 and n_img > 0:
+            self.credit = img_size[0] * img_size[1] * n_img
+        else:
+            raise ValueError("Either credit or img_size and n_img must be provided.")
+        self.use_coverage = k_coverage > 0
+        self.k_coverage = k_coverage
+
+    def _process(self, data, images):
+        import numpy as np
+        from ...multimodal.image import ImageData
+        if images.num_views == 0:
+            return data, images
+        picked = [[] for _ in range(images.num_settings)]
+        img_indices = [[i, j] for i, im in enumerate(images) for j in range(im.num_views)]
+        img_sizes = [images[i].img_size[0] * images[i].img_size[1] for i, j in img_indices]
+        if self.use_coverage:
+            seen = torch.zeros(images.num_views, _num_nodes(data), dtype=torch.bool, device=images.device)
+            off = 0
+            for im in images:
+                mp = im.mappings
+                sizes = mp.pointers[1:] - mp.pointers[:-1]
+                seen[mp.images + off, torch.arange(mp.num_groups, device=seen.device).repeat_interleave(sizes)] = True
+                off += im.num_views
+            img_unseen_points = [x for x in seen.cpu().numpy()]
+        credit = self.credit
+        assert credit > 0 and credit >= min(img_sizes), \
+            f"Insufficient credit={credit} to pick any of the provided images with min_size={min(img_sizes)}."
+        while credit > 0 and len(img_indices) > 0 and credit >= min(img_sizes):
+            for idx in range(len(img_indices), 0, -1):
+                if img_sizes[idx - 1] > credit:
+                    img_indices.pop(idx - 1)
+                    img_sizes.pop(idx - 1)
+                    if self.use_coverage:
+                        img_unseen_points.pop(idx - 1)
+            if self.use_coverage:
+                w_cov = np.array([x.sum() for x in img_unseen_points])
+                w_cov = self.k_coverage * w_cov / (w_cov.max() + 1)
+            else:
+                w_cov = np.zeros(len(img_indices))
+            w_size = np.array(img_sizes) / np.array(img_sizes).max()
+            weights = w_size + w_cov
+            probas = weights / weights.sum()
+            idx = np.random.choice(np.arange(probas.shape[0]), p=probas)
+            i, j = img_indices.pop(idx)
+            s = img_sizes.pop(idx)
+            if self.use_coverage:
+                newly_seen = img_unseen_points.pop(idx)
+            picked[i].append(j)
+            credit -= s
+            if self.use_coverage:
+                img_unseen_points = [np.logical_and(x, ~newly_seen) for x in img_unseen_points]
+        images = ImageData([im[torch.LongTensor(idx)] for im, idx in zip(images, picked) if len(idx) > 0])
+        return data, images

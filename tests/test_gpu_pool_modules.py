@@ -333,3 +333,4 @@ def test_deepset_bf16_activation_storage():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert fused_deepset._act_dtype() == torch.bfloat16
     print("bf16-storage error vs reference-autocast error per parameter:", report)
+
