@@ -16,6 +16,8 @@ _ALIASES = {
     "torch_points3d.modules.multimodal.pooling": "deepviewagg_amd.modules.multimodal.pooling",
     "torch_points3d.modules.multimodal.fusion": "deepviewagg_amd.modules.multimodal.fusion",
     "torch_points3d.modules.multimodal.dropout": "deepviewagg_amd.modules.multimodal.dropout",
+    "torch_points3d.modules.multimodal.modules": "deepviewagg_amd.modules.multimodal.modules",
+    "torch_points3d.core.data_transform.multimodal.image": "deepviewagg_amd.core.data_transform.multimodal.image",
     "torch_points3d.core.multimodal.csr": "deepviewagg_amd.core.multimodal.csr",
     "torch_points3d.core.multimodal.image": "deepviewagg_amd.core.multimodal.image",
     "torch_points3d.core.multimodal.visibility": "deepviewagg_amd.core.multimodal.visibility",
