@@ -244,15 +244,23 @@ def neighborhood_bench(device, n_points=1 << 20, k=50, n_images=32, views_per_po
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: everything else that may write to fd 1 (RCCL prints a version
+    # banner there at communicator creation) is redirected to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # one process per GPU over RCCL; a 1-rank torchrun launch (RANK set) also goes through the process group so
+    # that the collective path can be exercised on a single-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     from deepviewagg_amd import ops, _lib
@@ -267,7 +275,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -283,7 +291,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -328,8 +336,8 @@ def main():
             res["neighborhood_features"] = neighborhood_bench(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
-        print(json.dumps(res))
-    if world > 1:
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

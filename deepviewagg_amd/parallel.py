@@ -38,8 +38,6 @@ class GradientBucket:
         if not dist.is_available() or not dist.is_initialized():
             return
         world = dist.get_world_size(self.group)
-        if world == 1:
-            return
         off = 0
         for p, n in zip(self.params, self.sizes):
             if p.grad is None:
