@@ -401,3 +401,99 @@ class PickImagesFromMemoryCredit(ImageTransform):
                 img_unseen_points = [np.logical_and(x, ~newly_seen) for x in img_unseen_points]
         images = ImageData([im[torch.LongTensor(idx)] for im, idx in zip(images, picked) if len(idx) > 0])
         return data, images
+
+
+class CenterRoll(ImageTransform):
+    """Roll spherical images and mappings along the width so that the mappings sit as close to the image
+    centre as possible (reference :962-1037): per image, the roll offset (among ``angular_res`` candidates)
+    minimising span + centring distance of the mapped columns, evaluated in 8-bit angular coordinates."""
+
+    def __init__(self, angular_res=16):
+        assert isinstance(angular_res, int)
+        assert angular_res <= 256
+        self.angular_res = angular_res
+
+    def _process(self, data, images):
+        from ....utils.multimodal import lexunique
+        assert images.mappings is not None, "No mappings found in images."
+        name = self.__class__.__name__
+        assert images.ref_size[0] == images.img_size[0], \
+            f"{name} cannot operate if images and mappings underwent prior cropping or resizing."
+        assert images.crop_size is None or images.crop_size[0] == images.ref_size[0], \
+            f"{name} cannot operate if images and mappings underwent prior cropping or resizing."
+        assert images.downscale is None or images.downscale == 1, \
+            f"{name} cannot operate if images and mappings underwent prior cropping or resizing."
+        m = images.mappings
+        if m.images.shape[0] == 0:
+            return data, images
+        dev = m.device
+        idx = m.images.repeat_interleave(m._atom_sizes())
+        w_pix = (m.pixels[:, 0].float() * 256 / images.ref_size[0]).long()
+        idx, w_pix = lexunique(idx, w_pix)
+        w_pix = w_pix.to(torch.uint8)
+        rolls = torch.arange(0, 256, int(256 / self.angular_res), device=dev).to(torch.uint8)
+        w_pix = torch.cat([(w_pix + r).view(-1, 1) for r in rolls], dim=1)        # uint8 wrap-around
+        B, n_r = images.num_views, rolls.shape[0]
+        ix = idx.view(-1, 1).expand(-1, n_r)
+        w32 = w_pix.to(torch.int32)
+        w_min = torch.full((B, n_r), 255, dtype=torch.int32, device=dev).scatter_reduce_(0, ix, w32, 'amin')
+        w_max = torch.zeros((B, n_r), dtype=torch.int32, device=dev).scatter_reduce_(0, ix, w32, 'amax')
+        w_center_dist = ((w_max.float() + w_min) / 2. - 128).abs().int()
+        w_cost = (w_max - w_min) + w_center_dist
+        roll_idx = w_cost.min(dim=1).indices
+        rollings = (rolls[roll_idx].float() / 256. * images.ref_size[0]).long()
+        assert torch.equal(torch.unique(idx), torch.arange(images.num_views, device=dev)), \
+            "Image indices discrepancy in the rollings."
+        images.update_rollings(rollings)
+        return data, images
+
+
+class CropImageGroups(ImageTransform):
+    """Greedy cropping of the images around their mappings (+ padding) into a family of power-of-two crop
+    sizes; images of the same crop size are grouped (reference :1040-1141).  Returns an ``ImageData`` with
+    one ``SameSettingImageData`` per crop size."""
+
+    def __init__(self, padding=0, min_size=64):
+        assert padding >= 0, f"Expected a positive scalar but got {padding} instead."
+        assert ((min_size & (min_size - 1)) == 0) & (min_size != 0), \
+            f"Expected a power of two but got {min_size} instead."
+        self.padding = padding
+        self.min_size = min_size
+
+    def _process(self, data, images):
+        from ...multimodal.image import ImageData
+        assert images.mappings is not None, "No mappings found in images."
+        if images.num_views == 0:
+            return data, ImageData([images])
+        dev = images.device
+        w_min, w_max, h_min, h_max = images.mappings.bounding_boxes
+        w_min = torch.clamp(w_min - self.padding, 0)
+        h_min = torch.clamp(h_min - self.padding, 0)
+        w_max = torch.clamp(w_max + self.padding, 0, images.img_size[0])
+        h_max = torch.clamp(h_max + self.padding, 0, images.img_size[1])
+        widths, heights = w_max - w_min, h_max - h_min
+        crop_families = {}
+        size = (self.min_size, self.min_size)
+        i_crop = 0
+        image_ids = torch.arange(images.num_views, device=dev)
+        while all(a <= b for a, b in zip(size, images.img_size)):
+            if image_ids.shape[0] == 0:
+                break
+            if size == tuple(images.img_size):
+                crop_families[size] = image_ids
+                break
+            valid = torch.logical_and(widths[image_ids] <= size[0], heights[image_ids] <= size[1])
+            if image_ids[valid].shape[0] > 0:
+                crop_families[size] = image_ids[valid]
+            image_ids = image_ids[~valid]
+            size = (min(size[0] * 2 ** ((i_crop + 1) % 2), images.img_size[0]),
+                    min(size[1] * 2 ** (i_crop % 2), images.img_size[1]))
+            i_crop += 1
+        if tuple(images.img_size) not in crop_families.keys() and image_ids.shape[0] > 0:
+            crop_families[tuple(images.img_size)] = image_ids
+        for size, idx in crop_families.items():
+            off_x = torch.clamp((w_min[idx] - (size[0] - widths[idx]) / 2.).long(), 0, images.img_size[0] - size[0])
+            off_y = torch.clamp((h_min[idx] - (size[1] - heights[idx]) / 2.).long(), 0, images.img_size[1] - size[1])
+            offsets = torch.stack((off_x, off_y), dim=1).long()
+            crop_families[size] = images[idx].update_cropping(size, offsets)
+        return data, ImageData(list(crop_families.values()))

@@ -8,7 +8,7 @@ poke (SURVEY.md §8b seam 3): ``pointers``, ``values[0]`` images, ``values[1]`` 
 
 Sorting / unique go through the HIP lex kernels (``utils.multimodal``), per-view feature means through
 ``ops.segment_csr``; what remains is index arithmetic in torch on the device.  File / PIL loading
-(``load``, ``read_images``), rollings and interactive cropping of the reference are outside the hot
+(``load``, ``read_images``) and the interactive visualisation helpers of the reference are outside the hot
 path and not provided.
 """
 import copy
@@ -259,6 +259,28 @@ class ImageMapping(CSRData):
                              is_index_value=self.is_index_value)
         point_ids = point_ids[out.pointers[1:] - 1]
         return out.insert_empty_groups(point_ids, num_groups=self.num_groups)
+
+    def crop(self, crop_size, crop_offsets):
+        """Copy of the mapping for images cropped to ``crop_size`` (W, H) at per-image ``crop_offsets``
+        [B, 2]: pixel coordinates are shifted, pixels outside the box are dropped (reference
+        image.py:2279-2342, including its early return when no pixel at all is inside the boxes)."""
+        n_img = self.images.unique().numel()
+        assert crop_offsets.shape == (n_img, 2), \
+            f"Expected crop_offsets to have shape {(n_img, 2)} but got shape {crop_offsets.shape} instead."
+        sizes = self._atom_sizes()
+        image_ids = self.images.repeat_interleave(sizes)
+        pixels = self.pixels - crop_offsets.to(self.device)[image_ids].to(self.pixels.dtype)
+        lim = torch.tensor(crop_size, device=self.device)
+        inside = torch.where((pixels >= 0).all(dim=1) & (pixels < lim).all(dim=1))[0]
+        if inside.shape[0] == 0:
+            out = self.clone()
+            out.pixels = pixels
+            return out
+        point_ids = torch.arange(self.num_groups, device=self.device).repeat_interleave(
+            self.pointers[1:] - self.pointers[:-1]).repeat_interleave(sizes)
+        features = self.features.repeat_interleave(sizes, dim=0)[inside] if self.has_features else None
+        return ImageMapping.from_dense(point_ids[inside], image_ids[inside], pixels[inside], features,
+                                       num_points=self.num_groups)
 
     def select_views(self, view_mask):
         """Keep the views selected by a boolean mask; returns (mapping, seen image indices)
@@ -570,6 +592,43 @@ class SameSettingImageData:
         self._mappings = held
         images.mappings = mappings
         return images
+
+    def update_rollings(self, rollings):
+        """Roll spherical images and their mappings along the width, with respect to the reference state
+        (reference image.py:578-628).  No prior cropping along the width or resizing."""
+        assert self.ref_size[0] == self.img_size[0], \
+            "CenterRoll cannot operate if images and mappings underwent prior cropping or resizing."
+        assert self.crop_size is None or tuple(self.crop_size) == tuple(self.ref_size), \
+            "CenterRoll cannot operate if images and mappings underwent prior cropping or resizing."
+        assert self.downscale is None or self.downscale == 1, \
+            "CenterRoll cannot operate if images and mappings underwent prior cropping or resizing."
+        self.rollings = rollings.to(self.device).long()
+        if self.x is not None:
+            # per-image roll along W as one gather (the reference loops over images with .item())
+            W = self.x.shape[-1]
+            src = (torch.arange(W, device=self.device).view(1, -1) - self.rollings.view(-1, 1)) % W
+            self.x = torch.gather(self.x, 3, src.view(-1, 1, 1, W).expand_as(self.x))
+        if self.mappings is not None:
+            pix_roll = self.rollings[self.mappings.images].repeat_interleave(self.mappings._atom_sizes())
+            w_pix = (self.mappings.pixels[:, 0].long() + pix_roll) % self.ref_size[0]
+            self.mappings.pixels[:, 0] = w_pix.to(self.mappings.pixels.dtype)
+        return self
+
+    def update_cropping(self, crop_size, crop_offsets):
+        """Crop ``x`` and the mappings with respect to the CURRENT ``img_size``; the stored crop state is
+        kept with respect to ``ref_size`` (reference image.py:688-722)."""
+        crop_offsets = crop_offsets.long().to(self.device)
+        self._crop_size = tuple(int(v * self.downscale) for v in crop_size)
+        self._crop_offsets = (self.crop_offsets + crop_offsets * self.downscale).long()
+        if self.x is not None:
+            Wc, Hc = int(crop_size[0]), int(crop_size[1])
+            cols = crop_offsets[:, 0].view(-1, 1) + torch.arange(Wc, device=self.device).view(1, -1)
+            rows = crop_offsets[:, 1].view(-1, 1) + torch.arange(Hc, device=self.device).view(1, -1)
+            b = torch.arange(self.x.shape[0], device=self.device).view(-1, 1, 1)
+            self._x = self.x[b, :, rows.view(-1, Hc, 1), cols.view(-1, 1, Wc)].permute(0, 3, 1, 2).contiguous()
+        if self.mappings is not None:
+            self.mappings = self.mappings.crop(crop_size, crop_offsets)
+        return self
 
     def __len__(self):
         return self.num_views
