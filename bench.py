@@ -202,6 +202,20 @@ def mapping_build_bench(device, n_images=4, n_points=200_000):
             "cpu_oracle_ms_per_image_1core": cpu_s * 1e3, "indices_bit_exact_vs_oracle": exact}
 
 
+def copy_ceiling(device, nbytes=1 << 32, reps=5):
+    """Practical HBM ceiling: read + write rate of a plain device copy of `nbytes`."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def neighborhood_bench(device, n_points=1 << 20, k=50, n_images=32, views_per_point=8):
     """Secondary measurement: K-NN (k = 50, the S3DIS setting) over a 1M-point
     surface cloud + per-view occlusion, next to an exact KD-tree (scipy, 1 host core) on a 2^15-point sample
@@ -327,11 +341,16 @@ def main():
             "kernels": {n: {"avg_ms": v["ms"] / v["launches"], "launches": v["launches"],
                             "GBps": (v["bytes"] / v["launches"]) / (v["ms"] / v["launches"] * 1e-3) / 1e9}
                         for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
+            "hbm_copy_GBps": None,
             "gather_GBps": None if gk is None else (gk["bytes"] / gk["launches"]) / (gk["ms"] / gk["launches"] * 1e-3) / 1e9,
             "loss": float(loss.item()),
         }
         if world == 1 and not args.no_mapping_build:
             res["mapping_build"] = mapping_build_bench(device)
+        # practical ceiling next to the nominal one: a plain device copy in this process
+        res["hbm_copy_GBps"] = copy_ceiling(device)
+        res["roofline"]["copy_ceiling"] = res["hbm_copy_GBps"]
+        res["roofline"]["frac_of_copy_ceiling"] = achieved / res["hbm_copy_GBps"]
         if world == 1 and not args.no_mapping_build:
             res["neighborhood_features"] = neighborhood_bench(device)
         if world == 1 and not args.no_cpu_baseline:
