@@ -204,34 +204,36 @@ __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ 
     const int64_t beg = valid ? ptr[p] : 0;
     const int64_t end = valid ? ptr[p + 1] : 0;
     float m[VEC];
-    int64_t am[VEC];
+    int am[VEC];            // row offset inside the segment (32-bit: halves the shuffle / select work)
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       m[k] = -INFINITY;
       am[k] = -1;
     }
     // both half-waves iterate together (shuffles below need every lane)
-    const int64_t n_max = max(end - beg, __shfl_xor(end - beg, 32));
-    for (int64_t i0 = 0; i0 < n_max; i0 += SLOTS * U) {
+    const int n_seg = (int)(end - beg);
+    const int n_max = max(n_seg, __shfl_xor(n_seg, 32));
+    for (int i0 = 0; i0 < n_max; i0 += SLOTS * U) {
       raw_t raw[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int64_t r = beg + i0 + u * SLOTS + slot;
-        ok[u] = r < end;
-        raw[u] = *reinterpret_cast<const raw_t*>(a + (ok[u] ? r : (end > beg ? beg : 0)) * D + c0);
+        const int i = i0 + u * SLOTS + slot;
+        ok[u] = i < n_seg;
+        const int64_t r = n_seg > 0 ? beg + (ok[u] ? i : 0) : 0;   // clamped: loads are unconditional
+        raw[u] = *reinterpret_cast<const raw_t*>(a + r * D + c0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float f[VEC];
         SegVec<AT>::unpack(raw[u], f);
-        const int64_t r = beg + i0 + u * SLOTS + slot;
+        const int i = i0 + u * SLOTS + slot;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           const float v = leaky(bn_z(f[k], b[k]));
           if (ok[u] && v > m[k]) {   // rows ascend within a lane: strict > keeps the first row on ties
             m[k] = v;
-            am[k] = r;
+            am[k] = i;
           }
         }
       }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ 
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const float ov = __shfl_xor(m[k], off);
-        const int64_t oa = __shfl_xor(am[k], off);
+        const int oa = __shfl_xor(am[k], off);
         if (oa >= 0 && (am[k] < 0 || ov > m[k] || (ov == m[k] && oa < am[k]))) {
           m[k] = ov;
           am[k] = oa;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ 
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         pooled[p * D + c0 + k] = am[k] >= 0 ? m[k] : 0.f;
-        arg[p * D + c0 + k] = (int32_t)am[k];
+        arg[p * D + c0 + k] = am[k] >= 0 ? (int32_t)(beg + am[k]) : -1;
       }
     }
   }
