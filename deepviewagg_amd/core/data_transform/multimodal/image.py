@@ -360,47 +360,49 @@ class PickImagesFromMemoryCredit(ImageTransform):
         from ...multimodal.image import ImageData
         if images.num_views == 0:
             return data, images
-        picked = [[] for _ in range(images.num_settings)]
-        img_indices = [[i, j] for i, im in enumerate(images) for j in range(im.num_views)]
-        img_sizes = [images[i].img_size[0] * images[i].img_size[1] for i, j in img_indices]
+        # flat table of candidate images: (setting, index in setting, pixel area)
+        setting = np.concatenate([np.full(im.num_views, i) for i, im in enumerate(images)])
+        local = np.concatenate([np.arange(im.num_views) for im in images])
+        area = np.array([images[int(i)].img_size[0] * images[int(i)].img_size[1] for i in setting], dtype=np.float64)
+        unseen = None
         if self.use_coverage:
-            seen = torch.zeros(images.num_views, _num_nodes(data), dtype=torch.bool, device=images.device)
-            off = 0
+            # unseen[i, p]: image i sees point p and no picked image has seen p yet
+            seen = torch.zeros(len(setting), _num_nodes(data), dtype=torch.bool, device=images.device)
+            first = 0
             for im in images:
                 mp = im.mappings
-                sizes = mp.pointers[1:] - mp.pointers[:-1]
-                seen[mp.images + off, torch.arange(mp.num_groups, device=seen.device).repeat_interleave(sizes)] = True
-                off += im.num_views
-            img_unseen_points = [x for x in seen.cpu().numpy()]
+                pts = torch.arange(mp.num_groups, device=seen.device).repeat_interleave(mp.pointers[1:] - mp.pointers[:-1])
+                seen[mp.images + first, pts] = True
+                first += im.num_views
+            unseen = seen.cpu().numpy()
         credit = self.credit
-        assert credit > 0 and credit >= min(img_sizes), \
-            f"Insufficient credit={credit} to pick any of the provided images with min_size={min(img_sizes)}."
-        while credit > 0 and len(img_indices) > 0 and credit >= min(img_sizes):
-            for idx in range(len(img_indices), 0, -1):
-                if img_sizes[idx - 1] > credit:
-                    img_indices.pop(idx - 1)
-                    img_sizes.pop(idx - 1)
-                    if self.use_coverage:
-                        img_unseen_points.pop(idx - 1)
+        assert credit > 0 and credit >= area.min(), \
+            f"Insufficient credit={credit} to pick any of the provided images with min_size={int(area.min())}."
+        alive = np.ones(len(setting), dtype=bool)
+        chosen = []
+        while credit > 0 and alive.any():
+            alive &= area <= credit                         # images that no longer fit the remaining credit
+            cand = np.flatnonzero(alive)
+            if cand.size == 0:
+                break
             if self.use_coverage:
-                w_cov = np.array([x.sum() for x in img_unseen_points])
-                w_cov = self.k_coverage * w_cov / (w_cov.max() + 1)
+                cover = unseen[cand].sum(axis=1)
+                w_cov = self.k_coverage * cover / (cover.max() + 1)
             else:
-                w_cov = np.zeros(len(img_indices))
-            w_size = np.array(img_sizes) / np.array(img_sizes).max()
-            weights = w_size + w_cov
-            probas = weights / weights.sum()
-            idx = np.random.choice(np.arange(probas.shape[0]), p=probas)
-            i, j = img_indices.pop(idx)
-            s = img_sizes.pop(idx)
+                w_cov = 0.0
+            weights = area[cand] / area[cand].max() + w_cov      # size weight + coverage weight (:836-850)
+            pick = cand[np.random.choice(cand.size, p=weights / weights.sum())]
+            chosen.append(pick)
+            alive[pick] = False
+            credit -= area[pick]
             if self.use_coverage:
-                newly_seen = img_unseen_points.pop(idx)
-            picked[i].append(j)
-            credit -= s
-            if self.use_coverage:
-                img_unseen_points = [np.logical_and(x, ~newly_seen) for x in img_unseen_points]
-        images = ImageData([im[torch.LongTensor(idx)] for im, idx in zip(images, picked) if len(idx) > 0])
-        return data, images
+                unseen &= ~unseen[pick]
+        groups = []
+        for i, im in enumerate(images):
+            mine = [int(local[c]) for c in chosen if setting[c] == i]
+            if mine:
+                groups.append(im[torch.LongTensor(mine)])
+        return data, ImageData(groups)
 
 
 class CenterRoll(ImageTransform):
@@ -427,23 +429,21 @@ class CenterRoll(ImageTransform):
         if m.images.shape[0] == 0:
             return data, images
         dev = m.device
-        idx = m.images.repeat_interleave(m._atom_sizes())
-        w_pix = (m.pixels[:, 0].float() * 256 / images.ref_size[0]).long()
-        idx, w_pix = lexunique(idx, w_pix)
-        w_pix = w_pix.to(torch.uint8)
-        rolls = torch.arange(0, 256, int(256 / self.angular_res), device=dev).to(torch.uint8)
-        w_pix = torch.cat([(w_pix + r).view(-1, 1) for r in rolls], dim=1)        # uint8 wrap-around
-        B, n_r = images.num_views, rolls.shape[0]
-        ix = idx.view(-1, 1).expand(-1, n_r)
-        w32 = w_pix.to(torch.int32)
-        w_min = torch.full((B, n_r), 255, dtype=torch.int32, device=dev).scatter_reduce_(0, ix, w32, 'amin')
-        w_max = torch.zeros((B, n_r), dtype=torch.int32, device=dev).scatter_reduce_(0, ix, w32, 'amax')
-        w_center_dist = ((w_max.float() + w_min) / 2. - 128).abs().int()
-        w_cost = (w_max - w_min) + w_center_dist
-        roll_idx = w_cost.min(dim=1).indices
-        rollings = (rolls[roll_idx].float() / 256. * images.ref_size[0]).long()
-        assert torch.equal(torch.unique(idx), torch.arange(images.num_views, device=dev)), \
+        B, W = images.num_views, images.ref_size[0]
+        # mapped columns in 8-bit angular coordinates, one entry per distinct (image, column)
+        img, col8 = lexunique(m.images.repeat_interleave(m._atom_sizes()), (m.pixels[:, 0].float() * 256 / W).long())
+        assert torch.equal(torch.unique(img), torch.arange(B, device=dev)), \
             "Image indices discrepancy in the rollings."
+        step = int(256 / self.angular_res)
+        cand = torch.arange(0, 256, step, device=dev)                       # candidate roll offsets
+        rolled = (col8.view(-1, 1) + cand.view(1, -1)) % 256                  # uint8 wrap-around, [pixels, cand]
+        tgt = img.view(-1, 1).expand_as(rolled)
+        lo = torch.full((B, cand.numel()), 255, dtype=torch.long, device=dev).scatter_reduce_(0, tgt, rolled, 'amin')
+        hi = torch.zeros((B, cand.numel()), dtype=torch.long, device=dev).scatter_reduce_(0, tgt, rolled, 'amax')
+        # cost = angular span + distance of the span's centre to the image centre (:1011-1020)
+        cost = (hi - lo).int() + ((hi.float() + lo) / 2. - 128).abs().int()
+        best = cand[cost.min(dim=1).indices]
+        rollings = (best.float() / 256. * W).long()
         images.update_rollings(rollings)
         return data, images
 
@@ -466,34 +466,29 @@ class CropImageGroups(ImageTransform):
         if images.num_views == 0:
             return data, ImageData([images])
         dev = images.device
-        w_min, w_max, h_min, h_max = images.mappings.bounding_boxes
-        w_min = torch.clamp(w_min - self.padding, 0)
-        h_min = torch.clamp(h_min - self.padding, 0)
-        w_max = torch.clamp(w_max + self.padding, 0, images.img_size[0])
-        h_max = torch.clamp(h_max + self.padding, 0, images.img_size[1])
-        widths, heights = w_max - w_min, h_max - h_min
+        W, H = images.img_size
+        x0, x1, y0, y1 = images.mappings.bounding_boxes
+        x0, y0 = (x0 - self.padding).clamp(min=0), (y0 - self.padding).clamp(min=0)
+        x1, y1 = (x1 + self.padding).clamp(0, W), (y1 + self.padding).clamp(0, H)
+        bw, bh = x1 - x0, y1 - y0
+        # the ladder of crop sizes: (s, s), (2s, s), (2s, 2s), (4s, 2s), ... capped by the image, ending with
+        # the full image (:1085-1123)
+        ladder, size, k = [], (self.min_size, self.min_size), 0
+        while size[0] <= W and size[1] <= H and size != (W, H):
+            ladder.append(size)
+            size = (min(size[0] * 2 ** ((k + 1) % 2), W), min(size[1] * 2 ** (k % 2), H))
+            k += 1
+        ladder.append((W, H))
+        # every image goes to the first size of the ladder that holds its padded bounding box
+        fits = torch.stack([(bw <= sw) & (bh <= sh) for sw, sh in ladder[:-1]] +
+                           [torch.ones_like(bw, dtype=torch.bool)], dim=1)
+        level = fits.int().argmax(dim=1)
         crop_families = {}
-        size = (self.min_size, self.min_size)
-        i_crop = 0
-        image_ids = torch.arange(images.num_views, device=dev)
-        while all(a <= b for a, b in zip(size, images.img_size)):
-            if image_ids.shape[0] == 0:
-                break
-            if size == tuple(images.img_size):
-                crop_families[size] = image_ids
-                break
-            valid = torch.logical_and(widths[image_ids] <= size[0], heights[image_ids] <= size[1])
-            if image_ids[valid].shape[0] > 0:
-                crop_families[size] = image_ids[valid]
-            image_ids = image_ids[~valid]
-            size = (min(size[0] * 2 ** ((i_crop + 1) % 2), images.img_size[0]),
-                    min(size[1] * 2 ** (i_crop % 2), images.img_size[1]))
-            i_crop += 1
-        if tuple(images.img_size) not in crop_families.keys() and image_ids.shape[0] > 0:
-            crop_families[tuple(images.img_size)] = image_ids
-        for size, idx in crop_families.items():
-            off_x = torch.clamp((w_min[idx] - (size[0] - widths[idx]) / 2.).long(), 0, images.img_size[0] - size[0])
-            off_y = torch.clamp((h_min[idx] - (size[1] - heights[idx]) / 2.).long(), 0, images.img_size[1] - size[1])
-            offsets = torch.stack((off_x, off_y), dim=1).long()
-            crop_families[size] = images[idx].update_cropping(size, offsets)
+        for lv in torch.unique(level).tolist():
+            sw, sh = ladder[lv]
+            idx = torch.where(level == lv)[0]
+            # centre the box in the crop, inside the image borders
+            off_x = (x0[idx] - (sw - bw[idx]) / 2.).long().clamp(0, W - sw)
+            off_y = (y0[idx] - (sh - bh[idx]) / 2.).long().clamp(0, H - sh)
+            crop_families[(sw, sh)] = images[idx].update_cropping((sw, sh), torch.stack((off_x, off_y), dim=1))
         return data, ImageData(list(crop_families.values()))
