@@ -99,11 +99,11 @@ SIGNATURES = {
     "dva_deepset_fwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "dva_deepset_fwd_layer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "dva_deepset_fwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "dva_deepset_bwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
-                                             _vp]),
+    "dva_deepset_fwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "dva_deepset_bwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32,
+                                             _i32, _vp]),
     "dva_deepset_bwd_layer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                             _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+                                             _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_deepset_bwd_max": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "dva_deepset_bwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "dva_rowbn_stats": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -675,15 +675,15 @@ int dsm_launch_fwd_first(const float*, const float*, const float*, const float*,
                          int, int, hipStream_t);
 int dsm_launch_fwd_layer(const void*, const float*, const float*, const float*, const int32_t*, void*,
                          double*, int64_t, int, hipStream_t);
-int dsm_launch_fwd_score(const void*, const float*, const float*, const float*, float*, int64_t, int, int,
-                         hipStream_t);
+int dsm_launch_fwd_score(const void*, const float*, const float*, const float*, float*, int64_t, int,
+                         const float*, const float*, int, hipStream_t);
 int dsm_launch_bwd_layer(const void*, const void*, const float*, const float*, const float*, const void*,
                          const float*, const float*, void*, float*, double*, float*, const int32_t*, float*,
-                         int64_t, int, int, int, hipStream_t);
+                         const float*, int64_t, int, int, int, hipStream_t);
 int dsm_launch_bwd_max(const void*, const void*, const float*, const int32_t*, const float*, const int32_t*,
                        void*, double*, int64_t, int, hipStream_t);
 int dsm_launch_bwd_score(const float*, const void*, const float*, const float*, void*, float*, float*,
-                         double*, int64_t, int, int, hipStream_t);
+                         double*, int64_t, int, const float*, const float*, int, hipStream_t);
 
 // activation storage code of the C ABI -> 0 (fp32) / 1 (bf16) / -1 (invalid)
 static inline int act_bf(int32_t act_dtype) {
@@ -764,7 +764,8 @@ int dva_deepset_fwd_layer(const void* a_in_, const float* bn_in, const float* W,
   const float* a_in = (const float*)a_in_;
   float* a_out = (float*)a_out_;
   if (V == 0) return DVA_OK;
-  if (!a_in || !W || !a_out) return DVA_ERR_INVALID;
+  if (!a_in || !W) return DVA_ERR_INVALID;
+  if (!a_out && algo == 1) return DVA_ERR_UNSUPPORTED;   // statistics-only pass: MFMA generation
   if (addend && !group_of_row) return DVA_ERR_INVALID;
   if (!bn_in && algo == 1) return DVA_ERR_UNSUPPORTED;  // raw-input layers only in the MFMA generation
   hipStream_t s = (hipStream_t)stream;
@@ -784,16 +785,18 @@ int dva_deepset_fwd_layer(const void* a_in_, const float* bn_in, const float* W,
 }
 
 int dva_deepset_fwd_score(const void* a_, const float* bn, const float* Ws, const float* bs,
-                          float* compat, int64_t V, int32_t G, int32_t algo, int32_t act_dtype,
-                          void* stream) {
+                          float* compat, int64_t V, int32_t G, const float* bn_pre, const float* W_pre,
+                          int32_t algo, int32_t act_dtype, void* stream) {
   const int bf = act_bf(act_dtype);
   if (V < 0 || G <= 0 || G > 32 || bf < 0) return DVA_ERR_INVALID;
   if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  if ((bn_pre == nullptr) != (W_pre == nullptr)) return DVA_ERR_INVALID;
+  if (W_pre && algo == 1) return DVA_ERR_UNSUPPORTED;
   const float* a = (const float*)a_;
   if (V == 0) return DVA_OK;
   if (!a || !bn || !Ws || !bs || !compat) return DVA_ERR_INVALID;
   if (algo != 1) {
-    dsm_launch_fwd_score(a_, bn, Ws, bs, compat, V, G, bf, (hipStream_t)stream);
+    dsm_launch_fwd_score(a_, bn, Ws, bs, compat, V, G, bn_pre, W_pre, bf, (hipStream_t)stream);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -807,17 +810,20 @@ int dva_deepset_fwd_score(const void* a_, const float* bn, const float* Ws, cons
 
 int dva_deepset_bwd_score(const float* dcompat, const void* a_, const float* bn, const float* Ws,
                           void* dz_, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
-                          int32_t algo, int32_t act_dtype, void* stream) {
+                          const float* bn_pre, const float* W_pre, int32_t algo, int32_t act_dtype,
+                          void* stream) {
   const int bf = act_bf(act_dtype);
   if (V < 0 || G <= 0 || bf < 0) return DVA_ERR_INVALID;
   if (bf && algo == 1) return DVA_ERR_UNSUPPORTED;
+  if ((bn_pre == nullptr) != (W_pre == nullptr)) return DVA_ERR_INVALID;
+  if (W_pre && (!bf || algo == 1)) return DVA_ERR_UNSUPPORTED;   // recompute: bf16 storage, MFMA generation
   const float* a = (const float*)a_;
   float* dz = (float*)dz_;
   if (G > 32) return DVA_ERR_UNSUPPORTED;
   if (V == 0) return DVA_OK;
   if (!dcompat || !a || !bn || !Ws || !dz || !dWs || !dbs || !st) return DVA_ERR_INVALID;
   if (algo != 1) {
-    dsm_launch_bwd_score(dcompat, a_, bn, Ws, dz_, dWs, dbs, st, V, G, bf, (hipStream_t)stream);
+    dsm_launch_bwd_score(dcompat, a_, bn, Ws, dz_, dWs, dbs, st, V, G, bn_pre, W_pre, bf, (hipStream_t)stream);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
@@ -834,7 +840,7 @@ int dva_deepset_bwd_score(const float* dcompat, const void* a_, const float* bn,
 int dva_deepset_bwd_layer(const void* dz_L_, const void* a_L_, const float* bn_L, const float* sm_L,
                           const float* W_L, const void* a_prev_, const float* Wa, const float* bn_prev,
                           void* out_, float* dW, double* st_prev, float* dt,
-                          const int32_t* group_of_row, float* first_grad, int64_t V,
+                          const int32_t* group_of_row, float* first_grad, const float* addend, int64_t V,
                           int32_t prev_is_xmap, int32_t raw_out, int32_t algo, int32_t act_dtype,
                           void* stream) {
   const int bf = act_bf(act_dtype);
@@ -845,16 +851,19 @@ int dva_deepset_bwd_layer(const void* dz_L_, const void* a_L_, const float* bn_L
   const float *dz_L = (const float*)dz_L_, *a_L = (const float*)a_L_, *a_prev = (const float*)a_prev_;
   float* out = (float*)out_;
   if (V == 0) return DVA_OK;
-  if (!dz_L || !a_L || !bn_L || !sm_L || !W_L || !a_prev || (!out && !first_grad) || !dW)
-    return DVA_ERR_INVALID;
+  if (!dz_L || !bn_L || !sm_L || !W_L || !a_prev || (!out && !first_grad) || !dW) return DVA_ERR_INVALID;
+  // a_L == NULL: the layer output is recomputed from its input (bf16 storage, MFMA generation)
+  if (!a_L && (!bf || algo == 1 || !bn_prev)) return DVA_ERR_UNSUPPORTED;
+  if (addend && (a_L || !group_of_row)) return DVA_ERR_INVALID;
   if (!bn_prev && (!raw_out || algo == 1 || prev_is_xmap)) return DVA_ERR_UNSUPPORTED;
   if (!raw_out && !st_prev) return DVA_ERR_INVALID;
   if (prev_is_xmap && !Wa) return DVA_ERR_INVALID;
   if (dt && !group_of_row) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   if (algo != 1) {
-    dsm_launch_bwd_layer(dz_L_, a_L_, bn_L, sm_L, W_L, a_prev_, Wa, bn_prev, out_, dW, st_prev, dt,
-                         group_of_row, first_grad, V, prev_is_xmap, raw_out, bf, s);
+    if (dsm_launch_bwd_layer(dz_L_, a_L_, bn_L, sm_L, W_L, a_prev_, Wa, bn_prev, out_, dW, st_prev, dt,
+                             group_of_row, first_grad, addend, V, prev_is_xmap, raw_out, bf, s))
+      return DVA_ERR_UNSUPPORTED;
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }

@@ -584,11 +584,18 @@ __global__ __launch_bounds__(256) void dsm_fwd_first_kernel(const float* __restr
 
 // a_out[v] = leaky(BN_in(a_in[v])) . W^T (+ addend[vp[v]]) ; statistics of a_out.
 // SCORE: W has G <= 32 valid rows (others zero), bias added, only columns < G stored, no statistics.
-template <typename AT, bool HAS_ADD, bool SCORE>
+// STORE = false: statistics of a_out only (the activation is recomputed by its consumers instead of being
+//   stored: one [V, 32] write now and one read per consumer saved).
+// PRE (with SCORE): the scores are those of the layer AFTER this one: a_mid = leaky(BN_in(a_in)).W^T is
+//   recomputed in registers (it was never stored) and out = leaky(BN2(a_mid)).W2^T + bias.
+template <typename AT, bool HAS_ADD, bool SCORE, bool STORE = true, bool PRE = false>
 __global__ __launch_bounds__(256, (HAS_ADD ? 2 : 3)) void dsm_fwd_layer_kernel(
     const AT* __restrict__ a_in, const float* __restrict__ bn_in, const float* __restrict__ W,
     const float* __restrict__ addend, const int32_t* __restrict__ vp, const float* __restrict__ bias,
-    void* __restrict__ a_out_, double* __restrict__ stats, int64_t V, int G) {
+    void* __restrict__ a_out_, double* __restrict__ stats, int64_t V, int G,
+    const float* __restrict__ bn2, const float* __restrict__ W2) {
+  static_assert(!PRE || SCORE, "PRE is a score variant");
+  __shared__ __attribute__((aligned(16))) float s_bn2[PRE ? 4 : 1][DM];
   // SCORE writes the fp32 compatibilities [V, G]; layers write activations in the storage type
   float* __restrict__ c_out = reinterpret_cast<float*>(a_out_);
   AT* __restrict__ a_out = reinterpret_cast<AT*>(a_out_);
@@ -597,13 +604,21 @@ __global__ __launch_bounds__(256, (HAS_ADD ? 2 : 3)) void dsm_fwd_layer_kernel(
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const bool ident = bn_in == nullptr;  // raw input (no BatchNorm / activation), e.g. pooled set features
   stage_bn(s_bn, bn_in);
+  if (PRE) stage_bn(s_bn2, bn2);
   __syncthreads();
   ViewProd<AT> pw;  // W[n=j][16h + s]
   {
     float w[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) w[s] = (!SCORE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
+    for (int s = 0; s < 16; ++s) w[s] = (!SCORE || PRE || j < G) ? W[j * DM + 16 * h + s] : 0.f;
     pw.prep(w);
+  }
+  ViewProd<AT> pw2;  // PRE: W2[g=j][acc_chan(r, h)] (the recomputed layer comes out in the accumulator layout)
+  if (PRE) {
+    float w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = j < G ? W2[j * DM + acc_chan(r, h)] : 0.f;
+    pw2.prep(w);
   }
   float bia[16];
   if (SCORE) {
@@ -637,6 +652,16 @@ __global__ __launch_bounds__(256, (HAS_ADD ? 2 : 3)) void dsm_fwd_layer_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) xin[s] = ok ? (ident ? x[s] : leaky_m(zx[s])) : 0.f;
     acc = pw.mul(xin, acc);
+    if (PRE) {
+      float am[16], ah2[16], z2[16], x2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) am[r] = acc[r];
+      bn_norm16<true>(s_bn2, h, am, ah2, z2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[r] = leaky_m(z2[r]);
+      f32x16 acc2 = {0};
+      acc = pw2.mul(x2, acc2);
+    }
     if (SCORE) {
       // scores [V, G] fp32; lanes / registers without a score column store out of bounds (dropped)
       const RowTile C(c_out, t * 32, V, G * 4);
@@ -655,7 +680,7 @@ __global__ __launch_bounds__(256, (HAS_ADD ? 2 : 3)) void dsm_fwd_layer_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += ad[r];
       }
-      tile_store_acc<AT>(RowTile(a_out, t * 32, V, RB), j, h, acc);
+      if (STORE) tile_store_acc<AT>(RowTile(a_out, t * 32, V, RB), j, h, acc);
       if (ok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -678,14 +703,19 @@ __global__ __launch_bounds__(256, (HAS_ADD ? 2 : 3)) void dsm_fwd_layer_kernel(
 //   P = sum_v dz1 x^T,  Q = sum_v a1_hat x^T,  SX = sum_v x     (first = P[32][8] | Q[32][8] | SX[8])
 // so P, Q, SX are accumulated here (two more channel-major bf16 products per tile) and dz1 is never
 // written: saves the dva_deepset_bwd_first pass and 2 x V x 64 bytes of traffic.
-template <typename AT, bool PREV_XMAP, bool RAW_OUT, bool HAS_DT, bool FUSE1 = false>
+// RC (bf16 storage): a_L is not read but RECOMPUTED from the layer input, a_L = leaky(BN_prev(a_prev)).W_L^T
+//   (+ addend[point] for the concatenation layer): 3 tensors per view instead of 4 cross the memory system
+//   for one more product on the (idle) matrix cores.  Everything then lives in the accumulator layout:
+//   dz_L is loaded in it, da and the dx product use W_L rows indexed by acc_chan.
+template <typename AT, bool PREV_XMAP, bool RAW_OUT, bool HAS_DT, bool FUSE1 = false, bool RC = false>
 __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
     const AT* __restrict__ dz_L, const AT* __restrict__ a_L, const float* __restrict__ bn_L,
     const float* __restrict__ sm_L, const float* __restrict__ W_L, const void* __restrict__ a_prev_,
     const float* __restrict__ Wa, const float* __restrict__ bn_prev, AT* __restrict__ out,
     float* __restrict__ dW, double* __restrict__ st_prev, float* __restrict__ dt,
-    const int32_t* __restrict__ vp, float* __restrict__ first, int64_t V) {
+    const int32_t* __restrict__ vp, float* __restrict__ first, const float* __restrict__ addend, int64_t V) {
   static_assert(!FUSE1 || (PREV_XMAP && !RAW_OUT && !HAS_DT && sizeof(AT) == 2), "FUSE1 variant");
+  static_assert(!RC || sizeof(AT) == 2, "RC variant: bf16 storage");
   // per-wavefront transposed bf16 tiles of the fused first-layer products: dz1 | a1_hat | x (32 rows each)
   __shared__ __attribute__((aligned(16))) bf16_t s_f1[FUSE1 ? 4 : 1][FUSE1 ? 96 * TSB : 8];
   // the layer input: raw x_map rows (fp32 [V, 8]) or activations in the storage type
@@ -709,12 +739,19 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
   __syncthreads();
   const bool pident = bn_prev == nullptr;  // the layer input is raw (only valid with RAW_OUT)
   constexpr bool BF = sizeof(AT) == 2;
-  ViewProd<AT> pt;  // W_L[n = 16h + s][k = j]
+  ViewProd<AT> pt;  // W_L[n = 16h + s][k = j]  (RC: n = acc_chan(s, h))
   {
     float wt[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) wt[s] = W_L[(16 * h + s) * DM + j];
+    for (int s = 0; s < 16; ++s) wt[s] = W_L[(RC ? acc_chan(s, h) : 16 * h + s) * DM + j];
     pt.prep(wt);
+  }
+  ViewProd<AT> pf;  // RC: forward weights W_L[n = j][c = acc_chan(r, h)]
+  if (RC) {
+    float wf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wf[r] = W_L[j * DM + acc_chan(r, h)];
+    pf.prep(wf);
   }
   ViewProd4<AT> p4;
   if (PREV_XMAP) {
@@ -740,38 +777,75 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
   }
 
   struct Raw {
-    HalfRow<AT> dz, al;
+    HalfRow<AT> dz, al;      // (RC: dz holds the row in the accumulator layout, al is unused)
     AccRow<AT> ap;
     float4 xm;
     int32_t pnt;
   };
   constexpr int RB = DM * (int)sizeof(AT);
+  constexpr bool NEED_P = HAS_DT;
   for_each_tile_pf<(sizeof(AT) == 2) && !HAS_DT && !FUSE1>(V, [&](int64_t t) {
     // ---- the tile is read ONCE, view-major (each lane: half a row of dz_L, a_L; a_prev in the
     //      accumulator layout); the channel-major operands of the weight gradient come from LDS
     Raw r;
-    r.dz = tile_load_half<AT>(RowTile(dz_L, t * 32, V, RB), j, h);
-    r.al = tile_load_half<AT>(RowTile(a_L, t * 32, V, RB), j, h);
+    r.dz = tile_load_half<AT>(RowTile(dz_L, t * 32, V, RB), j, h);   // RC: swapped into acc layout at unpack
+    if (!RC) r.al = tile_load_half<AT>(RowTile(a_L, t * 32, V, RB), j, h);
     if (PREV_XMAP) r.xm = as_f4(RowTile(x_prev, t * 32, V, 32).b128(j * 32 + h * 16));
     else r.ap = tile_load_acc<AT>(RowTile(a_prev, t * 32, V, RB), j, h);
-    r.pnt = HAS_DT ? (int32_t)RowTile(vp, t * 32, V, 4).b32(j * 4) : 0;
+    r.pnt = NEED_P ? (int32_t)RowTile(vp, t * 32, V, 4).b32(j * 4) : 0;
     return r;
   }, [&](int64_t t, const Raw& raw) {
     const int64_t row0 = t * 32;
     const int64_t v = row0 + j;
     const bool ok = v < V;
     float dzv[16], alv[16], ap[16];
-    unpack(raw.dz, dzv);
-    unpack(raw.al, alv);
+    if (RC) {
+      AccRow<AT> dq;                   // same bytes, accumulator-layout view (bf16: half row + permlane swap)
+      dq.q[0] = raw.dz.q[0];
+      dq.q[1] = raw.dz.q[1];
+      unpack(dq, dzv);
+    } else {
+      unpack(raw.dz, dzv);
+      unpack(raw.al, alv);
+    }
     if (!PREV_XMAP) unpack(raw.ap, ap);
     const float4 xm = raw.xm;
     const int32_t pnt = raw.pnt;
+    // ---------------- (PREV_XMAP) a1 = x_map . Wa^T;  x_L = leaky(BN_prev(a_prev)), accumulator layout.
+    // RC needs x_L first (a_L is recomputed from it); the other variants compute it after the dx product,
+    // which keeps 48 registers out of the da / dx phase.
+    float ahp[16], zp[16], xl[16];
+    auto input_side = [&]() {
+      if (PREV_XMAP) {
+        f32x16 a1 = {0};
+        a1 = p4.mul(xm, a1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ap[r] = a1[r];
+      }
+      bn_norm16<true>(s_p, h, ap, ahp, zp);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xl[r] = ok ? (pident ? ap[r] : leaky_m(zp[r])) : 0.f;
+    };
+    if (RC) input_side();
+    if (RC) {
+      // ---------------- a_L recomputed: x_L . W_L^T (+ the per-point addend of the concatenation layer)
+      f32x16 aL = {0};
+      aL = pf.mul(xl, aL);
+      if (HAS_DT && addend) {
+        float ad[16];
+        load_acc_layout(addend + (int64_t)pnt * DM, h, ad);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aL[r] += ad[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) alv[r] = aL[r];
+    }
     // ---------------- da = BN_L-backward(dz_L); view-major product dx = da . W_L
     float da[16];
     f32x16 accx = {0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int base = 16 * h + 4 * q;
+      const int base = RC ? 8 * q + 4 * h : 16 * h + 4 * q;
       const float4 g4 = *reinterpret_cast<const float4*>(&s_c[0][base]);
       const float4 m4 = *reinterpret_cast<const float4*>(&s_c[1][base]);
       const float4 i4 = *reinterpret_cast<const float4*>(&s_c[2][base]);
@@ -788,19 +862,11 @@ __global__ __launch_bounds__(256, 2) void dsm_bwd_layer_kernel(
       }
     }
     accx = pt.mul(da, accx);
-    if (BF) tileT_put_half(reinterpret_cast<bf16_t*>(tda), j, h, da);
+    if (RC) tileT_put_acc(reinterpret_cast<bf16_t*>(tda), j, h, da);
+    else if (BF) tileT_put_half(reinterpret_cast<bf16_t*>(tda), j, h, da);
     else tile_put_half(tda, j, h, da);
-    // ---------------- x_L = leaky(BN_prev(a_prev)) in the accumulator layout -> LDS; dz_prev
-    if (PREV_XMAP) {
-      f32x16 a1 = {0};
-      a1 = p4.mul(xm, a1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ap[r] = a1[r];
-    }
-    float ahp[16], zp[16], xl[16];
-    bn_norm16<true>(s_p, h, ap, ahp, zp);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xl[r] = ok ? (pident ? ap[r] : leaky_m(zp[r])) : 0.f;
+    // ---------------- x_L -> LDS; dz_prev
+    if (!RC) input_side();
     if (BF) tileT_put_acc(reinterpret_cast<bf16_t*>(tx), j, h, xl);
     else tile_put_acc(tx, j, h, xl);
     if (!RAW_OUT) {
@@ -999,18 +1065,30 @@ __global__ __launch_bounds__(256) void dsm_bwd_max_kernel(
 // Score layer backward on the matrix cores: out = f(a4).Ws^T + bs with f = leaky(BN4(.)).
 //   dz4[v,k] = (sum_g dc[v,g] Ws[g,k]) * leaky'(z4[v,k])   (view-major, ceil(G/2) k-steps)
 //   dWs[g,k] = sum_v dc[v,g] f(a4)[v,k],  dbs[g] = sum_v dc[v,g]   (channel-major, 16 k-steps)
-template <typename AT>
+// PRE: `a` is the input of the layer before the scores (never-stored activation recomputed here as
+//   leaky(BN_pre(a)).W_pre^T, see dsm_fwd_layer_kernel).
+template <typename AT, bool PRE = false>
 __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
     const float* __restrict__ dcompat, const AT* __restrict__ a, const float* __restrict__ bn,
     const float* __restrict__ Ws, AT* __restrict__ dz, float* __restrict__ dWs,
-    float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G) {
+    float* __restrict__ dbs, double* __restrict__ st, int64_t V, int G, const float* __restrict__ bn_pre,
+    const float* __restrict__ W_pre) {
   __shared__ float s_red[DM * DM];
   __shared__ __attribute__((aligned(16))) float s_p[4][DM];
+  __shared__ __attribute__((aligned(16))) float s_pre[PRE ? 4 : 1][DM];
   __shared__ __attribute__((aligned(16))) float s_x[4][32 * TS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const int GH = (G + 1) / 2;  // k-step s pairs score columns (s, s + GH)
   stage_bn(s_p, bn);
+  if (PRE) stage_bn(s_pre, bn_pre);
   __syncthreads();
+  ViewProd<AT> ppre;  // W_pre[n = j][acc_chan(r, h)]
+  if (PRE) {
+    float w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = W_pre[j * DM + acc_chan(r, h)];
+    ppre.prep(w);
+  }
   float* tx = s_x[wv];
   f32x16 accW = {0};
   float db = 0.f;
@@ -1048,6 +1126,16 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
     const int64_t vc = ok ? v : V - 1;
     float ap[16];
     unpack(raw.ap, ap);
+    if (PRE) {
+      float ah0[16], z0[16], x0[16];
+      bn_norm16<true>(s_pre, h, ap, ah0, z0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x0[r] = leaky_m(z0[r]);
+      f32x16 am = {0};
+      am = ppre.mul(x0, am);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ap[r] = am[r];
+    }
     const float (&dcr)[16] = raw.dcr;
     f32x16 accx = {0};
     if (G == 4) {
@@ -1137,13 +1225,15 @@ template <typename AT>
 static void launch_fwd_layer(const void* a_in, const float* bn_in, const float* W, const float* addend,
                              const int32_t* vp, void* a_out, double* stats, int64_t V, hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
-  if (addend)
-    hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, true, false>), grid, block, 0, s, (const AT*)a_in, bn_in, W,
-                       addend, vp, (const float*)nullptr, a_out, stats, V, 32);
-  else
-    hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, false, false>), grid, block, 0, s, (const AT*)a_in, bn_in,
-                       W, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, a_out,
-                       stats, V, 32);
+  const float* nf = nullptr;
+#define DVA_F(ADD, ST)                                                                                \
+  hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, ADD, false, ST, false>), grid, block, 0, s, (const AT*)a_in, \
+                     bn_in, W, addend, vp, nf, a_out, stats, V, 32, nf, nf)
+  if (addend && a_out) DVA_F(true, true);
+  else if (addend) DVA_F(true, false);
+  else if (a_out) DVA_F(false, true);
+  else DVA_F(false, false);
+#undef DVA_F
 }
 int dsm_launch_fwd_layer(const void* a_in, const float* bn_in, const float* W, const float* addend,
                          const int32_t* vp, void* a_out, double* stats, int64_t V, int bf, hipStream_t s) {
@@ -1152,55 +1242,69 @@ int dsm_launch_fwd_layer(const void* a_in, const float* bn_in, const float* W, c
   return 0;
 }
 
-int dsm_launch_fwd_score(const void* a, const float* bn, const float* Ws, const float* bs, float* compat,
-                         int64_t V, int G, int bf, hipStream_t s) {
+template <typename AT>
+static void launch_fwd_score(const void* a, const float* bn, const float* Ws, const float* bs, float* compat,
+                             int64_t V, int G, const float* bn_pre, const float* W_pre, hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
-  DVA_ACT(bf,
-          hipLaunchKernelGGL((dsm_fwd_layer_kernel<float, false, true>), grid, block, 0, s, (const float*)a,
-                             bn, Ws, (const float*)nullptr, (const int32_t*)nullptr, bs, (void*)compat,
-                             (double*)nullptr, V, G),
-          hipLaunchKernelGGL((dsm_fwd_layer_kernel<bf16_t, false, true>), grid, block, 0, s,
-                             (const bf16_t*)a, bn, Ws, (const float*)nullptr, (const int32_t*)nullptr, bs,
-                             (void*)compat, (double*)nullptr, V, G));
+  const float* nf = nullptr;
+  const int32_t* ni = nullptr;
+  if (W_pre)   // a = input of the layer BEFORE the scores: (bn_pre, W_pre) first, then (bn, Ws)
+    hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, false, true, true, true>), grid, block, 0, s, (const AT*)a,
+                       bn_pre, W_pre, nf, ni, bs, (void*)compat, (double*)nullptr, V, G, bn, Ws);
+  else
+    hipLaunchKernelGGL((dsm_fwd_layer_kernel<AT, false, true, true, false>), grid, block, 0, s, (const AT*)a, bn,
+                       Ws, nf, ni, bs, (void*)compat, (double*)nullptr, V, G, nf, nf);
+}
+int dsm_launch_fwd_score(const void* a, const float* bn, const float* Ws, const float* bs, float* compat,
+                         int64_t V, int G, const float* bn_pre, const float* W_pre, int bf, hipStream_t s) {
+  DVA_ACT(bf, launch_fwd_score<float>(a, bn, Ws, bs, compat, V, G, bn_pre, W_pre, s),
+          launch_fwd_score<bf16_t>(a, bn, Ws, bs, compat, V, G, bn_pre, W_pre, s));
   return 0;
 }
 
 template <typename AT>
-static void launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
-                             const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
-                             void* out, float* dW, double* st_prev, float* dt, const int32_t* vp,
-                             float* first, int64_t V, int prev_is_xmap, int raw_out, hipStream_t s) {
+static int launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
+                            const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
+                            void* out, float* dW, double* st_prev, float* dt, const int32_t* vp,
+                            float* first, const float* addend, int64_t V, int prev_is_xmap, int raw_out,
+                            hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
-#define DVA_L(P, R, T)                                                                               \
-  hipLaunchKernelGGL((dsm_bwd_layer_kernel<AT, P, R, T>), grid, block, 0, s, (const AT*)dz_L,        \
-                     (const AT*)a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, (AT*)out, dW, st_prev, dt, \
-                     vp, (float*)nullptr, V)
+#define DVA_L(P, R, T, F, C)                                                                            \
+  hipLaunchKernelGGL((dsm_bwd_layer_kernel<AT, P, R, T, F, C>), grid, block, 0, s, (const AT*)dz_L,     \
+                     (const AT*)a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, (AT*)out, dW, st_prev, dt, vp, \
+                     first, addend, V)
   if constexpr (sizeof(AT) == 2) {
+    if (!a_L) {   // recompute variants (bf16 storage): the three layers of the element-wise MLPs
+      if (first && prev_is_xmap && !raw_out && !dt) DVA_L(true, false, false, true, true);
+      else if (!prev_is_xmap && raw_out && dt) DVA_L(false, true, true, false, true);
+      else if (!prev_is_xmap && !raw_out && !dt && !first) DVA_L(false, false, false, false, true);
+      else return -2;
+      return 0;
+    }
     if (first) {
-      hipLaunchKernelGGL((dsm_bwd_layer_kernel<AT, true, false, false, true>), grid, block, 0, s,
-                         (const AT*)dz_L, (const AT*)a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, (AT*)out, dW,
-                         st_prev, dt, vp, first, V);
-      return;
+      DVA_L(true, false, false, true, false);
+      return 0;
     }
   }
-  if (prev_is_xmap && raw_out) DVA_L(true, true, false);
-  else if (prev_is_xmap) DVA_L(true, false, false);
-  else if (raw_out && dt) DVA_L(false, true, true);
-  else if (raw_out) DVA_L(false, true, false);
-  else if (dt) DVA_L(false, false, true);
-  else DVA_L(false, false, false);
+  if (!a_L) return -2;
+  if (prev_is_xmap && raw_out) DVA_L(true, true, false, false, false);
+  else if (prev_is_xmap) DVA_L(true, false, false, false, false);
+  else if (raw_out && dt) DVA_L(false, true, true, false, false);
+  else if (raw_out) DVA_L(false, true, false, false, false);
+  else if (dt) DVA_L(false, false, true, false, false);
+  else DVA_L(false, false, false, false, false);
 #undef DVA_L
+  return 0;
 }
 int dsm_launch_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
                          const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
                          void* out, float* dW, double* st_prev, float* dt, const int32_t* vp, float* first,
-                         int64_t V, int prev_is_xmap, int raw_out, int bf, hipStream_t s) {
-  DVA_ACT(bf,
-          launch_bwd_layer<float>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp,
-                                  first, V, prev_is_xmap, raw_out, s),
-          launch_bwd_layer<bf16_t>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt,
-                                   vp, first, V, prev_is_xmap, raw_out, s));
-  return 0;
+                         const float* addend, int64_t V, int prev_is_xmap, int raw_out, int bf, hipStream_t s) {
+  if (bf)
+    return launch_bwd_layer<bf16_t>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp,
+                                    first, addend, V, prev_is_xmap, raw_out, s);
+  return launch_bwd_layer<float>(dz_L, a_L, bn_L, sm_L, W_L, a_prev, Wa, bn_prev, out, dW, st_prev, dt, vp,
+                                 first, addend, V, prev_is_xmap, raw_out, s);
 }
 
 int dsm_launch_bwd_max(const void* dcat, const void* a2, const float* bn2, const int32_t* arg,
@@ -1216,13 +1320,20 @@ int dsm_launch_bwd_max(const void* dcat, const void* a2, const float* bn2, const
 }
 
 int dsm_launch_bwd_score(const float* dcompat, const void* a, const float* bn, const float* Ws, void* dz,
-                         float* dWs, float* dbs, double* st, int64_t V, int G, int bf, hipStream_t s) {
+                         float* dWs, float* dbs, double* st, int64_t V, int G, const float* bn_pre,
+                         const float* W_pre, int bf, hipStream_t s) {
   const dim3 grid(grid_tiles(V)), block(256);
+  if (W_pre) {   // bf16 storage only (checked by the caller)
+    hipLaunchKernelGGL((dsm_bwd_score_kernel<bf16_t, true>), grid, block, 0, s, dcompat, (const bf16_t*)a, bn, Ws,
+                       (bf16_t*)dz, dWs, dbs, st, V, G, bn_pre, W_pre);
+    return 0;
+  }
+  const float* nf = nullptr;
   DVA_ACT(bf,
-          hipLaunchKernelGGL((dsm_bwd_score_kernel<float>), grid, block, 0, s, dcompat, (const float*)a, bn,
-                             Ws, (float*)dz, dWs, dbs, st, V, G),
-          hipLaunchKernelGGL((dsm_bwd_score_kernel<bf16_t>), grid, block, 0, s, dcompat, (const bf16_t*)a,
-                             bn, Ws, (bf16_t*)dz, dWs, dbs, st, V, G));
+          hipLaunchKernelGGL((dsm_bwd_score_kernel<float, false>), grid, block, 0, s, dcompat, (const float*)a,
+                             bn, Ws, (float*)dz, dWs, dbs, st, V, G, nf, nf),
+          hipLaunchKernelGGL((dsm_bwd_score_kernel<bf16_t, false>), grid, block, 0, s, dcompat,
+                             (const bf16_t*)a, bn, Ws, (bf16_t*)dz, dWs, dbs, st, V, G, nf, nf));
   return 0;
 }
 

@@ -19,6 +19,13 @@ from ._lib import check, ptr, require_device, stream_of
 D = 32
 # layer-kernel generation: 0 = fp32 matrix cores, 1 = VALU + LDS broadcast (tests flip this)
 ALGO = 0
+# bf16 storage only: layer outputs that are cheap to recompute are not stored / not re-read -- a4 is never
+# materialised, and the backward layer passes rebuild a_L from the layer input instead of reading it (one
+# [V, 32] tensor less per pass for one more product on the matrix cores).  Measured on MI355X (S1/F-S):
+# 8.6 GB less HBM traffic per step but 22.2 instead of 20.7 ms/step -- the passes are register / VALU limited
+# once the extra product and its BatchNorm are added (spills in the x_map variant) -- so it is OFF by default
+# and kept for parts with a lower bandwidth-to-VALU ratio.  Tests cover both settings.
+RECOMPUTE = False
 # storage type of the [V, 32] activation / gradient tensors between the kernels.  None = auto: bf16 inside
 # torch.autocast(bfloat16) (what the reference's autocast keeps for these tensors; arithmetic, statistics
 # and parameters stay fp32 here), fp32 otherwise.  Tests pin it.
@@ -155,19 +162,33 @@ class _DeepSetLinear(torch.autograd.Function):
                                             AC, st),
                   "dva_deepset_fwd_layer")
         bn3 = _bn_consts(s3, V, bns[2], training)
-        a4 = torch.empty((V, D), dtype=act, device=dev)
+        recompute = RECOMPUTE and act == torch.bfloat16 and ALGO == 0
         s4 = zstats()
-        with ops._timed("deepset_fwd_layer", V * 2 * RB):
-            check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, ALGO, AC, st),
-                  "dva_deepset_fwd_layer")
+        if recompute:
+            # statistics of a4 only; the scores pass recomputes a4 from a3 in registers
+            a4 = None
+            with ops._timed("deepset_fwd_layer_stats", V * RB):
+                check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, None, ptr(s4), V, ALGO, AC, st),
+                      "dva_deepset_fwd_layer")
+        else:
+            a4 = torch.empty((V, D), dtype=act, device=dev)
+            with ops._timed("deepset_fwd_layer", V * 2 * RB):
+                check(lib.dva_deepset_fwd_layer(ptr(a3), ptr(bn3), ptr(Wd), None, None, ptr(a4), ptr(s4), V, ALGO, AC, st),
+                      "dva_deepset_fwd_layer")
         bn4 = _bn_consts(s4, V, bns[3], training)
         # ---- trailing Linear (E_score / K)
         out = torch.empty((V, G), dtype=torch.float32, device=dev)
         with ops._timed("deepset_fwd_score", V * (RB + 4 * G)):
-            check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, ALGO, AC, st),
-                  "dva_deepset_fwd_score")
+            if recompute:
+                check(lib.dva_deepset_fwd_score(ptr(a3), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, ptr(bn3), ptr(Wd),
+                                                ALGO, AC, st), "dva_deepset_fwd_score")
+            else:
+                check(lib.dva_deepset_fwd_score(ptr(a4), ptr(bn4), ptr(Ws), ptr(bs), ptr(out), V, G, None, None,
+                                                ALGO, AC, st), "dva_deepset_fwd_score")
 
-        ctx.save_for_backward(x_map, csr_idx, vp, a2, a3, a4, arg, bn1, bn2, bn3, bn4, Wa, Wb, WcA, Wd, Ws)
+        ctx.save_for_backward(x_map, csr_idx, vp, a2, a3, a4 if a4 is not None else a3, arg, bn1, bn2, bn3, bn4,
+                              Wa, Wb, WcA, Wd, Ws)
+        ctx.recompute = recompute
         ctx.set_branch = (pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx)
         ctx.modules = (e_map, linear)
         ctx.training = training
@@ -208,24 +229,27 @@ class _DeepSetLinear(torch.autograd.Function):
         dz4, s4 = buf(), zstats()
         dWs = torch.zeros_like(Ws)
         dbs = torch.zeros(G, dtype=torch.float32, device=dev)
+        rc = ctx.recompute          # a4 was never stored (the saved slot holds a3); a_L rebuilt from the layer input
         with ops._timed("deepset_bwd_score", V * (2 * RB + 4 * G)):
-            check(lib.dva_deepset_bwd_score(ptr(dout), ptr(a4), ptr(bn4), ptr(Ws), ptr(dz4), ptr(dWs), ptr(dbs),
-                                            ptr(s4), V, G, ALGO, AC, st), "dva_deepset_bwd_score")
+            check(lib.dva_deepset_bwd_score(ptr(dout), ptr(a3 if rc else a4), ptr(bn4), ptr(Ws), ptr(dz4), ptr(dWs),
+                                            ptr(dbs), ptr(s4), V, G, ptr(bn3) if rc else None,
+                                            ptr(Wd) if rc else None, ALGO, AC, st), "dva_deepset_bwd_score")
         # Wd layer (a3 -> a4)
         dz3, s3, dWd = buf(), zstats(), torch.zeros_like(Wd)
         sm4 = sm_of(s4)
-        with ops._timed("deepset_bwd_layer", V * RB * 4):
-            check(lib.dva_deepset_bwd_layer(ptr(dz4), ptr(a4), ptr(bn4), ptr(sm4), ptr(Wd), ptr(a3), None, ptr(bn3),
-                                            ptr(dz3), ptr(dWd), ptr(s3), None, None, None, V, 0, 0, ALGO, AC, st),
-                  "dva_deepset_bwd_layer")
+        with ops._timed("deepset_bwd_layer", V * RB * (3 if rc else 4)):
+            check(lib.dva_deepset_bwd_layer(ptr(dz4), None if rc else ptr(a4), ptr(bn4), ptr(sm4), ptr(Wd), ptr(a3),
+                                            None, ptr(bn3), ptr(dz3), ptr(dWd), ptr(s3), None, None, None, None, V,
+                                            0, 0, ALGO, AC, st), "dva_deepset_bwd_layer")
         del dz4
         # Wc layer (cat(h1, set) -> a3): raw dx on the h1 half, per-point sum on the set half
         dcat, dWcA = buf(), torch.zeros_like(WcA)
         dt = torch.zeros((N, D), dtype=torch.float32, device=dev)
         sm3 = sm_of(s3)
-        with ops._timed("deepset_bwd_layer_cat", V * (RB * 4 + 4) + N * 128):
-            check(lib.dva_deepset_bwd_layer(ptr(dz3), ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2), None, ptr(bn2),
-                                            ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), None, V, 0, 1, ALGO, AC, st),
+        with ops._timed("deepset_bwd_layer_cat", V * (RB * (3 if rc else 4) + 4) + N * 128):
+            check(lib.dva_deepset_bwd_layer(ptr(dz3), None if rc else ptr(a3), ptr(bn3), ptr(sm3), ptr(WcA), ptr(a2),
+                                            None, ptr(bn2), ptr(dcat), ptr(dWcA), None, ptr(dt), ptr(vp), None,
+                                            ptr(t_add) if rc else None, V, 0, 1, ALGO, AC, st),
                   "dva_deepset_bwd_layer")
         del dz3
         # set branch backward with the same layer kernels over the N points
@@ -235,21 +259,21 @@ class _DeepSetLinear(torch.autograd.Function):
         dWcB = torch.zeros_like(WcB)
         dzs2, ss2 = buf(N, torch.float32), zstats()
         check(lib.dva_deepset_bwd_layer(ptr(dt), ptr(t_add), ptr(ident_bn), ptr(zero_sm), ptr(WcB), ptr(u2), None,
-                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, None, N, 0, 0, 0, F32C, st),
+                                        ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, None, None, N, 0, 0, 0, F32C, st),
               "dva_deepset_bwd_layer")
         dWsb = torch.zeros_like(Wsb)
         dzs1, ss1 = buf(N, torch.float32), zstats()
         sms2 = sm_of(ss2, n_rows)
         check(lib.dva_deepset_bwd_layer(ptr(dzs2), ptr(u2), ptr(bns2), ptr(sms2), ptr(Wsb), ptr(u1), None,
-                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, None, N, 0, 0, 0, F32C, st),
+                                        ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, None, None, N, 0, 0, 0, F32C, st),
               "dva_deepset_bwd_layer")
         dWsaP = torch.zeros_like(WsaP)
         dpooled = buf(N, torch.float32)
         da1 = torch.zeros((N, D), dtype=torch.float32, device=dev) if num is not None else None
         sms1 = sm_of(ss1, n_rows)
         check(lib.dva_deepset_bwd_layer(ptr(dzs1), ptr(u1), ptr(bns1), ptr(sms1), ptr(WsaP), ptr(pooled), None,
-                                        None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), None, N, 0, 1,
-                                        0, F32C, st), "dva_deepset_bwd_layer")
+                                        None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), None, None, N, 0,
+                                        1, 0, F32C, st), "dva_deepset_bwd_layer")
         if num is not None:
             dWsa = torch.cat([dWsaP, (da1 * num.view(-1, 1)).sum(0).view(-1, 1)], dim=1)
         else:
@@ -269,10 +293,10 @@ class _DeepSetLinear(torch.autograd.Function):
             # first layer folded in: the pass also accumulates P | Q | SX (BN1-backward is linear in the
             # statistics it produces), dz1 is never written and there is no bwd_first pass
             first = torch.zeros(520, dtype=torch.float32, device=dev)
-            with ops._timed("deepset_bwd_layer_xmap_first", V * (RB * 2 + 32)):
-                check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
-                                                ptr(bn1), None, ptr(dWb), ptr(s1), None, None, ptr(first), V, 1, 0,
-                                                ALGO, AC, st), "dva_deepset_bwd_layer")
+            with ops._timed("deepset_bwd_layer_xmap_first", V * (RB * (1 if rc else 2) + 32)):
+                check(lib.dva_deepset_bwd_layer(ptr(dz2), None if rc else ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb),
+                                                ptr(x_map), ptr(Wa), ptr(bn1), None, ptr(dWb), ptr(s1), None, None,
+                                                ptr(first), None, V, 1, 0, ALGO, AC, st), "dva_deepset_bwd_layer")
             del dz2
             sm1 = sm_of(s1)
             P, Q, SX = first[:256].view(D, 8), first[256:512].view(D, 8), first[512:]
@@ -282,7 +306,7 @@ class _DeepSetLinear(torch.autograd.Function):
             dz1 = buf()
             with ops._timed("deepset_bwd_layer_xmap", V * (RB * 3 + 32)):
                 check(lib.dva_deepset_bwd_layer(ptr(dz2), ptr(a2), ptr(bn2), ptr(sm2), ptr(Wb), ptr(x_map), ptr(Wa),
-                                                ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, None, V, 1, 0,
+                                                ptr(bn1), ptr(dz1), ptr(dWb), ptr(s1), None, None, None, None, V, 1, 0,
                                                 ALGO, AC, st), "dva_deepset_bwd_layer")
             del dz2
             dWa = torch.zeros_like(Wa)

@@ -222,17 +222,22 @@ int dva_deepset_segmax(const void* a, const float* bn, const int64_t* ptr, float
                        int32_t* arg, int64_t N, int32_t act_dtype, void* stream);
 /* a_out[v] = leaky(BN_in(a_in[v])).W^T (+ addend[group_of_row[v]]) with statistics of a_out.
  * The addend carries the set half of the concatenation: cat(x, x_set).Wc^T = x.WcA^T + (x_set.WcB^T)[p]
- * (pooling.py:666-668).  bn_in == NULL: the input is used raw (set MLP on the pooled features). */
+ * (pooling.py:666-668).  bn_in == NULL: the input is used raw (set MLP on the pooled features).
+ * a_out == NULL (algo 0): statistics only -- the activation is recomputed by its consumers. */
 int dva_deepset_fwd_layer(const void* a_in, const float* bn_in, const float* W, const float* addend,
                           const int32_t* group_of_row, void* a_out, double* stats, int64_t V,
                           int32_t algo, int32_t act_dtype, void* stream);
-/* out[v, g] = leaky(BN(a[v])).Ws[g] + bs[g], G <= 32 (E_score, pooling.py:258,:282; also Q/K). */
+/* out[v, g] = leaky(BN(a[v])).Ws[g] + bs[g], G <= 32 (E_score, pooling.py:258,:282; also Q/K).
+ * (bn_pre, W_pre) non-NULL (algo 0): `a` is the INPUT of the layer before the scores and that layer's
+ * output is recomputed in registers, a_mid = leaky(BN_pre(a)).W_pre^T, instead of having been stored
+ * (the statistics of a_mid come from dva_deepset_fwd_layer with a_out == NULL). */
 int dva_deepset_fwd_score(const void* a, const float* bn, const float* Ws, const float* bs,
-                          float* compat, int64_t V, int32_t G, int32_t algo, int32_t act_dtype,
-                          void* stream);
+                          float* compat, int64_t V, int32_t G, const float* bn_pre, const float* W_pre,
+                          int32_t algo, int32_t act_dtype, void* stream);
 int dva_deepset_bwd_score(const float* dcompat, const void* a, const float* bn, const float* Ws,
                           void* dz, float* dWs, float* dbs, double* st, int64_t V, int32_t G,
-                          int32_t algo, int32_t act_dtype, void* stream);
+                          const float* bn_pre, const float* W_pre, int32_t algo, int32_t act_dtype,
+                          void* stream);
 /* Backward of one layer: da_L = BN-backward(dz_L), dW_L += da_L^T x_L, dx = da_L.W_L;
  * out = dx (raw_out) or dz_prev = dx*leaky'(BN_prev(a_prev)) with S1/S2 of BN_prev in st_prev;
  * dt[group_of_row[v]] += da_L[v] (nullable). prev_is_xmap: a_prev is x_map [V,8] and the previous
@@ -242,11 +247,15 @@ int dva_deepset_bwd_score(const float* dcompat, const void* a, const float* bn, 
  * P[32][8] | Q[32][8] | SX[8] with P = sum_v dz_prev x^T, Q = sum_v a_prev_hat x^T, SX = sum_v x, from
  * which the first layer's weight gradient follows without another pass (BN-backward is linear in the
  * statistics): dWa[n][f] = gamma invstd (P - (S1/M)[n] SX[f] - (S2/M)[n] Q)[n][f].  `out` is then not
- * written (may be NULL) and dva_deepset_bwd_first is not needed. */
+ * written (may be NULL) and dva_deepset_bwd_first is not needed.
+ * a_L == NULL (DVA_BF16 storage, algo 0, for the plain / dt+raw_out / first_grad forms): the layer output is
+ * not read but recomputed from its input, a_L = leaky(BN_prev(a_prev)).W_L^T (+ addend[group_of_row[v]],
+ * the per-point half of the concatenation layer, nullable): three [V, 32] tensors cross the memory system
+ * per view instead of four. */
 int dva_deepset_bwd_layer(const void* dz_L, const void* a_L, const float* bn_L, const float* sm_L,
                           const float* W_L, const void* a_prev, const float* Wa, const float* bn_prev,
                           void* out, float* dW, double* st_prev, float* dt,
-                          const int32_t* group_of_row, float* first_grad, int64_t V,
+                          const int32_t* group_of_row, float* first_grad, const float* addend, int64_t V,
                           int32_t prev_is_xmap, int32_t raw_out, int32_t algo, int32_t act_dtype,
                           void* stream);
 /* dz2 = (dcat + [arg[p]==v] dpooled[p]) * leaky'(BN2(a2)): joins the max-pool path (segment max

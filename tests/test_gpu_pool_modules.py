@@ -334,3 +334,40 @@ def test_deepset_bf16_activation_storage():
         assert fused_deepset._act_dtype() == torch.bfloat16
     print("bf16-storage error vs reference-autocast error per parameter:", report)
 
+
+
+def test_deepset_recompute_equals_stored_activations():
+    """bf16 storage with RECOMPUTE (a4 never stored, layer outputs rebuilt from the layer inputs in the
+    backward passes) against the stored-activation variant: same maths, the recomputed values are the fp32
+    ones instead of their bf16 roundings -> relative L2 differences at the 2^-9 level."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import fused_deepset
+    gen = torch.Generator().manual_seed(21)
+    N, C = 20011, 32
+    sizes = torch.randint(0, 9, (N,), generator=gen)
+    sizes[:40] = 70
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    m = P.GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=4, use_num=True).to(DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen).to(DEV) * 0.4)
+    x_mod = torch.randn(V, C, generator=gen).to(DEV)
+    x_map = torch.rand(V, 8, generator=gen).to(DEV)
+    w = torch.randn(N, C, generator=gen).to(DEV)
+    for train in (True, False):
+        m.train(train)
+        res = {}
+        for rc in (False, True):
+            fused_deepset.ACT_DTYPE, fused_deepset.RECOMPUTE = torch.bfloat16, rc
+            try:
+                out = m(None, x_mod, x_map, csr)
+                res[rc] = (out, torch.autograd.grad((out * w).sum(), list(m.parameters())))
+            finally:
+                fused_deepset.ACT_DTYPE, fused_deepset.RECOMPUTE = None, False
+        assert not torch.equal(res[True][0], res[False][0])
+        rel = float((res[True][0].detach() - res[False][0].detach()).norm() / res[False][0].detach().norm())
+        assert rel < 1e-2, rel
+        for (n, _), a, b in zip(m.named_parameters(), res[True][1], res[False][1]):
+            rel = float((a - b).norm() / (b.norm() + 1e-6))
+            assert rel < 1.5e-1, (n, rel)      # two bf16 schemes: each is ~10 % from fp32 on the deepest gradients
