@@ -80,14 +80,14 @@ KERNEL_SYMBOL = {
     "view_gather_attention_bwd": "att_bwd_team_kernel<unsigned short>",
     "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short>",
     "deepset_fwd_first": "dsm_fwd_first_kernel<unsigned short, false>",
-    "deepset_fwd_layer": "dsm_fwd_layer_kernel<unsigned short, false, false>",
-    "deepset_fwd_layer_add": "dsm_fwd_layer_kernel<unsigned short, true, false>",
-    "deepset_fwd_score": "dsm_fwd_layer_kernel<unsigned short, false, true>",
+    "deepset_fwd_layer": "dsm_fwd_layer_kernel<unsigned short, false, false, true, false>",
+    "deepset_fwd_layer_add": "dsm_fwd_layer_kernel<unsigned short, true, false, true, false>",
+    "deepset_fwd_score": "dsm_fwd_layer_kernel<unsigned short, false, true, true, false>",
     "deepset_segmax": "dsf_segmax_kernel<unsigned short>",
-    "deepset_bwd_score": "dsm_bwd_score_kernel<unsigned short>",
-    "deepset_bwd_layer": "dsm_bwd_layer_kernel<unsigned short, false, false, false, false>",
-    "deepset_bwd_layer_cat": "dsm_bwd_layer_kernel<unsigned short, false, true, true, false>",
-    "deepset_bwd_layer_xmap_first": "dsm_bwd_layer_kernel<unsigned short, true, false, false, true>",
+    "deepset_bwd_score": "dsm_bwd_score_kernel<unsigned short, false>",
+    "deepset_bwd_layer": "dsm_bwd_layer_kernel<unsigned short, false, false, false, false, false>",
+    "deepset_bwd_layer_cat": "dsm_bwd_layer_kernel<unsigned short, false, true, true, false, false>",
+    "deepset_bwd_layer_xmap_first": "dsm_bwd_layer_kernel<unsigned short, true, false, false, true, false>",
     "deepset_bwd_max": "dsm_bwd_max_kernel<unsigned short>",
 }
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
