@@ -46,3 +46,35 @@ def test_camera_struct_layout_matches_oracle():
     from oracle import mapping_oracle as M
     assert ctypes.sizeof(_lib.DvaCamera) == ctypes.sizeof(M.Camera)
     assert [f[0] for f in _lib.DvaCamera._fields_] == [f[0] for f in M.Camera._fields_]
+
+
+def _prototypes():
+    """name -> (return type, [parameter types]) parsed from include/dva.h."""
+    text = open(os.path.join(ROOT, "include", "dva.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int64_t|int)\s+(dva_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        ptypes = []
+        if params and params != "void":
+            for p in params.split(","):
+                p = " ".join(p.split())
+                ptypes.append("ptr" if "*" in p else re.sub(r"\s+\w+$", "", p).replace("const ", ""))
+        out[name] = (ret, ptypes)
+    return out
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every ctypes prototype has the arity and the scalar / pointer kinds of the C declaration: a mismatch
+    would corrupt the call silently (ctypes does not check)."""
+    kind = {ctypes.c_void_p: "ptr", ctypes.c_int64: "int64_t", ctypes.c_int32: "int32_t",
+            ctypes.c_float: "float", ctypes.c_double: "double"}       # c_int is c_int32 here
+    norm = lambda t: "int32_t" if t == "int" else t
+    protos = _prototypes()
+    assert set(protos) == set(_lib.SIGNATURES)
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        ret, ptypes = protos[name]
+        assert kind[restype] == norm(ret), (name, ret, restype)
+        got = ["ptr" if (isinstance(a, type) and issubclass(a, ctypes._Pointer)) else kind[a] for a in argtypes]
+        want = [norm(t) for t in ptypes]
+        assert got == want, (name, got, want)
