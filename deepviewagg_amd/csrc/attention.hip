@@ -453,6 +453,10 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
   constexpr int VEC = Vec16<T>::N;
   typedef typename Vec16<T>::raw raw_t;
   __shared__ float s_wb[64];  // [2*G], G <= 32
+  // long segments of the fused-gather form: d[v, g] of a point is parked in LDS between the two passes
+  // (DBUF floats per wavefront, shared by its teams) instead of making a round trip through grad_compat
+  constexpr int DBUF = 1024;
+  __shared__ float s_dbuf[4][DBUF];
   if (threadIdx.x < 64) s_wb[threadIdx.x] = 0.f;
   __syncthreads();
 
@@ -530,6 +534,10 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     // short segments (the common case): row indices, value rows and attentions of the whole point are
     // loaded before the first use and d stays in registers (no round trip through grad_compat)
     const bool small = n <= U * tg.rows;
+    // LDS form of the long path: fused gather only (no per-row grad_val writes), segment fits the team's share
+    const int team_cap = DBUF / (64 / tg.ts);
+    const bool lds_d = !small && row_idx && n * G <= team_cap;
+    float* sd = s_dbuf[threadIdx.x >> 6] + (lane / tg.ts) * team_cap;
     float dreg[U], areg[U];
     bool okr[U];
     if (small) {
@@ -584,7 +592,8 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
           for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
           for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
           if (g_first && ok[u]) {
-            gcompat[rr[u] * G + g_lane] = d;
+            if (lds_d) sd[(rr[u] - beg) * G + g_lane] = d;
+            else gcompat[rr[u] * G + g_lane] = d;
             sum_ad += av[u] * d;
           }
         }
@@ -635,6 +644,32 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (okr[u]) emit(beg + row_slot + u * tg.rows, areg[u], dreg[u]);
+    } else if (lds_d) {
+      // lane i of the team takes (view, group) pair i of each batch of ts / G views: coalesced reads of the
+      // attentions, coalesced writes of grad_compat, two iterations for 32 views instead of 32 serial ones.
+      // The per-group scalars live in the lanes of that group: fetched from the group's first lane.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int g2 = li & (G - 1), vs = li / G, per = tg.ts / G;
+      const int src = (lane - li) + g2 * tg.lpg;
+      const float gt2 = __shfl(gt, src), tt2 = __shfl(tt, src), gmx2 = __shfl(g_mx, src);
+      const int am2 = __shfl((int)(am - beg), src);
+      for (int v0 = 0; v0 < n; v0 += per) {
+        const int v = v0 + vs;
+        if (v < n) {
+          const int64_t r = beg + v;
+          const float a = att[r * G + g2];
+          float gc = a * (gt2 * sd[v * G + g2] - tt2) / dn;
+          if (v == am2) gc += gmx2;
+          gcompat[r * G + g2] = gc;
+          if (rec) {
+            rec[r * rs + 1 + g2] = a * gt2;
+            if (g2 == 0) rec[r * rs] = __int_as_float((int)p);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is reused by the team's next point
+      __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll 2
       for (int v = row_slot; v < n; v += tg.rows) {

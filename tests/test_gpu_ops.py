@@ -375,3 +375,41 @@ def test_rowbn_and_tall_linear_match_torch(R, C, slope, dtype):
             close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
         else:
             assert float((a.float().cpu() - b).norm() / b.norm()) < 5e-2
+
+
+@pytest.mark.parametrize("dtype,C,G", [(torch.float32, 64, 4), (torch.bfloat16, 512, 4), (torch.bfloat16, 256, 8)])
+def test_view_gather_attention_long_segments(dtype, C, G):
+    """Segments longer than the register-resident short path (up to 300 views per point, one or few rows per
+    team): the LDS-parked long path of the backward kernel against plain torch, forward and all gradients."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C + G)
+    N, R = 300, 500
+    sizes = torch.randint(0, 70, (N,), generator=gen)
+    sizes[:3] = torch.tensor([300, 129, 64])          # beyond the LDS share of a team -> global fallback
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    rows = torch.randn(R, C, generator=gen).to(dtype)
+    compat = torch.randn(V, G, generator=gen)
+    gw, gb = torch.randn(G, generator=gen), torch.randn(G, generator=gen)
+    w = torch.randn(N, C, generator=gen)
+    rd, cd = rows.to(DEV).requires_grad_(), compat.to(DEV).requires_grad_()
+    gwd, gbd = gw.to(DEV).requires_grad_(), gb.to(DEV).requires_grad_()
+    out, att, gate = ops.view_gather_attention(rd, row_idx.to(DEV), cd, csr.to(DEV), gwd, gbd)
+    grads = torch.autograd.grad((out.float() * w.to(DEV)).sum(), [rd, cd, gwd, gbd])
+    # torch reference on the materialised gather
+    rr, cr = rows.float().requires_grad_(), compat.clone().requires_grad_()
+    gwr, gbr = gw.clone().requires_grad_(), gb.clone().requires_grad_()
+    a_ref = O.segment_softmax_csr(cr, csr, scaling=False)
+    xp = O.segment_csr(rr[row_idx.long()] * O.expand_group_feat(a_ref, G, C), csr, 'sum')
+    mx = O.segment_csr(cr, csr, 'max')
+    xp = xp * O.expand_group_feat(torch.tanh(torch.relu(mx * gwr + gbr)), G, C)
+    ref = torch.autograd.grad((xp * w).sum(), [rr, cr, gwr, gbr])
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=4e-2, atol=4e-2)
+    close(out, xp, **tol)
+    close(att, a_ref, rtol=1e-5, atol=1e-6)
+    for a, b in zip(grads, ref):
+        if dtype == torch.float32:
+            close(a, b, **tol)
+        else:
+            assert float((a.float().cpu() - b).norm() / (b.norm() + 1e-6)) < 3e-2
