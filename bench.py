@@ -41,20 +41,37 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2-points", type=int, default=15)
     ap.add_argument("--no-mapping-build", action="store_true")
+    ap.add_argument("--workload", default="S1", choices=["S1", "S2"],
+                    help="S1: every point seen by --views images (headline); S2: ragged view counts "
+                         "min(views, 1 + Geom(0.2)), 10 %% of the points unseen (SURVEY.md 8(d))")
     return ap.parse_args()
 
 
-def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed):
-    """Synthetic scene of SURVEY.md §8(d): every point seen by `views` images at random pixels."""
+def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed, workload="S1"):
+    """Synthetic scene of SURVEY.md §8(d).  S1: every point seen by `views` images at random pixels;
+    S2: ragged view counts k_i = min(views, 1 + Geom(0.2)), 10 % of the points unseen."""
     g = torch.Generator(device=device).manual_seed(seed)
-    V = n_points * views
-    csr = torch.arange(0, V + 1, views, dtype=torch.int64, device=device)
-    # image ids: each point's views hit distinct images (sorted per point, like from_dense)
-    if views == n_images:
-        images = torch.arange(n_images, device=device).repeat(n_points)
+    if workload == "S1":
+        V = n_points * views
+        csr = torch.arange(0, V + 1, views, dtype=torch.int64, device=device)
+        # image ids: each point's views hit distinct images (sorted per point, like from_dense)
+        if views == n_images:
+            images = torch.arange(n_images, device=device).repeat(n_points)
+        else:
+            images = torch.stack([torch.randperm(n_images, generator=g, device=device)[:views].sort()[0]
+                                  for _ in range(1024)]).repeat((n_points + 1023) // 1024, 1)[:n_points].reshape(-1)
     else:
-        images = torch.stack([torch.randperm(n_images, generator=g, device=device)[:views].sort()[0]
-                              for _ in range(1024)]).repeat((n_points + 1023) // 1024, 1)[:n_points].reshape(-1)
+        u = torch.rand(n_points, generator=g, device=device).clamp_(1e-9, 1 - 1e-9)
+        k = (1 + torch.floor(torch.log(u) / float(torch.log(torch.tensor(0.8))))).long().clamp_(max=views)
+        k[torch.rand(n_points, generator=g, device=device) < 0.1] = 0
+        csr = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), k.cumsum(0)])
+        V = int(csr[-1])
+        # k_i consecutive image ids from a random cyclic start, sorted inside the point
+        start = torch.randint(0, n_images, (n_points,), generator=g, device=device).repeat_interleave(k)
+        rank = torch.arange(V, device=device) - csr[:-1].repeat_interleave(k)
+        pt = torch.arange(n_points, device=device).repeat_interleave(k)
+        img = (start + rank) % n_images
+        images = img[torch.argsort(pt * n_images + img)]
     pixels = torch.stack([torch.randint(0, W, (V,), generator=g, device=device),
                           torch.randint(0, H, (V,), generator=g, device=device)], 1).to(torch.int16)
     atom_ptr = torch.arange(V + 1, dtype=torch.int64, device=device)  # exact mapping: 1 pixel/view
@@ -281,7 +298,8 @@ def main():
     _lib.load()  # fail loudly if the HIP library is missing
 
     N, views, C, H, W = 1 << args.log2_points, args.views, args.channels, 64, 128
-    scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank)
+    scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank, workload=args.workload)
+    V_scene = int(scene["x_map"].shape[0])
     mods = build_modules(C, device)
     from deepviewagg_amd.parallel import GradientBucket
     bucket = GradientBucket(mods[1].parameters())
@@ -319,14 +337,16 @@ def main():
         avg_ms = k["ms"] / k["launches"]
         achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
         gk = kern.get("gather_nearest_fwd")
-        default_workload = (args.log2_points == 20 and args.dtype == "bf16")
+        default_workload = (args.log2_points == 20 and args.dtype == "bf16" and args.workload == "S1"
+                            and args.channels == 64 and args.views == 32)
         traffic = pmc_traffic(name, default_workload)
         res = {
             "metric": "points/sec fused fwd+bwd (1M pts, 32 views)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"S1/F-S: N=2^{args.log2_points} points x {views} views (V={N * views}), "
+            "config": {"workload": f"{args.workload}/F-S: N=2^{args.log2_points} points x "
+                                   f"{views if args.workload == 'S1' else 'ragged <= ' + str(views)} views (V={V_scene}), "
                                    f"32 feature maps [{C},{H},{W}] {args.dtype} channels-last, nearest gather -> "
                                    f"max atomic pool -> GroupBimodalCSRPool(G=4, DeepSetFeat, train) -> concat; "
                                    f"one scene per GPU",
