@@ -725,9 +725,11 @@ static bool team_geometry(int C, int G, int64_t N, int64_t V, TeamGeom* tg) {
   if (!is_pow2(G) || G > 32 || C % G) return false;
   if ((C / G) % VEC) return false;
   int rows = 64 / lpr;  // default: a whole wavefront per point
-  // shrink the team for short segments so that lanes are not idle (avg views per point)
+  // shrink the team for short segments so that lanes are not idle: the short-segment path covers 4 * rows
+  // views, so rows ~ 0.75 x the average segment keeps ~95 % of geometric-tailed segments on it while
+  // several points share a wavefront
   const double avg = N > 0 ? (double)V / (double)N : 0.0;
-  while (rows > 1 && (double)(rows / 2) >= avg && lpr * (rows / 2) >= G) rows >>= 1;
+  while (rows > 1 && (double)(rows / 2) >= 0.75 * avg && lpr * (rows / 2) >= G) rows >>= 1;
   while (lpr * rows < G) rows <<= 1;
   if (lpr * rows > 64) return false;
   tg->lpr = lpr;
