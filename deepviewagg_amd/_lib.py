@@ -97,7 +97,7 @@ SIGNATURES = {
                                                  _i32, _i32, _i32, _vp]),
     "dva_csr_expand": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "dva_deepset_fwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "dva_deepset_fwd_layer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "dva_deepset_fwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp]),
     "dva_deepset_bwd_score": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32,

@@ -183,22 +183,25 @@ struct SegVec<bf16_t> {
   }
 };
 
-template <typename AT>
+// LPP lanes per point (32, 16 or 8; at least LPR): the host picks it from the average segment length so that
+// short ragged segments (a handful of views per point) do not leave most row slots idle.
+template <typename AT, int LPP>
 __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ a,
                                                           const float* __restrict__ bn,
                                                           const int64_t* __restrict__ ptr,
                                                           float* __restrict__ pooled,
                                                           int32_t* __restrict__ arg, int64_t N) {
-  constexpr int VEC = SegVec<AT>::VEC, LPR = D / VEC, SLOTS = 32 / LPR, U = 4;
+  constexpr int VEC = SegVec<AT>::VEC, LPR = D / VEC, SLOTS = LPP / LPR, U = 4, PPW = 64 / LPP;
+  static_assert(LPP >= LPR && SLOTS >= 1, "a point needs at least one row of lanes");
   typedef typename SegVec<AT>::raw raw_t;
-  const int lane = threadIdx.x & 63, hl = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, hl = lane & (LPP - 1), h = lane / LPP;
   const int cl = hl % LPR, slot = hl / LPR, c0 = cl * VEC;
   BNc b[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) b[k] = load_bn(bn, c0 + k);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t p2 = wave * 2; p2 < N; p2 += n_waves * 2) {
+  for (int64_t p2 = wave * PPW; p2 < N; p2 += n_waves * PPW) {
     const int64_t p = p2 + h;
     const bool valid = p < N;
     const int64_t beg = valid ? ptr[p] : 0;
@@ -210,9 +213,11 @@ __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ 
       m[k] = -INFINITY;
       am[k] = -1;
     }
-    // both half-waves iterate together (shuffles below need every lane)
+    // the points of a wavefront iterate together (shuffles below need every lane)
     const int n_seg = (int)(end - beg);
-    const int n_max = max(n_seg, __shfl_xor(n_seg, 32));
+    int n_max = n_seg;
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) n_max = max(n_max, __shfl_xor(n_max, off));
     for (int i0 = 0; i0 < n_max; i0 += SLOTS * U) {
       raw_t raw[U];
       bool ok[U];
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void dsf_segmax_kernel(const AT* __restrict__ 
     }
     // merge the row slots: lanes hl, hl ^ off hold the same channels for different rows
 #pragma unroll
-    for (int off = LPR; off < 32; off <<= 1) {
+    for (int off = LPR; off < LPP; off <<= 1) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const float ov = __shfl_xor(m[k], off);
@@ -738,19 +743,32 @@ int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1,
 }
 
 int dva_deepset_segmax(const void* a, const float* bn, const int64_t* ptr, float* pooled,
-                       int32_t* arg, int64_t N, int32_t act_dtype, void* stream) {
+                       int32_t* arg, int64_t N, int64_t n_views, int32_t act_dtype, void* stream) {
   const int bf = act_bf(act_dtype);
   if (N < 0 || bf < 0) return DVA_ERR_INVALID;
   if (N == 0) return DVA_OK;
   if (!a || !bn || !ptr || !pooled || !arg) return DVA_ERR_INVALID;
-  int64_t b = (N + 7) / 8;
+  // lanes per point from the average segment: a batch covers 4 * (lanes / lanes-per-row) views
+  const double avg = n_views > 0 ? (double)n_views / (double)N : 32.0;
+  const int lpr = bf ? 4 : 8;
+  int lpp = 32;
+  while (lpp > lpr && lpp > 8 && 4.0 * (lpp / 2 / lpr) >= 3.0 * avg) lpp >>= 1;
+  const int ppb = 4 * (64 / lpp);   // points per block
+  int64_t b = (N + ppb - 1) / ppb;
   if (b > 256 * 8) b = 256 * 8;
-  if (bf)
-    hipLaunchKernelGGL((dsf_segmax_kernel<bf16_t>), dim3((int)b), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)a, bn, ptr, pooled, arg, N);
-  else
-    hipLaunchKernelGGL((dsf_segmax_kernel<float>), dim3((int)b), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)a, bn, ptr, pooled, arg, N);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_SM(T, L) \
+  hipLaunchKernelGGL((dsf_segmax_kernel<T, L>), dim3((int)b), dim3(256), 0, s, (const T*)a, bn, ptr, pooled, arg, N)
+  if (bf) {
+    if (lpp == 32) DVA_SM(bf16_t, 32);
+    else if (lpp == 16) DVA_SM(bf16_t, 16);
+    else DVA_SM(bf16_t, 8);
+  } else {
+    if (lpp == 32) DVA_SM(float, 32);
+    else if (lpp == 16) DVA_SM(float, 16);
+    else DVA_SM(float, 8);
+  }
+#undef DVA_SM
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -124,7 +124,7 @@ class _DeepSetLinear(torch.autograd.Function):
         pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
         arg = torch.empty((N, D), dtype=torch.int32, device=dev)
         with ops._timed("deepset_segmax", V * RB + N * (256 + 8)):
-            check(lib.dva_deepset_segmax(ptr(a2), ptr(bn2), ptr(csr_idx), ptr(pooled), ptr(arg), N, AC, st),
+            check(lib.dva_deepset_segmax(ptr(a2), ptr(bn2), ptr(csr_idx), ptr(pooled), ptr(arg), N, V, AC, st),
                   "dva_deepset_segmax")
         # set MLP on the N points with the same layer kernels (raw input, the set-size column of
         # use_num enters as a rank-1 per-row addend), then the WcB half of the concatenation layer

@@ -217,9 +217,10 @@ int dva_deepset_fwd_first(const float* x_map, const float* Wa, const float* bn1,
                           void* a2, double* stats, int64_t V, int32_t F, int32_t stats_only,
                           int32_t algo, int32_t act_dtype, void* stream);
 /* pooled[p] = max_v leaky(BN(a[v])) over the point's views (first row on ties; 0 / arg -1 for
- * unseen points): segment_csr(x, csr, 'max') of pooling.py:660,:628. */
+ * unseen points): segment_csr(x, csr, 'max') of pooling.py:660,:628.  n_views = ptr[N] (launch-geometry hint:
+ * lanes per point follow the average segment length; <= 0: default). */
 int dva_deepset_segmax(const void* a, const float* bn, const int64_t* ptr, float* pooled,
-                       int32_t* arg, int64_t N, int32_t act_dtype, void* stream);
+                       int32_t* arg, int64_t N, int64_t n_views, int32_t act_dtype, void* stream);
 /* a_out[v] = leaky(BN_in(a_in[v])).W^T (+ addend[group_of_row[v]]) with statistics of a_out.
  * The addend carries the set half of the concatenation: cat(x, x_set).Wc^T = x.WcA^T + (x_set.WcB^T)[p]
  * (pooling.py:666-668).  bn_in == NULL: the input is used raw (set MLP on the pooled features).
