@@ -901,6 +901,92 @@ __global__ __launch_bounds__(256) void rows_grad_generic_kernel(
   }
 }
 
+// Backward of a plain nearest gather (x_mod[p] = rows[row_idx[p]]) over the row plan:
+// grows[r, :] = sum over the atoms i of row r of gout[perm[i], :]   (deterministic, no atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_sum_team_kernel(const T* __restrict__ gout,
+                                                             const int32_t* __restrict__ perm,
+                                                             const int32_t* __restrict__ row_ptr,
+                                                             float* __restrict__ grows, int64_t R, int C,
+                                                             int lpr) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int U = 4;
+  typedef typename Vec16<T>::raw raw_t;
+  const int lane = threadIdx.x & 63;
+  const int lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
+  const int64_t col = (int64_t)lane_r * VEC;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < R; r += n_waves) {
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int i0 = beg; i0 < end; i0 += slots * U) {
+      int v[U];
+      bool ok[U];
+      raw_t raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * slots + slot;
+        ok[u] = i < end;
+        v[u] = perm[ok[u] ? i : beg];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)v[u] * C + col);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[VEC];
+        Vec16<T>::unpack(raw[u], f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += ok[u] ? f[k] : 0.f;
+      }
+    }
+    for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+    }
+    if (slot == 0) {
+      float* dst = grows + r * C + col;
+#pragma unroll
+      for (int k = 0; k < VEC; k += 4)
+        *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_sum_generic_kernel(const T* __restrict__ gout,
+                                                                const int32_t* __restrict__ perm,
+                                                                const int32_t* __restrict__ row_ptr,
+                                                                float* __restrict__ grows, int64_t R, int C) {
+  const int64_t total = R * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    float acc = 0.f;
+    for (int i = row_ptr[r]; i < row_ptr[r + 1]; ++i) acc += Elt<T>::ld(gout, (int64_t)perm[i] * C + c);
+    grows[t] = acc;
+  }
+}
+
+template <typename T>
+static int rows_sum_impl(const void* gout, const int32_t* perm, const int32_t* row_ptr, float* grows,
+                         int64_t R, int C, hipStream_t s) {
+  constexpr int VEC = Vec16<T>::N;
+  const int lpr = C / VEC;
+  const bool team_ok = (C % VEC) == 0 && is_pow2(lpr) && lpr <= 64 && ((uintptr_t)gout % 16 == 0) &&
+                       ((uintptr_t)grows % 16 == 0);
+  if (team_ok)
+    hipLaunchKernelGGL((rows_sum_team_kernel<T>), dim3(grid_cap((R + 3) / 4)), dim3(256), 0, s, (const T*)gout,
+                       perm, row_ptr, grows, R, C, lpr);
+  else
+    hipLaunchKernelGGL((rows_sum_generic_kernel<T>), dim3(grid_cap((R * C + 255) / 256)), dim3(256), 0, s,
+                       (const T*)gout, perm, row_ptr, grows, R, C);
+  return DVA_OK;
+}
+
 template <typename T>
 static int rows_grad_impl(const void* gout, const float* att, const float* gate, const int32_t* vp,
                           const int32_t* perm, const int32_t* row_ptr, const float* rec, int rs,
@@ -1043,6 +1129,25 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
   else if (dtype == DVA_BF16)
     rc = rows_grad_impl<bf16_t>(grad_out, att, gate, view_point, perm, row_ptr, view_rec, rec_stride,
                                 grad_rows, n_rows, C, G, (hipStream_t)stream);
+  else
+    return DVA_ERR_INVALID;
+  if (rc) return rc;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, float* grad_rows,
+                        int64_t n_rows, int64_t n_atoms, int32_t C, int32_t dtype, void* stream) {
+  if (n_rows < 0 || n_atoms < 0 || C <= 0) return DVA_ERR_INVALID;
+  if (n_atoms > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_rows == 0) return DVA_OK;
+  if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
+  if (n_atoms > 0 && (!grad_out || !perm)) return DVA_ERR_INVALID;
+  int rc;
+  if (dtype == DVA_F32)
+    rc = rows_sum_impl<float>(grad_out, perm, row_ptr, grad_rows, n_rows, C, (hipStream_t)stream);
+  else if (dtype == DVA_BF16)
+    rc = rows_sum_impl<bf16_t>(grad_out, perm, row_ptr, grad_rows, n_rows, C, (hipStream_t)stream);
   else
     return DVA_ERR_INVALID;
   if (rc) return rc;

@@ -372,8 +372,16 @@ class _GatherNearest(torch.autograd.Function):
         (packed,) = ctx.saved_tensors
         B, C, H, W, dt = ctx.meta
         gout = gout.contiguous()
-        gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
         P = packed.shape[0]
+        if ROWS_GRAD_ALGO == 0:
+            # deterministic segmented reduction over the row plan (sorted atoms) instead of fp32 atomics
+            row_idx, _, (perm, row_ptr) = gather_row_index(packed, B, H, W, with_counts=False, with_plan=True)
+            gx = torch.empty((B, H, W, C), dtype=torch.float32, device=gout.device)
+            with _timed("gather_nearest_bwd", P * (C * gout.element_size() + 12) + B * H * W * C * 4):
+                check(lib.dva_gather_rows_sum(ptr(gout), ptr(perm), ptr(row_ptr), ptr(gx), B * H * W, P, C,
+                                              dtype_code(gout), stream_of(gout)), "dva_gather_rows_sum")
+            return gx.permute(0, 3, 1, 2).to(dt), None
+        gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
         # P*(C*s + idx) + P*g*C*4*2 (read-modify-write of the fp32 gradient map)
         with _timed("gather_nearest_bwd", P * (C * gout.element_size() + 8) + P * C * 4 * 2):
             check(lib.dva_gather_nearest_bwd(ptr(gout), ptr(packed), ptr(gx), P, B, H, W,

@@ -194,6 +194,12 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
                               int64_t n_rows, int64_t n_views, int32_t C, int32_t G, int32_t dtype,
                               void* stream);
 
+/* Backward of a plain nearest gather over the row plan (dva_row_plan of the atoms' row index):
+ * grad_rows[r, :] = sum over the atoms i of row r of grad_out[perm[i], :]  (fp32 [n_rows, C], written, not
+ * accumulated; deterministic).  Same result as dva_gather_nearest_bwd without fp32 atomics. */
+int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, float* grad_rows,
+                        int64_t n_rows, int64_t n_atoms, int32_t C, int32_t dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * Fused DeepSetFeat (+ score Linear) chain over the V views, exact fp32, forward and backward.
  * Replaces, for map_encoder='DeepSetFeat' (pool='max', fusion='concatenation', nc_inner=32,

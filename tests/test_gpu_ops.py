@@ -413,3 +413,28 @@ def test_view_gather_attention_long_segments(dtype, C, G):
             close(a, b, **tol)
         else:
             assert float((a.float().cpu() - b).norm() / (b.norm() + 1e-6)) < 3e-2
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 24), (torch.bfloat16, 64), (torch.float32, 64)])
+def test_gather_nearest_backward_plan_equals_atomics(dtype, C):
+    """dva_gather_rows_sum (segmented reduction over the row plan) against dva_gather_nearest_bwd (atomics)."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C)
+    B, H, W, P = 3, 9, 14, 5000
+    x = torch.randn(B, C, H, W, generator=gen).to(dtype)
+    images = torch.randint(0, B, (P,), generator=gen)
+    pixels = torch.stack([torch.randint(0, W, (P,), generator=gen), torch.randint(0, H, (P,), generator=gen)], 1).short()
+    w = torch.randn(P, C, generator=gen).to(dtype)
+    packed = ops.pack_gather_index(images.to(DEV), torch.arange(P + 1, device=DEV), pixels.to(DEV))
+    res = {}
+    for algo in (0, 1):
+        old, ops.ROWS_GRAD_ALGO = ops.ROWS_GRAD_ALGO, algo
+        try:
+            xd = x.to(DEV).requires_grad_()
+            (res[algo],) = torch.autograd.grad((ops.gather_nearest(xd, packed).float() * w.to(DEV).float()).sum(), xd)
+        finally:
+            ops.ROWS_GRAD_ALGO = old
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    close(res[0], res[1], **tol)
+    ref = torch.zeros(B, H, W, C).index_put_((images, pixels[:, 1].long(), pixels[:, 0].long()), w.float(), accumulate=True)
+    close(res[0].permute(0, 2, 3, 1), ref, **tol)
