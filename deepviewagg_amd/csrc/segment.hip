@@ -129,6 +129,125 @@ __global__ __launch_bounds__(256) void segment_softmax_bwd_kernel(const float* _
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 16-byte variants (C a multiple of 8 bf16 / 4 fp32 channels, 16-byte aligned rows): one thread owns VEC
+// consecutive channels of a group, so a row costs one load / store instruction per thread instead of VEC.
+// Same arithmetic and tie rule (first row) as the scalar kernels.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct SVec;
+template <> struct SVec<float> {
+  static constexpr int N = 4;
+  typedef float4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+  static __device__ __forceinline__ raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct SVec<bf16_t> {
+  static constexpr int N = 8;
+  typedef uint4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = __uint_as_float(w[e] << 16);
+      f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ raw pack(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                      pack_bf16x2(f[6], f[7]));
+  }
+};
+
+template <typename T, int REDUCE>
+__global__ __launch_bounds__(256) void segment_csr_fwd_vec_kernel(const T* __restrict__ src,
+                                                                   const int64_t* __restrict__ ptr,
+                                                                   T* __restrict__ out,
+                                                                   int32_t* __restrict__ arg,
+                                                                   int64_t n_groups, int C) {
+  constexpr int VEC = SVec<T>::N;
+  typedef typename SVec<T>::raw raw_t;
+  const int cpr = C / VEC;
+  const int64_t total = n_groups * (int64_t)cpr;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = t / cpr;
+    const int c0 = (int)(t - g * cpr) * VEC;
+    const int64_t beg = ptr[g], end = ptr[g + 1];
+    float acc[VEC];
+    int32_t best[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      acc[k] = 0.f;
+      best[k] = -1;
+    }
+    for (int64_t r = beg; r < end; ++r) {
+      float f[VEC];
+      SVec<T>::unpack(*reinterpret_cast<const raw_t*>(src + r * C + c0), f);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (REDUCE == DVA_SUM || REDUCE == DVA_MEAN) {
+          acc[k] += f[k];
+        } else if (r == beg || (REDUCE == DVA_MAX ? f[k] > acc[k] : f[k] < acc[k])) {
+          acc[k] = f[k];
+          best[k] = (int32_t)r;
+        }
+      }
+    }
+    if (REDUCE == DVA_MEAN && end > beg) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] /= (float)(end - beg);
+    }
+    *reinterpret_cast<raw_t*>(out + g * C + c0) = SVec<T>::pack(acc);
+    if ((REDUCE == DVA_MAX || REDUCE == DVA_MIN) && arg) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) arg[g * C + c0 + k] = best[k];
+    }
+  }
+}
+
+template <typename T, int REDUCE>
+__global__ __launch_bounds__(256) void segment_csr_bwd_vec_kernel(const T* __restrict__ gout,
+                                                                   const int64_t* __restrict__ ptr,
+                                                                   const int32_t* __restrict__ arg,
+                                                                   T* __restrict__ gsrc,
+                                                                   int64_t n_groups, int C) {
+  constexpr int VEC = SVec<T>::N;
+  typedef typename SVec<T>::raw raw_t;
+  const int cpr = C / VEC;
+  const int64_t total = n_groups * (int64_t)cpr;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = t / cpr;
+    const int c0 = (int)(t - g * cpr) * VEC;
+    const int64_t beg = ptr[g], end = ptr[g + 1];
+    if (end <= beg) continue;
+    float go[VEC];
+    SVec<T>::unpack(*reinterpret_cast<const raw_t*>(gout + g * C + c0), go);
+    if (REDUCE == DVA_MEAN) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) go[k] /= (float)(end - beg);
+    }
+    int32_t a[VEC];
+    if (REDUCE == DVA_MAX || REDUCE == DVA_MIN) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) a[k] = arg[g * C + c0 + k];
+    }
+    for (int64_t r = beg; r < end; ++r) {
+      float f[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        f[k] = (REDUCE == DVA_SUM || REDUCE == DVA_MEAN) ? go[k] : ((int64_t)a[k] == r ? go[k] : 0.f);
+      *reinterpret_cast<raw_t*>(gsrc + r * C + c0) = SVec<T>::pack(f);
+    }
+  }
+}
+
+template <typename T>
+static inline bool vec_ok(const void* a, const void* b, int C) {
+  return C % SVec<T>::N == 0 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+}
+
 static inline int grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
   const int64_t cap = 256 * 32;  // 256 CUs x 32 blocks, grid-stride beyond
@@ -140,10 +259,17 @@ static inline int grid_for(int64_t total) {
 template <typename T>
 static int launch_segment_fwd(const void* src, const int64_t* ptr, void* out, int32_t* arg,
                               int64_t n, int C, int reduce, hipStream_t s) {
-  const int grid = grid_for(n * (int64_t)C);
-#define DVA_L(R)                                                                                  \
-  hipLaunchKernelGGL((segment_csr_fwd_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)src, \
-                     ptr, (T*)out, arg, n, C)
+  const bool vec = vec_ok<T>(src, out, C);
+  const int grid = grid_for(n * (int64_t)(vec ? C / SVec<T>::N : C));
+#define DVA_L(R)                                                                                        \
+  do {                                                                                                  \
+    if (vec)                                                                                            \
+      hipLaunchKernelGGL((segment_csr_fwd_vec_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)src, \
+                         ptr, (T*)out, arg, n, C);                                                      \
+    else                                                                                                \
+      hipLaunchKernelGGL((segment_csr_fwd_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)src,    \
+                         ptr, (T*)out, arg, n, C);                                                      \
+  } while (0)
   switch (reduce) {
     case DVA_SUM: DVA_L(DVA_SUM); break;
     case DVA_MEAN: DVA_L(DVA_MEAN); break;
@@ -158,10 +284,17 @@ static int launch_segment_fwd(const void* src, const int64_t* ptr, void* out, in
 template <typename T>
 static int launch_segment_bwd(const void* gout, const int64_t* ptr, const int32_t* arg, void* gsrc,
                               int64_t n, int C, int reduce, hipStream_t s) {
-  const int grid = grid_for(n * (int64_t)C);
-#define DVA_L(R)                                                                                   \
-  hipLaunchKernelGGL((segment_csr_bwd_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)gout, \
-                     ptr, arg, (T*)gsrc, n, C)
+  const bool vec = vec_ok<T>(gout, gsrc, C);
+  const int grid = grid_for(n * (int64_t)(vec ? C / SVec<T>::N : C));
+#define DVA_L(R)                                                                                         \
+  do {                                                                                                   \
+    if (vec)                                                                                             \
+      hipLaunchKernelGGL((segment_csr_bwd_vec_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)gout, \
+                         ptr, arg, (T*)gsrc, n, C);                                                      \
+    else                                                                                                 \
+      hipLaunchKernelGGL((segment_csr_bwd_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)gout,    \
+                         ptr, arg, (T*)gsrc, n, C);                                                      \
+  } while (0)
   switch (reduce) {
     case DVA_SUM: DVA_L(DVA_SUM); break;
     case DVA_MEAN: DVA_L(DVA_MEAN); break;
