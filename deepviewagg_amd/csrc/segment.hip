@@ -366,15 +366,23 @@ int dva_gather_csr(const void* src, const int64_t* ptr, void* out, int64_t n_gro
                    int32_t dtype, void* stream) {
   if (n_groups < 0 || C < 0 || !ptr) return DVA_ERR_INVALID;
   if (n_groups == 0 || C == 0) return DVA_OK;
+  // pure byte movement: with 16-byte aligned rows every thread copies 16 bytes of a group's row
+  const int64_t row_bytes = (int64_t)C * (dtype == DVA_F32 ? 4 : 2);
+  if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
+  if (row_bytes % 16 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    const int u = (int)(row_bytes / 16);
+    hipLaunchKernelGGL((gather_csr_kernel<uint4>), dim3(grid_for(n_groups * (int64_t)u)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4*)src, ptr, (uint4*)out, n_groups, u);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   const int grid = grid_for(n_groups * (int64_t)C);
   if (dtype == DVA_F32)
     hipLaunchKernelGGL((gather_csr_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)src, ptr, (float*)out, n_groups, C);
-  else if (dtype == DVA_BF16)
+  else
     hipLaunchKernelGGL((gather_csr_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, ptr, (bf16_t*)out, n_groups, C);
-  else
-    return DVA_ERR_INVALID;
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
