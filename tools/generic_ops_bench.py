@@ -70,3 +70,12 @@ def gn_bwd():
 timeit("gather_nearest fwd+bwd", gn_bwd, V * (3 * C * 2 + 16))
 coords = torch.rand(V, 2, generator=g, device=dev)
 timeit("gather_bilinear fwd", lambda: ops.gather_bilinear(fm.detach(), packed, coords), V * (5 * C * 2 + 16))
+
+
+def gb_bwd():
+    out = ops.gather_bilinear(fm, packed, coords)
+    out.backward(x.detach())
+    fm.grad = None
+
+
+timeit("gather_bilinear fwd+bwd", gb_bwd, V * (6 * C * 2 + 16) + V * 4 * C * 8)
