@@ -95,7 +95,8 @@ SIGNATURES = {
     "dva_row_plan": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_view_gather_rows_grad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64,
                                                  _i32, _i32, _i32, _vp]),
-    "dva_gather_rows_sum": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "dva_gather_rows_sum": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "dva_gather_bilinear_taps": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dva_csr_expand": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "dva_deepset_fwd_first": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_deepset_segmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),

@@ -903,10 +903,13 @@ __global__ __launch_bounds__(256) void rows_grad_generic_kernel(
 
 // Backward of a plain nearest gather (x_mod[p] = rows[row_idx[p]]) over the row plan:
 // grows[r, :] = sum over the atoms i of row r of gout[perm[i], :]   (deterministic, no atomics).
+// With `weights`: the plan is over ENTRIES (entry e belongs to atom e >> shift and carries weights[e]), e.g.
+// the 4 bilinear corner taps of every atom (shift = 2).
 template <typename T>
 __global__ __launch_bounds__(256) void rows_sum_team_kernel(const T* __restrict__ gout,
                                                              const int32_t* __restrict__ perm,
                                                              const int32_t* __restrict__ row_ptr,
+                                                             const float* __restrict__ weights, int shift,
                                                              float* __restrict__ grows, int64_t R, int C,
                                                              int lpr) {
   constexpr int VEC = Vec16<T>::N;
@@ -932,14 +935,18 @@ __global__ __launch_bounds__(256) void rows_sum_team_kernel(const T* __restrict_
         ok[u] = i < end;
         v[u] = perm[ok[u] ? i : beg];
       }
+      float wu[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)v[u] * C + col);
+      for (int u = 0; u < U; ++u) {
+        raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)(v[u] >> shift) * C + col);
+        wu[u] = ok[u] ? (weights ? weights[v[u]] : 1.f) : 0.f;
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float f[VEC];
         Vec16<T>::unpack(raw[u], f);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += ok[u] ? f[k] : 0.f;
+        for (int k = 0; k < VEC; ++k) acc[k] = fmaf(wu[u], f[k], acc[k]);
       }
     }
     for (int off = lpr; off < 64; off <<= 1) {
@@ -959,6 +966,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rows_sum_generic_kernel(const T* __restrict__ gout,
                                                                 const int32_t* __restrict__ perm,
                                                                 const int32_t* __restrict__ row_ptr,
+                                                                const float* __restrict__ weights, int shift,
                                                                 float* __restrict__ grows, int64_t R, int C) {
   const int64_t total = R * (int64_t)C;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
@@ -966,24 +974,27 @@ __global__ __launch_bounds__(256) void rows_sum_generic_kernel(const T* __restri
     const int64_t r = t / C;
     const int c = (int)(t - r * C);
     float acc = 0.f;
-    for (int i = row_ptr[r]; i < row_ptr[r + 1]; ++i) acc += Elt<T>::ld(gout, (int64_t)perm[i] * C + c);
+    for (int i = row_ptr[r]; i < row_ptr[r + 1]; ++i) {
+      const int e = perm[i];
+      acc = fmaf(weights ? weights[e] : 1.f, Elt<T>::ld(gout, (int64_t)(e >> shift) * C + c), acc);
+    }
     grows[t] = acc;
   }
 }
 
 template <typename T>
-static int rows_sum_impl(const void* gout, const int32_t* perm, const int32_t* row_ptr, float* grows,
-                         int64_t R, int C, hipStream_t s) {
+static int rows_sum_impl(const void* gout, const int32_t* perm, const int32_t* row_ptr, const float* weights,
+                         int shift, float* grows, int64_t R, int C, hipStream_t s) {
   constexpr int VEC = Vec16<T>::N;
   const int lpr = C / VEC;
   const bool team_ok = (C % VEC) == 0 && is_pow2(lpr) && lpr <= 64 && ((uintptr_t)gout % 16 == 0) &&
                        ((uintptr_t)grows % 16 == 0);
   if (team_ok)
     hipLaunchKernelGGL((rows_sum_team_kernel<T>), dim3(grid_cap((R + 3) / 4)), dim3(256), 0, s, (const T*)gout,
-                       perm, row_ptr, grows, R, C, lpr);
+                       perm, row_ptr, weights, shift, grows, R, C, lpr);
   else
     hipLaunchKernelGGL((rows_sum_generic_kernel<T>), dim3(grid_cap((R * C + 255) / 256)), dim3(256), 0, s,
-                       (const T*)gout, perm, row_ptr, grows, R, C);
+                       (const T*)gout, perm, row_ptr, weights, shift, grows, R, C);
   return DVA_OK;
 }
 
@@ -1136,18 +1147,19 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
   return DVA_OK;
 }
 
-int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, float* grad_rows,
-                        int64_t n_rows, int64_t n_atoms, int32_t C, int32_t dtype, void* stream) {
-  if (n_rows < 0 || n_atoms < 0 || C <= 0) return DVA_ERR_INVALID;
+int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                        const float* weights, int32_t atom_shift, float* grad_rows, int64_t n_rows,
+                        int64_t n_atoms, int32_t C, int32_t dtype, void* stream) {
+  if (n_rows < 0 || n_atoms < 0 || C <= 0 || atom_shift < 0 || atom_shift > 8) return DVA_ERR_INVALID;
   if (n_atoms > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
   if (n_rows == 0) return DVA_OK;
   if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
   if (n_atoms > 0 && (!grad_out || !perm)) return DVA_ERR_INVALID;
   int rc;
   if (dtype == DVA_F32)
-    rc = rows_sum_impl<float>(grad_out, perm, row_ptr, grad_rows, n_rows, C, (hipStream_t)stream);
+    rc = rows_sum_impl<float>(grad_out, perm, row_ptr, weights, atom_shift, grad_rows, n_rows, C, (hipStream_t)stream);
   else if (dtype == DVA_BF16)
-    rc = rows_sum_impl<bf16_t>(grad_out, perm, row_ptr, grad_rows, n_rows, C, (hipStream_t)stream);
+    rc = rows_sum_impl<bf16_t>(grad_out, perm, row_ptr, weights, atom_shift, grad_rows, n_rows, C, (hipStream_t)stream);
   else
     return DVA_ERR_INVALID;
   if (rc) return rc;

@@ -167,6 +167,21 @@ __global__ __launch_bounds__(256) void gather_bilinear_bwd_kernel(
   }
 }
 
+// rows[4p + k], weights[4p + k]: the 4 corner rows of the [B*H*W, C] map and their bilinear weights for atom p
+// (same taps as the forward), the input of the row-plan backward (dva_gather_rows_sum with weights).
+__global__ __launch_bounds__(256) void bilinear_taps_kernel(const PackedIdx* __restrict__ idx,
+                                                             const float* __restrict__ coords,
+                                                             int64_t n_atoms, int H, int W,
+                                                             int32_t* __restrict__ rows,
+                                                             float* __restrict__ weights) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_atoms;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const Taps tp = bilinear_taps(idx[p], coords[2 * p], coords[2 * p + 1], H, W);
+    *reinterpret_cast<int4*>(rows + 4 * p) = make_int4((int)tp.tl, (int)tp.tr, (int)tp.bl, (int)tp.br);
+    *reinterpret_cast<float4*>(weights + 4 * p) = make_float4(tp.w_tl, tp.w_tr, tp.w_bl, tp.w_br);
+  }
+}
+
 static inline int grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
   const int64_t cap = 256 * 32;
@@ -312,6 +327,18 @@ int dva_gather_bilinear_bwd(const void* grad_out, const void* packed_idx, const 
   else
     hipLaunchKernelGGL((gather_bilinear_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s,
                        (const bf16_t*)grad_out, idx, coords, grad_x, n_atoms, H, W, C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_bilinear_taps(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
+                             int32_t H, int32_t W, int32_t* rows, float* weights, void* stream) {
+  if (n_atoms < 0 || B < 0 || H <= 0 || W <= 0) return DVA_ERR_INVALID;
+  if ((int64_t)B * H * W > 0x7fffffffLL || n_atoms > 0x1fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_atoms == 0) return DVA_OK;
+  if (!packed_idx || !coords || !rows || !weights) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(bilinear_taps_kernel, dim3(grid_for(n_atoms)), dim3(256), 0, (hipStream_t)stream,
+                     (const PackedIdx*)packed_idx, coords, n_atoms, H, W, rows, weights);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

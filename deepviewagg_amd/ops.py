@@ -378,7 +378,7 @@ class _GatherNearest(torch.autograd.Function):
             row_idx, _, (perm, row_ptr) = gather_row_index(packed, B, H, W, with_counts=False, with_plan=True)
             gx = torch.empty((B, H, W, C), dtype=torch.float32, device=gout.device)
             with _timed("gather_nearest_bwd", P * (C * gout.element_size() + 12) + B * H * W * C * 4):
-                check(lib.dva_gather_rows_sum(ptr(gout), ptr(perm), ptr(row_ptr), ptr(gx), B * H * W, P, C,
+                check(lib.dva_gather_rows_sum(ptr(gout), ptr(perm), ptr(row_ptr), None, 0, ptr(gx), B * H * W, P, C,
                                               dtype_code(gout), stream_of(gout)), "dva_gather_rows_sum")
             return gx.permute(0, 3, 1, 2).to(dt), None
         gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
@@ -418,6 +418,20 @@ class _GatherBilinear(torch.autograd.Function):
         packed, coords = ctx.saved_tensors
         B, C, H, W, dt = ctx.meta
         gout = gout.contiguous()
+        P = packed.shape[0]
+        if ROWS_GRAD_ALGO == 0 and 4 * P < 2 ** 31:
+            # the 4 corner taps of every atom, grouped by map row (row plan), then a weighted segmented
+            # reduction: deterministic, no fp32 atomics
+            rows4 = torch.empty(4 * P, dtype=torch.int32, device=gout.device)
+            w4 = torch.empty(4 * P, dtype=torch.float32, device=gout.device)
+            check(lib.dva_gather_bilinear_taps(ptr(packed), ptr(coords), P, B, H, W, ptr(rows4), ptr(w4),
+                                               stream_of(gout)), "dva_gather_bilinear_taps")
+            (perm, row_ptr), _ = row_plan(rows4, B * H * W, with_counts=False)
+            gx = torch.empty((B, H, W, C), dtype=torch.float32, device=gout.device)
+            with _timed("gather_bilinear_bwd", 4 * P * (C * gout.element_size() + 12) + B * H * W * C * 4):
+                check(lib.dva_gather_rows_sum(ptr(gout), ptr(perm), ptr(row_ptr), ptr(w4), 2, ptr(gx), B * H * W,
+                                              4 * P, C, dtype_code(gout), stream_of(gout)), "dva_gather_rows_sum")
+            return gx.permute(0, 3, 1, 2).to(dt), None, None
         gx = torch.zeros((B, H, W, C), dtype=torch.float32, device=gout.device)
         check(lib.dva_gather_bilinear_bwd(ptr(gout), ptr(packed), ptr(coords), ptr(gx),
                                           packed.shape[0], B, H, W, C, dtype_code(gout),

@@ -194,11 +194,18 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
                               int64_t n_rows, int64_t n_views, int32_t C, int32_t G, int32_t dtype,
                               void* stream);
 
-/* Backward of a plain nearest gather over the row plan (dva_row_plan of the atoms' row index):
- * grad_rows[r, :] = sum over the atoms i of row r of grad_out[perm[i], :]  (fp32 [n_rows, C], written, not
- * accumulated; deterministic).  Same result as dva_gather_nearest_bwd without fp32 atomics. */
-int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, float* grad_rows,
-                        int64_t n_rows, int64_t n_atoms, int32_t C, int32_t dtype, void* stream);
+/* Backward of a gather over the row plan (dva_row_plan): grad_rows[r, :] = sum over the plan entries e of row r
+ * of weights[e] * grad_out[e >> atom_shift, :]  (fp32 [n_rows, C], written, not accumulated; deterministic).
+ * Nearest gather: entries = atoms (weights NULL, atom_shift 0) -- dva_gather_nearest_bwd without atomics.
+ * Bilinear gather: entries = the 4 corner taps of every atom from dva_gather_bilinear_taps (atom_shift 2);
+ * n_atoms = number of ENTRIES. */
+int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                        const float* weights, int32_t atom_shift, float* grad_rows, int64_t n_rows,
+                        int64_t n_atoms, int32_t C, int32_t dtype, void* stream);
+/* rows int32 [4 * n_atoms], weights fp32 [4 * n_atoms]: corner rows (tl, tr, bl, br) of the [B*H*W, C] map and
+ * bilinear weights of every atom, exactly the taps of dva_gather_bilinear_fwd (image.py:138-165). */
+int dva_gather_bilinear_taps(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
+                             int32_t H, int32_t W, int32_t* rows, float* weights, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Fused DeepSetFeat (+ score Linear) chain over the V views, exact fp32, forward and backward.

@@ -438,3 +438,35 @@ def test_gather_nearest_backward_plan_equals_atomics(dtype, C):
     close(res[0], res[1], **tol)
     ref = torch.zeros(B, H, W, C).index_put_((images, pixels[:, 1].long(), pixels[:, 0].long()), w.float(), accumulate=True)
     close(res[0].permute(0, 2, 3, 1), ref, **tol)
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 24), (torch.bfloat16, 64)])
+def test_gather_bilinear_backward_plan_equals_atomics(dtype, C):
+    """Bilinear gather backward: weighted segmented reduction over the row plan of the 4 corner taps
+    (dva_gather_bilinear_taps + dva_row_plan + dva_gather_rows_sum) against the atomic scatter and autograd of
+    the oracle's sparse_interpolation."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C + 1)
+    B, H, W, P = 3, 9, 14, 4000
+    x = torch.randn(B, C, H, W, generator=gen).to(dtype)
+    images = torch.randint(0, B, (P,), generator=gen)
+    pixels = torch.zeros(P, 2, dtype=torch.int16)
+    coords = torch.rand(P, 2, generator=gen)
+    coords[:50] = torch.tensor([0.0, 1.0])                 # borders: replication padding taps collapse
+    w = torch.randn(P, C, generator=gen).to(dtype)
+    packed = ops.pack_gather_index(images.to(DEV), torch.arange(P + 1, device=DEV), pixels.to(DEV))
+    res = {}
+    for algo in (0, 1):
+        old, ops.ROWS_GRAD_ALGO = ops.ROWS_GRAD_ALGO, algo
+        try:
+            xd = x.to(DEV).requires_grad_()
+            out = ops.gather_bilinear(xd, packed, coords.to(DEV))
+            (res[algo],) = torch.autograd.grad((out.float() * w.to(DEV).float()).sum(), xd)
+        finally:
+            ops.ROWS_GRAD_ALGO = old
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    close(res[0], res[1], **tol)
+    xr = x.float().requires_grad_()
+    ref_out = O.sparse_interpolation(xr, coords, images)
+    (g_ref,) = torch.autograd.grad((ref_out * w.float()).sum(), xr)
+    close(res[0], g_ref, **tol)
