@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2-points", type=int, default=15)
     ap.add_argument("--no-mapping-build", action="store_true")
+    ap.add_argument("--materialize", action="store_true",
+                    help="diagnostic: materialised [V, C] gather + per-view E_mod (the reference's dataflow) instead "
+                         "of the lazy gather / hoisted E_mod")
     ap.add_argument("--workload", default="S1", choices=["S1", "S2"],
                     help="S1: every point seen by --views images (headline); S2: ragged view counts "
                          "min(views, 1 + Geom(0.2)), 10 %% of the points unseen (SURVEY.md 8(d))")
@@ -312,13 +315,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(scene, packed, mods, dtype)
+        step(scene, packed, mods, dtype, lazy=not args.materialize)
         bucket.reduce(average=True)
     barrier()
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(scene, packed, mods, dtype)
+        loss = step(scene, packed, mods, dtype, lazy=not args.materialize)
         bucket.reduce(average=True)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -338,7 +341,7 @@ def main():
         achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
         gk = kern.get("gather_nearest_fwd")
         default_workload = (args.log2_points == 20 and args.dtype == "bf16" and args.workload == "S1"
-                            and args.channels == 64 and args.views == 32)
+                            and args.channels == 64 and args.views == 32 and not args.materialize)
         traffic = pmc_traffic(name, default_workload)
         res = {
             "metric": "points/sec fused fwd+bwd (1M pts, 32 views)",

@@ -20,31 +20,33 @@ constexpr int RB_ROWS = 4;  // rows per block iteration (blockDim = 64 x 4)
 
 // sums[0..C) += sum_r w_r f1, sums[C..2C) += sum_r w_r f2 with (f1, f2) produced per element by `F`
 template <typename T, typename F>
-__device__ __forceinline__ void row_sums(int64_t R, int C, double* __restrict__ sums, float* s_red, F&& f) {
-  for (int i = threadIdx.y * 64 + threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.f;
+__device__ __forceinline__ void row_sums(int64_t R, int C, double* __restrict__ sums, double* s_red, F&& f) {
+  // fp64 partial sums: the variance is E[y^2] - mean^2, and with fp32 partials the cancellation showed up as
+  // 1e-4 relative errors downstream when |mean| >> std (the passes are memory bound, fp64 adds are free)
+  for (int i = threadIdx.y * 64 + threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.0;
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 64) {
-    float a0 = 0.f, a1 = 0.f;
+    double a0 = 0.0, a1 = 0.0;
     for (int64_t r = (int64_t)blockIdx.x * RB_ROWS + threadIdx.y; r < R; r += (int64_t)gridDim.x * RB_ROWS) {
       float f1, f2;
       f(r, c, f1, f2);
-      a0 += f1;
-      a1 += f2;
+      a0 += (double)f1;
+      a1 += (double)f2;
     }
     atomicAdd(&s_red[c], a0);
     atomicAdd(&s_red[C + c], a1);
   }
   __syncthreads();
-  for (int i = threadIdx.y * 64 + threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], (double)s_red[i]);
+  for (int i = threadIdx.y * 64 + threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], s_red[i]);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void rowbn_stats_kernel(const T* __restrict__ y,
                                                            const int32_t* __restrict__ counts,
                                                            double* __restrict__ sums, int64_t R, int C) {
-  extern __shared__ float s_red[];
+  extern __shared__ double s_red[];
   row_sums<T>(R, C, sums, s_red, [&](int64_t r, int c, float& f1, float& f2) {
-    const float w = (float)counts[r], v = Elt<T>::ld(y, r * C + c);
+    const float w = counts ? (float)counts[r] : 1.f, v = Elt<T>::ld(y, r * C + c);
     f1 = w * v;
     f2 = w * v * v;
   });
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void rowbn_bwd_stats_kernel(const T* __restric
                                                                const float* __restrict__ bn,
                                                                double* __restrict__ sums, int64_t R,
                                                                int C, float slope) {
-  extern __shared__ float s_red[];
+  extern __shared__ double s_red[];
   row_sums<T>(R, C, sums, s_red, [&](int64_t r, int c, float& f1, float& f2) {
     const float a = (Elt<T>::ld(y, r * C + c) - bn[c]) * bn[C + c];
     const float z = a * bn[2 * C + c] + bn[3 * C + c];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void rowbn_bwd_apply_kernel(
     const float a = (Elt<T>::ld(y, t) - bn[c]) * bn[C + c];
     const float z = a * bn[2 * C + c] + bn[3 * C + c];
     const float dz = Elt<T>::ld(gout, t) * (z > 0.f ? 1.f : slope);
-    const float w = (float)counts[r];
+    const float w = counts ? (float)counts[r] : 1.f;
     Elt<T>::st(dy, t, bn[2 * C + c] * bn[C + c] * (dz - w * sm[c] - w * a * sm[C + c]));
   }
 }
@@ -125,9 +127,9 @@ int dva_rowbn_stats(const void* y, const int32_t* counts, double* sums, int64_t 
   if (R < 0 || C <= 0 || C > 4096 || !sums) return DVA_ERR_INVALID;
   if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
   if (R == 0) return DVA_OK;
-  if (!y || !counts) return DVA_ERR_INVALID;
+  if (!y) return DVA_ERR_INVALID;
   const dim3 block(64, 4);
-  const size_t lds = 2 * (size_t)C * sizeof(float);
+  const size_t lds = 2 * (size_t)C * sizeof(double);
   if (dtype == DVA_F32)
     hipLaunchKernelGGL((rowbn_stats_kernel<float>), dim3(rows_grid(R)), block, lds, (hipStream_t)stream,
                        (const float*)y, counts, sums, R, C);
@@ -162,7 +164,7 @@ int dva_rowbn_bwd_stats(const void* grad_out, const void* y, const float* bn, do
   if (R == 0) return DVA_OK;
   if (!grad_out || !y || !bn) return DVA_ERR_INVALID;
   const dim3 block(64, 4);
-  const size_t lds = 2 * (size_t)C * sizeof(float);
+  const size_t lds = 2 * (size_t)C * sizeof(double);
   if (dtype == DVA_F32)
     hipLaunchKernelGGL((rowbn_bwd_stats_kernel<float>), dim3(rows_grid(R)), block, lds,
                        (hipStream_t)stream, (const float*)grad_out, (const float*)y, bn, sums, R, C, slope);
@@ -180,7 +182,7 @@ int dva_rowbn_bwd_apply(const void* grad_out, const void* y, const int32_t* coun
   if (R < 0 || C <= 0) return DVA_ERR_INVALID;
   if (dtype != DVA_F32 && dtype != DVA_BF16) return DVA_ERR_INVALID;
   if (R == 0) return DVA_OK;
-  if (!grad_out || !y || !counts || !bn || !sm || !grad_y) return DVA_ERR_INVALID;
+  if (!grad_out || !y || !bn || !sm || !grad_y) return DVA_ERR_INVALID;
   const dim3 grid(elems_grid(R * C));
   if (dtype == DVA_F32)
     hipLaunchKernelGGL((rowbn_bwd_apply_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream,

@@ -739,7 +739,7 @@ class _RowBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, counts, gamma, beta, mean, invstd, n, batch_stats, slope):
         lib = _lib.load()
-        require_device(y, counts)
+        require_device(y)
         y = y.contiguous()
         R, C = y.shape
         g = gamma.detach().float() if gamma is not None else torch.ones(C, device=y.device)
@@ -749,14 +749,15 @@ class _RowBNAct(torch.autograd.Function):
         with _timed("rowbn_apply", R * C * 2 * y.element_size()):
             check(lib.dva_rowbn_apply(ptr(y), ptr(bn), ptr(out), R, C, float(slope), dtype_code(y),
                                       stream_of(y)), "dva_rowbn_apply")
-        ctx.save_for_backward(y, counts, bn)
+        ctx.save_for_backward(y, bn, *([counts] if counts is not None else []))
         ctx.meta = (float(n), bool(batch_stats), float(slope), gamma is not None, beta is not None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
-        y, counts, bn = ctx.saved_tensors
+        y, bn = ctx.saved_tensors[:2]
+        counts = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
         n, batch_stats, slope, has_g, has_b = ctx.meta
         R, C = y.shape
         gout = gout.contiguous().to(y.dtype)
@@ -777,7 +778,7 @@ class _RowBNAct(torch.autograd.Function):
 def rowbn_stats(y, counts):
     """(sum_r counts_r y_r, sum_r counts_r y_r^2) as float64 [C] each."""
     lib = _lib.load()
-    require_device(y, counts)
+    require_device(y)
     y = y.contiguous()
     R, C = y.shape
     sums = torch.zeros(2 * C, dtype=torch.float64, device=y.device)

@@ -286,7 +286,8 @@ int dva_deepset_bwd_first(const void* dz1, const float* x_map, const float* Wa, 
  * Weighted BatchNorm1d + LeakyReLU over the R rows of a feature map: one MLP block of E_mod
  * (pooling.py:245,275; core/common_modules/base_modules.py:38-48) evaluated on the map rows instead of
  * the V gathered views.  counts int32 [R] = views per row (dva_row_plan / dva_gather_row_index): the
- * batch statistics over the views are the statistics over the rows weighted by counts.
+ * batch statistics over the views are the statistics over the rows weighted by counts.  counts NULL = every
+ * row counts once: plain BatchNorm1d + LeakyReLU over [R, C] (used for E_mod on materialised [V, C] views).
  * y / out / grad_* are [R, C] in dtype; sums = caller-zeroed double[2*C]; bn = fp32 [4][C] =
  * mean | invstd | gamma | beta; sm = fp32 [2][C] = S1/n | S2/n (zeros when running statistics are used).
  * ------------------------------------------------------------------------------------------ */
