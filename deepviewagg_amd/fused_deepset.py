@@ -254,7 +254,8 @@ class _DeepSetLinear(torch.autograd.Function):
         del dz3
         # set branch backward with the same layer kernels over the N points
         n_rows = float(max(N, 1))
-        ident_bn = torch.tensor([0.0, 1.0, 1.0, 0.0], device=dev).repeat_interleave(D).contiguous()
+        ident_bn = torch.zeros(4 * D, dtype=torch.float32, device=dev)   # (mean 0 | invstd 1 | gamma 1 | beta 0),
+        ident_bn[D:3 * D] = 1.0                                          # built on the device: no host copy
         zero_sm = torch.zeros(2 * D, dtype=torch.float32, device=dev)
         dWcB = torch.zeros_like(WcB)
         dzs2, ss2 = buf(N, torch.float32), zstats()
