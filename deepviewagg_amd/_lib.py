@@ -117,6 +117,11 @@ SIGNATURES = {
     "dva_scale_f64": (ctypes.c_int, [_vp, ctypes.c_double, _vp, _i32, _vp]),
     "dva_voxel_parent_workspace_bytes": (ctypes.c_int64, [_i64]),
     "dva_voxel_parent_index": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "dva_voxel_kernel_map": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "dva_sparse_conv_workspace_bytes": (ctypes.c_int64, [_i32, _i32, _i32, _i32]),
+    "dva_sparse_conv_apply": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp,
+                                             _i64, _vp]),
+    "dva_sparse_conv_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_knn_workspace_bytes": (ctypes.c_int64, [_i64]),
     "dva_knn": (ctypes.c_int, [_vp, _i64, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_view_occlusion": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),

@@ -78,6 +78,39 @@ __global__ __launch_bounds__(256) void voxel_query_kernel(const int4* __restrict
   }
 }
 
+
+// Kernel map of a sparse convolution (torchsparse 1.1 `sphash(dst, offsets)` + `sphashquery`): for every
+// destination voxel j and kernel offset k, the source voxel whose coordinates are dst[j] + offsets[k]
+// (batch column untouched), or -1.  One thread per (k, j); the table is over the SOURCE voxels.
+__global__ __launch_bounds__(256) void voxel_kernel_map_kernel(const int4* __restrict__ src_coords,
+                                                                const int4* __restrict__ dst_coords,
+                                                                int64_t n_dst, const int32_t* __restrict__ offsets,
+                                                                int K, const int32_t* __restrict__ table,
+                                                                uint32_t mask, int32_t* __restrict__ nbr) {
+  const int64_t total = n_dst * (int64_t)K;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t / n_dst);
+    const int64_t j = t - (int64_t)k * n_dst;
+    int4 c = dst_coords[j];
+    c.x += offsets[3 * k];
+    c.y += offsets[3 * k + 1];
+    c.z += offsets[3 * k + 2];
+    uint32_t h = hash_coords(c) & mask;
+    int32_t found = -1;
+    for (;;) {
+      const int32_t i = table[h];
+      if (i == -1) break;
+      if (same(src_coords[i], c)) {
+        found = i;
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+    nbr[t] = found;
+  }
+}
+
 static inline uint64_t table_capacity(int64_t n_out) {
   uint64_t cap = 64;
   while (cap < 2 * (uint64_t)n_out) cap <<= 1;
@@ -121,6 +154,30 @@ int dva_voxel_parent_index(const int32_t* in_coords, int64_t n_in, const int32_t
                        n_out, table, (uint32_t)(cap - 1));
   hipLaunchKernelGGL(voxel_query_kernel, dim3(grid_of(n_in)), dim3(256), 0, s, (const int4*)in_coords, n_in,
                      (const int4*)out_coords, table, (uint32_t)(cap - 1), stride_out, batch_col, idx);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_voxel_kernel_map(const int32_t* src_coords, int64_t n_src, const int32_t* dst_coords, int64_t n_dst,
+                         const int32_t* offsets, int32_t K, int32_t* nbr, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  if (n_src < 0 || n_dst < 0 || K <= 0) return DVA_ERR_INVALID;
+  if (n_src > 0x3fffffffLL || n_dst > 0x3fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_dst == 0) return DVA_OK;
+  if (!dst_coords || !offsets || !nbr || !workspace) return DVA_ERR_INVALID;
+  if (n_src > 0 && !src_coords) return DVA_ERR_INVALID;
+  if (((uintptr_t)src_coords | (uintptr_t)dst_coords) & 15) return DVA_ERR_INVALID;
+  const uint64_t cap = table_capacity(n_src);
+  if ((int64_t)(cap * sizeof(int32_t)) > workspace_bytes) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* table = (int32_t*)workspace;
+  if (hipMemsetAsync(table, 0xff, cap * sizeof(int32_t), s) != hipSuccess) return DVA_ERR_LAUNCH;
+  if (n_src > 0)
+    hipLaunchKernelGGL(voxel_insert_kernel, dim3(grid_of(n_src)), dim3(256), 0, s, (const int4*)src_coords,
+                       n_src, table, (uint32_t)(cap - 1));
+  hipLaunchKernelGGL(voxel_kernel_map_kernel, dim3(grid_of(n_dst * K)), dim3(256), 0, s,
+                     (const int4*)src_coords, (const int4*)dst_coords, n_dst, offsets, (int)K, table,
+                     (uint32_t)(cap - 1), nbr);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -39,6 +39,30 @@ def _materialize(x_mod):
     return x_mod.materialize() if isinstance(x_mod, ops.GatheredFeatures) else x_mod
 
 
+def batchnorm_act_rows(y, bn, slope, counts=None, n=None):
+    """``leaky_slope(BatchNorm1d(y))`` on the rows of ``y`` [R, C] with the HIP row kernels (slope 0 = ReLU,
+    slope 1 = no activation).  ``counts`` weights the batch statistics (row r stands for counts[r] gathered
+    rows, ``n`` of them in total); running statistics are updated as ``nn.BatchNorm1d`` does."""
+    batch_stats = bn.training or not bn.track_running_stats
+    if batch_stats:
+        n = float(y.shape[0]) if n is None else float(n)
+        s1, s2 = ops.rowbn_stats(y, counts)
+        mean = s1 / n
+        var = (s2 / n - mean * mean).clamp_(min=0.0)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1 - m).add_(m * mean.float())
+                bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1.0, 1.0))).float())
+                bn.num_batches_tracked += 1
+        mean, var = mean.float(), var.float()
+    else:
+        n, mean, var = 1.0, bn.running_mean, bn.running_var
+    invstd = torch.rsqrt(var + bn.eps)
+    return ops.rowbn_act(y, counts, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                         mean, invstd, n, batch_stats, slope)
+
+
 def mlp_on_gathered_rows(mlp, rows, counts, n_views=None):
     """Evaluate ``mlp(rows[row_idx])`` WITHOUT gathering: returns ``out_rows`` such that
     ``out_rows[row_idx] == mlp(rows[row_idx])`` row for row.
@@ -58,27 +82,10 @@ def mlp_on_gathered_rows(mlp, rows, counts, n_views=None):
         if slope is None or x.dtype not in (torch.float32, torch.bfloat16):
             return _mlp_on_gathered_rows_torch(mlp, rows, counts)
         y = ops.tall_linear(x, lin.weight, lin.bias)
-        batch_stats = bn.training or not bn.track_running_stats
-        if n is None:
+        if n is None and (bn.training or not bn.track_running_stats):
             # number of gathered rows (views); callers pass it to avoid a device synchronisation
-            n = float(n_views if n_views is not None else (counts.sum() if counts is not None else x.shape[0])) \
-                if batch_stats else 1.0
-        if batch_stats:
-            s1, s2 = ops.rowbn_stats(y, counts)
-            mean = s1 / n
-            var = (s2 / n - mean * mean).clamp_(min=0.0)
-            if bn.training and bn.track_running_stats:
-                with torch.no_grad():
-                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                    bn.running_mean.mul_(1 - m).add_(m * mean.float())
-                    bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1.0, 1.0))).float())
-                    bn.num_batches_tracked += 1
-            mean, var = mean.float(), var.float()
-        else:
-            mean, var = bn.running_mean, bn.running_var
-        invstd = torch.rsqrt(var + bn.eps)
-        x = ops.rowbn_act(y, counts, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
-                          mean, invstd, n, batch_stats, slope)
+            n = float(n_views if n_views is not None else (counts.sum() if counts is not None else x.shape[0]))
+        x = batchnorm_act_rows(y, bn, slope, counts, n)
     return x
 
 

@@ -817,6 +817,116 @@ def voxel_parent_index(in_coords, out_coords, stride_out, batch_col=3):
 
 
 # ---------------------------------------------------------------------------------------------
+# sparse 3D convolution on voxel tensors (modules/SparseConv3d over torchsparse 1.1.0 Conv3d)
+# ---------------------------------------------------------------------------------------------
+
+def voxel_kernel_map(src_coords, dst_coords, offsets):
+    """``nbr[k, j] = i`` with ``src_coords[i] == dst_coords[j] + offsets[k]`` (spatial columns; equal batch
+    column), ``-1`` when absent.  int32 [K, n_dst]."""
+    lib = _lib.load()
+    require_device(src_coords, dst_coords)
+    assert src_coords.dim() == 2 and src_coords.shape[1] == 4 and dst_coords.dim() == 2 and dst_coords.shape[1] == 4
+    sc = src_coords.to(torch.int32).contiguous()
+    dc = dst_coords.to(torch.int32).contiguous()
+    off = torch.as_tensor(offsets, dtype=torch.int32).reshape(-1, 3).to(sc.device).contiguous()
+    K, n_src, n_dst = off.shape[0], sc.shape[0], dc.shape[0]
+    nbr = torch.empty((K, n_dst), dtype=torch.int32, device=sc.device)
+    nbytes = lib.dva_voxel_parent_workspace_bytes(n_src)
+    if nbytes < 0:
+        raise _lib.DvaError("dva_voxel_parent_workspace_bytes", int(nbytes))
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=sc.device)
+    with _timed("voxel_kernel_map", n_src * 24 + K * n_dst * 24):
+        check(lib.dva_voxel_kernel_map(ptr(sc), n_src, ptr(dc), n_dst, ptr(off), K, ptr(nbr), ptr(ws), int(nbytes),
+                                       stream_of(sc)), "dva_voxel_kernel_map")
+    return nbr
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+def _sparse_conv_apply(x, nbr, W, bias, n_dst, mode):
+    """out[j] = bias + sum_k x[nbr[k, j]] @ (W[k] if mode == 0 else W[k].T); channel counts padded to 16."""
+    lib = _lib.load()
+    K = nbr.shape[0]
+    cin, cout = (W.shape[1], W.shape[2]) if mode == 0 else (W.shape[2], W.shape[1])
+    assert x.shape[1] == cin, f"features have {x.shape[1]} channels, the kernel expects {cin}"
+    if x.shape[0] == 0 or n_dst == 0:
+        out = torch.zeros((n_dst, cout), dtype=x.dtype, device=x.device)
+        return out if bias is None else out + bias.to(x.dtype)
+    cin_p, cout_p = _pad16(cin), _pad16(cout)
+    Wf = W.detach().float()
+    if cin_p != cin or cout_p != cout:
+        pa, pb = (cin_p - cin, cout_p - cout) if mode == 0 else (cout_p - cout, cin_p - cin)
+        Wf = torch.nn.functional.pad(Wf, (0, pb, 0, pa))
+        x = torch.nn.functional.pad(x, (0, cin_p - cin))
+        if bias is not None:
+            bias = torch.nn.functional.pad(bias.detach().float(), (0, cout_p - cout))
+    x, Wf = x.contiguous(), Wf.contiguous()
+    bias = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty((n_dst, cout_p), dtype=x.dtype, device=x.device)
+    code = dtype_code(x)
+    nbytes = int(lib.dva_sparse_conv_workspace_bytes(K, cin_p, cout_p, code))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    s = x.element_size()
+    with _timed("sparse_conv_apply", n_dst * (K * 4 + cout_p * s) + x.shape[0] * cin_p * s):
+        check(lib.dva_sparse_conv_apply(ptr(x), ptr(nbr), ptr(Wf), ptr(bias), ptr(out), x.shape[0], n_dst, K, cin_p,
+                                        cout_p, mode, code, ptr(ws), nbytes, stream_of(x)), "dva_sparse_conv_apply")
+    return out if cout_p == cout else out[:, :cout].contiguous()
+
+
+def _sparse_conv_wgrad(x, nbr, gout, cin, cout):
+    lib = _lib.load()
+    K, n_dst = nbr.shape
+    cin_p, cout_p = _pad16(cin), _pad16(cout)
+    if cin_p != cin:
+        x = torch.nn.functional.pad(x, (0, cin_p - cin))
+    if cout_p != cout:
+        gout = torch.nn.functional.pad(gout, (0, cout_p - cout))
+    x, gout = x.contiguous(), gout.contiguous()
+    gW = torch.empty((K, cin_p, cout_p), dtype=torch.float32, device=x.device)
+    s = x.element_size()
+    with _timed("sparse_conv_wgrad", n_dst * (K * 4 + cout_p * s) + x.shape[0] * cin_p * s):
+        check(lib.dva_sparse_conv_wgrad(ptr(x), ptr(nbr), ptr(gout), ptr(gW), x.shape[0], n_dst, K, cin_p, cout_p,
+                                        dtype_code(x), stream_of(x)), "dva_sparse_conv_wgrad")
+    return gW if (cin_p == cin and cout_p == cout) else gW[:, :cin, :cout].contiguous()
+
+
+class _SparseConv(torch.autograd.Function):
+    """out = bias + sum_k x[nbr[k]] @ W[k].  ``nbr`` [K, n_dst] maps destination voxels to source rows, ``nbr_t``
+    [K, n_src] is the transposed map (source voxel -> destination row under the same offset)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, nbr, nbr_t):
+        require_device(x, W, nbr, nbr_t)
+        ctx.save_for_backward(x, W, nbr, nbr_t)
+        ctx.has_bias = bias is not None
+        return _sparse_conv_apply(x, nbr, W, bias, nbr.shape[1], 0)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, W, nbr, nbr_t = ctx.saved_tensors
+        gout = gout.contiguous().to(x.dtype)
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _sparse_conv_apply(gout, nbr_t, W, None, x.shape[0], 1)
+        if ctx.needs_input_grad[1]:
+            gW = _sparse_conv_wgrad(x, nbr, gout, W.shape[1], W.shape[2]).to(W.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gout.float().sum(0)
+        return gx, gW, gb, None, None
+
+
+def sparse_conv(x, W, bias, nbr, nbr_t):
+    """Sparse convolution over a kernel map pair (see ``voxel_kernel_map``): x [n_src, Cin] (fp32 or bf16),
+    W fp32 [K, Cin, Cout], bias [Cout] or None -> [n_dst, Cout].  Under ``torch.autocast`` the features are
+    taken in the autocast dtype (the weights stay fp32 masters, rounded to bf16 inside the kernel)."""
+    if torch.is_autocast_enabled() and x.is_cuda:
+        x = x.to(torch.get_autocast_gpu_dtype())
+    return _SparseConv.apply(x, W, bias, nbr, nbr_t)
+
+
+# ---------------------------------------------------------------------------------------------
 # neighbourhood-based mapping features (data_transform/multimodal/image.py:431-612)
 # ---------------------------------------------------------------------------------------------
 

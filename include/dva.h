@@ -333,6 +333,37 @@ int dva_voxel_parent_index(const int32_t* in_coords, int64_t n_in, const int32_t
                            int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * Sparse 3D convolution on voxel tensors.  Replaces torchsparse v1.1.0 `Conv3d` /
+ * transposed `Conv3d` (not in the reference tree) behind modules/SparseConv3d/nn/torchsparse.py:6-40, used by
+ * ResNetDown / ResNetUp / ResBlock (modules/SparseConv3d/modules.py:10-220).
+ *
+ * dva_voxel_kernel_map: nbr[k * n_dst + j] = i such that src_coords[i] == dst_coords[j] + offsets[k] on the
+ * first three columns with equal fourth (batch) column, else -1 (torchsparse `sphashquery(sphash(dst,
+ * offsets), sphash(src))`).  Coordinates int32 [n, 4], 16-byte aligned; offsets int32 [K, 3] on the device.
+ * Workspace: dva_voxel_parent_workspace_bytes(n_src).
+ *
+ * dva_sparse_conv_apply: out[j, :] = bias + sum_k x[nbr[k][j], :] @ Wk   (missing neighbours contribute 0).
+ *   mode 0: W = fp32 [K, Cin, Cout], Wk = W[k]            (forward; transposed convolution with its own map)
+ *   mode 1: W = fp32 [K, Cout, Cin], Wk = W[k]^T          (input gradient, with the transposed kernel map)
+ * x [n_src, Cin], out [n_dst, Cout] in `dtype` (DVA_F32: fp32 accuracy through a 3-term bf16 split on the
+ * matrix cores; DVA_BF16: bf16 operands, fp32 accumulation), bias fp32 [Cout] nullable.  Cin and Cout must be
+ * multiples of 16 (the host pads), n_src >= 1.  Workspace: dva_sparse_conv_workspace_bytes (re-packed weights).
+ * Every output row is written exactly once: deterministic, no atomics.
+ *
+ * dva_sparse_conv_wgrad: grad_W[k][a][b] = sum_j x[nbr[k][j]][a] * grad_out[j][b], fp32 [K, Cin, Cout],
+ * zeroed by the call, accumulated with fp32 atomics (summation order not fixed).
+ * ------------------------------------------------------------------------------------------ */
+int dva_voxel_kernel_map(const int32_t* src_coords, int64_t n_src, const int32_t* dst_coords, int64_t n_dst,
+                         const int32_t* offsets, int32_t K, int32_t* nbr, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int64_t dva_sparse_conv_workspace_bytes(int32_t K, int32_t Cin, int32_t Cout, int32_t dtype);
+int dva_sparse_conv_apply(const void* x, const int32_t* nbr, const float* W, const float* bias, void* out,
+                          int64_t n_src, int64_t n_dst, int32_t K, int32_t Cin, int32_t Cout, int32_t mode,
+                          int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream);
+int dva_sparse_conv_wgrad(const void* x, const int32_t* nbr, const void* grad_out, float* grad_W, int64_t n_src,
+                          int64_t n_dst, int32_t K, int32_t Cin, int32_t Cout, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * Neighbourhood-based mapping features (core/data_transform/multimodal/image.py:431-612): exact k nearest
  * neighbours of every point among all points (replaces KeOps `((x_i - x_j)**2).sum(2).argKmin(k, dim=1)`,
  * :506-507; pykeops 1.4.2 is not in the reference tree) and the per-view occlusion counts (:560-599).
