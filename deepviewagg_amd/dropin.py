@@ -22,6 +22,8 @@ _ALIASES = {
     "torch_points3d.core.multimodal.image": "deepviewagg_amd.core.multimodal.image",
     "torch_points3d.core.multimodal.visibility": "deepviewagg_amd.core.multimodal.visibility",
     "torch_points3d.utils.multimodal": "deepviewagg_amd.utils.multimodal",
+    "torch_points3d.modules.SparseConv3d.modules": "deepviewagg_amd.modules.SparseConv3d.modules",
+    "torch_points3d.modules.SparseConv3d.nn": "deepviewagg_amd.modules.SparseConv3d.nn",
 }
 
 

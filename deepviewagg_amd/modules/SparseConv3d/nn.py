@@ -29,6 +29,22 @@ from ..multimodal.pooling import batchnorm_act_rows
 
 __all__ = ["cat", "Conv3d", "Conv3dTranspose", "ReLU", "SparseTensor", "BatchNorm"]
 
+# modules/SparseConv3d/nn/__init__.py:28-60: the reference switches between two sparse libraries; here there
+# is one backend, which carries the torchsparse field names (F, C, s, coord_maps) the multimodal blocks read.
+sp3d_backend = "torchsparse"
+
+
+def backend_valid(_backend):
+    return _backend in {"torchsparse", "minkowski"}
+
+
+def get_backend():
+    return sp3d_backend
+
+
+def set_backend(_backend):
+    assert backend_valid(_backend)
+
 
 class SparseVoxelTensor:
     """``F`` features, ``C`` int32 [n, 4] (x, y, z, batch), ``s`` tensor stride, shared caches."""
@@ -132,7 +148,12 @@ class Conv3d(nn.Module):
         out_coords = x.C if stride == 1 else downsample_coords(x.C, out_stride)
         offs = kernel_offsets(kernel_size, x.s, dilation)
         nbr = ops.voxel_kernel_map(x.C, out_coords, offs)          # destination j <- source i
-        nbr_t = ops.voxel_kernel_map(out_coords, x.C, -offs)       # source i <- destination j
+        if stride == 1 and kernel_size % 2 == 1:
+            # same voxels on both sides and a point-symmetric offset list (offset_k = -offset_{K-1-k}): the
+            # transposed map is the map itself with the offsets in reverse order
+            nbr_t = torch.flip(nbr, [0])
+        else:
+            nbr_t = ops.voxel_kernel_map(out_coords, x.C, -offs)   # source i <- destination j
         x.kernel_maps[key] = (nbr, nbr_t)
         x.coord_maps.setdefault(out_stride, out_coords)
 

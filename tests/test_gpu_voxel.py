@@ -117,3 +117,43 @@ def test_multimodal_block_down_merges_mappings_onto_parent_voxels():
     exp_seen = torch.zeros(out_c.shape[0], dtype=torch.int64).index_add_(0, ref_idx, x_seen.cpu().long()) > 0
     assert torch.equal(out['x_seen'].cpu().bool(), exp_seen)
     assert out['x_3d'].s == 2 and got.num_groups == out_c.shape[0]
+
+
+def test_multimodal_block_down_with_the_hip_resnet_stage():
+    """The same contract with the real strided block: ResNetDown (HIP sparse convolution) between the
+    multimodal branches; its output voxels / stride drive the re-indexing of the mappings."""
+    from deepviewagg_amd.core.multimodal.image import ImageMapping
+    from deepviewagg_amd.modules.multimodal.modules import MultimodalBlockDown, IdentityBranch
+    from deepviewagg_amd.modules.SparseConv3d import ResNetDown, nn as snn
+    g = load_golden("mapping_build")
+    n_pts = len(g["pointers"]) - 1
+    m = ImageMapping.from_dense(t(g["dense_point_ids"], DEV), t(g["dense_image_ids"], DEV),
+                                t(g["dense_pixels"], DEV), t(g["dense_features"], DEV), num_points=n_pts)
+    gen = torch.Generator().manual_seed(2)
+    side = int(np.ceil(n_pts ** (1 / 3))) + 1
+    lin = torch.randperm(side ** 3, generator=gen)[:n_pts]
+    coords = torch.stack([lin % side, (lin // side) % side, lin // (side * side), torch.zeros_like(lin)], 1).int()
+    x_seen = (m.pointers[1:] > m.pointers[:-1])
+
+    class _Mod:
+        def __init__(self, mapping):
+            self.mapping = mapping
+
+        def select_points(self, idx, mode='pick'):
+            return _Mod(self.mapping.select_points(idx, mode=mode))
+
+    torch.manual_seed(0)
+    stage = ResNetDown(down_conv_nn=[4, 16], N=1).to(DEV)
+    x = snn.SparseVoxelTensor(torch.randn(n_pts, 4, device=DEV), coords.to(DEV))
+    out = MultimodalBlockDown(stage, None, image=IdentityBranch())(
+        dict(x_3d=x, x_seen=x_seen, modalities=dict(image=_Mod(m))))
+    out_c = out['x_3d'].C.cpu()
+    assert out['x_3d'].s == 2 and out['x_3d'].F.shape == (out_c.shape[0], 16)
+    assert torch.equal(torch.unique(out_c, dim=0), torch.unique(VO.floor_coords(coords, 2), dim=0))
+    ref_idx = torch.from_numpy(VO.voxel_parent_index(coords.numpy(), out_c.numpy(), 2))
+    assert int(ref_idx.min()) >= 0
+    exp = m.select_points(ref_idx.to(DEV), mode='merge')
+    got = out['modalities']['image'].mapping
+    assert torch.equal(got.pointers, exp.pointers) and torch.equal(got.images, exp.images)
+    assert torch.equal(got.pixels, exp.pixels) and torch.allclose(got.features, exp.features)
+    assert got.num_groups == out_c.shape[0]

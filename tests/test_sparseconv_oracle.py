@@ -30,6 +30,8 @@ def test_oracle_matches_dense_conv3d_stride1():
     out = O.sparse_conv(x, W, None, nbr)
     ref, _ = O.dense_reference(x, coords, W, 3)
     assert torch.allclose(out, ref, atol=1e-10)
+    # same voxels on both sides + point-symmetric offsets: the transposed map is the map in reverse offset order
+    assert torch.equal(O.kernel_map(coords, coords, -O.kernel_offsets(3)), torch.flip(nbr, [0]))
 
 
 def test_oracle_matches_dense_conv3d_strided_and_transposed():

@@ -30,14 +30,15 @@ key = ((coords[:, 2] // 8).long() * 4096 + (coords[:, 1] // 8).long()) * 4096 + 
 coords = coords[torch.argsort(key)].contiguous()
 n = coords.shape[0]
 offs = snn.kernel_offsets(3, 1)
+ops.voxel_kernel_map(coords[:1000], coords[:1000], offs)      # warm-up
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 nbr = ops.voxel_kernel_map(coords, coords, offs)
-nbr_t = ops.voxel_kernel_map(coords, coords, -offs)
 torch.cuda.synchronize()
 t_map = (time.perf_counter() - t0) * 1e3
+nbr_t = torch.flip(nbr, [0])
 pairs = int((nbr >= 0).sum())
-print(f"{n} voxels, {pairs / n:.1f} neighbours / voxel of 27, kernel maps (both directions) {t_map:.2f} ms")
+print(f"{n} voxels, {pairs / n:.1f} neighbours / voxel of 27, kernel map 3x3x3 {t_map:.2f} ms")
 
 x = torch.randn(n, C, device=dev, dtype=dtype, requires_grad=True)
 W = (torch.randn(27, C, C, device=dev) / 40).requires_grad_(True)
@@ -70,10 +71,14 @@ with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat1
         y = stage(xs)
         y.F.float().square().mean().backward()
     torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(reps):
         y = stage(xs)
         y.F.float().square().mean().backward()
     torch.cuda.synchronize()
+timer, ops.TIMER = ops.TIMER, None
+for name, a in sorted(timer.summary().items(), key=lambda kv: -kv[1]["ms"]):
+    print(f"  {name:22s} {a['ms'] / reps:7.3f} ms/step in {a['launches'] // reps} launches")
 print(f"ResNetDown({C}->{2 * C}, N=2) on {n} -> {y.F.shape[0]} voxels: fwd+bwd "
       f"{(time.perf_counter() - t0) / reps * 1e3:.2f} ms (kernel maps cached)")
