@@ -41,6 +41,18 @@ class SparseVoxels:
         self.coord_maps.setdefault(s, C)
 
 
+def multimodal_input(data, device, is_multimodal=True):
+    """The input dictionary the multimodal blocks consume, from a batch object with ``x``, ``coords``, ``batch``
+    and ``modalities`` (reference ``BaseSparseConv3d._set_input``, applications/sparseconv3d.py:145-165):
+    ``{'x_3d': voxel tensor, 'x_seen': None, 'modalities': data.to(device).modalities}``; a bare voxel tensor
+    for a 3D-only model."""
+    from ..SparseConv3d import nn as snn
+    x_3d = snn.SparseTensor(data.x, data.coords, data.batch, device)
+    if not is_multimodal:
+        return x_3d
+    return {'x_3d': x_3d, 'x_seen': None, 'modalities': data.to(device).modalities}
+
+
 def _is_voxel_tensor(x):
     return all(hasattr(x, a) for a in ('C', 's', 'coord_maps'))
 

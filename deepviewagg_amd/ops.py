@@ -841,6 +841,9 @@ def voxel_kernel_map(src_coords, dst_coords, offsets):
     return nbr
 
 
+SPARSE_CONV_TIMER_SHAPES = False   # bench tools: label the KernelTimer entries with the layer shape
+
+
 def _pad16(c):
     return (c + 15) // 16 * 16
 
@@ -869,7 +872,8 @@ def _sparse_conv_apply(x, nbr, W, bias, n_dst, mode):
     nbytes = int(lib.dva_sparse_conv_workspace_bytes(K, cin_p, cout_p, code))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     s = x.element_size()
-    with _timed("sparse_conv_apply", n_dst * (K * 4 + cout_p * s) + x.shape[0] * cin_p * s):
+    with _timed(f"sparse_conv_apply{SPARSE_CONV_TIMER_SHAPES and f'[{K}x{cin_p}->{cout_p}@{n_dst}]' or ''}",
+                n_dst * (K * 4 + cout_p * s) + x.shape[0] * cin_p * s):
         check(lib.dva_sparse_conv_apply(ptr(x), ptr(nbr), ptr(Wf), ptr(bias), ptr(out), x.shape[0], n_dst, K, cin_p,
                                         cout_p, mode, code, ptr(ws), nbytes, stream_of(x)), "dva_sparse_conv_apply")
     return out if cout_p == cout else out[:, :cout].contiguous()
@@ -886,7 +890,8 @@ def _sparse_conv_wgrad(x, nbr, gout, cin, cout):
     x, gout = x.contiguous(), gout.contiguous()
     gW = torch.empty((K, cin_p, cout_p), dtype=torch.float32, device=x.device)
     s = x.element_size()
-    with _timed("sparse_conv_wgrad", n_dst * (K * 4 + cout_p * s) + x.shape[0] * cin_p * s):
+    with _timed(f"sparse_conv_wgrad{SPARSE_CONV_TIMER_SHAPES and f'[{K}x{cin_p}->{cout_p}@{n_dst}]' or ''}",
+                n_dst * (K * 4 + cout_p * s) + x.shape[0] * cin_p * s):
         check(lib.dva_sparse_conv_wgrad(ptr(x), ptr(nbr), ptr(gout), ptr(gW), x.shape[0], n_dst, K, cin_p, cout_p,
                                         dtype_code(x), stream_of(x)), "dva_sparse_conv_wgrad")
     return gW if (cin_p == cin and cout_p == cout) else gW[:, :cin, :cout].contiguous()

@@ -196,3 +196,76 @@ def test_image_batch_round_trip():
             assert torch.equal(sa.mappings.images, sb.mappings.images)
             assert torch.equal(sa.mappings.pixels, sb.mappings.pixels)
             assert torch.equal(sa.mappings.features, sb.mappings.features)
+
+
+def test_end_to_end_multimodal_encoder_decoder():
+    """mapping -> lazy gather -> atomic + view pooling -> fusion INTO a voxel tensor -> strided HIP sparse
+    convolution stage (mappings merged onto the parent voxels) -> second branch at the coarse stride -> decoder
+    stage with the skip connection.  Every piece has its own parity test; here the assembled pipeline must equal
+    the manual composition of those pieces, be repeatable, and give every parameter and input a gradient."""
+    from types import SimpleNamespace
+    from deepviewagg_amd.core.multimodal.image import ImageData
+    from deepviewagg_amd.modules.multimodal import (UnimodalBranch, BimodalCSRPool, GroupBimodalCSRPool,
+                                                    BimodalFusion)
+    from deepviewagg_amd.modules.multimodal.modules import MultimodalBlockDown, multimodal_input
+    from deepviewagg_amd.modules.SparseConv3d import ResNetDown, ResNetUp
+    g = load_golden("branch_nearest")
+    n_set = int(g["n_settings"])
+    torch.manual_seed(0)
+
+    def fresh_inputs():
+        xs = [t(g[f"s{i}_x_img"], DEV).requires_grad_() for i in range(n_set)]
+        sds = [make_image_data(g, f"s{i}_", xs[i], g[f"s{i}_ref_size"], DEV) for i in range(n_set)]
+        x_3d = t(g["x_3d"])
+        n = x_3d.shape[0]
+        side = int(np.ceil(n ** (1 / 3))) + 1
+        lin = torch.randperm(side ** 3, generator=torch.Generator().manual_seed(7))[:n]
+        coords = torch.stack([lin % side, (lin // side) % side, lin // (side * side)], 1).int()
+
+        class _Batch(SimpleNamespace):
+            def to(self, device):
+                return self
+        data = _Batch(x=x_3d.requires_grad_(), coords=coords, batch=torch.zeros(n, dtype=torch.long), pos=None,
+                      modalities={"image": ImageData(sds)})
+        return xs, data
+
+    def branch(c3d):
+        pool = GroupBimodalCSRPool(in_map=8, in_mod=8, num_groups=4, use_num=True)
+        return UnimodalBranch(Conv(6, 8), BimodalCSRPool(mode="max"), pool, BimodalFusion(mode="concatenation"))
+    nc = int(g["x_3d"].shape[1])
+    enc = MultimodalBlockDown(ResNetDown(down_conv_nn=[nc, 16], N=1), ResNetDown(down_conv_nn=[24, 32], stride=1,
+                                                                               kernel_size=3, N=1),
+                              image=branch(16)).to(DEV).train()
+    dec = ResNetUp(up_conv_nn=[32, nc, 12], N=1).to(DEV).train()
+
+    def run():
+        xs, data = fresh_inputs()
+        mm = multimodal_input(data, DEV)
+        skip = mm["x_3d"]
+        out = enc(mm)
+        y = dec(out["x_3d"], skip)
+        return xs, data, out, y
+    xs, data, out, y = run()
+    n = data.x.shape[0]
+    assert out["x_3d"].s == 2 and out["x_3d"].F.shape[1] == 32 and y.s == 1 and y.F.shape == (n, 12)
+    assert out["modalities"]["image"].num_points == out["x_3d"].C.shape[0] == out["x_seen"].shape[0]
+    assert torch.isfinite(y.F).all()
+    loss = y.F.square().mean()
+    params = [p for p in list(enc.parameters()) + list(dec.parameters())]
+    grads = torch.autograd.grad(loss, xs + [data.x] + params, allow_unused=True)
+    assert all(gr is not None and torch.isfinite(gr).all() for gr in grads)
+    assert all(float(gr.abs().sum()) > 0 for gr in grads[:len(xs) + 1])
+    # repeatable: eval mode (no running-statistics drift), two evaluations agree bit for bit on the features
+    enc.eval(), dec.eval()
+    _, _, _, y1 = run()
+    _, _, _, y2 = run()
+    assert torch.equal(y1.F, y2.F)
+    # manual composition of the separately tested pieces
+    xs, data = fresh_inputs()
+    mm = multimodal_input(data, DEV)
+    skip = mm["x_3d"]
+    mm = MultimodalBlockDown.forward_3d_block_down(mm, enc.block_1)
+    mm = enc.image(mm, "image")
+    mm = MultimodalBlockDown.forward_3d_block_down(mm, enc.block_2)
+    y3 = dec(mm["x_3d"], skip)
+    assert torch.equal(y3.F, y1.F)

@@ -72,6 +72,7 @@ with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat1
         y.F.float().square().mean().backward()
     torch.cuda.synchronize()
     ops.TIMER = ops.KernelTimer()
+    ops.SPARSE_CONV_TIMER_SHAPES = True
     t0 = time.perf_counter()
     for _ in range(reps):
         y = stage(xs)
