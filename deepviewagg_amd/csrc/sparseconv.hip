@@ -109,8 +109,10 @@ template <> struct OutStore<bf16_t> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void sconv_apply_kernel(const T* __restrict__ x, const int32_t* __restrict__ nbr,
+// NT = 32-channel output blocks per wavefront (2: 64 output channels per workgroup, 4: 128 -- wide layers
+// gather each input row once per 128 output channels instead of once per 64)
+template <typename T, int NT>
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void sconv_apply_kernel(const T* __restrict__ x, const int32_t* __restrict__ nbr,
                                                            const bf16_t* __restrict__ w_hi,
                                                            const bf16_t* __restrict__ w_lo,
                                                            const float* __restrict__ bias, T* __restrict__ out,
@@ -118,17 +120,18 @@ __global__ __launch_bounds__(256) void sconv_apply_kernel(const T* __restrict__ 
                                                            int Cout_p) {
   constexpr bool SPLIT = sizeof(T) == 4;
   constexpr int NB = SPLIT ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) bf16_t s_w[];  // [2 buffers][NB][SC_TILE][SC_WS]
+  constexpr int NROWS = 32 * NT;                                 // output channels of this workgroup
+  extern __shared__ __attribute__((aligned(16))) bf16_t s_w[];  // [2 buffers][NB][NROWS][SC_WS]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jl = lane & 31, h = lane >> 5;
   const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-  const int n0 = blockIdx.y * SC_TILE;
+  const int n0 = blockIdx.y * NROWS;
   const int chunks = Cin_p / SC_TILE;
   const int total = K * chunks;
 
-  sc_f32x16 acc[2][2];
+  sc_f32x16 acc[NT][2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -137,14 +140,13 @@ __global__ __launch_bounds__(256) void sconv_apply_kernel(const T* __restrict__ 
   auto stage = [&](int it, int buf) {
     const int k = it / chunks, cc = it - k * chunks;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = threadIdx.x + 256 * i;  // 512 pieces of 16 bytes
+    for (int i = 0; i < NT; ++i) {
+      const int p = threadIdx.x + 256 * i;  // NROWS * 8 pieces of 16 bytes
       const int n = p >> 3, c8 = p & 7;
       const int64_t g = ((int64_t)k * Cout_p + n0 + n) * Cin_p + cc * SC_TILE + c8 * 8;
-      bf16_t* dst = s_w + ((size_t)(buf * NB) * SC_TILE + n) * SC_WS + c8 * 8;
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(w_hi + g);
-      if (SPLIT)
-        *reinterpret_cast<uint4*>(dst + SC_TILE * SC_WS) = *reinterpret_cast<const uint4*>(w_lo + g);
+      bf16_t* dst = s_w + ((size_t)(buf * NB) * NROWS + n) * SC_WS + c8 * 8;
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(w_hi + g);  // Cout_p: multiple of NROWS
+      if (SPLIT) *reinterpret_cast<uint4*>(dst + NROWS * SC_WS) = *reinterpret_cast<const uint4*>(w_lo + g);
     }
   };
 
@@ -170,21 +172,21 @@ __global__ __launch_bounds__(256) void sconv_apply_kernel(const T* __restrict__ 
         for (int t = 0; t < 2; ++t)
           xf[t][m].load(x + (int64_t)max(idx[t], 0) * Cin + c0 + 16 * m + 8 * h);
       }
-    const bf16_t* wb = s_w + (size_t)((it & 1) * NB) * SC_TILE * SC_WS;
+    const bf16_t* wb = s_w + (size_t)((it & 1) * NB) * NROWS * SC_WS;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
       if (m < msteps) {
-        sc_bf16x8 bh[2], bl[2], ah[2], al[2];
+        sc_bf16x8 bh[2], bl[2], ah[NT], al[NT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) xf[t][m].get(idx[t] >= 0, bh[t], bl[t]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NT; ++u) {
           const bf16_t* wp = wb + (32 * u + jl) * SC_WS + 16 * m + 8 * h;
           ah[u] = *reinterpret_cast<const sc_bf16x8*>(wp);
-          if (SPLIT) al[u] = *reinterpret_cast<const sc_bf16x8*>(wp + SC_TILE * SC_WS);
+          if (SPLIT) al[u] = *reinterpret_cast<const sc_bf16x8*>(wp + NROWS * SC_WS);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NT; ++u)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             acc[u][t] = SC_MFMA(ah[u], bh[t], acc[u][t]);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void sconv_apply_kernel(const T* __restrict__ 
     const int64_t j = j0 + 32 * t + jl;
     if (j >= n_dst) continue;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + 32 * u + 8 * q + 4 * h;
@@ -363,12 +365,14 @@ __global__ __launch_bounds__(256) void sconv_wgrad_kernel(const T* __restrict__ 
 }
 
 static inline int pad_tile(int c) { return (c + SC_TILE - 1) / SC_TILE * SC_TILE; }
+// output channels of the re-packed weights: one 64-wide tile, or multiples of the 128-wide tile of wide layers
+static inline int pad_out(int c) { return c <= SC_TILE ? SC_TILE : (c + 127) / 128 * 128; }
 
 template <typename T>
 static int sconv_apply_impl(const void* x, const int32_t* nbr, const float* W, const float* bias, void* out,
                             int64_t n_dst, int K, int Cin, int Cout, int mode, void* ws, hipStream_t s) {
   constexpr bool SPLIT = sizeof(T) == 4;
-  const int Cin_p = pad_tile(Cin), Cout_p = pad_tile(Cout);
+  const int Cin_p = pad_tile(Cin), Cout_p = pad_out(Cout);
   const int64_t elems = (int64_t)K * Cin_p * Cout_p;
   bf16_t* w_hi = (bf16_t*)ws;
   bf16_t* w_lo = SPLIT ? w_hi + elems : nullptr;
@@ -377,9 +381,15 @@ static int sconv_apply_impl(const void* x, const int32_t* nbr, const float* W, c
   hipLaunchKernelGGL(sconv_prep_weights_kernel, dim3((int)pb), dim3(256), 0, s, W, K, Cin, Cout, Cin_p, Cout_p,
                      mode, w_hi, w_lo);
   const int64_t gx = (n_dst + 255) / 256;
-  const size_t lds = (size_t)2 * (SPLIT ? 2 : 1) * SC_TILE * SC_WS * sizeof(bf16_t);
-  hipLaunchKernelGGL((sconv_apply_kernel<T>), dim3((unsigned)gx, Cout_p / SC_TILE), dim3(256), lds, s,
-                     (const T*)x, nbr, w_hi, w_lo, bias, (T*)out, n_dst, K, Cin, Cout, Cin_p, Cout_p);
+  if (Cout_p >= 128) {
+    const size_t lds = (size_t)2 * (SPLIT ? 2 : 1) * 128 * SC_WS * sizeof(bf16_t);
+    hipLaunchKernelGGL((sconv_apply_kernel<T, 4>), dim3((unsigned)gx, Cout_p / 128), dim3(256), lds, s,
+                       (const T*)x, nbr, w_hi, w_lo, bias, (T*)out, n_dst, K, Cin, Cout, Cin_p, Cout_p);
+  } else {
+    const size_t lds = (size_t)2 * (SPLIT ? 2 : 1) * SC_TILE * SC_WS * sizeof(bf16_t);
+    hipLaunchKernelGGL((sconv_apply_kernel<T, 2>), dim3((unsigned)gx, Cout_p / SC_TILE), dim3(256), lds, s,
+                       (const T*)x, nbr, w_hi, w_lo, bias, (T*)out, n_dst, K, Cin, Cout, Cin_p, Cout_p);
+  }
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
@@ -392,7 +402,7 @@ extern "C" {
 
 int64_t dva_sparse_conv_workspace_bytes(int32_t K, int32_t Cin, int32_t Cout, int32_t dtype) {
   if (K <= 0 || Cin <= 0 || Cout <= 0 || (dtype != DVA_F32 && dtype != DVA_BF16)) return DVA_ERR_INVALID;
-  return (int64_t)K * pad_tile(Cin) * pad_tile(Cout) * 2 * (dtype == DVA_F32 ? 2 : 1);
+  return (int64_t)K * pad_tile(Cin) * pad_out(Cout) * 2 * (dtype == DVA_F32 ? 2 : 1);
 }
 
 int dva_sparse_conv_apply(const void* x, const int32_t* nbr, const float* W, const float* bias, void* out,
