@@ -35,3 +35,22 @@ def test_voxel_oracle_floor_and_lookup():
     assert VO.floor_coords(c, 2).tolist() == [[0, 0, 2, 0], [2, -2, 4, 1], [-4, -4, 6, 1], [8, 8, 8, 0]]
     out = np.array([[2, -2, 4, 1], [0, 0, 2, 0], [-4, -4, 6, 1]], dtype=np.int32)
     assert VO.voxel_parent_index(c, out, 2).tolist() == [1, 0, 2, -1]
+
+
+def test_modality_dropout_drops_the_whole_tensor():
+    """dropout.py:5-15: train = all-or-nothing Bernoulli(1 - p) per call, eval = scale by 1 / (1 - p)."""
+    import pytest
+    import torch
+    from deepviewagg_amd.modules.multimodal.dropout import ModalityDropout
+    torch.manual_seed(0)
+    x = torch.randn(50, 7)
+    drop = ModalityDropout(p=0.3, inplace=True).train()
+    kept = 0
+    for _ in range(400):
+        y = drop(x)
+        assert torch.equal(y, x) or float(y.abs().sum()) == 0.0
+        kept += int(torch.equal(y, x))
+    assert 0.6 < kept / 400 < 0.8 and torch.equal(x, x.clone())      # input untouched
+    assert torch.allclose(drop.eval()(x), x / 0.7)
+    with pytest.raises(AssertionError):
+        ModalityDropout(p=1.5)
