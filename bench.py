@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--materialize", action="store_true",
                     help="diagnostic: materialised [V, C] gather + per-view E_mod (the reference's dataflow) instead "
                          "of the lazy gather / hoisted E_mod")
-    ap.add_argument("--workload", default="S1", choices=["S1", "S2"],
+    ap.add_argument("--workload", default="S1", choices=["S1", "S2", "S1c"],
                     help="S1: every point seen by --views images (headline); S2: ragged view counts "
                          "min(views, 1 + Geom(0.2)), 10 %% of the points unseen (SURVEY.md 8(d))")
     return ap.parse_args()
@@ -52,9 +52,12 @@ def parse():
 
 def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed, workload="S1"):
     """Synthetic scene of SURVEY.md §8(d).  S1: every point seen by `views` images at random pixels;
-    S2: ragged view counts k_i = min(views, 1 + Geom(0.2)), 10 % of the points unseen."""
+    S2: ragged view counts k_i = min(views, 1 + Geom(0.2)), 10 % of the points unseen.
+    S1c (not in the survey; a locality probe): S1 with projection-like pixels -- the points lie on a raster in
+    memory order and neighbouring points hit neighbouring pixels of every image (+-1 pixel jitter), as the
+    points of a voxelised scan do; same number of views per feature-map row as S1."""
     g = torch.Generator(device=device).manual_seed(seed)
-    if workload == "S1":
+    if workload in ("S1", "S1c"):
         V = n_points * views
         csr = torch.arange(0, V + 1, views, dtype=torch.int64, device=device)
         # image ids: each point's views hit distinct images (sorted per point, like from_dense)
@@ -75,8 +78,17 @@ def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed, workload
         pt = torch.arange(n_points, device=device).repeat_interleave(k)
         img = (start + rank) % n_images
         images = img[torch.argsort(pt * n_images + img)]
-    pixels = torch.stack([torch.randint(0, W, (V,), generator=g, device=device),
-                          torch.randint(0, H, (V,), generator=g, device=device)], 1).to(torch.int16)
+    if workload == "S1c":
+        side = int(round(n_points ** 0.5))
+        pid = torch.arange(n_points, device=device).repeat_interleave(views)
+        u, v = pid % side, (pid // side).clamp_(max=side - 1)
+        shift = torch.randint(0, 1 << 16, (n_images, 2), generator=g, device=device)[images]
+        jit = torch.randint(-1, 2, (V, 2), generator=g, device=device)
+        pixels = torch.stack([(u * W // side + shift[:, 0] + jit[:, 0]) % W,
+                              (v * H // side + shift[:, 1] + jit[:, 1]) % H], 1).to(torch.int16)
+    else:
+        pixels = torch.stack([torch.randint(0, W, (V,), generator=g, device=device),
+                              torch.randint(0, H, (V,), generator=g, device=device)], 1).to(torch.int16)
     atom_ptr = torch.arange(V + 1, dtype=torch.int64, device=device)  # exact mapping: 1 pixel/view
     x = torch.randn(n_images, C, H, W, generator=g, device=device).to(dtype)
     x = x.contiguous(memory_format=torch.channels_last)
@@ -354,7 +366,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}/F-S: N=2^{args.log2_points} points x "
-                                   f"{views if args.workload == 'S1' else 'ragged <= ' + str(views)} views (V={V_scene}), "
+                                   f"{views if args.workload != 'S2' else 'ragged <= ' + str(views)} views (V={V_scene}), "
                                    f"32 feature maps [{C},{H},{W}] {args.dtype} channels-last, nearest gather -> "
                                    f"max atomic pool -> GroupBimodalCSRPool(G=4, DeepSetFeat, train) -> concat; backward seeded "
                                    f"with a fixed upstream gradient [N, 4+C]; "

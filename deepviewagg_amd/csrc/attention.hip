@@ -216,7 +216,7 @@ struct TeamGeom {
 
 // Forward.  Requirements (checked by the host): C % VEC == 0, C/VEC == lpr exactly (power of two),
 // C % G == 0, (C/G) % VEC == 0, G <= ts, G power of two.
-template <typename T>
+template <typename T, int LPR, int ROWS>   // LPR > 0: compile-time team geometry (LPR lanes per row x ROWS rows)
 __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     const T* __restrict__ val, const int32_t* __restrict__ row_idx, const float* __restrict__ compat,
     const int64_t* __restrict__ ptr,
@@ -224,21 +224,25 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     float* __restrict__ att, float* __restrict__ gate, int32_t* __restrict__ amax, int64_t N, int C,
     int G, int scaling, float eps, TeamGeom tg) {
   constexpr int VEC = Vec16<T>::N;
+  // team geometry: constants in the specialised instances (divisions become shifts, the reduction loops unroll,
+  // the shuffle offsets are immediates), taken from `tg` in the generic one
+  const int tg_lpr = LPR > 0 ? LPR : tg.lpr, tg_rows = LPR > 0 ? ROWS : tg.rows;
+  const int tg_ts = tg_lpr * tg_rows, tg_lpg = tg_lpr / G;
   typedef typename Vec16<T>::raw raw_t;
   const int lane = threadIdx.x & 63;
-  const int li = lane & (tg.ts - 1);        // lane in team
+  const int li = lane & (tg_ts - 1);        // lane in team
   const int team_base = lane - li;          // first lane of the team inside the wave
-  const int lane_r = li & (tg.lpr - 1);     // position inside the row
-  const int row_slot = li / tg.lpr;         // which of the R rows in flight
-  const int g_lane = lane_r / tg.lpg;       // group of this lane's channels
-  const bool g_first = (lane_r % tg.lpg) == 0;
+  const int lane_r = li & (tg_lpr - 1);     // position inside the row
+  const int row_slot = li / tg_lpr;         // which of the R rows in flight
+  const int g_lane = lane_r / tg_lpg;       // group of this lane's channels
+  const bool g_first = (lane_r % tg_lpg) == 0;
   // softmax-statistics mapping: lane li <-> (view slot, group)
   const int sg = li & (G - 1);
   const int vslot = li / G;
-  const int VS = tg.ts / G;
+  const int VS = tg_ts / G;
 
-  const int teams_per_block = blockDim.x / tg.ts;
-  const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg.ts;
+  const int teams_per_block = blockDim.x / tg_ts;
+  const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg_ts;
   const int64_t team_stride = (int64_t)gridDim.x * teams_per_block;
 
   // Software pipeline over the points of a team, three stages deep, so that the three dependent loads of
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     int32_t ri[U];
     float cg[U];
   };
-  auto is_small = [&](int n) { return n > 0 && n <= U * tg.rows; };
+  auto is_small = [&](int n) { return n > 0 && n <= U * tg_rows; };
   auto load_a = [&](int64_t p, int64_t& beg, int& n) {
     beg = 0;
     n = 0;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     if (is_small(n)) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int v = row_slot + u * tg.rows;
+        const int v = row_slot + u * tg_rows;
         const int64_t r = beg + (v < n ? v : 0);
         if (row_idx) b.ri[u] = row_idx[r];
         b.cg[u] = compat[r * G + g_lane];
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       raw_t x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int v = row_slot + u * tg.rows;
+        const int v = row_slot + u * tg_rows;
         ok[u] = v < n;
         rr[u] = beg + (ok[u] ? v : 0);
         const int64_t ri = row_idx ? (int64_t)sb.ri[u] : rr[u];
@@ -306,10 +310,10 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       for (int u = 0; u < U; ++u) {
         if (ok[u] && cg[u] > m) {     // views ascend with u inside a lane: strict > keeps the first
           m = cg[u];
-          am = row_slot + u * tg.rows;
+          am = row_slot + u * tg_rows;
         }
       }
-      for (int off = tg.lpr; off < tg.ts; off <<= 1) {
+      for (int off = tg_lpr; off < tg_ts; off <<= 1) {
         const float m2 = __shfl_xor(m, off);
         const int a2 = __shfl_xor(am, off);
         if (m2 > m || (m2 == m && a2 < am)) {
@@ -317,14 +321,16 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
           am = a2;
         }
       }
-      const float dn = scaling ? sqrtf((float)n) : 1.f;
+      // one reciprocal per point instead of a division per view, hardware exp2: the kernel is VALU-bound (its
+      // row gathers hit the cache hierarchy), and the IEEE divisions + expf were ~40 % of its instructions
+      const float inv_dn = scaling ? 1.f / sqrtf((float)n) : 1.f;
       float e[U], s = 0.f;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        e[u] = ok[u] ? expf((cg[u] - m) / dn) : 0.f;
+        e[u] = ok[u] ? __expf((cg[u] - m) * inv_dn) : 0.f;
         s += e[u];
       }
-      for (int off = tg.lpr; off < tg.ts; off <<= 1) s += __shfl_xor(s, off);
+      for (int off = tg_lpr; off < tg_ts; off <<= 1) s += __shfl_xor(s, off);
       s += eps;
       float gt = 1.f;
       if (gw) gt = tanhf(fmaxf(gw[g_lane] * m + gb[g_lane], 0.f));
@@ -335,16 +341,17 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       float acc[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+      const float inv_s = 1.f / s;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float a = e[u] / s;
+        const float a = e[u] * inv_s;
         if (ok[u] && g_first) att[rr[u] * G + g_lane] = a;
         float f[VEC];
         Vec16<T>::unpack(x[u], f);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
       }
-      for (int off = tg.lpr; off < tg.ts; off <<= 1) {
+      for (int off = tg_lpr; off < tg_ts; off <<= 1) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
       }
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
         am = v;
       }
     }
-    for (int off = G; off < tg.ts; off <<= 1) {
+    for (int off = G; off < tg_ts; off <<= 1) {
       const float m2 = __shfl_xor(m, off);
       const int a2 = __shfl_xor(am, off);
       if (m2 > m || (m2 == m && a2 < am)) {
@@ -374,10 +381,10 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       }
     }
     if (n == 0) m = 0.f;
-    const float dn = scaling ? sqrtf((float)n) : 1.f;
+    const float inv_dn = (scaling && n > 0) ? 1.f / sqrtf((float)n) : 1.f;
     float s = 0.f;
-    for (int v = vslot; v < n; v += VS) s += expf((compat[(beg + v) * G + sg] - m) / dn);
-    for (int off = G; off < tg.ts; off <<= 1) s += __shfl_xor(s, off);
+    for (int v = vslot; v < n; v += VS) s += __expf((compat[(beg + v) * G + sg] - m) * inv_dn);
+    for (int off = G; off < tg_ts; off <<= 1) s += __shfl_xor(s, off);
     s += eps;
     float gt = 1.f;
     if (gw) gt = tanhf(fmaxf(gw[sg] * m + gb[sg], 0.f));
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     }
     // broadcast the statistics of this lane's own channel group
     const float m_l = __shfl(m, team_base + g_lane);
-    const float s_l = __shfl(s, team_base + g_lane);
+    const float inv_s_l = 1.f / __shfl(s, team_base + g_lane);
     const float gt_l = __shfl(gt, team_base + g_lane);
 
     // ---- attention-weighted sum over views
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
     const int64_t col = (int64_t)lane_r * VEC;
     // chunks of 4 rows per lane: row indices + scores, then the value rows, are issued before the first use
-    for (int v0 = 0; v0 < n; v0 += 4 * tg.rows) {
+    for (int v0 = 0; v0 < n; v0 += 4 * tg_rows) {
       constexpr int U = 4;
       bool ok[U];
       int64_t rr[U], ri[U];
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       raw_t x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int v = v0 + row_slot + u * tg.rows;
+        const int v = v0 + row_slot + u * tg_rows;
         ok[u] = v < n;
         rr[u] = beg + (ok[u] ? v : 0);
       }
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const raw_t*>(val + ri[u] * C + col);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float a = ok[u] ? expf((cg[u] - m_l) / dn) / s_l : 0.f;
+        const float a = ok[u] ? __expf((cg[u] - m_l) * inv_dn) * inv_s_l : 0.f;
         if (ok[u] && g_first) att[rr[u] * G + g_lane] = a;
         float f[VEC];
         Vec16<T>::unpack(x[u], f);
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
         for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
       }
     }
-    for (int off = tg.lpr; off < tg.ts; off <<= 1) {
+    for (int off = tg_lpr; off < tg_ts; off <<= 1) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
     }
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 // gradient is scatter-added into the fp32 value map: that phase switches to a channel-per-lane
 // layout so that one atomic instruction covers whole contiguous rows (2 cache lines per 64 atomics
 // instead of 16 with the 16-byte-per-lane layout: measured 8.7x on the first version).
-template <typename T>
+template <typename T, int LPR, int ROWS>   // LPR > 0: compile-time team geometry (LPR lanes per row x ROWS rows)
 __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     const T* __restrict__ gout, const T* __restrict__ val, const int32_t* __restrict__ row_idx,
     float* __restrict__ grows, const float* __restrict__ compat,
@@ -451,6 +458,10 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     float* __restrict__ gcompat, float* __restrict__ gwb, float* __restrict__ rec, int rs, int64_t N,
     int C, int G, int scaling, TeamGeom tg) {
   constexpr int VEC = Vec16<T>::N;
+  // team geometry: constants in the specialised instances (divisions become shifts, the reduction loops unroll,
+  // the shuffle offsets are immediates), taken from `tg` in the generic one
+  const int tg_lpr = LPR > 0 ? LPR : tg.lpr, tg_rows = LPR > 0 ? ROWS : tg.rows;
+  const int tg_ts = tg_lpr * tg_rows, tg_lpg = tg_lpr / G;
   typedef typename Vec16<T>::raw raw_t;
   __shared__ float s_wb[64];  // [2*G], G <= 32
   // long segments of the fused-gather form: d[v, g] of a point is parked in LDS between the two passes
@@ -461,13 +472,13 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int li = lane & (tg.ts - 1);
-  const int lane_r = li & (tg.lpr - 1);
-  const int row_slot = li / tg.lpr;
-  const int g_lane = lane_r / tg.lpg;
-  const bool g_first = (lane_r % tg.lpg) == 0;
-  const int teams_per_wave = 64 / tg.ts;
-  const int team_in_wave = lane / tg.ts;
+  const int li = lane & (tg_ts - 1);
+  const int lane_r = li & (tg_lpr - 1);
+  const int row_slot = li / tg_lpr;
+  const int g_lane = lane_r / tg_lpg;
+  const bool g_first = (lane_r % tg_lpg) == 0;
+  const int teams_per_wave = 64 / tg_ts;
+  const int team_in_wave = lane / tg_ts;
 
   // wave-uniform outer loop: the teams of one wavefront always iterate together
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -501,10 +512,10 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     if (n > 0) {
       b.go = *reinterpret_cast<const raw_t*>(gout + p * C + (int64_t)lane_r * VEC);
       if (gate) b.gt = gate[p * G + g_lane];
-      if (n <= U * tg.rows) {
+      if (n <= U * tg_rows) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int v = row_slot + u * tg.rows;
+          const int v = row_slot + u * tg_rows;
           const int64_t r = beg + (v < n ? v : 0);
           if (row_idx) b.ri[u] = row_idx[r];
           b.av[u] = att[r * G + g_lane];
@@ -533,18 +544,18 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     float sum_ad = 0.f;
     // short segments (the common case): row indices, value rows and attentions of the whole point are
     // loaded before the first use and d stays in registers (no round trip through grad_compat)
-    const bool small = n <= U * tg.rows;
+    const bool small = n <= U * tg_rows;
     // LDS form of the long path: fused gather only (no per-row grad_val writes), segment fits the team's share
-    const int team_cap = DBUF / (64 / tg.ts);
+    const int team_cap = DBUF / (64 / tg_ts);
     const bool lds_d = !small && row_idx && n * G <= team_cap;
-    float* sd = s_dbuf[threadIdx.x >> 6] + (lane / tg.ts) * team_cap;
+    float* sd = s_dbuf[threadIdx.x >> 6] + (lane / tg_ts) * team_cap;
     float dreg[U], areg[U];
     bool okr[U];
     if (small) {
       raw_t x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int v = row_slot + u * tg.rows;
+        const int v = row_slot + u * tg_rows;
         okr[u] = v < n;
         areg[u] = sb.av[u];
         const int64_t rr = beg + (okr[u] ? v : 0);
@@ -559,20 +570,20 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
         float d = 0.f;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
-        for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
+        for (int off = 1; off < tg_lpg; off <<= 1) d += __shfl_xor(d, off);
         dreg[u] = d;
         if (g_first && okr[u]) sum_ad += areg[u] * d;
       }
     } else {
       // long segments: same load-first chunks, d goes through grad_compat (re-read by the same lane in 2a)
-      for (int v0 = 0; v0 < n; v0 += U * tg.rows) {
+      for (int v0 = 0; v0 < n; v0 += U * tg_rows) {
         bool ok[U];
         int64_t rr[U], ri[U];
         float av[U];
         raw_t x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int v = v0 + row_slot + u * tg.rows;
+          const int v = v0 + row_slot + u * tg_rows;
           ok[u] = v < n;
           rr[u] = beg + (ok[u] ? v : 0);
         }
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
           float d = 0.f;
 #pragma unroll
           for (int k = 0; k < VEC; ++k) d = fmaf(go[k], f[k], d);
-          for (int off = 1; off < tg.lpg; off <<= 1) d += __shfl_xor(d, off);
+          for (int off = 1; off < tg_lpg; off <<= 1) d += __shfl_xor(d, off);
           if (g_first && ok[u]) {
             if (lds_d) sd[(rr[u] - beg) * G + g_lane] = d;
             else gcompat[rr[u] * G + g_lane] = d;
@@ -600,11 +611,11 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
       }
     }
     // lanes of one column position in the R row slots hold partials of the same group
-    for (int off = tg.lpr; off < tg.ts; off <<= 1) sum_ad += __shfl_xor(sum_ad, off);
+    for (int off = tg_lpr; off < tg_ts; off <<= 1) sum_ad += __shfl_xor(sum_ad, off);
     // make the group total visible to every lane of the group (only g_first lanes accumulated)
-    sum_ad = __shfl(sum_ad, lane - (lane_r % tg.lpg));
+    sum_ad = __shfl(sum_ad, lane - (lane_r % tg_lpg));
 
-    const float dn = scaling ? sqrtf((float)(n > 0 ? n : 1)) : 1.f;
+    const float inv_dn = scaling ? 1.f / sqrtf((float)(n > 0 ? n : 1)) : 1.f;
     float g_mx = 0.f;
     const int64_t am = n > 0 ? amax[p * G + g_lane] : -1;
     if (gw && n > 0) {
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     for (int k = 0; k < VEC; ++k) go[k] *= gt;
     auto emit = [&](int64_t r, float a, float d) {
       if (g_first) {
-        float gc = a * (gt * d - tt) / dn;
+        float gc = a * (gt * d - tt) * inv_dn;
         if (r == am) gc += g_mx;
         gcompat[r * G + g_lane] = gc;
         if (rec) {
@@ -643,15 +654,15 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     if (small) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (okr[u]) emit(beg + row_slot + u * tg.rows, areg[u], dreg[u]);
+        if (okr[u]) emit(beg + row_slot + u * tg_rows, areg[u], dreg[u]);
     } else if (lds_d) {
       // lane i of the team takes (view, group) pair i of each batch of ts / G views: coalesced reads of the
       // attentions, coalesced writes of grad_compat, two iterations for 32 views instead of 32 serial ones.
       // The per-group scalars live in the lanes of that group: fetched from the group's first lane.
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      const int g2 = li & (G - 1), vs = li / G, per = tg.ts / G;
-      const int src = (lane - li) + g2 * tg.lpg;
+      const int g2 = li & (G - 1), vs = li / G, per = tg_ts / G;
+      const int src = (lane - li) + g2 * tg_lpg;
       const float gt2 = __shfl(gt, src), tt2 = __shfl(tt, src), gmx2 = __shfl(g_mx, src);
       const int am2 = __shfl((int)(am - beg), src);
       for (int v0 = 0; v0 < n; v0 += per) {
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
         if (v < n) {
           const int64_t r = beg + v;
           const float a = att[r * G + g2];
-          float gc = a * (gt2 * sd[v * G + g2] - tt2) / dn;
+          float gc = a * (gt2 * sd[v * G + g2] - tt2) * inv_dn;
           if (v == am2) gc += gmx2;
           gcompat[r * G + g2] = gc;
           if (rec) {
@@ -672,7 +683,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
       __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll 2
-      for (int v = row_slot; v < n; v += tg.rows) {
+      for (int v = row_slot; v < n; v += tg_rows) {
         const int64_t r = beg + v;
         emit(r, att[r * G + g_lane], g_first ? gcompat[r * G + g_lane] : 0.f);
       }
@@ -682,7 +693,7 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     if (row_idx && grows) {
       const int cpg = C / G;
       for (int t = 0; t < teams_per_wave; ++t) {
-        const int src = t * tg.ts;
+        const int src = t * tg_ts;
         const int nb = __shfl(n, src);
         if (nb == 0) continue;  // wave-uniform
         const int64_t pp = pw + t;
@@ -757,8 +768,13 @@ static int fwd_impl(const void* val, const int32_t* row_idx, const float* compat
   if (algo != 1 && team_ok) {
     const int tpb = 256 / tg.ts;
     const int grid = grid_cap((N + tpb - 1) / tpb);
-    hipLaunchKernelGGL((att_fwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)val, row_idx,
-                       compat, ptr, gw, gb, (T*)out, att, gate, amax, N, C, G, scaling, eps, tg);
+#define DVA_FWD_TEAM(L, R)                                                                          \
+  hipLaunchKernelGGL((att_fwd_team_kernel<T, L, R>), dim3(grid), dim3(256), 0, s, (const T*)val,    \
+                     row_idx, compat, ptr, gw, gb, (T*)out, att, gate, amax, N, C, G, scaling, eps, tg)
+    if (tg.lpr == 8 && tg.rows == 8) DVA_FWD_TEAM(8, 8);          // C = 64 bf16, ~32 views per point
+    else if (tg.lpr == 16 && tg.rows == 4) DVA_FWD_TEAM(16, 4);   // C = 64 fp32 / C = 128 bf16
+    else DVA_FWD_TEAM(0, 0);
+#undef DVA_FWD_TEAM
     return DVA_OK;
   }
   hipLaunchKernelGGL(att_scores_kernel, dim3(grid_cap((N * G + 255) / 256)), dim3(256), 0, s, compat,
@@ -781,9 +797,14 @@ static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, f
   if (algo != 1 && team_ok) {
     const int tpb = 256 / tg.ts;
     const int grid = grid_cap((N + tpb - 1) / tpb);
-    hipLaunchKernelGGL((att_bwd_team_kernel<T>), dim3(grid), dim3(256), 0, s, (const T*)gout,
-                       (const T*)val, row_idx, grows, compat, att, gw ? gate : nullptr, amax, ptr, gw,
-                       (T*)gval, gcompat, gwb, rec, rs, N, C, G, scaling, tg);
+#define DVA_BWD_TEAM(L, R)                                                                          \
+  hipLaunchKernelGGL((att_bwd_team_kernel<T, L, R>), dim3(grid), dim3(256), 0, s, (const T*)gout,   \
+                     (const T*)val, row_idx, grows, compat, att, gw ? gate : nullptr, amax, ptr, gw, \
+                     (T*)gval, gcompat, gwb, rec, rs, N, C, G, scaling, tg)
+    if (tg.lpr == 8 && tg.rows == 8) DVA_BWD_TEAM(8, 8);
+    else if (tg.lpr == 16 && tg.rows == 4) DVA_BWD_TEAM(16, 4);
+    else DVA_BWD_TEAM(0, 0);
+#undef DVA_BWD_TEAM
     return DVA_OK;
   }
   hipLaunchKernelGGL((att_bwd_scores_kernel<T>), dim3(grid_cap((N * G + 255) / 256)), dim3(256),
