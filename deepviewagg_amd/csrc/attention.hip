@@ -242,8 +242,19 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
   const int VS = tg_ts / G;
 
   const int teams_per_block = blockDim.x / tg_ts;
-  const int64_t team0 = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg_ts;
+  // WAVE: a team is a whole wavefront, so the point, its CSR range and every base address derived from them
+  // are wave-uniform: they are kept in SGPRs (readfirstlane) and the per-lane part of an address is a 32-bit
+  // offset (global_load ... v_off, s[base]) instead of 64-bit vector arithmetic per access.
+  constexpr bool WAVE = LPR > 0 && LPR * ROWS == 64;
+  const int64_t team0 = WAVE ? (int64_t)blockIdx.x * teams_per_block +
+                                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+                             : (int64_t)blockIdx.x * teams_per_block + threadIdx.x / tg_ts;
   const int64_t team_stride = (int64_t)gridDim.x * teams_per_block;
+  auto uniform64 = [](int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  };
 
   // Software pipeline over the points of a team, three stages deep, so that the three dependent loads of
   // a point (CSR pointers -> row indices + scores -> value rows) of three consecutive points are in flight
@@ -260,6 +271,10 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
     if (p < N) {
       beg = ptr[p];
       n = (int)(ptr[p + 1] - beg);
+      if (WAVE) {
+        beg = uniform64(beg);
+        n = __builtin_amdgcn_readfirstlane(n);
+      }
     }
   };
   auto load_b = [&](int64_t beg, int n, StageB& b) {
@@ -269,12 +284,24 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
       b.cg[u] = 0.f;
     }
     if (is_small(n)) {
+      if (WAVE) {
+        const int32_t* ri_base = row_idx ? row_idx + beg : nullptr;   // uniform bases, 32-bit lane offsets
+        const float* c_base = compat + beg * G;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int v = row_slot + u * tg_rows;
-        const int64_t r = beg + (v < n ? v : 0);
-        if (row_idx) b.ri[u] = row_idx[r];
-        b.cg[u] = compat[r * G + g_lane];
+        for (int u = 0; u < U; ++u) {
+          const uint32_t v = (uint32_t)(row_slot + u * tg_rows);
+          const uint32_t vv = v < (uint32_t)n ? v : 0u;
+          if (row_idx) b.ri[u] = ri_base[vv];
+          b.cg[u] = c_base[vv * (uint32_t)G + (uint32_t)g_lane];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = row_slot + u * tg_rows;
+          const int64_t r = beg + (v < n ? v : 0);
+          if (row_idx) b.ri[u] = row_idx[r];
+          b.cg[u] = compat[r * G + g_lane];
+        }
       }
     }
   };
@@ -345,7 +372,12 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float a = e[u] * inv_s;
-        if (ok[u] && g_first) att[rr[u] * G + g_lane] = a;
+        if (ok[u] && g_first) {
+          if (WAVE)
+            (att + beg * G)[(uint32_t)(row_slot + u * tg_rows) * (uint32_t)G + (uint32_t)g_lane] = a;
+          else
+            att[rr[u] * G + g_lane] = a;
+        }
         float f[VEC];
         Vec16<T>::unpack(x[u], f);
 #pragma unroll
