@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 // layout so that one atomic instruction covers whole contiguous rows (2 cache lines per 64 atomics
 // instead of 16 with the 16-byte-per-lane layout: measured 8.7x on the first version).
 template <typename T, int LPR, int ROWS>   // LPR > 0: compile-time team geometry (LPR lanes per row x ROWS rows)
-__global__ __launch_bounds__(256) void att_bwd_team_kernel(
+__global__ __launch_bounds__(256, 3) void att_bwd_team_kernel(
     const T* __restrict__ gout, const T* __restrict__ val, const int32_t* __restrict__ row_idx,
     float* __restrict__ grows, const float* __restrict__ compat,
     const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
@@ -512,8 +512,18 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
   const int teams_per_wave = 64 / tg_ts;
   const int team_in_wave = lane / tg_ts;
 
+  // WAVE: a team is a whole wavefront -- point, CSR range and the base addresses derived from them live in
+  // SGPRs, the per-lane part of an address is a 32-bit offset (see the forward kernel)
+  constexpr bool WAVE = LPR > 0 && LPR * ROWS == 64;
+  auto uniform64 = [](int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  };
   // wave-uniform outer loop: the teams of one wavefront always iterate together
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = WAVE ? (int64_t)blockIdx.x * (blockDim.x >> 6) +
+                                  __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+                            : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   // Three-stage software pipeline over the points of a team (same scheme as the forward kernel): CSR
   // pointers of point i+2, row indices / attentions / grad_out row / gate of point i+1 and the value rows of
@@ -531,6 +541,10 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
     if (p < N) {
       beg = ptr[p];
       n = (int)(ptr[p + 1] - beg);
+      if (WAVE) {
+        beg = uniform64(beg);
+        n = __builtin_amdgcn_readfirstlane(n);
+      }
     }
   };
   auto load_b = [&](int64_t p, int64_t beg, int n, StageB& b) {
@@ -545,12 +559,24 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
       b.go = *reinterpret_cast<const raw_t*>(gout + p * C + (int64_t)lane_r * VEC);
       if (gate) b.gt = gate[p * G + g_lane];
       if (n <= U * tg_rows) {
+        if (WAVE) {
+          const int32_t* ri_base = row_idx ? row_idx + beg : nullptr;
+          const float* a_base = att + beg * G;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int v = row_slot + u * tg_rows;
-          const int64_t r = beg + (v < n ? v : 0);
-          if (row_idx) b.ri[u] = row_idx[r];
-          b.av[u] = att[r * G + g_lane];
+          for (int u = 0; u < U; ++u) {
+            const uint32_t v = (uint32_t)(row_slot + u * tg_rows);
+            const uint32_t vv = v < (uint32_t)n ? v : 0u;
+            if (row_idx) b.ri[u] = ri_base[vv];
+            b.av[u] = a_base[vv * (uint32_t)G + (uint32_t)g_lane];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int v = row_slot + u * tg_rows;
+            const int64_t r = beg + (v < n ? v : 0);
+            if (row_idx) b.ri[u] = row_idx[r];
+            b.av[u] = att[r * G + g_lane];
+          }
         }
       }
     }
@@ -668,12 +694,22 @@ __global__ __launch_bounds__(256) void att_bwd_team_kernel(
       if (g_first) {
         float gc = a * (gt * d - tt) * inv_dn;
         if (r == am) gc += g_mx;
-        gcompat[r * G + g_lane] = gc;
-        if (rec) {
-          // view record for dva_view_gather_rows_grad: point id | gate * attention per group, one
-          // 32-byte sector per view instead of three scattered reads (view_point, att, gate)
-          rec[r * rs + 1 + g_lane] = a * gt;
-          if (g_lane == 0) rec[r * rs] = __int_as_float((int)p);
+        if (WAVE) {
+          const uint32_t vl = (uint32_t)(r - beg);   // view inside the point: 32-bit lane offsets, SGPR bases
+          (gcompat + beg * G)[vl * (uint32_t)G + (uint32_t)g_lane] = gc;
+          if (rec) {
+            float* rb = rec + beg * rs;
+            rb[vl * (uint32_t)rs + 1u + (uint32_t)g_lane] = a * gt;
+            if (g_lane == 0) rb[vl * (uint32_t)rs] = __int_as_float((int)p);
+          }
+        } else {
+          gcompat[r * G + g_lane] = gc;
+          if (rec) {
+            // view record for dva_view_gather_rows_grad: point id | gate * attention per group, one
+            // 32-byte sector per view instead of three scattered reads (view_point, att, gate)
+            rec[r * rs + 1 + g_lane] = a * gt;
+            if (g_lane == 0) rec[r * rs] = __int_as_float((int)p);
+          }
         }
       }
       if (!row_idx) {
