@@ -841,6 +841,8 @@ static int fwd_impl(const void* val, const int32_t* row_idx, const float* compat
                      row_idx, compat, ptr, gw, gb, (T*)out, att, gate, amax, N, C, G, scaling, eps, tg)
     if (tg.lpr == 8 && tg.rows == 8) DVA_FWD_TEAM(8, 8);          // C = 64 bf16, ~32 views per point
     else if (tg.lpr == 16 && tg.rows == 4) DVA_FWD_TEAM(16, 4);   // C = 64 fp32 / C = 128 bf16
+    else if (tg.lpr == 8 && tg.rows == 4) DVA_FWD_TEAM(8, 4);     // the same with ~4-8 views per point (ragged)
+    else if (tg.lpr == 16 && tg.rows == 2) DVA_FWD_TEAM(16, 2);
     else DVA_FWD_TEAM(0, 0);
 #undef DVA_FWD_TEAM
     return DVA_OK;
@@ -871,6 +873,8 @@ static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, f
                      (T*)gval, gcompat, gwb, rec, rs, N, C, G, scaling, tg)
     if (tg.lpr == 8 && tg.rows == 8) DVA_BWD_TEAM(8, 8);
     else if (tg.lpr == 16 && tg.rows == 4) DVA_BWD_TEAM(16, 4);
+    else if (tg.lpr == 8 && tg.rows == 4) DVA_BWD_TEAM(8, 4);
+    else if (tg.lpr == 16 && tg.rows == 2) DVA_BWD_TEAM(16, 2);
     else DVA_BWD_TEAM(0, 0);
 #undef DVA_BWD_TEAM
     return DVA_OK;
