@@ -214,6 +214,66 @@ struct TeamGeom {
   int lpg;      // lanes per group inside a row = lpr / G
 };
 
+// ---- reductions across the row slots of a team without the LDS crossbar (compile-time geometry only):
+// lanes l and l ^ OFF exchange through DPP (OFF = 8: row_ror:8 inside a 16-lane row) or through the gfx950 row
+// swaps v_permlane16_swap / v_permlane32_swap (both operands = the value: afterwards one register holds the value
+// of the lower row of each pair in every lane, the other the upper one, so op(a, b) is the pair's reduction).
+template <int OFF>
+__device__ __forceinline__ void xor_pair(float v, float& a, float& b) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  const uint32_t x = __float_as_uint(v);
+  if constexpr (OFF == 32) {
+    const u2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+  } else if constexpr (OFF == 16) {
+    const u2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+  } else if constexpr (OFF == 8) {
+    a = v;
+    b = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));  // row_ror:8
+  } else {
+    a = v;
+    b = __shfl_xor(v, OFF);
+  }
+}
+template <int OFF>
+__device__ __forceinline__ void xor_pair(int v, int& a, int& b) {
+  float fa, fb;
+  xor_pair<OFF>(__int_as_float(v), fa, fb);
+  a = __float_as_int(fa);
+  b = __float_as_int(fb);
+}
+// sum over the ROWS row slots (lane stride LPR) of a team
+template <int LPR, int ROWS>
+__device__ __forceinline__ float team_sum(float v) {
+  float a, b;
+  if constexpr (ROWS >= 2) { xor_pair<LPR>(v, a, b); v = a + b; }
+  if constexpr (ROWS >= 4) { xor_pair<2 * LPR>(v, a, b); v = a + b; }
+  if constexpr (ROWS >= 8) { xor_pair<4 * LPR>(v, a, b); v = a + b; }
+  if constexpr (ROWS >= 16) { xor_pair<8 * LPR>(v, a, b); v = a + b; }
+  return v;
+}
+// lexicographic (max value, then smallest index) over the row slots
+template <int OFF>
+__device__ __forceinline__ void argmax_step(float& m, int& am) {
+  float ma, mb;
+  int ia, ib;
+  xor_pair<OFF>(m, ma, mb);
+  xor_pair<OFF>(am, ia, ib);
+  const bool take_b = mb > ma || (mb == ma && ib < ia);
+  m = take_b ? mb : ma;
+  am = take_b ? ib : ia;
+}
+template <int LPR, int ROWS>
+__device__ __forceinline__ void team_argmax(float& m, int& am) {
+  if constexpr (ROWS >= 2) argmax_step<LPR>(m, am);
+  if constexpr (ROWS >= 4) argmax_step<2 * LPR>(m, am);
+  if constexpr (ROWS >= 8) argmax_step<4 * LPR>(m, am);
+  if constexpr (ROWS >= 16) argmax_step<8 * LPR>(m, am);
+}
+
 // Forward.  Requirements (checked by the host): C % VEC == 0, C/VEC == lpr exactly (power of two),
 // C % G == 0, (C/G) % VEC == 0, G <= ts, G power of two.
 template <typename T, int LPR, int ROWS>   // LPR > 0: compile-time team geometry (LPR lanes per row x ROWS rows)
@@ -340,12 +400,16 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
           am = row_slot + u * tg_rows;
         }
       }
-      for (int off = tg_lpr; off < tg_ts; off <<= 1) {
-        const float m2 = __shfl_xor(m, off);
-        const int a2 = __shfl_xor(am, off);
-        if (m2 > m || (m2 == m && a2 < am)) {
-          m = m2;
-          am = a2;
+      if constexpr (LPR > 0) {
+        team_argmax<LPR, ROWS>(m, am);
+      } else {
+        for (int off = tg_lpr; off < tg_ts; off <<= 1) {
+          const float m2 = __shfl_xor(m, off);
+          const int a2 = __shfl_xor(am, off);
+          if (m2 > m || (m2 == m && a2 < am)) {
+            m = m2;
+            am = a2;
+          }
         }
       }
       // one reciprocal per point instead of a division per view, hardware exp2: the kernel is VALU-bound (its
@@ -357,7 +421,9 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
         e[u] = ok[u] ? __expf((cg[u] - m) * inv_dn) : 0.f;
         s += e[u];
       }
-      for (int off = tg_lpr; off < tg_ts; off <<= 1) s += __shfl_xor(s, off);
+      if constexpr (LPR > 0) s = team_sum<LPR, ROWS>(s);
+      else
+        for (int off = tg_lpr; off < tg_ts; off <<= 1) s += __shfl_xor(s, off);
       s += eps;
       float gt = 1.f;
       if (gw) gt = tanhf(fmaxf(gw[g_lane] * m + gb[g_lane], 0.f));
@@ -383,9 +449,14 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = fmaf(a, f[k], acc[k]);
       }
-      for (int off = tg_lpr; off < tg_ts; off <<= 1) {
+      if constexpr (LPR > 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+        for (int k = 0; k < VEC; ++k) acc[k] = team_sum<LPR, ROWS>(acc[k]);
+      } else {
+        for (int off = tg_lpr; off < tg_ts; off <<= 1) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+        }
       }
       if (row_slot == 0) {
 #pragma unroll
@@ -669,7 +740,9 @@ __global__ __launch_bounds__(256, 3) void att_bwd_team_kernel(
       }
     }
     // lanes of one column position in the R row slots hold partials of the same group
-    for (int off = tg_lpr; off < tg_ts; off <<= 1) sum_ad += __shfl_xor(sum_ad, off);
+    if constexpr (LPR > 0) sum_ad = team_sum<LPR, ROWS>(sum_ad);
+    else
+      for (int off = tg_lpr; off < tg_ts; off <<= 1) sum_ad += __shfl_xor(sum_ad, off);
     // make the group total visible to every lane of the group (only g_first lanes accumulated)
     sum_ad = __shfl(sum_ad, lane - (lane_r % tg_lpg));
 
