@@ -54,3 +54,26 @@ def test_modality_dropout_drops_the_whole_tensor():
     assert torch.allclose(drop.eval()(x), x / 0.7)
     with pytest.raises(AssertionError):
         ModalityDropout(p=1.5)
+
+
+def test_multimodal_input_builds_the_block_dictionary():
+    """applications/sparseconv3d.py:145-165 (`_set_input`): voxel tensor with (x, y, z, batch) int32 coordinates,
+    x_seen None, the batch's modalities moved to the device; a bare voxel tensor for a 3D-only model."""
+    from types import SimpleNamespace
+    import torch
+    from deepviewagg_amd.modules.multimodal.modules import multimodal_input, _is_voxel_tensor
+
+    class Batch(SimpleNamespace):
+        def to(self, device):
+            self.moved_to = device
+            return self
+    data = Batch(x=torch.randn(5, 3), coords=torch.arange(15).view(5, 3), batch=torch.tensor([0, 0, 1, 1, 1]),
+                 modalities={"image": object()})
+    mm = multimodal_input(data, "cpu")
+    assert set(mm) == {"x_3d", "x_seen", "modalities"} and mm["x_seen"] is None
+    assert mm["modalities"] is data.modalities and data.moved_to == "cpu"
+    x = mm["x_3d"]
+    assert _is_voxel_tensor(x) and x.s == 1 and x.C.dtype == torch.int32 and x.C.shape == (5, 4)
+    assert torch.equal(x.C[:, 3], data.batch.int()) and torch.equal(x.C[:, :3], data.coords.int())
+    assert torch.equal(x.F, data.x) and x.coord_maps[1] is x.C
+    assert _is_voxel_tensor(multimodal_input(data, "cpu", is_multimodal=False))
