@@ -184,7 +184,8 @@ class Conv3d(nn.Module):
             f = x.F @ self.kernel.to(x.F.dtype)
             return x.like(f if self.bias is None else f + self.bias.to(f.dtype))
         nbr, nbr_t, out_coords, out_stride = self._maps(x)
-        f = ops.sparse_conv(x.F, self.kernel, self.bias, nbr, nbr_t)
+        W = self.kernel if self.kernel.dim() == 3 else self.kernel.unsqueeze(0)   # strided 1x1x1: K = 1
+        f = ops.sparse_conv(x.F, W, self.bias, nbr, nbr_t)
         return SparseVoxelTensor(f, out_coords, out_stride, x.coord_maps, x.kernel_maps)
 
 
