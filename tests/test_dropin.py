@@ -30,5 +30,15 @@ def test_install_aliases_reference_paths():
     assert pickle.loads(pickle.dumps(model)).voxel == 0.02          # stored on the image data, pickled
     fusion = importlib.import_module("torch_points3d.modules.multimodal.fusion")
     assert fusion.BimodalFusion(mode="concatenation").mode == "concatenation"
+    # sparse-convolution stages and the backend shim (applications/sparseconv3d.py, SparseConv3d/nn/__init__.py)
+    sp3d_nn = importlib.import_module("torch_points3d.modules.SparseConv3d.nn")
+    sp3d_mod = importlib.import_module("torch_points3d.modules.SparseConv3d.modules")
+    sp3d_nn.set_backend("torchsparse")
+    assert sp3d_nn.get_backend() == "torchsparse" and sp3d_nn.backend_valid("minkowski")
+    for name in ("cat", "Conv3d", "Conv3dTranspose", "ReLU", "SparseTensor", "BatchNorm"):
+        assert hasattr(sp3d_nn, name), name
+    stage = getattr(sp3d_mod, "ResNetDown")(down_conv_nn=[[16, 32]], kernel_size=2, stride=2, N=1, index=0)
+    assert "blocks.0.block.0.kernel" in stage.state_dict() and "conv_in.1.bn.running_var" in stage.state_dict()
+    assert getattr(sp3d_mod, "ResNetUp")(up_conv_nn=[32, 16, 16], N=1).CONVOLUTION == "Conv3dTranspose"
     for k in [k for k in sys.modules if k.startswith("torch_points3d")]:
         del sys.modules[k]
