@@ -135,6 +135,8 @@ class NeighborhoodBasedMappingFeatures:
         xyz = data.pos.float().to(device)
         mappings = images.mappings
         pointers = mappings.pointers.to(device)
+        assert xyz.shape[0] >= self.k_list[-1], \
+            f"NeighborhoodBasedMappingFeatures needs at least k={self.k_list[-1]} points, got {xyz.shape[0]}"
         neighbors, _ = ops.knn(xyz, self.k_list[-1])
         new = []
         if self.compute_density:

@@ -727,7 +727,12 @@ class SameSettingImageData:
             coords = (self.mappings.pixels / (resolution - 1))[:, [1, 0]]
             packed = self.mappings.packed_gather_index(ratio=1.0)
             return ops.gather_bilinear(self.x, packed, coords)
-        packed = self.mappings.packed_gather_index(ratio=float(self.downscale))
+        if self.downscale < 1:
+            # feature map larger than the mapping resolution: the reference goes through
+            # rescale_images -> upscale_images (pix * ratio + ratio / 2, image.py:1982-2027)
+            packed = self.mappings.upscale_images(1 / self.downscale).packed_gather_index(ratio=1.0)
+        else:
+            packed = self.mappings.packed_gather_index(ratio=float(self.downscale))
         if lazy:
             return ops.lazy_gather_nearest(self.x, packed, exact=self.mappings.is_exact)
         return ops.gather_nearest(self.x, packed)

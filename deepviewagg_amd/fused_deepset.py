@@ -63,6 +63,8 @@ def applicable(e_map, linear, x_map):
             if block[0].bias is not None or not bn.affine or not bn.track_running_stats \
                     or bn.momentum is None or getattr(block[2], 'negative_slope', None) != 0.2:
                 return False
+            if bn.training != e_map.training:
+                return False  # individually frozen BatchNorm layers: the generic path honours bn.training
     return True
 
 

@@ -262,7 +262,8 @@ class UnimodalBranch(nn.Module):
             x_map = mod_data.mapping_features
             csr_idx = mod_data.view_csr_indexing
         if self.keep_last_view:
-            mod_data.last_view_x_mod = x_mod
+            # reference consumers (applications/multimodal/no3d.py:128, view losses) expect the [V, C] tensor
+            mod_data.last_view_x_mod = x_mod.materialize() if isinstance(x_mod, ops.GatheredFeatures) else x_mod
             mod_data.last_view_x_map = x_map
             mod_data.last_view_csr_idx = csr_idx
         if 'v' in self.checkpointing and isinstance(x_mod, torch.Tensor):

@@ -170,9 +170,11 @@ class BimodalCSRPool(nn.Module, _SaveLast):
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map] (unused), csr_idx [N+1]."""
         if isinstance(x_mod, ops.GatheredFeatures):
-            if x_mod.exact and csr_idx.shape[0] - 1 == x_mod.shape[0]:
-                # atomic pooling of an exact mapping (one pixel per view): every group holds exactly
-                # one row, so max / min / mean / sum are all the identity -> stay lazy
+            if x_map is None and x_mod.exact and csr_idx.shape[0] - 1 == x_mod.shape[0]:
+                # ATOMIC pooling (UnimodalBranch passes x_map=None there) of an exact mapping (one pixel
+                # per view, atomic CSR = arange): every group holds exactly one row, so max / min / mean
+                # / sum are all the identity -> stay lazy.  At the view level (x_map given) N == V does
+                # not imply one view per point (csr = [0, 2, 2, 3]): always reduce there.
                 self._save(x_map, x_mod, csr_idx)
                 return x_mod
             x_mod = x_mod.materialize()
