@@ -115,6 +115,15 @@ SIGNATURES = {
     "dva_bn_finalize": (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _i32, _vp,
                                        _vp]),
     "dva_scale_f64": (ctypes.c_int, [_vp, ctypes.c_double, _vp, _i32, _vp]),
+    "dva_chain_prep": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "dva_chain_tile_count": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "dva_chain_tile_build": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "dva_chain_moments": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "dva_chain_stats2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dva_chain_pooled": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "dva_chain_stats": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "dva_chain_attn_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_voxel_parent_workspace_bytes": (ctypes.c_int64, [_i64]),
     "dva_voxel_parent_index": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "dva_voxel_kernel_map": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp]),

@@ -1,0 +1,349 @@
+// Shared device helpers of the recompute chain (chain_fwd.hip / chain_bwd.hip): DeepSetFeat re-evaluated from the
+// raw mapping features inside every pass instead of being streamed through HBM between passes.
+//
+// Geometry.  One wavefront owns one TILE = up to 32 consecutive views made of whole points (tile table built by
+// dva_chain_tile_build; points with more than 32 views are cut into consecutive fragment tiles that one
+// wavefront processes in order, carrying its per-point state in registers).  Lane l = (j, h) = (l & 31, l >> 5):
+// j = view of the tile, h = half.  A 32x32 layer is two v_mfma_f32_32x32x16_bf16 whose B operand is the packed
+// activation of the view (lane (j, h) supplies 8 input channels per k-block) and whose result lands as
+//   z[r] = Z[channel chan(r, h)][view j],  chan(r, h) = (r & 3) + 8 (r >> 2) + 4 h,   r < 16,
+// which is exactly the k-slot order the weight operands of the NEXT layer are prepared in (dva_chain_prep), so
+// BatchNorm + LeakyReLU + bf16 packing are register-to-register and layers chain without any data movement.
+// bf16 operands (activations and weights rounded like the reference under torch.autocast(bfloat16)), fp32
+// accumulation, BatchNorm / softmax / statistics in fp32.
+#pragma once
+#include "dva_common.h"
+
+namespace dva {
+namespace chain {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define CH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int D = 32;
+constexpr float SLOPE = 0.2f;
+constexpr uint32_t OOB = 0x7ffffff0u;  // byte offset beyond every buffer: loads return 0, stores are dropped
+
+__host__ __device__ __forceinline__ int chan(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// weight operand table (dva_chain_prep): N_OPS x 64 lanes x 16 bytes
+enum {
+  OP_W1 = 0,    // x_map (8) -> 32: slots 0..3 = W1[c][4h + s], 4..7 = the same (x enters as hi | lo)
+  OP_W2 = 1,    // +m: W2[c][chan(8m + s, h)]
+  OP_W5 = 3,    // concatenation layer, h1 half: Wc[c][chan(8m + s, h)]
+  OP_W6 = 5,
+  OP_WS = 7,    // score rows (rows >= G are zero)
+  OP_W6T = 9,   // transposed operands of the input-gradient products: W[chan(8m + s, h)][c]
+  OP_W5T = 11,
+  OP_W2T = 13,
+  OP_WST = 15,  // Ws^T for da6 = Ws^T dc: h = 0: slots 0..3 = Ws[s][c], 4..7 = the same (dc enters as hi | lo)
+  N_OPS = 16
+};
+
+// per-layer constant table in LDS, accumulator-permuted (index 16 h + r <-> channel chan(r, h)):
+//   G = gamma * invstd | B = beta - mean * G | I = invstd | M = -mean * invstd | S1 = S1/M | S2 = S2/M
+enum { T_G = 0, T_B = 1, T_I = 2, T_M = 3, T_S1 = 4, T_S2 = 5, T_ROWS = 6 };
+constexpr int TAB_FLOATS = T_ROWS * D;
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint64_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = rfl((uint32_t)a), hi = rfl((uint32_t)(a >> 32));
+  const uint32_t n = rfl((uint32_t)(bytes > 0xfffffff0ull ? 0xfffffff0ull : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld128(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ u32x2 ld64(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ uint32_t ld32(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void st128(__amdgpu_buffer_rsrc_t r, uint32_t off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void st32(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ float4 as_f4(u32x4 v) { return __builtin_bit_cast(float4, v); }
+__device__ __forceinline__ u32x4 as_u4(float a, float b, float c, float d) {
+  const float4 f = make_float4(a, b, c, d);
+  return __builtin_bit_cast(u32x4, f);
+}
+
+// DS operations of one wavefront execute in order: a wave-level hand-off through LDS needs the counter wait
+// and a scheduling barrier, no s_barrier.
+__device__ __forceinline__ void wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float leaky(float y) { return fmaxf(y, SLOPE * y); }
+__device__ __forceinline__ float dleaky(float y) { return y > 0.f ? 1.f : SLOPE; }
+
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+  // lanes [32, 64) of a <-> lanes [0, 32) of b
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r.x;
+  b = r.y;
+}
+__device__ __forceinline__ float shfl(float v, int src_lane) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)__float_as_uint(v)));
+}
+__device__ __forceinline__ int shfl(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+// ---- tiles -------------------------------------------------------------------------------------------------
+// int2 {v0, nv | frag << 8}: frag 0 = whole points, 1 / 2 / 3 = first / middle / last fragment of a long point
+struct TileInfo {
+  int v0, nv, frag;
+};
+__device__ __forceinline__ TileInfo get_tile(const int2* __restrict__ tiles, int t) {
+  const int2 d = tiles[t];
+  TileInfo ti;
+  ti.v0 = rfl(d.x);
+  const int m = rfl(d.y);
+  ti.nv = m & 0xff;
+  ti.frag = m >> 8;
+  return ti;
+}
+// Flat tile range of this wavefront; continuation fragments stay with the wavefront that owns the first one.
+__device__ __forceinline__ void wave_tile_range(const int2* __restrict__ tiles, int n_tiles, int& ta, int& tb) {
+  const int wave = rfl((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int n_waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  ta = (int)((int64_t)n_tiles * wave / n_waves);
+  tb = (int)((int64_t)n_tiles * (wave + 1) / n_waves);
+  while (ta < n_tiles && (rfl(tiles[ta].y) >> 8) >= 2) ++ta;
+  while (tb < n_tiles && (rfl(tiles[tb].y) >> 8) >= 2) ++tb;
+  if (ta > tb) ta = tb;
+}
+
+// Software-pipelined loop over the tiles [ta, tb): the loads of tile t + 1 are in flight while tile t is
+// computed; two register sets in ping-pong (a rotating copy would wait for the prefetch it has just issued).
+template <typename Pre, typename LoadF, typename BodyF>
+__device__ __forceinline__ void run_tiles(int ta, int tb, LoadF&& load, BodyF&& body) {
+  if (ta >= tb) return;
+  const int last = tb - 1;
+  Pre a = load(ta);
+  int t = ta + 1;
+  Pre b = load(t < tb ? t : last);
+  body(a);
+  while (t < tb) {
+    a = load(t + 1 < tb ? t + 1 : last);
+    body(b);
+    ++t;
+    if (t >= tb) break;
+    b = load(t + 1 < tb ? t + 1 : last);
+    body(a);
+    ++t;
+  }
+}
+
+// ---- layer pieces --------------------------------------------------------------------------------------------
+struct WOp {
+  bf16x8 m[2];
+};
+__device__ __forceinline__ bf16x8 load_op(const uint4* __restrict__ ops, int op, int lane) {
+  return __builtin_bit_cast(bf16x8, ops[op * 64 + lane]);
+}
+__device__ __forceinline__ WOp load_wop(const uint4* __restrict__ ops, int op, int lane) {
+  WOp w;
+  w.m[0] = load_op(ops, op, lane);
+  w.m[1] = load_op(ops, op + 1, lane);
+  return w;
+}
+__device__ __forceinline__ f32x16 mm32(const WOp& w, const bf16x8 (&a)[2], f32x16 c) {
+  c = CH_MFMA(w.m[0], a[0], c);
+  c = CH_MFMA(w.m[1], a[1], c);
+  return c;
+}
+__device__ __forceinline__ bf16x8 pack8(const float* x) {
+  const u32x4 v = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
+                   pack_bf16x2(x[6], x[7])};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 mask8(bf16x8 a, uint32_t keep) {  // keep = 0 or ~0
+  u32x4 v = __builtin_bit_cast(u32x4, a);
+  v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+  return __builtin_bit_cast(bf16x8, v);
+}
+// 4 features per lane as the 8 k-slots of its half: hi(x) | lo(x) = x - hi(x): the first layer sees x to 16 bits
+__device__ __forceinline__ bf16x8 pack_x(const float4& x) {
+  const uint32_t h0 = pack_bf16x2(x.x, x.y), h1 = pack_bf16x2(x.z, x.w);
+  const float r0 = x.x - __uint_as_float(h0 << 16), r1 = x.y - __uint_as_float(h0 & 0xffff0000u);
+  const float r2 = x.z - __uint_as_float(h1 << 16), r3 = x.w - __uint_as_float(h1 & 0xffff0000u);
+  const u32x4 v = {h0, h1, pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// the constants of this lane's 16 accumulator channels from an LDS table row
+__device__ __forceinline__ void tab16(const float* tab, int row, int h, float (&c)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(tab + row * D + 16 * h + 4 * q);
+    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+  }
+}
+// Fill the table of one layer from bn = [4][32] (mean | invstd | gamma | beta) and sm = [2][32] (S1/M | S2/M,
+// nullable).  Call from the whole block, then __syncthreads().
+__device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ bn, const float* __restrict__ sm) {
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const int c = chan(i & 15, i >> 4);
+    const float mean = bn[c], inv = bn[D + c], gam = bn[2 * D + c], bet = bn[3 * D + c];
+    const float g = gam * inv;
+    tab[T_G * D + i] = g;
+    tab[T_B * D + i] = bet - mean * g;
+    tab[T_I * D + i] = inv;
+    tab[T_M * D + i] = -mean * inv;
+    tab[T_S1 * D + i] = sm ? sm[c] : 0.f;
+    tab[T_S2 * D + i] = sm ? sm[D + c] : 0.f;
+  }
+}
+
+// y = z * G + B (BatchNorm), a = leaky(y), packed as the B operand of the next layer.  keep = 0 zeroes the
+// operand of a lane without a view.  The LDS reads stay inside the tile loop (asm barrier): hoisting 32
+// constants per layer into registers costs an occupancy step.
+__device__ __forceinline__ void act_pack(const f32x16& z, const float* tab, int h, uint32_t keep, bf16x8 (&a)[2],
+                                         float* y_out = nullptr) {
+  asm volatile("" ::: "memory");
+  float g[16], b[16], av[16];
+  tab16(tab, T_G, h, g);
+  tab16(tab, T_B, h, b);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float y = __builtin_fmaf(z[r], g[r], b[r]);
+    if (y_out) y_out[r] = y;
+    av[r] = leaky(y);
+  }
+  a[0] = mask8(pack8(&av[0]), keep);
+  a[1] = mask8(pack8(&av[8]), keep);
+}
+
+// ---- statistics ------------------------------------------------------------------------------------------------
+// per-lane fp32 partial sums of the 16 accumulator channels -> per block in LDS -> fp64 atomics
+template <int NV>
+__device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restrict__ out, float* s_red) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = st[n][r];
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+      if ((lane & 31) == 0) atomicAdd(&s_red[n * D + chan(r, h)], v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) atomicAdd(&out[i], (double)s_red[i]);
+}
+
+// transposed bf16 tile [channel][view], row stride 40 (80 bytes): the 8 consecutive views a lane feeds to the
+// weight-gradient MFMA are one ds_read_b128
+constexpr int TSB = 40;
+__device__ __forceinline__ void tileT_put(bf16_t* tile, int c0, int c1, int v, float x0, float x1) {
+  const uint32_t d = pack_bf16x2(x0, x1);
+  tile[c0 * TSB + v] = (bf16_t)(d & 0xffffu);
+  tile[c1 * TSB + v] = (bf16_t)(d >> 16);
+}
+__device__ __forceinline__ void tileT_put_acc(bf16_t* tile, int v, int h, const float* x) {
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) tileT_put(tile, chan(r, h), chan(r + 1, h), v, x[r], x[r + 1]);
+}
+__device__ __forceinline__ bf16x8 tileT_get(const bf16_t* tile, int c, int h, int m) {
+  return *reinterpret_cast<const bf16x8*>(tile + c * TSB + 16 * m + 8 * h);
+}
+
+static inline int chain_grid(int blocks_per_cu) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+  }
+  return cus * blocks_per_cu;
+}
+
+}  // namespace chain
+}  // namespace dva
+
+// ---- segments of a tile (lane j = view j; both half-waves hold the same bookkeeping) -------------------------
+namespace dva {
+namespace chain {
+
+struct SegInfo {
+  bool valid;        // lane has a view
+  bool same[5];      // lane j - (1 << o) belongs to the same point
+  int ss, se;        // first / last lane of this lane's point inside the tile
+  uint32_t smask;    // bit j: view j is the first view (in the tile) of its point
+  uint32_t emask;    // bit j: view j is the last view (in the tile) of its point
+  int nseg;          // points in the tile (uniform)
+};
+
+__device__ __forceinline__ SegInfo seg_setup(int vpj, int j, int lane, int nv) {
+  SegInfo s;
+  s.valid = j < nv;
+  const int lp = s.valid ? vpj : -1 - j;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    const int d = 1 << o;
+    const int other = shfl(lp, lane - d);
+    s.same[o] = (j >= d) && (other == lp);
+  }
+  const int nxt = shfl(lp, lane + 1);
+  const bool is_end = (j == 31) || (nxt != lp);
+  s.smask = (uint32_t)__ballot(!s.same[0] && s.valid);
+  s.emask = (uint32_t)__ballot(is_end && s.valid);
+  // invalid lanes: their own one-lane segments
+  const uint32_t below = s.smask & (0xffffffffu >> (31 - j));
+  s.ss = s.valid ? 31 - __clz((int)below) : j;
+  s.se = s.valid ? j + (__ffs((int)(s.emask >> j)) - 1) : j;
+  s.nseg = __popc(s.smask);
+  return s;
+}
+// inclusive segmented scans over the lanes of a half-wave; the last lane of a segment ends up with the
+// reduction of the whole segment
+__device__ __forceinline__ float seg_scan_max(float v, const SegInfo& s, int lane) {
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    const float t = shfl(v, lane - (1 << o));
+    v = s.same[o] ? fmaxf(v, t) : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float seg_scan_sum(float v, const SegInfo& s, int lane) {
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    const float t = shfl(v, lane - (1 << o));
+    v = s.same[o] ? v + t : v;
+  }
+  return v;
+}
+// value of the segment's last lane, in every lane of the segment
+__device__ __forceinline__ float seg_total(float scanned, const SegInfo& s, int h) {
+  return shfl(scanned, 32 * h + s.se);
+}
+
+// tanh for x >= 0 (the gate is tanh(relu(.))): odd polynomial below 0.1, (e^2x - 1) / (e^2x + 1) above
+__device__ __forceinline__ float tanh_pos(float x) {
+  x = fminf(x, 20.f);
+  const float x2 = x * x;
+  const float small = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
+  const float t = __expf(2.f * x);
+  const float big = (t - 1.f) * __builtin_amdgcn_rcpf(t + 1.f);
+  return x < 0.1f ? small : big;
+}
+
+}  // namespace chain
+}  // namespace dva

@@ -1,0 +1,761 @@
+// Recompute chain, forward side (see chain_common.h for the geometry):
+//   dva_chain_prep          weight operand table (bf16, MFMA k-slot order)
+//   dva_chain_tile_count / dva_chain_tile_build    tile table of a CSR pointer array
+//   dva_chain_moments       sum x, sum x x^T of the mapping features -> BatchNorm-1 statistics analytically
+//   dva_chain_stats2        statistics of layer 2 + per-point extremum of the layer-2 output (set pooling)
+//   dva_chain_pooled        pooled set features from the extrema
+//   dva_chain_stats         statistics of layer 5 / 6 (train mode only)
+//   dva_chain_attn_fwd      the fully fused view kernel: x_map -> DeepSetFeat -> scores -> softmax over the
+//                           point's views -> gather of the value rows -> weighted sum -> gate  (no [V, .] tensor
+//                           is read or written besides x_map / the view->point index / the row index)
+// Reference maths: modules/multimodal/pooling.py:658-669 (DeepSetFeat.forward), :263-315
+// (GroupBimodalCSRPool.forward), core/common_modules/base_modules.py:38-48 (MLP block).
+#include "chain_common.h"
+
+namespace dva {
+namespace chain {
+
+// ------------------------------------------------------------------------------------------------
+// weight operands
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void prep_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                  const float* __restrict__ W5, int ld5,
+                                                  const float* __restrict__ W6, const float* __restrict__ Ws, int G,
+                                                  uint4* __restrict__ ops) {
+  const int op = blockIdx.x, lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+  float w[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) w[s] = 0.f;
+  if (op == OP_W1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = w[s + 4] = W1[j * 8 + 4 * h + s];
+  } else if (op == OP_WST) {
+    if (h == 0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) w[s] = w[s + 4] = s < G ? Ws[s * D + j] : 0.f;
+    }
+  } else {
+    const int m = (op - 1) & 1;
+    const int base = op - m;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int c = chan(8 * m + s, h);
+      float v = 0.f;
+      if (base == OP_W2) v = W2[j * D + c];
+      else if (base == OP_W5) v = W5[j * ld5 + c];
+      else if (base == OP_W6) v = W6[j * D + c];
+      else if (base == OP_WS) v = j < G ? Ws[j * D + c] : 0.f;
+      else if (base == OP_W6T) v = W6[c * D + j];
+      else if (base == OP_W5T) v = W5[c * ld5 + j];
+      else if (base == OP_W2T) v = W2[c * D + j];
+      w[s] = v;
+    }
+  }
+  ops[op * 64 + lane] = __builtin_bit_cast(uint4, pack8(w));
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile table: one wavefront walks the points [cp[c], cp[c + 1]) of chunk c greedily
+// ------------------------------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(64) void tile_walk_kernel(const int64_t* __restrict__ ptr,
+                                                       const int64_t* __restrict__ cp, int n_chunks,
+                                                       int32_t* __restrict__ counts,
+                                                       const int64_t* __restrict__ offsets, int2* __restrict__ tiles) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c >= n_chunks) return;
+  int64_t p = cp[c];
+  const int64_t p_end = cp[c + 1];
+  int count = 0;
+  int64_t o = WRITE ? offsets[c] : 0;
+  auto emit = [&](int64_t v0, int nv, int frag) {
+    if (WRITE && lane == 0) tiles[o] = make_int2((int)v0, nv | (frag << 8));
+    ++o;
+    ++count;
+  };
+  while (p < p_end) {
+    // window: lane i holds the END pointer of point p + i
+    const int64_t pi = p + lane;
+    const int e_i = (int)ptr[(pi < p_end ? pi : p_end - 1) + 1];
+    int s = (int)ptr[p];
+    int base = 0;
+    const int win = (int)(p_end - p < 64 ? p_end - p : 64);
+    while (base < win) {
+      const uint64_t fit = __ballot(lane >= base && lane < win && e_i - s <= 32);
+      const int e_base = __builtin_amdgcn_readlane(e_i, base);
+      if (e_base - s > 32) {
+        // long point: fragments of 32 views
+        const int n = e_base - s;
+        const int nf = (n + 31) / 32;
+        for (int f = 0; f < nf; ++f)
+          emit(s + 32 * f, f == nf - 1 ? n - 32 * f : 32, f == 0 ? 1 : (f == nf - 1 ? 3 : 2));
+        s = e_base;
+        base += 1;
+        continue;
+      }
+      // points base .. base + k - 1 fit (pointers are monotone: the fitting lanes are a run starting at base)
+      const int k = __popcll(fit);
+      const int e = __builtin_amdgcn_readlane(e_i, base + k - 1);
+      if (base + k == 64 && win == 64 && p + 64 < p_end && base > 0) break;  // run may continue: reload the window here
+      if (e > s) emit(s, e - s, 0);
+      s = e;
+      base += k;
+    }
+    p += base;
+  }
+  if (!WRITE && lane == 0) counts[c] = count;
+}
+
+// ------------------------------------------------------------------------------------------------
+// first and second moments of the mapping features (fp64 sums): BatchNorm-1 statistics are a function of
+// them (z1 = W1 x is linear), and so is the Q term of the first layer's weight gradient
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x_map, int64_t V,
+                                                      double* __restrict__ mom /* 8 + 36 */) {
+  __shared__ float s_red[44];
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32);
+  float s1[8], s2[36];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) s2[i] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+    const float4 a = as_f4(ld128(X, (uint32_t)(v * 32))), b = as_f4(ld128(X, (uint32_t)(v * 32 + 16)));
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s1[i] += x[i];
+#pragma unroll
+      for (int jj = i; jj < 8; ++jj, ++k) s2[k] = __builtin_fmaf(x[i], x[jj], s2[k]);
+    }
+  }
+  if (threadIdx.x < 44) s_red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 44; ++i) {
+    float v = i < 8 ? s1[i] : s2[i - 8];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    if (lane == 0) atomicAdd(&s_red[i], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 44) atomicAdd(&mom[threadIdx.x], (double)s_red[threadIdx.x]);
+}
+
+// statistics of z1 = bf16(W1) x from the moments: stats = sum z1 | sum z1^2 (the form dva_bn_finalize takes)
+__global__ void stats1_kernel(const double* __restrict__ mom, const float* __restrict__ W1,
+                              double* __restrict__ stats) {
+  const int c = threadIdx.x;
+  if (c >= D) return;
+  double w[8];
+  for (int f = 0; f < 8; ++f) w[f] = (double)bf2f(f2bf(W1[c * 8 + f]));
+  double s = 0, q = 0;
+  int k = 0;
+  for (int i = 0; i < 8; ++i) {
+    s += w[i] * mom[i];
+    for (int jj = i; jj < 8; ++jj, ++k) q += (i == jj ? 1.0 : 2.0) * w[i] * w[jj] * mom[8 + k];
+  }
+  stats[c] = s;
+  stats[D + c] = q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer 2: statistics + per-point extremum.  a2 = leaky(G2 z2 + B2) is monotone in z2 per channel with the
+// sign of gamma2, so the set pooling max_v a2 is taken on sign(gamma2) * z2 BEFORE the statistics exist.
+// ------------------------------------------------------------------------------------------------
+constexpr int TZ = 36;  // fp32 tile row stride (floats)
+__global__ __launch_bounds__(256, 2) void stats2_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
+    const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops, const float* __restrict__ bn1,
+    const float* __restrict__ gamma2, double* __restrict__ stats, float* __restrict__ zstar,
+    int32_t* __restrict__ arg, int64_t V) {
+  __shared__ __attribute__((aligned(16))) float s_tab[TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_tile[4][32 * TZ];
+  __shared__ float s_red[2 * D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  stage_tab(s_tab, bn1, nullptr);
+  __syncthreads();
+  const bf16x8 w1 = load_op(ops, OP_W1, lane);
+  const WOp w2 = load_wop(ops, OP_W2, lane);
+  const uint32_t flip = gamma2[j] < 0.f ? 0x80000000u : 0u;   // walker lane c = j
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4);
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  float run_m = -INFINITY;
+  int run_a = -1;
+  float* tz = s_tile[wv];
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x;
+    int vpj;
+  };
+  run_tiles<Pre>(ta, tb, [&](int t) {
+    Pre p;
+    p.ti = get_tile(tiles, t);
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const int nv = p.ti.nv;
+    const uint32_t keep = j < nv ? 0xffffffffu : 0u;
+    const f32x16 zero = {0};
+    const f32x16 z1 = CH_MFMA(w1, pack_x(p.x), zero);
+    bf16x8 a1[2];
+    act_pack(z1, s_tab, h, keep, a1);
+    const f32x16 z2 = mm32(w2, a1, zero);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[0][r] += z2[r];
+      st[1][r] = __builtin_fmaf(z2[r], z2[r], st[1][r]);
+    }
+    // tile -> LDS [view][channel]; lane c then walks the views of its channel in order
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(tz + j * TZ + 8 * q + 4 * h) =
+          make_float4(z2[4 * q], z2[4 * q + 1], z2[4 * q + 2], z2[4 * q + 3]);
+    // last view of its point, and the point is complete in this tile
+    const int nxt = shfl(p.vpj, lane + 1);
+    const bool is_end = j < nv && (j == nv - 1 || nxt != p.vpj);
+    uint32_t endmask = (uint32_t)__ballot(is_end);
+    if (p.ti.frag == 1 || p.ti.frag == 2) endmask = 0;
+    wave_sync();
+    float xv[32];
+#pragma unroll
+    for (int v = 0; v < 32; ++v) xv[v] = __uint_as_float(__float_as_uint(tz[v * TZ + j]) ^ flip);
+#pragma unroll
+    for (int v = 0; v < 32; ++v) {
+      if (v < nv) {                      // uniform
+        const bool gt = xv[v] > run_m;   // strict: the first extremal view wins (torch_scatter arg semantics)
+        run_m = gt ? xv[v] : run_m;
+        run_a = gt ? p.ti.v0 + v : run_a;
+        if ((endmask >> v) & 1u) {       // uniform
+          const int pt = __builtin_amdgcn_readlane(p.vpj, v);
+          if (h == 0) {
+            zstar[(int64_t)pt * D + j] = __uint_as_float(__float_as_uint(run_m) ^ flip);
+            arg[(int64_t)pt * D + j] = run_a;
+          }
+          run_m = -INFINITY;
+          run_a = -1;
+        }
+      }
+    }
+    wave_sync();
+  });
+  flush_stats<2>(st, stats, s_red);
+}
+
+// pooled[p][c] = leaky(G2 z* + B2) for seen points, 0 for unseen ones (segment_csr max convention)
+__global__ __launch_bounds__(256) void pooled_kernel(const float* __restrict__ zstar, const float* __restrict__ bn2,
+                                                     const int64_t* __restrict__ ptr, float* __restrict__ pooled,
+                                                     int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 per thread
+  if (i >= N * 8) return;
+  const int64_t p = i >> 3;
+  const int c0 = (int)(i & 7) * 4;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ptr[p + 1] > ptr[p]) {
+    const float4 z = *reinterpret_cast<const float4*>(zstar + p * D + c0);
+    const float zz[4] = {z.x, z.y, z.z, z.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      const float g = bn2[2 * D + c] * bn2[D + c];
+      o[e] = leaky(__builtin_fmaf(zz[e], g, bn2[3 * D + c] - bn2[c] * g));
+    }
+    out = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  *reinterpret_cast<float4*>(pooled + p * D + c0) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics of layer 5 (z5 = W5a a2 + u[point]) or layer 6 (train mode)
+// ------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256, 2) void stats_mid_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    double* __restrict__ stats, int64_t V, int64_t N) {
+  __shared__ __attribute__((aligned(16))) float s_tab[3][TAB_FLOATS];
+  __shared__ float s_red[2 * D];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  stage_tab(s_tab[0], bn1, nullptr);
+  stage_tab(s_tab[1], bn2, nullptr);
+  if (L == 6) stage_tab(s_tab[2], bn5, nullptr);
+  __syncthreads();
+  const bf16x8 w1 = load_op(ops, OP_W1, lane);
+  const WOp w2 = load_wop(ops, OP_W2, lane), w5 = load_wop(ops, OP_W5, lane);
+  WOp w6;
+  if (L == 6) w6 = load_wop(ops, OP_W6, lane);
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128);
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x;
+    int vpj;
+  };
+  run_tiles<Pre>(ta, tb, [&](int t) {
+    Pre p;
+    p.ti = get_tile(tiles, t);
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    f32x16 uacc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = as_f4(ld128(U, ok ? (uint32_t)p.vpj * 128u + (8u * q + 4u * h) * 4u : OOB));
+      uacc[4 * q] = v.x; uacc[4 * q + 1] = v.y; uacc[4 * q + 2] = v.z; uacc[4 * q + 3] = v.w;
+    }
+    const f32x16 zero = {0};
+    const f32x16 z1 = CH_MFMA(w1, pack_x(p.x), zero);
+    bf16x8 a1[2], a2[2];
+    act_pack(z1, s_tab[0], h, keep, a1);
+    const f32x16 z2 = mm32(w2, a1, zero);
+    act_pack(z2, s_tab[1], h, keep, a2);
+    f32x16 z = mm32(w5, a2, uacc);
+    if (L == 6) {
+      bf16x8 a5[2];
+      act_pack(z, s_tab[2], h, keep, a5);
+      z = mm32(w6, a5, zero);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[0][r] += z[r];
+      st[1][r] = __builtin_fmaf(z[r], z[r], st[1][r]);
+    }
+  });
+  flush_stats<2>(st, stats, s_red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused view kernel
+// ------------------------------------------------------------------------------------------------
+// Team layout of the value rows: LPR = C / 8 lanes cover one bf16 row with 16-byte loads, ROWS = 64 / LPR row
+// slots per wavefront, slot s handles the KV = 32 / ROWS consecutive views [s KV, (s + 1) KV) of the tile.
+// Single-point tiles (the 32-views-per-point headline shape, and the fragments of long points): per-lane
+// accumulators + a butterfly over the slots.  Tiles with several points: every slot accumulates runs of views
+// of one point; a point that lies inside one slot is stored directly, a point split over slots is summed in a
+// [ROWS][C] LDS buffer keyed by the slot it starts in (each slot starts at most one split point) and stored by
+// the slot it ends in.
+template <int LPR, int G>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ rows,
+    const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
+    const float* __restrict__ gb, bf16_t* __restrict__ out, int scaling, float eps, int64_t V, int64_t N,
+    int64_t R) {
+  constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
+  constexpr int KB = KV < 8 ? KV : 8, NB = KV / KB;
+  constexpr int NE = G == 1 ? 1 : 2;           // score values per lane on the softmax side
+  static_assert(LPR % G == 0, "whole 16-byte lanes per channel group");
+  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_ev[4][4 * 32];     // exp(.) per [group][view]
+  __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][view]
+  __shared__ __attribute__((aligned(16))) int s_ss[4][32], s_se[4][32], s_pid[4][32], s_ri[4][32];
+  __shared__ __attribute__((aligned(16))) float s_alpha[4][4];
+  __shared__ __attribute__((aligned(16))) float s_acc[4][ROWS * C];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  stage_tab(s_tab[0], bn1, nullptr);
+  stage_tab(s_tab[1], bn2, nullptr);
+  stage_tab(s_tab[2], bn5, nullptr);
+  stage_tab(s_tab[3], bn6, nullptr);
+  for (int i = threadIdx.x; i < 4 * ROWS * C; i += blockDim.x) (&s_acc[0][0])[i] = 0.f;
+  __syncthreads();
+  const bf16x8 w1 = load_op(ops, OP_W1, lane);
+  const WOp w2 = load_wop(ops, OP_W2, lane), w5 = load_wop(ops, OP_W5, lane), w6 = load_wop(ops, OP_W6, lane),
+            wsc = load_wop(ops, OP_WS, lane);
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
+                               RW = make_rsrc(rows, (uint64_t)R * C * 2), O = make_rsrc(out, (uint64_t)N * C * 2);
+  // softmax side: lane (j, h) owns the groups gl[e]
+  const bool s_active = G == 4 || h == 0;
+  int gl[NE];
+  float bias[NE], gwl[NE], gbl[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    gl[e] = (G == 4 ? 2 * h : 0) + e;
+    if (gl[e] >= G) gl[e] = G - 1;
+    bias[e] = bs[gl[e]];
+    gwl[e] = gw ? gw[gl[e]] : 0.f;
+    gbl[e] = gw ? gb[gl[e]] : 0.f;
+  }
+  // team side
+  const int slot = lane / LPR, q = lane % LPR, sv0 = slot * KV;
+  const int tg = q / (LPR / G);
+  float* ev_t = s_ev[wv];
+  float* sc_t = s_sc[wv];
+  int* ss_t = s_ss[wv];
+  int* se_t = s_se[wv];
+  int* pid_t = s_pid[wv];
+  int* ri_t = s_ri[wv];
+  float* acc_t = s_acc[wv];
+  // carry of a long point (fragments)
+  float run_m[NE], run_s[NE], run_acc[8];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { run_m[e] = -INFINITY; run_s[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) run_acc[k] = 0.f;
+
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x;
+    int vpj, rij;
+  };
+  run_tiles<Pre>(ta, tb, [&](int t) {
+    Pre p;
+    p.ti = get_tile(tiles, t);
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    p.rij = (int)ld32(RI, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const int nv = p.ti.nv, frag = p.ti.frag;
+    const bool ok = j < nv;
+    // ---- row indices to the team lanes, value rows in flight before the chain starts
+    if (h == 0) ri_t[j] = p.rij;     // lanes without a view read 0 (row 0, weight 0)
+    f32x16 uacc;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const float4 v = as_f4(ld128(U, ok ? (uint32_t)p.vpj * 128u + (8u * qq + 4u * h) * 4u : OOB));
+      uacc[4 * qq] = v.x; uacc[4 * qq + 1] = v.y; uacc[4 * qq + 2] = v.z; uacc[4 * qq + 3] = v.w;
+    }
+    wave_sync();
+    u32x4 xr[2][KB];
+    auto issue_rows = [&](int b) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const uint32_t ri = (uint32_t)ri_t[sv0 + b * KB + kk];
+        xr[b & 1][kk] = ld128(RW, ri * (uint32_t)(C * 2) + (uint32_t)q * 16u);
+      }
+    };
+    issue_rows(0);
+    // ---- DeepSetFeat chain -> scores
+    const f32x16 zero = {0};
+    const uint32_t keep = 0xffffffffu;
+    bf16x8 a[2], a2[2];
+    f32x16 z = CH_MFMA(w1, pack_x(p.x), zero);
+    act_pack(z, s_tab[0], h, keep, a);
+    z = mm32(w2, a, zero);
+    act_pack(z, s_tab[1], h, keep, a2);
+    z = mm32(w5, a2, uacc);
+    act_pack(z, s_tab[2], h, keep, a);
+    z = mm32(w6, a, zero);
+    act_pack(z, s_tab[3], h, keep, a2);
+    z = mm32(wsc, a2, zero);
+    float c[NE];
+    if (G == 4) {
+      uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
+      uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
+      swap_halves(A0, A2);   // A0: h = 0 -> group 0, h = 1 -> group 2
+      swap_halves(A1, A3);
+      c[0] = __uint_as_float(A0) + bias[0];
+      c[1] = __uint_as_float(A1) + bias[1];
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
+    }
+    // ---- softmax over the views of each point
+    const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
+    const bool multi = frag == 0 && sg.nseg > 1;
+    int n_pt = sg.se - sg.ss + 1;
+    if (frag != 0) {
+      const int64_t pt = __builtin_amdgcn_readfirstlane(p.vpj);
+      n_pt = (int)(ptr[pt + 1] - ptr[pt]);
+    }
+    const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
+    float ev[NE], sc[NE], alpha[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      float m = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
+      alpha[e] = 0.f;
+      if (frag != 0) {           // uniform: online softmax across the fragments of a long point
+        const float m_new = fmaxf(run_m[e], m);
+        alpha[e] = __expf((run_m[e] - m_new) * isn);   // frag 1: run_m = -inf -> 0
+        m = m_new;
+      }
+      ev[e] = ok ? __expf((c[e] - m) * isn) : 0.f;
+      float s = seg_total(seg_scan_sum(ev[e], sg, lane), sg, h);
+      if (frag != 0) {
+        s = run_s[e] * alpha[e] + s;
+        run_s[e] = s;
+        run_m[e] = m;
+      }
+      const float gt = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+      sc[e] = gt * __builtin_amdgcn_rcpf(s + eps);
+    }
+    if (frag == 3) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) { run_m[e] = -INFINITY; run_s[e] = 0.f; }
+    }
+    if (s_active) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        ev_t[gl[e] * 32 + j] = ev[e];
+        sc_t[gl[e] * 32 + j] = sc[e];
+        if (j == 0) s_alpha[wv][gl[e]] = alpha[e];
+      }
+    }
+    if (h == 0) {
+      ss_t[j] = ok ? sg.ss : 64 + j;
+      se_t[j] = sg.se;
+      pid_t[j] = p.vpj;
+    }
+    wave_sync();
+    // ---- value rows: weighted sum
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    bool pend = false;
+    int pend_slot = 0, pend_view = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) issue_rows(b + 1);
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int k = b * KB + kk, vt = sv0 + k;
+        const float w = ev_t[tg * 32 + vt];
+        const u32x4 r = xr[b & 1][kk];
+        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] = __builtin_fmaf(w, __uint_as_float(rw[i] << 16), acc[2 * i]);
+          acc[2 * i + 1] = __builtin_fmaf(w, __uint_as_float(rw[i] & 0xffff0000u), acc[2 * i + 1]);
+        }
+        if (multi) {   // uniform
+          const int ssk = ss_t[vt];
+          const bool last = (k == KV - 1) || (ss_t[vt + 1] != ssk);
+          if (last) {
+            if (vt < nv) {
+              const int sek = se_t[vt];
+              if (ssk >= sv0 && sek < sv0 + KV) {
+                const float s = sc_t[tg * 32 + vt];
+                const u32x4 o = {pack_bf16x2(acc[0] * s, acc[1] * s), pack_bf16x2(acc[2] * s, acc[3] * s),
+                                 pack_bf16x2(acc[4] * s, acc[5] * s), pack_bf16x2(acc[6] * s, acc[7] * s)};
+                st128(O, (uint32_t)pid_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
+              } else {
+                float* dst = acc_t + (ssk / KV) * C + q * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) atomicAdd(dst + i, acc[i]);
+                if (sek < sv0 + KV) {
+                  pend = true;
+                  pend_slot = ssk / KV;
+                  pend_view = vt;
+                }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+          }
+        }
+      }
+    }
+    if (multi) {
+      wave_sync();
+      if (pend) {
+        float* src = acc_t + pend_slot * C + q * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        *reinterpret_cast<float4*>(src) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(src + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float s = sc_t[tg * 32 + pend_view];
+        const u32x4 o = {pack_bf16x2(lo.x * s, lo.y * s), pack_bf16x2(lo.z * s, lo.w * s),
+                         pack_bf16x2(hi.x * s, hi.y * s), pack_bf16x2(hi.z * s, hi.w * s)};
+        st128(O, (uint32_t)pid_t[pend_view] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
+      }
+    } else {
+      // one point in the tile: butterfly over the row slots
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off);
+      }
+      if (frag != 0) {
+        const float al = s_alpha[wv][tg];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] = __builtin_fmaf(run_acc[i], al, acc[i]);
+          run_acc[i] = frag == 3 ? 0.f : acc[i];
+        }
+      }
+      if ((frag == 0 || frag == 3) && nv > 0) {
+        const float s = sc_t[tg * 32];
+        const u32x4 o = {pack_bf16x2(acc[0] * s, acc[1] * s), pack_bf16x2(acc[2] * s, acc[3] * s),
+                         pack_bf16x2(acc[4] * s, acc[5] * s), pack_bf16x2(acc[6] * s, acc[7] * s)};
+        st128(O, slot == 0 ? (uint32_t)pid_t[0] * (uint32_t)(C * 2) + (uint32_t)q * 16u : OOB, o);
+      }
+    }
+    wave_sync();
+  });
+}
+
+}  // namespace chain
+}  // namespace dva
+
+using namespace dva;
+using namespace dva::chain;
+
+extern "C" {
+
+int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6,
+                   const float* Ws, int32_t G, void* ops, void* stream) {
+  if (!W1 || !W2 || !W5 || !W6 || !Ws || !ops || G < 1 || G > 4 || ld5 < D) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(prep_kernel, dim3(N_OPS), dim3(64), 0, (hipStream_t)stream, W1, W2, W5, ld5, W6, Ws, G,
+                     (uint4*)ops);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_tile_count(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks, int32_t* counts,
+                         void* stream) {
+  if (n_chunks < 0) return DVA_ERR_INVALID;
+  if (n_chunks == 0) return DVA_OK;
+  if (!ptr || !chunk_points || !counts) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL((tile_walk_kernel<false>), dim3(n_chunks), dim3(64), 0, (hipStream_t)stream, ptr,
+                     chunk_points, n_chunks, counts, (const int64_t*)nullptr, (int2*)nullptr);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks,
+                         const int64_t* offsets, void* tiles, void* stream) {
+  if (n_chunks < 0) return DVA_ERR_INVALID;
+  if (n_chunks == 0) return DVA_OK;
+  if (!ptr || !chunk_points || !offsets || !tiles) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL((tile_walk_kernel<true>), dim3(n_chunks), dim3(64), 0, (hipStream_t)stream, ptr,
+                     chunk_points, n_chunks, (int32_t*)nullptr, offsets, (int2*)tiles);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, double* moments, double* stats1,
+                      void* stream) {
+  if (n_views < 0 || !moments || !stats1 || !W1) return DVA_ERR_INVALID;
+  if (n_views > 0) {
+    if (!x_map) return DVA_ERR_INVALID;
+    int64_t blocks = (n_views + 255) / 256;
+    const int cap = chain_grid(8);
+    hipLaunchKernelGGL(moments_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0, (hipStream_t)stream,
+                       x_map, n_views, moments);
+    DVA_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(stats1_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments, W1, stats1);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_stats2(const float* x_map, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                     const void* ops, const float* bn1, const float* gamma2, double* stats, float* zstar,
+                     int32_t* arg, int64_t n_views, void* stream) {
+  if (n_views < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !tiles || !n_tiles || !ops || !bn1 || !gamma2 || !stats || !zstar || !arg)
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(stats2_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map, view_point,
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, gamma2, stats, zstar, arg, n_views);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_pooled(const float* zstar, const float* bn2, const int64_t* ptr, float* pooled, int64_t n_points,
+                     void* stream) {
+  if (n_points < 0) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  if (!zstar || !bn2 || !ptr || !pooled) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(pooled_kernel, dim3(blocks_for(n_points * 8, 256)), dim3(256), 0, (hipStream_t)stream, zstar,
+                     bn2, ptr, pooled, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
+                    const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                    const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
+                    void* stream) {
+  if (n_views < 0 || (layer != 5 && layer != 6)) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !stats ||
+      (layer == 6 && !bn5))
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(2)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (layer == 5)
+    hipLaunchKernelGGL((stats_mid_kernel<5>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
+                       n_tiles, (const uint4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
+  else
+    hipLaunchKernelGGL((stats_mid_kernel<6>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
+                       n_tiles, (const uint4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                       const float* bn5, const float* bn6, const float* score_bias, const void* rows,
+                       const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
+                       void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
+                       int32_t scaling, float eps, void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
+      !rows || !row_idx || !ptr || !out || ((gate_w == nullptr) != (gate_b == nullptr)))
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
+      n_points * C * 2 > 0xfffffff0ll)
+    return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(2)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_ATTN_FWD(LPR_, G_)                                                                                  \
+  hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, \
+                     n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)rows, row_idx, \
+                     ptr, gate_w, gate_b, (bf16_t*)out, scaling, eps, n_views, n_points, n_rows)
+  const int key = C * 8 + G;
+  switch (key) {
+    case 32 * 8 + 1: DVA_ATTN_FWD(4, 1); break;
+    case 32 * 8 + 2: DVA_ATTN_FWD(4, 2); break;
+    case 32 * 8 + 4: DVA_ATTN_FWD(4, 4); break;
+    case 64 * 8 + 1: DVA_ATTN_FWD(8, 1); break;
+    case 64 * 8 + 2: DVA_ATTN_FWD(8, 2); break;
+    case 64 * 8 + 4: DVA_ATTN_FWD(8, 4); break;
+    case 128 * 8 + 1: DVA_ATTN_FWD(16, 1); break;
+    case 128 * 8 + 2: DVA_ATTN_FWD(16, 2); break;
+    case 128 * 8 + 4: DVA_ATTN_FWD(16, 4); break;
+    case 256 * 8 + 1: DVA_ATTN_FWD(32, 1); break;
+    case 256 * 8 + 2: DVA_ATTN_FWD(32, 2); break;
+    case 256 * 8 + 4: DVA_ATTN_FWD(32, 4); break;
+    case 512 * 8 + 1: DVA_ATTN_FWD(64, 1); break;
+    case 512 * 8 + 2: DVA_ATTN_FWD(64, 2); break;
+    case 512 * 8 + 4: DVA_ATTN_FWD(64, 4); break;
+    default: return DVA_ERR_UNSUPPORTED;
+  }
+#undef DVA_ATTN_FWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+"""GroupBimodalCSRPool on a lazily gathered bf16 value map through the recompute chain
+(``csrc/chain_fwd.hip`` / ``csrc/chain_bwd.hip``, C ABI ``dva_chain_*``).
+
+Computes ``gate * sum_v softmax_v(E_score(E_map(x_map))) * rows[row_idx[v]]`` of the reference
+(modules/multimodal/pooling.py:263-315 with map_encoder = DeepSetFeat :658-669) without any [V, .]
+activation tensor: every kernel re-evaluates the per-view DeepSetFeat chain from the 32-byte mapping features
+(bf16 matrix cores, layers chained in registers).  The only view-sized reads are ``x_map``, the view -> point
+index and the row index; the only view-sized writes of a training step are the score gradients [V, G] and
+the per-view records of the rows gradient.  Train-mode BatchNorm keeps one statistics pass per layer.
+
+Selected by ``pooling.GroupBimodalCSRPool`` inside ``torch.autocast(bfloat16)`` (or with ``FORCE = True``)
+when ``applicable`` holds; everything else takes the fp32 kernels of ``fused_deepset`` / ``ops``.
+The per-point set branch (``mlp_set`` on N rows) runs through the fp32 layer kernels of ``csrc/deepset_mfma.hip``.
+"""
+import torch
+
+from . import _lib, ops, fused_deepset
+from ._lib import check, ptr, require_device, stream_of
+from .fused_deepset import D, _bn_of, _bn_consts
+
+# None = auto (inside torch.autocast(bfloat16) only); True / False pin the choice (tests, bench A/B)
+FORCE = None
+VIEWS_PER_CHUNK = 2048      # tile-table construction granularity (one wavefront walks one chunk)
+OPS_BYTES = 16 * 64 * 16
+
+
+def enabled():
+    if FORCE is not None:
+        return FORCE
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+def applicable(module, x_mod, x_map):
+    """Can ``module`` (a GroupBimodalCSRPool) pool ``x_mod`` (an ops.GatheredFeatures) on the chain?"""
+    if not enabled() or module.use_mod or module.save_last:
+        return False
+    if not isinstance(x_mod, ops.GatheredFeatures) or x_mod.rows.dtype != torch.bfloat16:
+        return False
+    if not fused_deepset.applicable(module.E_map, module.E_score, x_map):
+        return False
+    C, G = module.out_mod, module.num_groups
+    if C not in (32, 64, 128, 256, 512) or G not in (1, 2, 4) or C % G or (C // G) % 8:
+        return False
+    N_max, V = 1 << 24, x_map.shape[0]
+    return V * 32 < (1 << 32) - 16 and x_mod.rows.shape[0] * C * 2 < (1 << 32) - 16 and V < (1 << 31) - 64 \
+        and N_max > 0
+
+
+def build_tiles(csr_idx, V):
+    """Tile table of a CSR pointer array: (tiles int32 [T_max, 2], n_tiles int32 [1]), no host sync."""
+    lib = _lib.load()
+    dev, N = csr_idx.device, csr_idx.shape[0] - 1
+    st = stream_of(csr_idx)
+    n_chunks = max(1, min(16384, (V + VIEWS_PER_CHUNK - 1) // VIEWS_PER_CHUNK))
+    step = (V + n_chunks - 1) // n_chunks if V > 0 else 1
+    bounds = torch.arange(n_chunks, device=dev, dtype=torch.int64) * step
+    cp = torch.searchsorted(csr_idx[:N].contiguous(), bounds)
+    cp = torch.cat([cp, torch.full((1,), N, dtype=torch.int64, device=dev)])
+    cp[0] = 0
+    counts = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+    check(lib.dva_chain_tile_count(ptr(csr_idx), ptr(cp), n_chunks, ptr(counts), st), "dva_chain_tile_count")
+    incl = counts.to(torch.int64).cumsum(0)
+    offsets = (incl - counts).contiguous()
+    n_tiles = incl[-1:].to(torch.int32)
+    t_max = min(N, V) + V // 32 + 1
+    tiles = torch.empty((t_max, 2), dtype=torch.int32, device=dev)
+    check(lib.dva_chain_tile_build(ptr(csr_idx), ptr(cp), n_chunks, ptr(offsets), ptr(tiles), st),
+          "dva_chain_tile_build")
+    return tiles, n_tiles
+
+
+def _set_branch_forward(e_map, pooled, csr_idx, training, zstats):
+    """mlp_set on the N points + the per-point half of the concatenation layer, fp32 layer kernels
+    (the set-size column of use_num enters as a rank-1 per-row addend).  Returns (t_add, saved)."""
+    lib = _lib.load()
+    dev, N = pooled.device, pooled.shape[0]
+    st = stream_of(pooled)
+    F32C = _lib.DVA_F32
+    mlp_set = e_map.mlp_set
+    Wc = e_map.mlp_elt_2[0][0].weight.detach()
+    Wsa_full = mlp_set[0][0].weight.detach()
+    WsaP = Wsa_full[:, :D].contiguous()
+    Wsb = mlp_set[1][0].weight.detach().contiguous()
+    WcB = Wc[:, D:].contiguous()
+    set_bns = [_bn_of(mlp_set[0]), _bn_of(mlp_set[1])]
+    num = add1 = ident_idx = None
+    if e_map.use_num:
+        sizes = csr_idx[1:] - csr_idx[:-1]
+        num = torch.sqrt(1 / (sizes + 1e-3)).float()
+        add1 = (num.view(-1, 1) * Wsa_full[:, D].view(1, -1)).contiguous()
+        ident_idx = torch.arange(N, dtype=torch.int32, device=dev)
+    u1, su1 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
+    check(lib.dva_deepset_fwd_layer(ptr(pooled), None, ptr(WsaP), ptr(add1), ptr(ident_idx), ptr(u1), ptr(su1),
+                                    N, 0, F32C, st), "dva_deepset_fwd_layer")
+    bns1 = _bn_consts(su1, N, set_bns[0], training)
+    u2, su2 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
+    check(lib.dva_deepset_fwd_layer(ptr(u1), ptr(bns1), ptr(Wsb), None, None, ptr(u2), ptr(su2), N, 0, F32C, st),
+          "dva_deepset_fwd_layer")
+    bns2 = _bn_consts(su2, N, set_bns[1], training)
+    t_add, su3 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
+    check(lib.dva_deepset_fwd_layer(ptr(u2), ptr(bns2), ptr(WcB), None, None, ptr(t_add), ptr(su3), N, 0, F32C, st),
+          "dva_deepset_fwd_layer")
+    return t_add, (pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx)
+
+
+def _set_branch_backward(saved, dt, training, zstats):
+    """Backward of _set_branch_forward: dt [N, 32] = gradient of t_add.  Returns (dpooled, dWcB, d_set) with
+    d_set = gradients of list(mlp_set.parameters())."""
+    lib = _lib.load()
+    pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx = saved
+    dev, N = pooled.device, pooled.shape[0]
+    st = stream_of(pooled)
+    F32C = _lib.DVA_F32
+    n_rows = float(max(N, 1))
+
+    def sm_of(stats):
+        if not training:
+            return torch.zeros(2 * D, dtype=torch.float32, device=dev)
+        out = torch.empty(2 * D, dtype=torch.float32, device=dev)
+        check(lib.dva_scale_f64(ptr(stats), 1.0 / n_rows, ptr(out), 2 * D, st), "dva_scale_f64")
+        return out
+
+    def buf():
+        return torch.empty((N, D), dtype=torch.float32, device=dev)
+
+    ident_bn = torch.zeros(4 * D, dtype=torch.float32, device=dev)   # mean 0 | invstd 1 | gamma 1 | beta 0
+    ident_bn[D:3 * D] = 1.0
+    zero_sm = torch.zeros(2 * D, dtype=torch.float32, device=dev)
+    dWcB = torch.zeros_like(WcB)
+    dzs2, ss2 = buf(), zstats()
+    check(lib.dva_deepset_bwd_layer(ptr(dt), ptr(t_add), ptr(ident_bn), ptr(zero_sm), ptr(WcB), ptr(u2), None,
+                                    ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, None, None, N, 0, 0, 0,
+                                    F32C, st), "dva_deepset_bwd_layer")
+    dWsb = torch.zeros_like(Wsb)
+    dzs1, ss1 = buf(), zstats()
+    sms2 = sm_of(ss2)
+    check(lib.dva_deepset_bwd_layer(ptr(dzs2), ptr(u2), ptr(bns2), ptr(sms2), ptr(Wsb), ptr(u1), None,
+                                    ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, None, None, N, 0, 0, 0,
+                                    F32C, st), "dva_deepset_bwd_layer")
+    dWsaP = torch.zeros_like(WsaP)
+    dpooled = buf()
+    da1 = torch.zeros((N, D), dtype=torch.float32, device=dev) if num is not None else None
+    sms1 = sm_of(ss1)
+    check(lib.dva_deepset_bwd_layer(ptr(dzs1), ptr(u1), ptr(bns1), ptr(sms1), ptr(WsaP), ptr(pooled), None,
+                                    None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), None, None, N, 0,
+                                    1, 0, F32C, st), "dva_deepset_bwd_layer")
+    if num is not None:
+        dWsa = torch.cat([dWsaP, (da1 * num.view(-1, 1)).sum(0).view(-1, 1)], dim=1)
+    else:
+        dWsa = dWsaP
+    d_set = [dWsa, ss1[D:].float(), ss1[:D].float(), dWsb, ss2[D:].float(), ss2[:D].float()]
+    return dpooled, dWcB, d_set
+
+
+class _ChainPool(torch.autograd.Function):
+    """params: Wa, g1, b1, Wb, g2, b2, Wc, g3, b3, Wd, g4, b4, Ws, bs, gate_w, gate_b (or None), mlp_set params."""
+
+    @staticmethod
+    def forward(ctx, rows, row_idx, plan, x_map, csr_idx, module, scaling, eps, *params):
+        lib = _lib.load()
+        require_device(rows, row_idx, x_map, csr_idx)
+        e_map, e_score, gate = module.E_map, module.E_score, module.G
+        rows = rows.contiguous()
+        x_map = x_map.contiguous()
+        dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
+        R, C = rows.shape
+        st = stream_of(x_map)
+        training = e_map.training
+        W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
+        W2 = e_map.mlp_elt_1[1][0].weight.detach().contiguous()
+        W5 = e_map.mlp_elt_2[0][0].weight.detach().contiguous()       # [32, 64]: per-view half | per-point half
+        W6 = e_map.mlp_elt_2[1][0].weight.detach().contiguous()
+        Ws, bs = e_score.weight.detach().contiguous(), e_score.bias.detach().contiguous()
+        G = Ws.shape[0]
+        bns = [_bn_of(e_map.mlp_elt_1[0]), _bn_of(e_map.mlp_elt_1[1]),
+               _bn_of(e_map.mlp_elt_2[0]), _bn_of(e_map.mlp_elt_2[1])]
+        gw = gate.weight.detach().reshape(-1).float().contiguous() if gate is not None else None
+        gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
+
+        zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
+
+        def zstats():
+            return next(zpool)
+
+        with ops._timed("chain_tiles", N * 8):
+            tiles, n_tiles = build_tiles(csr_idx, V)
+            vp = torch.empty(V, dtype=torch.int32, device=dev)
+            check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
+        wops = torch.empty(OPS_BYTES, dtype=torch.uint8, device=dev)
+        check(lib.dva_chain_prep(ptr(W1), ptr(W2), ptr(W5), W5.shape[1], ptr(W6), ptr(Ws), G, ptr(wops), st),
+              "dva_chain_prep")
+        # ---- layer 1: statistics from the moments of x_map
+        s1 = zstats()
+        mom = torch.zeros(44, dtype=torch.float64, device=dev)
+        if training:
+            with ops._timed("chain_moments", V * 32):
+                check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), ptr(mom), ptr(s1), st), "dva_chain_moments")
+        bn1 = _bn_consts(s1, V, bns[0], training)
+        # ---- layer 2: statistics + set pooling
+        s2 = zstats()
+        zstar = torch.empty((N, D), dtype=torch.float32, device=dev)
+        arg = torch.empty((N, D), dtype=torch.int32, device=dev)
+        with ops._timed("chain_stats2", V * 36 + N * 256):
+            check(lib.dva_chain_stats2(ptr(x_map), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1),
+                                       ptr(bns[1].weight.detach()), ptr(s2), ptr(zstar), ptr(arg), V, st),
+                  "dva_chain_stats2")
+        bn2 = _bn_consts(s2, V, bns[1], training)
+        pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
+        check(lib.dva_chain_pooled(ptr(zstar), ptr(bn2), ptr(csr_idx), ptr(pooled), N, st), "dva_chain_pooled")
+        t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats)
+        # ---- layers 5, 6: statistics (train mode)
+        s5, s6 = zstats(), zstats()
+        if training:
+            with ops._timed("chain_stats5", V * 36 + N * 128):
+                check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                          ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
+        bn5 = _bn_consts(s5, V, bns[2], training)
+        if training:
+            with ops._timed("chain_stats6", V * 36 + N * 128):
+                check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                          ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
+        bn6 = _bn_consts(s6, V, bns[3], training)
+        # ---- the fused view kernel
+        out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
+        # SURVEY.md 8(d) fused view-gather + attention: V (C s + F_map 4 + idx) + N (C s + ptr); idx = view->point
+        # index + row index (4 + 4), per point the set-branch row (128) on top
+        with ops._timed("chain_attn_fwd", V * (C * 2 + 32 + 8) + N * (C * 2 + 128 + 8)):
+            check(lib.dva_chain_attn_fwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                         ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
+                                         ptr(csr_idx), ptr(gw), ptr(gb), ptr(out), N, V, R, C, G, int(scaling),
+                                         float(eps), st), "dva_chain_attn_fwd")
+        ctx.save_for_backward(rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
+                              bn1, bn2, bn5, bn6, out)
+        ctx.plan = plan
+        ctx.module = module
+        ctx.set_saved = set_saved
+        ctx.training = training
+        ctx.meta = (int(scaling), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import fused_chain_bwd
+        return fused_chain_bwd.backward(ctx, gout)
+
+
+def chain_pool(module, x_mod, x_map, csr_idx):
+    """``module`` = GroupBimodalCSRPool, ``x_mod`` = ops.GatheredFeatures whose rows are already E_mod(rows)."""
+    e_map, e_score, gate = module.E_map, module.E_score, module.G
+    blocks = (e_map.mlp_elt_1[0], e_map.mlp_elt_1[1], e_map.mlp_elt_2[0], e_map.mlp_elt_2[1])
+    params = []
+    for blk in blocks:
+        bn = _bn_of(blk)
+        params += [blk[0].weight, bn.weight, bn.bias]
+    params += [e_score.weight, e_score.bias]
+    params += [gate.weight, gate.bias] if gate is not None else [None, None]
+    params += list(e_map.mlp_set.parameters())
+    csr_idx = ops._check_ptr(csr_idx)
+    return _ChainPool.apply(x_mod.rows, x_mod.row_idx.contiguous(), x_mod.plan, x_map, csr_idx, module,
+                            module.group_scaling, 1e-12, *params)

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from ...core.common_modules import MLP
 from ... import ops
-from ... import fused_deepset
+from ... import fused_deepset, fused_chain
 from ...ops import (segment_csr, gather_csr, segment_gather_csr,  # noqa: F401 (re-exported)
                     segment_softmax_csr)
 
@@ -304,6 +304,13 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
+        val_rows = None
+        if isinstance(x_mod, ops.GatheredFeatures) and fused_chain.applicable(self, x_mod, x_map):
+            # bf16 recompute chain: E_mod on the map rows, then ONE view kernel (DeepSetFeat scores, softmax,
+            # row gather, weighted sum, gate) -- no [V, .] activation tensor at all (fused_chain.py)
+            val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0])
+            if val_rows.dtype == torch.bfloat16:
+                return fused_chain.chain_pool(self, x_mod.with_rows(val_rows), x_map, csr_idx)
         fused_scores = (not self.use_mod and not self.save_last
                         and fused_deepset.applicable(self.E_map, self.E_score, x_map))
         if fused_scores:
@@ -314,7 +321,8 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
         if isinstance(x_mod, ops.GatheredFeatures) and not self.use_mod:
             # lazy nearest gather: E_mod runs on the map rows, the gather is fused into the
             # attention kernel (no [V, C] tensor exists on this path)
-            val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0])
+            if val_rows is None:
+                val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0])
             if not fused_scores:
                 compatibilities = self.E_score(x_map)
             x_mod = x_mod.with_rows(val_rows)

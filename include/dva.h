@@ -318,6 +318,62 @@ int dva_bn_finalize(const double* sums, double m, float* running_mean, float* ru
 int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * Recompute chain (bf16 matrix cores): GroupBimodalCSRPool with map_encoder = DeepSetFeat(8 -> 32, max,
+ * concatenation) for a lazily gathered (nearest, exact mapping) bf16 value map -- modules/multimodal/
+ * pooling.py:263-315 + :658-669 -- without any [V, .] activation tensor: every pass re-evaluates the
+ * per-view chain  x_map -> L1 -> L2 -> (+ set branch of the point) -> L5 -> L6 -> scores  from the 32-byte
+ * mapping features inside the kernel (v_mfma_f32_32x32x16_bf16, layers chained in registers).  Train-mode
+ * BatchNorm keeps its global barriers: one statistics pass per V-level BatchNorm layer (forward) and per
+ * BatchNorm-backward (backward); in eval mode the forward is dva_chain_stats2 (set pooling) +
+ * dva_chain_attn_fwd.  Operands are rounded to bf16 (what torch.autocast(bfloat16) feeds the reference's
+ * Linear layers), accumulation / BatchNorm / softmax / statistics are fp32 / fp64.
+ * Views are processed in TILES of <= 32 consecutive views made of whole points (points with more than 32
+ * views: consecutive fragment tiles); "bn" arrays are fp32 [4][32] = mean | invstd | gamma | beta
+ * (dva_bn_finalize), "stats" caller-zeroed double[64].  All per-point outputs are only written for points
+ * that have views: the caller zero-fills them.
+ * ------------------------------------------------------------------------------------------ */
+/* ops: 16 KiB device buffer receiving the weight operands.  W1 [32][8], W2 [32][32], W5 [32][ld5] (the
+ * first 32 columns: the per-view half of the concatenation layer), W6 [32][32], Ws [G][32], G <= 4. */
+int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6,
+                   const float* Ws, int32_t G, void* ops, void* stream);
+/* Tile table of ptr (int64 [n_points + 1]).  chunk_points int64 [n_chunks + 1]: ascending point indices,
+ * chunk c = points [chunk_points[c], chunk_points[c + 1]) is tiled independently (first 0, last n_points).
+ * count: counts int32 [n_chunks] = tiles per chunk.  build: offsets int64 [n_chunks] = exclusive prefix sum
+ * of counts; tiles int32 [sum(counts)][2] = {first view, n_views | fragment << 8} (fragment 0 = whole
+ * points, 1 / 2 / 3 = first / middle / last fragment of a point with more than 32 views). */
+int dva_chain_tile_count(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks, int32_t* counts,
+                         void* stream);
+int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks,
+                         const int64_t* offsets, void* tiles, void* stream);
+/* moments double[44] (caller-zeroed) += sum_v x | sum_v x_i x_j (i <= j, row-major upper triangle);
+ * stats1 double[64] = sum z1 | sum z1^2 of z1 = bf16(W1) x, derived from the moments. */
+int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, double* moments, double* stats1,
+                      void* stream);
+/* stats += statistics of z2; zstar fp32 [N][32] / arg int32 [N][32] = value / first view of the per-point
+ * extremum of sign(gamma2) z2 (the view that max-pools a2 = leaky(BN2(z2))). */
+int dva_chain_stats2(const float* x_map, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                     const void* ops, const float* bn1, const float* gamma2, double* stats, float* zstar,
+                     int32_t* arg, int64_t n_views, void* stream);
+/* pooled fp32 [N][32] = leaky(BN2(zstar)) for seen points, 0 for unseen ones. */
+int dva_chain_pooled(const float* zstar, const float* bn2, const int64_t* ptr, float* pooled, int64_t n_points,
+                     void* stream);
+/* layer = 5: stats += statistics of z5 = W5a a2 + u[point]; layer = 6: of z6.  u fp32 [N][32] = the per-point
+ * half of the concatenation layer (W5b . set features). */
+int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
+                    const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                    const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
+                    void* stream);
+/* out bf16 [N][C] (caller-zeroed) = gate * sum_v softmax_v(scores) * rows[row_idx[v]]:
+ * x_map + rows in -> pooled features out.  rows bf16 [n_rows][C], C in {32, 64, 128, 256, 512},
+ * G in {1, 2, 4} with (C / G) % 8 == 0; gate_w / gate_b fp32 [G] nullable together. */
+int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                       const float* bn5, const float* bn6, const float* score_bias, const void* rows,
+                       const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
+                       void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
+                       int32_t scaling, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * Voxel parent index after a strided sparse 3D convolution.  Replaces the torchsparse (v1.1.0, not in the
  * reference tree) `sphashquery(sphash(in_coords), sphash(out_coords))` call of
  * modules/multimodal/modules.py:176-198 together with the flooring of the spatial columns:
