@@ -1,0 +1,758 @@
+// Recompute chain, backward side (see chain_common.h for the geometry, chain_fwd.hip for the forward).
+// Every pass re-evaluates the DeepSetFeat chain of a tile from x_map in registers and walks the gradient back as
+// far as the BatchNorm-backward statistics allow; a pass ends where the next global sum (S1 = sum dy,
+// S2 = sum dy * z_hat of a BatchNorm layer) is needed:
+//   dva_chain_attn_bwd   attention + gate backward, score gradients dc [V, 4], view records, S of layer 6
+//   dva_chain_bwd_layer  stage 6: dW6, dWs, dbs, S of layer 5
+//                        stage 5: dW5 (per-view half), du [N, 32] (gradient of the per-point half), S of layer 2 (view part)
+//                        stage 2: set-pooling gradient routed to the arg views, dW2, P = sum dy1 x^T, S of layer 1
+//   dva_chain_route_stats  S of layer 2, per-point part (the routed set-pooling gradient)
+// BatchNorm backward per layer:  dz = G (dy - S1/M - z_hat S2/M),  dy = leaky'(y) da,  G = gamma * invstd.
+// Reference maths: autograd of modules/multimodal/pooling.py:263-315, :658-669.
+#include "chain_common.h"
+
+namespace dva {
+namespace chain {
+
+struct ChainKeep {
+  f32x16 z1, z2, z5, z6;
+  bf16x8 a1[2], a2[2], a5[2], a6[2];
+};
+// tabs[0..3] = layers 1, 2, 5, 6; weight operands from the LDS copy of the table
+__device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
+                                              uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
+  const f32x16 zero = {0};
+  asm volatile("" ::: "memory");
+  k.z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(x), zero);
+  act_pack(k.z1, tabs[0], h, keep, k.a1);
+  k.z2 = mm32_lds(s_ops, OP_W2, lane, k.a1, zero);
+  act_pack(k.z2, tabs[1], h, keep, k.a2);
+  k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
+  act_pack(k.z5, tabs[2], h, keep, k.a5);
+  k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
+  act_pack(k.z6, tabs[3], h, keep, k.a6);
+}
+__device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int vpj, int h) {
+  f32x16 uacc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = as_f4(ld128(U, ok ? (uint32_t)vpj * 128u + (8u * q + 4u * h) * 4u : OOB));
+    uacc[4 * q] = v.x; uacc[4 * q + 1] = v.y; uacc[4 * q + 2] = v.z; uacc[4 * q + 3] = v.w;
+  }
+  return uacc;
+}
+// da6 = Ws^T dc: the score gradients of the view enter as hi | lo in the k-slots of the h = 0 lane
+__device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const float (&dc)[4], int h) {
+  const uint32_t h0 = pack_bf16x2(dc[0], dc[1]), h1 = pack_bf16x2(dc[2], dc[3]);
+  const float r0 = dc[0] - __uint_as_float(h0 << 16), r1 = dc[1] - __uint_as_float(h0 & 0xffff0000u);
+  const float r2 = dc[2] - __uint_as_float(h1 << 16), r3 = dc[3] - __uint_as_float(h1 & 0xffff0000u);
+  const uint32_t keep = h == 0 ? 0xffffffffu : 0u;
+  const u32x4 v = {h0 & keep, h1 & keep, pack_bf16x2(r0, r1) & keep, pack_bf16x2(r2, r3) & keep};
+  const f32x16 zero = {0};
+  asm volatile("" ::: "memory");
+  return CH_MFMA(lds_op(s_ops, OP_WST, lane), __builtin_bit_cast(bf16x8, v), zero);
+}
+// One BatchNorm + LeakyReLU layer backwards: dy = leaky'(y) da; statistics (STATS) and / or
+// dz = G (dy - S1/M - z_hat S2/M) for the lanes that own a view (APPLY).
+template <bool STATS, bool APPLY>
+__device__ __forceinline__ void layer_bwd(const f32x16& z, const f32x16& da, const float* tab, int h, bool ok,
+                                          float (&st)[2][16], float (&dz)[16]) {
+  asm volatile("" ::: "memory");
+  // four channels at a time: 6 float4 of constants live instead of 96 registers
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = 16 * h + 4 * q;
+    const float4 g4 = *reinterpret_cast<const float4*>(tab + T_G * D + o);
+    const float4 b4 = *reinterpret_cast<const float4*>(tab + T_B * D + o);
+    const float4 i4 = *reinterpret_cast<const float4*>(tab + T_I * D + o);
+    const float4 m4 = *reinterpret_cast<const float4*>(tab + T_M * D + o);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float iv[4] = {i4.x, i4.y, i4.z, i4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (APPLY) {
+      const float4 a4 = *reinterpret_cast<const float4*>(tab + T_S1 * D + o);
+      const float4 c4 = *reinterpret_cast<const float4*>(tab + T_S2 * D + o);
+      s1[0] = a4.x; s1[1] = a4.y; s1[2] = a4.z; s1[3] = a4.w;
+      s2[0] = c4.x; s2[1] = c4.y; s2[2] = c4.z; s2[3] = c4.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      const float y = __builtin_fmaf(z[r], g[e], b[e]);
+      const float dy = da[r] * dleaky(y);
+      const float zh = __builtin_fmaf(z[r], iv[e], mm[e]);
+      if (STATS) {
+        st[0][r] += dy;
+        st[1][r] = __builtin_fmaf(dy, zh, st[1][r]);
+      }
+      if (APPLY) dz[r] = ok ? g[e] * (dy - s1[e] - zh * s2[e]) : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void pack16(const float (&x)[16], bf16x8 (&a)[2]) {
+  a[0] = pack8(&x[0]);
+  a[1] = pack8(&x[8]);
+}
+// packed activation (k-slot s of block m = accumulator register 8m + s) -> transposed tile
+__device__ __forceinline__ void tileT_put_packed(bf16_t* tile, int v, int h, const bf16x8 (&a)[2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const u32x4 w = __builtin_bit_cast(u32x4, a[m]);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[chan(8 * m + 2 * i, h) * TSB + v] = (bf16_t)(ww[i] & 0xffffu);
+      tile[chan(8 * m + 2 * i + 1, h) * TSB + v] = (bf16_t)(ww[i] >> 16);
+    }
+  }
+}
+// weight gradient of one layer: acc[r] += sum_v A[chan(r, h)][v] B[j][v] from two transposed tiles
+__device__ __forceinline__ f32x16 wgrad(const bf16_t* ta, const bf16_t* tb, int j, int h, f32x16 acc) {
+  acc = CH_MFMA(tileT_get(ta, j, h, 0), tileT_get(tb, j, h, 0), acc);
+  acc = CH_MFMA(tileT_get(ta, j, h, 1), tileT_get(tb, j, h, 1), acc);
+  return acc;
+}
+// acc[r] = M[chan(r, h)][j] of every wavefront -> out[row * ld + col] (fp32 atomics), cols < ncol only
+__device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restrict__ out, int ld, int ncol,
+                                             bool transpose, float* s_red) {
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+  if (j < ncol) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(&s_red[chan(r, h) * D + j], acc[r]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
+    const int row = i / D, col = i % D;
+    if (col < ncol) atomicAdd(&out[transpose ? col * ld + row : row * ld + col], s_red[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention backward
+// ------------------------------------------------------------------------------------------------
+template <int LPR, int G>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ rows,
+    const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
+    const float* __restrict__ gb, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out,
+    float* __restrict__ dc_out, float* __restrict__ rec, double* __restrict__ stats6, float* __restrict__ gwb,
+    int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+  constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
+  constexpr int KB = KV < 4 ? KV : 4, NB = KV / KB;
+  constexpr int NE = G == 1 ? 1 : 2;
+  constexpr int LPG = LPR / G;                 // lanes per channel group inside a row
+  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_q[4][4 * 32];
+  __shared__ __attribute__((aligned(16))) int s_pid[4][32], s_ri[4][32];
+  __shared__ __attribute__((aligned(16))) float s_E[4][4];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[N_OPS * 64];
+  __shared__ float s_red[2 * D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  stage_ops(s_ops, ops);
+  stage_tab(s_tab[0], bn1, nullptr);
+  stage_tab(s_tab[1], bn2, nullptr);
+  stage_tab(s_tab[2], bn5, nullptr);
+  stage_tab(s_tab[3], bn6, nullptr);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
+                               RW = make_rsrc(rows, (uint64_t)R * C * 2), GO = make_rsrc(gout, (uint64_t)N * C * 2),
+                               OU = make_rsrc(out, (uint64_t)N * C * 2), DC = make_rsrc(dc_out, (uint64_t)V * 16),
+                               RC = make_rsrc(rec, (uint64_t)V * 32);
+  const bool s_active = G == 4 || h == 0;
+  int gl[NE];
+  float bias[NE], gwl[NE], gbl[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    gl[e] = (G == 4 ? 2 * h : 0) + e;
+    if (gl[e] >= G) gl[e] = G - 1;
+    bias[e] = bs[gl[e]];
+    gwl[e] = gw ? gw[gl[e]] : 0.f;
+    gbl[e] = gw ? gb[gl[e]] : 0.f;
+  }
+  const int slot = lane / LPR, q = lane % LPR, sv0 = slot * KV;
+  const int tg = q / LPG;
+  float* q_t = s_q[wv];
+  int* pid_t = s_pid[wv];
+  int* ri_t = s_ri[wv];
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  float dwa[NE], dba[NE];
+  // state of a long point across its fragments
+  float glob_m[NE], glob_s[NE], glob_E[NE];
+  bool seen[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { dwa[e] = dba[e] = 0.f; glob_m[e] = glob_s[e] = glob_E[e] = 0.f; seen[e] = false; }
+
+  auto scores = [&](const f32x16& z, float (&c)[NE]) {
+    if (G == 4) {
+      uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
+      uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
+      swap_halves(A0, A2);
+      swap_halves(A1, A3);
+      c[0] = __uint_as_float(A0) + bias[0];
+      c[1] = __uint_as_float(A1) + bias[1];
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
+    }
+  };
+  // max / sum over the lanes of a half-wave that own a view (single-point tiles)
+  auto half_max = [&](float v) {
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+  };
+  auto half_sum = [&](float v) {
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    int t;
+    float4 x;
+    int vpj, rij;
+  };
+  run_tiles<Pre>(ta, tb, [&](int t) {
+    Pre p;
+    p.ti = get_tile(tiles, t);
+    p.t = t;
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    p.rij = (int)ld32(RI, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const int nv = p.ti.nv, frag = p.ti.frag;
+    const bool ok = j < nv;
+    if (h == 0) {
+      ri_t[j] = p.rij;
+      pid_t[j] = p.vpj;
+    }
+    const f32x16 uacc = load_u(U, ok, p.vpj, h);
+    wave_sync();
+    u32x4 xr[2][KB], go[2][KB];
+    auto issue_rows = [&](int b) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int vt = sv0 + b * KB + kk;
+        xr[b & 1][kk] = ld128(RW, (uint32_t)ri_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u);
+        go[b & 1][kk] = ld128(GO, vt < nv ? (uint32_t)pid_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u : OOB);
+      }
+    };
+    issue_rows(0);
+    ChainKeep k;
+    chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
+    const f32x16 zero = {0};
+    float c[NE];
+    scores(mm32_lds(s_ops, OP_WS, lane, k.a6, zero), c);
+    const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
+    int n_pt = sg.se - sg.ss + 1;
+    if (frag != 0) {
+      const int64_t pt = __builtin_amdgcn_readfirstlane(p.vpj);
+      n_pt = (int)(ptr[pt + 1] - ptr[pt]);
+    }
+    const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
+    if (frag == 1) {
+      // ---- long point: softmax statistics over ALL its fragments first (scores only), and
+      //      E = sum_v a q from the saved forward output: E_g = sum_{ch in g} gout out / gate
+      float m_run[NE], s_run[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        m_run[e] = half_max(ok ? c[e] : -INFINITY);
+        s_run[e] = half_sum(ok ? __expf((c[e] - m_run[e]) * isn) : 0.f);
+        seen[e] = false;
+      }
+      for (int t2 = p.t + 1;; ++t2) {
+        const TileInfo t2i = get_tile(tiles, t2);
+        const bool ok2 = j < t2i.nv;
+        const float4 x2 = as_f4(ld128(X, ok2 ? (uint32_t)(t2i.v0 + j) * 32u + 16u * h : OOB));
+        ChainKeep k2;
+        chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, x2, uacc, k2);   // same point: same set-branch row
+        float c2[NE];
+        scores(mm32_lds(s_ops, OP_WS, lane, k2.a6, zero), c2);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const float m2 = fmaxf(m_run[e], half_max(ok2 ? c2[e] : -INFINITY));
+          s_run[e] = s_run[e] * __expf((m_run[e] - m2) * isn) + half_sum(ok2 ? __expf((c2[e] - m2) * isn) : 0.f);
+          m_run[e] = m2;
+        }
+        if (t2i.frag == 3) break;
+      }
+      const uint32_t pid0 = (uint32_t)__builtin_amdgcn_readfirstlane(p.vpj);
+      const u32x4 go0 = ld128(GO, pid0 * (uint32_t)(C * 2) + (uint32_t)q * 16u);
+      const u32x4 ou0 = ld128(OU, pid0 * (uint32_t)(C * 2) + (uint32_t)q * 16u);
+      const uint32_t ga[4] = {go0.x, go0.y, go0.z, go0.w}, oa[4] = {ou0.x, ou0.y, ou0.z, ou0.w};
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d = __builtin_fmaf(__uint_as_float(ga[i] << 16), __uint_as_float(oa[i] << 16), d);
+        d = __builtin_fmaf(__uint_as_float(ga[i] & 0xffff0000u), __uint_as_float(oa[i] & 0xffff0000u), d);
+      }
+#pragma unroll
+      for (int off = 1; off < LPG; off <<= 1) d += __shfl_xor(d, off);
+      if (slot == 0 && (q % LPG) == 0) s_E[wv][tg] = d;
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        glob_m[e] = m_run[e];
+        glob_s[e] = s_run[e];
+        const float gt0 = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m_run[e], gbl[e]), 0.f)) : 1.f;
+        glob_E[e] = gt0 > 0.f ? s_E[wv][gl[e]] / gt0 : 0.f;
+      }
+    }
+    // ---- softmax of the tile's views
+    float m[NE], a[NE], gt[NE], pre[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      float s;
+      if (frag == 0) {
+        m[e] = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
+        const float ev = ok ? __expf((c[e] - m[e]) * isn) : 0.f;
+        s = seg_total(seg_scan_sum(ev, sg, lane), sg, h);
+        a[e] = ev * __builtin_amdgcn_rcpf(s + eps);
+      } else {
+        m[e] = glob_m[e];
+        a[e] = ok ? __expf((c[e] - m[e]) * isn) * __builtin_amdgcn_rcpf(glob_s[e] + eps) : 0.f;
+      }
+      pre[e] = __builtin_fmaf(gwl[e], m[e], gbl[e]);
+      gt[e] = gw ? tanh_pos(fmaxf(pre[e], 0.f)) : 1.f;
+    }
+    // ---- team side: q[v][g] = sum_{ch in g} gout[p][ch] rows[v][ch]
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) issue_rows(b + 1);
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int vt = sv0 + b * KB + kk;
+        const u32x4 r = xr[b & 1][kk], g4 = go[b & 1][kk];
+        const uint32_t rw[4] = {r.x, r.y, r.z, r.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d = __builtin_fmaf(__uint_as_float(gg[i] << 16), __uint_as_float(rw[i] << 16), d);
+          d = __builtin_fmaf(__uint_as_float(gg[i] & 0xffff0000u), __uint_as_float(rw[i] & 0xffff0000u), d);
+        }
+#pragma unroll
+        for (int off = 1; off < LPG; off <<= 1) d += __shfl_xor(d, off);
+        if ((q % LPG) == 0) q_t[tg * 32 + vt] = d;
+      }
+    }
+    wave_sync();
+    // ---- softmax + gate backward
+    float dcv[NE], gav[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float qv = q_t[gl[e] * 32 + j];
+      float E;
+      if (frag == 0) E = seg_total(seg_scan_sum(a[e] * qv, sg, lane), sg, h);
+      else E = glob_E[e];
+      const float dpre = (gw && pre[e] > 0.f) ? E * (1.f - gt[e] * gt[e]) : 0.f;
+      // first view of the point that attains the maximum (ties -> lowest index, like segment_csr 'max')
+      const bool is_max = ok && c[e] == m[e];
+      const uint64_t F = __ballot(is_max);
+      const uint32_t Fh = (uint32_t)(F >> (32 * h));
+      const uint32_t before = Fh & ((1u << j) - 1u) & ~((1u << sg.ss) - 1u);
+      const bool first = is_max && before == 0u && !seen[e];
+      if (frag != 0) {
+        seen[e] = seen[e] || (Fh != 0u);
+        if (frag == 3) seen[e] = false;
+      }
+      dcv[e] = gt[e] * a[e] * (qv - E) * isn + (first ? dpre * gwl[e] : 0.f);
+      gav[e] = gt[e] * a[e];
+      // d gate_w, d gate_b: once per point, at the last view of the point
+      const bool last_view = ok && j == sg.se && (frag == 0 || frag == 3);
+      if (last_view) {
+        dwa[e] += dpre * m[e];
+        dba[e] += dpre;
+      }
+    }
+    // ---- per-view outputs: dc [V, 4] and the record {point | gate * attention per group}
+    float dc4[4] = {0.f, 0.f, 0.f, 0.f}, ga4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (G == 4) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        uint32_t x0 = __float_as_uint(dcv[e]), x1 = x0;
+        swap_halves(x0, x1);         // x1 in the h = 0 lanes = value of the h = 1 lane
+        dc4[e] = dcv[e];
+        dc4[2 + e] = __uint_as_float(x1);
+        uint32_t y0 = __float_as_uint(gav[e]), y1 = y0;
+        swap_halves(y0, y1);
+        ga4[e] = gav[e];
+        ga4[2 + e] = __uint_as_float(y1);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        dc4[e] = dcv[e];
+        ga4[e] = gav[e];
+      }
+    }
+    const bool wr = ok && h == 0;
+    const uint32_t vg = (uint32_t)(p.ti.v0 + j);
+    st128(DC, wr ? vg * 16u : OOB, as_u4(dc4[0], dc4[1], dc4[2], dc4[3]));
+    st128(RC, wr ? vg * 32u : OOB, as_u4(__int_as_float(p.vpj), ga4[0], ga4[1], ga4[2]));
+    st128(RC, wr ? vg * 32u + 16u : OOB, as_u4(ga4[3], 0.f, 0.f, 0.f));
+    // ---- statistics of BatchNorm-6 backward
+    if (!ok) { dc4[0] = dc4[1] = dc4[2] = dc4[3] = 0.f; }
+    const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
+    float dz_unused[16];
+    layer_bwd<true, false>(k.z6, da6, s_tab[3], h, ok, st, dz_unused);
+    wave_sync();
+  });
+  flush_stats<2>(st, stats6, s_red);
+  if (gw) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float dw = half_sum(dwa[e]), db = half_sum(dba[e]);
+      if (j == 0 && s_active && ((G == 4 ? 2 * h : 0) + e) < G) {
+        atomicAdd(&gwb[gl[e]], dw);
+        atomicAdd(&gwb[G + gl[e]], db);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer passes.  STAGE 6: dz6 -> dW6, dWs, dbs, S5.  STAGE 5: dz5 -> dW5, du, S2 (view part).
+// STAGE 2: set-pooling gradient + dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
+// ------------------------------------------------------------------------------------------------
+constexpr int TZB = 36;
+template <int STAGE>
+__global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ sm2, const float* __restrict__ sm5,
+    const float* __restrict__ sm6, const float* __restrict__ dc, const int32_t* __restrict__ arg,
+    const float* __restrict__ dpooled, float* __restrict__ dW, float* __restrict__ dWs, float* __restrict__ dbs,
+    float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N) {
+  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][32 * TSB];
+  __shared__ __attribute__((aligned(16))) float s_tz[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TZB : 4];
+  __shared__ float s_red[D * D];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[N_OPS * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  stage_ops(s_ops, ops);
+  stage_tab(s_tab[0], bn1, nullptr);
+  stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr);
+  stage_tab(s_tab[2], bn5, STAGE <= 5 ? sm5 : nullptr);
+  stage_tab(s_tab[3], bn6, sm6);
+  // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
+  for (int i = threadIdx.x; i < 4 * 32 * TSB; i += blockDim.x) {
+    if (STAGE != 5) (&s_td[0][0])[i] = 0;
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16),
+                               AR = make_rsrc(arg, (uint64_t)N * 128), DP = make_rsrc(dpooled, (uint64_t)N * 128);
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  f32x16 accW = {0}, accS = {0};      // layer weight gradient; dWs^T (STAGE 6) / P (STAGE 2)
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float run_u = 0.f;                  // STAGE 5: running per-point sum of the walker lane
+  bf16_t* ta = s_ta[wv];
+  bf16_t* tb_ = s_tb[wv];
+  bf16_t* tc = s_tc[STAGE == 5 ? 0 : wv];
+  bf16_t* td = s_td[STAGE == 5 ? 0 : wv];
+  float* tz = s_tz[STAGE == 5 ? wv : 0];
+
+  const int n_tiles = n_tiles_dev[0];
+  int t0, t1;
+  wave_tile_range(tiles, n_tiles, t0, t1);
+  struct Pre {
+    TileInfo ti;
+    float4 x, dc;
+    int vpj;
+  };
+  run_tiles<Pre>(t0, t1, [&](int t) {
+    Pre p;
+    p.ti = get_tile(tiles, t);
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    p.dc = as_f4(ld128(DC, ok && h == 0 ? (uint32_t)(p.ti.v0 + j) * 16u : OOB));
+    return p;
+  }, [&](const Pre& p) {
+    const int nv = p.ti.nv;
+    const bool ok = j < nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    const f32x16 uacc = load_u(U, ok, p.vpj, h);
+    // set-pooling gradient of this view's channels (STAGE 2): issued early, used after the chain
+    u32x4 arq[4], dpq[4];
+    if (STAGE == 2) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const uint32_t off = ok ? (uint32_t)p.vpj * 128u + (8u * qq + 4u * h) * 4u : OOB;
+        arq[qq] = ld128(AR, off);
+        dpq[qq] = ld128(DP, off);
+      }
+    }
+    ChainKeep k;
+    chain_forward(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
+    float dz[16], unused_st[2][16];
+    // ---- layer 6
+    const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
+    layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
+    bf16x8 dzp[2];
+    pack16(dz, dzp);
+    const f32x16 zero = {0};
+    if (STAGE == 6) {
+      tileT_put_packed(ta, j, h, dzp);
+      tileT_put_packed(tb_, j, h, k.a5);
+      tileT_put_packed(tc, j, h, k.a6);
+      if (h == 0) {
+        const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
+        td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
+        td[1 * TSB + j] = (bf16_t)(d01 >> 16);
+        td[2 * TSB + j] = (bf16_t)(d23 & 0xffffu);
+        td[3 * TSB + j] = (bf16_t)(d23 >> 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
+      }
+    }
+    const f32x16 da5 = mm32_lds(s_ops, OP_W6T, lane, dzp, zero);
+    if (STAGE == 6) {
+      layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dz);
+      wave_sync();
+      accW = wgrad(ta, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
+      accS = wgrad(tc, td, j, h, accS);       // dWs^T[k][g] = sum_v a6[v][k] dc[v][g]
+      wave_sync();
+      return;
+    }
+    // ---- layer 5
+    layer_bwd<false, true>(k.z5, da5, s_tab[2], h, ok, unused_st, dz);
+    pack16(dz, dzp);
+    if (STAGE == 5) {
+      tileT_put_packed(ta, j, h, dzp);
+      tileT_put_packed(tb_, j, h, k.a2);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+        *reinterpret_cast<float4*>(tz + j * TZB + 8 * qq + 4 * h) =
+            make_float4(dz[4 * qq], dz[4 * qq + 1], dz[4 * qq + 2], dz[4 * qq + 3]);
+    }
+    const f32x16 da2 = mm32_lds(s_ops, OP_W5T, lane, dzp, zero);
+    if (STAGE == 5) {
+      layer_bwd<true, false>(k.z2, da2, s_tab[1], h, ok, st, dz);
+      const int nxt = shfl(p.vpj, lane + 1);
+      const bool is_end = ok && (j == nv - 1 || nxt != p.vpj);
+      uint32_t endmask = (uint32_t)__ballot(is_end);
+      if (p.ti.frag == 1 || p.ti.frag == 2) endmask = 0;
+      wave_sync();
+      accW = wgrad(ta, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
+      // du[p][c] = sum of dz5 over the views of the point: lane c walks the views of the tile
+      float xv[32];
+#pragma unroll
+      for (int v = 0; v < 32; ++v) xv[v] = tz[v * TZB + j];
+#pragma unroll
+      for (int v = 0; v < 32; ++v) {
+        if (v < nv) {
+          run_u += xv[v];
+          if ((endmask >> v) & 1u) {
+            const int pt = __builtin_amdgcn_readlane(p.vpj, v);
+            if (h == 0) du[(int64_t)pt * D + j] = run_u;
+            run_u = 0.f;
+          }
+        }
+      }
+      wave_sync();
+      return;
+    }
+    // ---- STAGE 2: layers 1, 2 re-evaluated here (their registers were free during the layer 6 / 5 work)
+    bf16x8 a1r[2];
+    asm volatile("" ::: "memory");
+    const f32x16 z1r = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
+    act_pack(z1r, s_tab[0], h, keep, a1r);
+    const f32x16 z2r = mm32_lds(s_ops, OP_W2, lane, a1r, zero);
+    // gradient of the max-pooled set features goes to the arg view of each channel
+    f32x16 da2t = da2;
+    {
+      const int vg = p.ti.v0 + j;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const uint32_t ai[4] = {arq[qq].x, arq[qq].y, arq[qq].z, arq[qq].w};
+        const uint32_t di[4] = {dpq[qq].x, dpq[qq].y, dpq[qq].z, dpq[qq].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          da2t[4 * qq + e] += (ok && (int)ai[e] == vg) ? __uint_as_float(di[e]) : 0.f;
+      }
+    }
+    layer_bwd<false, true>(z2r, da2t, s_tab[1], h, ok, unused_st, dz);
+    pack16(dz, dzp);
+    tileT_put_packed(ta, j, h, dzp);
+    tileT_put_packed(tb_, j, h, a1r);
+    const f32x16 da1 = mm32_lds(s_ops, OP_W2T, lane, dzp, zero);
+    layer_bwd<true, false>(z1r, da1, s_tab[0], h, ok, st, dz);
+    // dy1 of the layer (recomputed: layer_bwd keeps it internal) for P = sum_v dy1 x^T
+    {
+      float g1[16], b1[16], dy1[16];
+      tab16(s_tab[0], T_G, h, g1);
+      tab16(s_tab[0], T_B, h, b1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dy1[r] = ok ? da1[r] * dleaky(__builtin_fmaf(z1r[r], g1[r], b1[r])) : 0.f;
+      tileT_put_acc(tc, j, h, dy1);
+      tileT_put(td, 4 * h, 4 * h + 1, j, p.x.x, p.x.y);      // lanes without a view loaded zeros
+      tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
+    }
+    wave_sync();
+    accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
+    accS = wgrad(tc, td, j, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
+    wave_sync();
+  });
+  flush_matrix(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red);
+  if (STAGE == 6) {
+    flush_matrix(accS, dWs, D, G, true, s_red);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = dbsum[g];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
+    }
+  }
+  if (STAGE == 2) flush_matrix(accS, Pm, 8, 8, false, s_red);
+  flush_stats<2>(st, stats, s_red);
+}
+
+// S2 of layer 2, per-point part: the set-pooling gradient lands on one view per (point, channel) whose z2 is
+// zstar: stats += sum_p leaky'(y*) dpooled | the same times z_hat*  over the seen points.
+__global__ __launch_bounds__(256) void route_stats_kernel(const float* __restrict__ zstar,
+                                                          const float* __restrict__ dpooled,
+                                                          const float* __restrict__ bn2,
+                                                          const int64_t* __restrict__ ptr, double* __restrict__ stats,
+                                                          int64_t N) {
+  __shared__ float s_red[2 * D];
+  const int c = threadIdx.x & 31, sub = threadIdx.x >> 5;      // 8 points per block iteration
+  const float g = bn2[2 * D + c] * bn2[D + c], b = bn2[3 * D + c] - bn2[c] * g;
+  const float iv = bn2[D + c], mm = -bn2[c] * bn2[D + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * 8 + sub; p < N; p += (int64_t)gridDim.x * 8) {
+    if (ptr[p + 1] > ptr[p]) {
+      const float z = zstar[p * D + c];
+      const float dy = dpooled[p * D + c] * dleaky(__builtin_fmaf(z, g, b));
+      s1 += dy;
+      s2 = __builtin_fmaf(dy, __builtin_fmaf(z, iv, mm), s2);
+    }
+  }
+  if (threadIdx.x < 2 * D) s_red[threadIdx.x] = 0.f;
+  __syncthreads();
+  atomicAdd(&s_red[c], s1);
+  atomicAdd(&s_red[D + c], s2);
+  __syncthreads();
+  if (threadIdx.x < 2 * D) atomicAdd(&stats[threadIdx.x], (double)s_red[threadIdx.x]);
+}
+
+}  // namespace chain
+}  // namespace dva
+
+using namespace dva;
+using namespace dva::chain;
+
+extern "C" {
+
+int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                       const float* bn5, const float* bn6, const float* score_bias, const void* rows,
+                       const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
+                       const void* grad_out, const void* out, float* grad_scores, float* view_rec,
+                       double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
+                       int32_t C, int32_t G, int32_t scaling, float eps, void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
+      !rows || !row_idx || !ptr || !grad_out || !out || !grad_scores || !view_rec || !stats6 ||
+      ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
+      n_points * C * 2 > 0xfffffff0ll)
+    return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(2)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_ATTN_BWD(LPR_, G_)                                                                                   \
+  hipLaunchKernelGGL((attn_bwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,  \
+                     n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)rows, row_idx,  \
+                     ptr, gate_w, gate_b, (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, view_rec,   \
+                     stats6, grad_gate_wb, scaling, eps, n_views, n_points, n_rows)
+  const int key = C * 8 + G;
+  switch (key) {
+    case 32 * 8 + 1: DVA_ATTN_BWD(4, 1); break;
+    case 32 * 8 + 2: DVA_ATTN_BWD(4, 2); break;
+    case 32 * 8 + 4: DVA_ATTN_BWD(4, 4); break;
+    case 64 * 8 + 1: DVA_ATTN_BWD(8, 1); break;
+    case 64 * 8 + 2: DVA_ATTN_BWD(8, 2); break;
+    case 64 * 8 + 4: DVA_ATTN_BWD(8, 4); break;
+    case 128 * 8 + 1: DVA_ATTN_BWD(16, 1); break;
+    case 128 * 8 + 2: DVA_ATTN_BWD(16, 2); break;
+    case 128 * 8 + 4: DVA_ATTN_BWD(16, 4); break;
+    case 256 * 8 + 1: DVA_ATTN_BWD(32, 1); break;
+    case 256 * 8 + 2: DVA_ATTN_BWD(32, 2); break;
+    case 256 * 8 + 4: DVA_ATTN_BWD(32, 4); break;
+    case 512 * 8 + 1: DVA_ATTN_BWD(64, 1); break;
+    case 512 * 8 + 2: DVA_ATTN_BWD(64, 2); break;
+    case 512 * 8 + 4: DVA_ATTN_BWD(64, 4); break;
+    default: return DVA_ERR_UNSUPPORTED;
+  }
+#undef DVA_ATTN_BWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
+                        const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                        const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
+                        const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
+                        float* dW, float* dWs, float* dbs, float* du, float* P, double* stats, int32_t G,
+                        int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !sm6 ||
+      !grad_scores || !dW || !stats)
+    return DVA_ERR_INVALID;
+  if (stage == 6 && (!dWs || !dbs)) return DVA_ERR_INVALID;
+  if (stage <= 5 && !sm5) return DVA_ERR_INVALID;
+  if (stage == 5 && !du) return DVA_ERR_INVALID;
+  if (stage == 2 && (!sm2 || !arg || !dpooled || !P)) return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_LAYER_BWD(ST_, BPC_)                                                                                  \
+  hipLaunchKernelGGL((layer_bwd_kernel<ST_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u,        \
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
+                     grad_scores, arg, dpooled, dW, dWs, dbs, du, P, stats, G, n_views, n_points)
+  if (stage == 6) DVA_LAYER_BWD(6, 2);
+  else if (stage == 5) DVA_LAYER_BWD(5, 2);
+  else DVA_LAYER_BWD(2, 2);
+#undef DVA_LAYER_BWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
+                          double* stats, int64_t n_points, void* stream) {
+  if (n_points < 0) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  if (!zstar || !dpooled || !bn2 || !ptr || !stats) return DVA_ERR_INVALID;
+  int64_t blocks = (n_points + 7) / 8;
+  const int cap = chain_grid(8);
+  hipLaunchKernelGGL(route_stats_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0,
+                     (hipStream_t)stream, zstar, dpooled, bn2, ptr, stats, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

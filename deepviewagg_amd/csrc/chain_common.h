@@ -159,6 +159,20 @@ __device__ __forceinline__ WOp load_wop(const uint4* __restrict__ ops, int op, i
   w.m[1] = load_op(ops, op + 1, lane);
   return w;
 }
+// weight operands staged in LDS (backward kernels: 64 registers per lane less than holding them)
+__device__ __forceinline__ void stage_ops(uint4* s_ops, const uint4* __restrict__ ops) {
+  for (int i = threadIdx.x; i < N_OPS * 64; i += blockDim.x) s_ops[i] = ops[i];
+}
+__device__ __forceinline__ bf16x8 lds_op(const uint4* s_ops, int op, int lane) {
+  return __builtin_bit_cast(bf16x8, s_ops[op * 64 + lane]);
+}
+__device__ __forceinline__ f32x16 mm32_lds(const uint4* s_ops, int op, int lane, const bf16x8 (&a)[2], f32x16 c) {
+  asm volatile("" ::: "memory");   // keep the two ds_read_b128 inside the tile loop
+  const bf16x8 w0 = lds_op(s_ops, op, lane), w1 = lds_op(s_ops, op + 1, lane);
+  c = CH_MFMA(w0, a[0], c);
+  c = CH_MFMA(w1, a[1], c);
+  return c;
+}
 __device__ __forceinline__ f32x16 mm32(const WOp& w, const bf16x8 (&a)[2], f32x16 c) {
   c = CH_MFMA(w.m[0], a[0], c);
   c = CH_MFMA(w.m[1], a[1], c);

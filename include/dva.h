@@ -373,6 +373,35 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
                        void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
                        int32_t scaling, float eps, void* stream);
 
+/* Backward of dva_chain_attn_fwd (+ the BatchNorm-backward statistics of layer 6).  grad_out / out bf16 [N][C]
+ * (out = the forward result; only read for points with more than 32 views).  Outputs: grad_scores fp32 [V][4]
+ * (columns >= G zero), view_rec fp32 [V][8] = {point id bits | gate * attention per group | 0} (the records
+ * dva_view_gather_rows_grad consumes), stats6 += S1 | S2 of layer 6, grad_gate_wb fp32 [2 G] (caller-zeroed,
+ * d gate_w | d gate_b; nullable with gating off). */
+int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                       const float* bn5, const float* bn6, const float* score_bias, const void* rows,
+                       const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
+                       const void* grad_out, const void* out, float* grad_scores, float* view_rec,
+                       double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
+                       int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
+/* One backward pass of the chain between two BatchNorm-backward barriers ("sm" = fp32 [2][32] = S1/M | S2/M of
+ * the layer, zeros with running statistics; all outputs caller-zeroed, accumulated with atomics):
+ *   stage 6: dW [32][32] = dW6, dWs [G][32], dbs [G], stats += S of layer 5          (needs sm6)
+ *   stage 5: dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u (written for
+ *            seen points), stats += S of layer 2, view part                          (needs sm5, sm6)
+ *   stage 2: dW [32][32] = dW2, P fp32 [32][8] = sum_v dy1 x^T, stats += S of layer 1; arg / dpooled = the
+ *            arg views of dva_chain_stats2 and the gradient of the pooled set features   (needs sm2, sm5, sm6) */
+int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
+                        const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                        const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
+                        const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
+                        float* dW, float* dWs, float* dbs, float* du, float* P, double* stats, int32_t G,
+                        int64_t n_views, int64_t n_points, void* stream);
+/* stats += S1 | S2 of layer 2, per-point part: sum over the seen points of leaky'(BN2(zstar)) dpooled (x z_hat). */
+int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
+                          double* stats, int64_t n_points, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * Voxel parent index after a strided sparse 3D convolution.  Replaces the torchsparse (v1.1.0, not in the
  * reference tree) `sphashquery(sphash(in_coords), sphash(out_coords))` call of

@@ -49,14 +49,16 @@ def full32(N, gen):
     return torch.full((N,), 32, dtype=torch.long)
 
 
-def build(case, G, train, gating=True, scaling=True, seed=5):
+def build(case, G, train, gating=True, scaling=True, seed=5, wscale=0.3):
     from deepviewagg_amd.modules.multimodal import pooling as P
     gen = torch.Generator().manual_seed(seed)
     kwargs = dict(in_map=8, in_mod=case["C"], num_groups=G, use_num=True, gating=gating, group_scaling=scaling)
     ref = O.GroupBimodalCSRPool(**kwargs)
     with torch.no_grad():
-        for p in ref.parameters():
-            p.copy_(torch.randn(p.shape, generator=gen) * 0.4)
+        for n, p in ref.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * wscale)
+            if "batch_norm.weight" in n or n == "G.weight":
+                p.add_(1.0)                      # BatchNorm / gate scales around their initial value 1
         for n, b in ref.named_buffers():
             if "running_mean" in n:
                 b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
@@ -145,3 +147,172 @@ def test_tile_table_properties():
         lo = np.searchsorted(v0, ptr[:-1], side='right')     # first cut > start
         hi = np.searchsorted(v0, ptr[1:], side='left')       # first cut >= end
         assert (lo[small] == hi[small]).all()
+
+
+def _oracle_grads(case, ref, autocast):
+    xr = case["x"].clone().requires_grad_()
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = ref(None, O.gather_nearest(xr, case["images"], case["pixels"]), case["x_map"], case["csr"])
+    else:
+        out = ref(None, O.gather_nearest(xr, case["images"], case["pixels"]), case["x_map"], case["csr"])
+    grads = torch.autograd.grad((out.float() * case["w"]).sum(), [xr] + list(ref.parameters()), allow_unused=True)
+    return out, grads
+
+
+@pytest.mark.parametrize("sizes_fn,N,C,G,train,gating", [
+    (ragged, 3000, 64, 4, True, True),
+    (ragged_long, 2000, 64, 4, True, True),
+    (full32, 4096, 64, 4, True, True),          # the headline instantiation: 32 views / point, bf16, C = 64, G = 4
+    (ragged, 3000, 64, 4, False, True),
+    (ragged_long, 1500, 32, 2, True, True),
+    (ragged, 1500, 128, 1, True, False),
+    (ragged_long, 700, 512, 4, True, True),
+])
+def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
+    """Gradients w.r.t. the feature maps and every parameter against the fp32 oracle; yardstick = the error of
+    the reference maths itself under torch.autocast(bfloat16): per tensor, relative L2 error
+    <= max(2 x reference-autocast error, 5e-2) (4 x for the gate / score parameters, see below)."""
+    case = make_case(7, N, C, sizes_fn)
+    ref, m = build(case, G, train, gating=gating)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    out_ref, g_ref = _oracle_grads(case, ref, autocast=False)
+    ref.load_state_dict(sd)
+    _, g_amp = _oracle_grads(case, ref, autocast=True)
+    out, g = run_dev(case, m, chain=True)
+    ref.load_state_dict(sd)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        out_amp = ref(None, O.gather_nearest(case["x"], case["images"], case["pixels"]), case["x_map"], case["csr"])
+    assert rel(out, out_ref) < max(2e-2, 1.5 * rel(out_amp, out_ref)), (rel(out, out_ref), rel(out_amp, out_ref))
+    names = ["x"] + [n for n, _ in ref.named_parameters()]
+    report, bad = [], []
+    for n, a, b, c in zip(names, g, g_ref, g_amp):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0, n
+            continue
+        assert a is not None, n
+        ours, amp = rel(a, b), rel(c, b)
+        report.append((n, round(ours, 4), round(amp, 4)))
+        # gate / score-bias gradients are sums of per-point terms of both signs routed through an arg-max:
+        # a handful of arg-max flips under the bf16 perturbation moves them by several % under either scheme
+        loose = n.startswith("G.") or n.startswith("E_score")
+        if ours > max((4.0 if loose else 2.0) * amp, 5e-2):
+            bad.append(report[-1])
+    print("chain bwd rel err (ours, reference under autocast):", report)
+    assert not bad, (bad, report)
+
+
+def test_chain_equals_stored_activation_path():
+    """A/B against the first-generation fp32-MFMA kernels with bf16 activation storage on the same inputs."""
+    case = make_case(11, 5000, 64, ragged)
+    ref, m = build(case, 4, True)
+    out_a, g_a = run_dev(case, m, chain=True)
+    m.load_state_dict(ref.state_dict())
+    out_b, g_b = run_dev(case, m, chain=False)
+    assert rel(out_a, out_b) < 2e-2
+    assert rel(g_a[0], g_b[0]) < 8e-2, rel(g_a[0], g_b[0])          # gradient w.r.t. the feature maps
+    # parameter gradients: both are bf16 perturbations of the same fp32 maths (each 10-20 % off the fp32 oracle in
+    # train mode, like the reference under autocast): same direction
+    for (n, _), a, b in zip(list(m.named_parameters()), g_a[1:], g_b[1:]):
+        if a is None or b is None or float(b.norm()) == 0:
+            continue
+        cos = float((a.flatten() @ b.flatten()) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.9, (n, cos)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tight parity: the oracle's maths with the chain's operand roundings made explicit (straight-through bf16
+# rounding of the activations and weights that enter the matrix-core products; everything else fp32).  Unlike
+# the comparison with the un-rounded fp32 oracle above, nothing chaotic (LeakyReLU sign / arg-max flips under a
+# 2^-9 perturbation) separates the two computations, so the forward and the rows gradient agree to < 1e-2 relative L2 and
+# the parameter gradients to a few % (the backward kernels round dz / the weight-gradient operands to bf16 once
+# more, and the arg-max routing of the gate gradient stays discrete).
+# ---------------------------------------------------------------------------------------------------------------
+def _bf(t):
+    return t + (t.bfloat16().float() - t).detach()
+
+
+def emulated_chain(ref, vals, x_map, csr):
+    """GroupBimodalCSRPool.forward of the oracle (pooling.py:263-315, :658-669) given the per-view values
+    ``vals`` = E_mod(x_mod) [V, C], with the chain's roundings."""
+    import torch.nn.functional as F
+    E = ref.E_map
+    idx = O.dense_index(csr)
+
+    def bn_act(blk, z):
+        return F.leaky_relu(blk[1](z), 0.2)
+
+    a1 = _bf(bn_act(E.mlp_elt_1[0], x_map @ _bf(E.mlp_elt_1[0][0].weight).t()))
+    a2f = bn_act(E.mlp_elt_1[1], a1 @ _bf(E.mlp_elt_1[1][0].weight).t())
+    x_set = O.segment_csr(a2f, csr, 'max')
+    if E.use_num:
+        set_num = torch.sqrt(1 / (csr[1:] - csr[:-1] + 1e-3))
+        x_set = torch.cat((x_set, set_num.view(-1, 1).float()), dim=1)
+    s = E.mlp_set(x_set)
+    Wc = E.mlp_elt_2[0][0].weight
+    u = s @ Wc[:, 32:].t()
+    a5 = _bf(bn_act(E.mlp_elt_2[0], _bf(a2f) @ _bf(Wc[:, :32]).t() + u[idx]))
+    a6 = _bf(bn_act(E.mlp_elt_2[1], a5 @ _bf(E.mlp_elt_2[1][0].weight).t()))
+    compat = a6 @ _bf(ref.E_score.weight).t() + ref.E_score.bias
+    out, _, _ = O.attention_tail(vals, compat, csr, ref.G, ref.num_groups, ref.out_mod, ref.group_scaling)
+    return out
+
+
+@pytest.mark.parametrize("sizes_fn,N,C,G,train,gating,scaling", [
+    (ragged, 3000, 64, 4, True, True, True),
+    (ragged_long, 2000, 64, 4, True, True, True),
+    (full32, 2048, 64, 4, True, True, True),       # the headline instantiation
+    (ragged_long, 2000, 64, 4, False, True, False),
+    (ragged_long, 1500, 32, 2, True, True, True),
+    (ragged, 1500, 128, 1, True, False, True),
+    (ragged_long, 700, 512, 4, True, True, True),
+    (ragged_long, 900, 256, 2, False, True, True),
+])
+def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling):
+    from deepviewagg_amd import ops, fused_chain
+    case = make_case(13, N, C, sizes_fn)
+    gen = case["gen"]
+    V, csr = case["V"], case["csr"]
+    R = 777
+    rows = (torch.randn(R, C, generator=gen)).bfloat16()
+    row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    ref, m = build(case, G, train, gating=gating, scaling=scaling)
+    # oracle side
+    rows_ref = rows.float().requires_grad_()
+    out_ref = emulated_chain(ref, rows_ref[row_idx.long()], case["x_map"], csr)
+    chain_params = [p for n, p in ref.named_parameters() if not n.startswith("E_mod")]
+    names = [n for n, _ in ref.named_parameters() if not n.startswith("E_mod")]
+    g_ref = torch.autograd.grad((out_ref * case["w"]).sum(), [rows_ref] + chain_params, allow_unused=True)
+    # device side: the chain on a GatheredFeatures whose rows are the values
+    rows_d = rows.to(DEV).requires_grad_()
+    gf = ops.GatheredFeatures(rows_d, row_idx.to(DEV), None, True, None)
+    fused_chain.FORCE = True
+    try:
+        out = fused_chain.chain_pool(m, gf, case["x_map"].to(DEV), csr.to(DEV))
+    finally:
+        fused_chain.FORCE = None
+    dev_params = [p for n, p in m.named_parameters() if not n.startswith("E_mod")]
+    g = torch.autograd.grad((out.float() * case["w"].to(DEV)).sum(), [rows_d] + dev_params, allow_unused=True)
+    r_out = rel(out, out_ref)
+    report = [("out", round(r_out, 5))]
+    bad = []
+    for n, a, b in zip(["rows"] + names, g, g_ref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0, n
+            continue
+        r = rel(a, b)
+        report.append((n, round(r, 5)))
+        # rows: no chaotic element.  Parameters: a rounding-boundary flip of one bf16 activation (1 view in ~30)
+        # moves a score by ~1e-3, which flips the arg-max view of a few near-tied points: their gate gradient
+        # lands on another view (measured: 3 views of 65536 carry the whole difference, tools/debug_chain.py)
+        if n == "E_score.bias" and not gating:
+            continue        # exactly zero in exact arithmetic (softmax is shift invariant): nothing to compare
+        if r > (1e-2 if n == "rows" else 1.5e-1):
+            bad.append((n, r))
+    print("chain vs bf16 emulation, rel L2:", report)
+    assert r_out < 6e-3, report          # bf16 rounding of the output itself: 2^-9
+    assert not bad, (bad, report)
+    if train:
+        for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
+            if "running" in k and not k.startswith("E_mod"):
+                torch.testing.assert_close(a.cpu(), b, rtol=1e-3, atol=1e-4)
