@@ -41,6 +41,16 @@ __device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int 
   }
   return uacc;
 }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// sum of the 8 bf16 products of two 16-byte chunks (v_dot2c_f32_bf16, fp32 accumulation)
+__device__ __forceinline__ float dot8(const u32x4& a, const u32x4& b) {
+  const uint32_t aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+  float d = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, aa[i]), __builtin_bit_cast(bf16x2_t, bb[i]), d, false);
+  return d;
+}
 // da6 = Ws^T dc: the score gradients of the view enter as hi | lo in the k-slots of the h = 0 lane
 __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const float (&dc)[4], int h) {
   const uint32_t h0 = pack_bf16x2(dc[0], dc[1]), h1 = pack_bf16x2(dc[2], dc[3]);
@@ -85,13 +95,13 @@ __device__ __forceinline__ void layer_bwd(const f32x16& z, const f32x16& da, con
         st[0][r] += dy;
         st[1][r] = __builtin_fmaf(dy, zh, st[1][r]);
       }
-      if (APPLY) dz[r] = ok ? g[e] * (dy - s1[e] - zh * s2[e]) : 0.f;
+      if (APPLY) dz[r] = g[e] * (dy - s1[e] - zh * s2[e]);   // lanes without a view: masked when packed
     }
   }
 }
-__device__ __forceinline__ void pack16(const float (&x)[16], bf16x8 (&a)[2]) {
-  a[0] = pack8(&x[0]);
-  a[1] = pack8(&x[8]);
+__device__ __forceinline__ void pack16(const float (&x)[16], uint32_t keep, bf16x8 (&a)[2]) {
+  a[0] = mask8(pack8(&x[0]), keep);
+  a[1] = mask8(pack8(&x[8]), keep);
 }
 // packed activation (k-slot s of block m = accumulator register 8m + s) -> transposed tile
 __device__ __forceinline__ void tileT_put_packed(bf16_t* tile, int v, int h, const bf16x8 (&a)[2]) {
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
   for (int e = 0; e < NE; ++e) { dwa[e] = dba[e] = 0.f; glob_m[e] = glob_s[e] = glob_E[e] = 0.f; seen[e] = false; }
 
   auto scores = [&](const f32x16& z, float (&c)[NE]) {
-    if (G == 4) {
+    if constexpr (G == 4) {
       uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
       uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
       swap_halves(A0, A2);
@@ -204,18 +214,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
     }
   };
-  // max / sum over the lanes of a half-wave that own a view (single-point tiles)
-  auto half_max = [&](float v) {
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-  };
-  auto half_sum = [&](float v) {
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
-    return v;
-  };
-
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
@@ -225,9 +223,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     float4 x;
     int vpj, rij;
   };
-  run_tiles<Pre>(ta, tb, [&](int t) {
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
-    p.ti = get_tile(tiles, t);
+    p.ti = ti;
     p.t = t;
     const bool ok = j < p.ti.nv;
     p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
@@ -258,13 +256,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     const f32x16 zero = {0};
     float c[NE];
     scores(mm32_lds(s_ops, OP_WS, lane, k.a6, zero), c);
-    const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
-    int n_pt = sg.se - sg.ss + 1;
-    if (frag != 0) {
-      const int64_t pt = __builtin_amdgcn_readfirstlane(p.vpj);
-      n_pt = (int)(ptr[pt + 1] - ptr[pt]);
+    const int vp0 = __builtin_amdgcn_readfirstlane(p.vpj);
+    const bool single = frag != 0 || __ballot(ok && p.vpj != vp0) == 0;     // one point in the tile
+    SegInfo sg;
+    if (single) {
+      sg.ss = 0;
+      sg.se = nv - 1;
+    } else {
+      sg = seg_setup(p.vpj, j, lane, nv);
     }
+    int n_pt = sg.se - sg.ss + 1;
+    if (frag != 0) n_pt = (int)(ptr[vp0 + 1] - ptr[vp0]);
     const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
+    auto red_max = [&](float v) { return single ? half_max(v) : seg_total(seg_scan_max(v, sg, lane), sg, h); };
+    auto red_sum = [&](float v) { return single ? half_sum(v) : seg_total(seg_scan_sum(v, sg, lane), sg, h); };
     if (frag == 1) {
       // ---- long point: softmax statistics over ALL its fragments first (scores only), and
       //      E = sum_v a q from the saved forward output: E_g = sum_{ch in g} gout out / gate
@@ -294,13 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       const uint32_t pid0 = (uint32_t)__builtin_amdgcn_readfirstlane(p.vpj);
       const u32x4 go0 = ld128(GO, pid0 * (uint32_t)(C * 2) + (uint32_t)q * 16u);
       const u32x4 ou0 = ld128(OU, pid0 * (uint32_t)(C * 2) + (uint32_t)q * 16u);
-      const uint32_t ga[4] = {go0.x, go0.y, go0.z, go0.w}, oa[4] = {ou0.x, ou0.y, ou0.z, ou0.w};
-      float d = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        d = __builtin_fmaf(__uint_as_float(ga[i] << 16), __uint_as_float(oa[i] << 16), d);
-        d = __builtin_fmaf(__uint_as_float(ga[i] & 0xffff0000u), __uint_as_float(oa[i] & 0xffff0000u), d);
-      }
+      float d = dot8(go0, ou0);
 #pragma unroll
       for (int off = 1; off < LPG; off <<= 1) d += __shfl_xor(d, off);
       if (slot == 0 && (q % LPG) == 0) s_E[wv][tg] = d;
@@ -319,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     for (int e = 0; e < NE; ++e) {
       float s;
       if (frag == 0) {
-        m[e] = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
+        m[e] = red_max(ok ? c[e] : -INFINITY);
         const float ev = ok ? __expf((c[e] - m[e]) * isn) : 0.f;
-        s = seg_total(seg_scan_sum(ev, sg, lane), sg, h);
+        s = red_sum(ev);
         a[e] = ev * __builtin_amdgcn_rcpf(s + eps);
       } else {
         m[e] = glob_m[e];
@@ -337,14 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk) {
         const int vt = sv0 + b * KB + kk;
-        const u32x4 r = xr[b & 1][kk], g4 = go[b & 1][kk];
-        const uint32_t rw[4] = {r.x, r.y, r.z, r.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
-        float d = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          d = __builtin_fmaf(__uint_as_float(gg[i] << 16), __uint_as_float(rw[i] << 16), d);
-          d = __builtin_fmaf(__uint_as_float(gg[i] & 0xffff0000u), __uint_as_float(rw[i] & 0xffff0000u), d);
-        }
+        float d = dot8(go[b & 1][kk], xr[b & 1][kk]);
 #pragma unroll
         for (int off = 1; off < LPG; off <<= 1) d += __shfl_xor(d, off);
         if ((q % LPG) == 0) q_t[tg * 32 + vt] = d;
@@ -357,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     for (int e = 0; e < NE; ++e) {
       const float qv = q_t[gl[e] * 32 + j];
       float E;
-      if (frag == 0) E = seg_total(seg_scan_sum(a[e] * qv, sg, lane), sg, h);
+      if (frag == 0) E = red_sum(a[e] * qv);
       else E = glob_E[e];
       const float dpre = (gw && pre[e] > 0.f) ? E * (1.f - gt[e] * gt[e]) : 0.f;
       // first view of the point that attains the maximum (ties -> lowest index, like segment_csr 'max')
@@ -479,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
     float4 x, dc;
     int vpj;
   };
-  run_tiles<Pre>(t0, t1, [&](int t) {
+  run_tiles<Pre>(tiles, t0, t1, [&](const TileInfo& ti, int t) {
     Pre p;
-    p.ti = get_tile(tiles, t);
+    p.ti = ti;
     const bool ok = j < p.ti.nv;
     p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
@@ -503,19 +495,20 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       }
     }
     ChainKeep k;
-    chain_forward(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
     const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
     float dz[16], unused_st[2][16];
     // ---- layer 6
     const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
     layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
     bf16x8 dzp[2];
-    pack16(dz, dzp);
+    pack16(dz, keep, dzp);
     const f32x16 zero = {0};
     if (STAGE == 6) {
       tileT_put_packed(ta, j, h, dzp);
-      tileT_put_packed(tb_, j, h, k.a5);
-      tileT_put_packed(tc, j, h, k.a6);
+      { bf16x8 t5[2] = {mask8(k.a5[0], keep), mask8(k.a5[1], keep)}, t6[2] = {mask8(k.a6[0], keep), mask8(k.a6[1], keep)};
+        tileT_put_packed(tb_, j, h, t5);
+        tileT_put_packed(tc, j, h, t6); }
       if (h == 0) {
         const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
         td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
@@ -537,10 +530,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
     }
     // ---- layer 5
     layer_bwd<false, true>(k.z5, da5, s_tab[2], h, ok, unused_st, dz);
-    pack16(dz, dzp);
+    pack16(dz, keep, dzp);
     if (STAGE == 5) {
       tileT_put_packed(ta, j, h, dzp);
-      tileT_put_packed(tb_, j, h, k.a2);
+      { bf16x8 t2[2] = {mask8(k.a2[0], keep), mask8(k.a2[1], keep)};
+        tileT_put_packed(tb_, j, h, t2); }
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
         *reinterpret_cast<float4*>(tz + j * TZB + 8 * qq + 4 * h) =
@@ -593,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       }
     }
     layer_bwd<false, true>(z2r, da2t, s_tab[1], h, ok, unused_st, dz);
-    pack16(dz, dzp);
+    pack16(dz, keep, dzp);
     tileT_put_packed(ta, j, h, dzp);
     tileT_put_packed(tb_, j, h, a1r);
     const f32x16 da1 = mm32_lds(s_ops, OP_W2T, lane, dzp, zero);

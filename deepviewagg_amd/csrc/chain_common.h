@@ -125,22 +125,54 @@ __device__ __forceinline__ void wave_tile_range(const int2* __restrict__ tiles, 
   if (ta > tb) ta = tb;
 }
 
+// Tile descriptors of 64 consecutive tiles in one register pair (lane i <-> tile base + i): the per-tile
+// descriptor is two v_readlane instead of a dependent global load in front of every prefetch (measured: that load
+// was a full memory latency per tile on the critical path).
+struct TileWindow {
+  int base;
+  int2 w;
+};
+__device__ __forceinline__ TileInfo window_tile(TileWindow& tw, const int2* __restrict__ tiles, int t, int last,
+                                                int lane) {
+  if (t - tw.base >= 64 || t < tw.base) {      // uniform
+    tw.base = t;
+    const int i = t + lane;
+    tw.w = tiles[i < last ? i : last];
+  }
+  const int idx = t - tw.base;
+  TileInfo ti;
+  ti.v0 = __builtin_amdgcn_readlane(tw.w.x, idx);
+  const int m = __builtin_amdgcn_readlane(tw.w.y, idx);
+  ti.nv = m & 0xff;
+  ti.frag = m >> 8;
+  return ti;
+}
+
 // Software-pipelined loop over the tiles [ta, tb): the loads of tile t + 1 are in flight while tile t is
 // computed; two register sets in ping-pong (a rotating copy would wait for the prefetch it has just issued).
+// load(TileInfo, t) issues the loads of a tile, body(pre) computes it.
 template <typename Pre, typename LoadF, typename BodyF>
-__device__ __forceinline__ void run_tiles(int ta, int tb, LoadF&& load, BodyF&& body) {
+__device__ __forceinline__ void run_tiles(const int2* __restrict__ tiles, int ta, int tb, LoadF&& load,
+                                          BodyF&& body) {
   if (ta >= tb) return;
+  const int lane = threadIdx.x & 63;
   const int last = tb - 1;
-  Pre a = load(ta);
+  TileWindow tw;
+  tw.base = ta - 64;
+  auto ld = [&](int t) {
+    const int tt = t < tb ? t : last;
+    return load(window_tile(tw, tiles, tt, last, lane), tt);
+  };
+  Pre a = ld(ta);
   int t = ta + 1;
-  Pre b = load(t < tb ? t : last);
+  Pre b = ld(t);
   body(a);
   while (t < tb) {
-    a = load(t + 1 < tb ? t + 1 : last);
+    a = ld(t + 1);
     body(b);
     ++t;
     if (t >= tb) break;
-    b = load(t + 1 < tb ? t + 1 : last);
+    b = ld(t + 1);
     body(a);
     ++t;
   }
@@ -347,6 +379,29 @@ __device__ __forceinline__ float seg_scan_sum(float v, const SegInfo& s, int lan
 // value of the segment's last lane, in every lane of the segment
 __device__ __forceinline__ float seg_total(float scanned, const SegInfo& s, int h) {
   return shfl(scanned, 32 * h + s.se);
+}
+
+// all-reduce over the 32 lanes of a half-wave without the LDS crossbar: quad_perm xor 1 / xor 2, row_half_mirror,
+// row_mirror (DPP, folded into the VALU operation), then v_permlane16_swap for the two rows of the half
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+template <typename Op>
+__device__ __forceinline__ float half_allreduce(float v, Op op) {
+  v = op(v, dpp_mov<0xB1>(v));    // quad_perm [1, 0, 3, 2]
+  v = op(v, dpp_mov<0x4E>(v));    // quad_perm [2, 3, 0, 1]
+  v = op(v, dpp_mov<0x141>(v));   // row_half_mirror
+  v = op(v, dpp_mov<0x140>(v));   // row_mirror
+  const uint32_t x = __float_as_uint(v);
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return op(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float half_max(float v) {
+  return half_allreduce(v, [](float a, float b) { return fmaxf(a, b); });
+}
+__device__ __forceinline__ float half_sum(float v) {
+  return half_allreduce(v, [](float a, float b) { return a + b; });
 }
 
 // tanh for x >= 0 (the gate is tanh(relu(.))): odd polynomial below 0.1, (e^2x - 1) / (e^2x + 1) above

@@ -167,7 +167,7 @@ __global__ void stats1_kernel(const double* __restrict__ mom, const float* __res
 // sign of gamma2, so the set pooling max_v a2 is taken on sign(gamma2) * z2 BEFORE the statistics exist.
 // ------------------------------------------------------------------------------------------------
 constexpr int TZ = 36;  // fp32 tile row stride (floats)
-__global__ __launch_bounds__(256, 2) void stats2_kernel(
+__global__ __launch_bounds__(256, 3) void stats2_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
     const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops, const float* __restrict__ bn1,
     const float* __restrict__ gamma2, double* __restrict__ stats, float* __restrict__ zstar,
@@ -196,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void stats2_kernel(
     float4 x;
     int vpj;
   };
-  run_tiles<Pre>(ta, tb, [&](int t) {
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
-    p.ti = get_tile(tiles, t);
+    p.ti = ti;
     const bool ok = j < p.ti.nv;
     p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void pooled_kernel(const float* __restrict__ z
 // statistics of layer 5 (z5 = W5a a2 + u[point]) or layer 6 (train mode)
 // ------------------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256, 2) void stats_mid_kernel(
+__global__ __launch_bounds__(256, 3) void stats_mid_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256, 2) void stats_mid_kernel(
     float4 x;
     int vpj;
   };
-  run_tiles<Pre>(ta, tb, [&](int t) {
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
-    p.ti = get_tile(tiles, t);
+    p.ti = ti;
     const bool ok = j < p.ti.nv;
     p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void stats_mid_kernel(
 // [ROWS][C] LDS buffer keyed by the slot it starts in (each slot starts at most one split point) and stored by
 // the slot it ends in.
 template <int LPR, int G>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -368,23 +368,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr int KB = KV < 8 ? KV : 8, NB = KV / KB;
   constexpr int NE = G == 1 ? 1 : 2;           // score values per lane on the softmax side
+  constexpr bool RS = LPR == 8;                // reduce-scatter epilogue of single-point tiles (C = 64)
   static_assert(LPR % G == 0, "whole 16-byte lanes per channel group");
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[N_OPS * 64];
   __shared__ __attribute__((aligned(16))) float s_ev[4][4 * 32];     // exp(.) per [group][view]
   __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][view]
   __shared__ __attribute__((aligned(16))) int s_ss[4][32], s_se[4][32], s_pid[4][32], s_ri[4][32];
-  __shared__ __attribute__((aligned(16))) float s_alpha[4][4];
+  __shared__ __attribute__((aligned(16))) float s_alpha[4][4], s_scg[4][4];
   __shared__ __attribute__((aligned(16))) float s_acc[4][ROWS * C];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  stage_ops(s_ops, ops);
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, nullptr);
   stage_tab(s_tab[2], bn5, nullptr);
   stage_tab(s_tab[3], bn6, nullptr);
   for (int i = threadIdx.x; i < 4 * ROWS * C; i += blockDim.x) (&s_acc[0][0])[i] = 0.f;
   __syncthreads();
-  const bf16x8 w1 = load_op(ops, OP_W1, lane);
-  const WOp w2 = load_wop(ops, OP_W2, lane), w5 = load_wop(ops, OP_W5, lane), w6 = load_wop(ops, OP_W6, lane),
-            wsc = load_wop(ops, OP_WS, lane);
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
                                RW = make_rsrc(rows, (uint64_t)R * C * 2), O = make_rsrc(out, (uint64_t)N * C * 2);
@@ -403,6 +403,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   // team side
   const int slot = lane / LPR, q = lane % LPR, sv0 = slot * KV;
   const int tg = q / (LPR / G);
+  // reduce-scatter epilogue (LPR == 8): the channel of the chunk this lane ends up with
+  const int rs_ch = 4 * (1 - ((lane >> 5) & 1)) + 2 * (1 - ((lane >> 4) & 1)) + (1 - ((lane >> 3) & 1));
   float* ev_t = s_ev[wv];
   float* sc_t = s_sc[wv];
   int* ss_t = s_ss[wv];
@@ -425,9 +427,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     float4 x;
     int vpj, rij;
   };
-  run_tiles<Pre>(ta, tb, [&](int t) {
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
-    p.ti = get_tile(tiles, t);
+    p.ti = ti;
     const bool ok = j < p.ti.nv;
     p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
@@ -458,17 +460,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const f32x16 zero = {0};
     const uint32_t keep = 0xffffffffu;
     bf16x8 a[2], a2[2];
-    f32x16 z = CH_MFMA(w1, pack_x(p.x), zero);
+    asm volatile("" ::: "memory");
+    f32x16 z = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
     act_pack(z, s_tab[0], h, keep, a);
-    z = mm32(w2, a, zero);
+    z = mm32_lds(s_ops, OP_W2, lane, a, zero);
     act_pack(z, s_tab[1], h, keep, a2);
-    z = mm32(w5, a2, uacc);
+    z = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
     act_pack(z, s_tab[2], h, keep, a);
-    z = mm32(w6, a, zero);
+    z = mm32_lds(s_ops, OP_W6, lane, a, zero);
     act_pack(z, s_tab[3], h, keep, a2);
-    z = mm32(wsc, a2, zero);
+    z = mm32_lds(s_ops, OP_WS, lane, a2, zero);
     float c[NE];
-    if (G == 4) {
+    if constexpr (G == 4) {
       uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
       uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
       swap_halves(A0, A2);   // A0: h = 0 -> group 0, h = 1 -> group 2
@@ -479,80 +482,144 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 #pragma unroll
       for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
     }
-    // ---- softmax over the views of each point
-    const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
-    const bool multi = frag == 0 && sg.nseg > 1;
-    int n_pt = sg.se - sg.ss + 1;
-    if (frag != 0) {
-      const int64_t pt = __builtin_amdgcn_readfirstlane(p.vpj);
-      n_pt = (int)(ptr[pt + 1] - ptr[pt]);
-    }
-    const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
-    float ev[NE], sc[NE], alpha[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      float m = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
-      alpha[e] = 0.f;
-      if (frag != 0) {           // uniform: online softmax across the fragments of a long point
-        const float m_new = fmaxf(run_m[e], m);
-        alpha[e] = __expf((run_m[e] - m_new) * isn);   // frag 1: run_m = -inf -> 0
-        m = m_new;
-      }
-      ev[e] = ok ? __expf((c[e] - m) * isn) : 0.f;
-      float s = seg_total(seg_scan_sum(ev[e], sg, lane), sg, h);
-      if (frag != 0) {
-        s = run_s[e] * alpha[e] + s;
-        run_s[e] = s;
-        run_m[e] = m;
-      }
-      const float gt = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
-      sc[e] = gt * __builtin_amdgcn_rcpf(s + eps);
-    }
-    if (frag == 3) {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) { run_m[e] = -INFINITY; run_s[e] = 0.f; }
-    }
-    if (s_active) {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        ev_t[gl[e] * 32 + j] = ev[e];
-        sc_t[gl[e] * 32 + j] = sc[e];
-        if (j == 0) s_alpha[wv][gl[e]] = alpha[e];
-      }
-    }
-    if (h == 0) {
-      ss_t[j] = ok ? sg.ss : 64 + j;
-      se_t[j] = sg.se;
-      pid_t[j] = p.vpj;
-    }
-    wave_sync();
-    // ---- value rows: weighted sum
+    const int vp0 = __builtin_amdgcn_readfirstlane(p.vpj);
+    const bool single = frag != 0 || __ballot(ok && p.vpj != vp0) == 0;
+    // the value-row accumulation of one lane (weights from the LDS table of the tile)
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    bool pend = false;
-    int pend_slot = 0, pend_view = 0;
+    auto fma_row = [&](const u32x4& r, float w) {
+      const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b + 1 < NB) issue_rows(b + 1);
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = __builtin_fmaf(w, __uint_as_float(rw[i] << 16), acc[2 * i]);
+        acc[2 * i + 1] = __builtin_fmaf(w, __uint_as_float(rw[i] & 0xffff0000u), acc[2 * i + 1]);
+      }
+    };
+    if (single) {
+      // ================= one point in the tile (32-views-per-point scenes, fragments of long points) ==========
+      int n_pt = nv;
+      if (frag != 0) n_pt = (int)(ptr[vp0 + 1] - ptr[vp0]);
+      const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
 #pragma unroll
-      for (int kk = 0; kk < KB; ++kk) {
-        const int k = b * KB + kk, vt = sv0 + k;
-        const float w = ev_t[tg * 32 + vt];
-        const u32x4 r = xr[b & 1][kk];
-        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+      for (int e = 0; e < NE; ++e) {
+        float m = half_max(ok ? c[e] : -INFINITY);
+        float alpha = 0.f;
+        if (frag != 0) {           // online softmax across the fragments
+          const float m_new = fmaxf(run_m[e], m);
+          alpha = __expf((run_m[e] - m_new) * isn);   // first fragment: run_m = -inf -> 0
+          m = m_new;
+        }
+        const float ev = ok ? __expf((c[e] - m) * isn) : 0.f;
+        float s = half_sum(ev);
+        if (frag != 0) {
+          s = run_s[e] * alpha + s;
+          run_s[e] = frag == 3 ? 0.f : s;
+          run_m[e] = frag == 3 ? -INFINITY : m;
+        }
+        const float gt = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+        if (s_active) {
+          ev_t[gl[e] * 32 + j] = ev;
+          if (j == 0) {
+            s_scg[wv][gl[e]] = gt * __builtin_amdgcn_rcpf(s + eps);
+            s_alpha[wv][gl[e]] = alpha;
+          }
+        }
+      }
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) issue_rows(b + 1);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) fma_row(xr[b & 1][kk], ev_t[tg * 32 + sv0 + b * KB + kk]);
+      }
+      const float sc = s_scg[wv][tg], al = s_alpha[wv][tg];
+      const bool done = frag == 0 || frag == 3;
+      if (RS) {
+        // reduce-scatter over the 8 row slots: each level halves the channels a lane carries (the row swaps
+        // exchange and the add reduces); the lane ends with channel rs_ch of its 8-channel chunk
+        float v4[4], v2[2], v1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc[2 * i] = __builtin_fmaf(w, __uint_as_float(rw[i] << 16), acc[2 * i]);
-          acc[2 * i + 1] = __builtin_fmaf(w, __uint_as_float(rw[i] & 0xffff0000u), acc[2 * i + 1]);
+          uint32_t x = __float_as_uint(acc[4 + i]), y = __float_as_uint(acc[i]);
+          swap_halves(x, y);                                   // lanes [32, 64) of x <-> lanes [0, 32) of y
+          v4[i] = __uint_as_float(x) + __uint_as_float(y);     // h = 0: channel 4 + i, h = 1: channel i
         }
-        if (multi) {   // uniform
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v4[2 + i]), __float_as_uint(v4[i]), false, false);
+          v2[i] = __uint_as_float(r.x) + __uint_as_float(r.y);  // even row: sub-channel 2 + i, odd row: i
+        }
+        {
+          const bool up = (lane >> 3) & 1;
+          const float mine = up ? v2[0] : v2[1], send = up ? v2[1] : v2[0];
+          v1 = mine + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(send), 0x128,
+                                                                            0xf, 0xf, false));   // row_ror:8
+        }
+        if (frag != 0) {
+          v1 = __builtin_fmaf(run_acc[0], al, v1);
+          run_acc[0] = frag == 3 ? 0.f : v1;
+        }
+        if (done)
+          __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(v1 * sc), O,
+                                                (int)((uint32_t)vp0 * (uint32_t)(C * 2) + (uint32_t)(q * 8 + rs_ch) * 2u),
+                                                0, 0);
+      } else {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off);
+        }
+        if (frag != 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_fmaf(run_acc[i], al, acc[i]);
+            run_acc[i] = frag == 3 ? 0.f : acc[i];
+          }
+        }
+        if (done) {
+          const u32x4 o = {pack_bf16x2(acc[0] * sc, acc[1] * sc), pack_bf16x2(acc[2] * sc, acc[3] * sc),
+                           pack_bf16x2(acc[4] * sc, acc[5] * sc), pack_bf16x2(acc[6] * sc, acc[7] * sc)};
+          st128(O, slot == 0 ? (uint32_t)vp0 * (uint32_t)(C * 2) + (uint32_t)q * 16u : OOB, o);
+        }
+      }
+    } else {
+      // ================= several points in the tile ==============================================================
+      const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
+      const float isn = scaling ? __builtin_amdgcn_rsqf((float)(sg.se - sg.ss + 1)) : 1.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const float m = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
+        const float ev = ok ? __expf((c[e] - m) * isn) : 0.f;
+        const float s = seg_total(seg_scan_sum(ev, sg, lane), sg, h);
+        const float gt = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+        if (s_active) {
+          ev_t[gl[e] * 32 + j] = ev;
+          sc_t[gl[e] * 32 + j] = gt * __builtin_amdgcn_rcpf(s + eps);
+        }
+      }
+      if (h == 0) {
+        ss_t[j] = ok ? sg.ss : 64 + j;
+        se_t[j] = sg.se;
+        pid_t[j] = p.vpj;
+      }
+      wave_sync();
+      bool pend = false;
+      int pend_slot = 0, pend_view = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) issue_rows(b + 1);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          const int k = b * KB + kk, vt = sv0 + k;
+          fma_row(xr[b & 1][kk], ev_t[tg * 32 + vt]);
           const int ssk = ss_t[vt];
           const bool last = (k == KV - 1) || (ss_t[vt + 1] != ssk);
           if (last) {
             if (vt < nv) {
               const int sek = se_t[vt];
               if (ssk >= sv0 && sek < sv0 + KV) {
+                // the point lies inside this slot: store it
                 const float s = sc_t[tg * 32 + vt];
                 const u32x4 o = {pack_bf16x2(acc[0] * s, acc[1] * s), pack_bf16x2(acc[2] * s, acc[3] * s),
                                  pack_bf16x2(acc[4] * s, acc[5] * s), pack_bf16x2(acc[6] * s, acc[7] * s)};
@@ -573,8 +640,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
           }
         }
       }
-    }
-    if (multi) {
       wave_sync();
       if (pend) {
         float* src = acc_t + pend_slot * C + q * 8;
@@ -585,27 +650,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         const u32x4 o = {pack_bf16x2(lo.x * s, lo.y * s), pack_bf16x2(lo.z * s, lo.w * s),
                          pack_bf16x2(hi.x * s, hi.y * s), pack_bf16x2(hi.z * s, hi.w * s)};
         st128(O, (uint32_t)pid_t[pend_view] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
-      }
-    } else {
-      // one point in the tile: butterfly over the row slots
-#pragma unroll
-      for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off);
-      }
-      if (frag != 0) {
-        const float al = s_alpha[wv][tg];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc[i] = __builtin_fmaf(run_acc[i], al, acc[i]);
-          run_acc[i] = frag == 3 ? 0.f : acc[i];
-        }
-      }
-      if ((frag == 0 || frag == 3) && nv > 0) {
-        const float s = sc_t[tg * 32];
-        const u32x4 o = {pack_bf16x2(acc[0] * s, acc[1] * s), pack_bf16x2(acc[2] * s, acc[3] * s),
-                         pack_bf16x2(acc[4] * s, acc[5] * s), pack_bf16x2(acc[6] * s, acc[7] * s)};
-        st128(O, slot == 0 ? (uint32_t)pid_t[0] * (uint32_t)(C * 2) + (uint32_t)q * 16u : OOB, o);
       }
     }
     wave_sync();
@@ -675,7 +719,7 @@ int dva_chain_stats2(const float* x_map, const int32_t* view_point, const void* 
   if (!x_map || !view_point || !tiles || !n_tiles || !ops || !bn1 || !gamma2 || !stats || !zstar || !arg)
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(stats2_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map, view_point,
+  hipLaunchKernelGGL(stats2_kernel, dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map, view_point,
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, gamma2, stats, zstar, arg, n_views);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
@@ -702,7 +746,7 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
       (layer == 6 && !bn5))
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(2)), block(256);
+  const dim3 grid(chain_grid(3)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layer == 5)
     hipLaunchKernelGGL((stats_mid_kernel<5>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
@@ -728,7 +772,7 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
       n_points * C * 2 > 0xfffffff0ll)
     return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(2)), block(256);
+  const dim3 grid(chain_grid(3)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_ATTN_FWD(LPR_, G_)                                                                                  \
   hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, \

@@ -1,10 +1,12 @@
-#!/usr/bin/env python
-"""Print the per-kernel table of a bench.py JSON line: python tools/show_bench.py <file>."""
-import json
-import sys
-
-d = json.load(open(sys.argv[1]))
-print(f"{d['ms_per_step']:.2f} ms/step   {d['value'] / 1e6:.2f} M {d['unit']}   roofline {d['roofline']['kernel']} "
-      f"frac={d['roofline']['frac']:.3f}")
+"""Pretty-print the bench JSON line (kernel table)."""
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("ms/step", round(d["ms_per_step"], 3), " value", round(d["value"] / 1e6, 2), "M points/s")
+tot = 0
 for k, v in d["kernels"].items():
-    print(f"{k:34s} {v['avg_ms']:8.3f} ms x{v['launches']:<3d} {v['GBps']:8.0f} GB/s")
+    tot += v["avg_ms"] * v["launches"] / d["steps"]
+    print(f"{k:32s} {v['avg_ms']:.3f} ms  {v['GBps']:7.0f} GB/s  x{v['launches'] / d['steps']:.0f}/step")
+print("sum of timed kernels per step:", round(tot, 3), "ms")
+for k in ("roofline", "roofline_view_gather_attention"):
+    if k in d:
+        print(k, {a: d[k][a] for a in ("kernel", "frac", "avg_launch_ms") if a in d[k]})
