@@ -39,11 +39,19 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-points", type=int, default=15)
+    ap.add_argument("--cpu-log2-points", type=int, default=14)
     ap.add_argument("--no-mapping-build", action="store_true")
     ap.add_argument("--materialize", action="store_true",
                     help="diagnostic: materialised [V, C] gather + per-view E_mod (the reference's dataflow) instead "
                          "of the lazy gather / hoisted E_mod")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S2 / F-L secondary workloads")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: ONE scene of 2^log2-points points split into WORLD_SIZE spatial tiles "
+                         "(parallel.tile_partition), each rank pools its tile (default: one scene per rank = weak)")
+    ap.add_argument("--standin-mb", type=float, default=112.0,
+                    help="N > 1: size (MB, fp32) of the stand-in gradient bucket for the parts of the model outside "
+                         "the path (2D encoder + 3D backbone, SURVEY.md 8(e): 28.1 M parameters = 112 MB), "
+                         "all-reduced on a side stream under the backward of every step; 0 disables")
     ap.add_argument("--workload", default="S1", choices=["S1", "S2", "S1c"],
                     help="S1: every point seen by --views images (headline); S2: ragged view counts "
                          "min(views, 1 + Geom(0.2)), 10 %% of the points unseen (SURVEY.md 8(d))")
@@ -108,19 +116,16 @@ def build_modules(C, device):
 
 # HIP-event timer name -> kernel symbol in the rocprofv3 outputs (bf16 headline workload)
 KERNEL_SYMBOL = {
-    "view_gather_attention_fwd": "att_fwd_team_kernel<unsigned short, 8, 8>",
-    "view_gather_attention_bwd": "att_bwd_team_kernel<unsigned short, 8, 8>",
+    "chain_attn_fwd": "chain::attn_fwd_kernel<8, 4>",
+    "chain_attn_bwd": "chain::attn_bwd_kernel<8, 4>",
+    "chain_bwd_l6": "chain::layer_bwd_kernel<6>",
+    "chain_bwd_l5": "chain::layer_bwd_kernel<5>",
+    "chain_bwd_l2": "chain::layer_bwd_kernel<2>",
+    "chain_stats2": "chain::stats2_kernel",
+    "chain_stats5": "chain::stats_mid_kernel<5>",
+    "chain_stats6": "chain::stats_mid_kernel<6>",
+    "chain_moments": "chain::moments_kernel",
     "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short>",
-    "deepset_fwd_first": "dsm_fwd_first_kernel<unsigned short, false>",
-    "deepset_fwd_layer": "dsm_fwd_layer_kernel<unsigned short, false, false, true, false>",
-    "deepset_fwd_layer_add": "dsm_fwd_layer_kernel<unsigned short, true, false, true, false>",
-    "deepset_fwd_score": "dsm_fwd_layer_kernel<unsigned short, false, true, true, false>",
-    "deepset_segmax": "dsf_segmax_kernel<unsigned short>",
-    "deepset_bwd_score": "dsm_bwd_score_kernel<unsigned short, false>",
-    "deepset_bwd_layer": "dsm_bwd_layer_kernel<unsigned short, false, false, false, false, false>",
-    "deepset_bwd_layer_cat": "dsm_bwd_layer_kernel<unsigned short, false, true, true, false, false>",
-    "deepset_bwd_layer_xmap_first": "dsm_bwd_layer_kernel<unsigned short, true, false, false, true, false>",
-    "deepset_bwd_max": "dsm_bwd_max_kernel<unsigned short>",
 }
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 
@@ -137,7 +142,7 @@ def pmc_traffic(timer_name, default_workload):
     return None if entry is None else entry["hbm_bytes"]
 
 
-def step(scene, packed, mods, dtype, lazy=True):
+def step(scene, packed, mods, dtype, lazy=True, before_backward=None):
     """One fused forward + backward of the hot path (metric M1 of SURVEY.md 8(d): gather -> atomic pool -> view
     attention pool -> fusion-concat).  The backward is seeded with a fixed upstream gradient [N, 4 + C] resident in
     HBM -- what the 3D backbone hands back -- so that no loss kernels sit inside the timed region.  Returns the
@@ -163,6 +168,8 @@ def step(scene, packed, mods, dtype, lazy=True):
     if scene.get("grad_out") is None or scene["grad_out"].shape != out.shape:
         scene["grad_out"] = torch.randn(out.shape, device=out.device, dtype=out.dtype,
                                         generator=torch.Generator(device=out.device).manual_seed(99)) / out.shape[0]
+    if before_backward is not None:
+        before_backward()        # N > 1: the stand-in bucket's all-reduce starts on its side stream here
     out.backward(scene["grad_out"])
     return out.detach()
 
@@ -196,7 +203,9 @@ def cpu_baseline(log2_points, views, C, threads):
     for _ in range(reps):
         one()
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=n / dt, unit="points/s", cores=threads, kind="port",
+    return dict(value=n / dt, unit="points/s", cores=torch.get_num_threads(), cores_effective=1, kind="port",
+                note="PyTorch-CPU restatement: bound by per-op dispatch and single-threaded index / segment ops (the "
+                     "same rate on 8 and on 64 host threads), NOT a tuned multi-core implementation",
                 sample=f"oracle/pooling_oracle.py (PyTorch CPU fp32), N=2^{log2_points} points x {views} views, "
                        f"C={C}, {reps} fwd+bwd steps, {dt:.2f} s/step")
 
@@ -234,23 +243,105 @@ def mapping_build_bench(device, n_images=4, n_points=200_000):
     exact = bool(np.array_equal(outs[0]["idx"].cpu().numpy(), ref["idx"])
                  and np.array_equal(outs[0]["x"].cpu().numpy(), ref["x"])
                  and np.array_equal(outs[0]["y"].cpu().numpy(), ref["y"]))
-    return {"images_per_s": 1.0 / gpu_s, "ms_per_image": gpu_s * 1e3, "candidates_per_image": n_points,
+    # SURVEY.md 8(d) bytes per image: n 12 B of xyz read + W_p H_p 12 B of z-buffer / pixel map cleared and scanned
+    # (+ 8 B per covered splat pixel, not counted here: lower bound) -> fraction of the HBM peak; the build is bound
+    # by 64-bit atomics on a cache-resident map and by launch latency, not by bandwidth
+    lb = n_points * 12 + 2048 * 1024 * 12
+    return {"roofline": {"bound": "hbm", "algorithmic_bytes_lower_bound": lb, "achieved": lb / gpu_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lb / gpu_s / 1e9 / HBM_PEAK_GBS},
+            "images_per_s": 1.0 / gpu_s, "ms_per_image": gpu_s * 1e3, "candidates_per_image": n_points,
             "proj_map": [2048, 1024], "mapped_points_image0": int(ref["idx"].shape[0]),
             "cpu_oracle_ms_per_image_1core": cpu_s * 1e3, "indices_bit_exact_vs_oracle": exact}
 
 
 def copy_ceiling(device, nbytes=1 << 32, reps=5):
-    """Practical HBM ceiling: read + write rate of a plain device copy of `nbytes`."""
+    """Practical HBM ceiling: read + write rate of the library's float4 grid-stride copy kernel
+    (dva_copy_ceiling) over `nbytes`; MI355X_MICROARCH.md measures 6.29 TB/s for this pattern."""
+    from deepviewagg_amd import _lib
+    lib = _lib.load()
     src = torch.empty(nbytes, dtype=torch.uint8, device=device)
     dst = torch.empty_like(src)
-    dst.copy_(src)
+    st = _lib.stream_of(src)
+    _lib.check(lib.dva_copy_ceiling(_lib.ptr(src), _lib.ptr(dst), nbytes, st), "dva_copy_ceiling")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dst.copy_(src)
+        _lib.check(lib.dva_copy_ceiling(_lib.ptr(src), _lib.ptr(dst), nbytes, st), "dva_copy_ceiling")
     e1.record()
     torch.cuda.synchronize()
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def gather_bench(scene, reps=5):
+    """Metric M2 of SURVEY.md 8(d): the materialised nearest view gather (image.py:1285) at the scene's V --
+    GB/s on the algorithmic bytes  P (C s + idx) read + P C s written  (the fused path never runs this kernel)."""
+    from deepviewagg_amd import ops
+    x = scene["x"].detach()
+    packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
+    out = ops.gather_nearest(x, packed)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = ops.gather_nearest(x, packed)
+    e1.record()
+    torch.cuda.synchronize()
+    P, C = out.shape
+    nbytes = P * (2 * C * out.element_size() + 8)
+    ms = e0.elapsed_time(e1) / reps
+    del out
+    return {"GBps": nbytes / (ms * 1e-3) / 1e9, "ms": ms, "atoms": P, "bytes": nbytes}
+
+
+def timed_steps(scene, mods, dtype, steps, warmup, lazy=True):
+    """`steps` timed steps of one workload on the current device (secondary workloads; no collectives)."""
+    from deepviewagg_amd import ops
+    for _ in range(warmup):
+        step(scene, None, mods, dtype, lazy=lazy)
+    torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(scene, None, mods, dtype, lazy=lazy)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    timer, ops.TIMER = ops.TIMER, None
+    return ms, timer.summary()
+
+
+def fused_fwd_bytes(V, N, C, es):
+    """SURVEY.md 8(d) 'fused view-gather + attention' forward minimum: V (g C s + F_map 4 + idx) + N (C s + ptr),
+    g = 1 (nearest), idx = 8 bytes / view (here: view -> point index + row index), ptr = 8 bytes / point."""
+    return V * (C * es + 32 + 8) + N * (C * es + 8)
+
+
+def fused_bwd_bytes(V, N, C, es, G=4):
+    """Attention backward on the same accounting: per view the gathered row, the mapping features, the indices, the
+    score gradients [G] written and the 32-byte record of the rows-gradient pass; per point grad_out + out rows."""
+    return V * (C * es + 32 + 8 + 4 * G + 32) + N * (2 * C * es + 8)
+
+
+def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warmup=1):
+    """One secondary workload of SURVEY.md 8(d) (S2: ragged view counts; F-L: C = 512, value map > MALL):
+    ms/step and the roofline fractions of the fused view kernel (forward) and of the attention backward kernel."""
+    wl = "S2" if name == "S2" else "S1"
+    N = 1 << log2_points
+    scene = make_scene(N, views, 32, C, 64, 128, dtype, device, seed=4321, workload=wl)
+    mods = build_modules(C, device)
+    ms, kern = timed_steps(scene, mods, dtype, steps, warmup)
+    V = int(scene["x_map"].shape[0])
+    es = 2 if dtype == torch.bfloat16 else 4
+    out = {"points": N, "views": V, "channels": C, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3)}
+    for key, nbytes in (("chain_attn_fwd", fused_fwd_bytes(V, N, C, es)), ("chain_attn_bwd", fused_bwd_bytes(V, N, C, es))):
+        k = kern.get(key)
+        if k is not None:
+            t = k["ms"] / k["launches"]
+            out[key] = {"avg_launch_ms": t, "algorithmic_bytes": nbytes, "GBps": nbytes / (t * 1e-3) / 1e9,
+                        "frac_of_hbm_peak": nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:4]
+    out["top_kernels_ms"] = {n: v["ms"] / v["launches"] for n, v in top}
+    del scene, mods
+    torch.cuda.empty_cache()
+    return out
 
 
 def neighborhood_bench(device, n_points=1 << 20, k=50, n_images=32, views_per_point=8):
@@ -293,6 +384,23 @@ def neighborhood_bench(device, n_points=1 << 20, k=50, n_images=32, views_per_po
             "kth_distances_match_kdtree": same}
 
 
+def tile_of_scene(scene, rank, world):
+    """Strong scaling: the spatial tile `rank` of `world` of a scene (points by x-y slab of a synthetic raster,
+    the views of a point travel with the point, the feature maps are replicated: SURVEY.md 8(e))."""
+    from deepviewagg_amd.parallel import tile_partition, shard_mapping
+    N = scene["csr"].shape[0] - 1
+    side = int(round(N ** 0.5))
+    pid = torch.arange(N, device=scene["csr"].device)
+    xyz = torch.stack([(pid % side).float(), (pid // side).float(), torch.zeros_like(pid).float()], 1)
+    pts = tile_partition(xyz, world)[rank]
+    csr_t, views = shard_mapping(scene["csr"], pts)
+    out = dict(scene)
+    out.update(csr=csr_t, images=scene["images"][views], pixels=scene["pixels"][views].contiguous(),
+               atom_ptr=torch.arange(views.shape[0] + 1, dtype=torch.int64, device=views.device),
+               x_map=scene["x_map"][views].contiguous(), x_3d=scene["x_3d"][pts].contiguous())
+    return out
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE JSON line: everything else that may write to fd 1 (RCCL prints a version
@@ -318,12 +426,25 @@ def main():
     _lib.load()  # fail loudly if the HIP library is missing
 
     N, views, C, H, W = 1 << args.log2_points, args.views, args.channels, 64, 128
-    scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank, workload=args.workload)
+    if args.strong:
+        # the same scene on every rank (same seed), each rank keeps its tile
+        scene = tile_of_scene(make_scene(N, views, 32, C, H, W, dtype, device, seed=1234, workload=args.workload),
+                              rank, world)
+    else:
+        scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank, workload=args.workload)
     V_scene = int(scene["x_map"].shape[0])
+    N_rank = int(scene["csr"].shape[0] - 1)
     mods = build_modules(C, device)
     from deepviewagg_amd.parallel import GradientBucket
     bucket = GradientBucket(mods[1].parameters())
-    packed = None  # built inside every step
+    # stand-in for the gradients of the model parts outside the path (2D encoder, 3D backbone): all-reduced on a
+    # side stream, started when the backward of the path starts, awaited at the end of the step
+    standin = None
+    if use_dist and args.standin_mb > 0:
+        n_el = int(args.standin_mb * 1e6 / 4)
+        sp = torch.nn.Parameter(torch.zeros(n_el, device=device))
+        sp.grad = torch.full((n_el,), 1e-3, device=device)
+        standin = GradientBucket([sp], bucket_bytes=32 << 20)
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,15 +452,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(scene, packed, mods, dtype, lazy=not args.materialize)
+    def one_step():
+        fused = step(scene, None, mods, dtype, lazy=not args.materialize,
+                     before_backward=(lambda: standin.start(average=True)) if standin is not None else None)
         bucket.reduce(average=True)
+        if standin is not None:
+            standin.finish()
+        return fused
+
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        fused = step(scene, packed, mods, dtype, lazy=not args.materialize)
-        bucket.reduce(average=True)
+        fused = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
@@ -351,61 +478,91 @@ def main():
     if rank == 0:
         kern = timer.summary()
         ms_per_step = elapsed / args.steps * 1e3
-        value = N * world * args.steps / elapsed
+        total_points = N if args.strong else N * world
+        value = total_points * args.steps / elapsed
+        es = 2 if dtype == torch.bfloat16 else 4
         # dominant HIP kernel of the path: the one with the largest total time in the timed region
         name, k = max(kern.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = k["ms"] / k["launches"]
         achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
-        gk = kern.get("gather_nearest_fwd")
         default_workload = (args.log2_points == 20 and args.dtype == "bf16" and args.workload == "S1"
-                            and args.channels == 64 and args.views == 32 and not args.materialize)
+                            and args.channels == 64 and args.views == 32 and not args.materialize
+                            and not args.strong)
         traffic = pmc_traffic(name, default_workload)
+        chain = "chain_attn_fwd" in kern
         res = {
             "metric": "points/sec fused fwd+bwd (1M pts, 32 views)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}/F-S: N=2^{args.log2_points} points x "
-                                   f"{views if args.workload != 'S2' else 'ragged <= ' + str(views)} views (V={V_scene}), "
+                                   f"{views if args.workload != 'S2' else 'ragged <= ' + str(views)} views (V={V_scene}"
+                                   f"{' on this rank' if args.strong else ''}), "
                                    f"32 feature maps [{C},{H},{W}] {args.dtype} channels-last, nearest gather -> "
                                    f"max atomic pool -> GroupBimodalCSRPool(G=4, DeepSetFeat, train) -> concat; backward seeded "
                                    f"with a fixed upstream gradient [N, 4+C]; "
-                                   f"one scene per GPU",
-                       "points_per_gpu": N, "views_per_point": views, "parallelism": f"dp{world}"},
+                                   + ("one scene split into WORLD_SIZE spatial tiles" if args.strong else "one scene per GPU"),
+                       "points_per_gpu": N_rank, "views_per_point": views, "parallelism": f"dp{world}",
+                       "gradient_allreduce": None if not use_dist else
+                       {"pooling_parameters_bytes": int(bucket.flat.numel() * 4),
+                        "standin_bucket_MB": args.standin_mb if standin is not None else 0,
+                        "note": "stand-in fp32 bucket = the 28.1 M parameters of the full model outside the path "
+                                "(SURVEY.md 8(e)); all-reduced (RCCL) on a side stream under the backward of every step"}},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": None if traffic is None else
                          "profiles/pmc_traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                         "command, bytes per launch, FETCH_SIZE x2 (gfx950 correction)",
+                         "command, bytes per launch, FETCH_SIZE x2 (gfx950 correction), KiB units calibrated on the "
+                         "copy kernel of the same run",
                          "avg_launch_ms": avg_ms, "launches": k["launches"],
-                         "algorithmic_bytes_per_launch": k["bytes"] / k["launches"]},
+                         "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
+                         "note": "the recompute passes read 32-52 bytes per view by design (no stored activations): "
+                                 "they are bound by VALU instruction issue, not by HBM or the matrix cores "
+                                 "(profiles/*sq_counters*); their time, not their HBM fraction, is what is left to cut"
+                                 if chain else None},
             "kernels": {n: {"avg_ms": v["ms"] / v["launches"], "launches": v["launches"],
                             "GBps": (v["bytes"] / v["launches"]) / (v["ms"] / v["launches"] * 1e-3) / 1e9}
                         for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
+            "step_algorithmic_GB": sum(v["bytes"] for v in kern.values()) / args.steps / 1e9,
             "hbm_copy_GBps": None,
-            "gather_GBps": None if gk is None else (gk["bytes"] / gk["launches"]) / (gk["ms"] / gk["launches"] * 1e-3) / 1e9,
+            "gather_GBps": None,
             "fused_abs_mean": float(fused.float().abs().mean().item()),
         }
-        if world == 1 and not args.no_mapping_build:
-            res["mapping_build"] = mapping_build_bench(device)
-        # practical ceiling next to the nominal one: a plain device copy in this process
+        res["step_algorithmic_GBps"] = res["step_algorithmic_GB"] / (ms_per_step * 1e-3)
+        # practical ceiling next to the nominal one: the float4 copy kernel in this process
         res["hbm_copy_GBps"] = copy_ceiling(device)
         res["roofline"]["copy_ceiling"] = res["hbm_copy_GBps"]
         res["roofline"]["frac_of_copy_ceiling"] = achieved / res["hbm_copy_GBps"]
         # the kernel the north star's >= 70 % target names: the fused view-gather + attention forward
-        tk = kern.get("view_gather_attention_fwd")
+        tname = "chain_attn_fwd" if chain else "view_gather_attention_fwd"
+        tk = kern.get(tname)
         if tk is not None:
             t_ms = tk["ms"] / tk["launches"]
-            t_ach = (tk["bytes"] / tk["launches"]) / (t_ms * 1e-3) / 1e9
+            nb = fused_fwd_bytes(V_scene, N_rank, C, es) if chain else tk["bytes"] / tk["launches"]
+            t_ach = nb / (t_ms * 1e-3) / 1e9
             res["roofline_view_gather_attention"] = {
-                "bound": "hbm", "kernel": "view_gather_attention_fwd", "achieved": t_ach, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": tname, "achieved": t_ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS, "avg_launch_ms": t_ms, "launches": tk["launches"],
-                "algorithmic_bytes_per_launch": tk["bytes"] / tk["launches"],
-                "traffic": pmc_traffic("view_gather_attention_fwd", default_workload),
-                "note": "algorithmic bytes count every gathered row as an HBM read (SURVEY.md 8(d)); the rows of "
-                        "this workload come out of a 33 MB map (cache hierarchy), see DESIGN.md"}
+                "algorithmic_bytes_per_launch": nb, "frac_of_copy_ceiling": t_ach / res["hbm_copy_GBps"],
+                "traffic": pmc_traffic(tname, default_workload),
+                "note": "x_map + value rows in -> pooled features out in ONE kernel (DeepSetFeat scores, softmax, row "
+                        "gather, weighted sum, gate); SURVEY.md 8(d) bytes V (C s + 32 + 8) + N (C s + 8), every "
+                        "gathered row counted as an HBM read although the rows of this workload come out of a 33 MB "
+                        "map (cache hierarchy); the kernel also reads 128 bytes per point (set-branch row)"}
         if world == 1 and not args.no_mapping_build:
+            # M2: the materialised nearest gather at the scene's V (outside the step timer)
+            g = gather_bench(scene)
+            res["gather_GBps"] = g["GBps"]
+            res["gather"] = g
+            res["mapping_build"] = mapping_build_bench(device)
             res["neighborhood_features"] = neighborhood_bench(device)
+        if world == 1 and not args.no_secondary and default_workload:
+            del scene
+            torch.cuda.empty_cache()
+            res["workloads"] = {
+                "S2": secondary_workload("S2", device, dtype, args.log2_points, views, 64),
+                "F-L": secondary_workload("F-L", device, dtype, args.log2_points, views, 512),
+            }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
         os.write(json_fd, (json.dumps(res) + "\n").encode())

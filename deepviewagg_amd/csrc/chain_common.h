@@ -253,6 +253,16 @@ __device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ 
   }
 }
 
+// forward-only variant: rows G | B
+__device__ __forceinline__ void stage_tab_fwd(float* tab, const float* __restrict__ bn) {
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const int c = chan(i & 15, i >> 4);
+    const float g = bn[2 * D + c] * bn[D + c];
+    tab[T_G * D + i] = g;
+    tab[T_B * D + i] = bn[3 * D + c] - bn[c] * g;
+  }
+}
+
 // y = z * G + B (BatchNorm), a = leaky(y), packed as the B operand of the next layer.  keep = 0 zeroes the
 // operand of a lane without a view.  The LDS reads stay inside the tile loop (asm barrier): hoisting 32
 // constants per layer into registers costs an occupancy step.

@@ -370,20 +370,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
   constexpr int NE = G == 1 ? 1 : 2;           // score values per lane on the softmax side
   constexpr bool RS = LPR == 8;                // reduce-scatter epilogue of single-point tiles (C = 64)
   static_assert(LPR % G == 0, "whole 16-byte lanes per channel group");
-  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) uint4 s_ops[N_OPS * 64];
+  __shared__ __attribute__((aligned(16))) float s_tab[4][2 * D];      // G | B rows only
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[OP_W6T * 64];   // forward operands only
   __shared__ __attribute__((aligned(16))) float s_ev[4][4 * 32];     // exp(.) per [group][view]
-  __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][view]
-  __shared__ __attribute__((aligned(16))) int s_ss[4][32], s_se[4][32], s_pid[4][32], s_ri[4][32];
+  __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][local point]
+  __shared__ __attribute__((aligned(16))) int s_pid[4][32], s_ri[4][32];
   __shared__ __attribute__((aligned(16))) float s_alpha[4][4], s_scg[4][4];
+  // several points per tile: one private row [C] per row slot for the partial sums of points split over slots
   __shared__ __attribute__((aligned(16))) float s_acc[4][ROWS * C];
+  __shared__ __attribute__((aligned(16))) int s_ss[4][32], s_se[4][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  stage_ops(s_ops, ops);
-  stage_tab(s_tab[0], bn1, nullptr);
-  stage_tab(s_tab[1], bn2, nullptr);
-  stage_tab(s_tab[2], bn5, nullptr);
-  stage_tab(s_tab[3], bn6, nullptr);
-  for (int i = threadIdx.x; i < 4 * ROWS * C; i += blockDim.x) (&s_acc[0][0])[i] = 0.f;
+  for (int i = threadIdx.x; i < OP_W6T * 64; i += blockDim.x) s_ops[i] = ops[i];
+  stage_tab_fwd(s_tab[0], bn1);
+  stage_tab_fwd(s_tab[1], bn2);
+  stage_tab_fwd(s_tab[2], bn5);
+  stage_tab_fwd(s_tab[3], bn6);
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
@@ -585,6 +586,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
       }
     } else {
       // ================= several points in the tile ==============================================================
+      // Every row slot accumulates runs of consecutive views of one point.  A run whose point lies inside the slot
+      // is scaled and stored directly.  A point spread over several slots: every slot but the last writes its
+      // partial sum to its private LDS row (plain stores: LDS float atomics cost 0.5 ms on the ragged workload),
+      // the slot the point ends in adds the rows of the slots before it and stores.
       const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
       const float isn = scaling ? __builtin_amdgcn_rsqf((float)(sg.se - sg.ss + 1)) : 1.f;
 #pragma unroll
@@ -604,8 +609,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
         pid_t[j] = p.vpj;
       }
       wave_sync();
-      bool pend = false;
-      int pend_slot = 0, pend_view = 0;
+      float hp[8];
+      bool has_head = false;
+      int head_view = 0, head_slot0 = 0;
+      float* mine = acc_t + slot * C + q * 8;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         if (b + 1 < NB) issue_rows(b + 1);
@@ -618,21 +625,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
           if (last) {
             if (vt < nv) {
               const int sek = se_t[vt];
-              if (ssk >= sv0 && sek < sv0 + KV) {
-                // the point lies inside this slot: store it
-                const float s = sc_t[tg * 32 + vt];
-                const u32x4 o = {pack_bf16x2(acc[0] * s, acc[1] * s), pack_bf16x2(acc[2] * s, acc[3] * s),
-                                 pack_bf16x2(acc[4] * s, acc[5] * s), pack_bf16x2(acc[6] * s, acc[7] * s)};
+              if (sek >= sv0 + KV) {
+                // the point continues in the next slot: park the partial sum
+                *reinterpret_cast<float4*>(mine) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(mine + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+              } else if (ssk >= sv0) {
+                const float s1 = sc_t[tg * 32 + vt];
+                const u32x4 o = {pack_bf16x2(acc[0] * s1, acc[1] * s1), pack_bf16x2(acc[2] * s1, acc[3] * s1),
+                                 pack_bf16x2(acc[4] * s1, acc[5] * s1), pack_bf16x2(acc[6] * s1, acc[7] * s1)};
                 st128(O, (uint32_t)pid_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
               } else {
-                float* dst = acc_t + (ssk / KV) * C + q * 8;
+                // the point started in an earlier slot and ends here
+                has_head = true;
+                head_view = vt;
+                head_slot0 = ssk / KV;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) atomicAdd(dst + i, acc[i]);
-                if (sek < sv0 + KV) {
-                  pend = true;
-                  pend_slot = ssk / KV;
-                  pend_view = vt;
-                }
+                for (int i = 0; i < 8; ++i) hp[i] = acc[i];
               }
             }
 #pragma unroll
@@ -641,15 +649,20 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
         }
       }
       wave_sync();
-      if (pend) {
-        float* src = acc_t + pend_slot * C + q * 8;
-        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-        *reinterpret_cast<float4*>(src) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(src + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float s = sc_t[tg * 32 + pend_view];
-        const u32x4 o = {pack_bf16x2(lo.x * s, lo.y * s), pack_bf16x2(lo.z * s, lo.w * s),
-                         pack_bf16x2(hi.x * s, hi.y * s), pack_bf16x2(hi.z * s, hi.w * s)};
-        st128(O, (uint32_t)pid_t[pend_view] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
+      if (has_head) {
+#pragma unroll
+        for (int d = 1; d < ROWS; ++d) {
+          if (slot - d >= head_slot0) {
+            const float* src = acc_t + (slot - d) * C + q * 8;
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            hp[0] += lo.x; hp[1] += lo.y; hp[2] += lo.z; hp[3] += lo.w;
+            hp[4] += hi.x; hp[5] += hi.y; hp[6] += hi.z; hp[7] += hi.w;
+          }
+        }
+        const float s1 = sc_t[tg * 32 + head_view];
+        const u32x4 o = {pack_bf16x2(hp[0] * s1, hp[1] * s1), pack_bf16x2(hp[2] * s1, hp[3] * s1),
+                         pack_bf16x2(hp[4] * s1, hp[5] * s1), pack_bf16x2(hp[6] * s1, hp[7] * s1)};
+        st128(O, (uint32_t)pid_t[head_view] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
       }
     }
     wave_sync();

@@ -3,7 +3,14 @@ over xGMI on ROCm), scenes sharded by point-cloud tile, no collective on the dat
 
 The reference is single-GPU (trainer.py:59-61), so there is nothing to mirror: the
 pooled feature of a point depends only on its own views and images seen by several tiles are
-replicated, hence the only exchange is the data-parallel sum of parameter gradients.
+replicated, hence the only exchange is the data-parallel sum of parameter gradients (SURVEY.md 8(e):
+~28 M parameters = 112 MB fp32 for the full model; the pooling modules themselves own a few kB).
+
+``GradientBucket`` flattens a parameter list into fixed-size fp32 buckets.  ``start()`` enqueues, per bucket,
+copy-in -> all-reduce -> (average) on a SIDE stream that waits for the producing stream, so the ring transfers
+over xGMI (per-link bound: few large messages) run under whatever the main stream computes next -- in bench.py
+the backward of the view pooling; ``finish()`` makes the main stream wait and writes the reduced gradients back.
+``reduce()`` = ``start()`` + ``finish()``.
 """
 import torch
 import torch.distributed as dist
@@ -21,33 +28,80 @@ def tile_partition(xyz, n_tiles):
     return [torch.sort(order[int(bounds[i]):int(bounds[i + 1])]).values for i in range(n_tiles)]
 
 
-class GradientBucket:
-    """Flat fp32 bucket over a parameter list: one all-reduce (sum) per step instead of one per
-    tensor; the ring all-reduce over xGMI is per-link bound, so few large messages beat many small
-    ones.  ``reduce()`` may run on a side stream to overlap with the tail of the backward."""
+def shard_mapping(csr_idx, tile_points):
+    """CSR pointers + view selection of the points ``tile_points`` (sorted LongTensor) of a scene mapping:
+    returns (csr_tile [n + 1], view_index [V_tile]) -- the views of a point travel with the point."""
+    sizes = (csr_idx[1:] - csr_idx[:-1])[tile_points]
+    csr_tile = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+    starts = csr_idx[:-1][tile_points]
+    view_index = torch.repeat_interleave(starts - csr_tile[:-1], sizes) + torch.arange(
+        int(csr_tile[-1]), device=csr_idx.device)
+    return csr_tile, view_index
 
-    def __init__(self, params, process_group=None):
+
+class GradientBucket:
+    """Bucketed data-parallel gradient all-reduce (sum or mean) of a parameter list."""
+
+    def __init__(self, params, process_group=None, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.sizes = [p.numel() for p in self.params]
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
+        per = max(1, bucket_bytes // 4)
+        n = self.flat.numel()
+        self.chunks = [(o, min(o + per, n)) for o in range(0, n, per)] or [(0, 0)]
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._handles = None
+        self._average = True
 
-    def reduce(self, average=True):
-        """All-reduce the gradients of the bucket's parameters in place."""
-        if not dist.is_available() or not dist.is_initialized():
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def start(self, average=True):
+        """Copy the current gradients into the flat buffer and enqueue the bucket all-reduces; on a HIP device
+        they run on the bucket's own stream (after everything already enqueued on the current stream)."""
+        self._average = average
+        if not (dist.is_available() and dist.is_initialized()):
             return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            ctx = torch.cuda.stream(self.stream)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
         world = dist.get_world_size(self.group)
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        if average:
-            self.flat.div_(world)
+        with ctx:
+            off = 0
+            for p, n in zip(self.params, self.sizes):
+                if p.grad is None:
+                    self.flat[off:off + n].zero_()
+                else:
+                    self.flat[off:off + n].copy_(p.grad.reshape(-1))
+                off += n
+            self._handles = []
+            for a, b in self.chunks:
+                if b > a:
+                    self._handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
+            if self.stream is not None:
+                for hnd in self._handles:
+                    hnd.wait()               # orders the collective inside the side stream, does not block the host
+                if average:
+                    self.flat.div_(world)
+
+    def finish(self):
+        """Wait for the all-reduces and write the reduced gradients back into ``p.grad``."""
+        if not (dist.is_available() and dist.is_initialized()) or self._handles is None:
+            return
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        else:
+            for hnd in self._handles:
+                hnd.wait()
+            if self._average:
+                self.flat.div_(dist.get_world_size(self.group))
+        self._handles = None
         off = 0
         for p, n in zip(self.params, self.sizes):
             g = self.flat[off:off + n].view_as(p)
@@ -56,3 +110,8 @@ class GradientBucket:
             else:
                 p.grad.copy_(g)
             off += n
+
+    def reduce(self, average=True):
+        """All-reduce the gradients of the bucket's parameters in place."""
+        self.start(average)
+        self.finish()

@@ -402,6 +402,10 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
                           double* stats, int64_t n_points, void* stream);
 
+/* Measurement helper (bench.py): float4 grid-stride device copy of nbytes (multiple of 16) -- the practical HBM
+ * ceiling (read + write) beside which the roofline fractions are quoted. */
+int dva_copy_ceiling(const void* src, void* dst, int64_t nbytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * Voxel parent index after a strided sparse 3D convolution.  Replaces the torchsparse (v1.1.0, not in the
  * reference tree) `sphashquery(sphash(in_coords), sphash(out_coords))` call of
