@@ -125,7 +125,7 @@ SIGNATURES = {
     "dva_chain_attn_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 22 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
-    "dva_chain_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i32, _i64, _i64, _vp]),
+    "dva_chain_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 24 + [_i32, _i64, _i64, _vp]),
     "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_copy_ceiling": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "dva_voxel_parent_workspace_bytes": (ctypes.c_int64, [_i64]),

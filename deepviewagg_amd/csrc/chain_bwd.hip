@@ -418,10 +418,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer passes.  STAGE 6: dz6 -> dW6, dWs, dbs, S5.  STAGE 5: dz5 -> dW5, du, S2 (view part).
-// STAGE 2: set-pooling gradient + dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
+// layer passes.  STAGE 6: dz6 -> dW6, dWs, dbs, S5; hands da5 (bf16 [V, 32]) to the next pass.
+// STAGE 5: da5 -> dz5 -> dW5, du, S2 (view part); hands da2 to the next pass.
+// STAGE 2: da2 + set-pooling gradient -> dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
+// Each pass re-evaluates only the layers it differentiates (x_map -> ... -> its own layer); the gradient with
+// respect to the layer output crosses the BatchNorm barrier as one bf16 row per view (64 bytes), in the
+// accumulator order of the lane that wrote it: re-deriving it through the later layers cost 0.8 ms per pass.
 // ------------------------------------------------------------------------------------------------
 constexpr int TZB = 36;
+__device__ __forceinline__ void store_da(__amdgpu_buffer_rsrc_t R, bool ok, uint32_t view, int h, const f32x16& da) {
+  float t[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = da[r];
+  const bf16x8 lo = pack8(&t[0]), hi = pack8(&t[8]);
+  const uint32_t off = ok ? view * 64u + 32u * h : OOB;
+  st128(R, off, __builtin_bit_cast(u32x4, lo));
+  st128(R, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, hi));
+}
+__device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  f32x16 d;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    d[2 * i] = __uint_as_float(w[i] << 16);
+    d[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+  return d;
+}
+
 template <int STAGE>
 __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
@@ -429,20 +453,30 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     const float* __restrict__ bn6, const float* __restrict__ sm2, const float* __restrict__ sm5,
     const float* __restrict__ sm6, const float* __restrict__ dc, const int32_t* __restrict__ arg,
-    const float* __restrict__ dpooled, float* __restrict__ dW, float* __restrict__ dWs, float* __restrict__ dbs,
+    const float* __restrict__ dpooled, const bf16_t* __restrict__ da_in, bf16_t* __restrict__ da_out,
+    float* __restrict__ dW, float* __restrict__ dWs, float* __restrict__ dbs,
     float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N) {
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
   __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][32 * TSB];
   __shared__ __attribute__((aligned(16))) float s_tz[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TZB : 4];
   __shared__ float s_red[D * D];
-  __shared__ __attribute__((aligned(16))) uint4 s_ops[N_OPS * 64];
+  // only the operands of the pass (LDS budget: three blocks per CU for stages 5 and 2):
+  // stage 5: W1 W2 W5 | W5T -> local 5, 6;  stage 2: W1 W2 | W2T -> local 3, 4
+  constexpr int NOPS = STAGE == 6 ? N_OPS : (STAGE == 5 ? 7 : 5);
+  constexpr int L_W5T = 5, L_W2T = 3;
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  stage_ops(s_ops, ops);
+  for (int i = threadIdx.x; i < NOPS * 64; i += blockDim.x) {
+    int op = i >> 6;
+    if (STAGE == 5 && op >= 5) op = OP_W5T + (op - 5);
+    if (STAGE == 2 && op >= 3) op = OP_W2T + (op - 3);
+    s_ops[i] = ops[op * 64 + (i & 63)];
+  }
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr);
-  stage_tab(s_tab[2], bn5, STAGE <= 5 ? sm5 : nullptr);
-  stage_tab(s_tab[3], bn6, sm6);
+  stage_tab(s_tab[2], bn5, STAGE == 5 ? sm5 : nullptr);
+  stage_tab(s_tab[3], bn6, STAGE == 6 ? sm6 : nullptr);
   // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
   for (int i = threadIdx.x; i < 4 * 32 * TSB; i += blockDim.x) {
     if (STAGE != 5) (&s_td[0][0])[i] = 0;
@@ -450,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16),
-                               AR = make_rsrc(arg, (uint64_t)N * 128), DP = make_rsrc(dpooled, (uint64_t)N * 128);
+                               AR = make_rsrc(arg, (uint64_t)N * 128), DP = make_rsrc(dpooled, (uint64_t)N * 128),
+                               DI = make_rsrc(da_in, (uint64_t)V * 64), DO = make_rsrc(da_out, (uint64_t)V * 64);
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
@@ -469,46 +504,45 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   struct Pre {
     TileInfo ti;
     float4 x, dc;
+    u32x4 dlo, dhi;
     int vpj;
   };
   run_tiles<Pre>(tiles, t0, t1, [&](const TileInfo& ti, int t) {
     Pre p;
     p.ti = ti;
     const bool ok = j < p.ti.nv;
-    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
-    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
-    p.dc = as_f4(ld128(DC, ok && h == 0 ? (uint32_t)(p.ti.v0 + j) * 16u : OOB));
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
+    if (STAGE == 6) {
+      p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+    } else {
+      p.dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB);
+      p.dhi = ld128(DI, ok ? view * 64u + 32u * h + 16u : OOB);
+    }
     return p;
   }, [&](const Pre& p) {
     const int nv = p.ti.nv;
     const bool ok = j < nv;
     const uint32_t keep = ok ? 0xffffffffu : 0u;
-    const f32x16 uacc = load_u(U, ok, p.vpj, h);
-    // set-pooling gradient of this view's channels (STAGE 2): issued early, used after the chain
-    u32x4 arq[4], dpq[4];
-    if (STAGE == 2) {
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const uint32_t off = ok ? (uint32_t)p.vpj * 128u + (8u * qq + 4u * h) * 4u : OOB;
-        arq[qq] = ld128(AR, off);
-        dpq[qq] = ld128(DP, off);
-      }
-    }
-    ChainKeep k;
-    chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
-    const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
-    float dz[16], unused_st[2][16];
-    // ---- layer 6
-    const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
-    layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
-    bf16x8 dzp[2];
-    pack16(dz, keep, dzp);
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
     const f32x16 zero = {0};
-    if (STAGE == 6) {
+    float dz[16], unused_st[2][16];
+    bf16x8 dzp[2];
+    if constexpr (STAGE == 6) {
+      const f32x16 uacc = load_u(U, ok, p.vpj, h);
+      ChainKeep k;
+      chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
+      const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
+      const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
+      layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
+      pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
-      { bf16x8 t5[2] = {mask8(k.a5[0], keep), mask8(k.a5[1], keep)}, t6[2] = {mask8(k.a6[0], keep), mask8(k.a6[1], keep)};
+      {
+        bf16x8 t5[2] = {mask8(k.a5[0], keep), mask8(k.a5[1], keep)}, t6[2] = {mask8(k.a6[0], keep), mask8(k.a6[1], keep)};
         tileT_put_packed(tb_, j, h, t5);
-        tileT_put_packed(tc, j, h, t6); }
+        tileT_put_packed(tc, j, h, t6);
+      }
       if (h == 0) {
         const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
         td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
@@ -518,31 +552,35 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
       }
-    }
-    const f32x16 da5 = mm32_lds(s_ops, OP_W6T, lane, dzp, zero);
-    if (STAGE == 6) {
+      const f32x16 da5 = mm32_lds(s_ops, OP_W6T, lane, dzp, zero);
+      store_da(DO, ok, view, h, da5);
       layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dz);
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
       accS = wgrad(tc, td, j, h, accS);       // dWs^T[k][g] = sum_v a6[v][k] dc[v][g]
       wave_sync();
-      return;
-    }
-    // ---- layer 5
-    layer_bwd<false, true>(k.z5, da5, s_tab[2], h, ok, unused_st, dz);
-    pack16(dz, keep, dzp);
-    if (STAGE == 5) {
+    } else if constexpr (STAGE == 5) {
+      f32x16 uacc = load_u(U, ok, p.vpj, h);
+      // forward up to layer 5
+      bf16x8 a1[2], a2[2];
+      asm volatile("" ::: "memory");
+      const f32x16 z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
+      act_pack(z1, s_tab[0], h, 0xffffffffu, a1);
+      const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
+      act_pack(z2, s_tab[1], h, keep, a2);
+      const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
+      const f32x16 da5 = unpack_da(p.dlo, p.dhi);
+      layer_bwd<false, true>(z5, da5, s_tab[2], h, ok, unused_st, dz);
+      pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
-      { bf16x8 t2[2] = {mask8(k.a2[0], keep), mask8(k.a2[1], keep)};
-        tileT_put_packed(tb_, j, h, t2); }
+      tileT_put_packed(tb_, j, h, a2);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
         *reinterpret_cast<float4*>(tz + j * TZB + 8 * qq + 4 * h) =
             make_float4(dz[4 * qq], dz[4 * qq + 1], dz[4 * qq + 2], dz[4 * qq + 3]);
-    }
-    const f32x16 da2 = mm32_lds(s_ops, OP_W5T, lane, dzp, zero);
-    if (STAGE == 5) {
-      layer_bwd<true, false>(k.z2, da2, s_tab[1], h, ok, st, dz);
+      const f32x16 da2 = mm32_lds(s_ops, L_W5T, lane, dzp, zero);
+      store_da(DO, ok, view, h, da2);
+      layer_bwd<true, false>(z2, da2, s_tab[1], h, ok, st, dz);
       const int nxt = shfl(p.vpj, lane + 1);
       const bool is_end = ok && (j == nv - 1 || nxt != p.vpj);
       uint32_t endmask = (uint32_t)__ballot(is_end);
@@ -550,63 +588,75 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
       // du[p][c] = sum of dz5 over the views of the point: lane c walks the views of the tile
-      float xv[32];
 #pragma unroll
-      for (int v = 0; v < 32; ++v) xv[v] = tz[v * TZB + j];
+      for (int v0 = 0; v0 < 32; v0 += 8) {
+        if (v0 < nv) {
+          float xv[8];
 #pragma unroll
-      for (int v = 0; v < 32; ++v) {
-        if (v < nv) {
-          run_u += xv[v];
-          if ((endmask >> v) & 1u) {
-            const int pt = __builtin_amdgcn_readlane(p.vpj, v);
-            if (h == 0) du[(int64_t)pt * D + j] = run_u;
-            run_u = 0.f;
+          for (int v = 0; v < 8; ++v) xv[v] = tz[(v0 + v) * TZB + j];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) {
+            if (v0 + v < nv) {
+              run_u += xv[v];
+              if ((endmask >> (v0 + v)) & 1u) {
+                const int pt = __builtin_amdgcn_readlane(p.vpj, v0 + v);
+                if (h == 0) du[(int64_t)pt * D + j] = run_u;
+                run_u = 0.f;
+              }
+            }
           }
         }
       }
       wave_sync();
-      return;
-    }
-    // ---- STAGE 2: layers 1, 2 re-evaluated here (their registers were free during the layer 6 / 5 work)
-    bf16x8 a1r[2];
-    asm volatile("" ::: "memory");
-    const f32x16 z1r = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
-    act_pack(z1r, s_tab[0], h, keep, a1r);
-    const f32x16 z2r = mm32_lds(s_ops, OP_W2, lane, a1r, zero);
-    // gradient of the max-pooled set features goes to the arg view of each channel
-    f32x16 da2t = da2;
-    {
-      const int vg = p.ti.v0 + j;
+    } else {
+      // set-pooling gradient of this view's channels: issued early, used after the two layers
+      u32x4 arq[4], dpq[4];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const uint32_t ai[4] = {arq[qq].x, arq[qq].y, arq[qq].z, arq[qq].w};
-        const uint32_t di[4] = {dpq[qq].x, dpq[qq].y, dpq[qq].z, dpq[qq].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          da2t[4 * qq + e] += (ok && (int)ai[e] == vg) ? __uint_as_float(di[e]) : 0.f;
+        const uint32_t off = ok ? (uint32_t)p.vpj * 128u + (8u * qq + 4u * h) * 4u : OOB;
+        arq[qq] = ld128(AR, off);
+        dpq[qq] = ld128(DP, off);
       }
-    }
-    layer_bwd<false, true>(z2r, da2t, s_tab[1], h, ok, unused_st, dz);
-    pack16(dz, keep, dzp);
-    tileT_put_packed(ta, j, h, dzp);
-    tileT_put_packed(tb_, j, h, a1r);
-    const f32x16 da1 = mm32_lds(s_ops, OP_W2T, lane, dzp, zero);
-    layer_bwd<true, false>(z1r, da1, s_tab[0], h, ok, st, dz);
-    // dy1 of the layer (recomputed: layer_bwd keeps it internal) for P = sum_v dy1 x^T
-    {
-      float g1[16], b1[16], dy1[16];
-      tab16(s_tab[0], T_G, h, g1);
-      tab16(s_tab[0], T_B, h, b1);
+      bf16x8 a1[2];
+      asm volatile("" ::: "memory");
+      const f32x16 z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
+      act_pack(z1, s_tab[0], h, keep, a1);
+      const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
+      // gradient of the max-pooled set features goes to the arg view of each channel
+      f32x16 da2t = unpack_da(p.dlo, p.dhi);
+      {
+        const int vg = p.ti.v0 + j;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dy1[r] = ok ? da1[r] * dleaky(__builtin_fmaf(z1r[r], g1[r], b1[r])) : 0.f;
-      tileT_put_acc(tc, j, h, dy1);
-      tileT_put(td, 4 * h, 4 * h + 1, j, p.x.x, p.x.y);      // lanes without a view loaded zeros
-      tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
+        for (int qq = 0; qq < 4; ++qq) {
+          const uint32_t ai[4] = {arq[qq].x, arq[qq].y, arq[qq].z, arq[qq].w};
+          const uint32_t di[4] = {dpq[qq].x, dpq[qq].y, dpq[qq].z, dpq[qq].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            da2t[4 * qq + e] += (ok && (int)ai[e] == vg) ? __uint_as_float(di[e]) : 0.f;
+        }
+      }
+      layer_bwd<false, true>(z2, da2t, s_tab[1], h, ok, unused_st, dz);
+      pack16(dz, keep, dzp);
+      tileT_put_packed(ta, j, h, dzp);
+      tileT_put_packed(tb_, j, h, a1);
+      const f32x16 da1 = mm32_lds(s_ops, L_W2T, lane, dzp, zero);
+      layer_bwd<true, false>(z1, da1, s_tab[0], h, ok, st, dz);
+      // dy1 of the layer (layer_bwd keeps it internal) for P = sum_v dy1 x^T
+      {
+        float g1[16], b1[16], dy1[16];
+        tab16(s_tab[0], T_G, h, g1);
+        tab16(s_tab[0], T_B, h, b1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dy1[r] = ok ? da1[r] * dleaky(__builtin_fmaf(z1[r], g1[r], b1[r])) : 0.f;
+        tileT_put_acc(tc, j, h, dy1);
+        tileT_put(td, 4 * h, 4 * h + 1, j, p.x.x, p.x.y);      // lanes without a view loaded zeros
+        tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
+      }
+      wave_sync();
+      accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
+      accS = wgrad(tc, td, j, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
+      wave_sync();
     }
-    wave_sync();
-    accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
-    accS = wgrad(tc, td, j, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
-    wave_sync();
   });
   flush_matrix(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red);
   if (STAGE == 6) {
@@ -710,24 +760,24 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
-                        float* dW, float* dWs, float* dbs, float* du, float* P, double* stats, int32_t G,
-                        int64_t n_views, int64_t n_points, void* stream) {
+                        const void* da_in, void* da_out, float* dW, float* dWs, float* dbs, float* du, float* P,
+                        double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
   if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !sm6 ||
-      !grad_scores || !dW || !stats)
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW || !stats)
     return DVA_ERR_INVALID;
-  if (stage == 6 && (!dWs || !dbs)) return DVA_ERR_INVALID;
-  if (stage <= 5 && !sm5) return DVA_ERR_INVALID;
-  if (stage == 5 && !du) return DVA_ERR_INVALID;
-  if (stage == 2 && (!sm2 || !arg || !dpooled || !P)) return DVA_ERR_INVALID;
+  if (stage == 6 && (!sm6 || !grad_scores || !dWs || !dbs || !da_out)) return DVA_ERR_INVALID;
+  if (stage == 5 && (!sm5 || !du || !da_in || !da_out)) return DVA_ERR_INVALID;
+  if (stage == 2 && (!sm2 || !arg || !dpooled || !P || !da_in)) return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_LAYER_BWD(ST_, BPC_)                                                                                  \
   hipLaunchKernelGGL((layer_bwd_kernel<ST_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u,        \
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
-                     grad_scores, arg, dpooled, dW, dWs, dbs, du, P, stats, G, n_views, n_points)
+                     grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, dWs, dbs, du, P, stats, G, \
+                     n_views, n_points)
   if (stage == 6) DVA_LAYER_BWD(6, 2);
   else if (stage == 5) DVA_LAYER_BWD(5, 2);
   else DVA_LAYER_BWD(2, 2);

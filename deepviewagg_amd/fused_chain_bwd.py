@@ -61,25 +61,33 @@ def backward(ctx, gout):
         grows = grows.to(rows.dtype)
     del rec
 
-    def layer(stage, sm2, sm5, sm6, arg_, dpooled_, dW, dWs, dbs, du, P, stats, name, nbytes):
+    def layer(stage, sm2, sm5, sm6, arg_, dpooled_, da_in, da_out, dW, dWs, dbs, du, P, stats, name, nbytes):
         with ops._timed(name, nbytes):
             check(lib.dva_chain_bwd_layer(stage, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                           ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm2), ptr(sm5), ptr(sm6),
-                                          ptr(dc), ptr(arg_), ptr(dpooled_), ptr(dW), ptr(dWs), ptr(dbs), ptr(du),
-                                          ptr(P), ptr(stats), G, V, N, st), "dva_chain_bwd_layer")
+                                          ptr(dc), ptr(arg_), ptr(dpooled_), ptr(da_in), ptr(da_out), ptr(dW),
+                                          ptr(dWs), ptr(dbs), ptr(du), ptr(P), ptr(stats), G, V, N, st),
+                  "dva_chain_bwd_layer")
 
-    per_view = V * (32 + 4 + 16) + N * 128
+    # per view: x_map 32 + view->point 4 (+ score gradients 16) + the 64-byte gradient row handed between the passes
     sm6 = sm_of(s6)
     dW6 = torch.zeros((D, D), dtype=torch.float32, device=dev)
     dWs = torch.zeros((G, D), dtype=torch.float32, device=dev)
     dbs = torch.zeros(G, dtype=torch.float32, device=dev)
     s5 = zstats()
-    layer(6, None, None, sm6, None, None, dW6, dWs, dbs, None, None, s5, "chain_bwd_l6", per_view)
+    da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
+    layer(6, None, None, sm6, None, None, None, da5, dW6, dWs, dbs, None, None, s5, "chain_bwd_l6",
+          V * (32 + 4 + 16 + 64) + N * 128)
+    del dc
     sm5 = sm_of(s5)
     dW5 = torch.zeros((D, 2 * D), dtype=torch.float32, device=dev)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
     s2 = zstats()
-    layer(5, None, sm5, sm6, None, None, dW5, None, None, du, None, s2, "chain_bwd_l5", per_view + N * 128)
+    da2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
+    dc = None
+    layer(5, None, sm5, None, None, None, da5, da2, dW5, None, None, du, None, s2, "chain_bwd_l5",
+          V * (32 + 4 + 64 + 64) + N * 256)
+    del da5
     # ---- per-point set branch
     dpooled, dWcB, d_set = _set_branch_backward(ctx.set_saved, du, training, zstats)
     dW5[:, D:] = dWcB
@@ -89,7 +97,9 @@ def backward(ctx, gout):
     dW2 = torch.zeros((D, D), dtype=torch.float32, device=dev)
     P = torch.zeros((D, 8), dtype=torch.float32, device=dev)
     s1 = zstats()
-    layer(2, sm2, sm5, sm6, arg, dpooled, dW2, None, None, None, P, s1, "chain_bwd_l2", per_view + N * 256)
+    layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, None, None, P, s1, "chain_bwd_l2",
+          V * (32 + 4 + 64) + N * 256)
+    del da2
     sm1 = sm_of(s1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so
     #      dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q) with Q = sum_v z1_hat x^T from the moments of x_map

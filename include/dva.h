@@ -386,18 +386,21 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
                        double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
                        int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
 /* One backward pass of the chain between two BatchNorm-backward barriers ("sm" = fp32 [2][32] = S1/M | S2/M of
- * the layer, zeros with running statistics; all outputs caller-zeroed, accumulated with atomics):
- *   stage 6: dW [32][32] = dW6, dWs [G][32], dbs [G], stats += S of layer 5          (needs sm6)
- *   stage 5: dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u (written for
- *            seen points), stats += S of layer 2, view part                          (needs sm5, sm6)
- *   stage 2: dW [32][32] = dW2, P fp32 [32][8] = sum_v dy1 x^T, stats += S of layer 1; arg / dpooled = the
- *            arg views of dva_chain_stats2 and the gradient of the pooled set features   (needs sm2, sm5, sm6) */
+ * the pass's own layer, zeros with running statistics; dW / dWs / dbs / P / stats caller-zeroed, accumulated with
+ * atomics).  Each pass re-evaluates the chain from x_map up to its own layer; the gradient w.r.t. the layer's
+ * OUTPUT is handed from pass to pass as da_out -> da_in, bf16 [V][32] (64 bytes per view, in the lane order of
+ * the kernels: opaque to the caller):
+ *   stage 6: grad_scores -> dW [32][32] = dW6, dWs [G][32], dbs [G], stats += S of layer 5, da_out = d a5  (sm6)
+ *   stage 5: da_in = d a5 -> dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u
+ *            (written for seen points), stats += S of layer 2 (view part), da_out = d a2               (sm5)
+ *   stage 2: da_in = d a2 (+ dpooled routed to the arg views of dva_chain_stats2) -> dW [32][32] = dW2,
+ *            P fp32 [32][8] = sum_v dy1 x^T, stats += S of layer 1                                      (sm2) */
 int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
-                        float* dW, float* dWs, float* dbs, float* du, float* P, double* stats, int32_t G,
-                        int64_t n_views, int64_t n_points, void* stream);
+                        const void* da_in, void* da_out, float* dW, float* dWs, float* dbs, float* du, float* P,
+                        double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream);
 /* stats += S1 | S2 of layer 2, per-point part: sum over the seen points of leaky'(BN2(zstar)) dpooled (x z_hat). */
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
                           double* stats, int64_t n_points, void* stream);
