@@ -2,15 +2,20 @@
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs into per-kernel HBM traffic.
 
 Usage: python profiles/summarize_pmc.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> <out.json>
-Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports exactly half of the bytes of
-a coalesced streaming read, so the read side is doubled; both counters are in units of 1 KiB... this
-rocprofv3 build reports them in KB (1e3 B), checked against the known 4.29 GB streams of the layer kernels.
+Units and correction (MI355X_MICROARCH.md, HBM section): both counters are in KiB (1024 B); on gfx950 FETCH_SIZE
+reports exactly half of the bytes of a coalesced 16-byte-per-lane streaming read, so the read side is doubled.
+Calibration instead of trust: the same run contains dva::copy_kernel (bench.py's copy ceiling: 4 GiB read + 4 GiB
+written per launch, float4 grid-stride) -- the measured / known ratios of that kernel are printed and stored under
+"_calibration"; they are NOT applied to the other kernels (access widths differ), only reported.
 """
 import collections
 import csv
 import json
 import os
 import sys
+
+KIB = 1024.0
+COPY_BYTES = float(1 << 32)
 
 
 def load(path):
@@ -31,11 +36,19 @@ def main(src, dst):
     for k in sorted(set(fetch) | set(write)):
         f = max(fetch.get(k, [0.0]))      # largest launch of the kernel = the V-sized one
         w = max(write.get(k, [0.0]))
-        res[k] = {"fetch_bytes_corrected": 2 * f * 1e3, "write_bytes": w * 1e3,
-                  "hbm_bytes": 2 * f * 1e3 + w * 1e3}
+        res[k] = {"fetch_bytes_corrected": 2 * f * KIB, "write_bytes": w * KIB,
+                  "hbm_bytes": 2 * f * KIB + w * KIB}
+    if "copy_kernel" in res:
+        c = res["copy_kernel"]
+        res["_calibration"] = {"kernel": "copy_kernel", "known_read_bytes": COPY_BYTES, "known_write_bytes": COPY_BYTES,
+                               "read_measured_over_known": c["fetch_bytes_corrected"] / COPY_BYTES,
+                               "write_measured_over_known": c["write_bytes"] / COPY_BYTES}
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
-        print(f"{k:40s} {v['hbm_bytes'] / 1e9:8.2f} GB")
+        if k.startswith("_"):
+            print(k, v)
+        else:
+            print(f"{k:48s} {v['hbm_bytes'] / 1e9:8.2f} GB")
 
 
 if __name__ == "__main__":

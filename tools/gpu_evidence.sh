@@ -9,12 +9,12 @@ export TMPDIR=/tmp
 cd $ROOT
 timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -6 > $OUT/pytest_gpu.log
 tail -2 $OUT/pytest_gpu.log
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 python tools/show_bench.py $OUT/bench.json | head -3
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-mapping-build > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err
 python tools/show_bench.py $OUT/bench_torchrun1.json | head -1
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-mapping-build"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-mapping-build --no-secondary"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG --output-format csv -- $BENCH > $OUT/bench_prof.json 2> $OUT/prof.err)
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc --output-format csv -- $BENCH --steps 1 --warmup 1 > /dev/null 2> $OUT/pmc_$C.err)
