@@ -519,13 +519,213 @@ def gen_mapping():
     save("mapping_build", **res)
 
 
+def gen_mapping_cylinder():
+    """MapImages with cylinder=True (the KITTI-360 configuration, core/data_transform/multimodal/image.py:242-243):
+    per image the candidates are the points inside the vertical cylinder of radius r_max around the camera
+    (CylinderSampling: KD-tree radius query in the xy plane, core/data_transform/transforms.py:353-403), in the
+    order of the query result -- made explicit here by sorting it --, then the same per-image loop as
+    gen_mapping() with the kitti360_perspective camera."""
+    print("MapImages, cylinder candidate sampling (KITTI-360 perspective camera)")
+    from sklearn.neighbors import KDTree
+    patch_numba_promotion()
+    gen = torch.Generator().manual_seed(12)
+    N = 6000
+    xyz = room_cloud(N, gen, size=(30.0, 30.0, 4.0))
+    lin, pla, sca = (torch.rand(N, generator=gen) for _ in range(3))
+    nrm = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=1)
+    ref_size, proj_upscale, r_max = (352, 94), 2, 9.0
+    proj_size = (ref_size[0] * proj_upscale, ref_size[1] * proj_upscale)
+
+    def look_at(eye, yaw):
+        c, sn = np.cos(yaw), np.sin(yaw)
+        R = np.array([[sn, 0, c], [-c, 0, sn], [0, -1, 0]], dtype=np.float32)
+        E = np.eye(4, dtype=np.float32)
+        E[:3, :3] = R
+        E[:3, 3] = eye
+        return torch.from_numpy(E)
+    poses = [look_at(np.array([6.0, 7.0, 1.6], dtype=np.float32), 0.3),
+             look_at(np.array([20.0, 12.0, 1.5], dtype=np.float32), 2.2),
+             look_at(np.array([14.0, 25.0, 1.7], dtype=np.float32), -1.4)]
+    fx, fy, mx, my = 276.3, 276.3, 341.0, 119.4          # KITTI-360 intrinsics scaled to the 704 x 188 projection
+    K = torch.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, mx, my
+    model = ref_vis.SplattingVisibility(
+        img_size=proj_size, r_max=np.float64(r_max), r_min=np.float64(0.3), camera='kitti360_perspective',
+        voxel=np.float64(0.08), k_swell=np.float64(1.2), d_swell=1000, exact=True)
+    tree = KDTree(np.asarray(xyz[:, :-1]), leaf_size=50)
+    image_ids, point_ids, features, pixels, n_cand = [], [], [], [], []
+    for i_img, E in enumerate(poses):
+        ind = torch.LongTensor(np.sort(tree.query_radius(np.asarray(E[:2, 3]).reshape(1, 2), r=r_max)[0]))
+        n_cand.append(len(ind))
+        out = model(xyz[ind], E[:3, 3].clone(), img_extrinsic=E, img_intrinsic_pinhole=K, linearity=lin[ind],
+                    planarity=pla[ind], scattering=sca[ind], normals=nrm[ind])
+        if out['idx'].shape[0] == 0:
+            continue
+        pid = ind[out['idx']]
+        px = out['x'].long() // proj_upscale
+        py = out['y'].long() // proj_upscale
+        keep = torch.where((px >= 0) & (py >= 0) & (px < ref_size[0]) & (py < ref_size[1]))
+        px, py, pid, ft = px[keep], py[keep], pid[keep], out['features'].float()[keep]
+        u = ref_mm.lexargunique(pid, px, py)
+        image_ids.append(i_img)
+        point_ids.append(pid[u])
+        features.append(ft[u])
+        pixels.append(torch.stack((px[u], py[u]), dim=1).short())
+    assert min(n_cand) < N and len(image_ids) == len(poses)
+    image_ids = torch.arange(len(image_ids)).repeat_interleave(torch.LongTensor([x.shape[0] for x in point_ids]))
+    point_ids, pixels, features = torch.cat(point_ids), torch.cat(pixels), torch.cat(features)
+    mapping = ref_image.ImageMapping.from_dense(point_ids, image_ids, pixels, features, num_points=N)
+    save("mapping_build_cylinder", xyz=xyz, linearity=lin, planarity=pla, scattering=sca, normals=nrm,
+         extrinsic=torch.stack(poses), fx=np.array(fx), fy=np.array(fy), mx=np.array(mx), my=np.array(my),
+         ref_size=np.array(ref_size), proj_upscale=np.array(proj_upscale), r_max=np.array(r_max),
+         n_candidates=np.array(n_cand), pointers=mapping.pointers, images=mapping.images,
+         atom_pointers=mapping.values[1].pointers, pixels=mapping.pixels, features=mapping.features)
+
+
+def import_ref_transforms():
+    """core/data_transform/multimodal/image.py of the reference, loaded as a single file: its package __init__
+    pulls torch_geometric.transforms, torch_cluster, torch_points_kernels, datasets ... (absent).  The names the
+    file imports from there (samplers, FAISS finder, torchvision) are placeholders: none of the transforms
+    pinned below calls them."""
+    import importlib.util
+    name = "torch_points3d.core.data_transform.multimodal.image"
+    if name in sys.modules:
+        return sys.modules[name]
+
+    def placeholder(mod_name, names, is_pkg=False):
+        m = types.ModuleType(mod_name)
+        if is_pkg:
+            m.__path__ = []
+        for n in names:
+            setattr(m, n, type(n, (), {}))
+        sys.modules[mod_name] = m
+        return m
+    placeholder("torch_points3d.core.data_transform",
+                ["SphereSampling", "CylinderSampling", "GridSampling3D", "SaveOriginalPosId"], is_pkg=True)
+    placeholder("torch_points3d.core.data_transform.multimodal", [], is_pkg=True)
+    placeholder("torch_points3d.core.spatial_ops", [], is_pkg=True)
+    placeholder("torch_points3d.core.spatial_ops.neighbour_finder", ["FAISSGPUKNNNeighbourFinder"])
+    tv = placeholder("torchvision", [], is_pkg=True)
+    tv.transforms = placeholder("torchvision.transforms", ["ColorJitter", "GaussianBlur", "Normalize"])
+    spec = importlib.util.spec_from_file_location(
+        name, "/root/reference/torch_points3d/core/data_transform/multimodal/image.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _mapping_arrays(prefix, m):
+    return {prefix + "pointers": m.pointers, prefix + "images": m.images,
+            prefix + "atom_pointers": m.values[1].pointers, prefix + "pixels": m.pixels,
+            prefix + "features": m.features}
+
+
+def gen_transforms():
+    """ImageMapping rescale / crop / select_views (core/multimodal/image.py:1901-2027, 2095-2165, 2279-2342) and the
+    online transforms SelectMappingFromPointId, PickImagesFromMappingArea, CenterRoll, CropImageGroups,
+    PickImagesFromMemoryCredit (core/data_transform/multimodal/image.py:615-1141), run from the reference source."""
+    print("ImageMapping rescale / crop / select_views + online mapping transforms")
+    from torch_geometric.data import Data
+    T = import_ref_transforms()
+    gen = torch.Generator().manual_seed(21)
+    B, N = 6, 150
+    ref_w, ref_h = 128, 64
+    # non-exact mapping: each view owns 1-4 pixels clustered in a window of its image (so that rollings and
+    # croppings have something to do); points seen by 0..4 images
+    pts, imgs, pix = [], [], []
+    centre = torch.stack([torch.randint(0, ref_w, (B,), generator=gen), torch.randint(10, ref_h - 10, (B,), generator=gen)], 1)
+    span = torch.tensor([[15, 10], [45, 20], [100, 50], [20, 15], [125, 60], [8, 8]])
+    for p in range(N):
+        k = int(torch.randint(0, 5, (1,), generator=gen))
+        for i in torch.randperm(B, generator=gen)[:k].tolist():
+            na = int(torch.randint(1, 5, (1,), generator=gen))
+            dx = torch.randint(0, int(span[i, 0]), (na,), generator=gen) - int(span[i, 0]) // 2
+            dy = torch.randint(0, int(span[i, 1]), (na,), generator=gen) - int(span[i, 1]) // 2
+            x = (int(centre[i, 0]) + dx) % ref_w               # spherical images wrap along the width
+            y = (int(centre[i, 1]) + dy).clamp(0, ref_h - 1)
+            pts += [p] * na
+            imgs += [i] * na
+            pix += torch.stack([x, y], 1).tolist()
+    pts, imgs, pix = torch.LongTensor(pts), torch.LongTensor(imgs), torch.LongTensor(pix)
+    u = ref_mm.lexargunique(pts, imgs, pix[:, 0], pix[:, 1])
+    pts, imgs, pix = pts[u], imgs[u], pix[u].short()
+    feats = torch.rand(len(pts), 4, generator=gen)
+    x_img = torch.randint(0, 255, (B, 1, ref_h, ref_w), generator=gen, dtype=torch.uint8)
+    pos = torch.rand(B, 3, generator=gen) * 5
+
+    def fresh():
+        mapping = ref_image.ImageMapping.from_dense(pts, imgs, pix, feats, num_points=N)
+        sd = ref_image.SameSettingImageData(
+            path=np.array([f'img_{i}' for i in range(B)]), pos=pos.clone(), opk=torch.zeros(B, 3),
+            ref_size=(ref_w, ref_h), proj_upscale=1, mappings=mapping, x=x_img.clone())
+        return sd
+    res = dict(point_ids=pts, image_ids=imgs, pixels_dense=pix, map_features_dense=feats, x=x_img, pos=pos,
+               ref_size=np.array((ref_w, ref_h)), num_points=np.array(N))
+    sd = fresh()
+    m = sd.mappings
+    res.update(_mapping_arrays("in_", m))
+    # ---- ImageMapping methods
+    for r in (2, 4, 8):
+        res.update(_mapping_arrays(f"down{r}_", m.downscale_images(r)))
+    res.update(_mapping_arrays("up2_", m.upscale_images(2)))
+    res.update(_mapping_arrays("up3nc_", m.upscale_images(3, center=False)))
+    crop_size = (48, 32)
+    crop_off = torch.stack([torch.randint(0, ref_w - crop_size[0], (B,), generator=gen),
+                            torch.randint(0, ref_h - crop_size[1], (B,), generator=gen)], 1)
+    res.update(crop_size=np.array(crop_size), crop_offsets=crop_off)
+    res.update(_mapping_arrays("crop_", m.crop(crop_size, crop_off)))
+    view_mask = (torch.rand(m.num_items, generator=gen) < 0.6) & (m.images != 1) & (m.images != 4)   # two images vanish
+    out = m.select_views(view_mask)
+    mv, seen = out
+    assert seen is not None
+    res.update(view_mask=view_mask, sv_seen_images=seen)
+    res.update(_mapping_arrays("sv_", mv))
+    bb = m.bounding_boxes
+    res.update(bbox=torch.stack([b.long() for b in bb], 0))
+    # ---- SelectMappingFromPointId
+    keep = torch.randperm(N, generator=gen)[:40]
+    data = Data(pos=torch.rand(40, 3, generator=gen), mapping_index=keep.clone())
+    data.num_nodes = 40
+    d2, sd2 = T.SelectMappingFromPointId()(data, fresh())
+    res.update(sel_keep=keep, sel_mapping_index=d2.mapping_index, sel_pos=sd2.pos, sel_num_views=np.array(sd2.num_views))
+    res.update(_mapping_arrays("sel_", sd2.mappings))
+    # ---- PickImagesFromMappingArea (pixel count and bounding box variants)
+    data = Data(pos=torch.rand(N, 3, generator=gen), mapping_index=torch.arange(N))
+    for tag, kw in (("area", dict(area_ratio=0.003, n_max=4)), ("bbox", dict(area_ratio=0.05, n_max=None, use_bbox=True))):
+        _, sda = T.PickImagesFromMappingArea(**kw)(data, fresh())
+        res.update({f"pick_{tag}_pos": sda.pos, f"pick_{tag}_x": sda.x})
+        res.update(_mapping_arrays(f"pick_{tag}_", sda.mappings))
+    # ---- CenterRoll
+    _, sdr = T.CenterRoll(angular_res=16)(data, fresh())
+    res.update(roll_rollings=sdr.rollings, roll_x=sdr.x)
+    res.update(_mapping_arrays("roll_", sdr.mappings))
+    # ---- CropImageGroups (after the roll, like the S3DIS pipeline), then PickImagesFromMemoryCredit on the groups
+    _, idata = T.CropImageGroups(padding=2, min_size=16)(data, sdr)
+    res["crop_groups"] = np.array(len(idata))
+    for gi, g_sd in enumerate(idata):
+        res.update({f"cg{gi}_crop_size": np.array(g_sd.crop_size), f"cg{gi}_crop_offsets": g_sd.crop_offsets,
+                    f"cg{gi}_pos": g_sd.pos, f"cg{gi}_x": g_sd.x, f"cg{gi}_rollings": g_sd.rollings})
+        res.update(_mapping_arrays(f"cg{gi}_", g_sd.mappings))
+    data.num_nodes = N
+    np.random.seed(5)
+    credit = int(sum(g.img_size[0] * g.img_size[1] for g in idata) * 1.6)
+    _, picked = T.PickImagesFromMemoryCredit(credit=credit, k_coverage=2)(data, idata)
+    res.update(credit=np.array(credit), credit_seed=np.array(5), credit_groups=np.array(len(picked)))
+    for gi, g_sd in enumerate(picked):
+        res.update({f"mc{gi}_pos": g_sd.pos, f"mc{gi}_crop_size": np.array(g_sd.crop_size)})
+        res.update(_mapping_arrays(f"mc{gi}_", g_sd.mappings))
+    save("transforms", **res)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
     only = set(sys.argv[1:])
     jobs = dict(softmax=gen_softmax, segment=gen_segment, pools=gen_pools, gather=gen_gather,
-                branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping)
+                branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
+                transforms=gen_transforms, cylinder=gen_mapping_cylinder)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

