@@ -494,3 +494,49 @@ class CropImageGroups(ImageTransform):
             off_y = (y0[idx] - (sh - bh[idx]) / 2.).long().clamp(0, H - sh)
             crop_families[(sw, sh)] = images[idx].update_cropping((sw, sh), torch.stack((off_x, off_y), dim=1))
         return data, ImageData(list(crop_families.values()))
+
+
+# ---- transforms on the raw images that touch the mappings or the feature layout (reference :1163-1232) -----------
+
+class AddPixelHeightFeature(ImageTransform):
+    """Append the normalised pixel height as an image channel (:1163-1176)."""
+
+    def _process(self, data, images):
+        b, _, h, w = images.x.shape
+        feat = torch.linspace(0, 1, h, device=images.x.device).float().view(1, 1, h, 1).repeat(b, 1, 1, w)
+        images.x = torch.cat((images.x, feat), 1)
+        return data, images
+
+
+class AddPixelWidthFeature(ImageTransform):
+    """Append the normalised pixel width as an image channel (:1179-1192)."""
+
+    def _process(self, data, images):
+        b, _, h, w = images.x.shape
+        feat = torch.linspace(0, 1, w, device=images.x.device).float().view(1, 1, 1, w).repeat(b, 1, h, 1)
+        images.x = torch.cat((images.x, feat), 1)
+        return data, images
+
+
+class RandomHorizontalFlip(ImageTransform):
+    """Flip images AND the mapped pixel columns with probability ``p`` (:1195-1218); the draw is the reference's
+    ``torch.rand(1) <= p`` on the host generator."""
+
+    def __init__(self, p=0.50):
+        self.p = p
+
+    def _process(self, data, images):
+        if torch.rand(1) <= self.p:
+            images.x = torch.flip(images.x, [3])
+            width = images.x.shape[-1]
+            pix = images.mappings.pixels
+            pix[:, 0] = (width - 1 - pix[:, 0].long()).to(pix.dtype)
+        return data, images
+
+
+class ToFloatImage(ImageTransform):
+    """[0, 255] uint8 images -> [0, 1] float tensors (:1221-1232)."""
+
+    def _process(self, data, images):
+        images.x = images.x.float() / 255
+        return data, images

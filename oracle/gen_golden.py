@@ -715,6 +715,16 @@ def gen_transforms():
     for gi, g_sd in enumerate(picked):
         res.update({f"mc{gi}_pos": g_sd.pos, f"mc{gi}_crop_size": np.array(g_sd.crop_size)})
         res.update(_mapping_arrays(f"mc{gi}_", g_sd.mappings))
+    # ---- transforms on the raw images that touch the mappings / the channel layout (:1163-1232), two images
+    sdf = fresh()[torch.LongTensor([0, 3])]
+    torch.manual_seed(3)
+    _, sdf = T.RandomHorizontalFlip(p=1.0)(data, sdf)
+    res.update(flip_x=sdf.x)
+    res.update(_mapping_arrays("flip_", sdf.mappings))
+    _, sdf = T.ToFloatImage()(data, sdf)
+    _, sdf = T.AddPixelHeightFeature()(data, sdf)
+    _, sdf = T.AddPixelWidthFeature()(data, sdf)
+    res.update(feat_x=sdf.x[:, :, ::4, ::4])       # sub-sampled: the added channels are linear ramps
     save("transforms", **res)
 
 

@@ -112,3 +112,23 @@ def test_crop_image_groups_and_memory_credit_match_reference():
         assert tuple(sd.crop_size) == tuple(int(v) for v in g[f"mc{gi}_crop_size"])
         eq(sd.pos, g[f"mc{gi}_pos"])
         mapping_equals(sd.mappings, g, f"mc{gi}_")
+
+
+def test_flip_and_pixel_feature_transforms_match_reference():
+    from deepviewagg_amd.core.data_transform.multimodal.image import (RandomHorizontalFlip, ToFloatImage,
+                                                                      AddPixelHeightFeature, AddPixelWidthFeature)
+    g = load_golden("transforms")
+    N = int(g["num_points"])
+    data = Data(pos=torch.zeros(N, 3, device=DEV), mapping_index=torch.arange(N, device=DEV), num_nodes=N)
+    sd = fresh(g)[torch.tensor([0, 3], device=DEV)]
+    _, sd = RandomHorizontalFlip(p=1.0)(data, sd)
+    eq(sd.x, g["flip_x"])
+    mapping_equals(sd.mappings, g, "flip_")
+    for tr in (ToFloatImage(), AddPixelHeightFeature(), AddPixelWidthFeature()):
+        _, sd = tr(data, sd)
+    np.testing.assert_allclose(sd.x[:, :, ::4, ::4].cpu().numpy(), g["feat_x"], rtol=0, atol=1e-7)
+    # p = 0: nothing moves
+    sd0 = fresh(g)
+    before = sd0.mappings.pixels.clone()
+    _, sd0 = RandomHorizontalFlip(p=0.0)(data, sd0)
+    assert torch.equal(sd0.mappings.pixels, before)
