@@ -45,8 +45,9 @@ enum {
 };
 
 // per-layer constant table in LDS, accumulator-permuted (index 16 h + r <-> channel chan(r, h)):
-//   G = gamma * invstd | B = beta - mean * G | I = invstd | M = -mean * invstd | S1 = S1/M | S2 = S2/M
-enum { T_G = 0, T_B = 1, T_I = 2, T_M = 3, T_S1 = 4, T_S2 = 5, T_ROWS = 6 };
+//   G = gamma * invstd | B = beta - mean * G | I = invstd | M = -mean * invstd | S1 = S1/M | S2 = S2/M |
+//   G6 = 0.6 G | B6 = 0.6 B  (activation rows: leaky(y) = 0.6 y + 0.4 |y| = t + 2/3 |t| with t = 0.6 y)
+enum { T_G = 0, T_B = 1, T_I = 2, T_M = 3, T_S1 = 4, T_S2 = 5, T_G6 = 6, T_B6 = 7, T_ROWS = 8 };
 constexpr int TAB_FLOATS = T_ROWS * D;
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -250,33 +251,35 @@ __device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ 
     tab[T_M * D + i] = -mean * inv;
     tab[T_S1 * D + i] = sm ? sm[c] : 0.f;
     tab[T_S2 * D + i] = sm ? sm[D + c] : 0.f;
+    tab[T_G6 * D + i] = 0.6f * g;
+    tab[T_B6 * D + i] = 0.6f * (bet - mean * g);
   }
 }
 
-// forward-only variant: rows G | B
+// forward-only variant: two rows, 0.6 G | 0.6 B (act_pack with rg = 0, rb = 1)
 __device__ __forceinline__ void stage_tab_fwd(float* tab, const float* __restrict__ bn) {
   for (int i = threadIdx.x; i < D; i += blockDim.x) {
     const int c = chan(i & 15, i >> 4);
     const float g = bn[2 * D + c] * bn[D + c];
-    tab[T_G * D + i] = g;
-    tab[T_B * D + i] = bn[3 * D + c] - bn[c] * g;
+    tab[0 * D + i] = 0.6f * g;
+    tab[1 * D + i] = 0.6f * (bn[3 * D + c] - bn[c] * g);
   }
 }
 
-// y = z * G + B (BatchNorm), a = leaky(y), packed as the B operand of the next layer.  keep = 0 zeroes the
-// operand of a lane without a view.  The LDS reads stay inside the tile loop (asm barrier): hoisting 32
-// constants per layer into registers costs an occupancy step.
+// BatchNorm + LeakyReLU(0.2) + bf16 packing as the B operand of the next layer, two VALU operations per value:
+//   t = z * (0.6 G) + 0.6 B = 0.6 y;   leaky(y) = 0.6 y + 0.4 |y| = t + (2/3) |t|   (one fma with an |.| modifier)
+// keep = 0 zeroes the operand of a lane without a view.  The LDS reads stay inside the tile loop (asm barrier):
+// hoisting 32 constants per layer into registers costs an occupancy step.
 __device__ __forceinline__ void act_pack(const f32x16& z, const float* tab, int h, uint32_t keep, bf16x8 (&a)[2],
-                                         float* y_out = nullptr) {
+                                         int rg = T_G6, int rb = T_B6) {
   asm volatile("" ::: "memory");
   float g[16], b[16], av[16];
-  tab16(tab, T_G, h, g);
-  tab16(tab, T_B, h, b);
+  tab16(tab, rg, h, g);
+  tab16(tab, rb, h, b);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float y = __builtin_fmaf(z[r], g[r], b[r]);
-    if (y_out) y_out[r] = y;
-    av[r] = leaky(y);
+    const float t = __builtin_fmaf(z[r], g[r], b[r]);
+    av[r] = __builtin_fmaf(__builtin_fabsf(t), 0.6666667f, t);
   }
   a[0] = mask8(pack8(&av[0]), keep);
   a[1] = mask8(pack8(&av[8]), keep);

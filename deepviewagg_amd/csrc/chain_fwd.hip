@@ -463,13 +463,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     bf16x8 a[2], a2[2];
     asm volatile("" ::: "memory");
     f32x16 z = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
-    act_pack(z, s_tab[0], h, keep, a);
+    act_pack(z, s_tab[0], h, keep, a, 0, 1);
     z = mm32_lds(s_ops, OP_W2, lane, a, zero);
-    act_pack(z, s_tab[1], h, keep, a2);
+    act_pack(z, s_tab[1], h, keep, a2, 0, 1);
     z = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
-    act_pack(z, s_tab[2], h, keep, a);
+    act_pack(z, s_tab[2], h, keep, a, 0, 1);
     z = mm32_lds(s_ops, OP_W6, lane, a, zero);
-    act_pack(z, s_tab[3], h, keep, a2);
+    act_pack(z, s_tab[3], h, keep, a2, 0, 1);
     z = mm32_lds(s_ops, OP_WS, lane, a2, zero);
     float c[NE];
     if constexpr (G == 4) {
