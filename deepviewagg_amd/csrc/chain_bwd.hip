@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     int n_pt = sg.se - sg.ss + 1;
     if (frag != 0) n_pt = (int)(ptr[vp0 + 1] - ptr[vp0]);
     const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
+    const float isl = isn * 1.44269504f;        // exp(x isn) = exp2(x isl)
     auto red_max = [&](float v) { return single ? half_max(v) : seg_total(seg_scan_max(v, sg, lane), sg, h); };
     auto red_sum = [&](float v) { return single ? half_sum(v) : seg_total(seg_scan_sum(v, sg, lane), sg, h); };
     if (frag == 1) {
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         m_run[e] = half_max(ok ? c[e] : -INFINITY);
-        s_run[e] = half_sum(ok ? __expf((c[e] - m_run[e]) * isn) : 0.f);
+        s_run[e] = half_sum(ok ? __builtin_amdgcn_exp2f((c[e] - m_run[e]) * isl) : 0.f);
         seen[e] = false;
       }
       for (int t2 = p.t + 1;; ++t2) {
@@ -290,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
         scores(mm32_lds(s_ops, OP_WS, lane, k2.a6, zero), c2);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-          const float m2 = fmaxf(m_run[e], half_max(ok2 ? c2[e] : -INFINITY));
-          s_run[e] = s_run[e] * __expf((m_run[e] - m2) * isn) + half_sum(ok2 ? __expf((c2[e] - m2) * isn) : 0.f);
+          const float m2 = vmaxf(m_run[e], half_max(ok2 ? c2[e] : -INFINITY));
+          s_run[e] = s_run[e] * __builtin_amdgcn_exp2f((m_run[e] - m2) * isl) + half_sum(ok2 ? __builtin_amdgcn_exp2f((c2[e] - m2) * isl) : 0.f);
           m_run[e] = m2;
         }
         if (t2i.frag == 3) break;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       for (int e = 0; e < NE; ++e) {
         glob_m[e] = m_run[e];
         glob_s[e] = s_run[e];
-        const float gt0 = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m_run[e], gbl[e]), 0.f)) : 1.f;
+        const float gt0 = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m_run[e], gbl[e]), 0.f)) : 1.f;
         glob_E[e] = gt0 > 0.f ? s_E[wv][gl[e]] / gt0 : 0.f;
       }
     }
@@ -319,12 +320,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       float s;
       if (frag == 0) {
         m[e] = red_max(ok ? c[e] : -INFINITY);
-        const float ev = ok ? __expf((c[e] - m[e]) * isn) : 0.f;
+        const float ev = ok ? __builtin_amdgcn_exp2f((c[e] - m[e]) * isl) : 0.f;
         s = red_sum(ev);
         a[e] = ev * __builtin_amdgcn_rcpf(s + eps);
       } else {
         m[e] = glob_m[e];
-        a[e] = ok ? __expf((c[e] - m[e]) * isn) * __builtin_amdgcn_rcpf(glob_s[e] + eps) : 0.f;
+        a[e] = ok ? __builtin_amdgcn_exp2f((c[e] - m[e]) * isl) * __builtin_amdgcn_rcpf(glob_s[e] + eps) : 0.f;
       }
       pre[e] = __builtin_fmaf(gwl[e], m[e], gbl[e]);
       gt[e] = gw ? tanh_pos(fmaxf(pre[e], 0.f)) : 1.f;

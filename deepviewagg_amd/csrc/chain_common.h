@@ -87,6 +87,12 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// plain v_max_f32: fmaxf() makes hipcc quiet both operands first (v_max x, x) -- three instructions for one
+__device__ __forceinline__ float vmaxf(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float leaky(float y) { return fmaxf(y, SLOPE * y); }
 __device__ __forceinline__ float dleaky(float y) { return y > 0.f ? 1.f : SLOPE; }
 
@@ -377,7 +383,7 @@ __device__ __forceinline__ float seg_scan_max(float v, const SegInfo& s, int lan
 #pragma unroll
   for (int o = 0; o < 5; ++o) {
     const float t = shfl(v, lane - (1 << o));
-    v = s.same[o] ? fmaxf(v, t) : v;
+    v = s.same[o] ? vmaxf(v, t) : v;
   }
   return v;
 }
@@ -410,21 +416,33 @@ __device__ __forceinline__ float half_allreduce(float v, Op op) {
   const u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
   return op(__uint_as_float(r.x), __uint_as_float(r.y));
 }
+// max: fmaxf() makes hipcc quiet both operands first (v_max x, x) and keeps the DPP move separate -- five
+// instructions per step; the DPP form of v_max_f32 is written out (hipcc pads nothing inside asm: the two wait states
+// a DPP read needs after a VALU write of its source are the leading s_nop)
+#define DVA_MAX_DPP(ctrl)                                                                          \
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); \
+  v = r;
 __device__ __forceinline__ float half_max(float v) {
-  return half_allreduce(v, [](float a, float b) { return fmaxf(a, b); });
+  float r;
+  DVA_MAX_DPP("quad_perm:[1,0,3,2]")
+  DVA_MAX_DPP("quad_perm:[2,3,0,1]")
+  DVA_MAX_DPP("row_half_mirror")
+  DVA_MAX_DPP("row_mirror")
+  asm volatile("s_nop 1" ::: );
+  const uint32_t x = __float_as_uint(v);
+  const u32x2 sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return vmaxf(__uint_as_float(sw.x), __uint_as_float(sw.y));
 }
+#undef DVA_MAX_DPP
 __device__ __forceinline__ float half_sum(float v) {
   return half_allreduce(v, [](float a, float b) { return a + b; });
 }
 
-// tanh for x >= 0 (the gate is tanh(relu(.))): odd polynomial below 0.1, (e^2x - 1) / (e^2x + 1) above
+// tanh for x >= 0 (the gate is tanh(relu(.))): 1 - 2 / (e^2x + 1), absolute error ~1e-7 (the result multiplies
+// features that are stored in bf16); e^2x = inf gives exactly 1
 __device__ __forceinline__ float tanh_pos(float x) {
-  x = fminf(x, 20.f);
-  const float x2 = x * x;
-  const float small = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
-  const float t = __expf(2.f * x);
-  const float big = (t - 1.f) * __builtin_amdgcn_rcpf(t + 1.f);
-  return x < 0.1f ? small : big;
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(t + 1.f), 1.f);
 }
 
 }  // namespace chain

@@ -501,24 +501,24 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
       // ================= one point in the tile (32-views-per-point scenes, fragments of long points) ==========
       int n_pt = nv;
       if (frag != 0) n_pt = (int)(ptr[vp0 + 1] - ptr[vp0]);
-      const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
+      const float isn = (scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f) * 1.44269504f;   // x log2(e)
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         float m = half_max(ok ? c[e] : -INFINITY);
         float alpha = 0.f;
         if (frag != 0) {           // online softmax across the fragments
-          const float m_new = fmaxf(run_m[e], m);
-          alpha = __expf((run_m[e] - m_new) * isn);   // first fragment: run_m = -inf -> 0
+          const float m_new = vmaxf(run_m[e], m);
+          alpha = __builtin_amdgcn_exp2f((run_m[e] - m_new) * isn);   // first fragment: run_m = -inf -> 0
           m = m_new;
         }
-        const float ev = ok ? __expf((c[e] - m) * isn) : 0.f;
+        const float ev = ok ? __builtin_amdgcn_exp2f((c[e] - m) * isn) : 0.f;
         float s = half_sum(ev);
         if (frag != 0) {
           s = run_s[e] * alpha + s;
           run_s[e] = frag == 3 ? 0.f : s;
           run_m[e] = frag == 3 ? -INFINITY : m;
         }
-        const float gt = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+        const float gt = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
         if (s_active) {
           ev_t[gl[e] * 32 + j] = ev;
           if (j == 0) {
@@ -591,13 +591,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
       // partial sum to its private LDS row (plain stores: LDS float atomics cost 0.5 ms on the ragged workload),
       // the slot the point ends in adds the rows of the slots before it and stores.
       const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
-      const float isn = scaling ? __builtin_amdgcn_rsqf((float)(sg.se - sg.ss + 1)) : 1.f;
+      const float isn = (scaling ? __builtin_amdgcn_rsqf((float)(sg.se - sg.ss + 1)) : 1.f) * 1.44269504f;
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const float m = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
-        const float ev = ok ? __expf((c[e] - m) * isn) : 0.f;
+        const float ev = ok ? __builtin_amdgcn_exp2f((c[e] - m) * isn) : 0.f;
         const float s = seg_total(seg_scan_sum(ev, sg, lane), sg, h);
-        const float gt = gw ? tanh_pos(fmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+        const float gt = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
         if (s_active) {
           ev_t[gl[e] * 32 + j] = ev;
           sc_t[gl[e] * 32 + j] = gt * __builtin_amdgcn_rcpf(s + eps);
