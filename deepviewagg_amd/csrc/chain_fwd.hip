@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void stats_mid_kernel(
 // [ROWS][C] LDS buffer keyed by the slot it starts in (each slot starts at most one split point) and stored by
 // the slot it ends in.
 template <int LPR, int G>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
+__global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -785,7 +785,7 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
       n_points * C * 2 > 0xfffffff0ll)
     return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(3)), block(256);
+  const dim3 grid(chain_grid(C <= 64 ? 4 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_ATTN_FWD(LPR_, G_)                                                                                  \
   hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, \
