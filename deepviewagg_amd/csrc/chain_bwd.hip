@@ -62,40 +62,38 @@ __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const 
   asm volatile("" ::: "memory");
   return CH_MFMA(lds_op(s_ops, OP_WST, lane), __builtin_bit_cast(bf16x8, v), zero);
 }
-// One BatchNorm + LeakyReLU layer backwards: dy = leaky'(y) da; statistics (STATS) and / or
-// dz = G (dy - S1/M - z_hat S2/M) for the lanes that own a view (APPLY).
+// One BatchNorm + LeakyReLU layer backwards: dy = leaky'(y) da, then
+//   STATS: st[0] += dy, st[1] += dy * z   (the caller turns sum dy z into S2 = sum dy z_hat = I (sum dy z - mean S1))
+//   APPLY: dz = G (dy - S1/M - z_hat S2/M) = G dy - K1 - K2 z   (lanes without a view: masked when packed)
+// six VALU operations per value each.
 template <bool STATS, bool APPLY>
 __device__ __forceinline__ void layer_bwd(const f32x16& z, const f32x16& da, const float* tab, int h, bool ok,
                                           float (&st)[2][16], float (&dz)[16]) {
   asm volatile("" ::: "memory");
-  // four channels at a time: 6 float4 of constants live instead of 96 registers
+  // four channels at a time: a few float4 of constants live instead of 64+ registers
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int o = 16 * h + 4 * q;
     const float4 g4 = *reinterpret_cast<const float4*>(tab + T_G * D + o);
     const float4 b4 = *reinterpret_cast<const float4*>(tab + T_B * D + o);
-    const float4 i4 = *reinterpret_cast<const float4*>(tab + T_I * D + o);
-    const float4 m4 = *reinterpret_cast<const float4*>(tab + T_M * D + o);
     const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-    const float iv[4] = {i4.x, i4.y, i4.z, i4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float k1[4] = {0.f, 0.f, 0.f, 0.f}, k2[4] = {0.f, 0.f, 0.f, 0.f};
     if (APPLY) {
-      const float4 a4 = *reinterpret_cast<const float4*>(tab + T_S1 * D + o);
-      const float4 c4 = *reinterpret_cast<const float4*>(tab + T_S2 * D + o);
-      s1[0] = a4.x; s1[1] = a4.y; s1[2] = a4.z; s1[3] = a4.w;
-      s2[0] = c4.x; s2[1] = c4.y; s2[2] = c4.z; s2[3] = c4.w;
+      const float4 a4 = *reinterpret_cast<const float4*>(tab + T_K1 * D + o);
+      const float4 c4 = *reinterpret_cast<const float4*>(tab + T_K2 * D + o);
+      k1[0] = a4.x; k1[1] = a4.y; k1[2] = a4.z; k1[3] = a4.w;
+      k2[0] = c4.x; k2[1] = c4.y; k2[2] = c4.z; k2[3] = c4.w;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int r = 4 * q + e;
       const float y = __builtin_fmaf(z[r], g[e], b[e]);
-      const float dy = da[r] * dleaky(y);
-      const float zh = __builtin_fmaf(z[r], iv[e], mm[e]);
+      const float dy = y > 0.f ? da[r] : SLOPE * da[r];
       if (STATS) {
         st[0][r] += dy;
-        st[1][r] = __builtin_fmaf(dy, zh, st[1][r]);
+        st[1][r] = __builtin_fmaf(dy, z[r], st[1][r]);
       }
-      if (APPLY) dz[r] = g[e] * (dy - s1[e] - zh * s2[e]);   // lanes without a view: masked when packed
+      if (APPLY) dz[r] = __builtin_fmaf(-k2[e], z[r], __builtin_fmaf(g[e], dy, -k1[e]));
     }
   }
 }

@@ -45,9 +45,10 @@ enum {
 };
 
 // per-layer constant table in LDS, accumulator-permuted (index 16 h + r <-> channel chan(r, h)):
-//   G = gamma * invstd | B = beta - mean * G | I = invstd | M = -mean * invstd | S1 = S1/M | S2 = S2/M |
+//   G = gamma * invstd | B = beta - mean * G | I = invstd | M = -mean * invstd |
+//   K1 = G (S1/M + M S2/M) | K2 = G I S2/M   (BatchNorm backward dz = G dy - K1 - K2 z) |
 //   G6 = 0.6 G | B6 = 0.6 B  (activation rows: leaky(y) = 0.6 y + 0.4 |y| = t + 2/3 |t| with t = 0.6 y)
-enum { T_G = 0, T_B = 1, T_I = 2, T_M = 3, T_S1 = 4, T_S2 = 5, T_G6 = 6, T_B6 = 7, T_ROWS = 8 };
+enum { T_G = 0, T_B = 1, T_I = 2, T_M = 3, T_K1 = 4, T_K2 = 5, T_G6 = 6, T_B6 = 7, T_ROWS = 8 };
 constexpr int TAB_FLOATS = T_ROWS * D;
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -255,8 +256,9 @@ __device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ 
     tab[T_B * D + i] = bet - mean * g;
     tab[T_I * D + i] = inv;
     tab[T_M * D + i] = -mean * inv;
-    tab[T_S1 * D + i] = sm ? sm[c] : 0.f;
-    tab[T_S2 * D + i] = sm ? sm[D + c] : 0.f;
+    const float s1 = sm ? sm[c] : 0.f, s2 = sm ? sm[D + c] : 0.f;
+    tab[T_K1 * D + i] = g * (s1 - mean * inv * s2);
+    tab[T_K2 * D + i] = g * inv * s2;
     tab[T_G6 * D + i] = 0.6f * g;
     tab[T_B6 * D + i] = 0.6f * (bet - mean * g);
   }

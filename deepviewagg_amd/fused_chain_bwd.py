@@ -31,6 +31,11 @@ def backward(ctx, gout):
     def zstats():
         return next(zpool)
 
+    def to_hat(stats, bn):
+        """The kernels accumulate S1 = sum dy and sum dy z (raw layer output): S2 = sum dy z_hat =
+        invstd (sum dy z - mean S1), in place."""
+        stats[D:] = bn[1].double() * (stats[D:] - bn[0].double() * stats[:D])
+
     def sm_of(stats):
         if not training:
             return torch.zeros(2 * D, dtype=torch.float32, device=dev)
@@ -70,6 +75,7 @@ def backward(ctx, gout):
                   "dva_chain_bwd_layer")
 
     # per view: x_map 32 + view->point 4 (+ score gradients 16) + the 64-byte gradient row handed between the passes
+    to_hat(s6, bn6)
     sm6 = sm_of(s6)
     dW6 = torch.zeros((D, D), dtype=torch.float32, device=dev)
     dWs = torch.zeros((G, D), dtype=torch.float32, device=dev)
@@ -79,6 +85,7 @@ def backward(ctx, gout):
     layer(6, None, None, sm6, None, None, None, da5, dW6, dWs, dbs, None, None, s5, "chain_bwd_l6",
           V * (32 + 4 + 16 + 64) + N * 128)
     del dc
+    to_hat(s5, bn5)
     sm5 = sm_of(s5)
     dW5 = torch.zeros((D, 2 * D), dtype=torch.float32, device=dev)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
@@ -91,6 +98,7 @@ def backward(ctx, gout):
     # ---- per-point set branch
     dpooled, dWcB, d_set = _set_branch_backward(ctx.set_saved, du, training, zstats)
     dW5[:, D:] = dWcB
+    to_hat(s2, bn2)            # view part; the per-point part below is accumulated in z_hat directly
     check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), N, st),
           "dva_chain_route_stats")
     sm2 = sm_of(s2)
@@ -100,6 +108,7 @@ def backward(ctx, gout):
     layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, None, None, P, s1, "chain_bwd_l2",
           V * (32 + 4 + 64) + N * 256)
     del da2
+    to_hat(s1, bn1)
     sm1 = sm_of(s1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so
     #      dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q) with Q = sum_v z1_hat x^T from the moments of x_map
