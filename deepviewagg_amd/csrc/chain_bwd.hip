@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 // respect to the layer output crosses the BatchNorm barrier as one bf16 row per view (64 bytes), in the
 // accumulator order of the lane that wrote it: re-deriving it through the later layers cost 0.8 ms per pass.
 // ------------------------------------------------------------------------------------------------
-constexpr int TZB = 36;
 __device__ __forceinline__ void store_da(__amdgpu_buffer_rsrc_t R, bool ok, uint32_t view, int h, const f32x16& da) {
   float t[16];
 #pragma unroll
@@ -458,7 +457,9 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
   __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][32 * TSB];
-  __shared__ __attribute__((aligned(16))) float s_tz[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TZB : 4];
+  // STAGE 5: indicator tile [local point][view] (bf16 1.0 where the view belongs to the point) and the point ids
+  __shared__ __attribute__((aligned(16))) bf16_t s_ind[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TSB : 8];
+  __shared__ int s_plp[STAGE == 5 ? 4 : 1][32];
   __shared__ float s_red[D * D];
   // only the operands of the pass (LDS budget: three blocks per CU for stages 5 and 2):
   // stage 5: W1 W2 W5 | W5T -> local 5, 6;  stage 2: W1 W2 | W2T -> local 3, 4
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
   for (int i = threadIdx.x; i < 4 * 32 * TSB; i += blockDim.x) {
     if (STAGE != 5) (&s_td[0][0])[i] = 0;
+    else (&s_ind[0][0])[i] = 0;
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
@@ -490,12 +492,13 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
   f32x16 accW = {0}, accS = {0};      // layer weight gradient; dWs^T (STAGE 6) / P (STAGE 2)
   float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
-  float run_u = 0.f;                  // STAGE 5: running per-point sum of the walker lane
+  f32x16 accU = {0};                  // STAGE 5: per-point sums of dz5 (carried over the fragments of a long point)
   bf16_t* ta = s_ta[wv];
   bf16_t* tb_ = s_tb[wv];
   bf16_t* tc = s_tc[STAGE == 5 ? 0 : wv];
   bf16_t* td = s_td[STAGE == 5 ? 0 : wv];
-  float* tz = s_tz[STAGE == 5 ? wv : 0];
+  bf16_t* ind = s_ind[STAGE == 5 ? wv : 0];
+  int* plp = s_plp[STAGE == 5 ? wv : 0];
 
   const int n_tiles = n_tiles_dev[0];
   int t0, t1;
@@ -573,38 +576,34 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
       tileT_put_packed(tb_, j, h, a2);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq)
-        *reinterpret_cast<float4*>(tz + j * TZB + 8 * qq + 4 * h) =
-            make_float4(dz[4 * qq], dz[4 * qq + 1], dz[4 * qq + 2], dz[4 * qq + 3]);
+      // du[p][c] = sum of dz5 over the views of point p = dz5^T . indicator: one more product on the matrix cores
+      // (operands: the transposed dz5 tile and a [local point][view] indicator tile of 1.0 / 0)
+      const int prv = shfl(p.vpj, lane - 1);
+      const bool is_start = ok && (j == 0 || prv != p.vpj);
+      const uint32_t smask = (uint32_t)__ballot(is_start);
+      const int lpj = __popc(smask & (0xffffffffu >> (31 - j))) - 1;
+      const int nseg = __popc(smask);
+      if (h == 0 && ok) {
+        ind[lpj * TSB + j] = (bf16_t)0x3f80;
+        if (is_start) plp[lpj] = p.vpj;
+      }
       const f32x16 da2 = mm32_lds(s_ops, L_W5T, lane, dzp, zero);
       store_da(DO, ok, view, h, da2);
       layer_bwd<true, false>(z2, da2, s_tab[1], h, ok, st, dz);
-      const int nxt = shfl(p.vpj, lane + 1);
-      const bool is_end = ok && (j == nv - 1 || nxt != p.vpj);
-      uint32_t endmask = (uint32_t)__ballot(is_end);
-      if (p.ti.frag == 1 || p.ti.frag == 2) endmask = 0;
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
-      // du[p][c] = sum of dz5 over the views of the point: lane c walks the views of the tile
+      const int frag = p.ti.frag;
+      if (frag == 0 || frag == 1) accU = zero;
+      accU = wgrad(ta, ind, j, h, accU);      // du[c][local point j]
+      if (h == 0 && ok) ind[lpj * TSB + j] = 0;           // leave the indicator tile clean for the next tile
+      if (frag == 0 || frag == 3) {
+        const bool wr = j < nseg;
+        const uint32_t pt = wr ? (uint32_t)plp[j] : 0u;
+        const __amdgpu_buffer_rsrc_t DU = make_rsrc(du, (uint64_t)N * 128);
 #pragma unroll
-      for (int v0 = 0; v0 < 32; v0 += 8) {
-        if (v0 < nv) {
-          float xv[8];
-#pragma unroll
-          for (int v = 0; v < 8; ++v) xv[v] = tz[(v0 + v) * TZB + j];
-#pragma unroll
-          for (int v = 0; v < 8; ++v) {
-            if (v0 + v < nv) {
-              run_u += xv[v];
-              if ((endmask >> (v0 + v)) & 1u) {
-                const int pt = __builtin_amdgcn_readlane(p.vpj, v0 + v);
-                if (h == 0) du[(int64_t)pt * D + j] = run_u;
-                run_u = 0.f;
-              }
-            }
-          }
-        }
+        for (int qq = 0; qq < 4; ++qq)
+          st128(DU, wr ? pt * 128u + (8u * qq + 4u * h) * 4u : OOB,
+                as_u4(accU[4 * qq], accU[4 * qq + 1], accU[4 * qq + 2], accU[4 * qq + 3]));
       }
       wave_sync();
     } else {
