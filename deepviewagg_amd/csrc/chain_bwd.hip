@@ -62,82 +62,6 @@ __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const 
   asm volatile("" ::: "memory");
   return CH_MFMA(lds_op(s_ops, OP_WST, lane), __builtin_bit_cast(bf16x8, v), zero);
 }
-// One BatchNorm + LeakyReLU layer backwards: dy = leaky'(y) da, then
-//   STATS: st[0] += dy, st[1] += dy * z   (the caller turns sum dy z into S2 = sum dy z_hat = I (sum dy z - mean S1))
-//   APPLY: dz = G (dy - S1/M - z_hat S2/M) = G dy - K1 - K2 z   (lanes without a view: masked when packed)
-// six VALU operations per value each.
-template <bool STATS, bool APPLY>
-__device__ __forceinline__ void layer_bwd(const f32x16& z, const f32x16& da, const float* tab, int h, bool ok,
-                                          float (&st)[2][16], float (&dz)[16]) {
-  asm volatile("" ::: "memory");
-  // four channels at a time: a few float4 of constants live instead of 64+ registers
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int o = 16 * h + 4 * q;
-    const float4 g4 = *reinterpret_cast<const float4*>(tab + T_G * D + o);
-    const float4 b4 = *reinterpret_cast<const float4*>(tab + T_B * D + o);
-    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-    float k1[4] = {0.f, 0.f, 0.f, 0.f}, k2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (APPLY) {
-      const float4 a4 = *reinterpret_cast<const float4*>(tab + T_K1 * D + o);
-      const float4 c4 = *reinterpret_cast<const float4*>(tab + T_K2 * D + o);
-      k1[0] = a4.x; k1[1] = a4.y; k1[2] = a4.z; k1[3] = a4.w;
-      k2[0] = c4.x; k2[1] = c4.y; k2[2] = c4.z; k2[3] = c4.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = 4 * q + e;
-      const float y = __builtin_fmaf(z[r], g[e], b[e]);
-      const float dy = y > 0.f ? da[r] : SLOPE * da[r];
-      if (STATS) {
-        st[0][r] += dy;
-        st[1][r] = __builtin_fmaf(dy, z[r], st[1][r]);
-      }
-      if (APPLY) dz[r] = __builtin_fmaf(-k2[e], z[r], __builtin_fmaf(g[e], dy, -k1[e]));
-    }
-  }
-}
-__device__ __forceinline__ void pack16(const float (&x)[16], uint32_t keep, bf16x8 (&a)[2]) {
-  a[0] = mask8(pack8(&x[0]), keep);
-  a[1] = mask8(pack8(&x[8]), keep);
-}
-// packed activation (k-slot s of block m = accumulator register 8m + s) -> transposed tile
-__device__ __forceinline__ void tileT_put_packed(bf16_t* tile, int v, int h, const bf16x8 (&a)[2]) {
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const u32x4 w = __builtin_bit_cast(u32x4, a[m]);
-    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      tile[chan(8 * m + 2 * i, h) * TSB + v] = (bf16_t)(ww[i] & 0xffffu);
-      tile[chan(8 * m + 2 * i + 1, h) * TSB + v] = (bf16_t)(ww[i] >> 16);
-    }
-  }
-}
-// weight gradient of one layer: acc[r] += sum_v A[chan(r, h)][v] B[j][v] from two transposed tiles
-__device__ __forceinline__ f32x16 wgrad(const bf16_t* ta, const bf16_t* tb, int j, int h, f32x16 acc) {
-  acc = CH_MFMA(tileT_get(ta, j, h, 0), tileT_get(tb, j, h, 0), acc);
-  acc = CH_MFMA(tileT_get(ta, j, h, 1), tileT_get(tb, j, h, 1), acc);
-  return acc;
-}
-// acc[r] = M[chan(r, h)][j] of every wavefront -> out[row * ld + col] (fp32 atomics), cols < ncol only
-__device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restrict__ out, int ld, int ncol,
-                                             bool transpose, float* s_red) {
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  __syncthreads();
-  for (int i = threadIdx.x; i < D * D; i += blockDim.x) s_red[i] = 0.f;
-  __syncthreads();
-  if (j < ncol) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(&s_red[chan(r, h) * D + j], acc[r]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
-    const int row = i / D, col = i % D;
-    if (col < ncol) atomicAdd(&out[transpose ? col * ld + row : row * ld + col], s_red[i]);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // attention backward
 // ------------------------------------------------------------------------------------------------

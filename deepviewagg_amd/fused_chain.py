@@ -10,7 +10,7 @@ the per-view records of the rows gradient.  Train-mode BatchNorm keeps one stati
 
 Selected by ``pooling.GroupBimodalCSRPool`` inside ``torch.autocast(bfloat16)`` (or with ``FORCE = True``)
 when ``applicable`` holds; everything else takes the fp32 kernels of ``fused_deepset`` / ``ops``.
-The per-point set branch (``mlp_set`` on N rows) runs through the fp32 layer kernels of ``csrc/deepset_mfma.hip``.
+The per-point set branch (``mlp_set`` on N rows) runs on the same kind of kernels (``csrc/chain_set.hip``).
 """
 import torch
 
@@ -69,49 +69,50 @@ def build_tiles(csr_idx, V):
     return tiles, n_tiles
 
 
+SET_OPS_BYTES = 24 * 64 * 16
+
+
 def _set_branch_forward(e_map, pooled, csr_idx, training, zstats):
-    """mlp_set on the N points + the per-point half of the concatenation layer, fp32 layer kernels
-    (the set-size column of use_num enters as a rank-1 per-row addend).  Returns (t_add, saved)."""
+    """mlp_set on the N points + the per-point half of the concatenation layer on the chain kernels of
+    csrc/chain_set.hip (every pass re-evaluates the branch from ``pooled``).  Returns (t_add, saved)."""
     lib = _lib.load()
     dev, N = pooled.device, pooled.shape[0]
     st = stream_of(pooled)
-    F32C = _lib.DVA_F32
     mlp_set = e_map.mlp_set
-    Wc = e_map.mlp_elt_2[0][0].weight.detach()
-    Wsa_full = mlp_set[0][0].weight.detach()
-    WsaP = Wsa_full[:, :D].contiguous()
+    Wc = e_map.mlp_elt_2[0][0].weight.detach().contiguous()
+    Wsa = mlp_set[0][0].weight.detach().contiguous()               # [32, 32 (+ 1 with use_num)]
     Wsb = mlp_set[1][0].weight.detach().contiguous()
-    WcB = Wc[:, D:].contiguous()
     set_bns = [_bn_of(mlp_set[0]), _bn_of(mlp_set[1])]
-    num = add1 = ident_idx = None
-    if e_map.use_num:
-        sizes = csr_idx[1:] - csr_idx[:-1]
-        num = torch.sqrt(1 / (sizes + 1e-3)).float()
-        add1 = (num.view(-1, 1) * Wsa_full[:, D].view(1, -1)).contiguous()
-        ident_idx = torch.arange(N, dtype=torch.int32, device=dev)
-    u1, su1 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
-    check(lib.dva_deepset_fwd_layer(ptr(pooled), None, ptr(WsaP), ptr(add1), ptr(ident_idx), ptr(u1), ptr(su1),
-                                    N, 0, F32C, st), "dva_deepset_fwd_layer")
+    w33 = Wsa[:, D].contiguous() if e_map.use_num else None
+    sops = torch.empty(SET_OPS_BYTES, dtype=torch.uint8, device=dev)
+    check(lib.dva_chain_set_prep(ptr(Wsa), Wsa.shape[1], ptr(Wsb), ptr(Wc), Wc.shape[1], ptr(sops), st),
+          "dva_chain_set_prep")
+    su1, su2 = zstats(), zstats()
+    if training:
+        check(lib.dva_chain_set_fwd(1, ptr(pooled), ptr(csr_idx), ptr(w33), ptr(sops), None, None, None, ptr(su1), N,
+                                    st), "dva_chain_set_fwd")
     bns1 = _bn_consts(su1, N, set_bns[0], training)
-    u2, su2 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
-    check(lib.dva_deepset_fwd_layer(ptr(u1), ptr(bns1), ptr(Wsb), None, None, ptr(u2), ptr(su2), N, 0, F32C, st),
-          "dva_deepset_fwd_layer")
+    if training:
+        check(lib.dva_chain_set_fwd(2, ptr(pooled), ptr(csr_idx), ptr(w33), ptr(sops), ptr(bns1), None, None,
+                                    ptr(su2), N, st), "dva_chain_set_fwd")
     bns2 = _bn_consts(su2, N, set_bns[1], training)
-    t_add, su3 = torch.empty((N, D), dtype=torch.float32, device=dev), zstats()
-    check(lib.dva_deepset_fwd_layer(ptr(u2), ptr(bns2), ptr(WcB), None, None, ptr(t_add), ptr(su3), N, 0, F32C, st),
-          "dva_deepset_fwd_layer")
-    return t_add, (pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx)
+    t_add = torch.empty((N, D), dtype=torch.float32, device=dev)
+    check(lib.dva_chain_set_fwd(3, ptr(pooled), ptr(csr_idx), ptr(w33), ptr(sops), ptr(bns1), ptr(bns2), ptr(t_add),
+                                None, N, st), "dva_chain_set_fwd")
+    return t_add, (pooled, csr_idx, w33, sops, bns1, bns2, tuple(Wsa.shape))
 
 
-def _set_branch_backward(saved, dt, training, zstats):
-    """Backward of _set_branch_forward: dt [N, 32] = gradient of t_add.  Returns (dpooled, dWcB, d_set) with
-    d_set = gradients of list(mlp_set.parameters())."""
+def _set_branch_backward(saved, dt, dWc, training, zstats):
+    """Backward of _set_branch_forward: dt [N, 32] = gradient of t_add.  d Wc[:, 32:] is accumulated into ``dWc``
+    [32, 64] in place.  Returns (dpooled, d_set) with d_set = gradients of list(mlp_set.parameters())."""
     lib = _lib.load()
-    pooled, u1, u2, t_add, bns1, bns2, WsaP, Wsb, WcB, num, ident_idx = saved
+    pooled, csr_idx, w33, sops, bns1, bns2, wsa_shape = saved
     dev, N = pooled.device, pooled.shape[0]
     st = stream_of(pooled)
-    F32C = _lib.DVA_F32
     n_rows = float(max(N, 1))
+
+    def to_hat(stats, bn):
+        stats[D:] = bn[1].double() * (stats[D:] - bn[0].double() * stats[:D])
 
     def sm_of(stats):
         if not training:
@@ -120,36 +121,23 @@ def _set_branch_backward(saved, dt, training, zstats):
         check(lib.dva_scale_f64(ptr(stats), 1.0 / n_rows, ptr(out), 2 * D, st), "dva_scale_f64")
         return out
 
-    def buf():
-        return torch.empty((N, D), dtype=torch.float32, device=dev)
-
-    ident_bn = torch.zeros(4 * D, dtype=torch.float32, device=dev)   # mean 0 | invstd 1 | gamma 1 | beta 0
-    ident_bn[D:3 * D] = 1.0
-    zero_sm = torch.zeros(2 * D, dtype=torch.float32, device=dev)
-    dWcB = torch.zeros_like(WcB)
-    dzs2, ss2 = buf(), zstats()
-    check(lib.dva_deepset_bwd_layer(ptr(dt), ptr(t_add), ptr(ident_bn), ptr(zero_sm), ptr(WcB), ptr(u2), None,
-                                    ptr(bns2), ptr(dzs2), ptr(dWcB), ptr(ss2), None, None, None, None, N, 0, 0, 0,
-                                    F32C, st), "dva_deepset_bwd_layer")
-    dWsb = torch.zeros_like(Wsb)
-    dzs1, ss1 = buf(), zstats()
+    def call(stage, sm1, sm2, dpooled, dW, ld, dw33, stats):
+        check(lib.dva_chain_set_bwd(stage, ptr(pooled), ptr(csr_idx), ptr(w33), ptr(sops), ptr(bns1), ptr(bns2),
+                                    ptr(sm1), ptr(sm2), ptr(dt), ptr(dpooled), ptr(dW), ld, ptr(dw33), ptr(stats),
+                                    N, st), "dva_chain_set_bwd")
+    ss2, ss1 = zstats(), zstats()
+    call(1, None, None, None, dWc[:, D:], dWc.shape[1], None, ss2)
+    to_hat(ss2, bns2)
     sms2 = sm_of(ss2)
-    check(lib.dva_deepset_bwd_layer(ptr(dzs2), ptr(u2), ptr(bns2), ptr(sms2), ptr(Wsb), ptr(u1), None,
-                                    ptr(bns1), ptr(dzs1), ptr(dWsb), ptr(ss1), None, None, None, None, N, 0, 0, 0,
-                                    F32C, st), "dva_deepset_bwd_layer")
-    dWsaP = torch.zeros_like(WsaP)
-    dpooled = buf()
-    da1 = torch.zeros((N, D), dtype=torch.float32, device=dev) if num is not None else None
+    dWsb = torch.zeros((D, D), dtype=torch.float32, device=dev)
+    call(2, None, sms2, None, dWsb, D, None, ss1)
+    to_hat(ss1, bns1)
     sms1 = sm_of(ss1)
-    check(lib.dva_deepset_bwd_layer(ptr(dzs1), ptr(u1), ptr(bns1), ptr(sms1), ptr(WsaP), ptr(pooled), None,
-                                    None, ptr(dpooled), ptr(dWsaP), None, ptr(da1), ptr(ident_idx), None, None, N, 0,
-                                    1, 0, F32C, st), "dva_deepset_bwd_layer")
-    if num is not None:
-        dWsa = torch.cat([dWsaP, (da1 * num.view(-1, 1)).sum(0).view(-1, 1)], dim=1)
-    else:
-        dWsa = dWsaP
+    dWsa = torch.zeros(wsa_shape, dtype=torch.float32, device=dev)
+    dpooled = torch.empty((N, D), dtype=torch.float32, device=dev)
+    call(3, sms1, sms2, dpooled, dWsa, wsa_shape[1], dWsa[:, D:] if w33 is not None else None, None)
     d_set = [dWsa, ss1[D:].float(), ss1[:D].float(), dWsb, ss2[D:].float(), ss2[:D].float()]
-    return dpooled, dWcB, d_set
+    return dpooled, d_set
 
 
 class _ChainPool(torch.autograd.Function):

@@ -96,8 +96,7 @@ def backward(ctx, gout):
           V * (32 + 4 + 64 + 64) + N * 256)
     del da5
     # ---- per-point set branch
-    dpooled, dWcB, d_set = _set_branch_backward(ctx.set_saved, du, training, zstats)
-    dW5[:, D:] = dWcB
+    dpooled, d_set = _set_branch_backward(ctx.set_saved, du, dW5, training, zstats)
     to_hat(s2, bn2)            # view part; the per-point part below is accumulated in z_hat directly
     check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), N, st),
           "dva_chain_route_stats")

@@ -325,7 +325,8 @@ int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* s
  * mapping features inside the kernel (v_mfma_f32_32x32x16_bf16, layers chained in registers).  Train-mode
  * BatchNorm keeps its global barriers: one statistics pass per V-level BatchNorm layer (forward) and per
  * BatchNorm-backward (backward); in eval mode the forward is dva_chain_stats2 (set pooling) +
- * dva_chain_attn_fwd.  Operands are rounded to bf16 (what torch.autocast(bfloat16) feeds the reference's
+ * dva_chain_attn_fwd.  All backward statistics ("stats" of the *_bwd entries) are S1 = sum dy | sum dy z with z the RAW
+ * layer output: S2 = sum dy z_hat = invstd (sum dy z - mean S1) is the caller's one-liner.  Operands are rounded to bf16 (what torch.autocast(bfloat16) feeds the reference's
  * Linear layers), accumulation / BatchNorm / softmax / statistics are fp32 / fp64.
  * Views are processed in TILES of <= 32 consecutive views made of whole points (points with more than 32
  * views: consecutive fragment tiles); "bn" arrays are fp32 [4][32] = mean | invstd | gamma | beta
@@ -373,6 +374,25 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
                        void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
                        int32_t scaling, float eps, void* stream);
 
+/* Per-point set branch of DeepSetFeat on the chain (pooling.py:660-664): pooled fp32 [N][32] (+ the set-size
+ * feature sqrt(1 / (n + 1e-3)) when w33 = Wsa[:, 32] is given) -> mlp_set = MLP[32(+1), 32, 32] -> u = Wc[:, 32:] . s,
+ * the per-point half of the concatenation layer.  Every pass re-evaluates the branch from pooled (three-term bf16
+ * split: fp32-class accuracy); one pass per BatchNorm barrier.  ops: 24 KiB device buffer (dva_chain_set_prep:
+ * Wsa [32][ld_sa], Wsb [32][32], Wc [32][ld_c] of which the columns 32..63 are used).
+ *   fwd stage 1: stats += statistics of s1 | stage 2: of s2 (needs bn_s1) | stage 3: u fp32 [N][32] (bn_s1, bn_s2)
+ *   bwd stage 1: dW [32][ld_dw] += du^T a2 (= d Wc[:, 32:]), stats += S of layer s2
+ *       stage 2: dW += d Wsb, stats += S of layer s1                                   (sm_s2)
+ *       stage 3: dW += d Wsa[:, :32], dw33[i * ld_dw] += d Wsa[i, 32] (nullable), dpooled fp32 [N][32]  (sm_s1, sm_s2)
+ * Backward statistics are S1 = sum dy | sum dy z (raw layer output), like dva_chain_bwd_layer. */
+int dva_chain_set_prep(const float* Wsa, int32_t ld_sa, const float* Wsb, const float* Wc, int32_t ld_c, void* ops,
+                       void* stream);
+int dva_chain_set_fwd(int32_t stage, const float* pooled, const int64_t* ptr, const float* w33, const void* ops,
+                      const float* bn_s1, const float* bn_s2, float* u, double* stats, int64_t n_points,
+                      void* stream);
+int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, const float* w33, const void* ops,
+                      const float* bn_s1, const float* bn_s2, const float* sm_s1, const float* sm_s2,
+                      const float* du, float* dpooled, float* dW, int32_t ld_dw, float* dw33, double* stats,
+                      int64_t n_points, void* stream);
 /* Backward of dva_chain_attn_fwd (+ the BatchNorm-backward statistics of layer 6).  grad_out / out bf16 [N][C]
  * (out = the forward result; only read for points with more than 32 views).  Outputs: grad_scores fp32 [V][4]
  * (columns >= G zero), view_rec fp32 [V][8] = {point id bits | gate * attention per group | 0} (the records
