@@ -623,6 +623,45 @@ __global__ __launch_bounds__(256) void route_stats_kernel(const float* __restric
   if (threadIdx.x < 2 * D) atomicAdd(&stats[threadIdx.x], (double)s_red[threadIdx.x]);
 }
 
+// ---- host-side arithmetic on the 64-entry statistics, as single launches -----------------------------------------
+// stats fp64 [64] = S1 | sum dy z (raw layer output).  do_hat: S2 = invstd (sum dy z - mean S1) in place.
+// sm = stats * inv_m (the constants of the next pass), dgamma = S2, dbeta = S1.
+__global__ void bn_bwd_consts_kernel(double* __restrict__ stats, const float* __restrict__ bn, double inv_m,
+                                     int do_hat, float* __restrict__ sm, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double s1 = stats[c];
+    double s2 = stats[C + c];
+    if (do_hat) {
+      s2 = (double)bn[C + c] * (s2 - (double)bn[c] * s1);
+      stats[C + c] = s2;
+    }
+    if (sm) {
+      sm[c] = (float)(s1 * inv_m);
+      sm[C + c] = (float)(s2 * inv_m);
+    }
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+  }
+}
+
+// dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q),  Q = sum_v z1_hat x^T = invstd (bf16(W1) XX - mean SX^T) from the moments
+// of x_map (mom fp64 [44] = SX [8] | upper triangle of XX, row-major).  One thread per entry, fp64.
+__global__ void dw1_kernel(const float* __restrict__ P, const double* __restrict__ mom, const float* __restrict__ W1,
+                           const float* __restrict__ bn1, const float* __restrict__ sm1, float* __restrict__ dW1) {
+  const int i = threadIdx.x >> 3, k = threadIdx.x & 7;
+  double acc = 0.0;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const int a = l < k ? l : k, b = l < k ? k : l;
+    const double xx = mom[8 + a * 8 - a * (a - 1) / 2 + (b - a)];
+    acc += (double)bf2f(f2bf(W1[i * 8 + l])) * xx;
+  }
+  const double mean = bn1[i], inv = bn1[D + i], gam = bn1[2 * D + i], sx = mom[k];
+  const double q = inv * (acc - mean * sx);
+  dW1[i * 8 + k] = (float)(gam * inv * ((double)P[i * 8 + k] - (double)sm1[i] * sx - (double)sm1[D + i] * q));
+}
+
 }  // namespace chain
 }  // namespace dva
 
@@ -717,6 +756,23 @@ int dva_chain_route_stats(const float* zstar, const float* dpooled, const float*
   const int cap = chain_grid(8);
   hipLaunchKernelGGL(route_stats_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0,
                      (hipStream_t)stream, zstar, dpooled, bn2, ptr, stats, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_bn_bwd_consts(double* stats, const float* bn, double inv_m, int32_t do_hat, float* sm, float* dgamma,
+                      float* dbeta, int32_t C, void* stream) {
+  if (!stats || (do_hat && !bn) || C < 1) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3(1), dim3(C <= 64 ? 64 : 256), 0, (hipStream_t)stream, stats, bn,
+                     inv_m, (int)do_hat, sm, dgamma, dbeta, (int)C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_dw1(const float* P, const double* mom, const float* W1, const float* bn1, const float* sm1, float* dW1,
+                  void* stream) {
+  if (!P || !mom || !W1 || !bn1 || !sm1 || !dW1) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(dw1_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P, mom, W1, bn1, sm1, dW1);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -106,6 +106,49 @@ __global__ __launch_bounds__(64) void tile_walk_kernel(const int64_t* __restrict
   if (!WRITE && lane == 0) counts[c] = count;
 }
 
+// chunk c covers the views [c * step, (c + 1) * step): cp[c] = first point whose views start at or after c * step
+__global__ void tile_chunks_kernel(const int64_t* __restrict__ ptr, int64_t N, int64_t step, int n_chunks,
+                                   int64_t* __restrict__ cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_chunks) return;
+  if (c == 0 || c == n_chunks) {
+    cp[c] = c == 0 ? 0 : N;
+    return;
+  }
+  const int64_t bound = (int64_t)c * step;
+  int64_t lo = 0, hi = N;                       // lower bound over ptr[0 .. N)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (ptr[mid] < bound) lo = mid + 1;
+    else hi = mid;
+  }
+  cp[c] = lo;
+}
+
+// exclusive scan of the per-chunk tile counts (n_chunks <= 16384), one block
+__global__ __launch_bounds__(1024) void tile_offsets_kernel(const int32_t* __restrict__ counts, int n_chunks,
+                                                            int64_t* __restrict__ offsets,
+                                                            int32_t* __restrict__ n_tiles) {
+  __shared__ int s_sum[1024];
+  const int t = threadIdx.x, per = (n_chunks + 1023) / 1024, beg = t * per;
+  int local = 0;
+  for (int i = beg; i < beg + per && i < n_chunks; ++i) local += counts[i];
+  s_sum[t] = local;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? s_sum[t - off] : 0;
+    __syncthreads();
+    s_sum[t] += v;
+    __syncthreads();
+  }
+  int64_t run = s_sum[t] - local;
+  for (int i = beg; i < beg + per && i < n_chunks; ++i) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+  if (t == 1023) n_tiles[0] = s_sum[1023];
+}
+
 // ------------------------------------------------------------------------------------------------
 // first and second moments of the mapping features (fp64 sums): BatchNorm-1 statistics are a function of
 // them (z1 = W1 x is linear), and so is the Q term of the first layer's weight gradient
@@ -682,6 +725,25 @@ int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld
   if (!W1 || !W2 || !W5 || !W6 || !Ws || !ops || G < 1 || G > 4 || ld5 < D) return DVA_ERR_INVALID;
   hipLaunchKernelGGL(prep_kernel, dim3(N_OPS), dim3(64), 0, (hipStream_t)stream, W1, W2, W5, ld5, W6, Ws, G,
                      (uint4*)ops);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_tile_chunks(const int64_t* ptr, int64_t n_points, int64_t views_per_chunk, int32_t n_chunks,
+                          int64_t* chunk_points, void* stream) {
+  if (n_chunks < 0 || n_points < 0 || views_per_chunk < 1) return DVA_ERR_INVALID;
+  if (!ptr || !chunk_points) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(tile_chunks_kernel, dim3((n_chunks + 256) / 256), dim3(256), 0, (hipStream_t)stream, ptr,
+                     n_points, views_per_chunk, (int)n_chunks, chunk_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_tile_offsets(const int32_t* counts, int32_t n_chunks, int64_t* offsets, int32_t* n_tiles,
+                           void* stream) {
+  if (n_chunks < 0 || n_chunks > 16384 || !offsets || !n_tiles || (n_chunks && !counts)) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, (int)n_chunks,
+                     offsets, n_tiles);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

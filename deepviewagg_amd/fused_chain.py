@@ -53,17 +53,16 @@ def build_tiles(csr_idx, V):
     st = stream_of(csr_idx)
     n_chunks = max(1, min(16384, (V + VIEWS_PER_CHUNK - 1) // VIEWS_PER_CHUNK))
     step = (V + n_chunks - 1) // n_chunks if V > 0 else 1
-    bounds = torch.arange(n_chunks, device=dev, dtype=torch.int64) * step
-    cp = torch.searchsorted(csr_idx[:N].contiguous(), bounds)
-    cp = torch.cat([cp, torch.full((1,), N, dtype=torch.int64, device=dev)])
-    cp[0] = 0
+    cp = torch.empty(n_chunks + 1, dtype=torch.int64, device=dev)
     counts = torch.empty(n_chunks, dtype=torch.int32, device=dev)
-    check(lib.dva_chain_tile_count(ptr(csr_idx), ptr(cp), n_chunks, ptr(counts), st), "dva_chain_tile_count")
-    incl = counts.to(torch.int64).cumsum(0)
-    offsets = (incl - counts).contiguous()
-    n_tiles = incl[-1:].to(torch.int32)
+    offsets = torch.empty(n_chunks, dtype=torch.int64, device=dev)
+    n_tiles = torch.empty(1, dtype=torch.int32, device=dev)
     t_max = min(N, V) + V // 32 + 1
     tiles = torch.empty((t_max, 2), dtype=torch.int32, device=dev)
+    check(lib.dva_chain_tile_chunks(ptr(csr_idx), N, step, n_chunks, ptr(cp), st), "dva_chain_tile_chunks")
+    check(lib.dva_chain_tile_count(ptr(csr_idx), ptr(cp), n_chunks, ptr(counts), st), "dva_chain_tile_count")
+    check(lib.dva_chain_tile_offsets(ptr(counts), n_chunks, ptr(offsets), ptr(n_tiles), st),
+          "dva_chain_tile_offsets")
     check(lib.dva_chain_tile_build(ptr(csr_idx), ptr(cp), n_chunks, ptr(offsets), ptr(tiles), st),
           "dva_chain_tile_build")
     return tiles, n_tiles
@@ -102,24 +101,15 @@ def _set_branch_forward(e_map, pooled, csr_idx, training, zstats):
     return t_add, (pooled, csr_idx, w33, sops, bns1, bns2, tuple(Wsa.shape))
 
 
-def _set_branch_backward(saved, dt, dWc, training, zstats):
+def _set_branch_backward(saved, dt, dWc, training, zstats, arena):
     """Backward of _set_branch_forward: dt [N, 32] = gradient of t_add.  d Wc[:, 32:] is accumulated into ``dWc``
     [32, 64] in place.  Returns (dpooled, d_set) with d_set = gradients of list(mlp_set.parameters())."""
+    from .fused_chain_bwd import bn_bwd_consts
     lib = _lib.load()
     pooled, csr_idx, w33, sops, bns1, bns2, wsa_shape = saved
     dev, N = pooled.device, pooled.shape[0]
     st = stream_of(pooled)
     n_rows = float(max(N, 1))
-
-    def to_hat(stats, bn):
-        stats[D:] = bn[1].double() * (stats[D:] - bn[0].double() * stats[:D])
-
-    def sm_of(stats):
-        if not training:
-            return torch.zeros(2 * D, dtype=torch.float32, device=dev)
-        out = torch.empty(2 * D, dtype=torch.float32, device=dev)
-        check(lib.dva_scale_f64(ptr(stats), 1.0 / n_rows, ptr(out), 2 * D, st), "dva_scale_f64")
-        return out
 
     def call(stage, sm1, sm2, dpooled, dW, ld, dw33, stats):
         check(lib.dva_chain_set_bwd(stage, ptr(pooled), ptr(csr_idx), ptr(w33), ptr(sops), ptr(bns1), ptr(bns2),
@@ -127,17 +117,14 @@ def _set_branch_backward(saved, dt, dWc, training, zstats):
                                     N, st), "dva_chain_set_bwd")
     ss2, ss1 = zstats(), zstats()
     call(1, None, None, None, dWc[:, D:], dWc.shape[1], None, ss2)
-    to_hat(ss2, bns2)
-    sms2 = sm_of(ss2)
-    dWsb = torch.zeros((D, D), dtype=torch.float32, device=dev)
+    sms2, g2, b2 = bn_bwd_consts(lib, arena, ss2, bns2, n_rows, training, st)
+    dWsb = arena.take(D, D)
     call(2, None, sms2, None, dWsb, D, None, ss1)
-    to_hat(ss1, bns1)
-    sms1 = sm_of(ss1)
-    dWsa = torch.zeros(wsa_shape, dtype=torch.float32, device=dev)
+    sms1, g1, b1 = bn_bwd_consts(lib, arena, ss1, bns1, n_rows, training, st)
+    dWsa = arena.take(*wsa_shape)
     dpooled = torch.empty((N, D), dtype=torch.float32, device=dev)
     call(3, sms1, sms2, dpooled, dWsa, wsa_shape[1], dWsa[:, D:] if w33 is not None else None, None)
-    d_set = [dWsa, ss1[D:].float(), ss1[:D].float(), dWsb, ss2[D:].float(), ss2[:D].float()]
-    return dpooled, d_set
+    return dpooled, [dWsa, g1, b1, dWsb, g2, b2]
 
 
 class _ChainPool(torch.autograd.Function):

@@ -1,11 +1,38 @@
 """Backward of fused_chain._ChainPool: four view passes (attention, layer 6, layer 5, layer 2), each re-evaluating
 the DeepSetFeat chain from x_map, separated by the BatchNorm-backward statistics; the per-point set branch in
-between runs through the fp32 layer kernels (fused_chain._set_branch_backward)."""
+between runs on csrc/chain_set.hip (fused_chain._set_branch_backward)."""
 import torch
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_of
 from .fused_deepset import D
+
+
+class Arena:
+    """One zero-filled fp32 buffer handed out in 16-byte aligned pieces: the small accumulators and gradients of one
+    backward cost one fill launch instead of one each."""
+
+    def __init__(self, device, n_floats=1 << 15):
+        self.buf = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        off = self.used
+        self.used = off + (n + 3) // 4 * 4
+        assert self.used <= self.buf.numel(), "Arena too small"
+        return self.buf[off:off + n].view(*shape)
+
+
+def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=True):
+    sm = dg = db = None
+    if out:
+        sm, dg, db = arena.take(2 * D), arena.take(D), arena.take(D)
+    check(lib.dva_bn_bwd_consts(ptr(stats), ptr(bn), (1.0 / m_rows) if training else 0.0, 1 if hat else 0,
+                                ptr(sm), ptr(dg), ptr(db), D, st), "dva_bn_bwd_consts")
+    return sm, dg, db
 
 
 def backward(ctx, gout):
@@ -27,27 +54,21 @@ def backward(ctx, gout):
     gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
 
     zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
+    arena = Arena(dev)          # every small fp32 accumulator / gradient of this backward: one zero fill
 
     def zstats():
         return next(zpool)
 
-    def to_hat(stats, bn):
-        """The kernels accumulate S1 = sum dy and sum dy z (raw layer output): S2 = sum dy z_hat =
-        invstd (sum dy z - mean S1), in place."""
-        stats[D:] = bn[1].double() * (stats[D:] - bn[0].double() * stats[:D])
-
-    def sm_of(stats):
-        if not training:
-            return torch.zeros(2 * D, dtype=torch.float32, device=dev)
-        o = torch.empty(2 * D, dtype=torch.float32, device=dev)
-        check(lib.dva_scale_f64(ptr(stats), 1.0 / m_rows, ptr(o), 2 * D, st), "dva_scale_f64")
-        return o
+    def consts(stats, bn, hat=True, out=True):
+        """The arithmetic between two passes in one launch (dva_bn_bwd_consts): S2 -> z_hat form in place,
+        then (sm = S / M for the next pass, d gamma = S2, d beta = S1)."""
+        return bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat, out)
 
     # ---- attention + gate backward: score gradients, view records, S6
     dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
     rec = torch.empty((V, 8), dtype=torch.float32, device=dev)
     s6 = zstats()
-    gwb = torch.zeros(2 * G, dtype=torch.float32, device=dev) if gate is not None else None
+    gwb = arena.take(2 * G) if gate is not None else None
     with ops._timed("chain_attn_bwd", V * (C * 2 + 32 + 8 + 16 + 32) + N * (2 * C * 2 + 128 + 8)):
         check(lib.dva_chain_attn_bwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                      ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
@@ -75,19 +96,15 @@ def backward(ctx, gout):
                   "dva_chain_bwd_layer")
 
     # per view: x_map 32 + view->point 4 (+ score gradients 16) + the 64-byte gradient row handed between the passes
-    to_hat(s6, bn6)
-    sm6 = sm_of(s6)
-    dW6 = torch.zeros((D, D), dtype=torch.float32, device=dev)
-    dWs = torch.zeros((G, D), dtype=torch.float32, device=dev)
-    dbs = torch.zeros(G, dtype=torch.float32, device=dev)
+    sm6, g6, b6 = consts(s6, bn6)
+    dW6, dWs, dbs = arena.take(D, D), arena.take(G, D), arena.take(G)
     s5 = zstats()
     da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
     layer(6, None, None, sm6, None, None, None, da5, dW6, dWs, dbs, None, None, s5, "chain_bwd_l6",
           V * (32 + 4 + 16 + 64) + N * 128)
     del dc
-    to_hat(s5, bn5)
-    sm5 = sm_of(s5)
-    dW5 = torch.zeros((D, 2 * D), dtype=torch.float32, device=dev)
+    sm5, g5, b5 = consts(s5, bn5)
+    dW5 = arena.take(D, 2 * D)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
     s2 = zstats()
     da2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
@@ -96,40 +113,22 @@ def backward(ctx, gout):
           V * (32 + 4 + 64 + 64) + N * 256)
     del da5
     # ---- per-point set branch
-    dpooled, d_set = _set_branch_backward(ctx.set_saved, du, dW5, training, zstats)
-    to_hat(s2, bn2)            # view part; the per-point part below is accumulated in z_hat directly
+    dpooled, d_set = _set_branch_backward(ctx.set_saved, du, dW5, training, zstats, arena)
+    consts(s2, bn2, out=False)            # view part; the per-point part below is accumulated in z_hat directly
     check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), N, st),
           "dva_chain_route_stats")
-    sm2 = sm_of(s2)
-    dW2 = torch.zeros((D, D), dtype=torch.float32, device=dev)
-    P = torch.zeros((D, 8), dtype=torch.float32, device=dev)
+    sm2, g2, b2 = consts(s2, bn2, hat=False)
+    dW2, P = arena.take(D, D), arena.take(D, 8)
     s1 = zstats()
     layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, None, None, P, s1, "chain_bwd_l2",
           V * (32 + 4 + 64) + N * 256)
     del da2
-    to_hat(s1, bn1)
-    sm1 = sm_of(s1)
+    sm1, g1, b1 = consts(s1, bn1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so
     #      dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q) with Q = sum_v z1_hat x^T from the moments of x_map
-    W1b = e_map.mlp_elt_1[0][0].weight.detach().to(torch.bfloat16).double()
-    momd = mom
-    SX = momd[:8]
-    XX = torch.zeros((8, 8), dtype=torch.float64, device=dev)
-    iu = torch.triu_indices(8, 8, device=dev)
-    XX[iu[0], iu[1]] = momd[8:]
-    XX = XX + XX.t() - torch.diag(torch.diagonal(XX))
-    mean1, inv1, gam1 = bn1[0].double(), bn1[1].double(), bn1[2].double()
-    Q = inv1.view(D, 1) * (W1b @ XX - mean1.view(D, 1) * SX.view(1, 8))
-    sm1d = sm1.double()
-    dW1 = ((gam1 * inv1).view(D, 1) * (P.double() - sm1d[:D].view(D, 1) * SX.view(1, 8)
-                                       - sm1d[D:].view(D, 1) * Q)).float()
-
-    def gb_of(stats):   # d gamma = S2, d beta = S1
-        return stats[D:].float(), stats[:D].float()
-    g1, b1 = gb_of(s1)
-    g2, b2 = gb_of(s2)
-    g5, b5 = gb_of(s5)
-    g6, b6 = gb_of(s6)
+    W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
+    dW1 = arena.take(D, 8)
+    check(lib.dva_chain_dw1(ptr(P), ptr(mom), ptr(W1), ptr(bn1), ptr(sm1), ptr(dW1), st), "dva_chain_dw1")
     if gate is not None:
         dgw, dgb = gwb[:G].reshape(gate.weight.shape), gwb[G:].reshape(gate.bias.shape)
     else:

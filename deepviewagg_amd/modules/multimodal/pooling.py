@@ -44,6 +44,13 @@ def batchnorm_act_rows(y, bn, slope, counts=None, n=None):
     slope 1 = no activation).  ``counts`` weights the batch statistics (row r stands for counts[r] gathered
     rows, ``n`` of them in total); running statistics are updated as ``nn.BatchNorm1d`` does."""
     batch_stats = bn.training or not bn.track_running_stats
+    if bn.momentum is not None and y.is_cuda:
+        # statistics -> constants (+ running statistics) in one launch
+        n = (float(y.shape[0]) if n is None else float(n)) if batch_stats else 1.0
+        sums = ops.rowbn_sums(y, counts) if batch_stats else None
+        tab = ops.bn_table(sums, n, bn, batch_stats)
+        return ops.rowbn_act(y, counts, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                             None, None, n, batch_stats, slope, bn_tab=tab)
     if batch_stats:
         n = float(y.shape[0]) if n is None else float(n)
         s1, s2 = ops.rowbn_stats(y, counts)

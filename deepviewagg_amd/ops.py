@@ -737,14 +737,16 @@ class _RowBNAct(torch.autograd.Function):
     with ``batch_stats`` the backward includes the statistics terms."""
 
     @staticmethod
-    def forward(ctx, y, counts, gamma, beta, mean, invstd, n, batch_stats, slope):
+    def forward(ctx, y, counts, gamma, beta, mean, invstd, n, batch_stats, slope, bn_tab=None):
         lib = _lib.load()
         require_device(y)
         y = y.contiguous()
         R, C = y.shape
-        g = gamma.detach().float() if gamma is not None else torch.ones(C, device=y.device)
-        b = beta.detach().float() if beta is not None else torch.zeros(C, device=y.device)
-        bn = torch.stack([mean.float(), invstd.float(), g, b]).contiguous()
+        if bn_tab is None:
+            g = gamma.detach().float() if gamma is not None else torch.ones(C, device=y.device)
+            b = beta.detach().float() if beta is not None else torch.zeros(C, device=y.device)
+            bn_tab = torch.stack([mean.float(), invstd.float(), g, b]).contiguous()
+        bn = bn_tab
         out = torch.empty_like(y)
         with _timed("rowbn_apply", R * C * 2 * y.element_size()):
             check(lib.dva_rowbn_apply(ptr(y), ptr(bn), ptr(out), R, C, float(slope), dtype_code(y),
@@ -765,18 +767,19 @@ class _RowBNAct(torch.autograd.Function):
         with _timed("rowbn_bwd_stats", R * C * 2 * y.element_size()):
             check(lib.dva_rowbn_bwd_stats(ptr(gout), ptr(y), ptr(bn), ptr(sums), R, C, slope, dtype_code(y),
                                           stream_of(y)), "dva_rowbn_bwd_stats")
-        sm = (sums / n).float().contiguous() if batch_stats else torch.zeros(2 * C, device=y.device)
+        small = torch.empty(4 * C, dtype=torch.float32, device=y.device)    # S/n [2C] | d gamma [C] | d beta [C]
+        sm, dg, db = small[:2 * C], small[2 * C:3 * C], small[3 * C:]
+        check(lib.dva_bn_bwd_consts(ptr(sums), None, (1.0 / n) if batch_stats else 0.0, 0, ptr(sm), ptr(dg), ptr(db),
+                                    C, stream_of(y)), "dva_bn_bwd_consts")
         dy = torch.empty_like(y)
         with _timed("rowbn_bwd_apply", R * C * 3 * y.element_size()):
             check(lib.dva_rowbn_bwd_apply(ptr(gout), ptr(y), ptr(counts), ptr(bn), ptr(sm), ptr(dy), R, C, slope,
                                           dtype_code(y), stream_of(y)), "dva_rowbn_bwd_apply")
-        dg = sums[C:].float() if has_g else None
-        db = sums[:C].float() if has_b else None
-        return dy, None, dg, db, None, None, None, None, None
+        return dy, None, dg if has_g else None, db if has_b else None, None, None, None, None, None, None
 
 
-def rowbn_stats(y, counts):
-    """(sum_r counts_r y_r, sum_r counts_r y_r^2) as float64 [C] each."""
+def rowbn_sums(y, counts):
+    """sum_r counts_r y_r | sum_r counts_r y_r^2 as one float64 [2C] tensor."""
     lib = _lib.load()
     require_device(y)
     y = y.contiguous()
@@ -785,11 +788,36 @@ def rowbn_stats(y, counts):
     with _timed("rowbn_stats", R * (C * y.element_size() + 4)):
         check(lib.dva_rowbn_stats(ptr(y), ptr(counts), ptr(sums), R, C, dtype_code(y), stream_of(y)),
               "dva_rowbn_stats")
+    return sums
+
+
+def bn_table(sums, n, bn, batch_stats):
+    """fp32 [4, C] = mean | invstd | gamma | beta of an nn.BatchNorm1d from the float64 sums of its input over ``n``
+    rows (or from the running statistics), running statistics updated as the module does: one launch."""
+    lib = _lib.load()
+    C = bn.num_features
+    dev = bn.weight.device if bn.affine else sums.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)
+    update = batch_stats and bn.training and bn.track_running_stats
+    check(lib.dva_bn_finalize(ptr(sums), float(max(n, 1.0)), ptr(bn.running_mean if (update or not batch_stats) else None),
+                              ptr(bn.running_var if (update or not batch_stats) else None),
+                              ptr(bn.num_batches_tracked if update else None),
+                              ptr(bn.weight.detach()) if bn.affine else None,
+                              ptr(bn.bias.detach()) if bn.affine else None,
+                              float(bn.momentum), float(bn.eps), 1 if batch_stats else 0, C, ptr(out),
+                              stream_of(out)), "dva_bn_finalize")
+    return out
+
+
+def rowbn_stats(y, counts):
+    """(sum_r counts_r y_r, sum_r counts_r y_r^2) as float64 [C] each."""
+    sums = rowbn_sums(y, counts)
+    C = y.shape[1]
     return sums[:C], sums[C:]
 
 
-def rowbn_act(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope):
-    return _RowBNAct.apply(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope)
+def rowbn_act(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope, bn_tab=None):
+    return _RowBNAct.apply(y, counts, gamma, beta, mean, invstd, n, batch_stats, slope, bn_tab)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -342,6 +342,13 @@ int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld
  * count: counts int32 [n_chunks] = tiles per chunk.  build: offsets int64 [n_chunks] = exclusive prefix sum
  * of counts; tiles int32 [sum(counts)][2] = {first view, n_views | fragment << 8} (fragment 0 = whole
  * points, 1 / 2 / 3 = first / middle / last fragment of a point with more than 32 views). */
+/* The two host-side steps around count / build as launches: chunk_points[c] = first point whose views start at or
+ * after c * views_per_chunk (c = 1 .. n_chunks - 1; [0] = 0, [n_chunks] = n_points); offsets = exclusive prefix sum of
+ * counts (n_chunks <= 16384), n_tiles int32 [1] = the total. */
+int dva_chain_tile_chunks(const int64_t* ptr, int64_t n_points, int64_t views_per_chunk, int32_t n_chunks,
+                          int64_t* chunk_points, void* stream);
+int dva_chain_tile_offsets(const int32_t* counts, int32_t n_chunks, int64_t* offsets, int32_t* n_tiles,
+                           void* stream);
 int dva_chain_tile_count(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks, int32_t* counts,
                          void* stream);
 int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks,
@@ -374,6 +381,17 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
                        void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
                        int32_t scaling, float eps, void* stream);
 
+/* The arithmetic between two BatchNorm-backward passes as one launch.  stats fp64 [2C] = S1 | S2, bn fp32 [4][C] =
+ * mean | invstd | gamma | beta.  do_hat: S2 arrives as sum dy z (raw layer output) and becomes
+ * invstd (S2 - mean S1) = sum dy z_hat, in place.  Then sm fp32 [2C] = stats * inv_m, dgamma = S2, dbeta = S1
+ * (each nullable). */
+int dva_bn_bwd_consts(double* stats, const float* bn, double inv_m, int32_t do_hat, float* sm, float* dgamma,
+                      float* dbeta, int32_t C, void* stream);
+/* First-layer weight gradient without another view pass: BatchNorm-1 backward is linear in its statistics and
+ * z1 = W1 x is linear in x, so dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q), Q = sum_v z1_hat x^T from the moments.
+ * P fp32 [32][8] (dva_chain_bwd_layer stage 2), mom fp64 [44] (dva_chain_moments), sm1 = S/M of layer 1. */
+int dva_chain_dw1(const float* P, const double* mom, const float* W1, const float* bn1, const float* sm1, float* dW1,
+                  void* stream);
 /* Per-point set branch of DeepSetFeat on the chain (pooling.py:660-664): pooled fp32 [N][32] (+ the set-size
  * feature sqrt(1 / (n + 1e-3)) when w33 = Wsa[:, 32] is given) -> mlp_set = MLP[32(+1), 32, 32] -> u = Wc[:, 32:] . s,
  * the per-point half of the concatenation layer.  Every pass re-evaluates the branch from pooled (three-term bf16
