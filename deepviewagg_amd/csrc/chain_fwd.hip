@@ -399,8 +399,10 @@ __global__ __launch_bounds__(256, 3) void stats_mid_kernel(
 // of one point; a point that lies inside one slot is stored directly, a point split over slots is summed in a
 // [ROWS][C] LDS buffer keyed by the slot it starts in (each slot starts at most one split point) and stored by
 // the slot it ends in.
-template <int LPR, int G>
-__global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_fwd_kernel(
+// OCC = waves per SIMD the register budget is cut for: 4 pays when nearly every tile is one point (the single-point
+// path fits 128 VGPRs); the several-points path needs the 168 of OCC = 3.
+template <int LPR, int G, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -847,12 +849,19 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
       n_points * C * 2 > 0xfffffff0ll)
     return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(C <= 64 ? 4 : 3)), block(256);
+  const bool dense = C <= 64 && n_views >= 24 * n_points;   // mostly one point per tile
+  const dim3 grid(chain_grid(dense ? 4 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
+#define DVA_ATTN_FWD_O(LPR_, G_, OCC_)                                                                          \
+  hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_, OCC_>), grid, block, 0, s, x_map, view_point, u,               \
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias,            \
+                     (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b, (bf16_t*)out, scaling, eps, n_views,    \
+                     n_points, n_rows)
 #define DVA_ATTN_FWD(LPR_, G_)                                                                                  \
-  hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, \
-                     n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)rows, row_idx, \
-                     ptr, gate_w, gate_b, (bf16_t*)out, scaling, eps, n_views, n_points, n_rows)
+  do {                                                                                                          \
+    if (LPR_ <= 8 && dense) DVA_ATTN_FWD_O(LPR_, G_, (LPR_ <= 8 ? 4 : 3));                                      \
+    else DVA_ATTN_FWD_O(LPR_, G_, 3);                                                                           \
+  } while (0)
   const int key = C * 8 + G;
   switch (key) {
     case 32 * 8 + 1: DVA_ATTN_FWD(4, 1); break;
@@ -873,6 +882,7 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_ATTN_FWD
+#undef DVA_ATTN_FWD_O
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
