@@ -15,22 +15,38 @@ namespace dva {
 namespace chain {
 
 struct ChainKeep {
-  f32x16 z1, z2, z5, z6;
-  bf16x8 a1[2], a2[2], a5[2], a6[2];
+  f32x16 z5, z6;
+  bf16x8 a2[2], a5[2], a6[2];
 };
-// tabs[0..3] = layers 1, 2, 5, 6; weight operands from the LDS copy of the table
+// The forward chain as the forward passes evaluate it: layers 1 and 2 with BatchNorm folded into the operand (their
+// LDS blocks hold the folded operands), layer 5 plain (the per-point row enters before its BatchNorm), layer 6 twice:
+// the raw output z6 (BatchNorm backward, statistics) and the folded product (block OP_W6F) for the activation the
+// forward used.  tabs[0..3] = layers 1, 2, 5, 6.
+constexpr int OP_W6F = N_OPS;        // two extra LDS blocks behind the table
 __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
                                               uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
   const f32x16 zero = {0};
+  bf16x8 a1[2];
   asm volatile("" ::: "memory");
-  k.z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(x), zero);
-  act_pack(k.z1, tabs[0], h, keep, k.a1);
-  k.z2 = mm32_lds(s_ops, OP_W2, lane, k.a1, zero);
-  act_pack(k.z2, tabs[1], h, keep, k.a2);
+  const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(x), bias_acc(tabs[0], T_B6, h));
+  act_fold(t1, keep, a1);
+  const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(tabs[1], T_B6, h));
+  act_fold(t2, keep, k.a2);
   k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
   act_pack(k.z5, tabs[2], h, keep, k.a5);
   k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
-  act_pack(k.z6, tabs[3], h, keep, k.a6);
+  const f32x16 t6 = mm32_lds(s_ops, OP_W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
+  act_fold(t6, keep, k.a6);
+}
+// stage the whole table + the folded operands of chain_forward (call from the whole block, then __syncthreads())
+__device__ __forceinline__ void stage_ops_chain(uint4* s_ops, const uint4* __restrict__ ops,
+                                                const float* __restrict__ bn1, const float* __restrict__ bn2,
+                                                const float* __restrict__ bn6) {
+  for (int i = threadIdx.x; i < N_OPS * 64; i += blockDim.x)
+    if (i >= (OP_W2 + 2) * 64) s_ops[i] = ops[i];
+  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  fold_ops(s_ops, OP_W6F, ops, OP_W6, 2, bn6);
 }
 __device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int vpj, int h) {
   f32x16 uacc;
@@ -83,10 +99,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_q[4][4 * 32];
   __shared__ __attribute__((aligned(16))) int s_pid[4][32], s_ri[4][32];
   __shared__ __attribute__((aligned(16))) float s_E[4][4];
-  __shared__ __attribute__((aligned(16))) uint4 s_ops[N_OPS * 64];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[(N_OPS + 2) * 64];
   __shared__ float s_red[2 * D];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  stage_ops(s_ops, ops);
+  stage_ops_chain(s_ops, ops, bn1, bn2, bn6);
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, nullptr);
   stage_tab(s_tab[2], bn5, nullptr);
@@ -387,15 +403,29 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   __shared__ float s_red[D * D];
   // only the operands of the pass (LDS budget: three blocks per CU for stages 5 and 2):
   // stage 5: W1 W2 W5 | W5T -> local 5, 6;  stage 2: W1 W2 | W2T -> local 3, 4
-  constexpr int NOPS = STAGE == 6 ? N_OPS : (STAGE == 5 ? 7 : 5);
-  constexpr int L_W5T = 5, L_W2T = 3;
+  // plus the BatchNorm-folded operands (the forward passes' activations): stage 6 as chain_forward; stage 5: W1 in
+  // place, W2 as a second operand (the raw z2 feeds the statistics) -> local 7, 8; stage 2: W1 as a second operand
+  // -> local 5
+  constexpr int NOPS = STAGE == 6 ? N_OPS + 2 : (STAGE == 5 ? 9 : 6);
+  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5;
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < NOPS * 64; i += blockDim.x) {
-    int op = i >> 6;
-    if (STAGE == 5 && op >= 5) op = OP_W5T + (op - 5);
-    if (STAGE == 2 && op >= 3) op = OP_W2T + (op - 3);
-    s_ops[i] = ops[op * 64 + (i & 63)];
+  if (STAGE == 6) {
+    stage_ops_chain(s_ops, ops, bn1, bn2, bn6);
+  } else {
+    for (int i = threadIdx.x; i < (STAGE == 5 ? 7 : 5) * 64; i += blockDim.x) {
+      int op = i >> 6;
+      if (STAGE == 5 && op >= 5) op = OP_W5T + (op - 5);
+      if (STAGE == 2 && op >= 3) op = OP_W2T + (op - 3);
+      s_ops[i] = ops[op * 64 + (i & 63)];
+    }
+    __syncthreads();
+    if (STAGE == 5) {
+      fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+      fold_ops(s_ops, L_W2F, ops, OP_W2, 2, bn2);
+    } else {
+      fold_ops(s_ops, L_W1F, ops, OP_W1, 1, bn1);
+    }
   }
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr);
@@ -490,10 +520,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       // forward up to layer 5
       bf16x8 a1[2], a2[2];
       asm volatile("" ::: "memory");
-      const f32x16 z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
-      act_pack(z1, s_tab[0], h, 0xffffffffu, a1);
+      const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
+      act_fold(t1, 0xffffffffu, a1);
       const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
-      act_pack(z2, s_tab[1], h, keep, a2);
+      const f32x16 t2 = mm32_lds(s_ops, L_W2F, lane, a1, bias_acc(s_tab[1], T_B6, h));
+      act_fold(t2, keep, a2);
       const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
       const f32x16 da5 = unpack_da(p.dlo, p.dhi);
       layer_bwd<false, true>(z5, da5, s_tab[2], h, ok, unused_st, dz);
@@ -541,8 +572,10 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       }
       bf16x8 a1[2];
       asm volatile("" ::: "memory");
-      const f32x16 z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
-      act_pack(z1, s_tab[0], h, keep, a1);
+      const bf16x8 xp = pack_x(p.x);
+      const f32x16 z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), xp, zero);
+      const f32x16 t1 = CH_MFMA(lds_op(s_ops, L_W1F, lane), xp, bias_acc(s_tab[0], T_B6, h));
+      act_fold(t1, keep, a1);
       const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
       // gradient of the max-pooled set features goes to the arg view of each channel
       f32x16 da2t = unpack_da(p.dlo, p.dhi);

@@ -247,7 +247,9 @@ __device__ __forceinline__ void tab16(const float* tab, int row, int h, float (&
 }
 // Fill the table of one layer from bn = [4][32] (mean | invstd | gamma | beta) and sm = [2][32] (S1/M | S2/M,
 // nullable).  Call from the whole block, then __syncthreads().
-__device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ bn, const float* __restrict__ sm) {
+// ext: bn has a fifth row = the 0.6-scaled shift of the layer's (possibly folded) product (dva_chain_bn_consts).
+__device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ bn, const float* __restrict__ sm,
+                                          bool ext = true) {
   if (!bn) return;      // a layer the pass does not reach
   for (int i = threadIdx.x; i < D; i += blockDim.x) {
     const int c = chan(i & 15, i >> 4);
@@ -261,7 +263,7 @@ __device__ __forceinline__ void stage_tab(float* tab, const float* __restrict__ 
     tab[T_K1 * D + i] = g * (s1 - mean * inv * s2);
     tab[T_K2 * D + i] = g * inv * s2;
     tab[T_G6 * D + i] = 0.6f * g;
-    tab[T_B6 * D + i] = 0.6f * (bet - mean * g);
+    tab[T_B6 * D + i] = ext ? bn[4 * D + c] : 0.6f * (bet - mean * g);
   }
 }
 
@@ -271,7 +273,7 @@ __device__ __forceinline__ void stage_tab_fwd(float* tab, const float* __restric
     const int c = chan(i & 15, i >> 4);
     const float g = bn[2 * D + c] * bn[D + c];
     tab[0 * D + i] = 0.6f * g;
-    tab[1 * D + i] = 0.6f * (bn[3 * D + c] - bn[c] * g);
+    tab[1 * D + i] = bn[4 * D + c];
   }
 }
 
@@ -280,7 +282,7 @@ __device__ __forceinline__ void stage_tab_fwd(float* tab, const float* __restric
 // keep = 0 zeroes the operand of a lane without a view.  The LDS reads stay inside the tile loop (asm barrier):
 // hoisting 32 constants per layer into registers costs an occupancy step.
 __device__ __forceinline__ void act_pack(const f32x16& z, const float* tab, int h, uint32_t keep, bf16x8 (&a)[2],
-                                         int rg = T_G6, int rb = T_B6) {
+                                         int rg = T_G6, int rb = T_B6, float* sum = nullptr) {
   asm volatile("" ::: "memory");
   float g[16], b[16], av[16];
   tab16(tab, rg, h, g);
@@ -289,6 +291,70 @@ __device__ __forceinline__ void act_pack(const f32x16& z, const float* tab, int 
   for (int r = 0; r < 16; ++r) {
     const float t = __builtin_fmaf(z[r], g[r], b[r]);
     av[r] = __builtin_fmaf(__builtin_fabsf(t), 0.6666667f, t);
+  }
+  if (sum && keep) {      // per-channel sums of the activation (the mean the next layer's folded shift needs)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum[r] += av[r];
+  }
+  a[0] = mask8(pack8(&av[0]), keep);
+  a[1] = mask8(pack8(&av[8]), keep);
+}
+
+// ---- BatchNorm folded into the weight operand ---------------------------------------------------------------------
+// A layer whose raw output a pass does not need (only its activation) takes the BatchNorm scale inside the product:
+// W' = bf16(0.6 G W) (rows of the A operand: every 16-byte entry of lane l belongs to output channel l & 31), the
+// shift 0.6 B as the accumulator the MFMA starts from, so the product IS t = 0.6 y and the activation is the single
+// operation leaky(y) = t + (2/3) |t|.  fold_ops builds the folded operand `op` (n_blocks blocks) at block `dst` of the
+// LDS table from the fp32 entries dva_chain_prep appends to the table (one rounding, like the plain operand).
+constexpr int N_OPS32 = 7;                       // W1 | W2 (2) | W5 (2) | W6 (2): the forward operands that can fold
+constexpr int OPS_UINT4 = N_OPS * 64 + N_OPS32 * 64 * 2;
+__device__ __forceinline__ void fold_ops(uint4* s_ops, int dst, const uint4* __restrict__ ops, int op, int n_blocks,
+                                         const float* __restrict__ bn) {
+  const float4* w32 = reinterpret_cast<const float4*>(ops + N_OPS * 64);
+  for (int i = threadIdx.x; i < n_blocks * 64; i += blockDim.x) {
+    const int n = i & 31;
+    const float s = 0.6f * bn[2 * D + n] * bn[D + n];
+    const float4 a = w32[(op * 64 + i) * 2], b = w32[(op * 64 + i) * 2 + 1];
+    s_ops[dst * 64 + i] = make_uint4(pack_bf16x2(a.x * s, a.y * s), pack_bf16x2(a.z * s, a.w * s),
+                                     pack_bf16x2(b.x * s, b.y * s), pack_bf16x2(b.z * s, b.w * s));
+  }
+}
+// the same for a kernel that keeps its operands in registers: this lane's entry of block `op`, folded
+__device__ __forceinline__ bf16x8 load_op_fold(const uint4* __restrict__ ops, int op, int lane,
+                                               const float* __restrict__ bn) {
+  const float4* w32 = reinterpret_cast<const float4*>(ops + N_OPS * 64) + (op * 64 + lane) * 2;
+  const int n = lane & 31;
+  const float s = 0.6f * bn[2 * D + n] * bn[D + n];
+  const float4 a = w32[0], b = w32[1];
+  const u32x4 v = {pack_bf16x2(a.x * s, a.y * s), pack_bf16x2(a.z * s, a.w * s), pack_bf16x2(b.x * s, b.y * s),
+                   pack_bf16x2(b.z * s, b.w * s)};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ WOp load_wop_fold(const uint4* __restrict__ ops, int op, int lane,
+                                             const float* __restrict__ bn) {
+  WOp w;
+  w.m[0] = load_op_fold(ops, op, lane, bn);
+  w.m[1] = load_op_fold(ops, op + 1, lane, bn);
+  return w;
+}
+// the accumulator a folded layer starts from: row `row` of the table (0.6 B) for this lane's 16 channels
+__device__ __forceinline__ f32x16 bias_acc(const float* tab, int row, int h) {
+  asm volatile("" ::: "memory");
+  float b[16];
+  tab16(tab, row, h, b);
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = b[r];
+  return c;
+}
+// activation of a folded layer (t = 0.6 y from the product) + bf16 packing as the next B operand
+__device__ __forceinline__ void act_fold(const f32x16& t, uint32_t keep, bf16x8 (&a)[2], float* sum = nullptr) {
+  float av[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) av[r] = __builtin_fmaf(__builtin_fabsf(t[r]), 0.6666667f, t[r]);
+  if (sum && keep) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum[r] += av[r];
   }
   a[0] = mask8(pack8(&av[0]), keep);
   a[1] = mask8(pack8(&av[8]), keep);

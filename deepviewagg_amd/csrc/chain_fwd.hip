@@ -52,6 +52,56 @@ __global__ __launch_bounds__(64) void prep_kernel(const float* __restrict__ W1, 
     }
   }
   ops[op * 64 + lane] = __builtin_bit_cast(uint4, pack8(w));
+  if (op < N_OPS32) {       // fp32 copy of the forward operands: source of the BatchNorm-folded variants
+    float4* w32 = reinterpret_cast<float4*>(ops + N_OPS * 64) + (op * 64 + lane) * 2;
+    w32[0] = make_float4(w[0], w[1], w[2], w[3]);
+    w32[1] = make_float4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping of one chain layer (dva_bn_finalize semantics) + the fifth table row: the 0.6-scaled
+// shift of the layer's product.  Plain layer: 0.6 (beta - mean G).  Folded layer in training (W, suma given): the
+// product is a . bf16(0.6 G W)^T, whose batch mean is bf16(0.6 G W) . mean(a), NOT 0.6 G mean(z) (the rounded
+// operand is not G times the rounded W), so the shift is 0.6 beta - bf16(0.6 G W) . mean(a): the folded
+// pre-activation keeps the exact batch mean beta (a systematic per-channel offset otherwise).
+// ------------------------------------------------------------------------------------------------
+__global__ void chain_bn_consts_kernel(const double* __restrict__ sums, double m, float* __restrict__ rmean,
+                                       float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float momentum, float eps, int training, const float* __restrict__ W, int ldw,
+                                       int K, const double* __restrict__ suma, float* __restrict__ bn) {
+  const int c = threadIdx.x;
+  if (c >= D) return;
+  float mean, var;
+  if (training) {
+    const double mu = sums[c] / m;
+    double v = sums[D + c] / m - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean = (float)mu;
+    var = (float)v;
+    if (rmean) {
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(v * (m / (m > 1.0 ? m - 1.0 : 1.0)));
+    }
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  const float inv = rsqrtf(var + eps), g = gamma[c] * inv;
+  bn[c] = mean;
+  bn[D + c] = inv;
+  bn[2 * D + c] = gamma[c];
+  bn[3 * D + c] = beta[c];
+  float shift = 0.6f * (beta[c] - mean * g);
+  if (training && W && suma) {
+    const float s = 0.6f * g;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += (double)bf2f(f2bf(W[c * ldw + k] * s)) * (suma[k] / m);
+    shift = (float)(0.6 * (double)beta[c] - acc);
+  }
+  bn[4 * D + c] = shift;
+  if (training && nbt && c == 0) *nbt += 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -217,17 +267,17 @@ __global__ __launch_bounds__(256, 3) void stats2_kernel(
     int32_t* __restrict__ arg, int64_t V) {
   __shared__ __attribute__((aligned(16))) float s_tab[TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float s_tile[4][32 * TZ];
-  __shared__ float s_red[2 * D];
+  __shared__ float s_red[3 * D];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   stage_tab(s_tab, bn1, nullptr);
   __syncthreads();
-  const bf16x8 w1 = load_op(ops, OP_W1, lane);
+  const bf16x8 w1 = load_op_fold(ops, OP_W1, lane, bn1);     // layer 1: BatchNorm inside the product
   const WOp w2 = load_wop(ops, OP_W2, lane);
   const uint32_t flip = gamma2[j] < 0.f ? 0x80000000u : 0u;   // walker lane c = j
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4);
-  float st[2][16];
+  float st[3][16];      // sum z2 | sum z2^2 | sum a1
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = st[2][r] = 0.f;
   float run_m = -INFINITY;
   int run_a = -1;
   float* tz = s_tile[wv];
@@ -250,9 +300,9 @@ __global__ __launch_bounds__(256, 3) void stats2_kernel(
     const int nv = p.ti.nv;
     const uint32_t keep = j < nv ? 0xffffffffu : 0u;
     const f32x16 zero = {0};
-    const f32x16 z1 = CH_MFMA(w1, pack_x(p.x), zero);
+    const f32x16 t1 = CH_MFMA(w1, pack_x(p.x), bias_acc(s_tab, T_B6, h));
     bf16x8 a1[2];
-    act_pack(z1, s_tab, h, keep, a1);
+    act_fold(t1, keep, a1, st[2]);
     const f32x16 z2 = mm32(w2, a1, zero);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -292,7 +342,7 @@ __global__ __launch_bounds__(256, 3) void stats2_kernel(
     }
     wave_sync();
   });
-  flush_stats<2>(st, stats, s_red);
+  flush_stats<3>(st, stats, s_red);
 }
 
 // pooled[p][c] = leaky(G2 z* + B2) for seen points, 0 for unseen ones (segment_csr max convention)
@@ -329,21 +379,21 @@ __global__ __launch_bounds__(256, 3) void stats_mid_kernel(
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     double* __restrict__ stats, int64_t V, int64_t N) {
   __shared__ __attribute__((aligned(16))) float s_tab[3][TAB_FLOATS];
-  __shared__ float s_red[2 * D];
+  __shared__ float s_red[3 * D];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, nullptr);
   if (L == 6) stage_tab(s_tab[2], bn5, nullptr);
   __syncthreads();
-  const bf16x8 w1 = load_op(ops, OP_W1, lane);
-  const WOp w2 = load_wop(ops, OP_W2, lane), w5 = load_wop(ops, OP_W5, lane);
+  const bf16x8 w1 = load_op_fold(ops, OP_W1, lane, bn1);     // layers 1, 2: BatchNorm inside the product
+  const WOp w2 = load_wop_fold(ops, OP_W2, lane, bn2), w5 = load_wop(ops, OP_W5, lane);
   WOp w6;
   if (L == 6) w6 = load_wop(ops, OP_W6, lane);
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128);
-  float st[2][16];
+  float st[3][16];      // sum z | sum z^2 | (L == 6) sum a5
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = st[2][r] = 0.f;
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
@@ -369,15 +419,15 @@ __global__ __launch_bounds__(256, 3) void stats_mid_kernel(
       uacc[4 * q] = v.x; uacc[4 * q + 1] = v.y; uacc[4 * q + 2] = v.z; uacc[4 * q + 3] = v.w;
     }
     const f32x16 zero = {0};
-    const f32x16 z1 = CH_MFMA(w1, pack_x(p.x), zero);
+    const f32x16 t1 = CH_MFMA(w1, pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
     bf16x8 a1[2], a2[2];
-    act_pack(z1, s_tab[0], h, keep, a1);
-    const f32x16 z2 = mm32(w2, a1, zero);
-    act_pack(z2, s_tab[1], h, keep, a2);
+    act_fold(t1, keep, a1);
+    const f32x16 t2 = mm32(w2, a1, bias_acc(s_tab[1], T_B6, h));
+    act_fold(t2, keep, a2);
     f32x16 z = mm32(w5, a2, uacc);
     if (L == 6) {
       bf16x8 a5[2];
-      act_pack(z, s_tab[2], h, keep, a5);
+      act_pack(z, s_tab[2], h, keep, a5, T_G6, T_B6, st[2]);
       z = mm32(w6, a5, zero);
     }
 #pragma unroll
@@ -386,7 +436,7 @@ __global__ __launch_bounds__(256, 3) void stats_mid_kernel(
       st[1][r] = __builtin_fmaf(z[r], z[r], st[1][r]);
     }
   });
-  flush_stats<2>(st, stats, s_red);
+  flush_stats<3>(st, stats, s_red);      // L == 5: the third row stays zero
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,6 +480,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   stage_tab_fwd(s_tab[1], bn2);
   stage_tab_fwd(s_tab[2], bn5);
   stage_tab_fwd(s_tab[3], bn6);
+  __syncthreads();
+  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);  // layers 1, 2, 6: BatchNorm inside the product (layer 5 adds u[point] first)
+  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  fold_ops(s_ops, OP_W6, ops, OP_W6, 2, bn6);
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
@@ -507,14 +561,14 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     const uint32_t keep = 0xffffffffu;
     bf16x8 a[2], a2[2];
     asm volatile("" ::: "memory");
-    f32x16 z = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), zero);
-    act_pack(z, s_tab[0], h, keep, a, 0, 1);
-    z = mm32_lds(s_ops, OP_W2, lane, a, zero);
-    act_pack(z, s_tab[1], h, keep, a2, 0, 1);
+    f32x16 z = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], 1, h));
+    act_fold(z, keep, a);
+    z = mm32_lds(s_ops, OP_W2, lane, a, bias_acc(s_tab[1], 1, h));
+    act_fold(z, keep, a2);
     z = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
     act_pack(z, s_tab[2], h, keep, a, 0, 1);
-    z = mm32_lds(s_ops, OP_W6, lane, a, zero);
-    act_pack(z, s_tab[3], h, keep, a2, 0, 1);
+    z = mm32_lds(s_ops, OP_W6, lane, a, bias_acc(s_tab[3], 1, h));
+    act_fold(z, keep, a2);
     z = mm32_lds(s_ops, OP_WS, lane, a2, zero);
     float c[NE];
     if constexpr (G == 4) {
@@ -727,6 +781,21 @@ int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld
   if (!W1 || !W2 || !W5 || !W6 || !Ws || !ops || G < 1 || G > 4 || ld5 < D) return DVA_ERR_INVALID;
   hipLaunchKernelGGL(prep_kernel, dim3(N_OPS), dim3(64), 0, (hipStream_t)stream, W1, W2, W5, ld5, W6, Ws, G,
                      (uint4*)ops);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_bn_consts(const double* sums, double m, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, const float* gamma, const float* beta, float momentum, float eps,
+                        int32_t training, const float* W, int32_t ldw, int32_t K, const double* sum_a, float* bn,
+                        void* stream) {
+  if (!bn || !gamma || !beta) return DVA_ERR_INVALID;
+  if (training ? (!sums || m <= 0.0) : (!running_mean || !running_var)) return DVA_ERR_INVALID;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return DVA_ERR_INVALID;
+  if (W && (ldw < K || K < 1 || K > D)) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(chain_bn_consts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, m, running_mean,
+                     running_var, num_batches_tracked, gamma, beta, momentum, eps, (int)training, W, (int)ldw, (int)K,
+                     sum_a, bn);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void set_kernel(
   __shared__ float s_red[D * D];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < N_SOPS * 64; i += blockDim.x) s_ops[i] = ops[i];
-  stage_tab(s_tab[0], bn_s1, (DIR == 1 && STAGE == 3) ? sm_s1 : nullptr);
-  stage_tab(s_tab[1], bn_s2, (DIR == 1 && STAGE >= 2) ? sm_s2 : nullptr);
+  stage_tab(s_tab[0], bn_s1, (DIR == 1 && STAGE == 3) ? sm_s1 : nullptr, false);
+  stage_tab(s_tab[1], bn_s2, (DIR == 1 && STAGE >= 2) ? sm_s2 : nullptr, false);
   for (int i = threadIdx.x; i < D; i += blockDim.x) s_w33[i] = w33 ? w33[chan(i & 15, i >> 4)] : 0.f;
   __syncthreads();
   const __amdgpu_buffer_rsrc_t PL = make_rsrc(pooled, (uint64_t)N * 128), DU = make_rsrc(du, (uint64_t)N * 128),

@@ -21,7 +21,7 @@ from .fused_deepset import D, _bn_of, _bn_consts
 # None = auto (inside torch.autocast(bfloat16) only); True / False pin the choice (tests, bench A/B)
 FORCE = None
 VIEWS_PER_CHUNK = 2048      # tile-table construction granularity (one wavefront walks one chunk)
-OPS_BYTES = 16 * 64 * 16
+OPS_BYTES = 16 * 64 * 16 + 7 * 64 * 32       # bf16 operand blocks + the fp32 copy of the forward operands
 
 
 def enabled():
@@ -66,6 +66,21 @@ def build_tiles(csr_idx, V):
     check(lib.dva_chain_tile_build(ptr(csr_idx), ptr(cp), n_chunks, ptr(offsets), ptr(tiles), st),
           "dva_chain_tile_build")
     return tiles, n_tiles
+
+
+def _chain_bn(stats, m, bn, training, W=None, K=0, sum_a=None):
+    """fp32 [5, 32] = mean | invstd | gamma | beta | shift of one chain layer (dva_chain_bn_consts): batch statistics
+    (training; running statistics updated as nn.BatchNorm1d does) or running statistics; ``W`` / ``sum_a`` for a layer
+    that the passes evaluate with BatchNorm folded into the weight operand (exact batch mean of the folded product)."""
+    lib = _lib.load()
+    out = torch.empty((5, D), dtype=torch.float32, device=stats.device)
+    fold = training and W is not None and sum_a is not None
+    check(lib.dva_chain_bn_consts(ptr(stats), float(max(m, 1)), ptr(bn.running_mean), ptr(bn.running_var),
+                                  ptr(bn.num_batches_tracked), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                  float(bn.momentum), float(bn.eps), 1 if training else 0,
+                                  ptr(W) if fold else None, W.shape[1] if fold else 0, K if fold else 0,
+                                  ptr(sum_a) if fold else None, ptr(out), stream_of(stats)), "dva_chain_bn_consts")
+    return out
 
 
 SET_OPS_BYTES = 24 * 64 * 16
@@ -152,7 +167,7 @@ class _ChainPool(torch.autograd.Function):
         gw = gate.weight.detach().reshape(-1).float().contiguous() if gate is not None else None
         gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
 
-        zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
+        zpool = iter(torch.zeros((10, 3 * D), dtype=torch.float64, device=dev))   # sum | sum of squares | input sums
 
         def zstats():
             return next(zpool)
@@ -170,7 +185,7 @@ class _ChainPool(torch.autograd.Function):
         if training:
             with ops._timed("chain_moments", V * 32):
                 check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), ptr(mom), ptr(s1), st), "dva_chain_moments")
-        bn1 = _bn_consts(s1, V, bns[0], training)
+        bn1 = _chain_bn(s1, V, bns[0], training, W1, 8, mom)           # mom[:8] = sum of x_map
         # ---- layer 2: statistics + set pooling
         s2 = zstats()
         zstar = torch.empty((N, D), dtype=torch.float32, device=dev)
@@ -179,7 +194,7 @@ class _ChainPool(torch.autograd.Function):
             check(lib.dva_chain_stats2(ptr(x_map), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1),
                                        ptr(bns[1].weight.detach()), ptr(s2), ptr(zstar), ptr(arg), V, st),
                   "dva_chain_stats2")
-        bn2 = _bn_consts(s2, V, bns[1], training)
+        bn2 = _chain_bn(s2, V, bns[1], training, W2, D, s2[2 * D:])    # stats2 also sums the layer's input a1
         pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
         check(lib.dva_chain_pooled(ptr(zstar), ptr(bn2), ptr(csr_idx), ptr(pooled), N, st), "dva_chain_pooled")
         t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats)
@@ -189,12 +204,12 @@ class _ChainPool(torch.autograd.Function):
             with ops._timed("chain_stats5", V * 36 + N * 128):
                 check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                           ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
-        bn5 = _bn_consts(s5, V, bns[2], training)
+        bn5 = _chain_bn(s5, V, bns[2], training)                       # layer 5 is not folded
         if training:
             with ops._timed("chain_stats6", V * 36 + N * 128):
                 check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                           ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
-        bn6 = _bn_consts(s6, V, bns[3], training)
+        bn6 = _chain_bn(s6, V, bns[3], training, W6, D, s6[2 * D:])
         # ---- the fused view kernel
         out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
         # SURVEY.md 8(d) fused view-gather + attention: V (C s + F_map 4 + idx) + N (C s + ptr); idx = view->point

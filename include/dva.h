@@ -333,10 +333,22 @@ int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* s
  * (dva_bn_finalize), "stats" caller-zeroed double[64].  All per-point outputs are only written for points
  * that have views: the caller zero-fills them.
  * ------------------------------------------------------------------------------------------ */
-/* ops: 16 KiB device buffer receiving the weight operands.  W1 [32][8], W2 [32][32], W5 [32][ld5] (the
- * first 32 columns: the per-view half of the concatenation layer), W6 [32][32], Ws [G][32], G <= 4. */
+/* ops: DVA_CHAIN_OPS_BYTES (30 KiB) device buffer receiving the weight operands (16 bf16 matrix-core operand
+ * blocks + an fp32 copy of the forward ones, from which the kernels build BatchNorm-folded operands
+ * bf16(0.6 gamma invstd W) for the layers whose raw output a pass does not need).  W1 [32][8], W2 [32][32],
+ * W5 [32][ld5] (the first 32 columns: the per-view half of the concatenation layer), W6 [32][32], Ws [G][32], G <= 4. */
+#define DVA_CHAIN_OPS_BYTES (16 * 64 * 16 + 7 * 64 * 32)
 int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6,
                    const float* Ws, int32_t G, void* ops, void* stream);
+/* BatchNorm bookkeeping of one chain layer: dva_bn_finalize (C = 32) + a fifth table row, bn fp32 [5][32] =
+ * mean | invstd | gamma | beta | shift, shift = the 0.6-scaled constant the layer's product starts from.  Plain layer
+ * (W = NULL): 0.6 (beta - mean G).  Layer evaluated with BatchNorm folded into its operand, training: W fp32 [32][ldw]
+ * (first K columns), sum_a fp64 [K] = sum over the m rows of the layer's INPUT; shift = 0.6 beta - bf16(0.6 G W) .
+ * (sum_a / m): the folded product keeps the exact batch mean.  Every dva_chain_* kernel takes these 5-row tables. */
+int dva_chain_bn_consts(const double* sums, double m, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, const float* gamma, const float* beta, float momentum, float eps,
+                        int32_t training, const float* W, int32_t ldw, int32_t K, const double* sum_a, float* bn,
+                        void* stream);
 /* Tile table of ptr (int64 [n_points + 1]).  chunk_points int64 [n_chunks + 1]: ascending point indices,
  * chunk c = points [chunk_points[c], chunk_points[c + 1]) is tiled independently (first 0, last n_points).
  * count: counts int32 [n_chunks] = tiles per chunk.  build: offsets int64 [n_chunks] = exclusive prefix sum

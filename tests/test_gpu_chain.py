@@ -172,7 +172,8 @@ def _oracle_grads(case, ref, autocast):
 def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
     """Gradients w.r.t. the feature maps and every parameter against the fp32 oracle; yardstick = the error of
     the reference maths itself under torch.autocast(bfloat16): per tensor, relative L2 error
-    <= max(2 x reference-autocast error, 5e-2) (4 x for the gate / score parameters, see below)."""
+    <= max(2 x reference-autocast error, 5e-2) (4 x for the gate / score parameters; for the encoder's parameters the
+    reference error is floored by its median over them, see below)."""
     case = make_case(7, N, C, sizes_fn)
     ref, m = build(case, G, train, gating=gating)
     sd = {k: v.clone() for k, v in ref.state_dict().items()}
@@ -186,6 +187,11 @@ def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
     assert rel(out, out_ref) < max(2e-2, 1.5 * rel(out_amp, out_ref)), (rel(out, out_ref), rel(out_amp, out_ref))
     names = ["x"] + [n for n, _ in ref.named_parameters()]
     report, bad = [], []
+    # The autocast error of one parameter is a single draw of a chaotic quantity (LeakyReLU sign and arg-max flips
+    # under a 2^-9 perturbation): for the mapping-feature encoder the yardstick is at least the median autocast
+    # error over its parameters, so that one lucky draw of the reference does not set the bar.
+    amps = sorted(rel(c, b) for n, b, c in zip(names, g_ref, g_amp) if b is not None and n.startswith("E_map"))
+    med = amps[len(amps) // 2] if amps else 0.0
     for n, a, b, c in zip(names, g, g_ref, g_amp):
         if b is None:
             assert a is None or float(a.abs().max()) == 0, n
@@ -193,6 +199,8 @@ def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
         assert a is not None, n
         ours, amp = rel(a, b), rel(c, b)
         report.append((n, round(ours, 4), round(amp, 4)))
+        if n.startswith("E_map"):
+            amp = max(amp, med)
         # gate / score-bias gradients are sums of per-point terms of both signs routed through an arg-max:
         # a handful of arg-max flips under the bf16 perturbation moves them by several % under either scheme
         loose = n.startswith("G.") or n.startswith("E_score")
@@ -234,7 +242,12 @@ def _bf(t):
 
 def emulated_chain(ref, vals, x_map, csr):
     """GroupBimodalCSRPool.forward of the oracle (pooling.py:263-315, :658-669) given the per-view values
-    ``vals`` = E_mod(x_mod) [V, C], with the chain's roundings."""
+    ``vals`` = E_mod(x_mod) [V, C], with the chain's roundings.  A layer whose raw output a pass does not need is
+    evaluated with BatchNorm folded into the rounded weight operand: t = a . bf16(0.6 G W)^T + 0.6 B,
+    leaky(y) = t + (2/3) |t|; G comes from the statistics of the plain product a . bf16(W)^T (what the statistics
+    pass of that layer sees; the set pooling takes its max there too), the shift from the batch mean of the folded
+    product itself.  Layers 1, 2, 6 fold; layer 5 adds the
+    per-point row before its BatchNorm and stays as it is."""
     import torch.nn.functional as F
     E = ref.E_map
     idx = O.dense_index(csr)
@@ -242,9 +255,26 @@ def emulated_chain(ref, vals, x_map, csr):
     def bn_act(blk, z):
         return F.leaky_relu(blk[1](z), 0.2)
 
-    a1 = _bf(bn_act(E.mlp_elt_1[0], x_map @ _bf(E.mlp_elt_1[0][0].weight).t()))
-    a2f = bn_act(E.mlp_elt_1[1], a1 @ _bf(E.mlp_elt_1[1][0].weight).t())
-    x_set = O.segment_csr(a2f, csr, 'max')
+    def folded(blk, a_prev):
+        """(activation of the folded product, activation of the plain product)"""
+        W, bn = blk[0].weight, blk[1].batch_norm
+        z = a_prev @ _bf(W).t()
+        if bn.training:
+            mean, var = z.mean(0), z.var(0, unbiased=False)
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        g = bn.weight * torch.rsqrt(var + bn.eps)
+        Wf = _bf(0.6 * g.view(-1, 1) * W)
+        if bn.training:     # the shift keeps the exact batch mean of the folded product (dva_chain_bn_consts)
+            shift = 0.6 * bn.bias - Wf @ a_prev.mean(0)
+        else:
+            shift = 0.6 * (bn.bias - mean * g)
+        t = a_prev @ Wf.t() + shift
+        return t + (2.0 / 3.0) * t.abs(), bn_act(blk, z)      # the module call updates the running statistics
+
+    a1 = _bf(folded(E.mlp_elt_1[0], x_map)[0])
+    a2f, a2_plain = folded(E.mlp_elt_1[1], a1)
+    x_set = O.segment_csr(a2_plain, csr, 'max')
     if E.use_num:
         set_num = torch.sqrt(1 / (csr[1:] - csr[:-1] + 1e-3))
         x_set = torch.cat((x_set, set_num.view(-1, 1).float()), dim=1)
@@ -252,7 +282,7 @@ def emulated_chain(ref, vals, x_map, csr):
     Wc = E.mlp_elt_2[0][0].weight
     u = s @ Wc[:, 32:].t()
     a5 = _bf(bn_act(E.mlp_elt_2[0], _bf(a2f) @ _bf(Wc[:, :32]).t() + u[idx]))
-    a6 = _bf(bn_act(E.mlp_elt_2[1], a5 @ _bf(E.mlp_elt_2[1][0].weight).t()))
+    a6 = _bf(folded(E.mlp_elt_2[1], a5)[0])
     compat = a6 @ _bf(ref.E_score.weight).t() + ref.E_score.bias
     out, _, _ = O.attention_tail(vals, compat, csr, ref.G, ref.num_groups, ref.out_mod, ref.group_scaling)
     return out
@@ -277,12 +307,22 @@ def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling)
     rows = (torch.randn(R, C, generator=gen)).bfloat16()
     row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
     ref, m = build(case, G, train, gating=gating, scaling=scaling)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    chain_params = [p for n, p in ref.named_parameters() if not n.startswith("E_mod")]
+    names = [n for n, _ in ref.named_parameters() if not n.startswith("E_mod")]
+    # sensitivity of the case: how far the exact fp32 maths is from the emulated arithmetic (the 2^-9 operand
+    # roundings are amplified by the BatchNorm gains and, for gradients, by sign / arg-max flips)
+    rows_fp = rows.float().requires_grad_()
+    compat = ref.E_score(ref.E_map(case["x_map"], csr))
+    out_fp, _, _ = O.attention_tail(rows_fp[row_idx.long()], compat, csr, ref.G, ref.num_groups, ref.out_mod,
+                                    ref.group_scaling)
+    g_fp = torch.autograd.grad((out_fp * case["w"]).sum(), [rows_fp] + chain_params, allow_unused=True)
+    ref.load_state_dict(sd)
     # oracle side
     rows_ref = rows.float().requires_grad_()
     out_ref = emulated_chain(ref, rows_ref[row_idx.long()], case["x_map"], csr)
-    chain_params = [p for n, p in ref.named_parameters() if not n.startswith("E_mod")]
-    names = [n for n, _ in ref.named_parameters() if not n.startswith("E_mod")]
     g_ref = torch.autograd.grad((out_ref * case["w"]).sum(), [rows_ref] + chain_params, allow_unused=True)
+    sens_out = rel(out_ref, out_fp.detach())
     # device side: the chain on a GatheredFeatures whose rows are the values
     rows_d = rows.to(DEV).requires_grad_()
     gf = ops.GatheredFeatures(rows_d, row_idx.to(DEV), None, True, None)
@@ -296,21 +336,24 @@ def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling)
     r_out = rel(out, out_ref)
     report = [("out", round(r_out, 5))]
     bad = []
-    for n, a, b in zip(["rows"] + names, g, g_ref):
+    for n, a, b, f in zip(["rows"] + names, g, g_ref, g_fp):
         if b is None:
             assert a is None or float(a.abs().max()) == 0, n
             continue
         r = rel(a, b)
-        report.append((n, round(r, 5)))
+        sens = rel(b, f)
+        report.append((n, round(r, 5), round(sens, 5)))
         # rows: no chaotic element.  Parameters: a rounding-boundary flip of one bf16 activation (1 view in ~30)
         # moves a score by ~1e-3, which flips the arg-max view of a few near-tied points: their gate gradient
         # lands on another view (measured: 3 views of 65536 carry the whole difference, tools/debug_chain.py)
         if n == "E_score.bias" and not gating:
             continue        # exactly zero in exact arithmetic (softmax is shift invariant): nothing to compare
-        if r > (1e-2 if n == "rows" else 1.5e-1):
-            bad.append((n, r))
-    print("chain vs bf16 emulation, rel L2:", report)
-    assert r_out < 6e-3, report          # bf16 rounding of the output itself: 2^-9
+        # (tolerances scale with the sensitivity of the case: agreement with the emulation must be well inside
+        # the emulation's own distance from exact arithmetic)
+        if r > (max(1e-2, 0.25 * sens) if n == "rows" else max(1.5e-1, sens)):
+            bad.append((n, r, sens))
+    print("chain vs bf16 emulation, rel L2 (kernel vs emulation, emulation vs fp32):", report)
+    assert r_out < max(6e-3, 0.25 * sens_out), (report, sens_out)      # bf16 rounding of the output itself: 2^-9
     assert not bad, (bad, report)
     if train:
         for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
