@@ -54,6 +54,9 @@ class GradientBucket:
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._handles = None
         self._average = True
+        self._inplace = False
+        self._scale = False
+        self._buf = self.flat
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -71,24 +74,36 @@ class GradientBucket:
             import contextlib
             ctx = contextlib.nullcontext()
         world = dist.get_world_size(self.group)
+        # mean inside the collective where the backend has it (RCCL): no separate scaling pass over the bucket
+        avg_op = average and dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM
         with ctx:
-            off = 0
-            for p, n in zip(self.params, self.sizes):
-                if p.grad is None:
-                    self.flat[off:off + n].zero_()
-                else:
-                    self.flat[off:off + n].copy_(p.grad.reshape(-1))
-                off += n
+            # a single contiguous fp32 gradient is reduced where it lies (what DDP's gradient-as-bucket-view gives
+            # every parameter): no flatten / unflatten copies
+            g0 = self.params[0].grad if len(self.params) == 1 else None
+            self._inplace = g0 is not None and g0.is_contiguous() and g0.dtype == torch.float32
+            if self._inplace:
+                buf = g0.view(-1)
+            else:
+                buf = self.flat
+                off = 0
+                for p, n in zip(self.params, self.sizes):
+                    if p.grad is None:
+                        buf[off:off + n].zero_()
+                    else:
+                        buf[off:off + n].copy_(p.grad.reshape(-1))
+                    off += n
+            self._buf = buf
             self._handles = []
             for a, b in self.chunks:
                 if b > a:
-                    self._handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                                         async_op=True))
+                    self._handles.append(dist.all_reduce(buf[a:b], op=op, group=self.group, async_op=True))
+            self._scale = average and not avg_op and world > 1
             if self.stream is not None:
                 for hnd in self._handles:
                     hnd.wait()               # orders the collective inside the side stream, does not block the host
-                if average:
-                    self.flat.div_(world)
+                if self._scale:
+                    buf.div_(world)
 
     def finish(self):
         """Wait for the all-reduces and write the reduced gradients back into ``p.grad``."""
@@ -99,9 +114,11 @@ class GradientBucket:
         else:
             for hnd in self._handles:
                 hnd.wait()
-            if self._average:
-                self.flat.div_(dist.get_world_size(self.group))
+            if self._scale:
+                self._buf.div_(dist.get_world_size(self.group))
         self._handles = None
+        if self._inplace:
+            return
         off = 0
         for p, n in zip(self.params, self.sizes):
             g = self.flat[off:off + n].view_as(p)

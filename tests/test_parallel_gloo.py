@@ -42,6 +42,15 @@ def _worker(rank, world, port, out):
     loss = model(feats[tiles[rank]]).square().mean()
     loss.backward()
     bucket.reduce(average=True)
+    # a bucket of ONE contiguous fp32 gradient is reduced where it lies (no flatten / unflatten copies)
+    big = torch.nn.Parameter(torch.zeros(1000))
+    big.grad = torch.full((1000,), float(rank + 1))
+    held = big.grad
+    single = GradientBucket([big], bucket_bytes=1024)                     # four chunks
+    single.start(average=True)
+    single.finish()
+    assert big.grad is held and single._inplace
+    torch.testing.assert_close(big.grad, torch.full((1000,), 1.5))         # mean of 1 and 2
     if rank == 0:
         torch.save([p.grad.clone() for p in model.parameters()], out)
     dist.barrier()
