@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
           const uint32_t di[4] = {dpq[qq].x, dpq[qq].y, dpq[qq].z, dpq[qq].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            da2t[4 * qq + e] += (ok && (int)ai[e] == vg) ? __uint_as_float(di[e]) : 0.f;
+            da2t[4 * qq + e] += (int)ai[e] == vg ? __uint_as_float(di[e]) : 0.f;   // lanes without a view: arg reads 0 != vg
         }
       }
       layer_bwd<false, true>(z2, da2t, s_tab[1], h, ok, unused_st, dz);
@@ -596,17 +596,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       tileT_put_packed(tb_, j, h, a1);
       const f32x16 da1 = mm32_lds(s_ops, L_W2T, lane, dzp, zero);
       layer_bwd<true, false>(z1, da1, s_tab[0], h, ok, st, dz);
-      // dy1 of the layer (layer_bwd keeps it internal) for P = sum_v dy1 x^T
-      {
-        float g1[16], b1[16], dy1[16];
-        tab16(s_tab[0], T_G, h, g1);
-        tab16(s_tab[0], T_B, h, b1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dy1[r] = ok ? da1[r] * dleaky(__builtin_fmaf(z1[r], g1[r], b1[r])) : 0.f;
-        tileT_put_acc(tc, j, h, dy1);
-        tileT_put(td, 4 * h, 4 * h + 1, j, p.x.x, p.x.y);      // lanes without a view loaded zeros
-        tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
-      }
+      // dy1 (handed back by the statistics-only layer_bwd; zero for lanes without a view: their da1 is) for
+      // P = sum_v dy1 x^T
+      tileT_put_acc(tc, j, h, dz);
+      tileT_put(td, 4 * h, 4 * h + 1, j, p.x.x, p.x.y);      // lanes without a view loaded zeros
+      tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
       accS = wgrad(tc, td, j, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]

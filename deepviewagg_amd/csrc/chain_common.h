@@ -430,6 +430,7 @@ __device__ __forceinline__ void layer_bwd(const f32x16& z, const f32x16& da, con
         st[1][r] = __builtin_fmaf(dy, z[r], st[1][r]);
       }
       if (APPLY) dz[r] = __builtin_fmaf(-k2[e], z[r], __builtin_fmaf(g[e], dy, -k1[e]));
+      else dz[r] = dy;        // statistics-only call: hands dy back (dead code where the caller ignores it)
     }
   }
 }

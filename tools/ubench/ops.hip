@@ -15,7 +15,7 @@
     _Pragma("unroll") for (int i = 0; i < 16; ++i) a[i] = i + threadIdx.x;                   \
     for (int it = 0; it < iters; ++it) {                                                     \
       _Pragma("unroll") for (int i = 0; i < 16; ++i)                                         \
-          asm volatile(ASM : "+v"(a[i]) : "v"(c), "v"(b), "v"(m), "v"(addr) : "vcc", "memory"); \
+          asm volatile(ASM : "+v"(a[i]) : "v"(c), "v"(b), "v"(m), "v"(addr) : "vcc", "s20", "s21", "memory"); \
     }                                                                                        \
     float s = 0;                                                                             \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) s += a[i];                                \
@@ -59,6 +59,13 @@ KERNEL(k_sub, "v_sub_f32 %0, %0, %1")
 KERNEL(k_bfe, "v_bfe_u32 %0, %0, 3, 5")
 KERNEL(k_cvt_u, "v_cvt_f32_u32 %0, %0")
 KERNEL(k_accw, "v_accvgpr_write_b32 a0, %0")
+KERNEL(k_bfi, "v_bfi_b32 %0, %3, %1, %0")
+KERNEL(k_xor, "v_xor_b32 %0, %0, %3")
+KERNEL(k_andor, "v_and_or_b32 %0, %0, %3, %1")
+KERNEL(k_cnd64, "v_cndmask_b32 %0, %0, %2, s[20:21]")
+KERNEL(k_cmp64, "v_cmp_lt_f32 s[20:21], %0, %1")
+KERNEL(k_cmpcnd64, "v_cmp_lt_f32 s[20:21], %0, %1\n v_cndmask_b32 %0, %0, %2, s[20:21]")
+KERNEL(k_fmak, "v_fma_f32 %0, %0, 0.5, %2")
 
 typedef void (*kern_t)(float*, int);
 void run(const char* name, kern_t f, int per_it) {
@@ -85,6 +92,6 @@ int main() {
   RUN(k_fma); RUN(k_fmac); RUN(k_add); RUN(k_sub); RUN(k_mul); RUN(k_mulabs); RUN(k_max); RUN(k_max3); RUN(k_med3);
   RUN(k_mov); RUN(k_and); RUN(k_or); RUN(k_addu); RUN(k_lshl); RUN(k_lshlor); RUN(k_perm); RUN(k_bfe); RUN(k_cvt_u);
   RUN(k_cmp); run("k_cmp_cnd", k_cmp_cnd, 2); RUN(k_cnd); RUN(k_cvtpk); RUN(k_dot2c); RUN(k_exp); RUN(k_rcp);
-  RUN(k_swap); RUN(k_dsr128); RUN(k_dsw32); RUN(k_dsw16); RUN(k_dsadd); RUN(k_accw);
+  RUN(k_swap); RUN(k_dsr128); RUN(k_dsw32); RUN(k_dsw16); RUN(k_dsadd); RUN(k_accw); RUN(k_bfi); RUN(k_xor); RUN(k_andor); RUN(k_cnd64); RUN(k_cmp64); run("k_cmpcnd64", k_cmpcnd64, 2); RUN(k_fmak);
   return 0;
 }
