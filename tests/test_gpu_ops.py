@@ -267,7 +267,9 @@ def test_gather_random_vs_oracle(dtype, C):
 # row plan (views grouped by feature-map row) and the rows gradient as a segmented reduction
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("V,R", [(0, 5), (1, 1), (1000, 7), (50000, 4096), (300000, 1 << 18)])
+# the last two: above the library's merge-sort limit with 17- / 18-bit row keys (the two-pass 9-bit onesweep instance)
+@pytest.mark.parametrize("V,R", [(0, 5), (1, 1), (1000, 7), (50000, 4096), (300000, 1 << 18),
+                                 (1500000, (1 << 16) + 9), (3000000, (1 << 18) - 3)])
 def test_row_plan_is_a_stable_sort(V, R):
     from deepviewagg_amd import ops
     gen = torch.Generator().manual_seed(V + R)
