@@ -396,7 +396,9 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
     float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N) {
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
-  __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][32 * TSB];
+  // second operand tile of the small products: 4 (score gradients) / 8 (x_map) rows + one shared zero row
+  constexpr int TD_ROWS = STAGE == 6 ? 4 : 8;
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][(TD_ROWS + 1) * TSB];
   // STAGE 5: indicator tile [local point][view] (bf16 1.0 where the view belongs to the point) and the point ids
   __shared__ __attribute__((aligned(16))) bf16_t s_ind[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TSB : 8];
   __shared__ int s_plp[STAGE == 5 ? 4 : 1][32];
@@ -433,8 +435,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   stage_tab(s_tab[3], bn6, STAGE == 6 ? sm6 : nullptr);
   // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
   for (int i = threadIdx.x; i < 4 * 32 * TSB; i += blockDim.x) {
-    if (STAGE != 5) (&s_td[0][0])[i] = 0;
-    else (&s_ind[0][0])[i] = 0;
+    if (STAGE != 5) {
+      if (i < 4 * (TD_ROWS + 1) * TSB) (&s_td[0][0])[i] = 0;
+    } else {
+      (&s_ind[0][0])[i] = 0;
+    }
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dz);
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
-      accS = wgrad(tc, td, j, h, accS);       // dWs^T[k][g] = sum_v a6[v][k] dc[v][g]
+      accS = wgrad_short(tc, td, j, TD_ROWS, h, accS);       // dWs^T[k][g] = sum_v a6[v][k] dc[v][g]
       wave_sync();
     } else if constexpr (STAGE == 5) {
       f32x16 uacc = load_u(U, ok, p.vpj, h);
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
-      accS = wgrad(tc, td, j, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
+      accS = wgrad_short(tc, td, j, TD_ROWS, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
       wave_sync();
     }
   });

@@ -457,6 +457,14 @@ __device__ __forceinline__ f32x16 wgrad(const bf16_t* ta, const bf16_t* tb, int 
   acc = CH_MFMA(tileT_get(ta, j, h, 1), tileT_get(tb, j, h, 1), acc);
   return acc;
 }
+// the same with a short second tile: its rows >= jb_max are one shared zero row (row jb_max)
+__device__ __forceinline__ f32x16 wgrad_short(const bf16_t* ta, const bf16_t* tb, int j, int jb_max, int h,
+                                              f32x16 acc) {
+  const int jb = j < jb_max ? j : jb_max;
+  acc = CH_MFMA(tileT_get(ta, j, h, 0), tileT_get(tb, jb, h, 0), acc);
+  acc = CH_MFMA(tileT_get(ta, j, h, 1), tileT_get(tb, jb, h, 1), acc);
+  return acc;
+}
 // acc[r] = M[chan(r, h)][j] of every wavefront -> out[row * ld + col] (fp32 atomics), cols < ncol only
 __device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restrict__ out, int ld, int ncol,
                                              bool transpose, float* s_red) {
