@@ -504,51 +504,59 @@ namespace chain {
 
 struct SegInfo {
   bool valid;        // lane has a view
-  bool same[5];      // lane j - (1 << o) belongs to the same point
+  bool pd[4];        // scan step k: lane j - (1 << k) lies in the same 16-lane row and in the same point
+  bool pb;           // row 1 lane whose point started in row 0 (takes the row-0 tail in the cross-row step)
   int ss, se;        // first / last lane of this lane's point inside the tile
   uint32_t smask;    // bit j: view j is the first view (in the tile) of its point
   uint32_t emask;    // bit j: view j is the last view (in the tile) of its point
   int nseg;          // points in the tile (uniform)
 };
 
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_keep(int old, int x) {     // lanes without a source lane keep `old`
+  return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xf, false);
+}
+
+// Point structure of a tile from the view -> point index: neighbours through DPP wave shifts (both half-waves hold
+// the same 32 views), first / last views through two ballots; no LDS crossbar operation.
 __device__ __forceinline__ SegInfo seg_setup(int vpj, int j, int lane, int nv) {
   SegInfo s;
   s.valid = j < nv;
   const int lp = s.valid ? vpj : -1 - j;
-#pragma unroll
-  for (int o = 0; o < 5; ++o) {
-    const int d = 1 << o;
-    const int other = shfl(lp, lane - d);
-    s.same[o] = (j >= d) && (other == lp);
-  }
-  const int nxt = shfl(lp, lane + 1);
+  const int prv = dpp_keep<0x138>(lp, lp);      // wave_shr:1
+  const int nxt = dpp_keep<0x130>(lp, lp);      // wave_shl:1
+  const bool is_start = (j == 0) || (prv != lp);
   const bool is_end = (j == 31) || (nxt != lp);
-  s.smask = (uint32_t)__ballot(!s.same[0] && s.valid);
+  s.smask = (uint32_t)__ballot(is_start && s.valid);
   s.emask = (uint32_t)__ballot(is_end && s.valid);
   // invalid lanes: their own one-lane segments
   const uint32_t below = s.smask & (0xffffffffu >> (31 - j));
   s.ss = s.valid ? 31 - __clz((int)below) : j;
   s.se = s.valid ? j + (__ffs((int)(s.emask >> j)) - 1) : j;
   s.nseg = __popc(s.smask);
+  const int dist = j - s.ss, jr = j & 15;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s.pd[k] = dist >= (1 << k) && jr >= (1 << k);
+  s.pb = j >= 16 && dist > jr;
   return s;
 }
-// inclusive segmented scans over the lanes of a half-wave; the last lane of a segment ends up with the
-// reduction of the whole segment
+// inclusive segmented scans over the 32 lanes of a half-wave (the last lane of a point ends up with the reduction over
+// the point): four DPP row shifts inside the 16-lane rows, then lane 15 of row 0 / 2 broadcast into row 1 / 3
+template <typename Op>
+__device__ __forceinline__ float seg_scan(float v, const SegInfo& s, Op op) {
+  float t;
+  t = __int_as_float(dpp_keep<0x111>(__float_as_int(v), __float_as_int(v)));  v = s.pd[0] ? op(v, t) : v;
+  t = __int_as_float(dpp_keep<0x112>(__float_as_int(v), __float_as_int(v)));  v = s.pd[1] ? op(v, t) : v;
+  t = __int_as_float(dpp_keep<0x114>(__float_as_int(v), __float_as_int(v)));  v = s.pd[2] ? op(v, t) : v;
+  t = __int_as_float(dpp_keep<0x118>(__float_as_int(v), __float_as_int(v)));  v = s.pd[3] ? op(v, t) : v;
+  t = __int_as_float(dpp_keep<0x142, 0xa>(__float_as_int(v), __float_as_int(v)));   // row_bcast:15 into rows 1, 3
+  return s.pb ? op(v, t) : v;
+}
 __device__ __forceinline__ float seg_scan_max(float v, const SegInfo& s, int lane) {
-#pragma unroll
-  for (int o = 0; o < 5; ++o) {
-    const float t = shfl(v, lane - (1 << o));
-    v = s.same[o] ? vmaxf(v, t) : v;
-  }
-  return v;
+  return seg_scan(v, s, [](float a, float b) { return vmaxf(a, b); });
 }
 __device__ __forceinline__ float seg_scan_sum(float v, const SegInfo& s, int lane) {
-#pragma unroll
-  for (int o = 0; o < 5; ++o) {
-    const float t = shfl(v, lane - (1 << o));
-    v = s.same[o] ? v + t : v;
-  }
-  return v;
+  return seg_scan(v, s, [](float a, float b) { return a + b; });
 }
 // value of the segment's last lane, in every lane of the segment
 __device__ __forceinline__ float seg_total(float scanned, const SegInfo& s, int h) {
