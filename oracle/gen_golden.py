@@ -193,6 +193,42 @@ def gen_pools():
     save("pool_simple", **res)
 
 
+def gen_pools_headline():
+    """The headline instantiation of the view pooling (C = 64, G = 4, DeepSetFeat, use_num) on a small ragged set that
+    contains 32-view points, unseen points and points with more than 32 views: the reference's own forward + backward
+    for the bf16 recompute chain (tests/test_gpu_chain.py).  Inputs lie on the bf16 grid so that the device holds
+    exactly the same values."""
+    print("GroupBimodalCSRPool, headline shape (C = 64, G = 4)")
+    gen = torch.Generator().manual_seed(11)
+    kwargs = dict(in_map=8, in_mod=64, num_groups=4, use_mod=False, map_encoder='DeepSetFeat', use_num=True)
+    for name, train in (("pool_group_c64_train", True), ("pool_group_c64_eval", False)):
+        sizes = torch.randint(1, 9, (64,), generator=gen)
+        sizes[torch.rand(64, generator=gen) < 0.2] = 0
+        sizes[:8] = 32
+        sizes[8], sizes[9] = 40, 70
+        sizes = sizes[torch.randperm(64, generator=gen)]
+        csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+        V = int(csr[-1])
+        module = ref_pooling.GroupBimodalCSRPool(**kwargs)
+        randomize(module, gen)
+        module.train(train)
+        sd = state(module)
+        x_mod = torch.randn(V, 64, generator=gen).bfloat16().float().requires_grad_()
+        x_map = torch.rand(V, 8, generator=gen)
+        module.save_last = True
+        out = module(None, x_mod, x_map, csr)
+        w = torch.randn(out.shape, generator=gen)
+        params = [p for p in module.parameters()]
+        grads = torch.autograd.grad((out * w).sum(), [x_mod] + params, allow_unused=True)
+        res = dict(csr=csr, x_mod=x_mod, x_map=x_map, w=w, out=out, train=np.array(int(train)), grad_x_mod=grads[0])
+        for (n, p), g in zip(module.named_parameters(), grads[1:]):
+            res['gp/' + n] = g if g is not None else torch.zeros_like(p)
+        res.update(state(module, prefix='sd_after/'))
+        res.update(sd)
+        res['kwargs'] = np.array(repr(kwargs))
+        save(name, **res)
+
+
 # ------------------------------------------------------------------------------------------------
 def gen_gather():
     print("get_mapped_features: nearest (after downscale) and bilinear (sparse_interpolation)")
@@ -733,7 +769,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = set(sys.argv[1:])
-    jobs = dict(softmax=gen_softmax, segment=gen_segment, pools=gen_pools, gather=gen_gather,
+    jobs = dict(softmax=gen_softmax, segment=gen_segment, pools=gen_pools, pools_headline=gen_pools_headline,
+                gather=gen_gather,
                 branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
                 transforms=gen_transforms, cylinder=gen_mapping_cylinder)
     for name, fn in jobs.items():

@@ -94,7 +94,8 @@ def run_dev(case, m, chain, need_grad=True):
 @pytest.mark.parametrize("train", [False, True])
 @pytest.mark.parametrize("sizes_fn,N,C,G", [(ragged, 3000, 64, 4), (ragged_long, 2000, 64, 4), (full32, 300, 64, 4),
                                             (ragged_long, 1500, 32, 2), (ragged, 1500, 128, 1),
-                                            (ragged_long, 700, 512, 4), (ragged, 900, 256, 4)])
+                                            (ragged_long, 700, 512, 4), (ragged, 900, 256, 4),
+                                            (ragged, 20000, 64, 4)])       # eval: the single fused launch at N = 20 k
 def test_chain_forward_matches_oracle(sizes_fn, N, C, G, train):
     case = make_case(3, N, C, sizes_fn)
     ref, m = build(case, G, train)
@@ -359,3 +360,66 @@ def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling)
         for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
             if "running" in k and not k.startswith("E_mod"):
                 torch.testing.assert_close(a.cpu(), b, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own output for the headline instantiation (fixtures written by oracle/gen_golden.py pools_headline
+# from the reference source: C = 64, G = 4, points with exactly 32 views, with 40 / 70 views, unseen points).  The
+# chain runs in bf16 on values that lie on the bf16 grid; yardstick = the oracle under torch.autocast(bfloat16).
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pool_group_c64_train", "pool_group_c64_eval"])
+def test_chain_against_reference_fixture(name):
+    import ast
+    from conftest import load_golden, t, state_dict_from
+    from deepviewagg_amd import ops
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    g = load_golden(name)
+    kwargs = ast.literal_eval(str(g["kwargs"]))
+    train = bool(g["train"])
+    csr, x_map, w = t(g["csr"]), t(g["x_map"]), t(g["w"])
+    V = x_map.shape[0]
+    m = P.GroupBimodalCSRPool(**kwargs)
+    m.load_state_dict(state_dict_from(g), strict=True)
+    m = m.to(DEV).train(train)
+    rows = t(g["x_mod"], DEV).bfloat16().requires_grad_()            # exact: the fixture's values are bf16 numbers
+    # every view its own map row: E_mod on the rows == E_mod on the gathered values
+    gf = ops.GatheredFeatures(rows, torch.arange(V, dtype=torch.int32, device=DEV),
+                              torch.ones(V, dtype=torch.int32, device=DEV), True, None)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(None, gf, x_map.to(DEV), csr.to(DEV))
+    assert out.dtype == torch.bfloat16, "the recompute chain must be the path that ran"
+    grads = torch.autograd.grad((out.float() * w.to(DEV)).sum(), [rows] + list(m.parameters()), allow_unused=True)
+    # yardstick: the oracle under autocast against the same fixture
+    ref = O.GroupBimodalCSRPool(**kwargs)
+    ref.load_state_dict(state_dict_from(g), strict=True)
+    ref.train(train)
+    xr = t(g["x_mod"]).requires_grad_()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out_amp = ref(None, xr, x_map, csr)
+    g_amp = torch.autograd.grad((out_amp.float() * w).sum(), [xr] + list(ref.parameters()), allow_unused=True)
+    r, r_amp = rel(out, t(g["out"])), rel(out_amp, t(g["out"]))
+    print(f"chain vs reference fixture {name}: out {r:.4f} (oracle under autocast {r_amp:.4f})")
+    assert r < max(2e-2, 1.5 * r_amp), (r, r_amp)
+    unseen = csr[1:] == csr[:-1]
+    assert float(out.float().cpu()[unseen].abs().max()) == 0.0
+    names = ["x_mod"] + [n for n, _ in m.named_parameters()]
+    refs = [t(g["grad_x_mod"])] + [t(g["gp/" + n]) for n in names[1:]]
+    amps = sorted(rel(c, b) for n, b, c in zip(names, refs, g_amp) if c is not None and n.startswith("E_map"))
+    med = amps[len(amps) // 2]
+    bad, report = [], []
+    for n, a, b, c in zip(names, grads, refs, g_amp):
+        if float(b.abs().max()) == 0 or a is None:
+            continue
+        ours, amp = rel(a, b), (rel(c, b) if c is not None else 0.0)
+        report.append((n, round(ours, 4), round(amp, 4)))
+        if n.startswith("E_map"):
+            amp = max(amp, med)
+        loose = n.startswith("G.") or n.startswith("E_score")
+        if ours > max((4.0 if loose else 2.0) * amp, 5e-2):
+            bad.append(report[-1])
+    print("chain vs reference fixture, gradients (ours, oracle under autocast):", report)
+    assert not bad, (bad, report)
+    if train:
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                torch.testing.assert_close(v.cpu(), t(g["sd_after/" + k]), rtol=2e-2, atol=2e-3)
