@@ -210,6 +210,38 @@ def cpu_baseline(log2_points, views, C, threads):
                        f"C={C}, {reps} fwd+bwd steps, {dt:.2f} s/step")
 
 
+def cpu_gather_attention_twin(log2_points, views, C, G=4):
+    """The C + OpenMP twin of the view gather + attention tail (oracle/attention_oracle.c: softmax over the views of a
+    point, gathered value rows, weighted group sum, gate; forward + backward incl. the rows scatter-add) on ALL host
+    cores: the part of the path that is a CPU kernel rather than a PyTorch op sequence.  Bounded sample of S1."""
+    import numpy as np
+    from oracle import attention_oracle as A
+    n = 1 << log2_points
+    rng = np.random.default_rng(0)
+    V, R = n * views, 32 * 64 * 128
+    csr = np.arange(0, V + 1, views, dtype=np.int64)
+    row_idx = rng.integers(0, R, V, dtype=np.int32)
+    rows = rng.standard_normal((R, C), dtype=np.float32)
+    compat = rng.standard_normal((V, G), dtype=np.float32)
+    gw, gb = np.ones(G, np.float32), np.zeros(G, np.float32)
+    gout = rng.standard_normal((n, C), dtype=np.float32)
+
+    def one():
+        out, att, gate, amax = A.forward(rows, row_idx, compat, csr, gw, gb, True)
+        A.backward(gout, rows, row_idx, compat, csr, att, gate, amax, gw, gb, True)
+    one()
+    reps, t0 = 3, time.perf_counter()
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=n / dt, unit="points/s", cores=A.num_threads(), kind="port",
+                sample=f"oracle/attention_oracle.c (C + OpenMP, fp32), view gather + attention forward + backward only "
+                       f"(no mapping-feature encoder, no E_mod), N=2^{log2_points} points x {views} views, C={C}, "
+                       f"G={G}, {reps} steps, {dt:.3f} s/step",
+                gpu_same_scope_note="on the GPU this scope is chain_attn_fwd + chain_attn_bwd + "
+                                    "view_gather_rows_grad + row_plan (kernels table) minus the encoder recompute")
+
+
 def mapping_build_bench(device, n_images=4, n_points=200_000):
     """Secondary measurement: mapping build at the S3DIS settings (2048x1024
     projection map, voxel 2 cm, r_max 8 m, exact=True): images/s on the GPU and for the C oracle on
@@ -565,6 +597,11 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
+            try:
+                res["cpu_baseline"]["gather_attention_openmp_twin"] = cpu_gather_attention_twin(
+                    min(args.log2_points, 18), views, C)
+            except OSError as e:         # the oracle library is built by __graft_entry__.build()
+                res["cpu_baseline"]["gather_attention_openmp_twin"] = {"error": str(e)}
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.barrier()
