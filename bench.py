@@ -164,7 +164,7 @@ def step(scene, packed, mods, dtype, lazy=True, before_backward=None):
         x_mod = ops.lazy_gather_nearest(x, packed, exact=exact) if lazy else ops.gather_nearest(x, packed)
         x_mod = atomic_pool(None, x_mod, None, scene["atom_ptr"])             # identity for exact mappings
         x_pool = view_pool(scene["x_3d"], x_mod, scene["x_map"], scene["csr"])  # [N, C]
-        out = fusion(scene["x_3d"], x_pool.to(scene["x_3d"].dtype))           # [N, 4 + C]
+        out = fusion(scene["x_3d"], x_pool)                                   # [N, 4 + C] fp32 (cat promotes)
     if scene.get("grad_out") is None or scene["grad_out"].shape != out.shape:
         scene["grad_out"] = torch.randn(out.shape, device=out.device, dtype=out.dtype,
                                         generator=torch.Generator(device=out.device).manual_seed(99)) / out.shape[0]

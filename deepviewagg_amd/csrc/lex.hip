@@ -9,6 +9,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "dva_common.h"
 
@@ -100,8 +101,10 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
     PlanSort9;
 static inline bool plan_wide_digits(int bits) { return bits == 17 || bits == 18; }
 
-static hipError_t plan_sort(void* temp, size_t& tmp, const uint32_t* kin, uint32_t* kout, const int32_t* vin,
-                            int32_t* vout, size_t n, int bits, hipStream_t s) {
+// values in = the view numbers 0 .. n-1 as a counting iterator (no iota array is written or read)
+static hipError_t plan_sort(void* temp, size_t& tmp, const uint32_t* kin, uint32_t* kout, int32_t* vout, size_t n,
+                            int bits, hipStream_t s) {
+  rocprim::counting_iterator<int32_t> vin(0);
   if (plan_wide_digits(bits))
     return rocprim::radix_sort_pairs<PlanSort9>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
   return rocprim::radix_sort_pairs(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
@@ -111,10 +114,10 @@ static int plan_layout(int64_t n, int bits, PlanLayout* L) {
   size_t tmp = 0;
   uint32_t* nk = nullptr;
   int32_t* nv = nullptr;
-  if (plan_sort(nullptr, tmp, nk, nk, nv, nv, (size_t)n, bits, (hipStream_t)0) != hipSuccess)
+  if (plan_sort(nullptr, tmp, nk, nk, nv, (size_t)n, bits, (hipStream_t)0) != hipSuccess)
     return DVA_ERR_LAUNCH;
   size_t off = 0;
-  L->off_iota = off;  off += align256((size_t)n * 4);
+  L->off_iota = off;                                       // (no view-number array: a counting iterator feeds the sort)
   L->off_keys = off;  off += align256((size_t)n * 4);
   L->off_temp = off;
   L->temp_bytes = tmp;
@@ -228,12 +231,9 @@ int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_
   if (rc) return rc;
   if ((int64_t)L.total > workspace_bytes) return DVA_ERR_INVALID;
   char* ws = (char*)workspace;
-  int32_t* iota = (int32_t*)(ws + L.off_iota);
   uint32_t* kout = (uint32_t*)(ws + L.off_keys);
-  hipLaunchKernelGGL(iota32_kernel, dim3(grid_for(n_views)), dim3(256), 0, s, iota, n_views);
   size_t tmp = L.temp_bytes;
-  if (plan_sort(ws + L.off_temp, tmp, (const uint32_t*)row_idx, kout, iota, perm, (size_t)n_views, bits, s) !=
-      hipSuccess)
+  if (plan_sort(ws + L.off_temp, tmp, (const uint32_t*)row_idx, kout, perm, (size_t)n_views, bits, s) != hipSuccess)
     return DVA_ERR_LAUNCH;
   hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(n_views + 1)), dim3(256), 0, s, kout, n_views,
                      n_rows, row_ptr);

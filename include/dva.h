@@ -455,6 +455,13 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
                           double* stats, int64_t n_points, void* stream);
 
+/* 'concatenation' fusion (modules/multimodal/fusion.py:7-53: torch.cat((x_main, x_mod), dim=-1)) with the dtype
+ * promotion of torch.cat folded in: x_main fp32 [N][C_main], x_mod fp32 / bf16 [N][C_mod] -> out fp32
+ * [N][C_main + C_mod]; bwd: grad_out -> grad_main fp32, grad_mod in mod_dtype.  C_main, C_mod multiples of 4. */
+int dva_concat_cast_fwd(const float* x_main, const void* x_mod, float* out, int64_t N, int32_t C_main, int32_t C_mod,
+                        int32_t mod_dtype, void* stream);
+int dva_concat_cast_bwd(const float* grad_out, float* grad_main, void* grad_mod, int64_t N, int32_t C_main,
+                        int32_t C_mod, int32_t mod_dtype, void* stream);
 /* Measurement helper (bench.py): float4 grid-stride device copy of nbytes (multiple of 16) -- the practical HBM
  * ceiling (read + write) beside which the roofline fractions are quoted. */
 int dva_copy_ceiling(const void* src, void* dst, int64_t nbytes, void* stream);

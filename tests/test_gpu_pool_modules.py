@@ -396,3 +396,23 @@ def test_view_level_pool_with_equal_counts_is_not_the_identity():
         close(out, ref)
     # atomic level: stays lazy
     assert isinstance(P.BimodalCSRPool()(None, lazy, None, torch.arange(V + 1, device=DEV)), ops.GatheredFeatures)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,Ca,Cb", [(1000, 4, 64), (37, 8, 512), (5, 4, 4), (0, 4, 64)])
+def test_concatenation_fusion_kernel_equals_torch_cat(N, Ca, Cb, dtype):
+    """BimodalFusion('concatenation') on device tensors = torch.cat with its dtype promotion, forward and backward."""
+    from deepviewagg_amd.modules.multimodal.fusion import BimodalFusion, _fusable
+    gen = torch.Generator().manual_seed(N + Cb)
+    a = torch.randn(N, Ca, generator=gen).to(DEV).requires_grad_()
+    b = torch.randn(N, Cb, generator=gen).to(dtype).to(DEV).requires_grad_()
+    assert _fusable(a, b)
+    out = BimodalFusion(mode='concatenation')(a, b)
+    ref = torch.cat((a.detach(), b.detach()), dim=-1)
+    assert out.dtype == ref.dtype == torch.float32 and torch.equal(out, ref)
+    w = torch.randn(N, Ca + Cb, generator=gen).to(DEV)
+    ga, gb = torch.autograd.grad((out * w).sum(), [a, b])
+    assert torch.equal(ga, w[:, :Ca]) and gb.dtype == dtype and torch.equal(gb, w[:, Ca:].to(dtype))
+    # shapes the kernel does not cover fall back to torch.cat
+    c = torch.randn(N, 3, device=DEV)
+    assert not _fusable(a, c) and BimodalFusion(mode='concatenation')(a, c).shape == (N, Ca + 3)
