@@ -179,10 +179,30 @@ __global__ __launch_bounds__(256) void rowbn_sums_vec_kernel(const T* __restrict
       }
     }
   }
+  // the threads of a wavefront that own the same channels (lanes ci, ci + cpr, ...) reduce with shuffles first:
+  // one LDS fp64 atomic per (wavefront, channel) instead of one per thread (fp64 LDS atomics are compare-and-swap
+  // loops), then one global atomic per (block, channel)
+  if (cpr <= 32 && (cpr & (cpr - 1)) == 0) {
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    atomicAdd(&s_red[c0 + k], a0[k]);
-    atomicAdd(&s_red[C + c0 + k], a1[k]);
+    for (int k = 0; k < VEC; ++k) {
+      for (int off = cpr; off < 64; off <<= 1) {
+        a0[k] += __shfl_xor(a0[k], off);
+        a1[k] += __shfl_xor(a1[k], off);
+      }
+    }
+    if ((threadIdx.x & 63) < cpr) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        atomicAdd(&s_red[c0 + k], a0[k]);
+        atomicAdd(&s_red[C + c0 + k], a1[k]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      atomicAdd(&s_red[c0 + k], a0[k]);
+      atomicAdd(&s_red[C + c0 + k], a1[k]);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], s_red[i]);
@@ -275,7 +295,7 @@ int dva_rowbn_stats(const void* y, const int32_t* counts, double* sums, int64_t 
   if (dtype == DVA_F32 ? rv_ok<float>(C, y, y, y) : rv_ok<bf16_t>(C, y, y, y)) {
     const int rpb = 256 / (C / (dtype == DVA_F32 ? 4 : 8));
     int64_t b = (R + rpb - 1) / rpb;
-    if (b > 256 * 8) b = 256 * 8;
+    if (b > 256 * 2) b = 256 * 2;
     if (dtype == DVA_F32)
       hipLaunchKernelGGL((rowbn_sums_vec_kernel<float, 0>), dim3((int)b), dim3(256), lds, (hipStream_t)stream,
                          (const float*)y, (const float*)nullptr, counts, (const float*)nullptr, sums, R, C, 0.f);
@@ -336,7 +356,7 @@ int dva_rowbn_bwd_stats(const void* grad_out, const void* y, const float* bn, do
   if (dtype == DVA_F32 ? rv_ok<float>(C, y, grad_out, y) : rv_ok<bf16_t>(C, y, grad_out, y)) {
     const int rpb = 256 / (C / (dtype == DVA_F32 ? 4 : 8));
     int64_t b = (R + rpb - 1) / rpb;
-    if (b > 256 * 8) b = 256 * 8;
+    if (b > 256 * 2) b = 256 * 2;
     if (dtype == DVA_F32)
       hipLaunchKernelGGL((rowbn_sums_vec_kernel<float, 1>), dim3((int)b), dim3(256), lds, (hipStream_t)stream,
                          (const float*)y, (const float*)grad_out, (const int32_t*)nullptr, bn, sums, R, C, slope);
