@@ -153,15 +153,19 @@ def step(scene, packed, mods, dtype, lazy=True, before_backward=None):
     x.grad = None
     for p in view_pool.parameters():
         p.grad = None
-    # mapping -> packed 8-byte gather index (image.py:1871-1885 + downscale), rebuilt every step
-    packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
+    # mapping -> gather index (image.py:1871-1885 + downscale), rebuilt every step like the reference's
+    # feature_map_indexing: the lazy path flattens (image, pixel) straight to map rows + the row plan (both are
+    # functions of the mapping only); the materialised path goes through the packed 8-byte index
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
-        # nearest gather, lazy: the packed index is flattened to rows + per-row view counts (both are
-        # functions of the mapping only, but rebuilt every step like the reference's
-        # feature_map_indexing), E_mod then runs on the map rows and the gather is fused into the
-        # attention kernel (DESIGN.md "E_mod hoisting")
+        # nearest gather, lazy: E_mod then runs on the map rows and the gather is fused into the attention kernel
+        # (DESIGN.md "E_mod hoisting")
         exact = scene["pixels"].shape[0] == scene["x_map"].shape[0]
-        x_mod = ops.lazy_gather_nearest(x, packed, exact=exact) if lazy else ops.gather_nearest(x, packed)
+        if lazy:
+            x_mod = ops.lazy_gather_nearest_mapping(x, scene["images"], scene["atom_ptr"], scene["pixels"], 1.0,
+                                                    exact=exact)
+        else:
+            packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
+            x_mod = ops.gather_nearest(x, packed)
         x_mod = atomic_pool(None, x_mod, None, scene["atom_ptr"])             # identity for exact mappings
         x_pool = view_pool(scene["x_3d"], x_mod, scene["x_map"], scene["csr"])  # [N, C]
         out = fusion(scene["x_3d"], x_pool)                                   # [N, 4 + C] fp32 (cat promotes)

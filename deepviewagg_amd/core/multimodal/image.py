@@ -730,12 +730,14 @@ class SameSettingImageData:
         if self.downscale < 1:
             # feature map larger than the mapping resolution: the reference goes through
             # rescale_images -> upscale_images (pix * ratio + ratio / 2, image.py:1982-2027)
-            packed = self.mappings.upscale_images(1 / self.downscale).packed_gather_index(ratio=1.0)
+            mappings, ratio = self.mappings.upscale_images(1 / self.downscale), 1.0
         else:
-            packed = self.mappings.packed_gather_index(ratio=float(self.downscale))
+            mappings, ratio = self.mappings, float(self.downscale)
         if lazy:
-            return ops.lazy_gather_nearest(self.x, packed, exact=self.mappings.is_exact)
-        return ops.gather_nearest(self.x, packed)
+            # (image, pixel) -> map row in one pass: the lazy gather needs no packed index
+            return ops.lazy_gather_nearest_mapping(self.x, mappings.images, mappings.values[1].pointers,
+                                                   mappings.pixels, ratio, exact=self.mappings.is_exact)
+        return ops.gather_nearest(self.x, mappings.packed_gather_index(ratio=ratio))
 
 
 class SameSettingImageBatch(SameSettingImageData):

@@ -635,22 +635,57 @@ __global__ __launch_bounds__(256) void route_stats_kernel(const float* __restric
                                                           const int64_t* __restrict__ ptr, double* __restrict__ stats,
                                                           int64_t N) {
   __shared__ float s_red[2 * D];
-  const int c = threadIdx.x & 31, sub = threadIdx.x >> 5;      // 8 points per block iteration
-  const float g = bn2[2 * D + c] * bn2[D + c], b = bn2[3 * D + c] - bn2[c] * g;
-  const float iv = bn2[D + c], mm = -bn2[c] * bn2[D + c];
-  float s1 = 0.f, s2 = 0.f;
-  for (int64_t p = (int64_t)blockIdx.x * 8 + sub; p < N; p += (int64_t)gridDim.x * 8) {
-    if (ptr[p + 1] > ptr[p]) {
-      const float z = zstar[p * D + c];
-      const float dy = dpooled[p * D + c] * dleaky(__builtin_fmaf(z, g, b));
-      s1 += dy;
-      s2 = __builtin_fmaf(dy, __builtin_fmaf(z, iv, mm), s2);
+  const int q = threadIdx.x & 7, sub = threadIdx.x >> 3;       // 32 points per block iteration, 4 channels per thread
+  float g[4], b[4], iv[4], mm[4], s1[4], s2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    g[e] = bn2[2 * D + c] * bn2[D + c];
+    b[e] = bn2[3 * D + c] - bn2[c] * g[e];
+    iv[e] = bn2[D + c];
+    mm[e] = -bn2[c] * bn2[D + c];
+    s1[e] = s2[e] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 32;
+  for (int64_t p0 = (int64_t)blockIdx.x * 32 + sub; p0 < N; p0 += 2 * stride) {
+    // two points in flight per thread
+    const int64_t p1 = p0 + stride;
+    const bool ok0 = ptr[p0 + 1] > ptr[p0], ok1 = p1 < N && ptr[p1 + 1] > ptr[p1];
+    float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f), d0 = z0, z1 = z0, d1 = z0;
+    if (ok0) {
+      z0 = *reinterpret_cast<const float4*>(zstar + p0 * D + 4 * q);
+      d0 = *reinterpret_cast<const float4*>(dpooled + p0 * D + 4 * q);
+    }
+    if (ok1) {
+      z1 = *reinterpret_cast<const float4*>(zstar + p1 * D + 4 * q);
+      d1 = *reinterpret_cast<const float4*>(dpooled + p1 * D + 4 * q);
+    }
+    const float zz[2][4] = {{z0.x, z0.y, z0.z, z0.w}, {z1.x, z1.y, z1.z, z1.w}};
+    const float dd[2][4] = {{d0.x, d0.y, d0.z, d0.w}, {d1.x, d1.y, d1.z, d1.w}};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dy = dd[u][e] * dleaky(__builtin_fmaf(zz[u][e], g[e], b[e]));   // unseen points: dpooled read as 0
+        s1[e] += dy;
+        s2[e] = __builtin_fmaf(dy, __builtin_fmaf(zz[u][e], iv[e], mm[e]), s2[e]);
+      }
     }
   }
   if (threadIdx.x < 2 * D) s_red[threadIdx.x] = 0.f;
   __syncthreads();
-  atomicAdd(&s_red[c], s1);
-  atomicAdd(&s_red[D + c], s2);
+  // lanes q, q + 8, ... of a wavefront own the same channels
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    for (int off = 8; off < 64; off <<= 1) {
+      s1[e] += __shfl_xor(s1[e], off);
+      s2[e] += __shfl_xor(s2[e], off);
+    }
+    if ((threadIdx.x & 63) < 8) {
+      atomicAdd(&s_red[4 * q + e], s1[e]);
+      atomicAdd(&s_red[D + 4 * q + e], s2[e]);
+    }
+  }
   __syncthreads();
   if (threadIdx.x < 2 * D) atomicAdd(&stats[threadIdx.x], (double)s_red[threadIdx.x]);
 }
@@ -784,8 +819,8 @@ int dva_chain_route_stats(const float* zstar, const float* dpooled, const float*
   if (n_points < 0) return DVA_ERR_INVALID;
   if (n_points == 0) return DVA_OK;
   if (!zstar || !dpooled || !bn2 || !ptr || !stats) return DVA_ERR_INVALID;
-  int64_t blocks = (n_points + 7) / 8;
-  const int cap = chain_grid(8);
+  int64_t blocks = (n_points + 63) / 64;
+  const int cap = chain_grid(4);
   hipLaunchKernelGGL(route_stats_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0,
                      (hipStream_t)stream, zstar, dpooled, bn2, ptr, stats, n_points);
   DVA_CHECK_LAUNCH();

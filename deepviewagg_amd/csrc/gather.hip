@@ -52,6 +52,31 @@ __global__ __launch_bounds__(256) void pack_index_kernel(const int64_t* __restri
   }
 }
 
+// pack_index + row_index in one pass for the lazy gather (no packed index is written or read back)
+template <typename PIX>
+__global__ __launch_bounds__(256) void mapping_row_index_kernel(const int64_t* __restrict__ images,
+                                                                 const int64_t* __restrict__ atom_ptr,
+                                                                 const PIX* __restrict__ pixels, double ratio,
+                                                                 int64_t n_views, int H, int W,
+                                                                 int32_t* __restrict__ row_idx) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n_views;
+       v += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t img = (int32_t)images[v];
+    for (int64_t a = atom_ptr[v]; a < atom_ptr[v + 1]; ++a) {
+      int32_t x, y;
+      if (ratio == 1.0) {
+        x = (int32_t)pixels[2 * a];
+        y = (int32_t)pixels[2 * a + 1];
+      } else {
+        const float rf = (float)ratio;
+        x = (int32_t)(int16_t)floordiv_f32((float)pixels[2 * a], rf);
+        y = (int32_t)(int16_t)floordiv_f32((float)pixels[2 * a + 1], rf);
+      }
+      row_idx[a] = (img * H + y) * W + x;
+    }
+  }
+}
+
 // Flat row index (img*H + y)*W + x of every atom into the [B*H*W, C] view of a channels-last map,
 // plus (optionally) the number of atoms that land on every row: the weights with which per-view
 // batch statistics can be evaluated at feature-map level (DESIGN.md "E_mod hoisting").
@@ -217,6 +242,35 @@ int dva_pack_gather_index(const int64_t* images, const int64_t* atom_ptr, const 
     case 8:
       hipLaunchKernelGGL((pack_index_kernel<int64_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
                          (const int64_t*)pixels, ratio, n_views, out);
+      break;
+    default:
+      return DVA_ERR_INVALID;
+  }
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_mapping_row_index(const int64_t* images, const int64_t* atom_ptr, const void* pixels, int32_t pix_bytes,
+                          double ratio, int64_t n_views, int64_t n_atoms, int32_t B, int32_t H, int32_t W,
+                          int32_t* row_idx, void* stream) {
+  if (n_views < 0 || n_atoms < 0 || !(ratio >= 1.0) || B < 0 || H < 0 || W < 0) return DVA_ERR_INVALID;
+  if ((int64_t)B * H * W > 0x7fffffffLL || H > 32767 || W > 32767) return DVA_ERR_UNSUPPORTED;
+  if (n_views == 0 || n_atoms == 0) return DVA_OK;
+  if (!images || !atom_ptr || !pixels || !row_idx) return DVA_ERR_INVALID;
+  const int grid = grid_for(n_views);
+  hipStream_t s = (hipStream_t)stream;
+  switch (pix_bytes) {
+    case 2:
+      hipLaunchKernelGGL((mapping_row_index_kernel<int16_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
+                         (const int16_t*)pixels, ratio, n_views, H, W, row_idx);
+      break;
+    case 4:
+      hipLaunchKernelGGL((mapping_row_index_kernel<int32_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
+                         (const int32_t*)pixels, ratio, n_views, H, W, row_idx);
+      break;
+    case 8:
+      hipLaunchKernelGGL((mapping_row_index_kernel<int64_t>), dim3(grid), dim3(256), 0, s, images, atom_ptr,
+                         (const int64_t*)pixels, ratio, n_views, H, W, row_idx);
       break;
     default:
       return DVA_ERR_INVALID;

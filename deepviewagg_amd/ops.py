@@ -500,6 +500,27 @@ def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True, with_p
     return row_idx, counts
 
 
+def mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W, with_counts=True, with_plan=True):
+    """``gather_row_index(pack_gather_index(images, atom_ptr, pixels, ratio), B, H, W)`` in one pass (no packed index):
+    (row_idx, counts, plan) with the counts taken from the row plan."""
+    lib = _lib.load()
+    require_device(images, atom_ptr, pixels)
+    images = images.contiguous()
+    atom_ptr = _check_ptr(atom_ptr)
+    pixels = pixels.contiguous()
+    if pixels.dtype not in (torch.int16, torch.int32, torch.int64):
+        raise TypeError(f"pixels must be int16/int32/int64, got {pixels.dtype}")
+    V, P = images.shape[0], pixels.shape[0]
+    row_idx = torch.empty(P, dtype=torch.int32, device=pixels.device)
+    with _timed("gather_row_index", V * 28 + P * 8):
+        check(lib.dva_mapping_row_index(ptr(images), ptr(atom_ptr), ptr(pixels), pixels.element_size(), float(ratio),
+                                        V, P, B, H, W, ptr(row_idx), stream_of(pixels)), "dva_mapping_row_index")
+    if not with_plan:
+        return row_idx, None, None
+    plan, counts = row_plan(row_idx, B * H * W, with_counts)
+    return row_idx, counts, plan
+
+
 class GatheredFeatures:
     """Result of a NEAREST view gather that has not been materialised: ``x_mod[p] = rows[row_idx[p]]``.
 
@@ -563,6 +584,15 @@ def lazy_gather_nearest(x, packed_idx, exact):
     B, C, H, W = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
     row_idx, counts, plan = gather_row_index(packed_idx, B, H, W, with_plan=True)
+    return GatheredFeatures(rows, row_idx, counts, exact, plan)
+
+
+def lazy_gather_nearest_mapping(x, images, atom_ptr, pixels, ratio, exact):
+    """``lazy_gather_nearest(x, pack_gather_index(images, atom_ptr, pixels, ratio), exact)`` without the packed index."""
+    assert x.dim() == 4
+    B, C, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
+    row_idx, counts, plan = mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W)
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
 
 

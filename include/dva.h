@@ -97,6 +97,12 @@ int dva_pack_gather_index(const int64_t* images, const int64_t* atom_ptr, const 
                           int32_t pix_bytes, double ratio, int64_t n_views, int64_t n_atoms,
                           void* packed_idx /* int64[P] */, void* stream);
 
+/* dva_pack_gather_index followed by dva_gather_row_index (row_offset 0, no counts) in one pass: the flat row index
+ * (image * H + y) * W + x of every atom straight from the mapping (image.py:1871-1885 + :1953-1954); what the lazy
+ * nearest gather needs.  Same pixel rounding as dva_pack_gather_index. */
+int dva_mapping_row_index(const int64_t* images, const int64_t* atom_ptr, const void* pixels, int32_t pix_bytes,
+                          double ratio, int64_t n_views, int64_t n_atoms, int32_t B, int32_t H, int32_t W,
+                          int32_t* row_idx, void* stream);
 /* row_idx[p] = row_offset + (img*H + y)*W + x : the atom's row in the [B*H*W, C] view of the map
  * (image.py:1871-1885 flattened).  counts (nullable, caller-zeroed int32[B*H*W]) += 1 per atom. */
 int dva_gather_row_index(const void* packed_idx, int64_t n_atoms, int32_t B, int32_t H, int32_t W,

@@ -472,3 +472,27 @@ def test_gather_bilinear_backward_plan_equals_atomics(dtype, C):
     ref_out = O.sparse_interpolation(xr, coords, images)
     (g_ref,) = torch.autograd.grad((ref_out * w.float()).sum(), xr)
     close(res[0], g_ref, **tol)
+
+
+@pytest.mark.parametrize("pix_dtype,ratio", [(torch.int16, 1.0), (torch.int16, 4.0), (torch.int32, 8.0),
+                                              (torch.int64, 2.0)])
+def test_mapping_row_index_equals_pack_then_row_index(pix_dtype, ratio):
+    """dva_mapping_row_index == dva_pack_gather_index + dva_gather_row_index (the one-pass form the lazy gather uses),
+    with several atoms per view and empty views."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(int(ratio) + 1)
+    V, B, H, W = 5000, 6, 24, 40
+    sizes = torch.randint(0, 4, (V,), generator=gen)
+    atom_ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    P = int(atom_ptr[-1])
+    images = torch.randint(0, B, (V,), generator=gen)
+    pixels = torch.stack([torch.randint(0, int(W * ratio), (P,), generator=gen),
+                          torch.randint(0, int(H * ratio), (P,), generator=gen)], 1).to(pix_dtype)
+    packed = ops.pack_gather_index(images.to(DEV), atom_ptr.to(DEV), pixels.to(DEV), ratio=ratio)
+    ref_idx, ref_counts, ref_plan = ops.gather_row_index(packed, B, H, W, with_plan=True)
+    row_idx, counts, plan = ops.mapping_row_index(images.to(DEV), atom_ptr.to(DEV), pixels.to(DEV), ratio, B, H, W)
+    assert torch.equal(row_idx, ref_idx) and torch.equal(counts, ref_counts)
+    assert torch.equal(plan[0], ref_plan[0]) and torch.equal(plan[1], ref_plan[1])
+    img_of_atom = images.repeat_interleave(sizes)
+    expect = (img_of_atom * H + (pixels[:, 1].long() // int(ratio))) * W + pixels[:, 0].long() // int(ratio)
+    assert torch.equal(row_idx.cpu().long(), expect)
