@@ -334,11 +334,17 @@ class ImageMapping(CSRData):
                 view_ids = CompositeTensor(point_ids, image_ids).data
                 _, inv = torch.unique(view_ids, return_inverse=True)
                 f2 = features.float() if features.dim() > 1 else features.float().view(-1, 1)
-                sums = torch.zeros((int(inv.max()) + 1, f2.shape[1]), dtype=torch.float32,
-                                   device=self.device).index_add_(0, inv, f2)
-                cnt = torch.zeros(sums.shape[0], dtype=torch.float32, device=self.device).index_add_(
-                    0, inv, torch.ones_like(inv, dtype=torch.float32))
-                mean = (sums / cnt.view(-1, 1))[inv]
+                # deterministic: views grouped by a stable sort, summed in their original order by the CSR
+                # reduction (an index_add_ on the device is an atomic scatter: the merged features would move by
+                # an ulp from call to call)
+                order = torch.sort(inv, stable=True).indices
+                cnt = torch.bincount(inv, minlength=int(inv.max()) + 1)
+                gptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)])
+                if f2.is_cuda:
+                    mean = ops.segment_csr(f2[order].contiguous(), gptr, reduce='mean')[inv]
+                else:
+                    sums = torch.zeros((cnt.shape[0], f2.shape[1]), dtype=torch.float32).index_add_(0, inv, f2)
+                    mean = (sums / cnt.view(-1, 1).float())[inv]
                 features = mean if features.dim() > 1 else mean.view(-1)
         point_ids = point_ids.repeat_interleave(atom_sizes)
         image_ids = image_ids.repeat_interleave(atom_sizes)

@@ -33,6 +33,28 @@ nc = int(g["x_3d"].shape[1])
 enc = MultimodalBlockDown(ResNetDown(down_conv_nn=[nc, 16], N=1), ResNetDown(down_conv_nn=[24, 32], stride=1, kernel_size=3, N=1), image=branch(16)).to(DEV).eval()
 dec = ResNetUp(up_conv_nn=[32, nc, 12], N=1).to(DEV).eval()
 
+CAP = {}
+def hook(name):
+    def f(mod, inp, out):
+        from deepviewagg_amd import ops
+        o = out
+        if isinstance(o, ops.GatheredFeatures):
+            o = o.materialize()
+        if not isinstance(o, torch.Tensor):
+            o = getattr(o, "F", None)
+        if isinstance(o, torch.Tensor):
+            CAP.setdefault(name, []).append(o.detach().clone())
+        ins = []
+        for a in inp:
+            if isinstance(a, ops.GatheredFeatures):
+                ins.append(a.materialize().detach().clone())
+            elif isinstance(a, torch.Tensor):
+                ins.append(a.detach().clone())
+        CAP.setdefault(name + "_in", []).append(ins)
+    return f
+for nm in ("conv", "atomic_pool", "view_pool", "fusion"):
+    getattr(enc.image, nm).register_forward_hook(hook(nm))
+
 def stages():
     xs, data = fresh_inputs()
     mm = multimodal_input(data, DEV)
@@ -56,15 +78,28 @@ xs, data = fresh_inputs(); mm = multimodal_input(data, DEV); skip = mm["x_3d"]
 y = dec(enc(mm)["x_3d"], skip)
 torch.autograd.grad(y.F.square().mean(), xs + [data.x] + list(enc.parameters()) + list(dec.parameters()), allow_unused=True)
 enc.eval(), dec.eval()
+CAP.clear()
 ref = stages()
-yf = full()
-print("full vs manual equal:", torch.equal(yf, ref[-1]))
+CAPREF = None
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
+    CAP.clear()
     cur = stages()
-    y2 = full()
-    if not torch.equal(y2, yf):
-        print("iter", it, "full() differs from first full():", float((y2 - yf).abs().max()))
+    capcur = {k: v for k, v in CAP.items()}
+    if it == 0:
+        CAPREF = capcur
+    y2 = None
+    if it > 0 and not all(torch.equal(a, b) for a, b in zip(ref, cur)) and bad < 3:
+        for k in capcur:
+            if k.endswith("_in"):
+                for j, (la, lb) in enumerate(zip(CAPREF[k], capcur[k])):
+                    for q, (a, b) in enumerate(zip(la, lb)):
+                        if a.shape == b.shape and not torch.equal(a, b):
+                            print("   input differs:", k, j, q, float((a.float() - b.float()).abs().max()))
+            else:
+                for j, (a, b) in enumerate(zip(CAPREF[k], capcur[k])):
+                    if not torch.equal(a, b):
+                        print("   output differs:", k, j, float((a.float() - b.float()).abs().max()))
     eq = [torch.equal(a, b) for a, b in zip(ref, cur)]
     if not all(eq):
         bad += 1
