@@ -352,8 +352,8 @@ def fused_fwd_bytes(V, N, C, es):
 
 def fused_bwd_bytes(V, N, C, es, G=4):
     """Attention backward on the same accounting: per view the gathered row, the mapping features, the indices, the
-    score gradients [G] written and the 32-byte record of the rows-gradient pass; per point grad_out + out rows."""
-    return V * (C * es + 32 + 8 + 4 * G + 32) + N * (2 * C * es + 8)
+    score gradients [G] written and the 16-byte record of the rows-gradient pass; per point grad_out + out rows."""
+    return V * (C * es + 32 + 8 + 4 * G + 16) + N * (2 * C * es + 8)
 
 
 def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warmup=1):

@@ -133,6 +133,7 @@ SIGNATURES = {
     "dva_concat_cast_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dva_concat_cast_bwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dva_mapping_row_index": (ctypes.c_int, [_vp, _vp, _vp, _i32, ctypes.c_double, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "dva_view_gather_rows_grad_rec16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "dva_chain_tile_chunks": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "dva_chain_tile_offsets": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "dva_bn_bwd_consts": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -968,7 +968,9 @@ static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, f
 // One wavefront per feature-map row, 64/lpr views in flight, 4 loads deep: the dependent chain
 // perm -> view_point -> gout row is issued for 4 views before the first use.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// REC16: rec holds packed 16-byte records {int32 point, 4 x bf16 gate * attention, 4 bytes unused} (G <= 4) instead of
+// fp32 records of stride rs.
+template <typename T, bool REC16 = false>
 __global__ __launch_bounds__(256) void rows_grad_team_kernel(
     const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
     const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
@@ -1001,7 +1003,18 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
         ok[u] = i < end;
         v[u] = perm[ok[u] ? i : beg];
       }
-      if (rec) {
+      if (REC16) {
+        // one 16-byte record per view: point id | gate * attention per group as bf16
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t* rv = reinterpret_cast<const uint32_t*>(rec) + (int64_t)v[u] * 4;
+          p[u] = (int)rv[0];
+          const uint32_t w2 = rv[1 + (g_lane >> 1)];
+          sc[u] = ok[u] ? __uint_as_float((g_lane & 1) ? (w2 & 0xffff0000u) : (w2 << 16)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)p[u] * C + col);
+      } else if (rec) {
         // one 32-byte record per view: point id | gate * attention per group
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1285,6 +1298,27 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
   return attention_bwd_entry(grad_out, rows, row_idx, grad_rows, compat, att, gate, amax, ptr, gate_w,
                              gate_b, nullptr, grad_compat, grad_gate_wb, view_rec, rec_stride, n_points,
                              n_views, C, G, scaling, dtype, algo, stream);
+}
+
+int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                                    const void* view_rec16, float* grad_rows, int64_t n_rows, int64_t n_views,
+                                    int32_t C, int32_t G, int32_t dtype, void* stream) {
+  if (n_rows < 0 || n_views < 0 || C <= 0 || G <= 0 || G > 4 || (G & (G - 1))) return DVA_ERR_INVALID;
+  if (n_views > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_rows == 0) return DVA_OK;
+  if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
+  if (n_views > 0 && (!grad_out || !perm || !view_rec16)) return DVA_ERR_INVALID;
+  if (dtype != DVA_BF16) return DVA_ERR_UNSUPPORTED;
+  const int lpr = C / 8;
+  if ((C % 8) || !is_pow2(lpr) || lpr > 64 || (C % G) || ((C / G) % 8) || ((uintptr_t)grad_out % 16) ||
+      ((uintptr_t)grad_rows % 16))
+    return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true>), dim3(grid_cap((n_rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr, (const float*)nullptr,
+                     (const int32_t*)nullptr, perm, row_ptr, (const float*)view_rec16, 4, grad_rows, n_rows, (int)C,
+                     (int)G, lpr, lpr / G);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
 }
 
 int dva_view_gather_rows_grad(const void* grad_out, const float* att, const float* gate,

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ rows,
     const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
     const float* __restrict__ gb, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out,
-    float* __restrict__ dc_out, float* __restrict__ rec, double* __restrict__ stats6, float* __restrict__ gwb,
+    float* __restrict__ dc_out, uint32_t* __restrict__ rec, double* __restrict__ stats6, float* __restrict__ gwb,
     int scaling, float eps, int64_t V, int64_t N, int64_t R) {
   constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr int KB = KV < 4 ? KV : 4, NB = KV / KB;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
                                U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
                                RW = make_rsrc(rows, (uint64_t)R * C * 2), GO = make_rsrc(gout, (uint64_t)N * C * 2),
                                OU = make_rsrc(out, (uint64_t)N * C * 2), DC = make_rsrc(dc_out, (uint64_t)V * 16),
-                               RC = make_rsrc(rec, (uint64_t)V * 32);
+                               RC = make_rsrc(rec, (uint64_t)V * 16);
   const bool s_active = G == 4 || h == 0;
   int gl[NE];
   float bias[NE], gwl[NE], gbl[NE];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
         dba[e] += dpre;
       }
     }
-    // ---- per-view outputs: dc [V, 4] and the record {point | gate * attention per group}
+    // ---- per-view outputs: dc [V, 4] and the 16-byte record {point | gate * attention per group as bf16}
     float dc4[4] = {0.f, 0.f, 0.f, 0.f}, ga4[4] = {0.f, 0.f, 0.f, 0.f};
     if (G == 4) {
 #pragma unroll
@@ -334,8 +334,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     const bool wr = ok && h == 0;
     const uint32_t vg = (uint32_t)(p.ti.v0 + j);
     st128(DC, wr ? vg * 16u : OOB, as_u4(dc4[0], dc4[1], dc4[2], dc4[3]));
-    st128(RC, wr ? vg * 32u : OOB, as_u4(__int_as_float(p.vpj), ga4[0], ga4[1], ga4[2]));
-    st128(RC, wr ? vg * 32u + 16u : OOB, as_u4(ga4[3], 0.f, 0.f, 0.f));
+    {   // 16-byte record: the rows gradient is rounded to bf16 anyway, its weights travel as bf16
+      const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), 0u};
+      st128(RC, wr ? vg * 16u : OOB, r);
+    }
     // ---- statistics of BatchNorm-6 backward
     if (!ok) { dc4[0] = dc4[1] = dc4[2] = dc4[3] = 0.f; }
     const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
@@ -741,7 +743,7 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
                        const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                        const float* bn5, const float* bn6, const float* score_bias, const void* rows,
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
-                       const void* grad_out, const void* out, float* grad_scores, float* view_rec,
+                       const void* grad_out, const void* out, float* grad_scores, void* view_rec,
                        double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
                        int32_t C, int32_t G, int32_t scaling, float eps, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
@@ -758,7 +760,7 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
 #define DVA_ATTN_BWD(LPR_, G_)                                                                                   \
   hipLaunchKernelGGL((attn_bwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,  \
                      n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)rows, row_idx,  \
-                     ptr, gate_w, gate_b, (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, view_rec,   \
+                     ptr, gate_w, gate_b, (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, (uint32_t*)view_rec,   \
                      stats6, grad_gate_wb, scaling, eps, n_views, n_points, n_rows)
   const int key = C * 8 + G;
   switch (key) {

@@ -66,10 +66,10 @@ def backward(ctx, gout):
 
     # ---- attention + gate backward: score gradients, view records, S6
     dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
-    rec = torch.empty((V, 8), dtype=torch.float32, device=dev)
+    rec = torch.empty((V, 4), dtype=torch.int32, device=dev)       # 16-byte records: point | 4 x bf16 weight | pad
     s6 = zstats()
     gwb = arena.take(2 * G) if gate is not None else None
-    with ops._timed("chain_attn_bwd", V * (C * 2 + 32 + 8 + 16 + 32) + N * (2 * C * 2 + 128 + 8)):
+    with ops._timed("chain_attn_bwd", V * (C * 2 + 32 + 8 + 16 + 16) + N * (2 * C * 2 + 128 + 8)):
         check(lib.dva_chain_attn_bwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                      ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
                                      ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
@@ -80,10 +80,9 @@ def backward(ctx, gout):
         plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
         perm, row_ptr = plan
         grows = torch.empty((R, C), dtype=torch.float32, device=dev)
-        with ops._timed("view_gather_rows_grad", V * (4 + 32 + C * 2) + R * (C * 4 + 4)):
-            check(lib.dva_view_gather_rows_grad(ptr(gout), None, None, None, ptr(perm), ptr(row_ptr), ptr(rec), 8,
-                                                ptr(grows), R, V, C, G, _lib.DVA_BF16, st),
-                  "dva_view_gather_rows_grad")
+        with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
+            check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), R, V, C,
+                                                      G, _lib.DVA_BF16, st), "dva_view_gather_rows_grad_rec16")
         grows = grows.to(rows.dtype)
     del rec
 

@@ -200,6 +200,12 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
                               int64_t n_rows, int64_t n_views, int32_t C, int32_t G, int32_t dtype,
                               void* stream);
 
+/* The same reduction over packed 16-byte view records {int32 point | 4 x bf16 weight | pad} (dva_chain_attn_bwd):
+ * bf16 grad_out, G in {1, 2, 4}, C / 8 a power of two <= 64, (C / G) % 8 == 0. */
+int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                                    const void* view_rec16, float* grad_rows, int64_t n_rows, int64_t n_views,
+                                    int32_t C, int32_t G, int32_t dtype, void* stream);
+
 /* Backward of a gather over the row plan (dva_row_plan): grad_rows[r, :] = sum over the plan entries e of row r
  * of weights[e] * grad_out[e >> atom_shift, :]  (fp32 [n_rows, C], written, not accumulated; deterministic).
  * Nearest gather: entries = atoms (weights NULL, atom_shift 0) -- dva_gather_nearest_bwd without atomics.
@@ -431,14 +437,15 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
                       int64_t n_points, void* stream);
 /* Backward of dva_chain_attn_fwd (+ the BatchNorm-backward statistics of layer 6).  grad_out / out bf16 [N][C]
  * (out = the forward result; only read for points with more than 32 views).  Outputs: grad_scores fp32 [V][4]
- * (columns >= G zero), view_rec fp32 [V][8] = {point id bits | gate * attention per group | 0} (the records
- * dva_view_gather_rows_grad consumes), stats6 += S1 | S2 of layer 6, grad_gate_wb fp32 [2 G] (caller-zeroed,
+ * (columns >= G zero), view_rec = V packed 16-byte records {int32 point id | gate * attention of groups 0..3 as
+ * bf16 | 4 unused bytes} (what dva_view_gather_rows_grad_rec16 consumes: the rows gradient is rounded to bf16, its
+ * weights travel as bf16), stats6 += S1 | S2 of layer 6, grad_gate_wb fp32 [2 G] (caller-zeroed,
  * d gate_w | d gate_b; nullable with gating off). */
 int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
                        const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                        const float* bn5, const float* bn6, const float* score_bias, const void* rows,
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
-                       const void* grad_out, const void* out, float* grad_scores, float* view_rec,
+                       const void* grad_out, const void* out, float* grad_scores, void* view_rec,
                        double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
                        int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
 /* One backward pass of the chain between two BatchNorm-backward barriers ("sm" = fp32 [2][32] = S1/M | S2/M of
