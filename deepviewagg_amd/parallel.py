@@ -86,13 +86,12 @@ class GradientBucket:
                 buf = g0.view(-1)
             else:
                 buf = self.flat
-                off = 0
-                for p, n in zip(self.params, self.sizes):
-                    if p.grad is None:
-                        buf[off:off + n].zero_()
-                    else:
-                        buf[off:off + n].copy_(p.grad.reshape(-1))
-                    off += n
+                # one multi-tensor copy instead of one launch per parameter
+                srcs = [p.grad.reshape(-1).to(torch.float32) if p.grad is not None else
+                        torch.zeros(n, dtype=torch.float32, device=buf.device)
+                        for p, n in zip(self.params, self.sizes)]
+                if srcs:
+                    torch._foreach_copy_(list(buf.split(self.sizes)), srcs)
             self._buf = buf
             self._handles = []
             for a, b in self.chunks:
@@ -119,14 +118,16 @@ class GradientBucket:
         self._handles = None
         if self._inplace:
             return
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            g = self.flat[off:off + n].view_as(p)
+        views = [v.view_as(p) for v, p in zip(self.flat.split(self.sizes), self.params)]
+        dst, src = [], []
+        for p, g in zip(self.params, views):
             if p.grad is None:
                 p.grad = g.clone().to(p.dtype)
             else:
-                p.grad.copy_(g)
-            off += n
+                dst.append(p.grad)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def reduce(self, average=True):
         """All-reduce the gradients of the bucket's parameters in place."""
