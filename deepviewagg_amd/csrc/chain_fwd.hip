@@ -320,6 +320,39 @@ __global__ __launch_bounds__(256, 3) void stats2_kernel(
     uint32_t endmask = (uint32_t)__ballot(is_end);
     if (p.ti.frag == 1 || p.ti.frag == 2) endmask = 0;
     wave_sync();
+    if (nv == 32 && p.ti.frag == 0 && endmask == 0x80000000u) {
+      // ---- one whole point of 32 views (the headline shape): the two half-waves take 16 views each, a
+      // comparison tree instead of the serial walk; ties go to the earlier view at every node
+      float m[16];
+      int a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        m[i] = __uint_as_float(__float_as_uint(tz[(16 * h + i) * TZ + j]) ^ flip);
+        a[i] = i;
+      }
+#pragma unroll
+      for (int w = 1; w < 16; w <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2 * w) {
+          const bool gt = m[i + w] > m[i];
+          m[i] = gt ? m[i + w] : m[i];
+          a[i] = gt ? a[i + w] : a[i];
+        }
+      }
+      uint32_t m0 = __float_as_uint(m[0]), m1 = m0, a0 = (uint32_t)(p.ti.v0 + 16 * h + a[0]), a1 = a0;
+      swap_halves(m0, m1);           // m1 / a1 in the h = 0 lanes = result of the h = 1 lane (views 16 .. 31)
+      swap_halves(a0, a1);
+      if (h == 0) {
+        const bool gt = __uint_as_float(m1) > m[0];
+        const float mm = gt ? __uint_as_float(m1) : m[0];
+        const int aa = gt ? (int)a1 : p.ti.v0 + a[0];
+        const int pt = __builtin_amdgcn_readfirstlane(p.vpj);
+        zstar[(int64_t)pt * D + j] = __uint_as_float(__float_as_uint(mm) ^ flip);
+        arg[(int64_t)pt * D + j] = aa;
+      }
+      wave_sync();
+      return;
+    }
     float xv[32];
 #pragma unroll
     for (int v = 0; v < 32; ++v) xv[v] = __uint_as_float(__float_as_uint(tz[v * TZ + j]) ^ flip);

@@ -30,7 +30,7 @@ def enabled():
     return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
 
 
-def applicable(module, x_mod, x_map):
+def applicable(module, x_mod, x_map, csr_idx=None):
     """Can ``module`` (a GroupBimodalCSRPool) pool ``x_mod`` (an ops.GatheredFeatures) on the chain?"""
     if not enabled() or module.use_mod or module.save_last:
         return False
@@ -41,9 +41,10 @@ def applicable(module, x_mod, x_map):
     C, G = module.out_mod, module.num_groups
     if C not in (32, 64, 128, 256, 512) or G not in (1, 2, 4) or C % G or (C // G) % 8:
         return False
-    N_max, V = 1 << 24, x_map.shape[0]
-    return V * 32 < (1 << 32) - 16 and x_mod.rows.shape[0] * C * 2 < (1 << 32) - 16 and V < (1 << 31) - 64 \
-        and N_max > 0
+    # 32-bit buffer addressing inside the kernels: x_map (32 B / view), value rows, the [V, 32] bf16 gradient row
+    V, R = x_map.shape[0], x_mod.rows.shape[0]
+    N = csr_idx.shape[0] - 1 if csr_idx is not None else 0
+    return V * 64 < (1 << 32) - 16 and R * C * 2 < (1 << 32) - 16 and N * max(C * 2, 128) < (1 << 32) - 16
 
 
 def build_tiles(csr_idx, V):

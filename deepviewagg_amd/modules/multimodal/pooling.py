@@ -312,7 +312,7 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
         val_rows = None
-        if isinstance(x_mod, ops.GatheredFeatures) and fused_chain.applicable(self, x_mod, x_map):
+        if isinstance(x_mod, ops.GatheredFeatures) and fused_chain.applicable(self, x_mod, x_map, csr_idx):
             # bf16 recompute chain: E_mod on the map rows, then ONE view kernel (DeepSetFeat scores, softmax,
             # row gather, weighted sum, gate) -- no [V, .] activation tensor at all (fused_chain.py)
             val_rows = mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0])
