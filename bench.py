@@ -116,7 +116,7 @@ def build_modules(C, device):
 
 # HIP-event timer name -> kernel symbol in the rocprofv3 outputs (bf16 headline workload)
 KERNEL_SYMBOL = {
-    "chain_attn_fwd": "chain::attn_fwd_kernel<8, 4>",
+    "chain_attn_fwd": "chain::attn_fwd_kernel<8, 4, 4>",
     "chain_attn_bwd": "chain::attn_bwd_kernel<8, 4>",
     "chain_bwd_l6": "chain::layer_bwd_kernel<6>",
     "chain_bwd_l5": "chain::layer_bwd_kernel<5>",
@@ -125,7 +125,7 @@ KERNEL_SYMBOL = {
     "chain_stats5": "chain::stats_mid_kernel<5>",
     "chain_stats6": "chain::stats_mid_kernel<6>",
     "chain_moments": "chain::moments_kernel",
-    "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short>",
+    "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short, true>",
 }
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 
