@@ -826,7 +826,7 @@ def bn_table(sums, n, bn, batch_stats):
     rows (or from the running statistics), running statistics updated as the module does: one launch."""
     lib = _lib.load()
     C = bn.num_features
-    dev = bn.weight.device if bn.affine else sums.device
+    dev = (bn.weight if bn.affine else (sums if sums is not None else bn.running_mean)).device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)
     update = batch_stats and bn.training and bn.track_running_stats
     check(lib.dva_bn_finalize(ptr(sums), float(max(n, 1.0)), ptr(bn.running_mean if (update or not batch_stats) else None),
