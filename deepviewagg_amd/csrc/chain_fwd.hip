@@ -105,55 +105,53 @@ __global__ void chain_bn_consts_kernel(const double* __restrict__ sums, double m
 }
 
 // ------------------------------------------------------------------------------------------------
-// tile table: one wavefront walks the points [cp[c], cp[c + 1]) of chunk c greedily
+// tile table: the points [cp[c], cp[c + 1]) of chunk c are tiled greedily
 // ------------------------------------------------------------------------------------------------
 template <bool WRITE>
 __global__ __launch_bounds__(64) void tile_walk_kernel(const int64_t* __restrict__ ptr,
                                                        const int64_t* __restrict__ cp, int n_chunks,
                                                        int32_t* __restrict__ counts,
                                                        const int64_t* __restrict__ offsets, int2* __restrict__ tiles) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+  // one LANE per chunk: the greedy grouping is a serial walk over the points of a chunk (every step depends on the
+  // tile opened before), so the parallelism is across chunks -- 64 independent walks per wavefront instead of one
+  // walk whose every step is a cross-lane ballot / readlane chain
+  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= n_chunks) return;
   int64_t p = cp[c];
   const int64_t p_end = cp[c + 1];
   int count = 0;
   int64_t o = WRITE ? offsets[c] : 0;
   auto emit = [&](int64_t v0, int nv, int frag) {
-    if (WRITE && lane == 0) tiles[o] = make_int2((int)v0, nv | (frag << 8));
+    if (WRITE) tiles[o] = make_int2((int)v0, nv | (frag << 8));
     ++o;
     ++count;
   };
-  while (p < p_end) {
-    // window: lane i holds the END pointer of point p + i
-    const int64_t pi = p + lane;
-    const int e_i = (int)ptr[(pi < p_end ? pi : p_end - 1) + 1];
-    int s = (int)ptr[p];
-    int base = 0;
-    const int win = (int)(p_end - p < 64 ? p_end - p : 64);
-    while (base < win) {
-      const uint64_t fit = __ballot(lane >= base && lane < win && e_i - s <= 32);
-      const int e_base = __builtin_amdgcn_readlane(e_i, base);
-      if (e_base - s > 32) {
-        // long point: fragments of 32 views
-        const int n = e_base - s;
-        const int nf = (n + 31) / 32;
-        for (int f = 0; f < nf; ++f)
-          emit(s + 32 * f, f == nf - 1 ? n - 32 * f : 32, f == 0 ? 1 : (f == nf - 1 ? 3 : 2));
-        s = e_base;
-        base += 1;
+  if (p < p_end) {
+    int64_t s = ptr[p];            // first view of the open tile
+    int64_t e_prev = s;            // end of the last point taken into the open tile
+    while (p < p_end) {
+      const int64_t e = ptr[p + 1];
+      if (e - s <= 32) {           // the point fits: extend the open tile
+        e_prev = e;
+        ++p;
         continue;
       }
-      // points base .. base + k - 1 fit (pointers are monotone: the fitting lanes are a run starting at base)
-      const int k = __popcll(fit);
-      const int e = __builtin_amdgcn_readlane(e_i, base + k - 1);
-      if (base + k == 64 && win == 64 && p + 64 < p_end && base > 0) break;  // run may continue: reload the window here
-      if (e > s) emit(s, e - s, 0);
-      s = e;
-      base += k;
+      if (e_prev > s) {            // close the open tile (whole points only) and retry the point on an empty one
+        emit(s, (int)(e_prev - s), 0);
+        s = e_prev;
+        continue;
+      }
+      // a point with more than 32 views on an empty tile: fragments of 32 views
+      const int64_t n = e - s;
+      const int nf = (int)((n + 31) / 32);
+      for (int f = 0; f < nf; ++f)
+        emit(s + 32 * f, f == nf - 1 ? (int)(n - 32 * f) : 32, f == 0 ? 1 : (f == nf - 1 ? 3 : 2));
+      s = e_prev = e;
+      ++p;
     }
-    p += base;
+    if (e_prev > s) emit(s, (int)(e_prev - s), 0);
   }
-  if (!WRITE && lane == 0) counts[c] = count;
+  if (!WRITE) counts[c] = count;
 }
 
 // chunk c covers the views [c * step, (c + 1) * step): cp[c] = first point whose views start at or after c * step
@@ -175,28 +173,31 @@ __global__ void tile_chunks_kernel(const int64_t* __restrict__ ptr, int64_t N, i
   cp[c] = lo;
 }
 
-// exclusive scan of the per-chunk tile counts (n_chunks <= 16384), one block
+// exclusive scan of the per-chunk tile counts: block b owns the entries [1024 b, 1024 b + 1024); it first sums
+// everything before its segment itself (coalesced, a few thousand integers: no second launch, no scratch buffer)
 __global__ __launch_bounds__(1024) void tile_offsets_kernel(const int32_t* __restrict__ counts, int n_chunks,
                                                             int64_t* __restrict__ offsets,
                                                             int32_t* __restrict__ n_tiles) {
   __shared__ int s_sum[1024];
-  const int t = threadIdx.x, per = (n_chunks + 1023) / 1024, beg = t * per;
-  int local = 0;
-  for (int i = beg; i < beg + per && i < n_chunks; ++i) local += counts[i];
-  s_sum[t] = local;
+  __shared__ long long s_prefix;
+  const int t = threadIdx.x, base = blockIdx.x * 1024;
+  long long acc = 0;
+  for (int i = t; i < base; i += 1024) acc += counts[i];
+  if (t == 0) s_prefix = 0;
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((t & 63) == 0 && acc) atomicAdd((unsigned long long*)&s_prefix, (unsigned long long)acc);
+  const int v = base + t < n_chunks ? counts[base + t] : 0;
+  s_sum[t] = v;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    const int v = t >= off ? s_sum[t - off] : 0;
+    const int u = t >= off ? s_sum[t - off] : 0;
     __syncthreads();
-    s_sum[t] += v;
+    s_sum[t] += u;
     __syncthreads();
   }
-  int64_t run = s_sum[t] - local;
-  for (int i = beg; i < beg + per && i < n_chunks; ++i) {
-    offsets[i] = run;
-    run += counts[i];
-  }
-  if (t == 1023) n_tiles[0] = s_sum[1023];
+  if (base + t < n_chunks) offsets[base + t] = s_prefix + s_sum[t] - v;
+  if (blockIdx.x == gridDim.x - 1 && t == 1023) n_tiles[0] = (int32_t)(s_prefix + s_sum[1023]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,9 +846,9 @@ int dva_chain_tile_chunks(const int64_t* ptr, int64_t n_points, int64_t views_pe
 
 int dva_chain_tile_offsets(const int32_t* counts, int32_t n_chunks, int64_t* offsets, int32_t* n_tiles,
                            void* stream) {
-  if (n_chunks < 0 || n_chunks > 16384 || !offsets || !n_tiles || (n_chunks && !counts)) return DVA_ERR_INVALID;
-  hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, (int)n_chunks,
-                     offsets, n_tiles);
+  if (n_chunks < 0 || n_chunks > (1 << 20) || !offsets || !n_tiles || (n_chunks && !counts)) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(tile_offsets_kernel, dim3(n_chunks > 0 ? (n_chunks + 1023) / 1024 : 1), dim3(1024), 0,
+                     (hipStream_t)stream, counts, (int)n_chunks, offsets, n_tiles);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
@@ -857,7 +858,7 @@ int dva_chain_tile_count(const int64_t* ptr, const int64_t* chunk_points, int32_
   if (n_chunks < 0) return DVA_ERR_INVALID;
   if (n_chunks == 0) return DVA_OK;
   if (!ptr || !chunk_points || !counts) return DVA_ERR_INVALID;
-  hipLaunchKernelGGL((tile_walk_kernel<false>), dim3(n_chunks), dim3(64), 0, (hipStream_t)stream, ptr,
+  hipLaunchKernelGGL((tile_walk_kernel<false>), dim3((n_chunks + 63) / 64), dim3(64), 0, (hipStream_t)stream, ptr,
                      chunk_points, n_chunks, counts, (const int64_t*)nullptr, (int2*)nullptr);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
@@ -868,7 +869,7 @@ int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_
   if (n_chunks < 0) return DVA_ERR_INVALID;
   if (n_chunks == 0) return DVA_OK;
   if (!ptr || !chunk_points || !offsets || !tiles) return DVA_ERR_INVALID;
-  hipLaunchKernelGGL((tile_walk_kernel<true>), dim3(n_chunks), dim3(64), 0, (hipStream_t)stream, ptr,
+  hipLaunchKernelGGL((tile_walk_kernel<true>), dim3((n_chunks + 63) / 64), dim3(64), 0, (hipStream_t)stream, ptr,
                      chunk_points, n_chunks, (int32_t*)nullptr, offsets, (int2*)tiles);
   DVA_CHECK_LAUNCH();
   return DVA_OK;

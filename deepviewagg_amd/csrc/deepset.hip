@@ -659,12 +659,23 @@ __global__ __launch_bounds__(256) void dsf_bwd_first_kernel(
   for (int i = threadIdx.x; i < D * 8; i += blockDim.x) atomicAdd(&dWa[i], s_red[i]);
 }
 
-// view -> point index (dense expansion of the CSR pointers), one thread per point
+// view -> point index (dense expansion of the CSR pointers): a wavefront takes 64 points, reads their pointers
+// coalesced and writes the views of one point after the other with all lanes (coalesced stores; one thread per point
+// wrote 4-byte words 128 bytes apart on the 32-views-per-point scenes)
 __global__ __launch_bounds__(256) void csr_expand_kernel(const int64_t* __restrict__ ptr, int64_t N,
                                                           int32_t* __restrict__ vp) {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N;
-       p += (int64_t)gridDim.x * blockDim.x)
-    for (int64_t r = ptr[p]; r < ptr[p + 1]; ++r) vp[r] = (int32_t)p;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p0 = wave * 64; p0 < N; p0 += n_waves * 64) {
+    const int64_t pl = p0 + lane < N ? p0 + lane : N - 1;
+    const int64_t b = ptr[pl], e = ptr[pl + 1];
+    const int n_here = (int)(N - p0 < 64 ? N - p0 : 64);
+    for (int i = 0; i < n_here; ++i) {
+      const int64_t bi = __shfl(b, i), ei = __shfl(e, i);
+      for (int64_t r = bi + lane; r < ei; r += 64) vp[r] = (int32_t)(p0 + i);
+    }
+  }
 }
 
 static inline int grid_rows(int64_t V) {
@@ -705,7 +716,7 @@ int dva_csr_expand(const int64_t* ptr, int64_t n_groups, int32_t* group_of_row, 
   if (n_groups < 0 || !ptr) return DVA_ERR_INVALID;
   if (n_groups == 0) return DVA_OK;
   if (!group_of_row) return DVA_ERR_INVALID;
-  int64_t b = (n_groups + 255) / 256;
+  int64_t b = (n_groups + 255) / 256;            // 4 wavefronts x 64 points per block
   if (b > 8192) b = 8192;
   hipLaunchKernelGGL(csr_expand_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, ptr, n_groups,
                      group_of_row);

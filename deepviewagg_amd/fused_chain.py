@@ -20,7 +20,7 @@ from .fused_deepset import D, _bn_of, _bn_consts
 
 # None = auto (inside torch.autocast(bfloat16) only); True / False pin the choice (tests, bench A/B)
 FORCE = None
-VIEWS_PER_CHUNK = 2048      # tile-table construction granularity (one wavefront walks one chunk)
+VIEWS_PER_CHUNK = 512       # tile-table construction granularity (one lane walks one chunk)
 OPS_BYTES = 16 * 64 * 16 + 7 * 64 * 32       # bf16 operand blocks + the fp32 copy of the forward operands
 
 
@@ -52,7 +52,7 @@ def build_tiles(csr_idx, V):
     lib = _lib.load()
     dev, N = csr_idx.device, csr_idx.shape[0] - 1
     st = stream_of(csr_idx)
-    n_chunks = max(1, min(16384, (V + VIEWS_PER_CHUNK - 1) // VIEWS_PER_CHUNK))
+    n_chunks = max(1, min(1 << 17, (V + VIEWS_PER_CHUNK - 1) // VIEWS_PER_CHUNK))
     step = (V + n_chunks - 1) // n_chunks if V > 0 else 1
     cp = torch.empty(n_chunks + 1, dtype=torch.int64, device=dev)
     counts = torch.empty(n_chunks, dtype=torch.int32, device=dev)

@@ -368,7 +368,7 @@ int dva_chain_bn_consts(const double* sums, double m, float* running_mean, float
  * points, 1 / 2 / 3 = first / middle / last fragment of a point with more than 32 views). */
 /* The two host-side steps around count / build as launches: chunk_points[c] = first point whose views start at or
  * after c * views_per_chunk (c = 1 .. n_chunks - 1; [0] = 0, [n_chunks] = n_points); offsets = exclusive prefix sum of
- * counts (n_chunks <= 16384), n_tiles int32 [1] = the total. */
+ * counts (n_chunks <= 2^20), n_tiles int32 [1] = the total. */
 int dva_chain_tile_chunks(const int64_t* ptr, int64_t n_points, int64_t views_per_chunk, int32_t n_chunks,
                           int64_t* chunk_points, void* stream);
 int dva_chain_tile_offsets(const int32_t* counts, int32_t n_chunks, int64_t* offsets, int32_t* n_tiles,
