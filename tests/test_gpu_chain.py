@@ -122,7 +122,10 @@ def test_tile_table_properties():
     from deepviewagg_amd import fused_chain
     gen = torch.Generator().manual_seed(0)
     for sizes in (ragged_long(5000, gen), full32(257, gen), torch.zeros(100, dtype=torch.long),
-                  torch.randint(0, 3, (100000,), generator=gen), torch.randint(20, 45, (3000,), generator=gen)):
+                  torch.randint(0, 3, (100000,), generator=gen), torch.randint(20, 45, (3000,), generator=gen),
+                  # more than 1024 chunks of 512 views: the offset scan runs over several blocks
+                  torch.randint(0, 9, (200000,), generator=gen),
+                  torch.cat([torch.randint(0, 70, (30000,), generator=gen), torch.full((7,), 5000)])):
         csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
         V = int(csr[-1])
         tiles, n = fused_chain.build_tiles(csr, V)
@@ -148,6 +151,14 @@ def test_tile_table_properties():
         lo = np.searchsorted(v0, ptr[:-1], side='right')     # first cut > start
         hi = np.searchsorted(v0, ptr[1:], side='left')       # first cut >= end
         assert (lo[small] == hi[small]).all()
+        # greedy: a tile of whole points is closed only when the next (non-empty) point does not fit any more
+        if T > 1:
+            nxt_end = ptr[np.minimum(np.searchsorted(ptr, v0[1:], side='right'), len(ptr) - 1)]
+            first_size = nxt_end - v0[1:]
+            whole = frag[:-1] == 0
+            # ... except at the chunk boundaries of the construction (chunks are tiled independently)
+            n_chunks = max(1, min(1 << 17, -(-V // fused_chain.VIEWS_PER_CHUNK)))
+            assert int((nv[:-1][whole] + first_size[whole] <= 32).sum()) <= n_chunks - 1
 
 
 def _oracle_grads(case, ref, autocast):
