@@ -137,6 +137,7 @@ SIGNATURES = {
     "dva_chain_tile_chunks": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "dva_chain_tile_offsets": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "dva_bn_bwd_consts": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "dva_chain_stats1": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "dva_chain_dw1": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dva_chain_set_prep": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "dva_chain_set_fwd": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

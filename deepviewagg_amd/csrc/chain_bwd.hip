@@ -387,7 +387,7 @@ __device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
 }
 
 template <int STAGE>
-__global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
+__global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -398,8 +398,9 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
     float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N) {
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
-  // second operand tile of the small products: 4 (score gradients) / 8 (x_map) rows + one shared zero row
-  constexpr int TD_ROWS = STAGE == 6 ? 4 : 8;
+  // second operand tile of the small products: 4 (score gradients) / 17 (x_map hi | lo | ones) rows + one shared zero row
+  // stage 2: x_map as hi | lo (8 + 8 rows) and a row of ones (P then also carries sum dy1: the statistics of layer 1)
+  constexpr int TD_ROWS = STAGE == 6 ? 4 : 17;
   __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][(TD_ROWS + 1) * TSB];
   // STAGE 5: indicator tile [local point][view] (bf16 1.0 where the view belongs to the point) and the point ids
   __shared__ __attribute__((aligned(16))) bf16_t s_ind[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TSB : 8];
@@ -569,7 +570,9 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       }
       wave_sync();
     } else {
-      // set-pooling gradient of this view's channels: issued early, used after the two layers
+      // Register diet of this stage (three wavefronts per SIMD need <= 168 VGPRs): the set-pooling gradient is routed
+      // into the gradient row as soon as it arrives (before the second layer is evaluated), and the raw first-layer
+      // output is evaluated again where its backward needs it instead of being carried through the stage.
       u32x4 arq[4], dpq[4];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
@@ -580,10 +583,10 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       bf16x8 a1[2];
       asm volatile("" ::: "memory");
       const bf16x8 xp = pack_x(p.x);
-      const f32x16 z1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), xp, zero);
-      const f32x16 t1 = CH_MFMA(lds_op(s_ops, L_W1F, lane), xp, bias_acc(s_tab[0], T_B6, h));
-      act_fold(t1, keep, a1);
-      const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
+      {
+        const f32x16 t1 = CH_MFMA(lds_op(s_ops, L_W1F, lane), xp, bias_acc(s_tab[0], T_B6, h));
+        act_fold(t1, keep, a1);
+      }
       // gradient of the max-pooled set features goes to the arg view of each channel
       f32x16 da2t = unpack_da(p.dlo, p.dhi);
       {
@@ -597,17 +600,36 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
             da2t[4 * qq + e] += (int)ai[e] == vg ? __uint_as_float(di[e]) : 0.f;   // lanes without a view: arg reads 0 != vg
         }
       }
-      layer_bwd<false, true>(z2, da2t, s_tab[1], h, ok, unused_st, dz);
+      asm volatile("" ::: "memory");
+      {
+        const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
+        layer_bwd<false, true>(z2, da2t, s_tab[1], h, ok, unused_st, dz);
+      }
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
       tileT_put_packed(tb_, j, h, a1);
       const f32x16 da1 = mm32_lds(s_ops, L_W2T, lane, dzp, zero);
-      layer_bwd<true, false>(z1, da1, s_tab[0], h, ok, st, dz);
-      // dy1 (handed back by the statistics-only layer_bwd; zero for lanes without a view: their da1 is) for
-      // P = sum_v dy1 x^T
+      {
+        // dy1 = leaky'(y1) da1 with the sign of the folded product (what the forward's activation saw), evaluated
+        // again here instead of carried through the stage; zero for lanes without a view (their da1 is)
+        const f32x16 t1 = CH_MFMA(lds_op(s_ops, L_W1F, lane), xp, bias_acc(s_tab[0], T_B6, h));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[r] = da1[r] * dleaky(t1[r]);
+      }
+      // P = sum_v dy1 [x_hi | x_lo | 1]^T: the first-layer weight gradient AND (BatchNorm-1 backward being linear in
+      // z1 = W1 x) the statistics of layer 1: S1 = P[:, 16], sum dy1 z1 = sum_f W1[:, f] (P[:, f] + P[:, 8 + f])
       tileT_put_acc(tc, j, h, dz);
-      tileT_put(td, 4 * h, 4 * h + 1, j, p.x.x, p.x.y);      // lanes without a view loaded zeros
-      tileT_put(td, 4 * h + 2, 4 * h + 3, j, p.x.z, p.x.w);
+      {
+        const float xs[4] = {p.x.x, p.x.y, p.x.z, p.x.w};      // features 4 h .. 4 h + 3; lanes without a view: zeros
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const uint32_t hi2 = pack_bf16x2(xs[e], xs[e + 1]);
+          tileT_put(td, 4 * h + e, 4 * h + e + 1, j, xs[e], xs[e + 1]);
+          tileT_put(td, 8 + 4 * h + e, 8 + 4 * h + e + 1, j, xs[e] - __uint_as_float(hi2 << 16),
+                    xs[e + 1] - __uint_as_float(hi2 & 0xffff0000u));
+        }
+        if (h == 0) td[16 * TSB + j] = ok ? (bf16_t)0x3f80 : (bf16_t)0;
+      }
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
       accS = wgrad_short(tc, td, j, TD_ROWS, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
@@ -625,8 +647,8 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
       if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
     }
   }
-  if (STAGE == 2) flush_matrix(accS, Pm, 8, 8, false, s_red);
-  flush_stats<2>(st, stats, s_red);
+  if (STAGE == 2) flush_matrix(accS, Pm, 20, 17, false, s_red);
+  else flush_stats<2>(st, stats, s_red);
 }
 
 // S2 of layer 2, per-point part: the set-pooling gradient lands on one view per (point, channel) whose z2 is
@@ -716,6 +738,7 @@ __global__ void bn_bwd_consts_kernel(double* __restrict__ stats, const float* __
 
 // dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q),  Q = sum_v z1_hat x^T = invstd (bf16(W1) XX - mean SX^T) from the moments
 // of x_map (mom fp64 [44] = SX [8] | upper triangle of XX, row-major).  One thread per entry, fp64.
+// P fp32 [32][20] = sum_v dy1 [x_hi (8) | x_lo (8) | 1 | .]^T from stage 2.
 __global__ void dw1_kernel(const float* __restrict__ P, const double* __restrict__ mom, const float* __restrict__ W1,
                            const float* __restrict__ bn1, const float* __restrict__ sm1, float* __restrict__ dW1) {
   const int i = threadIdx.x >> 3, k = threadIdx.x & 7;
@@ -728,7 +751,21 @@ __global__ void dw1_kernel(const float* __restrict__ P, const double* __restrict
   }
   const double mean = bn1[i], inv = bn1[D + i], gam = bn1[2 * D + i], sx = mom[k];
   const double q = inv * (acc - mean * sx);
-  dW1[i * 8 + k] = (float)(gam * inv * ((double)P[i * 8 + k] - (double)sm1[i] * sx - (double)sm1[D + i] * q));
+  const double pik = (double)P[i * 20 + k] + (double)P[i * 20 + 8 + k];
+  dW1[i * 8 + k] = (float)(gam * inv * (pik - (double)sm1[i] * sx - (double)sm1[D + i] * q));
+}
+
+// statistics of the BatchNorm-1 backward from P: S1 = sum dy1 = P[:, 16]; sum dy1 z1 with z1 = bf16(W1) x
+__global__ void stats1_from_p_kernel(const float* __restrict__ P, const float* __restrict__ W1,
+                                     double* __restrict__ stats) {
+  const int n = threadIdx.x;
+  if (n >= D) return;
+  double s2 = 0.0;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    s2 += (double)bf2f(f2bf(W1[n * 8 + f])) * ((double)P[n * 20 + f] + (double)P[n * 20 + 8 + f]);
+  stats[n] = (double)P[n * 20 + 16];
+  stats[D + n] = s2;
 }
 
 }  // namespace chain
@@ -794,7 +831,7 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
   if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW || !stats)
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW || (stage != 2 && !stats))
     return DVA_ERR_INVALID;
   if (stage == 6 && (!sm6 || !grad_scores || !dWs || !dbs || !da_out)) return DVA_ERR_INVALID;
   if (stage == 5 && (!sm5 || !du || !da_in || !da_out)) return DVA_ERR_INVALID;
@@ -810,7 +847,7 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                      n_views, n_points)
   if (stage == 6) DVA_LAYER_BWD(6, 2);
   else if (stage == 5) DVA_LAYER_BWD(5, 2);
-  else DVA_LAYER_BWD(2, 2);
+  else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD
   DVA_CHECK_LAUNCH();
   return DVA_OK;
@@ -834,6 +871,13 @@ int dva_bn_bwd_consts(double* stats, const float* bn, double inv_m, int32_t do_h
   if (!stats || (do_hat && !bn) || C < 1) return DVA_ERR_INVALID;
   hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3(1), dim3(C <= 64 ? 64 : 256), 0, (hipStream_t)stream, stats, bn,
                      inv_m, (int)do_hat, sm, dgamma, dbeta, (int)C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_stats1(const float* P, const float* W1, double* stats, void* stream) {
+  if (!P || !W1 || !stats) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(stats1_from_p_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P, W1, stats);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

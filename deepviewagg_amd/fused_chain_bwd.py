@@ -117,15 +117,16 @@ def backward(ctx, gout):
     check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), N, st),
           "dva_chain_route_stats")
     sm2, g2, b2 = consts(s2, bn2, hat=False)
-    dW2, P = arena.take(D, D), arena.take(D, 8)
+    dW2, P = arena.take(D, D), arena.take(D, 20)       # P = sum dy1 [x_hi | x_lo | 1]^T
     s1 = zstats()
-    layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, None, None, P, s1, "chain_bwd_l2",
+    layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, None, None, P, None, "chain_bwd_l2",
           V * (32 + 4 + 64) + N * 256)
     del da2
+    W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
+    check(lib.dva_chain_stats1(ptr(P), ptr(W1), ptr(s1), st), "dva_chain_stats1")    # layer 1 is linear in x_map
     sm1, g1, b1 = consts(s1, bn1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so
     #      dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q) with Q = sum_v z1_hat x^T from the moments of x_map
-    W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
     dW1 = arena.take(D, 8)
     check(lib.dva_chain_dw1(ptr(P), ptr(mom), ptr(W1), ptr(bn1), ptr(sm1), ptr(dW1), st), "dva_chain_dw1")
     if gate is not None:

@@ -411,9 +411,13 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
  * (each nullable). */
 int dva_bn_bwd_consts(double* stats, const float* bn, double inv_m, int32_t do_hat, float* sm, float* dgamma,
                       float* dbeta, int32_t C, void* stream);
+/* Statistics of the BatchNorm-1 backward from P (stage 2 of dva_chain_bwd_layer): P fp32 [32][20] = sum_v dy1
+ * [x_hi (8) | x_lo (8) | 1 | unused (3)]^T; stats fp64 [64] = sum dy1 (= P[:, 16]) | sum dy1 z1 with z1 = bf16(W1) x
+ * (= sum_f bf16(W1)[:, f] (P[:, f] + P[:, 8 + f]): z1 is linear in x).  Raw-z form like every other "stats". */
+int dva_chain_stats1(const float* P, const float* W1, double* stats, void* stream);
 /* First-layer weight gradient without another view pass: BatchNorm-1 backward is linear in its statistics and
  * z1 = W1 x is linear in x, so dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q), Q = sum_v z1_hat x^T from the moments.
- * P fp32 [32][8] (dva_chain_bwd_layer stage 2), mom fp64 [44] (dva_chain_moments), sm1 = S/M of layer 1. */
+ * P fp32 [32][20] (dva_chain_bwd_layer stage 2: x_map as hi | lo columns), mom fp64 [44] (dva_chain_moments), sm1 = S/M of layer 1. */
 int dva_chain_dw1(const float* P, const double* mom, const float* W1, const float* bn1, const float* sm1, float* dW1,
                   void* stream);
 /* Per-point set branch of DeepSetFeat on the chain (pooling.py:660-664): pooled fp32 [N][32] (+ the set-size
@@ -457,7 +461,8 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
  *   stage 5: da_in = d a5 -> dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u
  *            (written for seen points), stats += S of layer 2 (view part), da_out = d a2               (sm5)
  *   stage 2: da_in = d a2 (+ dpooled routed to the arg views of dva_chain_stats2) -> dW [32][32] = dW2,
- *            P fp32 [32][8] = sum_v dy1 x^T, stats += S of layer 1                                      (sm2) */
+ *            P fp32 [32][20] += sum_v dy1 [x_hi (8) | x_lo (8) | 1 | unused]^T; the statistics of layer 1 follow
+ *            from P (dva_chain_stats1; stats may be NULL)                                                (sm2) */
 int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
