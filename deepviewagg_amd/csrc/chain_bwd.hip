@@ -23,6 +23,8 @@ struct ChainKeep {
 // the raw output z6 (BatchNorm backward, statistics) and the folded product (block OP_W6F) for the activation the
 // forward used.  tabs[0..3] = layers 1, 2, 5, 6.
 constexpr int OP_W6F = N_OPS;        // two extra LDS blocks behind the table
+// W6F = position of the folded layer-6 operand in the kernel's LDS table (stage 6 keeps a compact table)
+template <int W6F = OP_W6F>
 __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
                                               uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
   const f32x16 zero = {0};
@@ -35,7 +37,7 @@ __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, cons
   k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
   act_pack(k.z5, tabs[2], h, keep, k.a5);
   k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
-  const f32x16 t6 = mm32_lds(s_ops, OP_W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
+  const f32x16 t6 = mm32_lds(s_ops, W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
   act_fold(t6, keep, k.a6);
 }
 // stage the whole table + the folded operands of chain_forward (call from the whole block, then __syncthreads())
@@ -68,6 +70,7 @@ __device__ __forceinline__ float dot8(const u32x4& a, const u32x4& b) {
   return d;
 }
 // da6 = Ws^T dc: the score gradients of the view enter as hi | lo in the k-slots of the h = 0 lane
+template <int WST = OP_WST>
 __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const float (&dc)[4], int h) {
   const uint32_t h0 = pack_bf16x2(dc[0], dc[1]), h1 = pack_bf16x2(dc[2], dc[3]);
   const float r0 = dc[0] - __uint_as_float(h0 << 16), r1 = dc[1] - __uint_as_float(h0 & 0xffff0000u);
@@ -76,7 +79,7 @@ __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const 
   const u32x4 v = {h0 & keep, h1 & keep, pack_bf16x2(r0, r1) & keep, pack_bf16x2(r2, r3) & keep};
   const f32x16 zero = {0};
   asm volatile("" ::: "memory");
-  return CH_MFMA(lds_op(s_ops, OP_WST, lane), __builtin_bit_cast(bf16x8, v), zero);
+  return CH_MFMA(lds_op(s_ops, WST, lane), __builtin_bit_cast(bf16x8, v), zero);
 }
 // ------------------------------------------------------------------------------------------------
 // attention backward
@@ -405,18 +408,30 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
   // STAGE 5: indicator tile [local point][view] (bf16 1.0 where the view belongs to the point) and the point ids
   __shared__ __attribute__((aligned(16))) bf16_t s_ind[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TSB : 8];
   __shared__ int s_plp[STAGE == 5 ? 4 : 1][32];
-  __shared__ float s_red[D * D];
+  // (the D x D reduction buffer of the epilogue lives in the first tile buffer: the tiles are dead by then)
+  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
+  float* s_red = reinterpret_cast<float*>(&s_ta[0][0]);
   // only the operands of the pass (LDS budget: three blocks per CU for stages 5 and 2):
   // stage 5: W1 W2 W5 | W5T -> local 5, 6;  stage 2: W1 W2 | W2T -> local 3, 4
   // plus the BatchNorm-folded operands (the forward passes' activations): stage 6 as chain_forward; stage 5: W1 in
   // place, W2 as a second operand (the raw z2 feeds the statistics) -> local 7, 8; stage 2: W1 as a second operand
   // -> local 5
-  constexpr int NOPS = STAGE == 6 ? N_OPS + 2 : (STAGE == 5 ? 9 : 6);
-  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5;
+  // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9; W6' -> 10, 11
+  constexpr int NOPS = STAGE == 6 ? 12 : (STAGE == 5 ? 9 : 6);
+  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9, L6_W6F = 10;
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (STAGE == 6) {
-    stage_ops_chain(s_ops, ops, bn1, bn2, bn6);
+    for (int i = threadIdx.x; i < 5 * 64; i += blockDim.x) {
+      const int blk = i >> 6, l = i & 63;
+      if (blk < 2) s_ops[(OP_W5 + blk) * 64 + l] = ops[(OP_W5 + blk) * 64 + l];
+      else if (blk < 4) s_ops[(OP_W6 + blk - 2) * 64 + l] = ops[(OP_W6 + blk - 2) * 64 + l];
+      else s_ops[L6_WST * 64 + l] = ops[OP_WST * 64 + l];
+    }
+    for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_W6T * 64 + i] = ops[OP_W6T * 64 + i];
+    fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+    fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+    fold_ops(s_ops, L6_W6F, ops, OP_W6, 2, bn6);
   } else {
     for (int i = threadIdx.x; i < (STAGE == 5 ? 7 : 5) * 64; i += blockDim.x) {
       int op = i >> 6;
@@ -496,9 +511,9 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
     if constexpr (STAGE == 6) {
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
       ChainKeep k;
-      chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
+      chain_forward<L6_W6F>(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
       const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
-      const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
+      const f32x16 da6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
       layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
       }
-      const f32x16 da5 = mm32_lds(s_ops, OP_W6T, lane, dzp, zero);
+      const f32x16 da5 = mm32_lds(s_ops, L6_W6T, lane, dzp, zero);
       store_da(DO, ok, view, h, da5);
       layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dz);
       wave_sync();
