@@ -2,8 +2,8 @@
 // Every pass re-evaluates the DeepSetFeat chain of a tile from x_map in registers and walks the gradient back as
 // far as the BatchNorm-backward statistics allow; a pass ends where the next global sum (S1 = sum dy,
 // S2 = sum dy * z_hat of a BatchNorm layer) is needed:
-//   dva_chain_attn_bwd   attention + gate backward, score gradients dc [V, 4], view records, S of layer 6
-//   dva_chain_bwd_layer  stage 6: dW6, dWs, dbs, S of layer 5
+//   dva_chain_attn_bwd   attention + gate backward, score gradients dc [V, 4], view records, dWs, dbs, S of layer 6
+//   dva_chain_bwd_layer  stage 6: dW6, S of layer 5
 //                        stage 5: dW5 (per-view half), du [N, 32] (gradient of the per-point half), S of layer 2 (view part)
 //                        stage 2: set-pooling gradient routed to the arg views, dW2, P = sum dy1 x^T, S of layer 1
 //   dva_chain_route_stats  S of layer 2, per-point part (the routed set-pooling gradient)
@@ -24,7 +24,7 @@ struct ChainKeep {
 // forward used.  tabs[0..3] = layers 1, 2, 5, 6.
 constexpr int OP_W6F = N_OPS;        // two extra LDS blocks behind the table
 // W6F = position of the folded layer-6 operand in the kernel's LDS table (stage 6 keeps a compact table)
-template <int W6F = OP_W6F>
+template <int W6F = OP_W6F, bool NEED_A6 = true>
 __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
                                               uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
   const f32x16 zero = {0};
@@ -37,8 +37,10 @@ __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, cons
   k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
   act_pack(k.z5, tabs[2], h, keep, k.a5);
   k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
-  const f32x16 t6 = mm32_lds(s_ops, W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
-  act_fold(t6, keep, k.a6);
+  if (NEED_A6) {
+    const f32x16 t6 = mm32_lds(s_ops, W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
+    act_fold(t6, keep, k.a6);
+  }
 }
 // stage the whole table + the folded operands of chain_forward (call from the whole block, then __syncthreads())
 __device__ __forceinline__ void stage_ops_chain(uint4* s_ops, const uint4* __restrict__ ops,
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
     const float* __restrict__ gb, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out,
     float* __restrict__ dc_out, uint32_t* __restrict__ rec, double* __restrict__ stats6, float* __restrict__ gwb,
-    int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+    float* __restrict__ dWs, float* __restrict__ dbs, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
   constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr int KB = KV < 4 ? KV : 4, NB = KV / KB;
   constexpr int NE = G == 1 ? 1 : 2;
@@ -103,8 +105,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
   __shared__ __attribute__((aligned(16))) int s_pid[4][32], s_ri[4][32];
   __shared__ __attribute__((aligned(16))) float s_E[4][4];
   __shared__ __attribute__((aligned(16))) uint4 s_ops[(N_OPS + 2) * 64];
-  __shared__ float s_red[2 * D];
+  // weight gradient of the score layer (dWs^T[k][g] = sum_v a6[v][k] dc[v][g]): a6 and dc both exist here;
+  // transposed a6 tile + a 4-row score-gradient tile (+ one shared zero row), as in the layer passes
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_td[4][5 * TSB];
+  float* s_red = reinterpret_cast<float*>(&s_tc[0][0]);        // epilogue only (D x D floats <= one tile buffer set)
+  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < 4 * 5 * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
   stage_ops_chain(s_ops, ops, bn1, bn2, bn6);
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, nullptr);
@@ -132,6 +139,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
   float* q_t = s_q[wv];
   int* pid_t = s_pid[wv];
   int* ri_t = s_ri[wv];
+  bf16_t* tc = s_tc[wv];
+  bf16_t* td = s_td[wv];
+  f32x16 accS = {0};
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
@@ -343,11 +354,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     }
     // ---- statistics of BatchNorm-6 backward
     if (!ok) { dc4[0] = dc4[1] = dc4[2] = dc4[3] = 0.f; }
+    // ---- score layer: dWs, dbs
+    {
+      const uint32_t keep = ok ? 0xffffffffu : 0u;
+      const bf16x8 t6[2] = {mask8(k.a6[0], keep), mask8(k.a6[1], keep)};
+      tileT_put_packed(tc, j, h, t6);
+      if (h == 0) {
+        const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
+        td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
+        td[1 * TSB + j] = (bf16_t)(d01 >> 16);
+        td[2 * TSB + j] = (bf16_t)(d23 & 0xffffu);
+        td[3 * TSB + j] = (bf16_t)(d23 >> 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
+      }
+    }
     const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
     float dz_unused[16];
     layer_bwd<true, false>(k.z6, da6, s_tab[3], h, ok, st, dz_unused);
     wave_sync();
+    accS = wgrad_short(tc, td, j, 4, h, accS);
+    wave_sync();
   });
+  flush_matrix(accS, dWs, D, G, true, s_red);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v = dbsum[g];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
+  }
   flush_stats<2>(st, stats6, s_red);
   if (gw) {
 #pragma unroll
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer passes.  STAGE 6: dz6 -> dW6, dWs, dbs, S5; hands da5 (bf16 [V, 32]) to the next pass.
+// layer passes.  STAGE 6: dz6 -> dW6, S5; hands da5 (bf16 [V, 32]) to the next pass.
 // STAGE 5: da5 -> dz5 -> dW5, du, S2 (view part); hands da2 to the next pass.
 // STAGE 2: da2 + set-pooling gradient -> dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
 // Each pass re-evaluates only the layers it differentiates (x_map -> ... -> its own layer); the gradient with
@@ -390,21 +426,21 @@ __device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
 }
 
 template <int STAGE>
-__global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
+__global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     const float* __restrict__ bn6, const float* __restrict__ sm2, const float* __restrict__ sm5,
     const float* __restrict__ sm6, const float* __restrict__ dc, const int32_t* __restrict__ arg,
     const float* __restrict__ dpooled, const bf16_t* __restrict__ da_in, bf16_t* __restrict__ da_out,
-    float* __restrict__ dW, float* __restrict__ dWs, float* __restrict__ dbs,
+    float* __restrict__ dW,
     float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N) {
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
   // second operand tile of the small products: 4 (score gradients) / 17 (x_map hi | lo | ones) rows + one shared zero row
   // stage 2: x_map as hi | lo (8 + 8 rows) and a row of ones (P then also carries sum dy1: the statistics of layer 1)
-  constexpr int TD_ROWS = STAGE == 6 ? 4 : 17;
-  __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 5 ? 1 : 4][32 * TSB], s_td[STAGE == 5 ? 1 : 4][(TD_ROWS + 1) * TSB];
+  constexpr int TD_ROWS = 17;
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[STAGE == 2 ? 4 : 1][STAGE == 2 ? 32 * TSB : 8], s_td[STAGE == 2 ? 4 : 1][STAGE == 2 ? (TD_ROWS + 1) * TSB : 8];
   // STAGE 5: indicator tile [local point][view] (bf16 1.0 where the view belongs to the point) and the point ids
   __shared__ __attribute__((aligned(16))) bf16_t s_ind[STAGE == 5 ? 4 : 1][STAGE == 5 ? 32 * TSB : 8];
   __shared__ int s_plp[STAGE == 5 ? 4 : 1][32];
@@ -416,9 +452,9 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
   // plus the BatchNorm-folded operands (the forward passes' activations): stage 6 as chain_forward; stage 5: W1 in
   // place, W2 as a second operand (the raw z2 feeds the statistics) -> local 7, 8; stage 2: W1 as a second operand
   // -> local 5
-  // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9; W6' -> 10, 11
-  constexpr int NOPS = STAGE == 6 ? 12 : (STAGE == 5 ? 9 : 6);
-  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9, L6_W6F = 10;
+  // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9
+  constexpr int NOPS = STAGE == 6 ? 10 : (STAGE == 5 ? 9 : 6);
+  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9;
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (STAGE == 6) {
@@ -431,7 +467,6 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
     for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_W6T * 64 + i] = ops[OP_W6T * 64 + i];
     fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
     fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
-    fold_ops(s_ops, L6_W6F, ops, OP_W6, 2, bn6);
   } else {
     for (int i = threadIdx.x; i < (STAGE == 5 ? 7 : 5) * 64; i += blockDim.x) {
       int op = i >> 6;
@@ -453,9 +488,9 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
   stage_tab(s_tab[3], bn6, STAGE == 6 ? sm6 : nullptr);
   // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
   for (int i = threadIdx.x; i < 4 * 32 * TSB; i += blockDim.x) {
-    if (STAGE != 5) {
+    if (STAGE == 2) {
       if (i < 4 * (TD_ROWS + 1) * TSB) (&s_td[0][0])[i] = 0;
-    } else {
+    } else if (STAGE == 5) {
       (&s_ind[0][0])[i] = 0;
     }
   }
@@ -467,13 +502,12 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  f32x16 accW = {0}, accS = {0};      // layer weight gradient; dWs^T (STAGE 6) / P (STAGE 2)
-  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 accW = {0}, accS = {0};      // layer weight gradient; P (STAGE 2)
   f32x16 accU = {0};                  // STAGE 5: per-point sums of dz5 (carried over the fragments of a long point)
   bf16_t* ta = s_ta[wv];
   bf16_t* tb_ = s_tb[wv];
-  bf16_t* tc = s_tc[STAGE == 5 ? 0 : wv];
-  bf16_t* td = s_td[STAGE == 5 ? 0 : wv];
+  bf16_t* tc = s_tc[STAGE == 2 ? wv : 0];
+  bf16_t* td = s_td[STAGE == 2 ? wv : 0];
   bf16_t* ind = s_ind[STAGE == 5 ? wv : 0];
   int* plp = s_plp[STAGE == 5 ? wv : 0];
 
@@ -511,32 +545,21 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
     if constexpr (STAGE == 6) {
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
       ChainKeep k;
-      chain_forward<L6_W6F>(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
+      chain_forward<0, false>(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
       const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
       const f32x16 da6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
       layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
       {
-        bf16x8 t5[2] = {mask8(k.a5[0], keep), mask8(k.a5[1], keep)}, t6[2] = {mask8(k.a6[0], keep), mask8(k.a6[1], keep)};
+        const bf16x8 t5[2] = {mask8(k.a5[0], keep), mask8(k.a5[1], keep)};
         tileT_put_packed(tb_, j, h, t5);
-        tileT_put_packed(tc, j, h, t6);
-      }
-      if (h == 0) {
-        const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
-        td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
-        td[1 * TSB + j] = (bf16_t)(d01 >> 16);
-        td[2 * TSB + j] = (bf16_t)(d23 & 0xffffu);
-        td[3 * TSB + j] = (bf16_t)(d23 >> 16);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
       }
       const f32x16 da5 = mm32_lds(s_ops, L6_W6T, lane, dzp, zero);
       store_da(DO, ok, view, h, da5);
       layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dz);
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
-      accS = wgrad_short(tc, td, j, TD_ROWS, h, accS);       // dWs^T[k][g] = sum_v a6[v][k] dc[v][g]
       wave_sync();
     } else if constexpr (STAGE == 5) {
       f32x16 uacc = load_u(U, ok, p.vpj, h);
@@ -652,16 +675,6 @@ __global__ __launch_bounds__(256, STAGE == 2 ? 3 : 2) void layer_bwd_kernel(
     }
   });
   flush_matrix(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red);
-  if (STAGE == 6) {
-    flush_matrix(accS, dWs, D, G, true, s_red);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = dbsum[g];
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-      if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
-    }
-  }
   if (STAGE == 2) flush_matrix(accS, Pm, 20, 17, false, s_red);
   else flush_stats<2>(st, stats, s_red);
 }
@@ -796,12 +809,13 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
                        const float* bn5, const float* bn6, const float* score_bias, const void* rows,
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
                        const void* grad_out, const void* out, float* grad_scores, void* view_rec,
-                       double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
+                       double* stats6, float* grad_gate_wb, float* dWs, float* dbs, int64_t n_points,
+                       int64_t n_views, int64_t n_rows,
                        int32_t C, int32_t G, int32_t scaling, float eps, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
-      !rows || !row_idx || !ptr || !grad_out || !out || !grad_scores || !view_rec || !stats6 ||
+      !rows || !row_idx || !ptr || !grad_out || !out || !grad_scores || !view_rec || !stats6 || !dWs || !dbs ||
       ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
@@ -813,7 +827,7 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
   hipLaunchKernelGGL((attn_bwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,  \
                      n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)rows, row_idx,  \
                      ptr, gate_w, gate_b, (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, (uint32_t*)view_rec,   \
-                     stats6, grad_gate_wb, scaling, eps, n_views, n_points, n_rows)
+                     stats6, grad_gate_wb, dWs, dbs, scaling, eps, n_views, n_points, n_rows)
   const int key = C * 8 + G;
   switch (key) {
     case 32 * 8 + 1: DVA_ATTN_BWD(4, 1); break;
@@ -842,13 +856,13 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
-                        const void* da_in, void* da_out, float* dW, float* dWs, float* dbs, float* du, float* P,
+                        const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
   if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW || (stage != 2 && !stats))
     return DVA_ERR_INVALID;
-  if (stage == 6 && (!sm6 || !grad_scores || !dWs || !dbs || !da_out)) return DVA_ERR_INVALID;
+  if (stage == 6 && (!sm6 || !grad_scores || !da_out)) return DVA_ERR_INVALID;
   if (stage == 5 && (!sm5 || !du || !da_in || !da_out)) return DVA_ERR_INVALID;
   if (stage == 2 && (!sm2 || !arg || !dpooled || !P || !da_in)) return DVA_ERR_INVALID;
   if (n_views * 64 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
@@ -858,9 +872,9 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
 #define DVA_LAYER_BWD(ST_, BPC_)                                                                                  \
   hipLaunchKernelGGL((layer_bwd_kernel<ST_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u,        \
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
-                     grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, dWs, dbs, du, P, stats, G, \
+                     grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, \
                      n_views, n_points)
-  if (stage == 6) DVA_LAYER_BWD(6, 2);
+  if (stage == 6) DVA_LAYER_BWD(6, 3);
   else if (stage == 5) DVA_LAYER_BWD(5, 2);
   else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD

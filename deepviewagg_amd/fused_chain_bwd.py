@@ -69,11 +69,13 @@ def backward(ctx, gout):
     rec = torch.empty((V, 4), dtype=torch.int32, device=dev)       # 16-byte records: point | 4 x bf16 weight | pad
     s6 = zstats()
     gwb = arena.take(2 * G) if gate is not None else None
+    dWs, dbs = arena.take(G, D), arena.take(G)          # score layer: a6 and the score gradients both exist in this pass
     with ops._timed("chain_attn_bwd", V * (C * 2 + 32 + 8 + 16 + 16) + N * (2 * C * 2 + 128 + 8)):
         check(lib.dva_chain_attn_bwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                      ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
                                      ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
-                                     ptr(s6), ptr(gwb), N, V, R, C, G, scaling, eps, st), "dva_chain_attn_bwd")
+                                     ptr(s6), ptr(gwb), ptr(dWs), ptr(dbs), N, V, R, C, G, scaling, eps, st),
+              "dva_chain_attn_bwd")
     # ---- rows gradient: segmented reduction over the row plan (deterministic, no atomics)
     grows = None
     if ctx.needs_input_grad[0]:
@@ -86,20 +88,20 @@ def backward(ctx, gout):
         grows = grows.to(rows.dtype)
     del rec
 
-    def layer(stage, sm2, sm5, sm6, arg_, dpooled_, da_in, da_out, dW, dWs, dbs, du, P, stats, name, nbytes):
+    def layer(stage, sm2, sm5, sm6, arg_, dpooled_, da_in, da_out, dW, du, P, stats, name, nbytes):
         with ops._timed(name, nbytes):
             check(lib.dva_chain_bwd_layer(stage, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                           ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm2), ptr(sm5), ptr(sm6),
                                           ptr(dc), ptr(arg_), ptr(dpooled_), ptr(da_in), ptr(da_out), ptr(dW),
-                                          ptr(dWs), ptr(dbs), ptr(du), ptr(P), ptr(stats), G, V, N, st),
+                                          ptr(du), ptr(P), ptr(stats), G, V, N, st),
                   "dva_chain_bwd_layer")
 
     # per view: x_map 32 + view->point 4 (+ score gradients 16) + the 64-byte gradient row handed between the passes
     sm6, g6, b6 = consts(s6, bn6)
-    dW6, dWs, dbs = arena.take(D, D), arena.take(G, D), arena.take(G)
+    dW6 = arena.take(D, D)
     s5 = zstats()
     da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
-    layer(6, None, None, sm6, None, None, None, da5, dW6, dWs, dbs, None, None, s5, "chain_bwd_l6",
+    layer(6, None, None, sm6, None, None, None, da5, dW6, None, None, s5, "chain_bwd_l6",
           V * (32 + 4 + 16 + 64) + N * 128)
     del dc
     sm5, g5, b5 = consts(s5, bn5)
@@ -108,7 +110,7 @@ def backward(ctx, gout):
     s2 = zstats()
     da2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
     dc = None
-    layer(5, None, sm5, None, None, None, da5, da2, dW5, None, None, du, None, s2, "chain_bwd_l5",
+    layer(5, None, sm5, None, None, None, da5, da2, dW5, du, None, s2, "chain_bwd_l5",
           V * (32 + 4 + 64 + 64) + N * 256)
     del da5
     # ---- per-point set branch
@@ -119,7 +121,7 @@ def backward(ctx, gout):
     sm2, g2, b2 = consts(s2, bn2, hat=False)
     dW2, P = arena.take(D, D), arena.take(D, 20)       # P = sum dy1 [x_hi | x_lo | 1]^T
     s1 = zstats()
-    layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, None, None, P, None, "chain_bwd_l2",
+    layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, P, None, "chain_bwd_l2",
           V * (32 + 4 + 64) + N * 256)
     del da2
     W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()

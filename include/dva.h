@@ -444,20 +444,21 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
  * (columns >= G zero), view_rec = V packed 16-byte records {int32 point id | gate * attention of groups 0..3 as
  * bf16 | 4 unused bytes} (what dva_view_gather_rows_grad_rec16 consumes: the rows gradient is rounded to bf16, its
  * weights travel as bf16), stats6 += S1 | S2 of layer 6, grad_gate_wb fp32 [2 G] (caller-zeroed,
- * d gate_w | d gate_b; nullable with gating off). */
+ * d gate_w | d gate_b; nullable with gating off), dWs fp32 [G][32] / dbs fp32 [G] (caller-zeroed) += the gradient of the
+ * score layer (a6 and the score gradients both exist in this pass). */
 int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
                        const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                        const float* bn5, const float* bn6, const float* score_bias, const void* rows,
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
                        const void* grad_out, const void* out, float* grad_scores, void* view_rec,
-                       double* stats6, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
-                       int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
+                       double* stats6, float* grad_gate_wb, float* dWs, float* dbs, int64_t n_points,
+                       int64_t n_views, int64_t n_rows, int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
 /* One backward pass of the chain between two BatchNorm-backward barriers ("sm" = fp32 [2][32] = S1/M | S2/M of
- * the pass's own layer, zeros with running statistics; dW / dWs / dbs / P / stats caller-zeroed, accumulated with
+ * the pass's own layer, zeros with running statistics; dW / P / stats caller-zeroed, accumulated with
  * atomics).  Each pass re-evaluates the chain from x_map up to its own layer; the gradient w.r.t. the layer's
  * OUTPUT is handed from pass to pass as da_out -> da_in, bf16 [V][32] (64 bytes per view, in the lane order of
  * the kernels: opaque to the caller):
- *   stage 6: grad_scores -> dW [32][32] = dW6, dWs [G][32], dbs [G], stats += S of layer 5, da_out = d a5  (sm6)
+ *   stage 6: grad_scores -> dW [32][32] = dW6, stats += S of layer 5, da_out = d a5                        (sm6)
  *   stage 5: da_in = d a5 -> dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u
  *            (written for seen points), stats += S of layer 2 (view part), da_out = d a2               (sm5)
  *   stage 2: da_in = d a2 (+ dpooled routed to the arg views of dva_chain_stats2) -> dW [32][32] = dW2,
@@ -467,7 +468,7 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
-                        const void* da_in, void* da_out, float* dW, float* dWs, float* dbs, float* du, float* P,
+                        const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream);
 /* stats += S1 | S2 of layer 2, per-point part: sum over the seen points of leaky'(BN2(zstar)) dpooled (x z_hat). */
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
