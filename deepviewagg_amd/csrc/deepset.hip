@@ -671,9 +671,16 @@ __global__ __launch_bounds__(256) void csr_expand_kernel(const int64_t* __restri
     const int64_t pl = p0 + lane < N ? p0 + lane : N - 1;
     const int64_t b = ptr[pl], e = ptr[pl + 1];
     const int n_here = (int)(N - p0 < 64 ? N - p0 : 64);
-    for (int i = 0; i < n_here; ++i) {
-      const int64_t bi = __shfl(b, i), ei = __shfl(e, i);
-      for (int64_t r = bi + lane; r < ei; r += 64) vp[r] = (int32_t)(p0 + i);
+    const int64_t first = __shfl(b, 0), last = __shfl(e, n_here - 1);
+    if (last - first <= 8 * n_here) {
+      // short segments (ragged scenes): every lane writes the few views of its own point
+      if (lane < n_here)
+        for (int64_t r = b; r < e; ++r) vp[r] = (int32_t)(p0 + lane);
+    } else {
+      for (int i = 0; i < n_here; ++i) {
+        const int64_t bi = __shfl(b, i), ei = __shfl(e, i);
+        for (int64_t r = bi + lane; r < ei; r += 64) vp[r] = (int32_t)(p0 + i);
+      }
     }
   }
 }
