@@ -127,6 +127,15 @@ KERNEL_SYMBOL = {
     "chain_moments": "chain::moments_kernel",
     "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short, true>",
 }
+# what bounds the kernel the roofline object is about (SQ counters: profiles/*sq_counters*)
+ROOFLINE_NOTES = {
+    "chain_attn_bwd": "attention backward (softmax / gate backward, score gradients, view records, score-layer weight "
+                      "gradient, BatchNorm-6 statistics): 253 VGPRs -> 2 wavefronts per SIMD, VALU ~59 % busy, "
+                      "HBM traffic (PMC) ~3.4 TB/s: bound by latency at that occupancy, not by HBM, VALU or the matrix "
+                      "cores; the value rows it re-gathers (128 of its ~200 bytes per view) come out of the cache hierarchy",
+    "*": "the recompute passes read 32-100 bytes per view by design (no stored activations): they are bound by VALU "
+         "instruction issue, not by HBM or the matrix cores; their time, not their HBM fraction, is what is left to cut",
+}
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 
 
@@ -552,10 +561,7 @@ def main():
                          "copy kernel of the same run",
                          "avg_launch_ms": avg_ms, "launches": k["launches"],
                          "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
-                         "note": "the recompute passes read 32-52 bytes per view by design (no stored activations): "
-                                 "they are bound by VALU instruction issue, not by HBM or the matrix cores "
-                                 "(profiles/*sq_counters*); their time, not their HBM fraction, is what is left to cut"
-                                 if chain else None},
+                         "note": ROOFLINE_NOTES.get(name, ROOFLINE_NOTES["*"]) if chain else None},
             "kernels": {n: {"avg_ms": v["ms"] / v["launches"], "launches": v["launches"],
                             "GBps": (v["bytes"] / v["launches"]) / (v["ms"] / v["launches"] * 1e-3) / 1e9}
                         for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
