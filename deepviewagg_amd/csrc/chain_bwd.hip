@@ -5,7 +5,8 @@
 //   dva_chain_attn_bwd   attention + gate backward, score gradients dc [V, 4], view records, dWs, dbs, S of layer 6
 //   dva_chain_bwd_layer  stage 6: dW6, S of layer 5
 //                        stage 5: dW5 (per-view half), du [N, 32] (gradient of the per-point half), S of layer 2 (view part)
-//                        stage 2: set-pooling gradient routed to the arg views, dW2, P = sum dy1 x^T, S of layer 1
+//                        stage 2: set-pooling gradient routed to the arg views, dW2, P = sum dy1 [x_hi | x_lo | 1]^T
+//   dva_chain_stats1     S of layer 1 from P (z1 is linear in x_map);  dva_chain_dw1: dW1 from P and the moments
 //   dva_chain_route_stats  S of layer 2, per-point part (the routed set-pooling gradient)
 // BatchNorm backward per layer:  dz = G (dy - S1/M - z_hat S2/M),  dy = leaky'(y) da,  G = gamma * invstd.
 // Reference maths: autograd of modules/multimodal/pooling.py:263-315, :658-669.

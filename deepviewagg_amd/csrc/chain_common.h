@@ -9,7 +9,8 @@
 //   z[r] = Z[channel chan(r, h)][view j],  chan(r, h) = (r & 3) + 8 (r >> 2) + 4 h,   r < 16,
 // which is exactly the k-slot order the weight operands of the NEXT layer are prepared in (dva_chain_prep), so
 // BatchNorm + LeakyReLU + bf16 packing are register-to-register and layers chain without any data movement.
-// bf16 operands (activations and weights rounded like the reference under torch.autocast(bfloat16)), fp32
+// bf16 operands (activations and weights rounded to bf16 like the reference under torch.autocast(bfloat16); layers whose
+// raw output a pass does not need take the BatchNorm scale inside the rounded operand: "BatchNorm folded" below), fp32
 // accumulation, BatchNorm / softmax / statistics in fp32.
 #pragma once
 #include "dva_common.h"

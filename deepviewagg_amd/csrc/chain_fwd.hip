@@ -1,6 +1,8 @@
 // Recompute chain, forward side (see chain_common.h for the geometry):
-//   dva_chain_prep          weight operand table (bf16, MFMA k-slot order)
-//   dva_chain_tile_count / dva_chain_tile_build    tile table of a CSR pointer array
+//   dva_chain_prep          weight operand table (bf16, MFMA k-slot order) + fp32 copy of the forward operands (the
+//                           kernels fold BatchNorm into them: bf16(0.6 gamma invstd W), chain_common.h)
+//   dva_chain_bn_consts     BatchNorm constants of one layer: mean | invstd | gamma | beta | shift of the folded product
+//   dva_chain_tile_chunks / _count / _offsets / _build    tile table of a CSR pointer array
 //   dva_chain_moments       sum x, sum x x^T of the mapping features -> BatchNorm-1 statistics analytically
 //   dva_chain_stats2        statistics of layer 2 + per-point extremum of the layer-2 output (set pooling)
 //   dva_chain_pooled        pooled set features from the extrema

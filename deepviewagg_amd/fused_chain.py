@@ -5,8 +5,9 @@ Computes ``gate * sum_v softmax_v(E_score(E_map(x_map))) * rows[row_idx[v]]`` of
 (modules/multimodal/pooling.py:263-315 with map_encoder = DeepSetFeat :658-669) without any [V, .]
 activation tensor: every kernel re-evaluates the per-view DeepSetFeat chain from the 32-byte mapping features
 (bf16 matrix cores, layers chained in registers).  The only view-sized reads are ``x_map``, the view -> point
-index and the row index; the only view-sized writes of a training step are the score gradients [V, G] and
-the per-view records of the rows gradient.  Train-mode BatchNorm keeps one statistics pass per layer.
+index and the row index; the only view-sized writes of a training step are the score gradients [V, G], the
+16-byte view records of the rows gradient and one bf16 [V, 32] gradient row handed between two backward passes.
+Train-mode BatchNorm keeps one statistics pass per layer.
 
 Selected by ``pooling.GroupBimodalCSRPool`` inside ``torch.autocast(bfloat16)`` (or with ``FORCE = True``)
 when ``applicable`` holds; everything else takes the fp32 kernels of ``fused_deepset`` / ``ops``.
