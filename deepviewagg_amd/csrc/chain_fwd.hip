@@ -882,7 +882,8 @@ int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, doub
   if (n_views < 0 || !moments || !stats1 || !W1) return DVA_ERR_INVALID;
   if (n_views > 0) {
     if (!x_map) return DVA_ERR_INVALID;
-    int64_t blocks = (n_views + 255) / 256;
+    int64_t blocks = (n_views + 256 * 16 - 1) / (256 * 16);       // >= 16 views per thread: every block ends with
+    if (blocks < 1) blocks = 1;                                    // 44 fp64 atomics on the same addresses
     const int cap = chain_grid(8);
     hipLaunchKernelGGL(moments_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0, (hipStream_t)stream,
                        x_map, n_views, moments);
