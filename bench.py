@@ -11,8 +11,12 @@ The 2D encoder and the 3D backbone are outside the path.
 
     python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  Every rank owns
-its own scene (tile) -> weak scaling; the only collective is the all-reduce of the pooling module's
-parameter gradients.  Rank 0 prints ONE JSON line.
+its own scene (tile) -> weak scaling (--strong: one 2^20-point scene cut into N slabs); the collectives are the
+all-reduce of the pooling module's parameter gradients and of a stand-in 112 MB fp32 bucket (--standin-mb: the rest of
+the model's gradients), both on a side stream under the backward.  Rank 0 prints ONE JSON line:
+the contract fields + `roofline` (dominant kernel), `roofline_view_gather_attention` (the fused kernel the north star
+names), `cpu_baseline` (PyTorch-CPU oracle of the whole path + the C/OpenMP twin of gather + attention), `workloads`
+(S2 ragged, F-L C = 512), `mapping_build`, `gather`, per-kernel HIP-event timings.
 """
 import argparse
 import json
