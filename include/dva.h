@@ -381,16 +381,18 @@ int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_
  * stats1 double[64] = sum z1 | sum z1^2 of z1 = bf16(W1) x, derived from the moments. */
 int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, double* moments, double* stats1,
                       void* stream);
-/* stats += statistics of z2; zstar fp32 [N][32] / arg int32 [N][32] = value / first view of the per-point
- * extremum of sign(gamma2) z2 (the view that max-pools a2 = leaky(BN2(z2))). */
+/* stats double[96] (caller-zeroed) += sum z2 | sum z2^2 | sum a1 (the layer's input: what dva_chain_bn_consts needs
+ * for the folded shift); zstar fp32 [N][32] / arg int32 [N][32] = value / first view of the per-point extremum of
+ * sign(gamma2) z2 (the view that max-pools a2 = leaky(BN2(z2))). */
 int dva_chain_stats2(const float* x_map, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
                      const void* ops, const float* bn1, const float* gamma2, double* stats, float* zstar,
                      int32_t* arg, int64_t n_views, void* stream);
 /* pooled fp32 [N][32] = leaky(BN2(zstar)) for seen points, 0 for unseen ones. */
 int dva_chain_pooled(const float* zstar, const float* bn2, const int64_t* ptr, float* pooled, int64_t n_points,
                      void* stream);
-/* layer = 5: stats += statistics of z5 = W5a a2 + u[point]; layer = 6: of z6.  u fp32 [N][32] = the per-point
- * half of the concatenation layer (W5b . set features). */
+/* layer = 5: stats double[96] += sum | sum of squares of z5 = W5a a2 + u[point] (third row untouched); layer = 6: of z6,
+ * third row += sum a5 (the layer's input).  u fp32 [N][32] = the per-point half of the concatenation layer
+ * (W5b . set features). */
 int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
                     const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                     const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
