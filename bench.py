@@ -122,9 +122,10 @@ def build_modules(C, device):
 KERNEL_SYMBOL = {
     "chain_attn_fwd": "chain::attn_fwd_kernel<8, 4, 4>",
     "chain_attn_bwd": "chain::attn_bwd_kernel<8, 4>",
-    "chain_bwd_l6": "chain::layer_bwd_kernel<6>",
-    "chain_bwd_l5": "chain::layer_bwd_kernel<5>",
-    "chain_bwd_l2": "chain::layer_bwd_kernel<2>",
+    "chain_score_stats": "chain::score_stats_kernel",
+    "chain_bwd_l6": "chain::layer_bwd_kernel<6, 3>",
+    "chain_bwd_l5": "chain::layer_bwd_kernel<5, 2>",
+    "chain_bwd_l2": "chain::layer_bwd_kernel<2, 3>",
     "chain_stats2": "chain::stats2_kernel",
     "chain_stats5": "chain::stats_mid_kernel<5>",
     "chain_stats6": "chain::stats_mid_kernel<6>",
@@ -133,10 +134,9 @@ KERNEL_SYMBOL = {
 }
 # what bounds the kernel the roofline object is about (SQ counters: profiles/*sq_counters*)
 ROOFLINE_NOTES = {
-    "chain_attn_bwd": "attention backward (softmax / gate backward, score gradients, view records, score-layer weight "
-                      "gradient, BatchNorm-6 statistics): 253 VGPRs -> 2 wavefronts per SIMD, VALU ~59 % busy, "
-                      "HBM traffic (PMC) ~3.4 TB/s: bound by latency at that occupancy, not by HBM, VALU or the matrix "
-                      "cores; the value rows it re-gathers (128 of its ~200 bytes per view) come out of the cache hierarchy",
+    "chain_attn_bwd": "attention backward from the stored scores (softmax / gate backward, score gradients, view "
+                      "records; no chain evaluation): 107 VGPRs -> 4 wavefronts per SIMD; the value rows it re-gathers "
+                      "(128 of its ~184 bytes per view) come out of the cache hierarchy",
     "*": "the recompute passes read 32-100 bytes per view by design (no stored activations): they are bound by VALU "
          "instruction issue, not by HBM or the matrix cores; their time, not their HBM fraction, is what is left to cut",
 }
@@ -364,9 +364,9 @@ def fused_fwd_bytes(V, N, C, es):
 
 
 def fused_bwd_bytes(V, N, C, es, G=4):
-    """Attention backward on the same accounting: per view the gathered row, the mapping features, the indices, the
-    score gradients [G] written and the 16-byte record of the rows-gradient pass; per point grad_out + out rows."""
-    return V * (C * es + 32 + 8 + 4 * G + 16) + N * (2 * C * es + 8)
+    """Attention backward on the same accounting: per view the gathered row, the stored scores (16), the indices (8), the
+    score gradients written (16) and the 16-byte record of the rows-gradient pass; per point the grad_out row."""
+    return V * (C * es + 16 + 8 + 16 + 16) + N * (C * es + 8)
 
 
 def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warmup=1):

@@ -122,11 +122,11 @@ SIGNATURES = {
     "dva_chain_stats2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_pooled": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_stats": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
-    "dva_chain_attn_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
-    "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 24 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_chain_attn_fwd": (ctypes.c_int, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_chain_score_stats": (ctypes.c_int, [_vp] * 14 + [_i32, _i64, _i64, _vp]),
     "dva_chain_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i32, _i64, _i64, _vp]),
-    "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_copy_ceiling": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "dva_chain_bn_consts": (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                            _i32, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -1,14 +1,17 @@
 // Recompute chain, backward side (see chain_common.h for the geometry, chain_fwd.hip for the forward).
-// Every pass re-evaluates the DeepSetFeat chain of a tile from x_map in registers and walks the gradient back as
+// Every chain pass re-evaluates the DeepSetFeat chain of a tile from x_map in registers and walks the gradient back as
 // far as the BatchNorm-backward statistics allow; a pass ends where the next global sum (S1 = sum dy,
 // S2 = sum dy * z_hat of a BatchNorm layer) is needed:
-//   dva_chain_attn_bwd   attention + gate backward, score gradients dc [V, 4], view records, dWs, dbs, S of layer 6
-//   dva_chain_bwd_layer  stage 6: dW6, S of layer 5
-//                        stage 5: dW5 (per-view half), du [N, 32] (gradient of the per-point half), S of layer 2 (view part)
-//                        stage 2: set-pooling gradient routed to the arg views, dW2, P = sum dy1 [x_hi | x_lo | 1]^T
-//   dva_chain_stats1     S of layer 1 from P (z1 is linear in x_map);  dva_chain_dw1: dW1 from P and the moments
+//   dva_chain_attn_bwd     attention + gate backward from the scores the forward left: score gradients dc [V, 4], view
+//                          records (no chain evaluation in this kernel)
+//   dva_chain_score_stats  score layer: dWs, dbs, S of layer 6
+//   dva_chain_bwd_layer    stage 6: dW6, S of layer 5
+//                          stage 5: dW5 (per-view half), du [N, 32] (gradient of the per-point half), S of layer 2 (view part)
+//                          stage 2: set-pooling gradient routed to the arg views, dW2, P = sum dy1 [x_hi | x_lo | 1]^T
+//   dva_chain_stats1       S of layer 1 from P (z1 is linear in x_map);  dva_chain_dw1: dW1 from P and the moments
 //   dva_chain_route_stats  S of layer 2, per-point part (the routed set-pooling gradient)
-// BatchNorm backward per layer:  dz = G (dy - S1/M - z_hat S2/M),  dy = leaky'(y) da,  G = gamma * invstd.
+// BatchNorm backward per layer:  dz = G (dy - S1/M - z_hat S2/M),  dy = leaky'(.) da with the sign of the pre-activation
+// the forward's activation saw (the folded product t of layers 1, 2, 6; G z + B of layer 5),  G = gamma * invstd.
 // Reference maths: autograd of modules/multimodal/pooling.py:263-315, :658-669.
 #include "chain_common.h"
 
@@ -16,16 +19,15 @@ namespace dva {
 namespace chain {
 
 struct ChainKeep {
-  f32x16 z5, z6;
+  f32x16 z5, z6, t6;
   bf16x8 a2[2], a5[2], a6[2];
 };
 // The forward chain as the forward passes evaluate it: layers 1 and 2 with BatchNorm folded into the operand (their
 // LDS blocks hold the folded operands), layer 5 plain (the per-point row enters before its BatchNorm), layer 6 twice:
-// the raw output z6 (BatchNorm backward, statistics) and the folded product (block OP_W6F) for the activation the
-// forward used.  tabs[0..3] = layers 1, 2, 5, 6.
-constexpr int OP_W6F = N_OPS;        // two extra LDS blocks behind the table
-// W6F = position of the folded layer-6 operand in the kernel's LDS table (stage 6 keeps a compact table)
-template <int W6F = OP_W6F, bool NEED_A6 = true>
+// the raw output z6 (BatchNorm backward, statistics) and the folded product t6 = 0.6 y6 (block W6F) whose sign the
+// forward's activation saw and whose activation a6 feeds the score layer.  tabs[0..3] = layers 1, 2, 5, 6.
+// L6: 0 = z6 only, 1 = + t6, 2 = + t6 and a6.
+template <int W6F, int L6>
 __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
                                               uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
   const f32x16 zero = {0};
@@ -38,20 +40,8 @@ __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, cons
   k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
   act_pack(k.z5, tabs[2], h, keep, k.a5);
   k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
-  if (NEED_A6) {
-    const f32x16 t6 = mm32_lds(s_ops, W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
-    act_fold(t6, keep, k.a6);
-  }
-}
-// stage the whole table + the folded operands of chain_forward (call from the whole block, then __syncthreads())
-__device__ __forceinline__ void stage_ops_chain(uint4* s_ops, const uint4* __restrict__ ops,
-                                                const float* __restrict__ bn1, const float* __restrict__ bn2,
-                                                const float* __restrict__ bn6) {
-  for (int i = threadIdx.x; i < N_OPS * 64; i += blockDim.x)
-    if (i >= (OP_W2 + 2) * 64) s_ops[i] = ops[i];
-  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
-  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
-  fold_ops(s_ops, OP_W6F, ops, OP_W6, 2, bn6);
+  if (L6 >= 1) k.t6 = mm32_lds(s_ops, W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
+  if (L6 >= 2) act_fold(k.t6, keep, k.a6);
 }
 __device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int vpj, int h) {
   f32x16 uacc;
@@ -73,7 +63,7 @@ __device__ __forceinline__ float dot8(const u32x4& a, const u32x4& b) {
   return d;
 }
 // da6 = Ws^T dc: the score gradients of the view enter as hi | lo in the k-slots of the h = 0 lane
-template <int WST = OP_WST>
+template <int WST>
 __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const float (&dc)[4], int h) {
   const uint32_t h0 = pack_bf16x2(dc[0], dc[1]), h1 = pack_bf16x2(dc[2], dc[3]);
   const float r0 = dc[0] - __uint_as_float(h0 << 16), r1 = dc[1] - __uint_as_float(h0 & 0xffff0000u);
@@ -85,53 +75,42 @@ __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const 
   return CH_MFMA(lds_op(s_ops, WST, lane), __builtin_bit_cast(bf16x8, v), zero);
 }
 // ------------------------------------------------------------------------------------------------
-// attention backward
+// attention backward (round 3: no chain in this kernel).  The fused forward kernel leaves the scores c [V, 4] (16 bytes
+// per view) in training mode; the softmax / gate backward needs only them, the value rows and the two per-point rows
+// grad_out / out: per view it writes the score gradients dc [V, 4] and the 16-byte record of the rows-gradient pass.
+// What the old kernel also did -- re-evaluating the DeepSetFeat chain to get the BatchNorm-6 statistics and the
+// score-layer weight gradient -- is the separate pass score_stats_kernel below: 253 VGPRs / 2 wavefronts per SIMD became
+// two kernels that each fit a register budget with twice the occupancy.
 // ------------------------------------------------------------------------------------------------
 template <int LPR, int G>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
-    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
-    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
-    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ rows,
-    const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
-    const float* __restrict__ gb, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out,
-    float* __restrict__ dc_out, uint32_t* __restrict__ rec, double* __restrict__ stats6, float* __restrict__ gwb,
-    float* __restrict__ dWs, float* __restrict__ dbs, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+__global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
+    const float* __restrict__ compat, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
+    const int32_t* __restrict__ n_tiles_dev, const bf16_t* __restrict__ rows, const int32_t* __restrict__ row_idx,
+    const int64_t* __restrict__ ptr, const float* __restrict__ gw, const float* __restrict__ gb,
+    const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out, float* __restrict__ dc_out,
+    uint32_t* __restrict__ rec, float* __restrict__ gwb, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
   constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr int KB = KV < 4 ? KV : 4, NB = KV / KB;
   constexpr int NE = G == 1 ? 1 : 2;
   constexpr int LPG = LPR / G;                 // lanes per channel group inside a row
-  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float s_q[4][4 * 32];
   __shared__ __attribute__((aligned(16))) int s_pid[4][32], s_ri[4][32];
   __shared__ __attribute__((aligned(16))) float s_E[4][4];
-  __shared__ __attribute__((aligned(16))) uint4 s_ops[(N_OPS + 2) * 64];
-  // weight gradient of the score layer (dWs^T[k][g] = sum_v a6[v][k] dc[v][g]): a6 and dc both exist here;
-  // transposed a6 tile + a 4-row score-gradient tile (+ one shared zero row), as in the layer passes
-  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_td[4][5 * TSB];
-  float* s_red = reinterpret_cast<float*>(&s_tc[0][0]);        // epilogue only (D x D floats <= one tile buffer set)
-  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < 4 * 5 * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
-  stage_ops_chain(s_ops, ops, bn1, bn2, bn6);
-  stage_tab(s_tab[0], bn1, nullptr);
-  stage_tab(s_tab[1], bn2, nullptr);
-  stage_tab(s_tab[2], bn5, nullptr);
-  stage_tab(s_tab[3], bn6, nullptr);
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
+  const __amdgpu_buffer_rsrc_t CP = make_rsrc(compat, (uint64_t)V * 16), P = make_rsrc(vp, (uint64_t)V * 4),
+                               RI = make_rsrc(row_idx, (uint64_t)V * 4),
                                RW = make_rsrc(rows, (uint64_t)R * C * 2), GO = make_rsrc(gout, (uint64_t)N * C * 2),
                                OU = make_rsrc(out, (uint64_t)N * C * 2), DC = make_rsrc(dc_out, (uint64_t)V * 16),
                                RC = make_rsrc(rec, (uint64_t)V * 16);
+  // softmax side: lane (j, h) owns the groups gl[e] of view j (G = 4: 2 h, 2 h + 1; G <= 2: the h = 0 lanes)
   const bool s_active = G == 4 || h == 0;
+  const uint32_t coff = G == 4 ? 8u * h : 0u;
   int gl[NE];
-  float bias[NE], gwl[NE], gbl[NE];
+  float gwl[NE], gbl[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     gl[e] = (G == 4 ? 2 * h : 0) + e;
     if (gl[e] >= G) gl[e] = G - 1;
-    bias[e] = bs[gl[e]];
     gwl[e] = gw ? gw[gl[e]] : 0.f;
     gbl[e] = gw ? gb[gl[e]] : 0.f;
   }
@@ -140,13 +119,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
   float* q_t = s_q[wv];
   int* pid_t = s_pid[wv];
   int* ri_t = s_ri[wv];
-  bf16_t* tc = s_tc[wv];
-  bf16_t* td = s_td[wv];
-  f32x16 accS = {0};
-  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
-  float st[2][16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
   float dwa[NE], dba[NE];
   // state of a long point across its fragments
   float glob_m[NE], glob_s[NE], glob_E[NE];
@@ -154,26 +126,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 #pragma unroll
   for (int e = 0; e < NE; ++e) { dwa[e] = dba[e] = 0.f; glob_m[e] = glob_s[e] = glob_E[e] = 0.f; seen[e] = false; }
 
-  auto scores = [&](const f32x16& z, float (&c)[NE]) {
-    if constexpr (G == 4) {
-      uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
-      uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
-      swap_halves(A0, A2);
-      swap_halves(A1, A3);
-      c[0] = __uint_as_float(A0) + bias[0];
-      c[1] = __uint_as_float(A1) + bias[1];
-    } else {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
-    }
-  };
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
   struct Pre {
     TileInfo ti;
     int t;
-    float4 x;
+    u32x2 cc;
     int vpj, rij;
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
@@ -181,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     p.ti = ti;
     p.t = t;
     const bool ok = j < p.ti.nv;
-    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.cc = ld64(CP, ok ? (uint32_t)(p.ti.v0 + j) * 16u + coff : OOB);
     p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
     p.rij = (int)ld32(RI, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
     return p;
@@ -192,7 +151,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       ri_t[j] = p.rij;
       pid_t[j] = p.vpj;
     }
-    const f32x16 uacc = load_u(U, ok, p.vpj, h);
     wave_sync();
     u32x4 xr[2][KB], go[2][KB];
     auto issue_rows = [&](int b) {
@@ -204,11 +162,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       }
     };
     issue_rows(0);
-    ChainKeep k;
-    chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
-    const f32x16 zero = {0};
     float c[NE];
-    scores(mm32_lds(s_ops, OP_WS, lane, k.a6, zero), c);
+    c[0] = __uint_as_float(p.cc.x);
+    if (NE > 1) c[NE - 1] = __uint_as_float(p.cc.y);
     const int vp0 = __builtin_amdgcn_readfirstlane(p.vpj);
     const bool single = frag != 0 || __ballot(ok && p.vpj != vp0) == 0;     // one point in the tile
     SegInfo sg;
@@ -225,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
     auto red_max = [&](float v) { return single ? half_max(v) : seg_total(seg_scan_max(v, sg, lane), sg, h); };
     auto red_sum = [&](float v) { return single ? half_sum(v) : seg_total(seg_scan_sum(v, sg, lane), sg, h); };
     if (frag == 1) {
-      // ---- long point: softmax statistics over ALL its fragments first (scores only), and
+      // ---- long point: softmax statistics over ALL its fragments first (their scores are 16 bytes per view), and
       //      E = sum_v a q from the saved forward output: E_g = sum_{ch in g} gout out / gate
       float m_run[NE], s_run[NE];
 #pragma unroll
@@ -237,11 +193,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       for (int t2 = p.t + 1;; ++t2) {
         const TileInfo t2i = get_tile(tiles, t2);
         const bool ok2 = j < t2i.nv;
-        const float4 x2 = as_f4(ld128(X, ok2 ? (uint32_t)(t2i.v0 + j) * 32u + 16u * h : OOB));
-        ChainKeep k2;
-        chain_forward(s_ops, lane, s_tab, h, 0xffffffffu, x2, uacc, k2);   // same point: same set-branch row
+        const u32x2 cc2 = ld64(CP, ok2 ? (uint32_t)(t2i.v0 + j) * 16u + coff : OOB);
         float c2[NE];
-        scores(mm32_lds(s_ops, OP_WS, lane, k2.a6, zero), c2);
+        c2[0] = __uint_as_float(cc2.x);
+        if (NE > 1) c2[NE - 1] = __uint_as_float(cc2.y);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           const float m2 = vmaxf(m_run[e], half_max(ok2 ? c2[e] : -INFINITY));
@@ -353,39 +308,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
       const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), 0u};
       st128(RC, wr ? vg * 16u : OOB, r);
     }
-    // ---- statistics of BatchNorm-6 backward
-    if (!ok) { dc4[0] = dc4[1] = dc4[2] = dc4[3] = 0.f; }
-    // ---- score layer: dWs, dbs
-    {
-      const uint32_t keep = ok ? 0xffffffffu : 0u;
-      const bf16x8 t6[2] = {mask8(k.a6[0], keep), mask8(k.a6[1], keep)};
-      tileT_put_packed(tc, j, h, t6);
-      if (h == 0) {
-        const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
-        td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
-        td[1 * TSB + j] = (bf16_t)(d01 >> 16);
-        td[2 * TSB + j] = (bf16_t)(d23 & 0xffffu);
-        td[3 * TSB + j] = (bf16_t)(d23 >> 16);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
-      }
-    }
-    const f32x16 da6 = score_bwd(s_ops, lane, dc4, h);
-    float dz_unused[16];
-    layer_bwd<true, false>(k.z6, da6, s_tab[3], h, ok, st, dz_unused);
-    wave_sync();
-    accS = wgrad_short(tc, td, j, 4, h, accS);
     wave_sync();
   });
-  flush_matrix(accS, dWs, D, G, true, s_red);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float v = dbsum[g];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
-  }
-  flush_stats<2>(st, stats6, s_red);
   if (gw) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -399,14 +323,110 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer passes.  STAGE 6: dz6 -> dW6, S5; hands da5 (bf16 [V, 32]) to the next pass.
-// STAGE 5: da5 -> dz5 -> dW5, du, S2 (view part); hands da2 to the next pass.
-// STAGE 2: da2 + set-pooling gradient -> dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
-// Each pass re-evaluates only the layers it differentiates (x_map -> ... -> its own layer); the gradient with
-// respect to the layer output crosses the BatchNorm barrier as one bf16 row per view (64 bytes), in the
-// accumulator order of the lane that wrote it: re-deriving it through the later layers cost 0.8 ms per pass.
+// score layer backward + statistics of the BatchNorm-6 backward: one chain evaluation per view (x_map 32 B + the
+// view -> point index 4 B + the score gradients 16 B in; nothing view-sized out).
+//   da6 = Ws^T dc;  dy6 = leaky'(t6) da6  (t6 = the folded product the forward's activation saw);
+//   S6 = sum dy6 | sum dy6 z6;   dWs^T[k][g] = sum_v a6[v][k] dc[v][g];   dbs = sum_v dc
+// LDS operand table: chain positions 0..6 (W1', W2', W5, W6), 7..8 = W6' (folded), 9 = Ws^T.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_da(__amdgpu_buffer_rsrc_t R, bool ok, uint32_t view, int h, const f32x16& da) {
+__global__ __launch_bounds__(256, 3) void score_stats_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ dc, double* __restrict__ stats6,
+    float* __restrict__ dWs, float* __restrict__ dbs, int G, int64_t V, int64_t N) {
+  constexpr int L_W6F = 7, L_WST = 9, NOPS = 10;
+  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
+  // transposed a6 tile + a 4-row score-gradient tile (+ one shared zero row), as in the layer passes
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_td[4][5 * TSB];
+  float* s_red = reinterpret_cast<float*>(&s_tc[0][0]);        // epilogue only (D x D floats <= the tile buffers)
+  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < 4 * 5 * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) s_ops[OP_W5 * 64 + i] = ops[OP_W5 * 64 + i];   // W5, W6
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_ops[L_WST * 64 + i] = ops[OP_WST * 64 + i];
+  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  fold_ops(s_ops, L_W6F, ops, OP_W6, 2, bn6);
+  stage_tab(s_tab[0], bn1, nullptr);
+  stage_tab(s_tab[1], bn2, nullptr);
+  stage_tab(s_tab[2], bn5, nullptr);
+  stage_tab(s_tab[3], bn6, nullptr);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16);
+  bf16_t* tc = s_tc[wv];
+  bf16_t* td = s_td[wv];
+  f32x16 accS = {0};
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float st[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x, dc;
+    int vpj;
+  };
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
+    p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    const f32x16 uacc = load_u(U, ok, p.vpj, h);
+    ChainKeep k;
+    chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};      // zeros in the lanes without a view and for h = 1
+    tileT_put_packed(tc, j, h, k.a6);
+    if (h == 0) {
+      const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
+      td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
+      td[1 * TSB + j] = (bf16_t)(d01 >> 16);
+      td[2 * TSB + j] = (bf16_t)(d23 & 0xffffu);
+      td[3 * TSB + j] = (bf16_t)(d23 >> 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
+    }
+    f32x16 dy6 = score_bwd<L_WST>(s_ops, lane, dc4, h);
+    dleaky_mul(k.t6, dy6);
+    bn_bwd_stats(k.z6, dy6, st);
+    wave_sync();
+    accS = wgrad_short(tc, td, j, 4, h, accS);
+    wave_sync();
+  });
+  flush_matrix(accS, dWs, D, G, true, s_red);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v = dbsum[g];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
+  }
+  flush_stats<2>(st, stats6, s_red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer passes.  STAGE 6: dz6 -> dW6, S5; hands dy5 = leaky'(y5) da5 (bf16 [V, 32]) to the next pass.
+// STAGE 5: dy5 -> dz5 -> dW5, du, S2 (view part); hands dy2 = leaky'(t2) da2 to the next pass.
+// STAGE 2: dy2 + set-pooling gradient -> dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
+// Each pass re-evaluates only the layers it differentiates (x_map -> ... -> its own layer); the gradient with
+// respect to the layer's BatchNorm output crosses the BatchNorm barrier as one bf16 row per view (64 bytes), in the
+// accumulator order of the lane that wrote it: re-deriving it through the later layers cost 0.8 ms per pass.
+// The row is handed over AFTER the derivative of the activation (the pass that produces it has the pre-activation
+// whose sign decides it: y5 in stage 6, the folded product t2 in stage 5).
+// ------------------------------------------------------------------------------------------------
+template <typename A16>
+__device__ __forceinline__ void store_da(__amdgpu_buffer_rsrc_t R, bool ok, uint32_t view, int h, const A16& da) {
   float t[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) t[r] = da[r];
@@ -426,8 +446,8 @@ __device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
   return d;
 }
 
-template <int STAGE>
-__global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
+template <int STAGE, int OCC>
+__global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -453,9 +473,9 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
   // plus the BatchNorm-folded operands (the forward passes' activations): stage 6 as chain_forward; stage 5: W1 in
   // place, W2 as a second operand (the raw z2 feeds the statistics) -> local 7, 8; stage 2: W1 as a second operand
   // -> local 5
-  // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9
-  constexpr int NOPS = STAGE == 6 ? 10 : (STAGE == 5 ? 9 : 6);
-  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9;
+  // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9; W6' (folded) -> 10, 11
+  constexpr int NOPS = STAGE == 6 ? 12 : (STAGE == 5 ? 9 : 6);
+  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9, L6_W6F = 10;
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (STAGE == 6) {
@@ -468,6 +488,7 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
     for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_W6T * 64 + i] = ops[OP_W6T * 64 + i];
     fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
     fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+    fold_ops(s_ops, L6_W6F, ops, OP_W6, 2, bn6);
   } else {
     for (int i = threadIdx.x; i < (STAGE == 5 ? 7 : 5) * 64; i += blockDim.x) {
       int op = i >> 6;
@@ -541,24 +562,41 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
     const uint32_t keep = ok ? 0xffffffffu : 0u;
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
     const f32x16 zero = {0};
-    float dz[16], unused_st[2][16];
+    float dz[16];
     bf16x8 dzp[2];
     if constexpr (STAGE == 6) {
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
-      ChainKeep k;
-      chain_forward<0, false>(s_ops, lane, s_tab, h, 0xffffffffu, p.x, uacc, k);
+      // forward up to a5 (layers 1, 2 folded, layer 5 plain); z5 stays for the statistics of layer 5
+      bf16x8 a5[2];
+      f32x16 z5;
+      {
+        bf16x8 a1[2], a2[2];
+        asm volatile("" ::: "memory");
+        const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
+        act_fold(t1, keep, a1);
+        const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(s_tab[1], T_B6, h));
+        act_fold(t2, keep, a2);
+        z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
+        act_pack(z5, s_tab[2], h, keep, a5);
+      }
+      tileT_put_packed(tb_, j, h, a5);
       const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
-      const f32x16 da6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
-      layer_bwd<false, true>(k.z6, da6, s_tab[3], h, ok, unused_st, dz);
+      {
+        // dy6 = leaky'(t6) Ws^T dc with the sign the forward's activation saw (the folded product), one 16-register
+        // block at a time: t6, then the raw z6 for the BatchNorm backward
+        f32x16 dy6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
+        {
+          const f32x16 t6 = mm32_lds(s_ops, L6_W6F, lane, a5, bias_acc(s_tab[3], T_B6, h));
+          dleaky_mul(t6, dy6);
+        }
+        const f32x16 z6 = mm32_lds(s_ops, OP_W6, lane, a5, zero);
+        bn_bwd_apply(z6, dy6, s_tab[3], h, dz);
+      }
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
-      {
-        const bf16x8 t5[2] = {mask8(k.a5[0], keep), mask8(k.a5[1], keep)};
-        tileT_put_packed(tb_, j, h, t5);
-      }
       const f32x16 da5 = mm32_lds(s_ops, L6_W6T, lane, dzp, zero);
-      store_da(DO, ok, view, h, da5);
-      layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dz);
+      layer_bwd<true, false>(z5, da5, s_tab[2], h, ok, st, dz);        // layer 5 is evaluated plain: sign of G5 z5 + B5
+      store_da(DO, ok, view, h, dz);                                    // dy5
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
       wave_sync();
@@ -569,12 +607,15 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
       asm volatile("" ::: "memory");
       const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
       act_fold(t1, 0xffffffffu, a1);
-      const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
-      const f32x16 t2 = mm32_lds(s_ops, L_W2F, lane, a1, bias_acc(s_tab[1], T_B6, h));
-      act_fold(t2, keep, a2);
-      const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
-      const f32x16 da5 = unpack_da(p.dlo, p.dhi);
-      layer_bwd<false, true>(z5, da5, s_tab[2], h, ok, unused_st, dz);
+      {
+        const f32x16 t2 = mm32_lds(s_ops, L_W2F, lane, a1, bias_acc(s_tab[1], T_B6, h));
+        act_fold(t2, keep, a2);
+      }
+      {
+        const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
+        const f32x16 dy5 = unpack_da(p.dlo, p.dhi);       // stage 6 hands leaky'(y5) da5
+        bn_bwd_apply(z5, dy5, s_tab[2], h, dz);
+      }
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
       tileT_put_packed(tb_, j, h, a2);
@@ -589,9 +630,17 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
         ind[lpj * TSB + j] = (bf16_t)0x3f80;
         if (is_start) plp[lpj] = p.vpj;
       }
-      const f32x16 da2 = mm32_lds(s_ops, L_W5T, lane, dzp, zero);
-      store_da(DO, ok, view, h, da2);
-      layer_bwd<true, false>(z2, da2, s_tab[1], h, ok, st, dz);
+      f32x16 dy2 = mm32_lds(s_ops, L_W5T, lane, dzp, zero);      // da2
+      {
+        // layer 2 was evaluated folded: leaky' follows the sign of t2 (evaluated again here: a1 is 8 registers, t2 16)
+        const f32x16 t2 = mm32_lds(s_ops, L_W2F, lane, a1, bias_acc(s_tab[1], T_B6, h));
+        dleaky_mul(t2, dy2);
+      }
+      store_da(DO, ok, view, h, dy2);
+      {
+        const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);     // the raw output: sum dy2 z2
+        bn_bwd_stats(z2, dy2, st);
+      }
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
       const int frag = p.ti.frag;
@@ -626,7 +675,8 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
         const f32x16 t1 = CH_MFMA(lds_op(s_ops, L_W1F, lane), xp, bias_acc(s_tab[0], T_B6, h));
         act_fold(t1, keep, a1);
       }
-      // gradient of the max-pooled set features goes to the arg view of each channel
+      // dy2 of the view path (stage 5) + the gradient of the max-pooled set features, which goes to the arg view of
+      // each channel; dpooled arrives as leaky'(y*) dpooled (dva_chain_route_stats: the set pooling saw the plain y2)
       f32x16 da2t = unpack_da(p.dlo, p.dhi);
       {
         const int vg = p.ti.v0 + j;
@@ -642,7 +692,7 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
       asm volatile("" ::: "memory");
       {
         const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
-        layer_bwd<false, true>(z2, da2t, s_tab[1], h, ok, unused_st, dz);
+        bn_bwd_apply(z2, da2t, s_tab[1], h, dz);
       }
       pack16(dz, keep, dzp);
       tileT_put_packed(ta, j, h, dzp);
@@ -681,12 +731,14 @@ __global__ __launch_bounds__(256, STAGE == 5 ? 2 : 3) void layer_bwd_kernel(
 }
 
 // S2 of layer 2, per-point part: the set-pooling gradient lands on one view per (point, channel) whose z2 is
-// zstar: stats += sum_p leaky'(y*) dpooled | the same times z_hat*  over the seen points.
+// zstar: stats += sum_p leaky'(y*) dpooled | the same times z_hat*  over the seen points.  dpy [N, 32] receives
+// leaky'(y*) dpooled (0 for unseen points): what stage 2 routes to the arg views (the set pooling took the activation
+// of the PLAIN product G2 z2 + B2, so its derivative follows that sign, not the folded product's).
 __global__ __launch_bounds__(256) void route_stats_kernel(const float* __restrict__ zstar,
                                                           const float* __restrict__ dpooled,
                                                           const float* __restrict__ bn2,
                                                           const int64_t* __restrict__ ptr, double* __restrict__ stats,
-                                                          int64_t N) {
+                                                          float* __restrict__ dpy, int64_t N) {
   __shared__ float s_red[2 * D];
   const int q = threadIdx.x & 7, sub = threadIdx.x >> 3;       // 32 points per block iteration, 4 channels per thread
   float g[4], b[4], iv[4], mm[4], s1[4], s2[4];
@@ -715,15 +767,19 @@ __global__ __launch_bounds__(256) void route_stats_kernel(const float* __restric
     }
     const float zz[2][4] = {{z0.x, z0.y, z0.z, z0.w}, {z1.x, z1.y, z1.z, z1.w}};
     const float dd[2][4] = {{d0.x, d0.y, d0.z, d0.w}, {d1.x, d1.y, d1.z, d1.w}};
+    float dyv[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float dy = dd[u][e] * dleaky(__builtin_fmaf(zz[u][e], g[e], b[e]));   // unseen points: dpooled read as 0
+        dyv[u][e] = dy;
         s1[e] += dy;
         s2[e] = __builtin_fmaf(dy, __builtin_fmaf(zz[u][e], iv[e], mm[e]), s2[e]);
       }
     }
+    *reinterpret_cast<float4*>(dpy + p0 * D + 4 * q) = make_float4(dyv[0][0], dyv[0][1], dyv[0][2], dyv[0][3]);
+    if (p1 < N) *reinterpret_cast<float4*>(dpy + p1 * D + 4 * q) = make_float4(dyv[1][0], dyv[1][1], dyv[1][2], dyv[1][3]);
   }
   if (threadIdx.x < 2 * D) s_red[threadIdx.x] = 0.f;
   __syncthreads();
@@ -805,30 +861,25 @@ using namespace dva::chain;
 
 extern "C" {
 
-int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
-                       const float* bn5, const float* bn6, const float* score_bias, const void* rows,
-                       const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
-                       const void* grad_out, const void* out, float* grad_scores, void* view_rec,
-                       double* stats6, float* grad_gate_wb, float* dWs, float* dbs, int64_t n_points,
-                       int64_t n_views, int64_t n_rows,
-                       int32_t C, int32_t G, int32_t scaling, float eps, void* stream) {
+int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                       const void* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                       const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
+                       float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
+                       int32_t scaling, float eps, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
-      !rows || !row_idx || !ptr || !grad_out || !out || !grad_scores || !view_rec || !stats6 || !dWs || !dbs ||
-      ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
+  if (!scores || !view_point || !tiles || !n_tiles || !rows || !row_idx || !ptr || !grad_out || !out ||
+      !grad_scores || !view_rec || ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
     return DVA_ERR_INVALID;
-  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
-      n_points * C * 2 > 0xfffffff0ll)
+  if (n_views * 16 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll || n_points * C * 2 > 0xfffffff0ll)
     return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(2)), block(256);
+  const dim3 grid(chain_grid(C <= 64 ? 4 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_ATTN_BWD(LPR_, G_)                                                                                   \
-  hipLaunchKernelGGL((attn_bwd_kernel<LPR_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,  \
-                     n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)rows, row_idx,  \
-                     ptr, gate_w, gate_b, (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, (uint32_t*)view_rec,   \
-                     stats6, grad_gate_wb, dWs, dbs, scaling, eps, n_views, n_points, n_rows)
+  hipLaunchKernelGGL((attn_bwd_kernel<LPR_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,    \
+                     n_tiles, (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b, (const bf16_t*)grad_out,        \
+                     (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, scaling, eps, n_views,  \
+                     n_points, n_rows)
   const int key = C * 8 + G;
   switch (key) {
     case 32 * 8 + 1: DVA_ATTN_BWD(4, 1); break;
@@ -853,6 +904,23 @@ int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const floa
   return DVA_OK;
 }
 
+int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                          const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                          const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
+                          float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !grad_scores ||
+      !stats6 || !dWs || !dbs)
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(score_stats_kernel, dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores, stats6, dWs, dbs,
+                     (int)G, n_views, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
 int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
@@ -871,11 +939,13 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_LAYER_BWD(ST_, BPC_)                                                                                  \
-  hipLaunchKernelGGL((layer_bwd_kernel<ST_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u,        \
+  hipLaunchKernelGGL((layer_bwd_kernel<ST_, BPC_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u,  \
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
                      grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, \
                      n_views, n_points)
+  static const int occ5 = tune_int("DVA_STAGE5_OCC", 2);
   if (stage == 6) DVA_LAYER_BWD(6, 3);
+  else if (stage == 5 && occ5 == 3) DVA_LAYER_BWD(5, 3);
   else if (stage == 5) DVA_LAYER_BWD(5, 2);
   else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD
@@ -884,14 +954,14 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
 }
 
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
-                          double* stats, int64_t n_points, void* stream) {
+                          double* stats, float* dpooled_dy, int64_t n_points, void* stream) {
   if (n_points < 0) return DVA_ERR_INVALID;
   if (n_points == 0) return DVA_OK;
-  if (!zstar || !dpooled || !bn2 || !ptr || !stats) return DVA_ERR_INVALID;
+  if (!zstar || !dpooled || !bn2 || !ptr || !stats || !dpooled_dy) return DVA_ERR_INVALID;
   int64_t blocks = (n_points + 63) / 64;
   const int cap = chain_grid(4);
   hipLaunchKernelGGL(route_stats_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(256), 0,
-                     (hipStream_t)stream, zstar, dpooled, bn2, ptr, stats, n_points);
+                     (hipStream_t)stream, zstar, dpooled, bn2, ptr, stats, dpooled_dy, n_points);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

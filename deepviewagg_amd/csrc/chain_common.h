@@ -13,6 +13,7 @@
 // raw output a pass does not need take the BatchNorm scale inside the rounded operand: "BatchNorm folded" below), fp32
 // accumulation, BatchNorm / softmax / statistics in fp32.
 #pragma once
+#include <cstdlib>
 #include "dva_common.h"
 
 namespace dva {
@@ -435,6 +436,41 @@ __device__ __forceinline__ void layer_bwd(const f32x16& z, const f32x16& da, con
     }
   }
 }
+// ---- backward of a layer whose activation the forward took from ANOTHER product than the raw z (BatchNorm folded
+// into the operand): the derivative of leaky follows the sign of what the forward's activation saw (t = 0.6 y of the
+// folded product), the BatchNorm-backward terms follow the raw z.  Taking the sign from G z + B instead flips
+// leaky' on the ~0.3 % of values where the two pre-activations straddle zero: measured 3-10 % on the parameter
+// gradients (tests/test_gpu_chain.py::test_chain_matches_bf16_emulation).
+__device__ __forceinline__ void dleaky_mul(const f32x16& t, f32x16& da) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) da[r] = t[r] > 0.f ? da[r] : SLOPE * da[r];
+}
+// statistics of a BatchNorm backward from dy = leaky' da: st[0] += dy, st[1] += dy * z (raw layer output)
+__device__ __forceinline__ void bn_bwd_stats(const f32x16& z, const f32x16& dy, float (&st)[2][16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    st[0][r] += dy[r];
+    st[1][r] = __builtin_fmaf(dy[r], z[r], st[1][r]);
+  }
+}
+// dz = G dy - K1 - K2 z (four channels at a time: a few float4 of constants live)
+__device__ __forceinline__ void bn_bwd_apply(const f32x16& z, const f32x16& dy, const float* tab, int h,
+                                             float (&dz)[16]) {
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = 16 * h + 4 * q;
+    const float4 g4 = *reinterpret_cast<const float4*>(tab + T_G * D + o);
+    const float4 a4 = *reinterpret_cast<const float4*>(tab + T_K1 * D + o);
+    const float4 c4 = *reinterpret_cast<const float4*>(tab + T_K2 * D + o);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, k1[4] = {a4.x, a4.y, a4.z, a4.w}, k2[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      dz[r] = __builtin_fmaf(-k2[e], z[r], __builtin_fmaf(g[e], dy[r], -k1[e]));
+    }
+  }
+}
 __device__ __forceinline__ void pack16(const float (&x)[16], uint32_t keep, bf16x8 (&a)[2]) {
   a[0] = mask8(pack8(&x[0]), keep);
   a[1] = mask8(pack8(&x[8]), keep);
@@ -485,6 +521,11 @@ __device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restric
 }
 
 
+// experiment switches of the kernels' launch configuration (environment, read once)
+static inline int tune_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 static inline int chain_grid(int blocks_per_cu) {
   static int cus = 0;
   if (cus == 0) {

@@ -494,8 +494,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ rows,
     const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
-    const float* __restrict__ gb, bf16_t* __restrict__ out, int scaling, float eps, int64_t V, int64_t N,
-    int64_t R) {
+    const float* __restrict__ gb, bf16_t* __restrict__ out, float* __restrict__ scores_out, int scaling, float eps,
+    int64_t V, int64_t N, int64_t R) {
   constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr int KB = KV < 8 ? KV : 8, NB = KV / KB;
   constexpr int NE = G == 1 ? 1 : 2;           // score values per lane on the softmax side
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
-                               RW = make_rsrc(rows, (uint64_t)R * C * 2), O = make_rsrc(out, (uint64_t)N * C * 2);
+                               RW = make_rsrc(rows, (uint64_t)R * C * 2), O = make_rsrc(out, (uint64_t)N * C * 2),
+                               SC = make_rsrc(scores_out, scores_out ? (uint64_t)V * 16 : 0);
   // softmax side: lane (j, h) owns the groups gl[e]
   const bool s_active = G == 4 || h == 0;
   int gl[NE];
@@ -617,6 +618,17 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     } else {
 #pragma unroll
       for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
+    }
+    // training: the scores [V, 4] stay for the attention backward (16 bytes per view instead of a chain evaluation);
+    // a null pointer makes a zero-sized buffer: the stores are dropped
+    if (s_active) {
+      const uint32_t so = ok ? (uint32_t)(p.ti.v0 + j) * 16u + (G == 4 ? 8u * h : 0u) : OOB;
+      if (NE == 2) {
+        const u32x2 cv = {__float_as_uint(c[0]), __float_as_uint(c[NE - 1])};
+        __builtin_amdgcn_raw_buffer_store_b64(cv, SC, (int)so, 0, 0);
+      } else {
+        st32(SC, so, __float_as_uint(c[0]));
+      }
     }
     const int vp0 = __builtin_amdgcn_readfirstlane(p.vpj);
     const bool single = frag != 0 || __ballot(ok && p.vpj != vp0) == 0;
@@ -945,8 +957,8 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
                        const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                        const float* bn5, const float* bn6, const float* score_bias, const void* rows,
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
-                       void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
-                       int32_t scaling, float eps, void* stream) {
+                       void* out, float* scores_out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C,
+                       int32_t G, int32_t scaling, float eps, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
@@ -961,8 +973,8 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
 #define DVA_ATTN_FWD_O(LPR_, G_, OCC_)                                                                          \
   hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_, OCC_>), grid, block, 0, s, x_map, view_point, u,               \
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias,            \
-                     (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b, (bf16_t*)out, scaling, eps, n_views,    \
-                     n_points, n_rows)
+                     (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b, (bf16_t*)out, scores_out, scaling, eps, \
+                     n_views, n_points, n_rows)
 #define DVA_ATTN_FWD(LPR_, G_)                                                                                  \
   do {                                                                                                          \
     if (LPR_ <= 8 && dense) DVA_ATTN_FWD_O(LPR_, G_, (LPR_ <= 8 ? 4 : 3));                                      \

@@ -214,15 +214,19 @@ class _ChainPool(torch.autograd.Function):
         bn6 = _chain_bn(s6, V, bns[3], training, W6, D, s6[2 * D:])
         # ---- the fused view kernel
         out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
+        # a backward will follow: the scores of every view stay (16 bytes per view) -- the attention backward starts from
+        # them instead of evaluating the chain once more
+        need_bwd = any(ctx.needs_input_grad)
+        scores = torch.empty((V, 4), dtype=torch.float32, device=dev) if need_bwd else None
         # SURVEY.md 8(d) fused view-gather + attention: V (C s + F_map 4 + idx) + N (C s + ptr); idx = view->point
-        # index + row index (4 + 4), per point the set-branch row (128) on top
-        with ops._timed("chain_attn_fwd", V * (C * 2 + 32 + 8) + N * (C * 2 + 128 + 8)):
+        # index + row index (4 + 4), per point the set-branch row (128) on top (+ 16 bytes per view of scores out in training)
+        with ops._timed("chain_attn_fwd", V * (C * 2 + 32 + 8 + (16 if need_bwd else 0)) + N * (C * 2 + 128 + 8)):
             check(lib.dva_chain_attn_fwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                          ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
-                                         ptr(csr_idx), ptr(gw), ptr(gb), ptr(out), N, V, R, C, G, int(scaling),
-                                         float(eps), st), "dva_chain_attn_fwd")
+                                         ptr(csr_idx), ptr(gw), ptr(gb), ptr(out), ptr(scores), N, V, R, C, G,
+                                         int(scaling), float(eps), st), "dva_chain_attn_fwd")
         ctx.save_for_backward(rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
-                              bn1, bn2, bn5, bn6, out)
+                              bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1)
         ctx.plan = plan
         ctx.module = module
         ctx.set_saved = set_saved

@@ -38,8 +38,11 @@ def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=Tru
 def backward(ctx, gout):
     from .fused_chain import _set_branch_backward
     lib = _lib.load()
+    if ctx.set_saved is None:
+        raise RuntimeError("the recompute chain's backward ran twice on the same graph: its per-step workspaces are "
+                           "released after the first backward (retain_graph is not supported on this path)")
     (rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
-     bn1, bn2, bn5, bn6, out) = ctx.saved_tensors
+     bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1) = ctx.saved_tensors
     module, training = ctx.module, ctx.training
     scaling, eps = ctx.meta
     e_map, e_score, gate = module.E_map, module.E_score, module.G
@@ -49,9 +52,7 @@ def backward(ctx, gout):
     st = stream_of(x_map)
     gout = gout.contiguous().to(torch.bfloat16)
     m_rows = float(max(V, 1))
-    bs = e_score.bias.detach().contiguous()
-    gw = gate.weight.detach().reshape(-1).float().contiguous() if gate is not None else None
-    gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
+    # bs, gw, gb, W1: the values the forward used (frozen with the operand table and the BatchNorm tables)
 
     zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
     arena = Arena(dev)          # every small fp32 accumulator / gradient of this backward: one zero fill
@@ -64,18 +65,24 @@ def backward(ctx, gout):
         then (sm = S / M for the next pass, d gamma = S2, d beta = S1)."""
         return bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat, out)
 
-    # ---- attention + gate backward: score gradients, view records, S6
+    # ---- attention + gate backward from the scores the forward left: score gradients, view records (no chain)
     dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
     rec = torch.empty((V, 4), dtype=torch.int32, device=dev)       # 16-byte records: point | 4 x bf16 weight | pad
-    s6 = zstats()
     gwb = arena.take(2 * G) if gate is not None else None
-    dWs, dbs = arena.take(G, D), arena.take(G)          # score layer: a6 and the score gradients both exist in this pass
-    with ops._timed("chain_attn_bwd", V * (C * 2 + 32 + 8 + 16 + 16) + N * (2 * C * 2 + 128 + 8)):
-        check(lib.dva_chain_attn_bwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                     ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
+    # per view: value row + scores 16 + view->point / row index 8 in, score gradients 16 + record 16 out; per point
+    # grad_out row (+ out row for points with more than 32 views)
+    with ops._timed("chain_attn_bwd", V * (C * 2 + 16 + 8 + 16 + 16) + N * (C * 2 + 8)):
+        check(lib.dva_chain_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx),
                                      ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
-                                     ptr(s6), ptr(gwb), ptr(dWs), ptr(dbs), N, V, R, C, G, scaling, eps, st),
-              "dva_chain_attn_bwd")
+                                     ptr(gwb), N, V, R, C, G, scaling, eps, st), "dva_chain_attn_bwd")
+    del scores
+    # ---- score layer: dWs, dbs, and the statistics of the BatchNorm-6 backward (one chain evaluation)
+    s6 = zstats()
+    dWs, dbs = arena.take(G, D), arena.take(G)
+    with ops._timed("chain_score_stats", V * (32 + 4 + 16) + N * 128):
+        check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                        ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
+                                        G, V, N, st), "dva_chain_score_stats")
     # ---- rows gradient: segmented reduction over the row plan (deterministic, no atomics)
     grows = None
     if ctx.needs_input_grad[0]:
@@ -116,15 +123,15 @@ def backward(ctx, gout):
     # ---- per-point set branch
     dpooled, d_set = _set_branch_backward(ctx.set_saved, du, dW5, training, zstats, arena)
     consts(s2, bn2, out=False)            # view part; the per-point part below is accumulated in z_hat directly
-    check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), N, st),
-          "dva_chain_route_stats")
+    dpooled_dy = torch.empty((N, D), dtype=torch.float32, device=dev)     # leaky'(y*) dpooled: what stage 2 routes
+    check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), ptr(dpooled_dy), N,
+                                    st), "dva_chain_route_stats")
     sm2, g2, b2 = consts(s2, bn2, hat=False)
     dW2, P = arena.take(D, D), arena.take(D, 20)       # P = sum dy1 [x_hi | x_lo | 1]^T
     s1 = zstats()
-    layer(2, sm2, None, None, arg, dpooled, da2, None, dW2, None, P, None, "chain_bwd_l2",
+    layer(2, sm2, None, None, arg, dpooled_dy, da2, None, dW2, None, P, None, "chain_bwd_l2",
           V * (32 + 4 + 64) + N * 256)
     del da2
-    W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
     check(lib.dva_chain_stats1(ptr(P), ptr(W1), ptr(s1), st), "dva_chain_stats1")    # layer 1 is linear in x_map
     sm1, g1, b1 = consts(s1, bn1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so

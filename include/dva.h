@@ -399,13 +399,15 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
                     void* stream);
 /* out bf16 [N][C] (caller-zeroed) = gate * sum_v softmax_v(scores) * rows[row_idx[v]]:
  * x_map + rows in -> pooled features out.  rows bf16 [n_rows][C], C in {32, 64, 128, 256, 512},
- * G in {1, 2, 4} with (C / G) % 8 == 0; gate_w / gate_b fp32 [G] nullable together. */
+ * G in {1, 2, 4} with (C / G) % 8 == 0; gate_w / gate_b fp32 [G] nullable together.
+ * scores_out (nullable; training): fp32 [V][4] receives the scores E_score(E_map(x_map)) of every view (columns < G),
+ * what dva_chain_attn_bwd starts from (16 bytes per view instead of one more chain evaluation). */
 int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
                        const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                        const float* bn5, const float* bn6, const float* score_bias, const void* rows,
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
-                       void* out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
-                       int32_t scaling, float eps, void* stream);
+                       void* out, float* scores_out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C,
+                       int32_t G, int32_t scaling, float eps, void* stream);
 
 /* The arithmetic between two BatchNorm-backward passes as one launch.  stats fp64 [2C] = S1 | S2, bn fp32 [4][C] =
  * mean | invstd | gamma | beta.  do_hat: S2 arrives as sum dy z (raw layer output) and becomes
@@ -441,29 +443,36 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
                       const float* bn_s1, const float* bn_s2, const float* sm_s1, const float* sm_s2,
                       const float* du, float* dpooled, float* dW, int32_t ld_dw, float* dw33, double* stats,
                       int64_t n_points, void* stream);
-/* Backward of dva_chain_attn_fwd (+ the BatchNorm-backward statistics of layer 6).  grad_out / out bf16 [N][C]
- * (out = the forward result; only read for points with more than 32 views).  Outputs: grad_scores fp32 [V][4]
- * (columns >= G zero), view_rec = V packed 16-byte records {int32 point id | gate * attention of groups 0..3 as
- * bf16 | 4 unused bytes} (what dva_view_gather_rows_grad_rec16 consumes: the rows gradient is rounded to bf16, its
- * weights travel as bf16), stats6 += S1 | S2 of layer 6, grad_gate_wb fp32 [2 G] (caller-zeroed,
- * d gate_w | d gate_b; nullable with gating off), dWs fp32 [G][32] / dbs fp32 [G] (caller-zeroed) += the gradient of the
- * score layer (a6 and the score gradients both exist in this pass). */
-int dva_chain_attn_bwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
-                       const float* bn5, const float* bn6, const float* score_bias, const void* rows,
-                       const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
-                       const void* grad_out, const void* out, float* grad_scores, void* view_rec,
-                       double* stats6, float* grad_gate_wb, float* dWs, float* dbs, int64_t n_points,
-                       int64_t n_views, int64_t n_rows, int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
+/* Backward of the softmax / weighted sum / gate of dva_chain_attn_fwd from the scores it left (scores fp32 [V][4]):
+ * no chain evaluation.  grad_out / out bf16 [N][C] (out = the forward result; only read for points with more than 32
+ * views).  Outputs: grad_scores fp32 [V][4] (columns >= G zero), view_rec = V packed 16-byte records {int32 point id |
+ * gate * attention of groups 0..3 as bf16 | 4 unused bytes} (what dva_view_gather_rows_grad_rec16 consumes: the rows
+ * gradient is rounded to bf16, its weights travel as bf16), grad_gate_wb fp32 [2 G] (caller-zeroed, d gate_w |
+ * d gate_b; nullable with gating off). */
+int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                       const void* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                       const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
+                       float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
+                       int32_t scaling, float eps, void* stream);
+/* Score layer backward + the statistics of the BatchNorm-6 backward (one chain evaluation per view):
+ * stats6 += S1 | S2 of layer 6 with dy6 = leaky'(t6) Ws^T grad_scores (t6 = the folded layer-6 product, the
+ * pre-activation the forward's activation saw), dWs fp32 [G][32] / dbs fp32 [G] (caller-zeroed) += the gradient of the
+ * score layer. */
+int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                          const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                          const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
+                          float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream);
 /* One backward pass of the chain between two BatchNorm-backward barriers ("sm" = fp32 [2][32] = S1/M | S2/M of
  * the pass's own layer, zeros with running statistics; dW / P / stats caller-zeroed, accumulated with
- * atomics).  Each pass re-evaluates the chain from x_map up to its own layer; the gradient w.r.t. the layer's
- * OUTPUT is handed from pass to pass as da_out -> da_in, bf16 [V][32] (64 bytes per view, in the lane order of
- * the kernels: opaque to the caller):
- *   stage 6: grad_scores -> dW [32][32] = dW6, stats += S of layer 5, da_out = d a5                        (sm6)
- *   stage 5: da_in = d a5 -> dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u
- *            (written for seen points), stats += S of layer 2 (view part), da_out = d a2               (sm5)
- *   stage 2: da_in = d a2 (+ dpooled routed to the arg views of dva_chain_stats2) -> dW [32][32] = dW2,
+ * atomics).  Each pass re-evaluates the chain from x_map up to its own layer; the gradient w.r.t. the BatchNorm
+ * output of the layer below (dy = leaky'(.) da, the derivative of the activation already applied with the sign of
+ * the pre-activation the forward saw) is handed from pass to pass as da_out -> da_in, bf16 [V][32] (64 bytes per
+ * view, in the lane order of the kernels: opaque to the caller):
+ *   stage 6: grad_scores -> dW [32][32] = dW6, stats += S of layer 5, da_out = dy5                         (sm6)
+ *   stage 5: da_in = dy5 -> dW [32][64] (first 32 columns) = dW5 per-view half, du fp32 [N][32] = gradient of u
+ *            (written for seen points), stats += S of layer 2 (view part), da_out = dy2                (sm5)
+ *   stage 2: da_in = dy2 (+ dpooled = the dpooled_dy of dva_chain_route_stats, routed to the arg views of
+ *            dva_chain_stats2) -> dW [32][32] = dW2,
  *            P fp32 [32][20] += sum_v dy1 [x_hi (8) | x_lo (8) | 1 | unused]^T; the statistics of layer 1 follow
  *            from P (dva_chain_stats1; stats may be NULL)                                                (sm2) */
 int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
@@ -472,9 +481,10 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
                         const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream);
-/* stats += S1 | S2 of layer 2, per-point part: sum over the seen points of leaky'(BN2(zstar)) dpooled (x z_hat). */
+/* stats += S1 | S2 of layer 2, per-point part: sum over the seen points of leaky'(BN2(zstar)) dpooled (x z_hat);
+ * dpooled_dy fp32 [N][32] = leaky'(BN2(zstar)) dpooled (0 for unseen points): the `dpooled` of stage 2. */
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,
-                          double* stats, int64_t n_points, void* stream);
+                          double* stats, float* dpooled_dy, int64_t n_points, void* stream);
 
 /* 'concatenation' fusion (modules/multimodal/fusion.py:7-53: torch.cat((x_main, x_mod), dim=-1)) with the dtype
  * promotion of torch.cat folded in: x_main fp32 [N][C_main], x_mod fp32 / bf16 [N][C_mod] -> out fp32

@@ -764,6 +764,52 @@ def gen_transforms():
     save("transforms", **res)
 
 
+def gen_neighborhood():
+    """NeighborhoodBasedMappingFeatures._process (core/data_transform/multimodal/image.py:482-612) run from the
+    reference source: K-NN through the KeOps branch (argKmin of the shim: brute force, ties to the lower index),
+    density and occlusion exactly as the reference writes them.  Two clouds: a noisy surface (no tied distances) and
+    a cloud with duplicated points (zero distances)."""
+    print("NeighborhoodBasedMappingFeatures")
+    from torch_geometric.data import Data
+    T = import_ref_transforms()
+    gen = torch.Generator().manual_seed(33)
+    res = {}
+    for tag, n in (("surf", 1200), ("dup", 400)):
+        xyz = torch.rand(n, 3, generator=gen) * torch.tensor([4.0, 4.0, 2.5])
+        if tag == "surf":
+            face = torch.randint(0, 3, (n,), generator=gen)
+            xyz[torch.arange(n), face] = 0.0
+            xyz += torch.randn(n, 3, generator=gen) * 1e-3
+        else:
+            xyz[n // 2:] = xyz[:n - n // 2]            # every point twice
+        B = 5
+        pts, imgs = [], []
+        for p in range(n):
+            k = int(torch.randint(0, 4, (1,), generator=gen))
+            for i in torch.randperm(B, generator=gen)[:k].tolist():
+                pts.append(p)
+                imgs.append(i)
+        pts, imgs = torch.LongTensor(pts), torch.LongTensor(imgs)
+        pix = torch.randint(0, 32, (len(pts), 2), generator=gen).short()
+        feats = torch.rand(len(pts), 3, generator=gen)
+        mapping = ref_image.ImageMapping.from_dense(pts, imgs, pix, feats, num_points=n)
+        sd = ref_image.SameSettingImageData(
+            path=np.array([f'img_{i}' for i in range(B)]), pos=torch.rand(B, 3, generator=gen), opk=torch.zeros(B, 3),
+            ref_size=(32, 32), proj_upscale=1, mappings=mapping)
+        data = Data(pos=xyz.clone())
+        data.num_nodes = n
+        k_list = [20, 5]
+        tr = T.NeighborhoodBasedMappingFeatures(k=k_list, voxel=0.05, density=True, occlusion=True, use_faiss=False)
+        assert tr.k_list == [5, 20]
+        _, sd_out = tr(data, sd)
+        f = sd_out.mappings.features
+        assert f.shape[1] == 3 + 4
+        res.update({f"{tag}_xyz": xyz, f"{tag}_point_ids": pts, f"{tag}_image_ids": imgs, f"{tag}_pixels": pix,
+                    f"{tag}_features_in": feats, f"{tag}_features_out": f, f"{tag}_pointers": sd_out.mappings.pointers,
+                    f"{tag}_images": sd_out.mappings.images})
+    save("neighborhood", k_list=np.array([5, 20]), voxel=np.array(0.05), **res)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -772,7 +818,8 @@ if __name__ == "__main__":
     jobs = dict(softmax=gen_softmax, segment=gen_segment, pools=gen_pools, pools_headline=gen_pools_headline,
                 gather=gen_gather,
                 branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
-                transforms=gen_transforms, cylinder=gen_mapping_cylinder)
+                transforms=gen_transforms, cylinder=gen_mapping_cylinder,
+                neighborhood=gen_neighborhood)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()

@@ -244,10 +244,12 @@ def test_chain_equals_stored_activation_path():
 # Tight parity: the oracle's maths with the chain's operand roundings made explicit (straight-through bf16
 # rounding of the activations and weights that enter the matrix-core products; everything else fp32).  Unlike
 # the comparison with the un-rounded fp32 oracle above, nothing chaotic (LeakyReLU sign / arg-max flips under a
-# 2^-9 perturbation) separates the two computations, so the forward and the rows gradient agree to < 1e-2 relative L2 and
-# the parameter gradients to a few % (the backward kernels round dz / the weight-gradient operands to bf16 once
-# more, and the arg-max routing of the gate gradient stays discrete).
+# 2^-9 perturbation) separates the two computations: the backward kernels take leaky' from the sign of the same
+# pre-activation the emulation's autograd differentiates (the folded product of the folded layers).  FIXED tolerances
+# (relative L2 per tensor): output 6e-3, rows gradient 1e-2, every parameter gradient 5e-2 (the backward kernels round
+# dz / the weight-gradient operands to bf16 once more; the gate gradient is routed through a discrete arg-max).
 # ---------------------------------------------------------------------------------------------------------------
+EMU_TOL = {"out": 6e-3, "rows": 1e-2, "param": 5e-2}
 def _bf(t):
     return t + (t.bfloat16().float() - t).detach()
 
@@ -360,12 +362,15 @@ def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling)
         # lands on another view (measured: 3 views of 65536 carry the whole difference, tools/debug_chain.py)
         if n == "E_score.bias" and not gating:
             continue        # exactly zero in exact arithmetic (softmax is shift invariant): nothing to compare
-        # (tolerances scale with the sensitivity of the case: agreement with the emulation must be well inside
-        # the emulation's own distance from exact arithmetic)
-        if r > (max(1e-2, 0.25 * sens) if n == "rows" else max(1.5e-1, sens)):
+        if r > (EMU_TOL["rows"] if n == "rows" else EMU_TOL["param"]):
             bad.append((n, r, sens))
     print("chain vs bf16 emulation, rel L2 (kernel vs emulation, emulation vs fp32):", report)
-    assert r_out < max(6e-3, 0.25 * sens_out), (report, sens_out)      # bf16 rounding of the output itself: 2^-9
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/emu_report_r3.txt", "a") as f:
+            f.write(f"{sizes_fn.__name__} N={N} C={C} G={G} train={train} gating={gating} scaling={scaling} "
+                    f"sens_out={sens_out:.5f} {report}\n")
+    assert r_out < EMU_TOL["out"], (report, sens_out)      # bf16 rounding of the output itself: 2^-9
     assert not bad, (bad, report)
     if train:
         for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
@@ -419,7 +424,9 @@ def test_chain_against_reference_fixture(name):
     med = amps[len(amps) // 2]
     bad, report = [], []
     for n, a, b, c in zip(names, grads, refs, g_amp):
-        if float(b.abs().max()) == 0 or a is None:
+        assert a is not None, f"no gradient for {n}"
+        if float(b.abs().max()) == 0:
+            assert float(a.abs().max()) == 0, n
             continue
         ours, amp = rel(a, b), (rel(c, b) if c is not None else 0.0)
         report.append((n, round(ours, 4), round(amp, 4)))

@@ -100,3 +100,35 @@ def test_neighborhood_features_match_oracle():
     assert torch.equal(got[:, :f0.shape[1]], f0.cpu())
     torch.testing.assert_close(got[:, f0.shape[1]:f0.shape[1] + 2], exp[:, :2], rtol=1e-6, atol=0)   # densities
     assert torch.equal(got[:, f0.shape[1] + 2:], exp[:, 2:])                                          # occlusions
+
+
+@pytest.mark.parametrize("tag", ["surf", "dup"])
+def test_neighborhood_features_match_reference_fixture(tag):
+    """The HIP transform (dva_knn + dva_view_occlusion + the density expression) against the reference's own
+    NeighborhoodBasedMappingFeatures._process output (tests/golden/neighborhood.npz, written by oracle/gen_golden.py
+    from core/data_transform/multimodal/image.py:482-612 with a brute-force argKmin in place of KeOps).
+    'dup' holds every point twice: zero distances, ties broken towards the lower index on both sides."""
+    from deepviewagg_amd.core.multimodal.image import ImageMapping
+    from deepviewagg_amd.core.data_transform.multimodal.image import NeighborhoodBasedMappingFeatures
+    g = load_golden("neighborhood")
+    k_list = [int(k) for k in g["k_list"]]
+    xyz = t(g[f"{tag}_xyz"])
+    n = xyz.shape[0]
+    m = ImageMapping.from_dense(t(g[f"{tag}_point_ids"], DEV), t(g[f"{tag}_image_ids"], DEV),
+                                t(g[f"{tag}_pixels"], DEV), t(g[f"{tag}_features_in"], DEV), num_points=n)
+    assert torch.equal(m.pointers.cpu(), t(g[f"{tag}_pointers"])) and torch.equal(m.images.cpu(), t(g[f"{tag}_images"]))
+
+    class D:
+        pos = xyz
+        num_nodes = n
+
+    class I:
+        mappings = m
+        device = torch.device(DEV)
+
+    NeighborhoodBasedMappingFeatures(k=list(reversed(k_list)), voxel=float(g["voxel"]))(D, I)
+    got, ref = I.mappings.features.cpu(), t(g[f"{tag}_features_out"])
+    assert got.shape == ref.shape
+    assert torch.equal(got[:, :3], ref[:, :3])                                    # the features that were there
+    torch.testing.assert_close(got[:, 3:5], ref[:, 3:5], rtol=1e-6, atol=0)       # densities
+    assert torch.equal(got[:, 5:], ref[:, 5:])                                    # occlusions

@@ -164,3 +164,19 @@ def test_gather_multipixel_atomic_max():
     out = O.gather_nearest(t(g["x"]), images_per_atom(g), t(g["pixels"]), float(g["downscale"]))
     assert torch.equal(out, t(g["out_nearest"]))
     close(O.segment_csr(out, t(g["atom_pointers"]), "max"), g["out_atomic_max"])
+
+
+@pytest.mark.parametrize("tag", ["surf", "dup"])
+def test_knn_oracle_matches_reference_neighborhood_features(tag):
+    """oracle/knn_oracle.py against the reference's own NeighborhoodBasedMappingFeatures._process
+    (core/data_transform/multimodal/image.py:482-612; fixture written by oracle/gen_golden.py neighborhood through the
+    KeOps branch with a brute-force argKmin): pins density + occlusion (mapping features 7-8)."""
+    from oracle import knn_oracle as KO
+    g = load_golden("neighborhood")
+    k_list = [int(k) for k in g["k_list"]]
+    xyz = g[f"{tag}_xyz"]
+    nbr, _ = KO.knn_bruteforce(xyz, k_list[-1])
+    got = KO.neighborhood_features(xyz, g[f"{tag}_pointers"], g[f"{tag}_images"], nbr, k_list, voxel=float(g["voxel"]))
+    ref = t(g[f"{tag}_features_out"])[:, 3:]
+    torch.testing.assert_close(got[:, :2], ref[:, :2], rtol=1e-6, atol=0)        # densities (inf for zero radii: equal)
+    assert torch.equal(got[:, 2:], ref[:, 2:])                                    # occlusions: counts / (k + 1)
