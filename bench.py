@@ -469,6 +469,14 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL really spans `world` ranks, one per device: all-gather of (rank, device ordinal) -- checked in-process
+        assert dist.get_world_size() == world and dist.get_backend() == "nccl"
+        who = torch.tensor([rank, local_rank], device=device, dtype=torch.int64)
+        gathered = [torch.empty_like(who) for _ in range(world)]
+        dist.all_gather(gathered, who)
+        ranks_devices = [tuple(int(v) for v in g.tolist()) for g in gathered]
+        assert sorted(r for r, _ in ranks_devices) == list(range(world)), ranks_devices
+        assert len({d for _, d in ranks_devices}) == world, f"ranks share a device: {ranks_devices}"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     from deepviewagg_amd import ops, _lib
@@ -519,7 +527,27 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    collective = None
     if use_dist:
+        # what the collectives of the LAST step cost: duration on the side stream, and the part the main stream had to
+        # wait for in finish() (0 = fully hidden under the backward)
+        t_standin = standin.timings() if standin is not None else None
+        t_pool = bucket.timings()
+        mine = torch.tensor([elapsed / args.steps * 1e3,
+                             t_standin[0] if t_standin else 0.0, t_standin[1] if t_standin else 0.0,
+                             t_pool[0] if t_pool else 0.0, t_pool[1] if t_pool else 0.0],
+                            device=device, dtype=torch.float64)
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank = torch.stack(per_rank).cpu()
+        collective = {"per_rank_ms_per_step": [float(v) for v in per_rank[:, 0]],
+                      "standin_allreduce_ms": [float(v) for v in per_rank[:, 1]],
+                      "standin_exposed_ms": [float(v) for v in per_rank[:, 2]],
+                      "pooling_bucket_allreduce_ms": [float(v) for v in per_rank[:, 3]],
+                      "pooling_bucket_exposed_ms": [float(v) for v in per_rank[:, 4]],
+                      "ranks_devices": ranks_devices,
+                      "note": "last timed step; allreduce_ms = copy-in + RCCL all-reduce on the side stream (HIP events), "
+                              "exposed_ms = how long the main stream was blocked in finish() waiting for it"}
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -575,6 +603,11 @@ def main():
             "fused_abs_mean": float(fused.float().abs().mean().item()),
         }
         res["step_algorithmic_GBps"] = res["step_algorithmic_GB"] / (ms_per_step * 1e-3)
+        if collective is not None:
+            res["allreduce_ms"] = max(collective["standin_allreduce_ms"])
+            res["exposed_ms"] = max(a + b for a, b in zip(collective["standin_exposed_ms"],
+                                                          collective["pooling_bucket_exposed_ms"]))
+            res["collective"] = collective
         # practical ceiling next to the nominal one: the float4 copy kernel in this process
         res["hbm_copy_GBps"] = copy_ceiling(device)
         res["roofline"]["copy_ceiling"] = res["hbm_copy_GBps"]

@@ -229,10 +229,12 @@ class ImageMapping(CSRData):
         if ratio == 1:
             return out
         pix = out.pixels
-        new = (pix * ratio).long()
+        # one expression, like the reference (image.py:2013-2014): (pix.float() * ratio + ratio / 2).long() -- rounding
+        # pix * ratio first differs for non-integer ratios
+        new = pix.float() * ratio
         if center:
-            new = (new + ratio / 2).long()
-        out.pixels = new.type(pix.dtype)
+            new = new + ratio / 2
+        out.pixels = new.long().type(pix.dtype)
         return out
 
     def select_images(self, idx):

@@ -363,12 +363,15 @@ __device__ __forceinline__ void act_fold(const f32x16& t, uint32_t keep, bf16x8 
 }
 
 // ---- statistics ------------------------------------------------------------------------------------------------
-// per-lane fp32 partial sums of the 16 accumulator channels -> per block in LDS -> fp64 atomics
+// per-lane fp32 partial sums of the 16 accumulator channels -> per wavefront (shuffles) -> per block in a FIXED order
+// (one LDS slot per wavefront, summed in fp64: no LDS float atomics, whose order would vary from run to run and
+// move the fp32 BatchNorm constants by an ulp -- enough to change bf16 roundings downstream) -> fp64 atomics (their
+// order varies, at 1e-16: the statistics are reproducible after rounding to fp32, and with them the whole forward).
+// s_red: 4 * NV * D floats (blocks of 4 wavefronts).
+constexpr int STATS_RED_FLOATS = 4 * 3 * D;
 template <int NV>
 __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restrict__ out, float* s_red) {
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  __syncthreads();
-  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) s_red[i] = 0.f;
+  const int lane = threadIdx.x & 63, h = lane >> 5, wv = threadIdx.x >> 6;
   __syncthreads();
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
@@ -377,11 +380,16 @@ __device__ __forceinline__ void flush_stats(float (&st)[NV][16], double* __restr
       float v = st[n][r];
 #pragma unroll
       for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
-      if ((lane & 31) == 0) atomicAdd(&s_red[n * D + chan(r, h)], v);
+      if ((lane & 31) == 0) s_red[wv * (NV * D) + n * D + chan(r, h)] = v;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) atomicAdd(&out[i], (double)s_red[i]);
+  const int n_waves = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) {
+    double acc = 0.0;
+    for (int w = 0; w < n_waves; ++w) acc += (double)s_red[w * (NV * D) + i];
+    atomicAdd(&out[i], acc);
+  }
 }
 
 // transposed bf16 tile [channel][view], row stride 40 (80 bytes): the 8 consecutive views a lane feeds to the

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void tile_offsets_kernel(const int32_t* __res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x_map, int64_t V,
                                                       double* __restrict__ mom /* 8 + 36 */) {
-  __shared__ float s_red[44];
+  __shared__ float s_red[4][44];      // one slot per wavefront, summed in a fixed order (see flush_stats)
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32);
   float s1[8], s2[36];
 #pragma unroll
@@ -227,18 +227,18 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
       for (int jj = i; jj < 8; ++jj, ++k) s2[k] = __builtin_fmaf(x[i], x[jj], s2[k]);
     }
   }
-  if (threadIdx.x < 44) s_red[threadIdx.x] = 0.f;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 44; ++i) {
     float v = i < 8 ? s1[i] : s2[i - 8];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    if (lane == 0) atomicAdd(&s_red[i], v);
+    if (lane == 0) s_red[wv][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 44) atomicAdd(&mom[threadIdx.x], (double)s_red[threadIdx.x]);
+  if (threadIdx.x < 44)
+    atomicAdd(&mom[threadIdx.x], (((double)s_red[0][threadIdx.x] + (double)s_red[1][threadIdx.x]) +
+                                  (double)s_red[2][threadIdx.x]) + (double)s_red[3][threadIdx.x]);
 }
 
 // statistics of z1 = bf16(W1) x from the moments: stats = sum z1 | sum z1^2 (the form dva_bn_finalize takes)
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void stats2_kernel(
     int32_t* __restrict__ arg, int64_t V) {
   __shared__ __attribute__((aligned(16))) float s_tab[TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float s_tile[4][32 * TZ];
-  __shared__ float s_red[3 * D];
+  __shared__ float s_red[STATS_RED_FLOATS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   stage_tab(s_tab, bn1, nullptr);
   __syncthreads();
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 3) void stats_mid_kernel(
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     double* __restrict__ stats, int64_t V, int64_t N) {
   __shared__ __attribute__((aligned(16))) float s_tab[3][TAB_FLOATS];
-  __shared__ float s_red[3 * D];
+  __shared__ float s_red[STATS_RED_FLOATS];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, nullptr);

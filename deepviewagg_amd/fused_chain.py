@@ -37,7 +37,9 @@ def applicable(module, x_mod, x_map, csr_idx=None):
         return False
     if not isinstance(x_mod, ops.GatheredFeatures) or x_mod.rows.dtype != torch.bfloat16:
         return False
-    if not fused_deepset.applicable(module.E_map, module.E_score, x_map):
+    if not fused_deepset.applicable(module.E_map, module.E_score, x_map):        # incl. fp32 parameters / buffers
+        return False
+    if module.G is not None and any(t is not None and t.dtype != torch.float32 for t in (module.G.weight, module.G.bias)):
         return False
     C, G = module.out_mod, module.num_groups
     if C not in (32, 64, 128, 256, 512) or G not in (1, 2, 4) or C % G or (C // G) % 8:

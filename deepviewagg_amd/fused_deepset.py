@@ -65,6 +65,12 @@ def applicable(e_map, linear, x_map):
                 return False
             if bn.training != e_map.training:
                 return False  # individually frozen BatchNorm layers: the generic path honours bn.training
+            # the kernels read the parameters and running statistics through raw fp32 pointers
+            if any(t.dtype != torch.float32 for t in (block[0].weight, bn.weight, bn.bias, bn.running_mean,
+                                                      bn.running_var)):
+                return False
+    if linear.weight.dtype != torch.float32 or linear.bias.dtype != torch.float32:
+        return False
     return True
 
 

@@ -44,7 +44,11 @@ def batchnorm_act_rows(y, bn, slope, counts=None, n=None):
     slope 1 = no activation).  ``counts`` weights the batch statistics (row r stands for counts[r] gathered
     rows, ``n`` of them in total); running statistics are updated as ``nn.BatchNorm1d`` does."""
     batch_stats = bn.training or not bn.track_running_stats
-    if bn.momentum is not None and y.is_cuda:
+    # the one-launch path hands raw fp32 pointers of the module's parameters / buffers to the kernels: anything else
+    # (a module cast with .half() / .bfloat16()) takes the generic branch below
+    f32 = all(t is None or t.dtype == torch.float32
+              for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    if bn.momentum is not None and y.is_cuda and f32:
         # statistics -> constants (+ running statistics) in one launch
         n = (float(y.shape[0]) if n is None else float(n)) if batch_stats else 1.0
         sums = ops.rowbn_sums(y, counts) if batch_stats else None

@@ -782,7 +782,8 @@ class _RowBNAct(torch.autograd.Function):
             check(lib.dva_rowbn_apply(ptr(y), ptr(bn), ptr(out), R, C, float(slope), dtype_code(y),
                                       stream_of(y)), "dva_rowbn_apply")
         ctx.save_for_backward(y, bn, *([counts] if counts is not None else []))
-        ctx.meta = (float(n), bool(batch_stats), float(slope), gamma is not None, beta is not None)
+        # the same clamped normaliser as the forward's statistics (bn_table): a sample without views has n = 0
+        ctx.meta = (max(float(n), 1.0), bool(batch_stats), float(slope), gamma is not None, beta is not None)
         return out
 
     @staticmethod

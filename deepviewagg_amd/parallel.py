@@ -40,7 +40,21 @@ def shard_mapping(csr_idx, tile_points):
 
 
 class GradientBucket:
-    """Bucketed data-parallel gradient all-reduce (sum or mean) of a parameter list."""
+    """Bucketed data-parallel gradient all-reduce (sum or mean) of a parameter list.
+
+    Contract between ``start()`` and ``finish()``: the gradients of the bucket's parameters belong to the side
+    stream.  ``start()`` reads ``p.grad`` there (and, for a single contiguous fp32 gradient, all-reduces ``p.grad``
+    itself in place), so NOTHING on the main stream may write or read these gradients until ``finish()`` has
+    returned: no gradient accumulation into them (a second backward), no ``zero_grad``, no clipping, no optimizer
+    step.  Call ``start()`` only after the backward that produces the bucket's gradients has been enqueued (autograd
+    hooks that fire later would race with the collective); ``finish()`` makes the main stream wait for the side
+    stream before it hands the gradients back.  The timing events of the last ``start()`` / ``finish()`` pair are
+    kept (``timings()``): duration of the collective on the side stream and the part of it the main stream had to
+    wait for.
+
+    BatchNorm: the recompute chain's batch statistics (fp64 sums per layer) stay per process, like the reference's
+    plain ``BatchNorm1d``: with dp > 1 every rank normalises with the statistics of its own
+    tile; only the parameter gradients are summed."""
 
     def __init__(self, params, process_group=None, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
@@ -57,6 +71,7 @@ class GradientBucket:
         self._inplace = False
         self._scale = False
         self._buf = self.flat
+        self._ev = None        # (collective start, collective end, main-stream wait start, wait end) of the last pair
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -77,7 +92,12 @@ class GradientBucket:
         # mean inside the collective where the backend has it (RCCL): no separate scaling pass over the bucket
         avg_op = average and dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM
+        ev = None
+        if self.stream is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         with ctx:
+            if ev is not None:
+                ev[0].record()
             # a single contiguous fp32 gradient is reduced where it lies (what DDP's gradient-as-bucket-view gives
             # every parameter): no flatten / unflatten copies
             g0 = self.params[0].grad if len(self.params) == 1 else None
@@ -103,13 +123,30 @@ class GradientBucket:
                     hnd.wait()               # orders the collective inside the side stream, does not block the host
                 if self._scale:
                     buf.div_(world)
+                ev[1].record()
+        self._ev = ev
+
+    def timings(self):
+        """(collective_ms, exposed_ms) of the last start() / finish() pair on a HIP device (synchronises), else None:
+        the time the bucket's copy-in + all-reduce took on the side stream, and how long the main stream was blocked
+        in finish() waiting for it (0 when the collective was fully hidden under the work enqueued in between)."""
+        if self._ev is None or self.stream is None:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        e = self._ev
+        return e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
 
     def finish(self):
         """Wait for the all-reduces and write the reduced gradients back into ``p.grad``."""
         if not (dist.is_available() and dist.is_initialized()) or self._handles is None:
             return
         if self.stream is not None:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+            main = torch.cuda.current_stream(self.flat.device)
+            if self._ev is not None:
+                self._ev[2].record(main)
+            main.wait_stream(self.stream)
+            if self._ev is not None:
+                self._ev[3].record(main)
         else:
             for hnd in self._handles:
                 hnd.wait()
