@@ -49,6 +49,13 @@ def parse():
                     help="diagnostic: materialised [V, C] gather + per-view E_mod (the reference's dataflow) instead "
                          "of the lazy gather / hoisted E_mod")
     ap.add_argument("--no-secondary", action="store_true", help="skip the S2 / F-L secondary workloads")
+    ap.add_argument("--interpolate", action="store_true",
+                    help="bilinear gather (interpolate=True, the published KITTI-360 configuration): mapping at 8x the "
+                         "feature-map resolution, E_mod per view inside the chain kernels (fused_bilinear); with "
+                         "--materialize: the reference's [V, C] dataflow")
+    ap.add_argument("--out-channels", type=int, default=None,
+                    help="out_mod of GroupBimodalCSRPool (default: --channels); the KITTI-360 pair is --channels 128 "
+                         "--out-channels 32")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE scene of 2^log2-points points split into WORLD_SIZE spatial tiles "
                          "(parallel.tile_partition), each rank pools its tile (default: one scene per rank = weak)")
@@ -62,7 +69,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed, workload="S1"):
+def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed, workload="S1", upscale=1):
     """Synthetic scene of SURVEY.md §8(d).  S1: every point seen by `views` images at random pixels;
     S2: ragged view counts k_i = min(views, 1 + Geom(0.2)), 10 % of the points unseen.
     S1c (not in the survey; a locality probe): S1 with projection-like pixels -- the points lie on a raster in
@@ -99,21 +106,23 @@ def make_scene(n_points, views, n_images, C, H, W, dtype, device, seed, workload
         pixels = torch.stack([(u * W // side + shift[:, 0] + jit[:, 0]) % W,
                               (v * H // side + shift[:, 1] + jit[:, 1]) % H], 1).to(torch.int16)
     else:
-        pixels = torch.stack([torch.randint(0, W, (V,), generator=g, device=device),
-                              torch.randint(0, H, (V,), generator=g, device=device)], 1).to(torch.int16)
+        # upscale > 1 (bilinear workload): the mapping lives at upscale x the feature-map resolution
+        pixels = torch.stack([torch.randint(0, W * upscale, (V,), generator=g, device=device),
+                              torch.randint(0, H * upscale, (V,), generator=g, device=device)], 1).to(torch.int16)
     atom_ptr = torch.arange(V + 1, dtype=torch.int64, device=device)  # exact mapping: 1 pixel/view
     x = torch.randn(n_images, C, H, W, generator=g, device=device).to(dtype)
     x = x.contiguous(memory_format=torch.channels_last)
     x_map = torch.rand(V, 8, generator=g, device=device)
     x_3d = torch.randn(n_points, 4, generator=g, device=device)
-    return dict(csr=csr, images=images.long(), pixels=pixels, atom_ptr=atom_ptr, x=x, x_map=x_map, x_3d=x_3d)
+    return dict(csr=csr, images=images.long(), pixels=pixels, atom_ptr=atom_ptr, x=x, x_map=x_map, x_3d=x_3d,
+                mapping_size=(W * upscale, H * upscale))
 
 
-def build_modules(C, device):
+def build_modules(C, device, C_out=None):
     from deepviewagg_amd.modules.multimodal.pooling import BimodalCSRPool, GroupBimodalCSRPool
     from deepviewagg_amd.modules.multimodal.fusion import BimodalFusion
     torch.manual_seed(0)
-    view_pool = GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=4, use_mod=False,
+    view_pool = GroupBimodalCSRPool(in_map=8, in_mod=C, out_mod=C_out, num_groups=4, use_mod=False,
                                     map_encoder='DeepSetFeat', use_num=True).to(device).train()
     return BimodalCSRPool(mode='max'), view_pool, BimodalFusion(mode='concatenation')
 
@@ -155,7 +164,7 @@ def pmc_traffic(timer_name, default_workload):
     return None if entry is None else entry["hbm_bytes"]
 
 
-def step(scene, packed, mods, dtype, lazy=True, before_backward=None):
+def step(scene, packed, mods, dtype, lazy=True, before_backward=None, interpolate=False):
     """One fused forward + backward of the hot path (metric M1 of SURVEY.md 8(d): gather -> atomic pool -> view
     attention pool -> fusion-concat).  The backward is seeded with a fixed upstream gradient [N, 4 + C] resident in
     HBM -- what the 3D backbone hands back -- so that no loss kernels sit inside the timed region.  Returns the
@@ -173,7 +182,13 @@ def step(scene, packed, mods, dtype, lazy=True, before_backward=None):
         # nearest gather, lazy: E_mod then runs on the map rows and the gather is fused into the attention kernel
         # (DESIGN.md "E_mod hoisting")
         exact = scene["pixels"].shape[0] == scene["x_map"].shape[0]
-        if lazy:
+        if interpolate:
+            # bilinear gather (image.py:1278-1283): coords = pixels / (mapping_size - 1) in (row, col) order
+            packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
+            res = torch.tensor([scene["mapping_size"]], dtype=torch.float32, device=x.device)
+            coords = (scene["pixels"] / (res - 1))[:, [1, 0]]
+            x_mod = ops.lazy_gather_bilinear(x, packed, coords, exact) if lazy else ops.gather_bilinear(x, packed, coords)
+        elif lazy:
             x_mod = ops.lazy_gather_nearest_mapping(x, scene["images"], scene["atom_ptr"], scene["pixels"], 1.0,
                                                     exact=exact)
         else:
@@ -341,16 +356,16 @@ def gather_bench(scene, reps=5):
     return {"GBps": nbytes / (ms * 1e-3) / 1e9, "ms": ms, "atoms": P, "bytes": nbytes}
 
 
-def timed_steps(scene, mods, dtype, steps, warmup, lazy=True):
+def timed_steps(scene, mods, dtype, steps, warmup, lazy=True, interpolate=False):
     """`steps` timed steps of one workload on the current device (secondary workloads; no collectives)."""
     from deepviewagg_amd import ops
     for _ in range(warmup):
-        step(scene, None, mods, dtype, lazy=lazy)
+        step(scene, None, mods, dtype, lazy=lazy, interpolate=interpolate)
     torch.cuda.synchronize()
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(scene, None, mods, dtype, lazy=lazy)
+        step(scene, None, mods, dtype, lazy=lazy, interpolate=interpolate)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     timer, ops.TIMER = ops.TIMER, None
@@ -488,10 +503,11 @@ def main():
         scene = tile_of_scene(make_scene(N, views, 32, C, H, W, dtype, device, seed=1234, workload=args.workload),
                               rank, world)
     else:
-        scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank, workload=args.workload)
+        scene = make_scene(N, views, 32, C, H, W, dtype, device, seed=1234 + rank, workload=args.workload,
+                           upscale=8 if args.interpolate else 1)
     V_scene = int(scene["x_map"].shape[0])
     N_rank = int(scene["csr"].shape[0] - 1)
-    mods = build_modules(C, device)
+    mods = build_modules(C, device, args.out_channels)
     from deepviewagg_amd.parallel import GradientBucket
     bucket = GradientBucket(mods[1].parameters())
     # stand-in for the gradients of the model parts outside the path (2D encoder, 3D backbone): all-reduced on a
@@ -510,7 +526,7 @@ def main():
         torch.cuda.synchronize()
 
     def one_step():
-        fused = step(scene, None, mods, dtype, lazy=not args.materialize,
+        fused = step(scene, None, mods, dtype, lazy=not args.materialize, interpolate=args.interpolate,
                      before_backward=(lambda: standin.start(average=True)) if standin is not None else None)
         bucket.reduce(average=True)
         if standin is not None:
@@ -564,7 +580,7 @@ def main():
         achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
         default_workload = (args.log2_points == 20 and args.dtype == "bf16" and args.workload == "S1"
                             and args.channels == 64 and args.views == 32 and not args.materialize
-                            and not args.strong)
+                            and not args.strong and not args.interpolate and args.out_channels is None)
         traffic = pmc_traffic(name, default_workload)
         chain = "chain_attn_fwd" in kern
         res = {
@@ -575,8 +591,10 @@ def main():
             "config": {"workload": f"{args.workload}/F-S: N=2^{args.log2_points} points x "
                                    f"{views if args.workload != 'S2' else 'ragged <= ' + str(views)} views (V={V_scene}"
                                    f"{' on this rank' if args.strong else ''}), "
-                                   f"32 feature maps [{C},{H},{W}] {args.dtype} channels-last, nearest gather -> "
-                                   f"max atomic pool -> GroupBimodalCSRPool(G=4, DeepSetFeat, train) -> concat; backward seeded "
+                                   f"32 feature maps [{C},{H},{W}] {args.dtype} channels-last, "
+                                   + ("bilinear gather (mapping at 8x the map resolution), E_mod "
+                                      f"{C}->{args.out_channels or C} per view -> " if args.interpolate else "nearest gather -> ")
+                                   + f"max atomic pool -> GroupBimodalCSRPool(G=4, DeepSetFeat, train) -> concat; backward seeded "
                                    f"with a fixed upstream gradient [N, 4+C]; "
                                    + ("one scene split into WORLD_SIZE spatial tiles" if args.strong else "one scene per GPU"),
                        "points_per_gpu": N_rank, "views_per_point": views, "parallelism": f"dp{world}",

@@ -734,6 +734,9 @@ class SameSettingImageData:
             resolution = torch.tensor([self.mapping_size], dtype=torch.float32, device=dev)
             coords = (self.mappings.pixels / (resolution - 1))[:, [1, 0]]
             packed = self.mappings.packed_gather_index(ratio=1.0)
+            if lazy and self.mappings.is_exact:
+                # one pixel per view: the taps are kept, no [P, C] tensor (fused_bilinear through GroupBimodalCSRPool)
+                return ops.lazy_gather_bilinear(self.x, packed, coords, exact=True)
             return ops.gather_bilinear(self.x, packed, coords)
         if self.downscale < 1:
             # feature map larger than the mapping resolution: the reference goes through

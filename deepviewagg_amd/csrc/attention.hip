@@ -1141,6 +1141,79 @@ __global__ __launch_bounds__(256) void rows_sum_team_kernel(const T* __restrict_
   }
 }
 
+// Backward of the bilinear gather over the ANCHOR plan (views grouped by the padded cell of their top-left tap):
+// S[a][k][:] = sum over the views v of anchor a of weights[v][k] * gout[v, :]  for the four taps k -- every view row
+// is read ONCE (the plan over the 4 V tap entries reads it four times and sorts four times as many keys); the map
+// gradient follows from S by dva_anchor_combine.  Deterministic, no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restrict__ gout,
+                                                               const int32_t* __restrict__ perm,
+                                                               const int32_t* __restrict__ row_ptr,
+                                                               const float4* __restrict__ weights,
+                                                               float* __restrict__ S, int64_t R, int C, int lpr) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int U = 2;
+  typedef typename Vec16<T>::raw raw_t;
+  const int lane = threadIdx.x & 63;
+  const int lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
+  const int64_t col = (int64_t)lane_r * VEC;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < R; r += n_waves) {
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    float acc[4][VEC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[k][e] = 0.f;
+    }
+    for (int i0 = beg; i0 < end; i0 += slots * U) {
+      int v[U];
+      bool ok[U];
+      raw_t raw[U];
+      float4 wu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * slots + slot;
+        ok[u] = i < end;
+        v[u] = perm[ok[u] ? i : beg];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)v[u] * C + col);
+        wu[u] = ok[u] ? weights[v[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[VEC];
+        Vec16<T>::unpack(raw[u], f);
+        const float ww[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[k][e] = fmaf(ww[k], f[e], acc[k][e]);
+        }
+      }
+    }
+    for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[k][e] += __shfl_xor(acc[k][e], off);
+      }
+    }
+    if (slot == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float* dst = S + (r * 4 + k) * C + col;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4)
+          *reinterpret_cast<float4*>(dst + e) = make_float4(acc[k][e], acc[k][e + 1], acc[k][e + 2], acc[k][e + 3]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rows_sum_generic_kernel(const T* __restrict__ gout,
                                                                 const int32_t* __restrict__ perm,
@@ -1343,6 +1416,29 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
   else
     return DVA_ERR_INVALID;
   if (rc) return rc;
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_anchor_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, const float* weights,
+                        float* S, int64_t n_anchors, int64_t n_views, int32_t C, int32_t dtype, void* stream) {
+  if (n_anchors < 0 || n_views < 0 || C <= 0) return DVA_ERR_INVALID;
+  if (n_anchors == 0) return DVA_OK;
+  if (!row_ptr || !S || (n_views > 0 && (!grad_out || !perm || !weights))) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DVA_BF16) {
+    const int lpr = C / 8;
+    if ((C % 8) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)grad_out % 16) || ((uintptr_t)S % 16)) return DVA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
+                       (const bf16_t*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr);
+  } else if (dtype == DVA_F32) {
+    const int lpr = C / 4;
+    if ((C % 4) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)grad_out % 16) || ((uintptr_t)S % 16)) return DVA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<float>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
+                       (const float*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr);
+  } else {
+    return DVA_ERR_INVALID;
+  }
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
     if (STAGE == 6) {
-      p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+      // (the score gradients are loaded in the body: they are consumed late, and 2 x 4 prefetch registers spilled)
     } else {
       p.dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB);
       p.dhi = ld128(DI, ok ? view * 64u + 32u * h + 16u : OOB);
@@ -566,6 +566,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     bf16x8 dzp[2];
     if constexpr (STAGE == 6) {
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
+      const float4 dcv = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
       // forward up to a5 (layers 1, 2 folded, layer 5 plain); z5 stays for the statistics of layer 5
       bf16x8 a5[2];
       f32x16 z5;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         act_pack(z5, s_tab[2], h, keep, a5);
       }
       tileT_put_packed(tb_, j, h, a5);
-      const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};
+      const float dc4[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
       {
         // dy6 = leaky'(t6) Ws^T dc with the sign the forward's activation saw (the folded product), one 16-register
         // block at a time: t6, then the raw z6 for the BatchNorm backward
@@ -943,9 +944,8 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
                      grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, \
                      n_views, n_points)
-  static const int occ5 = tune_int("DVA_STAGE5_OCC", 2);
+  // stage 5 at two wavefronts per SIMD: with the 168 registers of three it spills 13 and runs 2.13 instead of 1.46 ms
   if (stage == 6) DVA_LAYER_BWD(6, 3);
-  else if (stage == 5 && occ5 == 3) DVA_LAYER_BWD(5, 3);
   else if (stage == 5) DVA_LAYER_BWD(5, 2);
   else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD

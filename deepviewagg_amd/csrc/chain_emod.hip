@@ -1,0 +1,1226 @@
+// Recompute chain with a PER-VIEW E_mod: the fused path of the bilinear gather (`interpolate=True`: the published
+// KITTI-360 configuration, conf/models/segmentation/multimodal/sparseconv3d.yaml:7269-7340).
+//
+// Reference dataflow (core/multimodal/image.py:105-170 sparse_interpolation, modules/multimodal/modules.py:400,
+// modules/multimodal/pooling.py:263-315): x_interp[v] = sum of 4 bilinear taps of the feature map, then
+// E_mod = [Linear_a, BatchNorm_a, LeakyReLU, Linear_b, BatchNorm_b, LeakyReLU] PER VIEW, then the view attention.  E_mod
+// cannot be hoisted to the map rows as with the nearest gather (BatchNorm + LeakyReLU do not commute with the
+// interpolation) -- but its first Linear can: interp(x) W_a^T = interp(x W_a^T).  So Y = x W_a^T is one GEMM on the
+// R map rows (host side), and per view remains: 4 taps of Y (C_o channels, bf16) -> z_a -> BatchNorm_a -> LeakyReLU ->
+// Linear_b (C_o x C_o on the matrix cores, in registers) -> BatchNorm_b -> LeakyReLU -> value of the view, consumed
+// by the softmax-weighted sum in the same kernel.  No [V, C] tensor exists in the forward.  Train-mode BatchNorm
+// adds one statistics pass per layer, the backward one pass per BatchNorm barrier, exactly as for the DeepSetFeat
+// chain (chain_fwd.hip / chain_bwd.hip, whose kernels evaluate the scores here as there):
+//   dva_emod_prep        weight operands of Linear_b (bf16, MFMA k-slot order)
+//   dva_emod_stats       layer 1: sum z_a | sum z_a^2;  layer 2: sum z_b | sum z_b^2
+//   dva_emod_attn_fwd    x_map + taps of Y -> pooled features (DeepSetFeat scores, softmax, E_mod, weighted sum, gate)
+//   dva_emod_attn_bwd    attention + gate backward from the stored scores: score gradients, view records, S of BatchNorm_b
+//   dva_emod_bwd         stage 2: dW_b, dy_a = leaky'(y_a) W_b^T dz_b handed over as bf16 [V, C_o], S of BatchNorm_a
+//                        stage 1: dz_a in place -> the weighted scatter over the row plan (dva_gather_rows_sum) gives dY
+// Data layout: Y bf16 [R][C_o] in POSITION order: position 32 b + 16 h + r holds channel 32 b + chan(r, h), so that the
+// 16 channels lane (view, h) owns of a 32-channel block are 32 contiguous bytes and land in the registers in the
+// accumulator / B-operand order of chain_common.h.  The handed-over gradient [V][C_o] uses the same order.
+// Two orientations of Linear_b: "standard" D[out channel][view] (lane = view: chains into further products) and
+// "flipped" D[view][out channel] (the same operands in swapped roles: lane = channel, registers = views), in which
+// BatchNorm constants are per-lane scalars and a reduction over the views of a point is in-lane arithmetic.
+#include "chain_common.h"
+
+namespace dva {
+namespace emod {
+using namespace dva::chain;
+
+// view of accumulator register r in the lane half h of a flipped product
+__device__ __forceinline__ int view_of(int r, int h) { return chan(r, h); }
+
+// ---- operands of Linear_b --------------------------------------------------------------------------------------
+// FWD(mb, b, m): lane (rho, hh), slot s = W_b[32 mb + rho][32 b + chan(8 m + s, hh)]
+// BWD(b, mb, m): lane (rho, hh), slot s = W_b[32 mb + chan(8 m + s, hh)][32 b + rho]
+template <int NB> __host__ __device__ constexpr int op_fwd(int mb, int b, int m) { return (mb * NB + b) * 2 + m; }
+template <int NB> __host__ __device__ constexpr int op_bwd(int b, int mb, int m) { return NB * NB * 2 + (b * NB + mb) * 2 + m; }
+
+__global__ __launch_bounds__(64) void emod_prep_kernel(const float* __restrict__ Wb, int CO, uint4* __restrict__ ops) {
+  const int NB = CO / 32;
+  const int blk = blockIdx.x, lane = threadIdx.x, rho = lane & 31, hh = lane >> 5;
+  const bool bwd = blk >= NB * NB * 2;
+  const int i = bwd ? blk - NB * NB * 2 : blk;
+  const int m = i & 1, x1 = (i >> 1) % NB, x0 = (i >> 1) / NB;     // fwd: (mb, b) = (x0, x1); bwd: (b, mb) = (x0, x1)
+  float w[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int c = chan(8 * m + s, hh);
+    w[s] = bwd ? Wb[(32 * x1 + c) * CO + 32 * x0 + rho] : Wb[(32 * x0 + rho) * CO + 32 * x1 + c];
+  }
+  ops[blk * 64 + lane] = __builtin_bit_cast(uint4, pack8(w));
+}
+
+// ---- BatchNorm tables ---------------------------------------------------------------------------------------------
+// bn fp32 [4][CO] = mean | invstd | gamma | beta (dva_bn_finalize), natural channel order; sm fp32 [2][CO] = S1/M | S2/M.
+// Table of the 32-channel block c0 in the accumulator-permuted order of chain_common.h (index 16 h + r <-> channel
+// c0 + chan(r, h)), rows as there (T_G .. T_B6).
+__device__ __forceinline__ void stage_tab_c(float* tab, const float* __restrict__ bn, int CO, int c0,
+                                            const float* __restrict__ sm) {
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const int c = c0 + chan(i & 15, i >> 4);
+    const float mean = bn[c], inv = bn[CO + c], gam = bn[2 * CO + c], bet = bn[3 * CO + c];
+    const float g = gam * inv;
+    tab[T_G * D + i] = g;
+    tab[T_B * D + i] = bet - mean * g;
+    tab[T_I * D + i] = inv;
+    tab[T_M * D + i] = -mean * inv;
+    const float s1 = sm ? sm[c] : 0.f, s2 = sm ? sm[CO + c] : 0.f;
+    tab[T_K1 * D + i] = g * (s1 - mean * inv * s2);
+    tab[T_K2 * D + i] = g * inv * s2;
+    tab[T_G6 * D + i] = 0.6f * g;
+    tab[T_B6 * D + i] = 0.6f * (bet - mean * g);
+  }
+}
+
+// ---- taps ---------------------------------------------------------------------------------------------------------
+struct TapRec {
+  int4 rows;
+  float4 w;
+};
+// the 16 channels of block b this lane owns, for the 4 taps of its view: 4 x 2 x 16 bytes
+template <int CO>
+__device__ __forceinline__ void load_taps(__amdgpu_buffer_rsrc_t Y, const TapRec& t, bool ok, int b, int h,
+                                          u32x4 (&x)[4][2]) {
+  const int rr[4] = {t.rows.x, t.rows.y, t.rows.z, t.rows.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t off = ok ? (uint32_t)rr[k] * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+    x[k][0] = ld128(Y, off);
+    x[k][1] = ld128(Y, ok ? off + 16u : OOB);
+  }
+}
+__device__ __forceinline__ void interp16(const u32x4 (&x)[4][2], const float4& w, f32x16& z) {
+  const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t v[4] = {x[k][q].x, x[k][q].y, x[k][q].z, x[k][q].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        z[8 * q + 2 * i] = __builtin_fmaf(ww[k], __uint_as_float(v[i] << 16), z[8 * q + 2 * i]);
+        z[8 * q + 2 * i + 1] = __builtin_fmaf(ww[k], __uint_as_float(v[i] & 0xffff0000u), z[8 * q + 2 * i + 1]);
+      }
+    }
+  }
+}
+// z_a of every block of the view (taps of one block in flight at a time: 32 registers)
+template <int CO>
+__device__ __forceinline__ void eval_za(__amdgpu_buffer_rsrc_t Y, const TapRec& t, bool ok, int h,
+                                        f32x16 (&za)[CO / 32]) {
+#pragma unroll
+  for (int b = 0; b < CO / 32; ++b) {
+    u32x4 x[4][2];
+    load_taps<CO>(Y, t, ok, b, h, x);
+    interp16(x, t.w, za[b]);
+  }
+}
+// Linear_b, flipped: zb[mb][r] = z_b[view_of(r, h)][channel 32 mb + (lane & 31)]
+template <int NB>
+__device__ __forceinline__ void linear_b_flipped(const uint4* s_eops, int lane, const bf16x8 (&a)[NB][2],
+                                                 f32x16 (&zb)[NB]) {
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc = CH_MFMA(a[b][m], lds_op(s_eops, op_fwd<NB>(mb, b, m), lane), acc);
+    }
+    zb[mb] = acc;
+  }
+}
+// Linear_b, standard: zb[mb][r] = z_b[channel 32 mb + chan(r, h)][view lane & 31]
+template <int NB>
+__device__ __forceinline__ void linear_b_std(const uint4* s_eops, int lane, const bf16x8 (&a)[NB][2], f32x16 (&zb)[NB]) {
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc = CH_MFMA(lds_op(s_eops, op_fwd<NB>(mb, b, m), lane), a[b][m], acc);
+    }
+    zb[mb] = acc;
+  }
+}
+// per-lane BatchNorm constants of the flipped layer: channel 32 mb + (lane & 31)
+template <int NB>
+struct LaneBN {
+  float g6[NB], b6[NB];      // 0.6 G | 0.6 (beta - mean G)
+};
+template <int NB>
+__device__ __forceinline__ LaneBN<NB> lane_bn(const float* __restrict__ bn, int CO, int lane) {
+  LaneBN<NB> k;
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) {
+    const int c = 32 * mb + (lane & 31);
+    const float g = bn[2 * CO + c] * bn[CO + c];
+    k.g6[mb] = 0.6f * g;
+    k.b6[mb] = 0.6f * (bn[3 * CO + c] - bn[c] * g);
+  }
+  return k;
+}
+__device__ __forceinline__ float leaky06(float t) { return __builtin_fmaf(__builtin_fabsf(t), 0.6666667f, t); }
+
+// all-reduce over groups of LANES lanes (8, 16 or 32, aligned) inside a half-wave
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  if (LANES >= 16) v += dpp_mov<0x140>(v);   // row_mirror
+  if (LANES >= 32) {
+    const uint32_t x = __float_as_uint(v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  }
+  return v;
+}
+__device__ __forceinline__ float other_half(float v) {     // value of lane ^ 32
+  uint32_t a = __float_as_uint(v), b = a;
+  swap_halves(a, b);
+  return __uint_as_float((threadIdx.x & 32) ? a : b);
+}
+
+// deterministic block reduction of per-lane partials (one LDS slot per wavefront, fixed order, fp64) -> fp64 atomics
+// (v0, v1 of the lanes h = 0: channel base + (lane & 31)); s_red: 4 x 2 x 32 floats
+__device__ __forceinline__ void flush_lane_stats(float v0, float v1, double* __restrict__ out0, double* __restrict__ out1,
+                                                 int base, float* s_red) {
+  const int wv = threadIdx.x >> 6, n = threadIdx.x & 31;
+  __syncthreads();
+  if ((threadIdx.x & 32) == 0) {
+    s_red[(wv * 2 + 0) * 32 + n] = v0;
+    s_red[(wv * 2 + 1) * 32 + n] = v1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    double acc = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) acc += (double)s_red[(w * 2 + which) * 32 + n];
+    atomicAdd(which ? &out1[base + n] : &out0[base + n], acc);
+  }
+}
+
+// per-lane fp32 partial sums of a standard-layout block (16 accumulator channels) -> stats[n * ld + c0 + chan(r, h)]
+template <int NV>
+__device__ __forceinline__ void flush_stats_c(float (&st)[NV][16], double* __restrict__ out, int ld, int c0, float* s_red) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, wv = threadIdx.x >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = st[n][r];
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off);
+      if ((lane & 31) == 0) s_red[wv * (NV * D) + n * D + chan(r, h)] = v;
+    }
+  }
+  __syncthreads();
+  const int n_waves = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < NV * D; i += blockDim.x) {
+    double acc = 0.0;
+    for (int w = 0; w < n_waves; ++w) acc += (double)s_red[w * (NV * D) + i];
+    atomicAdd(&out[(i / D) * ld + c0 + (i % D)], acc);
+  }
+}
+
+// BatchNorm_a + LeakyReLU + bf16 packing of every block (operands of Linear_b)
+template <int NB>
+__device__ __forceinline__ void act_a(const f32x16 (&za)[NB], const float (*taba)[TAB_FLOATS], int h, uint32_t keep,
+                                      bf16x8 (&a)[NB][2]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) act_pack(za[b], taba[b], h, keep, a[b]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics passes (train mode).  L = 1: z_a (interpolated Y);  L = 2: z_b = W_b leaky(BatchNorm_a(z_a))
+// stats fp64 [2][CO] = sum | sum of squares, natural channel order
+// ------------------------------------------------------------------------------------------------
+template <int CO, int L>
+__global__ __launch_bounds__(256, 2) void emod_stats_kernel(
+    const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
+    const float* __restrict__ bna, double* __restrict__ stats, int64_t V, int64_t R) {
+  constexpr int NB = CO / 32;
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) uint4 s_eops[L == 2 ? NB * NB * 2 * 64 : 1];
+  __shared__ float s_red[STATS_RED_FLOATS];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  if (L == 2) {
+    for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
+                               W4 = make_rsrc(w4, (uint64_t)V * 16);
+  float st[L == 1 ? NB : 1][2][16];
+  float s1[NB], s2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    s1[b] = s2[b] = 0.f;
+    if (L == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[b][0][r] = st[b][1][r] = 0.f;
+    }
+  }
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    TapRec t;
+  };
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 16u : OOB;
+    p.t.rows = __builtin_bit_cast(int4, ld128(R4, off));
+    p.t.w = as_f4(ld128(W4, off));
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    f32x16 za[NB];
+    eval_za<CO>(Y, p.t, ok, h, za);         // lanes without a view: weights and taps read 0 -> z_a = 0
+    if constexpr (L == 1) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[b][0][r] += za[b][r];
+          st[b][1][r] = __builtin_fmaf(za[b][r], za[b][r], st[b][1][r]);
+        }
+      }
+    } else {
+      bf16x8 a[NB][2];
+      act_a<NB>(za, s_taba, h, keep, a);
+      f32x16 zb[NB];
+      linear_b_flipped<NB>(s_eops, lane, a, zb);    // views without a lane: a = 0 -> z_b = 0: no mask needed below
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s1[mb] += zb[mb][r];
+          s2[mb] = __builtin_fmaf(zb[mb][r], zb[mb][r], s2[mb]);
+        }
+      }
+    }
+  });
+  if constexpr (L == 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) flush_stats_c<2>(st[b], stats, CO, 32 * b, s_red);
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+      const float a0 = s1[mb] + other_half(s1[mb]), a1 = s2[mb] + other_half(s2[mb]);
+      flush_lane_stats(a0, a1, stats, stats + CO, 32 * mb, s_red);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused view kernel of the bilinear path
+// ------------------------------------------------------------------------------------------------
+template <int CO, int G>
+__global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ Yp,
+    const int4* __restrict__ rows4, const float4* __restrict__ w4, const uint4* __restrict__ eops,
+    const float* __restrict__ bna, const float* __restrict__ bnb, const int64_t* __restrict__ ptr,
+    const float* __restrict__ gw, const float* __restrict__ gb, bf16_t* __restrict__ out,
+    float* __restrict__ scores_out, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+  constexpr int NB = CO / 32, NE = G == 1 ? 1 : 2, GS = CO / G;
+  static_assert(GS % 8 == 0, "whole 8-lane groups");
+  __shared__ __attribute__((aligned(16))) float s_tab[4][2 * D];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[OP_W6T * 64];
+  __shared__ __attribute__((aligned(16))) uint4 s_eops[NB * NB * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_ev[4][4 * 32];     // exp(.) per [group][view]
+  __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][view]
+  __shared__ __attribute__((aligned(16))) int s_pid[4][32];
+  __shared__ __attribute__((aligned(16))) float s_alpha[4][4], s_scg[4][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < OP_W6T * 64; i += blockDim.x) s_ops[i] = ops[i];
+  for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
+  stage_tab_fwd(s_tab[0], bn1);
+  stage_tab_fwd(s_tab[1], bn2);
+  stage_tab_fwd(s_tab[2], bn5);
+  stage_tab_fwd(s_tab[3], bn6);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
+  __syncthreads();
+  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  fold_ops(s_ops, OP_W6, ops, OP_W6, 2, bn6);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), Y = make_rsrc(Yp, (uint64_t)R * CO * 2),
+                               R4 = make_rsrc(rows4, (uint64_t)V * 16), W4 = make_rsrc(w4, (uint64_t)V * 16),
+                               O = make_rsrc(out, (uint64_t)N * CO * 2),
+                               SC = make_rsrc(scores_out, scores_out ? (uint64_t)V * 16 : 0);
+  const bool s_active = G == 4 || h == 0;
+  int gl[NE];
+  float bias[NE], gwl[NE], gbl[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    gl[e] = (G == 4 ? 2 * h : 0) + e;
+    if (gl[e] >= G) gl[e] = G - 1;
+    bias[e] = bs[gl[e]];
+    gwl[e] = gw ? gw[gl[e]] : 0.f;
+    gbl[e] = gw ? gb[gl[e]] : 0.f;
+  }
+  const LaneBN<NB> kb = lane_bn<NB>(bnb, CO, lane);
+  int gch[NB];                 // group of this lane's channel in block mb
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) gch[mb] = (32 * mb + j) / GS;
+  float* ev_t = s_ev[wv];
+  float* sc_t = s_sc[wv];
+  int* pid_t = s_pid[wv];
+  float run_m[NE], run_s[NE], run_acc[NB];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { run_m[e] = -INFINITY; run_s[e] = 0.f; }
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) run_acc[mb] = 0.f;
+
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x;
+    int vpj;
+    TapRec t;
+  };
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
+    p.t.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
+    p.t.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    return p;
+  }, [&](const Pre& p) {
+    const int nv = p.ti.nv, frag = p.ti.frag;
+    const bool ok = j < nv;
+    const uint32_t keepv = ok ? 0xffffffffu : 0u;
+    f32x16 uacc;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const float4 v = as_f4(ld128(U, ok ? (uint32_t)p.vpj * 128u + (8u * qq + 4u * h) * 4u : OOB));
+      uacc[4 * qq] = v.x; uacc[4 * qq + 1] = v.y; uacc[4 * qq + 2] = v.z; uacc[4 * qq + 3] = v.w;
+    }
+    // ---- DeepSetFeat chain -> scores (as chain_fwd.hip attn_fwd_kernel)
+    float c[NE];
+    {
+      const f32x16 zero = {0};
+      const uint32_t keep = 0xffffffffu;
+      bf16x8 a[2], a2[2];
+      asm volatile("" ::: "memory");
+      f32x16 z = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], 1, h));
+      act_fold(z, keep, a);
+      z = mm32_lds(s_ops, OP_W2, lane, a, bias_acc(s_tab[1], 1, h));
+      act_fold(z, keep, a2);
+      z = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
+      act_pack(z, s_tab[2], h, keep, a, 0, 1);
+      z = mm32_lds(s_ops, OP_W6, lane, a, bias_acc(s_tab[3], 1, h));
+      act_fold(z, keep, a2);
+      z = mm32_lds(s_ops, OP_WS, lane, a2, zero);
+      if constexpr (G == 4) {
+        uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
+        uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
+        swap_halves(A0, A2);
+        swap_halves(A1, A3);
+        c[0] = __uint_as_float(A0) + bias[0];
+        c[1] = __uint_as_float(A1) + bias[1];
+      } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
+      }
+    }
+    if (s_active) {
+      const uint32_t so = ok ? (uint32_t)(p.ti.v0 + j) * 16u + (G == 4 ? 8u * h : 0u) : OOB;
+      if (NE == 2) {
+        const u32x2 cv = {__float_as_uint(c[0]), __float_as_uint(c[NE - 1])};
+        __builtin_amdgcn_raw_buffer_store_b64(cv, SC, (int)so, 0, 0);
+      } else {
+        st32(SC, so, __float_as_uint(c[0]));
+      }
+    }
+    const int vp0 = __builtin_amdgcn_readfirstlane(p.vpj);
+    const bool single = frag != 0 || __ballot(ok && p.vpj != vp0) == 0;
+    // ---- softmax weights of the tile -> LDS tables
+    SegInfo sg;
+    if (single) {
+      int n_pt = nv;
+      if (frag != 0) n_pt = (int)(ptr[vp0 + 1] - ptr[vp0]);
+      const float isn = (scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f) * 1.44269504f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        float m = half_max(ok ? c[e] : -INFINITY);
+        float alpha = 0.f;
+        if (frag != 0) {
+          const float m_new = vmaxf(run_m[e], m);
+          alpha = __builtin_amdgcn_exp2f((run_m[e] - m_new) * isn);
+          m = m_new;
+        }
+        const float ev = ok ? __builtin_amdgcn_exp2f((c[e] - m) * isn) : 0.f;
+        float s = half_sum(ev);
+        if (frag != 0) {
+          s = run_s[e] * alpha + s;
+          run_s[e] = frag == 3 ? 0.f : s;
+          run_m[e] = frag == 3 ? -INFINITY : m;
+        }
+        const float gt = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+        if (s_active) {
+          ev_t[gl[e] * 32 + j] = ev;
+          if (j == 0) {
+            s_scg[wv][gl[e]] = gt * __builtin_amdgcn_rcpf(s + eps);
+            s_alpha[wv][gl[e]] = alpha;
+          }
+        }
+      }
+    } else {
+      sg = seg_setup(p.vpj, j, lane, nv);
+      const float isn = (scaling ? __builtin_amdgcn_rsqf((float)(sg.se - sg.ss + 1)) : 1.f) * 1.44269504f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const float m = seg_total(seg_scan_max(ok ? c[e] : -INFINITY, sg, lane), sg, h);
+        const float ev = ok ? __builtin_amdgcn_exp2f((c[e] - m) * isn) : 0.f;
+        const float s = seg_total(seg_scan_sum(ev, sg, lane), sg, h);
+        const float gt = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
+        if (s_active) {
+          ev_t[gl[e] * 32 + j] = ev;
+          sc_t[gl[e] * 32 + j] = gt * __builtin_amdgcn_rcpf(s + eps);
+        }
+      }
+      if (h == 0) pid_t[j] = p.vpj;
+    }
+    // ---- E_mod of the 32 views: taps of Y -> z_a -> BatchNorm_a, LeakyReLU -> Linear_b (flipped) -> value
+    f32x16 zb[NB];
+    {
+      f32x16 za[NB];
+      eval_za<CO>(Y, p.t, ok, h, za);
+      bf16x8 a[NB][2];
+      act_a<NB>(za, s_taba, h, keepv, a);
+      linear_b_flipped<NB>(s_eops, lane, a, zb);
+    }
+    wave_sync();
+    // ---- softmax-weighted sum over the views of a point: in-lane (the lane owns channel 32 mb + j, its registers
+    //      16 of the 32 views; the other 16 sit in lane ^ 32)
+    auto weighted = [&](int mb, int lo, int hi, bool masked) {       // sum over the views [lo, hi] of the tile
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(ev_t + gch[mb] * 32 + 8 * q + 4 * h);
+        const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i, v = 8 * q + 4 * h + i;       // = view_of(r, h)
+          const float val = leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
+          const float wv_ = (!masked || (v >= lo && v <= hi)) ? ww[i] : 0.f;
+          acc = __builtin_fmaf(wv_, val, acc);
+        }
+      }
+      return acc + other_half(acc);
+    };
+    if (single) {
+      const bool done = frag == 0 || frag == 3;
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        float acc = weighted(mb, 0, 31, false);        // views without a lane carry weight 0
+        const float sc = s_scg[wv][gch[mb]], al = s_alpha[wv][gch[mb]];
+        if (frag != 0) {
+          acc = __builtin_fmaf(run_acc[mb], al, acc);
+          run_acc[mb] = frag == 3 ? 0.f : acc;
+        }
+        if (done)
+          __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(acc * sc), O,
+                                                h == 0 ? (int)((uint32_t)vp0 * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB,
+                                                0, 0);
+      }
+    } else {
+      // several points in the tile: one pass per point (uniform loop over the segments)
+      uint32_t sm_ = sg.smask, em_ = sg.emask;
+      while (sm_) {
+        const int lo = __builtin_ctz(sm_), hi = __builtin_ctz(em_);
+        sm_ &= sm_ - 1;
+        em_ &= em_ - 1;
+        const uint32_t pid = (uint32_t)pid_t[lo];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+          const float acc = weighted(mb, lo, hi, true);
+          const float sc = sc_t[gch[mb] * 32 + lo];
+          __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(acc * sc), O,
+                                                h == 0 ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB,
+                                                0, 0);
+        }
+      }
+    }
+    wave_sync();
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention backward of the bilinear path: scores (from the forward) + E_mod re-evaluated ->
+//   dc [V, 4], view records {point | gate * attention (bf16 x 4) | pad}, statistics of the BatchNorm_b backward
+//   (S1 = sum dy_b | sum dy_b z_b with dy_b = leaky'(y_b) gate attention grad_out)
+// ------------------------------------------------------------------------------------------------
+template <int CO, int G>
+__global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
+    const float* __restrict__ compat, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
+    const int32_t* __restrict__ n_tiles_dev, const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4,
+    const float4* __restrict__ w4, const uint4* __restrict__ eops, const float* __restrict__ bna,
+    const float* __restrict__ bnb, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
+    const float* __restrict__ gb, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out,
+    float* __restrict__ dc_out, uint32_t* __restrict__ rec, float* __restrict__ gwb, double* __restrict__ stats_b,
+    int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+  constexpr int NB = CO / 32, NE = G == 1 ? 1 : 2, GS = CO / G;
+  constexpr int GL = GS < 32 ? GS : 32;           // lanes of a group inside one block
+  __shared__ __attribute__((aligned(16))) uint4 s_eops[NB * NB * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_q[4][4 * 32], s_ga[4][4 * 32];
+  __shared__ __attribute__((aligned(16))) int s_pid[4][32];
+  __shared__ __attribute__((aligned(16))) float s_E[4][4];
+  __shared__ float s_red[4 * 2 * 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t CP = make_rsrc(compat, (uint64_t)V * 16), P = make_rsrc(vp, (uint64_t)V * 4),
+                               Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
+                               W4 = make_rsrc(w4, (uint64_t)V * 16), GO = make_rsrc(gout, (uint64_t)N * CO * 2),
+                               OU = make_rsrc(out, (uint64_t)N * CO * 2), DC = make_rsrc(dc_out, (uint64_t)V * 16),
+                               RC = make_rsrc(rec, (uint64_t)V * 16);
+  const bool s_active = G == 4 || h == 0;
+  const uint32_t coff = G == 4 ? 8u * h : 0u;
+  int gl[NE];
+  float gwl[NE], gbl[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    gl[e] = (G == 4 ? 2 * h : 0) + e;
+    if (gl[e] >= G) gl[e] = G - 1;
+    gwl[e] = gw ? gw[gl[e]] : 0.f;
+    gbl[e] = gw ? gb[gl[e]] : 0.f;
+  }
+  const LaneBN<NB> kb = lane_bn<NB>(bnb, CO, lane);
+  int gch[NB];
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) gch[mb] = (32 * mb + j) / GS;
+  float* q_t = s_q[wv];
+  float* ga_t = s_ga[wv];
+  int* pid_t = s_pid[wv];
+  float sb1[NB], sb2[NB];
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) sb1[mb] = sb2[mb] = 0.f;
+  float dwa[NE], dba[NE], glob_m[NE], glob_s[NE], glob_E[NE];
+  bool seen[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { dwa[e] = dba[e] = 0.f; glob_m[e] = glob_s[e] = glob_E[e] = 0.f; seen[e] = false; }
+
+  // sum over the lanes of a channel group of per-lane values that live in block mb (GS = 64: both blocks, in-lane first)
+  auto group_reduce = [&](float v) { return group_sum<GL>(v); };
+
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    int t;
+    u32x2 cc;
+    int vpj;
+    TapRec tr;
+  };
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    p.t = t;
+    const bool ok = j < p.ti.nv;
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    p.cc = ld64(CP, ok ? view * 16u + coff : OOB);
+    p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
+    p.tr.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
+    p.tr.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    return p;
+  }, [&](const Pre& p) {
+    const int nv = p.ti.nv, frag = p.ti.frag;
+    const bool ok = j < nv;
+    const uint32_t keepv = ok ? 0xffffffffu : 0u;
+    if (h == 0) pid_t[j] = ok ? p.vpj : 0;
+    float c[NE];
+    c[0] = __uint_as_float(p.cc.x);
+    if (NE > 1) c[NE - 1] = __uint_as_float(p.cc.y);
+    const int vp0 = __builtin_amdgcn_readfirstlane(p.vpj);
+    const bool single = frag != 0 || __ballot(ok && p.vpj != vp0) == 0;
+    SegInfo sg;
+    if (single) {
+      sg.ss = 0;
+      sg.se = nv - 1;
+    } else {
+      sg = seg_setup(p.vpj, j, lane, nv);
+    }
+    int n_pt = sg.se - sg.ss + 1;
+    if (frag != 0) n_pt = (int)(ptr[vp0 + 1] - ptr[vp0]);
+    const float isn = scaling ? __builtin_amdgcn_rsqf((float)n_pt) : 1.f;
+    const float isl = isn * 1.44269504f;
+    auto red_max = [&](float v) { return single ? half_max(v) : seg_total(seg_scan_max(v, sg, lane), sg, h); };
+    auto red_sum = [&](float v) { return single ? half_sum(v) : seg_total(seg_scan_sum(v, sg, lane), sg, h); };
+    // grad_out of this lane's channels: one value per block for a single-point tile
+    float go1[NB];
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb)
+      go1[mb] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
+          GO, (int)((uint32_t)vp0 * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u), 0, 0));
+    wave_sync();
+    if (frag == 1) {
+      float m_run[NE], s_run[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        m_run[e] = half_max(ok ? c[e] : -INFINITY);
+        s_run[e] = half_sum(ok ? __builtin_amdgcn_exp2f((c[e] - m_run[e]) * isl) : 0.f);
+        seen[e] = false;
+      }
+      for (int t2 = p.t + 1;; ++t2) {
+        const TileInfo t2i = get_tile(tiles, t2);
+        const bool ok2 = j < t2i.nv;
+        const u32x2 cc2 = ld64(CP, ok2 ? (uint32_t)(t2i.v0 + j) * 16u + coff : OOB);
+        float c2[NE];
+        c2[0] = __uint_as_float(cc2.x);
+        if (NE > 1) c2[NE - 1] = __uint_as_float(cc2.y);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const float m2 = vmaxf(m_run[e], half_max(ok2 ? c2[e] : -INFINITY));
+          s_run[e] = s_run[e] * __builtin_amdgcn_exp2f((m_run[e] - m2) * isl) + half_sum(ok2 ? __builtin_amdgcn_exp2f((c2[e] - m2) * isl) : 0.f);
+          m_run[e] = m2;
+        }
+        if (t2i.frag == 3) break;
+      }
+      // E_g = sum_{ch in g} grad_out out / gate from the saved forward output
+      float dsum = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const float ou = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
+            OU, (int)((uint32_t)vp0 * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u), 0, 0));
+        const float d = go1[mb] * ou;
+        if (GS >= 64) dsum += d;
+        else {
+          const float r = group_reduce(d);
+          if ((j % GL) == 0 && h == 0) s_E[wv][gch[mb]] = r;
+        }
+      }
+      if (GS >= 64) {
+        const float r = group_reduce(dsum);
+        if (j == 0 && h == 0) s_E[wv][0] = r;
+      }
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        glob_m[e] = m_run[e];
+        glob_s[e] = s_run[e];
+        const float gt0 = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m_run[e], gbl[e]), 0.f)) : 1.f;
+        glob_E[e] = gt0 > 0.f ? s_E[wv][gl[e]] / gt0 : 0.f;
+      }
+    }
+    // ---- softmax of the tile's views
+    float m[NE], a[NE], gt[NE], pre[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (frag == 0) {
+        m[e] = red_max(ok ? c[e] : -INFINITY);
+        const float ev = ok ? __builtin_amdgcn_exp2f((c[e] - m[e]) * isl) : 0.f;
+        const float s = red_sum(ev);
+        a[e] = ev * __builtin_amdgcn_rcpf(s + eps);
+      } else {
+        m[e] = glob_m[e];
+        a[e] = ok ? __builtin_amdgcn_exp2f((c[e] - m[e]) * isl) * __builtin_amdgcn_rcpf(glob_s[e] + eps) : 0.f;
+      }
+      pre[e] = __builtin_fmaf(gwl[e], m[e], gbl[e]);
+      gt[e] = gw ? tanh_pos(fmaxf(pre[e], 0.f)) : 1.f;
+    }
+    // ---- E_mod of the views (flipped): raw z_b stays for the statistics
+    f32x16 zb[NB];
+    {
+      f32x16 za[NB];
+      eval_za<CO>(Y, p.tr, ok, h, za);
+      bf16x8 aa[NB][2];
+      act_a<NB>(za, s_taba, h, keepv, aa);
+      linear_b_flipped<NB>(s_eops, lane, aa, zb);
+    }
+    // grad_out value of (block mb, register r): the point of view view_of(r, h)
+    auto go_of = [&](int mb, int r) {
+      if (single) return go1[mb];
+      const int v = view_of(r, h);
+      const uint32_t pid = (uint32_t)pid_t[v];
+      return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
+          GO, v < nv ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB, 0, 0));
+    };
+    // ---- q[v][g] = sum_{ch in g} grad_out[p(v)][ch] value[v][ch]: reduce over the lanes of the group
+    if (GS >= 64) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
+          d = __builtin_fmaf(go_of(mb, r), leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb])), d);
+        d = group_reduce(d);
+        if (j == 0) q_t[view_of(r, h)] = d;
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float d = go_of(mb, r) * leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
+          d = group_reduce(d);
+          if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = d;
+        }
+      }
+    }
+    wave_sync();
+    // ---- softmax + gate backward (as chain_bwd.hip attn_bwd_kernel)
+    float dcv[NE], gav[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float qv = q_t[gl[e] * 32 + j];
+      float E;
+      if (frag == 0) E = red_sum(a[e] * qv);
+      else E = glob_E[e];
+      const float dpre = (gw && pre[e] > 0.f) ? E * (1.f - gt[e] * gt[e]) : 0.f;
+      const bool is_max = ok && c[e] == m[e];
+      const uint64_t F = __ballot(is_max);
+      const uint32_t Fh = (uint32_t)(F >> (32 * h));
+      const uint32_t before = Fh & ((1u << j) - 1u) & ~((1u << sg.ss) - 1u);
+      const bool first = is_max && before == 0u && !seen[e];
+      if (frag != 0) {
+        seen[e] = seen[e] || (Fh != 0u);
+        if (frag == 3) seen[e] = false;
+      }
+      dcv[e] = gt[e] * a[e] * (qv - E) * isn + (first ? dpre * gwl[e] : 0.f);
+      gav[e] = gt[e] * a[e];
+      const bool last_view = ok && j == sg.se && (frag == 0 || frag == 3);
+      if (last_view) {
+        dwa[e] += dpre * m[e];
+        dba[e] += dpre;
+      }
+      if (s_active) ga_t[gl[e] * 32 + j] = ok ? gav[e] : 0.f;
+    }
+    float dc4[4] = {0.f, 0.f, 0.f, 0.f}, ga4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (G == 4) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        uint32_t x0 = __float_as_uint(dcv[e]), x1 = x0;
+        swap_halves(x0, x1);
+        dc4[e] = dcv[e];
+        dc4[2 + e] = __uint_as_float(x1);
+        uint32_t y0 = __float_as_uint(gav[e]), y1 = y0;
+        swap_halves(y0, y1);
+        ga4[e] = gav[e];
+        ga4[2 + e] = __uint_as_float(y1);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        dc4[e] = dcv[e];
+        ga4[e] = gav[e];
+      }
+    }
+    const bool wr = ok && h == 0;
+    const uint32_t vg = (uint32_t)(p.ti.v0 + j);
+    st128(DC, wr ? vg * 16u : OOB, as_u4(dc4[0], dc4[1], dc4[2], dc4[3]));
+    {
+      const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), 0u};
+      st128(RC, wr ? vg * 16u : OOB, r);
+    }
+    wave_sync();
+    // ---- statistics of the BatchNorm_b backward: d value = gate attention grad_out, dy_b = leaky'(y_b) d value
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(ga_t + gch[mb] * 32 + 8 * q + 4 * h);
+        const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          // the records carry gate * attention as bf16: the later passes see the rounded weight
+          const float gar = bf2f(f2bf(ww[i]));
+          const float dval = gar * go_of(mb, r);
+          const float t = __builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]);
+          const float dy = t > 0.f ? dval : SLOPE * dval;
+          sb1[mb] += dy;
+          sb2[mb] = __builtin_fmaf(dy, zb[mb][r], sb2[mb]);
+        }
+      }
+    }
+    wave_sync();
+  });
+#pragma unroll
+  for (int mb = 0; mb < NB; ++mb) {
+    const float a0 = sb1[mb] + other_half(sb1[mb]), a1 = sb2[mb] + other_half(sb2[mb]);
+    flush_lane_stats(a0, a1, stats_b, stats_b + CO, 32 * mb, s_red);
+  }
+  if (gw) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float dw = half_sum(dwa[e]), db = half_sum(dba[e]);
+      if (j == 0 && s_active && ((G == 4 ? 2 * h : 0) + e) < G) {
+        atomicAdd(&gwb[gl[e]], dw);
+        atomicAdd(&gwb[G + gl[e]], db);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// E_mod backward.
+// STAGE 2 (standard orientation): d value = record weight x grad_out -> dy_b -> dz_b (BatchNorm_b backward)
+//   -> dW_b, da = W_b^T dz_b, dy_a = leaky'(y_a) da written as bf16 [V][CO] (position order), S of BatchNorm_a.
+// STAGE 1: dz_a = G_a dy_a - K1 - K2 z_a in place: the gradient of the interpolated Y rows, scattered to the map by
+//   the weighted segmented reduction over the row plan of the taps (dva_gather_rows_sum).
+// ------------------------------------------------------------------------------------------------
+template <int CO, int G, int STAGE>
+__global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd_kernel(
+    const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
+    const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ sma,
+    const float* __restrict__ smb, const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout,
+    bf16_t* __restrict__ da, float* __restrict__ dWb, double* __restrict__ stats_a, int64_t V, int64_t N, int64_t R) {
+  constexpr int NB = CO / 32, GS = CO / G;
+  constexpr int NT = STAGE == 2 ? NB : 1;
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_tabb[STAGE == 2 ? NB : 1][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) uint4 s_eops[STAGE == 2 ? 2 * NB * NB * 2 * 64 : 1];
+  __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][NT][STAGE == 2 ? 32 * TSB : 8], s_tb[4][NT][STAGE == 2 ? 32 * TSB : 8];
+  __shared__ float s_redx[STAGE == 2 ? 1 : STATS_RED_FLOATS];
+  float* s_red = STAGE == 2 ? reinterpret_cast<float*>(&s_ta[0][0][0]) : s_redx;     // epilogue: D x D floats
+  static_assert(STAGE != 2 || sizeof(bf16_t) * 4 * NT * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  if (STAGE == 2) {
+    for (int i = threadIdx.x; i < 2 * NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) stage_tab_c(s_tabb[b], bnb, CO, 32 * b, smb);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, STAGE == 1 ? sma : nullptr);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
+                               W4 = make_rsrc(w4, (uint64_t)V * 16), RC = make_rsrc(rec, (uint64_t)V * 16),
+                               GO = make_rsrc(gout, (uint64_t)N * CO * 2);
+  float st[STAGE == 2 ? NB : 1][2][16];
+  f32x16 accW[STAGE == 2 ? NB : 1][STAGE == 2 ? NB : 1];
+  if (STAGE == 2) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[b][0][r] = st[b][1][r] = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const f32x16 zero = {0};
+        accW[mb][b] = zero;
+      }
+    }
+  }
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    TapRec t;
+    u32x4 rc;
+  };
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    p.t.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
+    p.t.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    if (STAGE == 2) p.rc = ld128(RC, ok ? view * 16u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    // the handed-over gradient [V][CO] reaches 4 GiB at the headline size (V = 2^25, CO = 64): one descriptor per tile
+    const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)p.ti.v0 * CO, (uint64_t)p.ti.nv * CO * 2);
+    f32x16 za[NB];
+    eval_za<CO>(Y, p.t, ok, h, za);
+    if constexpr (STAGE == 1) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+        const u32x4 lo = ld128(DA, off), hi = ld128(DA, ok ? off + 16u : OOB);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        f32x16 dy;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          dy[2 * i] = __uint_as_float(w[i] << 16);
+          dy[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+        float dz[16];
+        bn_bwd_apply(za[b], dy, s_taba[b], h, dz);
+        st128(DA, off, __builtin_bit_cast(u32x4, pack8(&dz[0])));
+        st128(DA, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pack8(&dz[8])));
+      }
+    } else {
+      bf16_t* tA[NB];
+      bf16_t* tB[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        tA[b] = s_ta[wv][b];
+        tB[b] = s_tb[wv][b];
+      }
+      bf16x8 a[NB][2];
+      act_a<NB>(za, s_taba, h, keep, a);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) tileT_put_packed(tB[b], j, h, a[b]);
+      f32x16 zb[NB];
+      linear_b_std<NB>(s_eops, lane, a, zb);
+      // d value[ch] = (gate attention)[g(ch)] grad_out[point][ch] for the lane's channels 32 mb + chan(r, h)
+      const uint32_t pid = p.rc.x;
+      const float ga4[4] = {__uint_as_float(p.rc.y << 16), __uint_as_float(p.rc.y & 0xffff0000u),
+                            __uint_as_float(p.rc.z << 16), __uint_as_float(p.rc.z & 0xffff0000u)};
+      bf16x8 dzp[NB][2];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        f32x16 dy;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * mb + 8 * q + 4 * h;            // channels c0 .. c0 + 3 = chan(4 q + i, h) + 32 mb
+          const u32x2 gv = ld64(GO, ok ? pid * (uint32_t)(CO * 2) + (uint32_t)c0 * 2u : OOB);
+          const float gg = ga4[G == 1 ? 0 : c0 / GS];
+          dy[4 * q] = gg * __uint_as_float(gv.x << 16);
+          dy[4 * q + 1] = gg * __uint_as_float(gv.x & 0xffff0000u);
+          dy[4 * q + 2] = gg * __uint_as_float(gv.y << 16);
+          dy[4 * q + 3] = gg * __uint_as_float(gv.y & 0xffff0000u);
+        }
+        // dy_b = leaky'(y_b) d value, y_b = G_b z_b + B_b;  dz_b = G_b dy_b - K1 - K2 z_b
+        float dz[16];
+        {
+          asm volatile("" ::: "memory");
+          float g_[16], b_[16];
+          tab16(s_tabb[mb], T_G, h, g_);
+          tab16(s_tabb[mb], T_B, h, b_);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dy[r] = __builtin_fmaf(zb[mb][r], g_[r], b_[r]) > 0.f ? dy[r] : SLOPE * dy[r];
+        }
+        bn_bwd_apply(zb[mb], dy, s_tabb[mb], h, dz);
+        pack16(dz, keep, dzp[mb]);
+        tileT_put_packed(tA[mb], j, h, dzp[mb]);
+      }
+      // da = W_b^T dz_b, dy_a = leaky'(y_a) da;  S of BatchNorm_a;  hand dy_a over (bf16, position order)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        f32x16 dya = {0};
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) dya = CH_MFMA(lds_op(s_eops, op_bwd<NB>(b, mb, m), lane), dzp[mb][m], dya);
+        }
+        {
+          asm volatile("" ::: "memory");
+          float g_[16], b_[16];
+          tab16(s_taba[b], T_G, h, g_);
+          tab16(s_taba[b], T_B, h, b_);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dya[r] = __builtin_fmaf(za[b][r], g_[r], b_[r]) > 0.f ? dya[r] : SLOPE * dya[r];
+        }
+        bn_bwd_stats(za[b], dya, st[b]);
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = dya[r];
+        const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+        st128(DA, off, __builtin_bit_cast(u32x4, pack8(&t[0])));
+        st128(DA, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pack8(&t[8])));
+      }
+      wave_sync();
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) accW[mb][b] = wgrad(tA[mb], tB[b], j, h, accW[mb][b]);   // dW_b[out][in]
+      }
+      wave_sync();
+    }
+  });
+  if constexpr (STAGE == 2) {
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) flush_matrix(accW[mb][b], dWb + (32 * mb) * CO + 32 * b, CO, D, false, s_red);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) flush_stats_c<2>(st[b], stats_a, CO, 32 * b, s_red);
+  }
+}
+
+}  // namespace emod
+}  // namespace dva
+
+using namespace dva;
+using namespace dva::chain;
+using namespace dva::emod;
+
+extern "C" {
+
+int dva_emod_prep(const float* Wb, int32_t C_out, void* ops, void* stream) {
+  if (!Wb || !ops || (C_out != 32 && C_out != 64)) return DVA_ERR_INVALID;
+  const int NB = C_out / 32;
+  hipLaunchKernelGGL(emod_prep_kernel, dim3(2 * NB * NB * 2), dim3(64), 0, (hipStream_t)stream, Wb, (int)C_out,
+                     (uint4*)ops);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+#define DVA_EMOD_CHECK_SIZES()                                                                            \
+  if (n_rows * (int64_t)C_out * 2 > 0xfffffff0ll || n_views * 32 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED
+
+int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
+                   const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, int64_t n_views,
+                   int64_t n_rows, int32_t C_out, void* stream) {
+  if (n_views < 0 || (layer != 1 && layer != 2) || (C_out != 32 && C_out != 64)) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!Y || !tap_rows || !tap_weights || !tiles || !n_tiles || !stats || (layer == 2 && (!eops || !bn_a)))
+    return DVA_ERR_INVALID;
+  DVA_EMOD_CHECK_SIZES();
+  const dim3 grid(chain_grid(2)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_EMOD_STATS(CO_, L_)                                                                              \
+  hipLaunchKernelGGL((emod_stats_kernel<CO_, L_>), grid, block, 0, s, (const bf16_t*)Y, (const int4*)tap_rows, \
+                     (const float4*)tap_weights, (const int2*)tiles, n_tiles, (const uint4*)eops, bn_a, stats,  \
+                     n_views, n_rows)
+  if (C_out == 32 && layer == 1) DVA_EMOD_STATS(32, 1);
+  else if (C_out == 32) DVA_EMOD_STATS(32, 2);
+  else if (layer == 1) DVA_EMOD_STATS(64, 1);
+  else DVA_EMOD_STATS(64, 2);
+#undef DVA_EMOD_STATS
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                      const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                      const float* bn6, const float* score_bias, const void* Y, const int32_t* tap_rows,
+                      const float* tap_weights, const void* eops, const float* bn_a, const float* bn_b,
+                      const int64_t* ptr, const float* gate_w, const float* gate_b, void* out, float* scores_out,
+                      int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling,
+                      float eps, void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias || !Y ||
+      !tap_rows || !tap_weights || !eops || !bn_a || !bn_b || !ptr || !out ||
+      ((gate_w == nullptr) != (gate_b == nullptr)))
+    return DVA_ERR_INVALID;
+  DVA_EMOD_CHECK_SIZES();
+  if (n_points * 128 > 0xfffffff0ll || n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(2)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_EMOD_FWD(CO_, G_)                                                                                    \
+  hipLaunchKernelGGL((emod_attn_fwd_kernel<CO_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, \
+                     n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)Y,                 \
+                     (const int4*)tap_rows, (const float4*)tap_weights, (const uint4*)eops, bn_a, bn_b, ptr,       \
+                     gate_w, gate_b, (bf16_t*)out, scores_out, scaling, eps, n_views, n_points, n_rows)
+  switch (C_out * 8 + G) {
+    case 32 * 8 + 1: DVA_EMOD_FWD(32, 1); break;
+    case 32 * 8 + 2: DVA_EMOD_FWD(32, 2); break;
+    case 32 * 8 + 4: DVA_EMOD_FWD(32, 4); break;
+    case 64 * 8 + 1: DVA_EMOD_FWD(64, 1); break;
+    case 64 * 8 + 2: DVA_EMOD_FWD(64, 2); break;
+    case 64 * 8 + 4: DVA_EMOD_FWD(64, 4); break;
+    default: return DVA_ERR_UNSUPPORTED;
+  }
+#undef DVA_EMOD_FWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                      const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* eops,
+                      const float* bn_a, const float* bn_b, const int64_t* ptr, const float* gate_w,
+                      const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
+                      float* grad_gate_wb, double* stats_b, int64_t n_points, int64_t n_views, int64_t n_rows,
+                      int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!scores || !view_point || !tiles || !n_tiles || !Y || !tap_rows || !tap_weights || !eops || !bn_a || !bn_b ||
+      !ptr || !grad_out || !out || !grad_scores || !view_rec || !stats_b ||
+      ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
+    return DVA_ERR_INVALID;
+  DVA_EMOD_CHECK_SIZES();
+  if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(2)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_EMOD_BWD(CO_, G_)                                                                                      \
+  hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \
+                     n_tiles, (const bf16_t*)Y, (const int4*)tap_rows, (const float4*)tap_weights,                   \
+                     (const uint4*)eops, bn_a, bn_b, ptr, gate_w, gate_b, (const bf16_t*)grad_out,                   \
+                     (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, stats_b, scaling, eps,       \
+                     n_views, n_points, n_rows)
+  switch (C_out * 8 + G) {
+    case 32 * 8 + 1: DVA_EMOD_BWD(32, 1); break;
+    case 32 * 8 + 2: DVA_EMOD_BWD(32, 2); break;
+    case 32 * 8 + 4: DVA_EMOD_BWD(32, 4); break;
+    case 64 * 8 + 1: DVA_EMOD_BWD(64, 1); break;
+    case 64 * 8 + 2: DVA_EMOD_BWD(64, 2); break;
+    case 64 * 8 + 4: DVA_EMOD_BWD(64, 4); break;
+    default: return DVA_ERR_UNSUPPORTED;
+  }
+#undef DVA_EMOD_BWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
+                 const int32_t* n_tiles, const void* eops, const float* bn_a, const float* bn_b, const float* sm_a,
+                 const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,
+                 int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, void* stream) {
+  if (n_views < 0 || (stage != 1 && stage != 2) || (C_out != 32 && C_out != 64) || (G != 1 && G != 2 && G != 4))
+    return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!Y || !tap_rows || !tap_weights || !tiles || !n_tiles || !bn_a || !da) return DVA_ERR_INVALID;
+  if (stage == 2 && (!eops || !bn_b || !sm_b || !view_rec || !grad_out || !dWb || !stats_a)) return DVA_ERR_INVALID;
+  if (stage == 1 && !sm_a) return DVA_ERR_INVALID;
+  DVA_EMOD_CHECK_SIZES();
+  if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_EMOD_L(CO_, G_, ST_)                                                                                     \
+  hipLaunchKernelGGL((emod_bwd_kernel<CO_, G_, ST_>), dim3(chain_grid((ST_ == 2 && CO_ > 32) ? 1 : 2)), block, 0, s, \
+                     (const bf16_t*)Y, (const int4*)tap_rows, (const float4*)tap_weights, (const int2*)tiles,         \
+                     n_tiles, (const uint4*)eops, bn_a, bn_b, sm_a, sm_b, (const uint32_t*)view_rec,                   \
+                     (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, n_views, n_points, n_rows)
+  if (stage == 1) {
+    if (C_out == 32) DVA_EMOD_L(32, 1, 1);
+    else DVA_EMOD_L(64, 1, 1);
+  } else {
+    switch (C_out * 8 + G) {
+      case 32 * 8 + 1: DVA_EMOD_L(32, 1, 2); break;
+      case 32 * 8 + 2: DVA_EMOD_L(32, 2, 2); break;
+      case 32 * 8 + 4: DVA_EMOD_L(32, 4, 2); break;
+      case 64 * 8 + 1: DVA_EMOD_L(64, 1, 2); break;
+      case 64 * 8 + 2: DVA_EMOD_L(64, 2, 2); break;
+      case 64 * 8 + 4: DVA_EMOD_L(64, 4, 2); break;
+      default: return DVA_ERR_UNSUPPORTED;
+    }
+  }
+#undef DVA_EMOD_L
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

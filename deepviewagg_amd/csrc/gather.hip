@@ -129,9 +129,16 @@ __global__ __launch_bounds__(256) void gather_nearest_bwd_kernel(const T* __rest
   }
 }
 
+// anchor of a view = the cell (top, left) of its 2 x 2 tap block on the REPLICATION-PADDED grid of its image,
+// (img (H + 1) + top) (W + 1) + left with top in [0, H], left in [0, W]: the four taps are then the padded cells
+// (top, left), (top, left + 1), (top + 1, left), (top + 1, left + 1) for every view, borders included -- the structure
+// the anchor scatter (dva_anchor_rows_sum / dva_anchor_combine) relies on.  A view whose floor(q + 1) != floor(q) + 1
+// (the reference evaluates both floors separately, image.py:142-145: possible when q + 1 rounds up across an integer)
+// does not have it and gets the dummy anchor B (H + 1) (W + 1): dva_anchor_fixup adds its taps one by one.
 struct Taps {
   int64_t tl, tr, bl, br;  // pixel offsets (in pixels) into [B,H,W]
   float w_tl, w_tr, w_bl, w_br;
+  int64_t anchor;          // see above; -1 = no 2 x 2 structure
 };
 
 // image.py:138-165 with ReplicationPad2d(1): padded index i -> clamp(i-1, 0, size-1)
@@ -152,6 +159,9 @@ __device__ __forceinline__ Taps bilinear_taps(const PackedIdx pi, float cy, floa
   t.tr = (base + it) * W + ir;
   t.bl = (base + ib) * W + il;
   t.br = (base + ib) * W + ir;
+  const bool regular = bottom == top + 1.f && right == left + 1.f && top >= 0.f && left >= 0.f &&
+                       top <= (float)H && left <= (float)W;
+  t.anchor = regular ? ((int64_t)pi.img * (H + 1) + (int)top) * (W + 1) + (int)left : -1;
   return t;
 }
 
@@ -198,12 +208,62 @@ __global__ __launch_bounds__(256) void bilinear_taps_kernel(const PackedIdx* __r
                                                              const float* __restrict__ coords,
                                                              int64_t n_atoms, int H, int W,
                                                              int32_t* __restrict__ rows,
-                                                             float* __restrict__ weights) {
+                                                             float* __restrict__ weights,
+                                                             int32_t* __restrict__ anchors, int32_t dummy) {
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_atoms;
        p += (int64_t)gridDim.x * blockDim.x) {
     const Taps tp = bilinear_taps(idx[p], coords[2 * p], coords[2 * p + 1], H, W);
     *reinterpret_cast<int4*>(rows + 4 * p) = make_int4((int)tp.tl, (int)tp.tr, (int)tp.bl, (int)tp.br);
     *reinterpret_cast<float4*>(weights + 4 * p) = make_float4(tp.w_tl, tp.w_tr, tp.w_bl, tp.w_br);
+    if (anchors) anchors[p] = tp.anchor >= 0 ? (int32_t)tp.anchor : dummy;
+  }
+}
+
+// dY[r][c] (fp32, written) from the per-anchor sums S[a][k][c] of dva_anchor_rows_sum: row (b, y, x) collects the padded
+// cells that replicate it -- (py, px) with clamp(py - 1) = y, clamp(px - 1) = x -- and a padded cell collects tap k of
+// the anchors it is tap k of: S0[py][px] + S1[py][px - 1] + S2[py - 1][px] + S3[py - 1][px - 1].
+__global__ __launch_bounds__(256) void anchor_combine_kernel(const float* __restrict__ S, float* __restrict__ dY,
+                                                              int B, int H, int W, int C) {
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const int H1 = H + 1, W1 = W + 1, cq = C / 4;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(t % cq);
+    const int64_t r = t / cq;
+    const int x = (int)(r % W), y = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    const int py0 = y == 0 ? 0 : y + 1, py1 = y == H - 1 ? H + 1 : y + 1;
+    const int px0 = x == 0 ? 0 : x + 1, px1 = x == W - 1 ? W + 1 : x + 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](int t_, int l_, int k) {
+      if (t_ < 0 || t_ > H || l_ < 0 || l_ > W) return;
+      const float4 v = *reinterpret_cast<const float4*>(S + ((((int64_t)b * H1 + t_) * W1 + l_) * 4 + k) * C + 4 * c4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    };
+    for (int py = py0; py <= py1; ++py) {
+      for (int px = px0; px <= px1; ++px) {
+        add(py, px, 0);
+        add(py, px - 1, 1);
+        add(py - 1, px, 2);
+        add(py - 1, px - 1, 3);
+      }
+    }
+    *reinterpret_cast<float4*>(dY + r * C + 4 * c4) = acc;
+  }
+}
+
+// views without the 2 x 2 structure (dummy anchor): their four taps, one by one (fp32 atomics: there are none on real
+// data, see bilinear_taps)
+template <typename T>
+__global__ __launch_bounds__(256) void anchor_fixup_kernel(const T* __restrict__ grad, const int32_t* __restrict__ rows,
+                                                            const float* __restrict__ weights,
+                                                            const int32_t* __restrict__ anchors, int32_t dummy,
+                                                            float* __restrict__ dY, int64_t n_atoms, int C) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_atoms; p += (int64_t)gridDim.x * blockDim.x) {
+    if (anchors[p] != dummy) continue;
+    for (int k = 0; k < 4; ++k) {
+      const float w = weights[4 * p + k];
+      const int64_t r = rows[4 * p + k];
+      for (int c = 0; c < C; ++c) atomicAdd(&dY[r * C + c], w * Elt<T>::ld(grad, p * C + c));
+    }
   }
 }
 
@@ -387,12 +447,47 @@ int dva_gather_bilinear_bwd(const void* grad_out, const void* packed_idx, const 
 
 int dva_gather_bilinear_taps(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
                              int32_t H, int32_t W, int32_t* rows, float* weights, void* stream) {
+  return dva_gather_bilinear_taps_anchor(packed_idx, coords, n_atoms, B, H, W, rows, weights, nullptr, stream);
+}
+
+int dva_gather_bilinear_taps_anchor(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
+                                    int32_t H, int32_t W, int32_t* rows, float* weights, int32_t* anchors,
+                                    void* stream) {
   if (n_atoms < 0 || B < 0 || H <= 0 || W <= 0) return DVA_ERR_INVALID;
-  if ((int64_t)B * H * W > 0x7fffffffLL || n_atoms > 0x1fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if ((int64_t)B * (H + 1) * (W + 1) >= 0x7fffffffLL || n_atoms > 0x1fffffffLL) return DVA_ERR_UNSUPPORTED;
   if (n_atoms == 0) return DVA_OK;
   if (!packed_idx || !coords || !rows || !weights) return DVA_ERR_INVALID;
   hipLaunchKernelGGL(bilinear_taps_kernel, dim3(grid_for(n_atoms)), dim3(256), 0, (hipStream_t)stream,
-                     (const PackedIdx*)packed_idx, coords, n_atoms, H, W, rows, weights);
+                     (const PackedIdx*)packed_idx, coords, n_atoms, H, W, rows, weights, anchors,
+                     (int32_t)((int64_t)B * (H + 1) * (W + 1)));
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_anchor_combine(const float* S, float* grad_rows, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return DVA_ERR_INVALID;
+  if (B == 0) return DVA_OK;
+  if (!S || !grad_rows) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(anchor_combine_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, S, grad_rows, (int)B, (int)H, (int)W, (int)C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_anchor_fixup(const void* grad, const int32_t* rows, const float* weights, const int32_t* anchors,
+                     float* grad_rows, int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                     void* stream) {
+  if (n_atoms < 0 || C <= 0 || (dtype != DVA_F32 && dtype != DVA_BF16)) return DVA_ERR_INVALID;
+  if (n_atoms == 0) return DVA_OK;
+  if (!grad || !rows || !weights || !anchors || !grad_rows) return DVA_ERR_INVALID;
+  const int32_t dummy = (int32_t)((int64_t)B * (H + 1) * (W + 1));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((anchor_fixup_kernel<float>), dim3(grid_for(n_atoms)), dim3(256), 0, s, (const float*)grad, rows,
+                       weights, anchors, dummy, grad_rows, n_atoms, (int)C);
+  else
+    hipLaunchKernelGGL((anchor_fixup_kernel<bf16_t>), dim3(grid_for(n_atoms)), dim3(256), 0, s, (const bf16_t*)grad,
+                       rows, weights, anchors, dummy, grad_rows, n_atoms, (int)C);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

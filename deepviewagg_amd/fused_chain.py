@@ -146,6 +146,80 @@ def _set_branch_backward(saved, dt, dWc, training, zstats, arena):
     return dpooled, [dWsa, g1, b1, dWsb, g2, b2]
 
 
+def chain_prologue(module, x_map, csr_idx):
+    """Everything of a chain forward that does not depend on the values: tile table, view -> point index, weight
+    operands, the statistics passes of the four BatchNorm layers of DeepSetFeat (train mode), the set branch.
+    Returns a namespace with the tensors the fused view kernel and the backward need (shared by the nearest path
+    below and the bilinear path of fused_bilinear.py)."""
+    from types import SimpleNamespace
+    lib = _lib.load()
+    e_map, e_score, gate = module.E_map, module.E_score, module.G
+    dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
+    st = stream_of(x_map)
+    training = e_map.training
+    W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
+    W2 = e_map.mlp_elt_1[1][0].weight.detach().contiguous()
+    W5 = e_map.mlp_elt_2[0][0].weight.detach().contiguous()       # [32, 64]: per-view half | per-point half
+    W6 = e_map.mlp_elt_2[1][0].weight.detach().contiguous()
+    Ws, bs = e_score.weight.detach().contiguous(), e_score.bias.detach().contiguous()
+    G = Ws.shape[0]
+    bns = [_bn_of(e_map.mlp_elt_1[0]), _bn_of(e_map.mlp_elt_1[1]),
+           _bn_of(e_map.mlp_elt_2[0]), _bn_of(e_map.mlp_elt_2[1])]
+    gw = gate.weight.detach().reshape(-1).float().contiguous() if gate is not None else None
+    gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
+
+    zpool = iter(torch.zeros((10, 3 * D), dtype=torch.float64, device=dev))   # sum | sum of squares | input sums
+
+    def zstats():
+        return next(zpool)
+
+    with ops._timed("chain_tiles", N * 8):
+        tiles, n_tiles = build_tiles(csr_idx, V)
+        vp = torch.empty(V, dtype=torch.int32, device=dev)
+        check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
+    wops = torch.empty(OPS_BYTES, dtype=torch.uint8, device=dev)
+    check(lib.dva_chain_prep(ptr(W1), ptr(W2), ptr(W5), W5.shape[1], ptr(W6), ptr(Ws), G, ptr(wops), st),
+          "dva_chain_prep")
+    # ---- layer 1: statistics from the moments of x_map
+    s1 = zstats()
+    mom = torch.zeros(44, dtype=torch.float64, device=dev)
+    if training:
+        with ops._timed("chain_moments", V * 32):
+            check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), ptr(mom), ptr(s1), st), "dva_chain_moments")
+    bn1 = _chain_bn(s1, V, bns[0], training, W1, 8, mom)           # mom[:8] = sum of x_map
+    # ---- layer 2: statistics + set pooling
+    s2 = zstats()
+    zstar = torch.empty((N, D), dtype=torch.float32, device=dev)
+    arg = torch.empty((N, D), dtype=torch.int32, device=dev)
+    with ops._timed("chain_stats2", V * 36 + N * 256):
+        check(lib.dva_chain_stats2(ptr(x_map), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1),
+                                   ptr(bns[1].weight.detach()), ptr(s2), ptr(zstar), ptr(arg), V, st),
+              "dva_chain_stats2")
+    bn2 = _chain_bn(s2, V, bns[1], training, W2, D, s2[2 * D:])    # stats2 also sums the layer's input a1
+    pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
+    check(lib.dva_chain_pooled(ptr(zstar), ptr(bn2), ptr(csr_idx), ptr(pooled), N, st), "dva_chain_pooled")
+    t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats)
+    # ---- layers 5, 6: statistics (train mode)
+    s5, s6 = zstats(), zstats()
+    if training:
+        with ops._timed("chain_stats5", V * 36 + N * 128):
+            check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                      ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
+    bn5 = _chain_bn(s5, V, bns[2], training)                       # layer 5 is not folded
+    if training:
+        with ops._timed("chain_stats6", V * 36 + N * 128):
+            check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                      ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
+    bn6 = _chain_bn(s6, V, bns[3], training, W6, D, s6[2 * D:])
+    return SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
+                           bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, bs=bs, gw=gw, gb=gb, W1=W1, G=G, training=training,
+                           set_saved=set_saved)
+
+
+# order of the chain's tensors in ctx.saved_tensors (after the path's own): tests/test_gpu_chain.py reads bn1 ..., scores
+CHAIN_SAVED = ("vp", "tiles", "n_tiles", "wops", "t_add", "zstar", "arg", "mom", "bn1", "bn2", "bn5", "bn6")
+
+
 class _ChainPool(torch.autograd.Function):
     """params: Wa, g1, b1, Wb, g2, b2, Wc, g3, b3, Wd, g4, b4, Ws, bs, gate_w, gate_b (or None), mlp_set params."""
 
@@ -153,67 +227,12 @@ class _ChainPool(torch.autograd.Function):
     def forward(ctx, rows, row_idx, plan, x_map, csr_idx, module, scaling, eps, *params):
         lib = _lib.load()
         require_device(rows, row_idx, x_map, csr_idx)
-        e_map, e_score, gate = module.E_map, module.E_score, module.G
         rows = rows.contiguous()
         x_map = x_map.contiguous()
         dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
         R, C = rows.shape
         st = stream_of(x_map)
-        training = e_map.training
-        W1 = e_map.mlp_elt_1[0][0].weight.detach().contiguous()
-        W2 = e_map.mlp_elt_1[1][0].weight.detach().contiguous()
-        W5 = e_map.mlp_elt_2[0][0].weight.detach().contiguous()       # [32, 64]: per-view half | per-point half
-        W6 = e_map.mlp_elt_2[1][0].weight.detach().contiguous()
-        Ws, bs = e_score.weight.detach().contiguous(), e_score.bias.detach().contiguous()
-        G = Ws.shape[0]
-        bns = [_bn_of(e_map.mlp_elt_1[0]), _bn_of(e_map.mlp_elt_1[1]),
-               _bn_of(e_map.mlp_elt_2[0]), _bn_of(e_map.mlp_elt_2[1])]
-        gw = gate.weight.detach().reshape(-1).float().contiguous() if gate is not None else None
-        gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
-
-        zpool = iter(torch.zeros((10, 3 * D), dtype=torch.float64, device=dev))   # sum | sum of squares | input sums
-
-        def zstats():
-            return next(zpool)
-
-        with ops._timed("chain_tiles", N * 8):
-            tiles, n_tiles = build_tiles(csr_idx, V)
-            vp = torch.empty(V, dtype=torch.int32, device=dev)
-            check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
-        wops = torch.empty(OPS_BYTES, dtype=torch.uint8, device=dev)
-        check(lib.dva_chain_prep(ptr(W1), ptr(W2), ptr(W5), W5.shape[1], ptr(W6), ptr(Ws), G, ptr(wops), st),
-              "dva_chain_prep")
-        # ---- layer 1: statistics from the moments of x_map
-        s1 = zstats()
-        mom = torch.zeros(44, dtype=torch.float64, device=dev)
-        if training:
-            with ops._timed("chain_moments", V * 32):
-                check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), ptr(mom), ptr(s1), st), "dva_chain_moments")
-        bn1 = _chain_bn(s1, V, bns[0], training, W1, 8, mom)           # mom[:8] = sum of x_map
-        # ---- layer 2: statistics + set pooling
-        s2 = zstats()
-        zstar = torch.empty((N, D), dtype=torch.float32, device=dev)
-        arg = torch.empty((N, D), dtype=torch.int32, device=dev)
-        with ops._timed("chain_stats2", V * 36 + N * 256):
-            check(lib.dva_chain_stats2(ptr(x_map), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1),
-                                       ptr(bns[1].weight.detach()), ptr(s2), ptr(zstar), ptr(arg), V, st),
-                  "dva_chain_stats2")
-        bn2 = _chain_bn(s2, V, bns[1], training, W2, D, s2[2 * D:])    # stats2 also sums the layer's input a1
-        pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
-        check(lib.dva_chain_pooled(ptr(zstar), ptr(bn2), ptr(csr_idx), ptr(pooled), N, st), "dva_chain_pooled")
-        t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats)
-        # ---- layers 5, 6: statistics (train mode)
-        s5, s6 = zstats(), zstats()
-        if training:
-            with ops._timed("chain_stats5", V * 36 + N * 128):
-                check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                          ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
-        bn5 = _chain_bn(s5, V, bns[2], training)                       # layer 5 is not folded
-        if training:
-            with ops._timed("chain_stats6", V * 36 + N * 128):
-                check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                          ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
-        bn6 = _chain_bn(s6, V, bns[3], training, W6, D, s6[2 * D:])
+        S = chain_prologue(module, x_map, csr_idx)
         # ---- the fused view kernel
         out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
         # a backward will follow: the scores of every view stay (16 bytes per view) -- the attention backward starts from
@@ -223,16 +242,16 @@ class _ChainPool(torch.autograd.Function):
         # SURVEY.md 8(d) fused view-gather + attention: V (C s + F_map 4 + idx) + N (C s + ptr); idx = view->point
         # index + row index (4 + 4), per point the set-branch row (128) on top (+ 16 bytes per view of scores out in training)
         with ops._timed("chain_attn_fwd", V * (C * 2 + 32 + 8 + (16 if need_bwd else 0)) + N * (C * 2 + 128 + 8)):
-            check(lib.dva_chain_attn_fwd(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                         ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(bs), ptr(rows), ptr(row_idx),
-                                         ptr(csr_idx), ptr(gw), ptr(gb), ptr(out), ptr(scores), N, V, R, C, G,
-                                         int(scaling), float(eps), st), "dva_chain_attn_fwd")
-        ctx.save_for_backward(rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
-                              bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1)
+            check(lib.dva_chain_attn_fwd(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
+                                         ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), ptr(rows),
+                                         ptr(row_idx), ptr(csr_idx), ptr(S.gw), ptr(S.gb), ptr(out), ptr(scores), N, V,
+                                         R, C, S.G, int(scaling), float(eps), st), "dva_chain_attn_fwd")
+        ctx.save_for_backward(rows, row_idx, x_map, csr_idx, S.vp, S.tiles, S.n_tiles, S.wops, S.t_add, S.zstar, S.arg,
+                              S.mom, S.bn1, S.bn2, S.bn5, S.bn6, out, scores, S.bs, S.gw, S.gb, S.W1)
         ctx.plan = plan
         ctx.module = module
-        ctx.set_saved = set_saved
-        ctx.training = training
+        ctx.set_saved = S.set_saved
+        ctx.training = S.training
         ctx.meta = (int(scaling), float(eps))
         return out
 
@@ -242,8 +261,8 @@ class _ChainPool(torch.autograd.Function):
         return fused_chain_bwd.backward(ctx, gout)
 
 
-def chain_pool(module, x_mod, x_map, csr_idx):
-    """``module`` = GroupBimodalCSRPool, ``x_mod`` = ops.GatheredFeatures whose rows are already E_mod(rows)."""
+def chain_params(module):
+    """The parameters of the chain in the order of the gradients fused_chain_bwd.chain_epilogue returns."""
     e_map, e_score, gate = module.E_map, module.E_score, module.G
     blocks = (e_map.mlp_elt_1[0], e_map.mlp_elt_1[1], e_map.mlp_elt_2[0], e_map.mlp_elt_2[1])
     params = []
@@ -253,6 +272,11 @@ def chain_pool(module, x_mod, x_map, csr_idx):
     params += [e_score.weight, e_score.bias]
     params += [gate.weight, gate.bias] if gate is not None else [None, None]
     params += list(e_map.mlp_set.parameters())
+    return params
+
+
+def chain_pool(module, x_mod, x_map, csr_idx):
+    """``module`` = GroupBimodalCSRPool, ``x_mod`` = ops.GatheredFeatures whose rows are already E_mod(rows)."""
     csr_idx = ops._check_ptr(csr_idx)
     return _ChainPool.apply(x_mod.rows, x_mod.row_idx.contiguous(), x_mod.plan, x_map, csr_idx, module,
-                            module.group_scaling, 1e-12, *params)
+                            module.group_scaling, 1e-12, *chain_params(module))

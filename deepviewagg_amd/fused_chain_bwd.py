@@ -35,27 +35,21 @@ def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=Tru
     return sm, dg, db
 
 
-def backward(ctx, gout):
+def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
+    """Everything of a chain backward behind the attention backward (which is specific to how the values are
+    produced): score layer + BatchNorm-6 statistics, the three layer passes, the per-point set branch, layer 1.
+    ``S``: namespace with vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, W1, G, training.
+    ``dc`` fp32 [V, 4] score gradients (consumed), ``gwb`` fp32 [2 G] gate gradients or None.
+    Returns the gradients in the order of fused_chain.chain_params(module)."""
     from .fused_chain import _set_branch_backward
-    lib = _lib.load()
-    if ctx.set_saved is None:
-        raise RuntimeError("the recompute chain's backward ran twice on the same graph: its per-step workspaces are "
-                           "released after the first backward (retain_graph is not supported on this path)")
-    (rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
-     bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1) = ctx.saved_tensors
-    module, training = ctx.module, ctx.training
-    scaling, eps = ctx.meta
-    e_map, e_score, gate = module.E_map, module.E_score, module.G
+    e_map, gate = module.E_map, module.G
     dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
-    R, C = rows.shape
-    G = e_score.weight.shape[0]
+    G, training = S.G, S.training
+    vp, tiles, n_tiles, wops, t_add = S.vp, S.tiles, S.n_tiles, S.wops, S.t_add
+    bn1, bn2, bn5, bn6 = S.bn1, S.bn2, S.bn5, S.bn6
     st = stream_of(x_map)
-    gout = gout.contiguous().to(torch.bfloat16)
     m_rows = float(max(V, 1))
-    # bs, gw, gb, W1: the values the forward used (frozen with the operand table and the BatchNorm tables)
-
     zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
-    arena = Arena(dev)          # every small fp32 accumulator / gradient of this backward: one zero fill
 
     def zstats():
         return next(zpool)
@@ -65,17 +59,6 @@ def backward(ctx, gout):
         then (sm = S / M for the next pass, d gamma = S2, d beta = S1)."""
         return bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat, out)
 
-    # ---- attention + gate backward from the scores the forward left: score gradients, view records (no chain)
-    dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
-    rec = torch.empty((V, 4), dtype=torch.int32, device=dev)       # 16-byte records: point | 4 x bf16 weight | pad
-    gwb = arena.take(2 * G) if gate is not None else None
-    # per view: value row + scores 16 + view->point / row index 8 in, score gradients 16 + record 16 out; per point
-    # grad_out row (+ out row for points with more than 32 views)
-    with ops._timed("chain_attn_bwd", V * (C * 2 + 16 + 8 + 16 + 16) + N * (C * 2 + 8)):
-        check(lib.dva_chain_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx),
-                                     ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
-                                     ptr(gwb), N, V, R, C, G, scaling, eps, st), "dva_chain_attn_bwd")
-    del scores
     # ---- score layer: dWs, dbs, and the statistics of the BatchNorm-6 backward (one chain evaluation)
     s6 = zstats()
     dWs, dbs = arena.take(G, D), arena.take(G)
@@ -83,17 +66,6 @@ def backward(ctx, gout):
         check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                         ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
                                         G, V, N, st), "dva_chain_score_stats")
-    # ---- rows gradient: segmented reduction over the row plan (deterministic, no atomics)
-    grows = None
-    if ctx.needs_input_grad[0]:
-        plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
-        perm, row_ptr = plan
-        grows = torch.empty((R, C), dtype=torch.float32, device=dev)
-        with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
-            check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), R, V, C,
-                                                      G, _lib.DVA_BF16, st), "dva_view_gather_rows_grad_rec16")
-        grows = grows.to(rows.dtype)
-    del rec
 
     def layer(stage, sm2, sm5, sm6, arg_, dpooled_, da_in, da_out, dW, du, P, stats, name, nbytes):
         with ops._timed(name, nbytes):
@@ -110,38 +82,80 @@ def backward(ctx, gout):
     da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
     layer(6, None, None, sm6, None, None, None, da5, dW6, None, None, s5, "chain_bwd_l6",
           V * (32 + 4 + 16 + 64) + N * 128)
-    del dc
     sm5, g5, b5 = consts(s5, bn5)
     dW5 = arena.take(D, 2 * D)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
     s2 = zstats()
     da2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
-    dc = None
     layer(5, None, sm5, None, None, None, da5, da2, dW5, du, None, s2, "chain_bwd_l5",
           V * (32 + 4 + 64 + 64) + N * 256)
     del da5
     # ---- per-point set branch
-    dpooled, d_set = _set_branch_backward(ctx.set_saved, du, dW5, training, zstats, arena)
+    dpooled, d_set = _set_branch_backward(set_saved, du, dW5, training, zstats, arena)
     consts(s2, bn2, out=False)            # view part; the per-point part below is accumulated in z_hat directly
     dpooled_dy = torch.empty((N, D), dtype=torch.float32, device=dev)     # leaky'(y*) dpooled: what stage 2 routes
-    check(lib.dva_chain_route_stats(ptr(zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), ptr(dpooled_dy), N,
+    check(lib.dva_chain_route_stats(ptr(S.zstar), ptr(dpooled), ptr(bn2), ptr(csr_idx), ptr(s2), ptr(dpooled_dy), N,
                                     st), "dva_chain_route_stats")
     sm2, g2, b2 = consts(s2, bn2, hat=False)
     dW2, P = arena.take(D, D), arena.take(D, 20)       # P = sum dy1 [x_hi | x_lo | 1]^T
     s1 = zstats()
-    layer(2, sm2, None, None, arg, dpooled_dy, da2, None, dW2, None, P, None, "chain_bwd_l2",
+    layer(2, sm2, None, None, S.arg, dpooled_dy, da2, None, dW2, None, P, None, "chain_bwd_l2",
           V * (32 + 4 + 64) + N * 256)
     del da2
-    check(lib.dva_chain_stats1(ptr(P), ptr(W1), ptr(s1), st), "dva_chain_stats1")    # layer 1 is linear in x_map
+    check(lib.dva_chain_stats1(ptr(P), ptr(S.W1), ptr(s1), st), "dva_chain_stats1")    # layer 1 is linear in x_map
     sm1, g1, b1 = consts(s1, bn1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so
     #      dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q) with Q = sum_v z1_hat x^T from the moments of x_map
     dW1 = arena.take(D, 8)
-    check(lib.dva_chain_dw1(ptr(P), ptr(mom), ptr(W1), ptr(bn1), ptr(sm1), ptr(dW1), st), "dva_chain_dw1")
+    check(lib.dva_chain_dw1(ptr(P), ptr(S.mom), ptr(S.W1), ptr(bn1), ptr(sm1), ptr(dW1), st), "dva_chain_dw1")
     if gate is not None:
         dgw, dgb = gwb[:G].reshape(gate.weight.shape), gwb[G:].reshape(gate.bias.shape)
     else:
         dgw = dgb = None
-    grads = [dW1, g1, b1, dW2, g2, b2, dW5, g5, b5, dW6, g6, b6, dWs, dbs, dgw, dgb] + d_set
+    return [dW1, g1, b1, dW2, g2, b2, dW5, g5, b5, dW6, g6, b6, dWs, dbs, dgw, dgb] + d_set
+
+
+def backward(ctx, gout):
+    from types import SimpleNamespace
+    lib = _lib.load()
+    if ctx.set_saved is None:
+        raise RuntimeError("the recompute chain's backward ran twice on the same graph: its per-step workspaces are "
+                           "released after the first backward (retain_graph is not supported on this path)")
+    (rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
+     bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1) = ctx.saved_tensors
+    module, training = ctx.module, ctx.training
+    scaling, eps = ctx.meta
+    gate = module.G
+    dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
+    R, C = rows.shape
+    G = module.E_score.weight.shape[0]
+    st = stream_of(x_map)
+    gout = gout.contiguous().to(torch.bfloat16)
+    S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
+                        bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G, training=training)
+    arena = Arena(dev)          # every small fp32 accumulator / gradient of this backward: one zero fill
+    # ---- attention + gate backward from the scores the forward left: score gradients, view records (no chain)
+    dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
+    rec = torch.empty((V, 4), dtype=torch.int32, device=dev)       # 16-byte records: point | 4 x bf16 weight | pad
+    gwb = arena.take(2 * G) if gate is not None else None
+    # per view: value row + scores 16 + view->point / row index 8 in, score gradients 16 + record 16 out; per point
+    # grad_out row (+ out row for points with more than 32 views)
+    with ops._timed("chain_attn_bwd", V * (C * 2 + 16 + 8 + 16 + 16) + N * (C * 2 + 8)):
+        check(lib.dva_chain_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx),
+                                     ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
+                                     ptr(gwb), N, V, R, C, G, scaling, eps, st), "dva_chain_attn_bwd")
+    del scores
+    # ---- rows gradient: segmented reduction over the row plan (deterministic, no atomics)
+    grows = None
+    if ctx.needs_input_grad[0]:
+        plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
+        perm, row_ptr = plan
+        grows = torch.empty((R, C), dtype=torch.float32, device=dev)
+        with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
+            check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), R, V, C,
+                                                      G, _lib.DVA_BF16, st), "dva_view_gather_rows_grad_rec16")
+        grows = grows.to(rows.dtype)
+    del rec
+    grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
     ctx.set_saved = None
     return (grows, None, None, None, None, None, None, None) + tuple(grads)

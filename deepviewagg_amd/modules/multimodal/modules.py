@@ -254,7 +254,7 @@ class UnimodalBranch(nn.Module):
             if all(isinstance(x, ops.GatheredFeatures) for x in x_mod):
                 x_mod = ops.GatheredFeatures.cat(x_mod, order=order)
             else:
-                x_mod = torch.cat([x.materialize() if isinstance(x, ops.GatheredFeatures) else x
+                x_mod = torch.cat([x.materialize() if isinstance(x, ops.LAZY_TYPES) else x
                                    for x in x_mod], dim=0)[order]
             x_map = torch.cat(mod_data.mapping_features, dim=0)[order]
             csr_idx = mod_data.view_cat_csr_indexing
@@ -263,7 +263,7 @@ class UnimodalBranch(nn.Module):
             csr_idx = mod_data.view_csr_indexing
         if self.keep_last_view:
             # reference consumers (applications/multimodal/no3d.py:128, view losses) expect the [V, C] tensor
-            mod_data.last_view_x_mod = x_mod.materialize() if isinstance(x_mod, ops.GatheredFeatures) else x_mod
+            mod_data.last_view_x_mod = x_mod.materialize() if isinstance(x_mod, ops.LAZY_TYPES) else x_mod
             mod_data.last_view_x_map = x_map
             mod_data.last_view_csr_idx = csr_idx
         if 'v' in self.checkpointing and isinstance(x_mod, torch.Tensor):
@@ -284,7 +284,7 @@ class UnimodalBranch(nn.Module):
             x_mod = self.drop_mod(x_mod)
             if self.keep_last_view:
                 last = mod_data.last_view_x_mod
-                last = last.materialize() if isinstance(last, ops.GatheredFeatures) else last
+                last = last.materialize() if isinstance(last, ops.LAZY_TYPES) else last
                 mod_data.last_view_x_mod = self.drop_mod(last)
         return x_3d, x_mod, mod_data
 

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from ...core.common_modules import MLP
 from ... import ops
-from ... import fused_deepset, fused_chain
+from ... import fused_deepset, fused_chain, fused_bilinear
 from ...ops import (segment_csr, gather_csr, segment_gather_csr,  # noqa: F401 (re-exported)
                     segment_softmax_csr)
 
@@ -36,7 +36,7 @@ def _dense_index(csr_idx, device):
 
 
 def _materialize(x_mod):
-    return x_mod.materialize() if isinstance(x_mod, ops.GatheredFeatures) else x_mod
+    return x_mod.materialize() if isinstance(x_mod, ops.LAZY_TYPES) else x_mod
 
 
 def batchnorm_act_rows(y, bn, slope, counts=None, n=None):
@@ -180,7 +180,7 @@ class BimodalCSRPool(nn.Module, _SaveLast):
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map] (unused), csr_idx [N+1]."""
-        if isinstance(x_mod, ops.GatheredFeatures):
+        if isinstance(x_mod, ops.LAZY_TYPES):
             if x_map is None and x_mod.exact and csr_idx.shape[0] - 1 == x_mod.shape[0]:
                 # ATOMIC pooling (UnimodalBranch passes x_map=None there) of an exact mapping (one pixel
                 # per view, atomic CSR = arange): every group holds exactly one row, so max / min / mean
@@ -316,6 +316,12 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
         val_rows = None
+        if isinstance(x_mod, ops.InterpolatedFeatures):
+            # bilinear gather (interpolate=True): E_mod per view inside the chain kernels, its first Linear on the map
+            # rows (fused_bilinear.py); anything the fused path does not cover materialises the reference's [V, C]
+            if fused_bilinear.applicable(self, x_mod, x_map, csr_idx):
+                return fused_bilinear.pool(self, x_mod, x_map, csr_idx)
+            x_mod = x_mod.materialize()
         if isinstance(x_mod, ops.GatheredFeatures) and fused_chain.applicable(self, x_mod, x_map, csr_idx):
             # bf16 recompute chain: E_mod on the map rows, then ONE view kernel (DeepSetFeat scores, softmax,
             # row gather, weighted sum, gate) -- no [V, .] activation tensor at all (fused_chain.py)

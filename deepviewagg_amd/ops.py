@@ -396,6 +396,35 @@ def gather_nearest(x, packed_idx):
     return _GatherNearest.apply(x, packed_idx)
 
 
+def _anchor_ok(C, dtype):
+    vec = 4 if dtype == torch.float32 else 8
+    lpr = C // vec
+    return C % vec == 0 and lpr > 0 and (lpr & (lpr - 1)) == 0 and lpr <= 64
+
+
+def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W):
+    """Transpose of the bilinear gather: fp32 [B*H*W, C] = sum over the views and their 4 taps of weight x grad row.
+    Views are grouped by ANCHOR (the padded cell of their top-left tap, ``dva_gather_bilinear_taps_anchor``): one
+    sort of P keys, every gradient row read once into four per-anchor sums, then a 2 x 2 stencil on the map
+    (csrc/attention.hip anchor_rows_sum_kernel, csrc/gather.hip anchor_combine_kernel).  Deterministic."""
+    lib = _lib.load()
+    grad = grad.contiguous()
+    P, C = grad.shape
+    n_anchor = B * (H + 1) * (W + 1) + 1            # + the dummy anchor of views without the 2 x 2 structure
+    (perm, row_ptr), _ = row_plan(anchors, n_anchor, with_counts=False)
+    S = torch.empty((n_anchor, 4, C), dtype=torch.float32, device=grad.device)
+    st = stream_of(grad)
+    with _timed("bilinear_anchor_sum", P * (C * grad.element_size() + 20) + n_anchor * 4 * C * 4):
+        check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(row_ptr), ptr(tap_weights), ptr(S), n_anchor, P, C,
+                                      dtype_code(grad), st), "dva_anchor_rows_sum")
+    out = torch.empty((B * H * W, C), dtype=torch.float32, device=grad.device)
+    with _timed("bilinear_anchor_combine", n_anchor * 4 * C * 4 + B * H * W * C * 4):
+        check(lib.dva_anchor_combine(ptr(S), ptr(out), B, H, W, C, st), "dva_anchor_combine")
+        check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, B, H, W, C,
+                                   dtype_code(grad), st), "dva_anchor_fixup")
+    return out
+
+
 class _GatherBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, packed, coords):
@@ -424,8 +453,13 @@ class _GatherBilinear(torch.autograd.Function):
             # reduction: deterministic, no fp32 atomics
             rows4 = torch.empty(4 * P, dtype=torch.int32, device=gout.device)
             w4 = torch.empty(4 * P, dtype=torch.float32, device=gout.device)
-            check(lib.dva_gather_bilinear_taps(ptr(packed), ptr(coords), P, B, H, W, ptr(rows4), ptr(w4),
-                                               stream_of(gout)), "dva_gather_bilinear_taps")
+            anchors = torch.empty(P, dtype=torch.int32, device=gout.device) if _anchor_ok(C, gout.dtype) else None
+            check(lib.dva_gather_bilinear_taps_anchor(ptr(packed), ptr(coords), P, B, H, W, ptr(rows4), ptr(w4),
+                                                      ptr(anchors), stream_of(gout)), "dva_gather_bilinear_taps_anchor")
+            if anchors is not None:
+                # grouped by anchor instead: P keys to sort, every gradient row read once (bilinear_scatter)
+                gx = bilinear_scatter(gout, rows4, w4, anchors, B, H, W).view(B, H, W, C)
+                return gx.permute(0, 3, 1, 2).to(dt), None, None
             (perm, row_ptr), _ = row_plan(rows4, B * H * W, with_counts=False)
             gx = torch.empty((B, H, W, C), dtype=torch.float32, device=gout.device)
             with _timed("gather_bilinear_bwd", 4 * P * (C * gout.element_size() + 12) + B * H * W * C * 4):
@@ -594,6 +628,62 @@ def lazy_gather_nearest_mapping(x, images, atom_ptr, pixels, ratio, exact):
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
     row_idx, counts, plan = mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W)
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
+
+
+class InterpolatedFeatures:
+    """Result of a BILINEAR view gather (``sparse_interpolation``, reference image.py:105-170) that has not been
+    materialised: ``x_mod[p] = sum_k tap_weights[p, k] * rows[tap_rows[p, k]]`` over the 4 corner taps.
+
+    ``rows`` is the [R, C] row view of the channels-last feature maps (a differentiable function of the 2D encoder
+    output), ``tap_rows`` int32 [P, 4] / ``tap_weights`` fp32 [P, 4] the taps of ``dva_gather_bilinear_taps`` (border
+    replicated: clamped rows).  A consumer that understands this type (GroupBimodalCSRPool through
+    ``fused_bilinear``) evaluates E_mod per view inside its kernels -- the first Linear commutes with the
+    interpolation and runs on the R map rows; everything else calls ``materialize()`` and gets the reference's
+    [P, C] tensor.  ``exact``: every view owns exactly one atom (P == V): the atomic pool is the identity."""
+
+    def __init__(self, x, packed_idx, coords, tap_rows, tap_weights, anchors, exact):
+        self.x, self.packed_idx, self.coords, self.exact = x, packed_idx, coords, exact
+        self.tap_rows, self.tap_weights, self.anchors = tap_rows, tap_weights, anchors
+        B, C, H, W = x.shape
+        self.rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)      # view when x is channels_last
+
+    @property
+    def shape(self):
+        return torch.Size((self.tap_rows.shape[0], self.rows.shape[1]))
+
+    @property
+    def device(self):
+        return self.rows.device
+
+    @property
+    def dtype(self):
+        return self.rows.dtype
+
+    def dim(self):
+        return 2
+
+    def materialize(self):
+        return gather_bilinear(self.x, self.packed_idx, self.coords)
+
+
+def lazy_gather_bilinear(x, packed_idx, coords, exact):
+    """Lazy counterpart of ``gather_bilinear``: the taps are computed, no [P, C] tensor is produced."""
+    assert x.dim() == 4 and coords.dim() == 2 and coords.shape[1] == 2
+    lib = _lib.load()
+    require_device(x, packed_idx, coords)
+    B, C, H, W = x.shape
+    coords = coords.float().contiguous()
+    P = packed_idx.shape[0]
+    rows4 = torch.empty((P, 4), dtype=torch.int32, device=x.device)
+    w4 = torch.empty((P, 4), dtype=torch.float32, device=x.device)
+    anchors = torch.empty(P, dtype=torch.int32, device=x.device)
+    with _timed("bilinear_taps", P * (16 + 36)):
+        check(lib.dva_gather_bilinear_taps_anchor(ptr(packed_idx), ptr(coords), P, B, H, W, ptr(rows4), ptr(w4),
+                                                  ptr(anchors), stream_of(x)), "dva_gather_bilinear_taps_anchor")
+    return InterpolatedFeatures(x, packed_idx, coords, rows4, w4, anchors, exact)
+
+
+LAZY_TYPES = (GatheredFeatures, InterpolatedFeatures)     # what .materialize() turns into the reference's [P, C] tensor
 
 
 class _GatherRows(torch.autograd.Function):

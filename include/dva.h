@@ -214,6 +214,22 @@ int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, c
 int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
                         const float* weights, int32_t atom_shift, float* grad_rows, int64_t n_rows,
                         int64_t n_atoms, int32_t C, int32_t dtype, void* stream);
+/* The bilinear backward over the ANCHOR plan (3 x fewer sorted keys, every gradient row read once instead of four
+ * times): anchors int32 [n_atoms] from dva_gather_bilinear_taps_anchor = the cell (top, left) of the view's 2 x 2 tap
+ * block on the replication-padded grid, (img (H + 1) + top) (W + 1) + left; views without that structure carry the
+ * dummy anchor B (H + 1) (W + 1).  Plan = dva_row_plan(anchors, B (H + 1) (W + 1) + 1).
+ *   dva_anchor_rows_sum: S fp32 [n_anchors][4][C] (written) = per anchor and tap the weighted sum of grad_out rows;
+ *   dva_anchor_combine:  grad_rows fp32 [B*H*W][C] (written) from S (pass the S of the first B (H+1) (W+1) anchors);
+ *   dva_anchor_fixup:    += the taps of the dummy-anchor views (fp32 atomics; none on real data). */
+int dva_gather_bilinear_taps_anchor(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
+                                    int32_t H, int32_t W, int32_t* rows, float* weights, int32_t* anchors,
+                                    void* stream);
+int dva_anchor_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, const float* weights,
+                        float* S, int64_t n_anchors, int64_t n_views, int32_t C, int32_t dtype, void* stream);
+int dva_anchor_combine(const float* S, float* grad_rows, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int dva_anchor_fixup(const void* grad, const int32_t* rows, const float* weights, const int32_t* anchors,
+                     float* grad_rows, int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                     void* stream);
 /* rows int32 [4 * n_atoms], weights fp32 [4 * n_atoms]: corner rows (tl, tr, bl, br) of the [B*H*W, C] map and
  * bilinear weights of every atom, exactly the taps of dva_gather_bilinear_fwd (image.py:138-165). */
 int dva_gather_bilinear_taps(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
@@ -408,6 +424,51 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
                        const int32_t* row_idx, const int64_t* ptr, const float* gate_w, const float* gate_b,
                        void* out, float* scores_out, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C,
                        int32_t G, int32_t scaling, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Recompute chain with a per-view E_mod: the fused path of the BILINEAR gather (interpolate=True;
+ * reference core/multimodal/image.py:105-170 sparse_interpolation + modules/multimodal/pooling.py:245,275 E_mod per
+ * view; csrc/chain_emod.hip).  The first Linear of E_mod commutes with the interpolation and runs on the map rows
+ * (caller): Y bf16 [n_rows][C_out] = rows W_a^T in POSITION order (position 32 b + 16 h + r = channel
+ * 32 b + (r & 3) + 8 (r >> 2) + 4 h: the 16 channels a lane owns are contiguous).  Per view: the 4 taps
+ * tap_rows int32 [V][4] / tap_weights fp32 [V][4] (dva_gather_bilinear_taps) of Y -> z_a -> BatchNorm_a ->
+ * LeakyReLU(0.2) -> Linear_b on the matrix cores -> BatchNorm_b -> LeakyReLU = the value of the view.
+ * C_out in {32, 64}, G in {1, 2, 4}.  bn_a / bn_b fp32 [4][C_out] = mean | invstd | gamma | beta (dva_bn_finalize),
+ * natural channel order; statistics fp64 [2][C_out] caller-zeroed; tiles / view_point / scores / chain arguments as
+ * for the dva_chain_* entries.
+ * ------------------------------------------------------------------------------------------ */
+/* eops: 2 * (C_out / 32)^2 * 2 KiB: Linear_b's weight W_b fp32 [C_out][C_out] as bf16 matrix-core operands
+ * (forward blocks, then the transposed blocks of the input gradient). */
+int dva_emod_prep(const float* Wb, int32_t C_out, void* eops, void* stream);
+/* layer 1: stats += sum z_a | sum z_a^2 (eops, bn_a unused);  layer 2: stats += sum z_b | sum z_b^2. */
+int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
+                   const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, int64_t n_views,
+                   int64_t n_rows, int32_t C_out, void* stream);
+/* The fused view kernel: x_map + taps of Y -> out bf16 [N][C_out] (caller-zeroed) = gate * sum_v softmax_v(scores)
+ * E_mod(view v); scores_out as dva_chain_attn_fwd. */
+int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                      const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                      const float* bn6, const float* score_bias, const void* Y, const int32_t* tap_rows,
+                      const float* tap_weights, const void* eops, const float* bn_a, const float* bn_b,
+                      const int64_t* ptr, const float* gate_w, const float* gate_b, void* out, float* scores_out,
+                      int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling,
+                      float eps, void* stream);
+/* Attention + gate backward from the stored scores with E_mod re-evaluated: grad_scores, view_rec, grad_gate_wb as
+ * dva_chain_attn_bwd; stats_b += S1 | sum dy_b z_b of the BatchNorm_b backward. */
+int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                      const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* eops,
+                      const float* bn_a, const float* bn_b, const int64_t* ptr, const float* gate_w,
+                      const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
+                      float* grad_gate_wb, double* stats_b, int64_t n_points, int64_t n_views, int64_t n_rows,
+                      int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream);
+/* E_mod backward.  stage 2: view_rec + grad_out -> dWb fp32 [C_out][C_out] (caller-zeroed) += the gradient of W_b,
+ * da bf16 [V][C_out] (position order) = leaky'(y_a) W_b^T dz_b, stats_a += S1 | sum dy_a z_a  (sm_b = S / M of
+ * BatchNorm_b).  stage 1: da <- dz_a = BatchNorm_a backward of da in place (sm_a); the gradient of Y follows as
+ * dva_gather_rows_sum(da, row plan of tap_rows, tap_weights, atom_shift 2). */
+int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
+                 const int32_t* n_tiles, const void* eops, const float* bn_a, const float* bn_b, const float* sm_a,
+                 const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,
+                 int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, void* stream);
 
 /* The arithmetic between two BatchNorm-backward passes as one launch.  stats fp64 [2C] = S1 | S2, bn fp32 [4][C] =
  * mean | invstd | gamma | beta.  do_hat: S2 arrives as sum dy z (raw layer output) and becomes

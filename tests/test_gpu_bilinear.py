@@ -1,0 +1,195 @@
+"""-m gpu: the fused bilinear path (interpolate=True; csrc/chain_emod.hip through fused_bilinear.py) against the CPU
+oracle (sparse_interpolation + per-view E_mod + GroupBimodalCSRPool, reference core/multimodal/image.py:105-170,
+modules/multimodal/pooling.py:263-315) and against the materialised device dataflow (gather_bilinear -> [V, C] ->
+E_mod through the row kernels -> first-generation attention kernels).
+
+Tolerances (bf16 operands on the matrix cores, like the reference under torch.autocast(bfloat16)): output relative
+L2 <= max(2e-2, 1.5 x the oracle's own autocast error); gradients <= max(2 x (4 x gate / score) autocast error, 5e-2)
+per tensor, the yardstick of the E_map / E_mod parameters floored by its median over them (tests/test_gpu_chain.py)."""
+import pytest
+import torch
+
+from oracle import pooling_oracle as O
+from test_gpu_chain import rel, ragged, ragged_long, full32
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+UP = 8          # mapping resolution = UP x feature-map resolution
+
+
+def make_case(seed, N, C_in, sizes_fn, B=3, H=12, W=20):
+    gen = torch.Generator().manual_seed(seed)
+    sizes = sizes_fn(N, gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    images = torch.randint(0, B, (V,), generator=gen)
+    msize = (W * UP, H * UP)
+    pixels = torch.stack([torch.randint(0, msize[0], (V,), generator=gen),
+                          torch.randint(0, msize[1], (V,), generator=gen)], 1).short()
+    # image borders (replicated padding) are hit on purpose
+    pixels[:8, 0] = torch.tensor([0, 0, msize[0] - 1, msize[0] - 1, 1, msize[0] - 2, 0, 5])
+    pixels[:8, 1] = torch.tensor([0, msize[1] - 1, 0, msize[1] - 1, 1, msize[1] - 2, 7, 0])
+    x = torch.randn(B, C_in, H, W, generator=gen).bfloat16().float()
+    x_map = torch.rand(V, 8, generator=gen)
+    return dict(gen=gen, csr=csr, V=V, images=images, pixels=pixels, x=x, x_map=x_map, N=N, C=C_in, msize=msize)
+
+
+def build(case, C_out, G, train, gating=True, seed=5, wscale=0.3):
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    gen = torch.Generator().manual_seed(seed)
+    kwargs = dict(in_map=8, in_mod=case["C"], out_mod=C_out, num_groups=G, use_num=True, gating=gating)
+    ref = O.GroupBimodalCSRPool(**kwargs)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * wscale)
+            if "batch_norm.weight" in n or n == "G.weight":
+                p.add_(1.0)
+        for n, b in ref.named_buffers():
+            if "running_mean" in n:
+                b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
+            if "running_var" in n:
+                b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+    ref.train(train)
+    m = P.GroupBimodalCSRPool(**kwargs)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    return ref, m.to(DEV).train(train)
+
+
+def run_dev(case, m, w, fused, need_grad=True):
+    from deepviewagg_amd import ops, fused_chain
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    V = case["V"]
+    xd = case["x"].to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(need_grad)
+    atom_ptr = torch.arange(V + 1, device=DEV)
+    packed = ops.pack_gather_index(case["images"].to(DEV), atom_ptr, case["pixels"].to(DEV))
+    res = torch.tensor([case["msize"]], dtype=torch.float32, device=DEV)
+    coords = (case["pixels"].to(DEV) / (res - 1))[:, [1, 0]]
+    fused_chain.FORCE = None if fused else False
+    used = {}
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lazy = ops.lazy_gather_bilinear(xd, packed, coords, exact=True)
+            lazy = P.BimodalCSRPool(mode='max')(None, lazy, None, atom_ptr)
+            assert isinstance(lazy, ops.InterpolatedFeatures), "the atomic pool of an exact mapping stays lazy"
+            out = m(None, lazy, case["x_map"].to(DEV), case["csr"].to(DEV))
+        used["fn"] = type(out.grad_fn).__name__ if out.grad_fn is not None else None
+        grads = None
+        if need_grad:
+            grads = torch.autograd.grad((out.float() * w.to(DEV)).sum(), [xd] + list(m.parameters()), allow_unused=True)
+    finally:
+        fused_chain.FORCE = None
+    return out, grads, used
+
+
+def oracle(case, ref, w, autocast):
+    xr = case["x"].clone().requires_grad_()
+
+    def fwd():
+        xm = O.gather_bilinear(xr, case["images"], case["pixels"], case["msize"])
+        return ref(None, xm, case["x_map"], case["csr"])
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = fwd()
+    else:
+        out = fwd()
+    grads = torch.autograd.grad((out.float() * w).sum(), [xr] + list(ref.parameters()), allow_unused=True)
+    return out, grads
+
+
+CASES = [
+    (ragged, 3000, 64, 64, 4, True),
+    (full32, 512, 64, 64, 4, True),            # the headline shape: 32 views per point
+    (ragged_long, 1500, 128, 32, 4, True),     # the KITTI-360 pair (l0: 128 -> 32), points with > 32 views
+    (ragged_long, 1200, 64, 32, 2, False),
+    (ragged, 900, 48, 64, 1, True),
+    (ragged_long, 1000, 64, 64, 2, True),
+]
+
+
+@pytest.mark.parametrize("sizes_fn,N,C_in,C_out,G,train", CASES)
+def test_fused_bilinear_matches_oracle_and_materialised_path(sizes_fn, N, C_in, C_out, G, train):
+    case = make_case(21, N, C_in, sizes_fn)
+    w = torch.randn(N, C_out, generator=case["gen"])
+    ref, m = build(case, C_out, G, train)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    out_ref, g_ref = oracle(case, ref, w, autocast=False)
+    ref.load_state_dict(sd)
+    out_amp, g_amp = oracle(case, ref, w, autocast=True)
+    out, g, used = run_dev(case, m, w, fused=True)
+    assert used["fn"] == "_EmodPoolBackward", f"the fused bilinear path must be the one that ran ({used})"
+    assert out.dtype == torch.bfloat16
+    r, r_amp = rel(out, out_ref), rel(out_amp, out_ref)
+    print(f"fused bilinear fwd rel err {r:.4f} (oracle under autocast {r_amp:.4f})")
+    assert r < max(2e-2, 1.5 * r_amp), (r, r_amp)
+    unseen = case["csr"][1:] == case["csr"][:-1]
+    assert float(out.detach().float().cpu()[unseen].abs().max() if unseen.any() else 0.0) == 0.0
+    if train:
+        for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
+            if "running" in k:
+                torch.testing.assert_close(a.cpu(), b, rtol=2e-2, atol=2e-3)
+    # gradients against the fp32 oracle, yardstick = the oracle under autocast
+    names = ["x"] + [n for n, _ in ref.named_parameters()]
+    amps = sorted(rel(c, b) for n, b, c in zip(names, g_ref, g_amp)
+                  if b is not None and (n.startswith("E_map") or n.startswith("E_mod")))
+    med = amps[len(amps) // 2]
+    report, bad = [], []
+    for n, a, b, c in zip(names, g, g_ref, g_amp):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0, n
+            continue
+        assert a is not None, n
+        ours, amp = rel(a, b), rel(c, b)
+        report.append((n, round(ours, 4), round(amp, 4)))
+        if n.startswith("E_map") or n.startswith("E_mod"):
+            amp = max(amp, med)
+        loose = n.startswith("G.") or n.startswith("E_score")
+        if ours > max((4.0 if loose else 2.0) * amp, 5e-2):
+            bad.append(report[-1])
+    print("fused bilinear bwd rel err (ours, oracle under autocast):", report)
+    assert not bad, (bad, report)
+    # A/B against the materialised device dataflow on the same inputs
+    m.load_state_dict(sd)
+    out_b, g_b, used_b = run_dev(case, m, w, fused=False)
+    assert used_b["fn"] != "_EmodPoolBackward"
+    assert rel(out, out_b) < 2e-2, rel(out, out_b)
+    assert rel(g[0], g_b[0]) < 1e-1, rel(g[0], g_b[0])
+
+
+def test_fused_bilinear_is_deterministic():
+    case = make_case(3, 2000, 64, ragged)
+    w = torch.randn(2000, 64, generator=case["gen"])
+    ref, m = build(case, 64, 4, True)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    out1, g1, _ = run_dev(case, m, w, fused=True)
+    m.load_state_dict(sd)
+    out2, g2, _ = run_dev(case, m, w, fused=True)
+    assert torch.equal(out1, out2)
+    assert torch.equal(g1[0], g2[0])            # the feature-map gradient: segmented reductions, no atomics
+
+
+def test_fused_bilinear_through_the_data_objects():
+    """get_mapped_features(interpolate=True) of an exact mapping stays lazy and GroupBimodalCSRPool takes the fused path."""
+    from deepviewagg_amd import ops
+    from deepviewagg_amd.core.multimodal.image import ImageMapping, SameSettingImageData
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    gen = torch.Generator().manual_seed(0)
+    B, C, H, W, N = 2, 64, 8, 16, 300
+    pts = torch.arange(N).repeat_interleave(2)
+    imgs = torch.arange(2).repeat(N)
+    pix = torch.stack([torch.randint(0, W * 4, (2 * N,), generator=gen), torch.randint(0, H * 4, (2 * N,), generator=gen)], 1)
+    feats = torch.rand(2 * N, 8, generator=gen)
+    m = ImageMapping.from_dense(pts.to(DEV), imgs.to(DEV), pix.short().to(DEV), feats.to(DEV), num_points=N)
+    sd = SameSettingImageData(path=[f"i{i}" for i in range(B)], pos=torch.rand(B, 3), opk=torch.zeros(B, 3),
+                              ref_size=(W * 4, H * 4), proj_upscale=1, mappings=m,
+                              x=torch.zeros(B, 3, H * 4, W * 4, dtype=torch.uint8)).to(DEV)
+    x = torch.randn(B, C, H, W, generator=gen).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    sd.x = x.requires_grad_()
+    pool = P.GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=4, use_num=True).to(DEV).train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xm = sd.get_mapped_features(interpolate=True)
+        assert isinstance(xm, ops.InterpolatedFeatures)
+        xm = P.BimodalCSRPool(mode='max')(None, xm, None, sd.atomic_csr_indexing)
+        out = pool(None, xm, sd.mapping_features, sd.view_csr_indexing)
+    assert type(out.grad_fn).__name__ == "_EmodPoolBackward" and out.shape == (N, C)
+    out.float().sum().backward()
+    assert sd.x.grad is not None and torch.isfinite(sd.x.grad.float()).all()

@@ -102,8 +102,10 @@ def test_get_mapped_features_matches_reference():
     assert torch.equal(out.cpu(), t(g["out_nearest"]))
     (gr,) = torch.autograd.grad((out * t(g["w_nearest"], DEV)).sum(), x)
     close(gr, g["grad_x_nearest"])
-    out = sd.get_mapped_features(interpolate=True)
-    close(out, g["out_bilinear"], rtol=1e-6, atol=1e-6)
+    lazy = sd.get_mapped_features(interpolate=True)
+    assert isinstance(lazy, ops.InterpolatedFeatures) and lazy.exact      # an exact mapping: the taps, no [P, C] tensor
+    close(lazy.materialize(), g["out_bilinear"], rtol=1e-6, atol=1e-6)
+    close(sd.get_mapped_features(interpolate=True, lazy=False), g["out_bilinear"], rtol=1e-6, atol=1e-6)
     # reference indexing tuple still available for user code
     idx = sd.feature_map_indexing
     assert idx[0].shape[0] == sd.mappings.num_atoms and idx[1] is Ellipsis

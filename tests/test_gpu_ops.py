@@ -442,11 +442,15 @@ def test_gather_nearest_backward_plan_equals_atomics(dtype, C):
     close(res[0].permute(0, 2, 3, 1), ref, **tol)
 
 
-@pytest.mark.parametrize("dtype,C", [(torch.float32, 24), (torch.bfloat16, 64)])
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 24), (torch.bfloat16, 64), (torch.float32, 32),
+                                     (torch.bfloat16, 32)])
 def test_gather_bilinear_backward_plan_equals_atomics(dtype, C):
-    """Bilinear gather backward: weighted segmented reduction over the row plan of the 4 corner taps
-    (dva_gather_bilinear_taps + dva_row_plan + dva_gather_rows_sum) against the atomic scatter and autograd of
-    the oracle's sparse_interpolation."""
+    """Bilinear gather backward against the atomic scatter and autograd of the oracle's sparse_interpolation:
+    C = 24 -> weighted segmented reduction over the row plan of the 4 P corner taps (dva_gather_bilinear_taps +
+    dva_row_plan + dva_gather_rows_sum); the other shapes -> the anchor plan (views grouped by the padded cell of
+    their top-left tap: dva_gather_bilinear_taps_anchor + dva_anchor_rows_sum + dva_anchor_combine + dva_anchor_fixup),
+    including views at the image borders and views WITHOUT the 2 x 2 tap structure (floor(q + 1) != floor(q) + 1,
+    which the reference evaluates separately: they take the fix-up path)."""
     from deepviewagg_amd import ops
     gen = torch.Generator().manual_seed(C + 1)
     B, H, W, P = 3, 9, 14, 4000
@@ -455,6 +459,11 @@ def test_gather_bilinear_backward_plan_equals_atomics(dtype, C):
     pixels = torch.zeros(P, 2, dtype=torch.int16)
     coords = torch.rand(P, 2, generator=gen)
     coords[:50] = torch.tensor([0.0, 1.0])                 # borders: replication padding taps collapse
+    coords[50:60] = torch.tensor([1.0, 0.0])
+    # q = 9 c + 0.5 = 1 - 2^-24: floor(q) = 0 but floor(q + 1) = 2 (q + 1 rounds up to 2.0)
+    coords[60:64, 0] = 0.0555555485188961
+    q = coords[60, 0] * 9 + 0.5
+    assert torch.floor(q + 1) != torch.floor(q) + 1
     w = torch.randn(P, C, generator=gen).to(dtype)
     packed = ops.pack_gather_index(images.to(DEV), torch.arange(P + 1, device=DEV), pixels.to(DEV))
     res = {}
