@@ -274,10 +274,11 @@ def cpu_gather_attention_twin(log2_points, views, C, G=4):
                                     "view_gather_rows_grad + row_plan (kernels table) minus the encoder recompute")
 
 
-def mapping_build_bench(device, n_images=4, n_points=200_000):
-    """Secondary measurement: mapping build at the S3DIS settings (2048x1024
-    projection map, voxel 2 cm, r_max 8 m, exact=True): images/s on the GPU and for the C oracle on
-    one host core, with a bit-exactness check of the indices."""
+def mapping_build_bench(device, n_images=32, n_points=200_000):
+    """Secondary measurement: mapping build at the S3DIS settings (2048x1024 projection map,
+    voxel 2 cm, r_max 8 m, exact=True), B = 32 cameras of one setting against a 200 k-point room: images/s of the
+    BATCHED build (VisibilityModel.batch -> dva_visibility_batch: one set of launches, one host synchronisation) and
+    of the image-by-image build, next to the C oracle on one host core, with a bit-exactness check of the indices."""
     import numpy as np
     from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
     from oracle import mapping_oracle as M
@@ -286,35 +287,63 @@ def mapping_build_bench(device, n_images=4, n_points=200_000):
     uvw = rng.random((n_points, 3))
     uvw[np.arange(n_points), face // 2] = face % 2
     xyz = (uvw * np.array([8.0, 6.0, 3.0])).astype(np.float32)
-    cams = np.array([[3.1, 2.2, 1.4], [5.0, 3.0, 1.2], [2.0, 4.5, 1.6], [6.5, 1.5, 1.5]], dtype=np.float32)[:n_images]
-    kw = dict(img_size=(2048, 1024), r_max=8.0, r_min=0.05, voxel=0.02, k_swell=1.0, d_swell=1000, exact=True)
+    cams = np.array([[3.1, 2.2, 1.4], [5.0, 3.0, 1.2], [2.0, 4.5, 1.6], [6.5, 1.5, 1.5]], dtype=np.float32)
+    extra = (rng.random((max(n_images - 4, 0), 3)) * np.array([6.0, 4.0, 1.0]) + np.array([1.0, 1.0, 1.0])).astype(np.float32)
+    cams = np.concatenate([cams, extra])[:n_images]
+    W, H = 2048, 1024
+    kw = dict(img_size=(W, H), r_max=8.0, r_min=0.05, voxel=0.02, k_swell=1.0, d_swell=1000, exact=True)
     model = SplattingVisibility(camera="s3dis_equirectangular", **kw)
     xyz_d = torch.from_numpy(xyz).to(device)
+    cams_d = torch.from_numpy(cams).to(device)
     opk = torch.zeros(3, device=device)
-    outs = [model(xyz_d, torch.from_numpy(c).to(device), img_opk=opk) for c in cams]  # warm-up
+    opk_b = torch.zeros((n_images, 3), device=device)
+    # ---- batched
+    out = model.batch(xyz_d, cams_d, img_opk=opk_b)          # warm-up
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = model.batch(xyz_d, cams_d, img_opk=opk_b)
+    torch.cuda.synchronize()
+    batch_s = (time.perf_counter() - t0) / (reps * n_images)
+    # ---- image by image (4 images)
+    single = [model(xyz_d, cams_d[i], img_opk=opk) for i in range(4)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 5
     for _ in range(reps):
-        outs = [model(xyz_d, torch.from_numpy(c).to(device), img_opk=opk) for c in cams]
+        single = [model(xyz_d, cams_d[i], img_opk=opk) for i in range(4)]
     torch.cuda.synchronize()
-    gpu_s = (time.perf_counter() - t0) / (reps * len(cams))
+    gpu_s = (time.perf_counter() - t0) / (reps * 4)
     cam0 = M.make_camera("s3dis_equirectangular", kw["img_size"], cams[0], r_min=kw["r_min"], r_max=kw["r_max"],
                          voxel=kw["voxel"], k_swell=1.0, d_swell=1000, exact=True, img_opk=np.zeros(3))
     t0 = time.perf_counter()
     ref = M.visibility(xyz, cam0)
     cpu_s = time.perf_counter() - t0
-    exact = bool(np.array_equal(outs[0]["idx"].cpu().numpy(), ref["idx"])
-                 and np.array_equal(outs[0]["x"].cpu().numpy(), ref["x"])
-                 and np.array_equal(outs[0]["y"].cpu().numpy(), ref["y"]))
+    rp = out["row_ptr"].cpu().numpy()
+    exact = all(bool(np.array_equal(out[k][rp[0]:rp[1]].cpu().numpy(), ref[k])) for k in ("idx", "x", "y")) and \
+        all(bool(torch.equal(out[k][rp[i]:rp[i + 1]], single[i][k])) for i in range(4) for k in ("idx", "x", "y"))
     # SURVEY.md 8(d) bytes per image: n 12 B of xyz read + W_p H_p 12 B of z-buffer / pixel map cleared and scanned
-    # (+ 8 B per covered splat pixel, not counted here: lower bound) -> fraction of the HBM peak; the build is bound
-    # by 64-bit atomics on a cache-resident map and by launch latency, not by bandwidth
-    lb = n_points * 12 + 2048 * 1024 * 12
-    return {"roofline": {"bound": "hbm", "algorithmic_bytes_lower_bound": lb, "achieved": lb / gpu_s / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lb / gpu_s / 1e9 / HBM_PEAK_GBS},
-            "images_per_s": 1.0 / gpu_s, "ms_per_image": gpu_s * 1e3, "candidates_per_image": n_points,
-            "proj_map": [2048, 1024], "mapped_points_image0": int(ref["idx"].shape[0]),
+    # + 8 B per pixel of every splat box (the z-buffer atomics); the box areas from the splat formula (visibility.py:651-704)
+    area = 0
+    for c in cams:
+        v = xyz - c
+        d = np.sqrt((v * v).sum(1))
+        ok = (d > kw["r_min"]) & (d < kw["r_max"])
+        v, d = v[ok].astype(np.float64), d[ok].astype(np.float64)
+        y = (H - 1) * np.arccos(np.clip(v[:, 2] / d, -1, 1)) / np.pi
+        a = (1.0 + np.exp(-d / np.log(1000.0))) * kw["voxel"] / d
+        wy = a * H / np.pi
+        wx = (a * W / (2 * np.pi)) / (np.sin(np.pi * y / H) + 0.001)
+        area += float((np.minimum(np.rint(wx + 1), W) * np.minimum(np.rint(wy + 1), H)).sum())
+    per_image = n_points * 12 + W * H * 12 + area / len(cams) * 8
+    return {"roofline": {"bound": "hbm", "algorithmic_bytes_per_image": per_image,
+                         "splat_box_pixels_per_image": area / len(cams), "achieved": per_image / batch_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_image / batch_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "64-bit atomics on a cache-resident z-buffer plane per image, scans and compaction: "
+                                 "bound by atomic throughput and launch count, not by HBM bandwidth"},
+            "images_per_s": 1.0 / batch_s, "ms_per_image": batch_s * 1e3, "batch": n_images,
+            "single_image_calls": {"images_per_s": 1.0 / gpu_s, "ms_per_image": gpu_s * 1e3},
+            "candidates_per_image": n_points, "proj_map": [W, H], "mapped_points_image0": int(ref["idx"].shape[0]),
             "cpu_oracle_ms_per_image_1core": cpu_s * 1e3, "indices_bit_exact_vs_oracle": exact}
 
 

@@ -169,6 +169,13 @@ SIGNATURES = {
     "dva_visibility": (ctypes.c_int,
                        [_vp, _i64, ctypes.POINTER(DvaCamera), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                         _vp, _i64, _vp]),
+    "dva_visibility_batch_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(DvaCamera), _i64, _i32]),
+    "dva_visibility_batch": (ctypes.c_int,
+                             [_vp, _i64, ctypes.POINTER(DvaCamera), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _i64, _vp]),
+    "dva_mapping_features_batch": (ctypes.c_int,
+                                   [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
+                                    ctypes.POINTER(ctypes.c_int32), _vp]),
     "dva_mapping_features": (ctypes.c_int,
                              [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(DvaCamera),
                               _i64, _vp, ctypes.POINTER(ctypes.c_int32), _vp]),

@@ -33,6 +33,15 @@ class MapImages:
     def __call__(self, data, images):
         return self._process(data, images)
 
+    @staticmethod
+    def _batch_size(visi_model, n_points, n_images, budget_bytes=8 << 30):
+        """Images per visibility batch: what fits ``budget_bytes`` of workspace + outputs (a 2048 x 1024 projection map
+        costs 42 MB of z-buffer / pixel maps per image, a candidate 100 bytes)."""
+        w, h = visi_model.img_size
+        per_image = w * h * 20 + n_points * 100 + (n_points if getattr(visi_model, 'exact', False)
+                                                   else max(n_points, w * h)) * 48
+        return int(max(1, min(n_images, budget_bytes // max(per_image, 1), 64)))
+
     def _process(self, data, images: SameSettingImageData):
         assert hasattr(data, self.key)
         assert isinstance(images, SameSettingImageData)
@@ -56,34 +65,47 @@ class MapImages:
         lin, pla, sca, nrm = dev32('linearity'), dev32('planarity'), dev32('scattering'), dev32('norm')
         mask = images.mask.to(device) if images.mask is not None else None
 
+        # the reference loops over the images (:238-353); here the images of the setting go through the visibility
+        # kernels in batches (VisibilityModel.batch: one set of launches and one host synchronisation per batch) and the
+        # per-image post-processing (:294-353) is applied to all rows at once, the image id leading the sort key
         image_ids, point_ids, features, pixels = [], [], [], []
-        for i_image in range(images.num_views):
-            def one(attr):
-                return attr[i_image].squeeze().float() if attr is not None else None
-            out = visi_model(
-                xyz, images.pos[i_image].squeeze().float(),
-                img_opk=one(images.opk) if images.has_opk else None,
-                img_intrinsic_pinhole=images.intrinsic_pinhole[i_image].float() if images.is_pinhole else None,
-                img_intrinsic_fisheye=images.intrinsic_fisheye[i_image].float() if images.is_fisheye else None,
-                img_extrinsic=one(images.extrinsic) if images.has_extrinsic else None,
+        n_img = images.num_views
+        step = self._batch_size(visi_model, xyz.shape[0], n_img)
+        for i0 in range(0, n_img, step):
+            sel = slice(i0, min(i0 + step, n_img))
+
+            def part(attr):
+                return attr[sel].float() if attr is not None else None
+            out = visi_model.batch(
+                xyz, images.pos[sel].float(),
+                img_opk=part(images.opk) if images.has_opk else None,
+                img_intrinsic_pinhole=images.intrinsic_pinhole[sel].float() if images.is_pinhole else None,
+                img_intrinsic_fisheye=images.intrinsic_fisheye[sel].float() if images.is_fisheye else None,
+                img_extrinsic=part(images.extrinsic) if images.has_extrinsic else None,
                 img_mask=mask, linearity=lin, planarity=pla, scattering=sca, normals=nrm)
             if out['idx'].shape[0] == 0:
                 continue
+            img = out['image'] + i0
             pid = point_index[out['idx']]
-            off = images.crop_offsets[i_image].to(device)
-            px = out['x'].long() // images.proj_upscale - off[0]
-            py = out['y'].long() // images.proj_upscale - off[1]
+            off = images.crop_offsets.to(device)[img]
+            px = out['x'].long() // images.proj_upscale - off[:, 0]
+            py = out['y'].long() // images.proj_upscale - off[:, 1]
             keep = torch.where((px >= 0) & (py >= 0) & (px < images.crop_size[0]) & (py < images.crop_size[1]))
-            px, py, pid, ft = px[keep], py[keep], pid[keep], out['features'].float()[keep]
+            px, py, pid, img, ft = px[keep], py[keep], pid[keep], img[keep], out['features'].float()[keep]
             px = (px // images.downscale).long()
             py = (py // images.downscale).long()
             if pid.shape[0] == 0:
                 continue
-            u = lexargunique(pid, px, py)
-            image_ids.append(i_image)
-            point_ids.append(pid[u])
-            features.append(ft[u])
-            pixels.append(torch.stack((px[u], py[u]), dim=1).type(images.pixel_dtype))
+            # per image: first occurrence of every (point, pixel) row, sorted by that key (:328)
+            u = lexargunique(img, pid, px, py)
+            img, pid, ft, pix = img[u], pid[u], ft[u], torch.stack((px[u], py[u]), dim=1).type(images.pixel_dtype)
+            present, counts = torch.unique_consecutive(img, return_counts=True)
+            for i_image, chunk_p, chunk_f, chunk_x in zip(present.tolist(), pid.split(counts.tolist()),
+                                                          ft.split(counts.tolist()), pix.split(counts.tolist())):
+                image_ids.append(i_image)
+                point_ids.append(chunk_p)
+                features.append(chunk_f)
+                pixels.append(chunk_x)
 
         if len(image_ids) == 0:
             raise ValueError(

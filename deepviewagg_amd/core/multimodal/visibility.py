@@ -158,6 +158,119 @@ class VisibilityModel:
         out['y_proj'] = y_proj[:q].to(in_device)
         return out
 
+    # -- batched build: B cameras of this setting against the same cloud --------------------------------------
+    def _camera_array(self, img_xyz, img_opk, img_intrinsic_pinhole, img_intrinsic_fisheye, img_extrinsic):
+        """numpy structured array of B ``dva_camera`` (same bytes as B x ``_camera_struct``), filled without a
+        Python loop over the images."""
+        if self.camera not in CAMERAS:
+            raise ValueError(f"Unknown camera '{self.camera}'")
+        pos = _np32(img_xyz).reshape(-1, 3)
+        B = pos.shape[0]
+        cams = np.zeros(B, dtype=np.dtype(DvaCamera))
+        cams['model'] = _lib.CAMERA_CODE[self.camera]
+        cams['img_w'], cams['img_h'] = int(self.img_size[0]), int(self.img_size[1])
+        cams['crop_top'], cams['crop_bottom'] = int(self.crop_top), int(self.crop_bottom)
+        cams['r_min'], cams['r_max'] = float(self.r_min), float(self.r_max)
+        cams['r_min_d'], cams['r_max_d'] = float(self.r_min), float(self.r_max)
+        cams['voxel'] = float(getattr(self, 'voxel', 0.1))
+        cams['k_swell'] = float(getattr(self, 'k_swell', 1.0))
+        cams['d_swell'] = float(getattr(self, 'd_swell', 1000))
+        cams['exact'] = int(bool(getattr(self, 'exact', False)))
+        cams['img_xyz'] = pos
+        rot = np.tile(np.eye(3, dtype=np.float32), (B, 1, 1))
+        trans = np.zeros((B, 3), dtype=np.float32)
+        if self.camera == 's3dis_equirectangular':
+            opk = np.zeros((B, 3), dtype=np.float32) if img_opk is None else _np32(img_opk).reshape(B, 3)
+            co, so = np.cos(opk[:, 0]), np.sin(opk[:, 0])
+            cp, sp = np.cos(opk[:, 1]), np.sin(opk[:, 1])
+            ck, sk = np.cos(opk[:, 2]), np.sin(opk[:, 2])
+            one, zero = np.ones(B, np.float32), np.zeros(B, np.float32)
+            m_o = np.stack([one, zero, zero, zero, co, -so, zero, so, co], 1).reshape(B, 3, 3).astype(np.float32)
+            m_p = np.stack([cp, zero, sp, zero, one, zero, -sp, zero, cp], 1).reshape(B, 3, 3).astype(np.float32)
+            m_k = np.stack([ck, -sk, zero, sk, ck, zero, zero, zero, one], 1).reshape(B, 3, 3).astype(np.float32)
+            # one image at a time through np.dot, like pose_to_rotation_matrix: float32 dot products in the same
+            # order (a batched matmul may accumulate differently)
+            rot = np.stack([np.dot(m_o[b], np.dot(m_p[b], m_k[b])) for b in range(B)])
+        else:
+            ext = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1)) if img_extrinsic is None \
+                else _np32(img_extrinsic).reshape(B, 4, 4)
+            if self.camera == 'scannet':
+                ext = np.stack([np.linalg.inv(np.ascontiguousarray(e)) for e in ext])
+            rot, trans = ext[:, :3, :3].copy(), ext[:, :3, 3].copy()
+        cams['rot'] = rot.astype(np.float32).reshape(B, 9)
+        cams['trans'] = trans.astype(np.float32)
+        k = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1)) if img_intrinsic_pinhole is None \
+            else _np32(img_intrinsic_pinhole).reshape(B, 4, 4) if _np32(img_intrinsic_pinhole).size == B * 16 \
+            else _np32(img_intrinsic_pinhole).reshape(B, 3, 3)
+        cams['fx'], cams['fy'], cams['mx'], cams['my'] = k[:, 0, 0], k[:, 1, 1], k[:, 0, 2], k[:, 1, 2]
+        fe = np.ones((B, 7), dtype=np.float32) if img_intrinsic_fisheye is None \
+            else _np32(img_intrinsic_fisheye).reshape(B, 7)
+        cams['fisheye'] = fe
+        return cams
+
+    def batch(self, xyz, img_xyz, linearity=None, planarity=None, scattering=None, normals=None, img_opk=None,
+              img_intrinsic_pinhole=None, img_intrinsic_fisheye=None, img_extrinsic=None, img_mask=None, **kwargs):
+        """``__call__`` for B cameras of this setting at once (``img_xyz`` [B, 3]; ``img_opk`` [B, 3],
+        ``img_intrinsic_pinhole`` [B, 4, 4] | [B, 3, 3], ``img_intrinsic_fisheye`` [B, 7], ``img_extrinsic``
+        [B, 4, 4] where the camera model has them): the kernels of the single-image build with an image axis
+        (``dva_visibility_batch``), ONE host synchronisation (the total row count) instead of one per image.
+
+        :return: the dict of ``__call__`` with the rows of all images concatenated in image order, plus ``image``
+          LongTensor[q] (image of every row) and ``row_ptr`` LongTensor[B + 1] (first row of every image).  Row for
+          row identical to B single calls (tests/test_gpu_mapping.py)."""
+        lib = _lib.load()
+        in_device = xyz.device
+        if not torch.cuda.is_available():
+            raise _lib.DvaError("the mapping build runs on a HIP device; none is visible "
+                                "(deepviewagg_amd has no CPU fallback)")
+        dev = in_device if xyz.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        assert img_mask is None or tuple(img_mask.shape) == tuple(self.img_size), \
+            f'Expected img_mask to be a torch.BoolTensor of shape img_size={self.img_size} but got ' \
+            f'size={None if img_mask is None else tuple(img_mask.shape)}.'
+        cams = self._camera_array(img_xyz, img_opk, img_intrinsic_pinhole, img_intrinsic_fisheye, img_extrinsic)
+        B = cams.shape[0]
+        cam0 = DvaCamera.from_buffer_copy(cams[0].tobytes())
+        cams_d = torch.from_numpy(cams.view(np.uint8).reshape(B, -1).copy()).to(dev)
+        xyz_d = xyz.detach().to(dev, torch.float32).contiguous()
+        n = xyz_d.shape[0]
+        mask_d = None if img_mask is None else img_mask.to(dev).to(torch.uint8).contiguous()
+        hc = cam0.img_h - cam0.crop_top - cam0.crop_bottom
+        cap = max((n if cam0.exact else max(n, cam0.img_w * hc)) * B, 1)
+        idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        x_pix = torch.empty(cap, dtype=torch.int64, device=dev)
+        y_pix = torch.empty(cap, dtype=torch.int64, device=dev)
+        depth = torch.empty(cap, dtype=torch.float32, device=dev)
+        x_proj = torch.empty(cap, dtype=torch.float64, device=dev)
+        y_proj = torch.empty(cap, dtype=torch.float64, device=dev)
+        row_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws_bytes = lib.dva_visibility_batch_workspace_bytes(ctypes.byref(cam0), n, B)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "dva_visibility_batch_workspace_bytes")
+        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        st = stream_of(xyz_d)
+        check(lib.dva_visibility_batch(ptr(xyz_d), n, ctypes.byref(cam0), ptr(cams_d), B, ptr(mask_d), ptr(idx),
+                                       ptr(x_pix), ptr(y_pix), ptr(depth), ptr(x_proj), ptr(y_proj), ptr(row_ptr),
+                                       ptr(n_out), ptr(ws), int(ws_bytes), st), "dva_visibility_batch")
+        q = int(n_out.item())          # the one host synchronisation of the batch
+        del ws
+
+        def dev32(a):
+            return None if a is None else a.detach().to(dev, torch.float32).contiguous()
+        lin, pla, sca, nrm = dev32(linearity), dev32(planarity), dev32(scattering), dev32(normals)
+        ncol = 2 + sum(a is not None for a in (lin, pla, sca, nrm))
+        feats = torch.empty((q, ncol), dtype=torch.float32, device=dev)
+        row_image = torch.empty(q, dtype=torch.int32, device=dev)
+        got = ctypes.c_int32(0)
+        check(lib.dva_mapping_features_batch(ptr(xyz_d), ptr(idx), ptr(depth), ptr(y_proj), ptr(lin), ptr(pla),
+                                             ptr(sca), ptr(nrm), ptr(cams_d), ptr(row_ptr), B, q, ptr(feats),
+                                             ptr(row_image), ctypes.byref(got), st), "dva_mapping_features_batch")
+        assert got.value == ncol
+        return {'idx': idx[:q].to(in_device), 'x': x_pix[:q].to(in_device), 'y': y_pix[:q].to(in_device),
+                'depth': depth[:q].to(in_device), 'features': feats.to(in_device),
+                'x_proj': x_proj[:q].to(in_device), 'y_proj': y_proj[:q].to(in_device),
+                'image': row_image.long().to(in_device), 'row_ptr': row_ptr.to(in_device)}
+
     def __repr__(self):
         attr_repr = ', '.join([f'{k}={v}' for k, v in self.__dict__.items()])
         return f'{self.__class__.__name__}({attr_repr})'

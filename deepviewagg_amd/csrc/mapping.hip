@@ -17,6 +17,7 @@
 // HBM-bound integer/atomic work; the 12-16 B/pixel maps (2048x1024 -> 33 MB) stay in L2/MALL.
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "dva_common.h"
 
@@ -63,17 +64,11 @@ __device__ __forceinline__ void to_camera(const dva_camera& c, float q0, float q
   }
 }
 
-__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ xyz, int64_t n,
-                                                       const dva_camera c,
-                                                       const uint8_t* __restrict__ mask,
-                                                       int32_t* __restrict__ flag,
-                                                       float* __restrict__ dist_u,
-                                                       double* __restrict__ xp_u,
-                                                       double* __restrict__ yp_u) {
+// one candidate point: range cull, projection, FoV / mask cull
+__device__ __forceinline__ int project_one(const dva_camera& c, const uint8_t* __restrict__ mask, float q0, float q1,
+                                           float q2, float* dist_out, double* x_out, double* y_out) {
   const int W = c.img_w, H = c.img_h;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float q0 = xyz[3 * i], q1 = xyz[3 * i + 1], q2 = xyz[3 * i + 2];
+  {
     const float d0 = q0 - c.img_xyz[0], d1 = q1 - c.img_xyz[1], d2 = q2 - c.img_xyz[2];
     const float dd = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
     int keep = (c.r_min_d < (double)dd && (double)dd < c.r_max_d) ? 1 : 0;
@@ -108,7 +103,25 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
         keep = mask[(size_t)xi * H + yi] ? 1 : 0;
       }
     }
-    flag[i] = keep;
+    *dist_out = dd;
+    *x_out = x;
+    *y_out = y;
+    return keep;
+  }
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ xyz, int64_t n,
+                                                       const dva_camera c,
+                                                       const uint8_t* __restrict__ mask,
+                                                       int32_t* __restrict__ flag,
+                                                       float* __restrict__ dist_u,
+                                                       double* __restrict__ xp_u,
+                                                       double* __restrict__ yp_u) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float dd;
+    double x, y;
+    flag[i] = project_one(c, mask, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &dd, &x, &y);
     dist_u[i] = dd;
     xp_u[i] = x;
     yp_u[i] = y;
@@ -143,20 +156,13 @@ __device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) {
 }
 
 // boxes in CROPPED coordinates (y shifted by -crop_top, :1138)
-__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ xyz,
-                                                     const int32_t* __restrict__ idx1,
-                                                     const float* __restrict__ dist,
-                                                     const double* __restrict__ xp,
-                                                     const double* __restrict__ yp, const dva_camera c,
-                                                     const MapCounters* __restrict__ cnt,
-                                                     int4* __restrict__ splat) {
+__device__ __forceinline__ int4 splat_one(const dva_camera& c, const float* __restrict__ xyz, int64_t i, float dist_j,
+                                          double xp_j, double yp_j) {
   const int W = c.img_w, H = c.img_h;
   const double logd = log(c.d_swell);
-  const int m = cnt->m;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+  {
     double wx, wy;
     if (c.model == DVA_CAM_FISHEYE_KITTI) {
-      const int64_t i = idx1[j];
       const float q0 = xyz[3 * i], q1 = xyz[3 * i + 1], q2 = xyz[3 * i + 2];
       const float da = sqrtf((q0 * q0 + q1 * q1) + q2 * q2);
       const double swell = 1.0 + c.k_swell * exp((double)(-da) / logd);
@@ -165,30 +171,42 @@ __global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ xy
       double x2, y2, z2;
       to_camera(c, q0 + 0.0f, q1 + 0.0f, q2o, p);
       fisheye_project(p[0], p[1], p[2], c.fisheye, &x2, &y2, &z2);
-      const double ex = xp[j] - x2, ey = yp[j] - y2;
+      const double ex = xp_j - x2, ey = yp_j - y2;
       wx = wy = 2.0 * sqrt(ex * ex + ey * ey);
     } else {
-      const double a = (1.0 + c.k_swell * exp((double)(-dist[j]) / logd)) * c.voxel / (double)dist[j];
+      const double a = (1.0 + c.k_swell * exp((double)(-dist_j) / logd)) * c.voxel / (double)dist_j;
       if (c.model == DVA_CAM_EQUIRECT) {
         wy = a * (double)H / M_PI;
-        wx = (a * (double)W / (2.0 * M_PI)) / (sin((M_PI / (double)H) * yp[j]) + 0.001);
+        wx = (a * (double)W / (2.0 * M_PI)) / (sin((M_PI / (double)H) * yp_j) + 0.001);
       } else {
         wx = a * (double)c.fx;
         wy = a * (double)c.fy;
       }
     }
-    const int32_t xa = (int32_t)(float)rint(xp[j] - wx / 2.0);
-    const int32_t xb = (int32_t)(float)rint(xp[j] + wx / 2.0 + 1.0);
-    const int32_t ya = (int32_t)(float)rint(yp[j] - wy / 2.0);
-    const int32_t yb = (int32_t)(float)rint(yp[j] + wy / 2.0 + 1.0);
+    const int32_t xa = (int32_t)(float)rint(xp_j - wx / 2.0);
+    const int32_t xb = (int32_t)(float)rint(xp_j + wx / 2.0 + 1.0);
+    const int32_t ya = (int32_t)(float)rint(yp_j - wy / 2.0);
+    const int32_t yb = (int32_t)(float)rint(yp_j + wy / 2.0 + 1.0);
     const int32_t y_min = c.crop_top, y_max = H - c.crop_bottom;
     int4 s;
     s.x = clampi(xa, 0, W - 1);
     s.y = clampi(xb, 1, W);
     s.z = clampi(ya, y_min, y_max - 1) - c.crop_top;
     s.w = clampi(yb, y_min + 1, y_max) - c.crop_top;
-    splat[j] = s;
+    return s;
   }
+}
+
+__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ xyz,
+                                                     const int32_t* __restrict__ idx1,
+                                                     const float* __restrict__ dist,
+                                                     const double* __restrict__ xp,
+                                                     const double* __restrict__ yp, const dva_camera c,
+                                                     const MapCounters* __restrict__ cnt,
+                                                     int4* __restrict__ splat) {
+  const int m = cnt->m;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x)
+    splat[j] = splat_one(c, xyz, idx1[j], dist[j], xp[j], yp[j]);
 }
 
 // One wavefront per point; lanes sweep the box column-major like the map ([x][y], y fastest).
@@ -300,6 +318,207 @@ __global__ __launch_bounds__(256) void features_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched build: B images of ONE setting (same projection size, crops, camera model, splatting parameters; a pose per
+// image) against the same candidate cloud in one set of launches.  Every per-image array gains an image axis laid
+// out image-major, so that ONE scan compacts the survivors of all images (image b owns [moff[b], moff[b + 1])) and ONE
+// scan orders the output rows (image-major, inside an image x-major then y like the single-image build).  The
+// survivor index j that breaks depth ties is the GLOBAL position in the compacted list: monotone in the local
+// position inside an image, and keys of different images never meet (each image has its own z-buffer plane).
+// The only host round trip is the total row count, once per batch.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void project_batch_kernel(const float* __restrict__ xyz, int64_t n,
+                                                             const dva_camera* __restrict__ cams,
+                                                             const uint8_t* __restrict__ mask,
+                                                             int32_t* __restrict__ flag, float* __restrict__ dist_u,
+                                                             double* __restrict__ xp_u, double* __restrict__ yp_u) {
+  __shared__ dva_camera c;
+  if (threadIdx.x == 0) c = cams[blockIdx.y];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.y * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float dd;
+    double x, y;
+    flag[base + i] = project_one(c, mask, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &dd, &x, &y);
+    dist_u[base + i] = dd;
+    xp_u[base + i] = x;
+    yp_u[base + i] = y;
+  }
+}
+
+__global__ __launch_bounds__(256) void compact_batch_kernel(int64_t n, int B, const int32_t* __restrict__ flag,
+                                                             const int32_t* __restrict__ pos,
+                                                             const float* __restrict__ dist_u,
+                                                             const double* __restrict__ xp_u,
+                                                             const double* __restrict__ yp_u,
+                                                             int32_t* __restrict__ idx1, int32_t* __restrict__ simg,
+                                                             float* __restrict__ dist, double* __restrict__ xp,
+                                                             double* __restrict__ yp, MapCounters* __restrict__ cnt) {
+  const int64_t total = n * B;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (flag[i]) {
+      const int32_t j = pos[i];
+      const int b = (int)(i / n);
+      idx1[j] = (int32_t)(i - (int64_t)b * n);
+      simg[j] = b;
+      dist[j] = dist_u[i];
+      xp[j] = xp_u[i];
+      yp[j] = yp_u[i];
+    }
+    if (i == total - 1) cnt->m = pos[i] + flag[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void splat_batch_kernel(const float* __restrict__ xyz,
+                                                           const int32_t* __restrict__ idx1,
+                                                           const int32_t* __restrict__ simg,
+                                                           const float* __restrict__ dist,
+                                                           const double* __restrict__ xp,
+                                                           const double* __restrict__ yp,
+                                                           const dva_camera* __restrict__ cams,
+                                                           const MapCounters* __restrict__ cnt,
+                                                           int4* __restrict__ splat) {
+  const int m = cnt->m;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x)
+    splat[j] = splat_one(cams[simg[j]], xyz, idx1[j], dist[j], xp[j], yp[j]);
+}
+
+// Footprints range from ~16 pixels (far points: the bulk) to several hundred (near points).  A wavefront takes FOUR
+// consecutive survivors at a time: if all four boxes are small (<= 128 pixels) each gets a quarter of the wavefront
+// (16 lanes, <= 8 sweeps) and the four are swept concurrently; otherwise the whole wavefront sweeps them one after
+// the other (the single-image kernel's scheme).  Measured on the S3DIS setting (23 pixels per box on average):
+// a wavefront per point keeps 36 % of the lanes busy.
+__global__ __launch_bounds__(256) void zbuffer_batch_kernel(const int4* __restrict__ splat,
+                                                             const int32_t* __restrict__ simg,
+                                                             const float* __restrict__ dist,
+                                                             const MapCounters* __restrict__ cnt,
+                                                             unsigned long long* __restrict__ zbuf, int Hc,
+                                                             int64_t npix) {
+  const int m = cnt->m;
+  const int lane = threadIdx.x & 63, quarter = lane >> 4, ql = lane & 15;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int j0 = wave * 4; j0 < m; j0 += n_waves * 4) {
+    // lane group `quarter` looks at survivor j0 + quarter
+    const int jq = j0 + quarter;
+    int4 sq = make_int4(0, 0, 0, 0);
+    if (jq < m) sq = splat[jq];
+    const int area_q = (sq.y - sq.x) * (sq.w - sq.z);
+    int amax = area_q;
+    amax = max(amax, __shfl_xor(amax, 16));
+    amax = max(amax, __shfl_xor(amax, 32));
+    if (amax <= 128) {
+      if (jq < m) {
+        const int bh = sq.w - sq.z;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dist[jq]) << 32) | (unsigned)jq;
+        unsigned long long* plane = zbuf + (size_t)simg[jq] * (size_t)npix;
+        for (int t = ql; t < area_q; t += 16) {
+          const int bx = t / bh, by = t - bx * bh;
+          unsigned long long* cell = plane + (size_t)(sq.x + bx) * Hc + (sq.z + by);
+          if (key < *cell) atomicMin(cell, key);
+        }
+      }
+    } else {
+      for (int u = 0; u < 4 && j0 + u < m; ++u) {
+        const int j = j0 + u;
+        const int4 s = splat[j];
+        const int bh = s.w - s.z;
+        const int area = (s.y - s.x) * bh;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)j;
+        unsigned long long* plane = zbuf + (size_t)simg[j] * (size_t)npix;
+        for (int t = lane; t < area; t += 64) {
+          const int bx = t / bh, by = t - bx * bh;
+          unsigned long long* cell = plane + (size_t)(s.x + bx) * Hc + (s.z + by);
+          if (key < *cell) atomicMin(cell, key);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void resplat_batch_kernel(const uint8_t* __restrict__ seen,
+                                                             const int32_t* __restrict__ simg,
+                                                             const double* __restrict__ xp,
+                                                             const double* __restrict__ yp,
+                                                             const MapCounters* __restrict__ cnt,
+                                                             int32_t* __restrict__ pixmap, int Hc, int crop_top,
+                                                             int64_t npix) {
+  const int m = cnt->m;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+    if (!seen[j]) continue;
+    const int x = (int)xp[j], y = (int)yp[j] - crop_top;
+    atomicMax(&pixmap[(size_t)simg[j] * (size_t)npix + (size_t)x * Hc + y], j);
+  }
+}
+
+struct IsMapped {
+  __host__ __device__ int32_t operator()(int32_t v) const { return v >= 0 ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(256) void emit_batch_kernel(
+    const int32_t* __restrict__ pixmap, const int32_t* __restrict__ pixpos,
+    int64_t npix, int B, int Hc, int crop_top, const int32_t* __restrict__ idx1, const float* __restrict__ dist,
+    const double* __restrict__ xp, const double* __restrict__ yp, int64_t* __restrict__ idx,
+    int64_t* __restrict__ x_pix, int64_t* __restrict__ y_pix, float* __restrict__ depth, double* __restrict__ x_proj,
+    double* __restrict__ y_proj, int64_t* __restrict__ row_ptr, int64_t* __restrict__ n_out) {
+  const int64_t total = npix * B;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(k / npix);
+    const int64_t kk = k - (int64_t)b * npix;
+    if (kk == 0) row_ptr[b] = pixpos[k];
+    const int32_t j = pixmap[k];
+    if (j >= 0) {
+      const int32_t o = pixpos[k];
+      idx[o] = idx1[j];
+      x_pix[o] = kk / Hc;
+      y_pix[o] = kk % Hc + crop_top;
+      depth[o] = dist[j];
+      x_proj[o] = xp[j];
+      y_proj[o] = yp[j];
+    }
+    if (k == total - 1) {
+      const int64_t q = (int64_t)pixpos[k] + (j >= 0 ? 1 : 0);
+      row_ptr[B] = q;
+      *n_out = q;
+    }
+  }
+}
+
+// mapping features of the rows of a batched build: the camera of row k is the image whose row range holds k
+__global__ __launch_bounds__(256) void features_batch_kernel(
+    const float* __restrict__ xyz, const int64_t* __restrict__ idx, const float* __restrict__ depth,
+    const double* __restrict__ y_proj, const float* __restrict__ lin, const float* __restrict__ pla,
+    const float* __restrict__ sca, const float* __restrict__ nrm, const dva_camera* __restrict__ cams,
+    const int64_t* __restrict__ row_ptr, int B, int64_t q, int ncol, float* __restrict__ out,
+    int32_t* __restrict__ row_image) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < q; k += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = B;                                  // largest b with row_ptr[b] <= k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (row_ptr[mid] <= k) lo = mid;
+      else hi = mid;
+    }
+    const dva_camera& c = cams[lo];
+    if (row_image) row_image[k] = lo;
+    const float rmin = (float)c.r_min_d;
+    const float den = (float)(c.r_max_d + 1e-4);
+    const int64_t i = idx[k];
+    float* o = out + k * ncol;
+    int col = 0;
+    o[col++] = (depth[k] - rmin) / den;
+    if (lin) o[col++] = lin[i];
+    if (pla) o[col++] = pla[i];
+    if (sca) o[col++] = sca[i];
+    if (nrm) {
+      const float dd = depth[k] + 1e-4f;
+      const float u0 = (xyz[3 * i] - c.img_xyz[0]) / dd, u1 = (xyz[3 * i + 1] - c.img_xyz[1]) / dd,
+                  u2 = (xyz[3 * i + 2] - c.img_xyz[2]) / dd;
+      o[col++] = fabsf((u0 * nrm[3 * i] + u1 * nrm[3 * i + 1]) + u2 * nrm[3 * i + 2]);
+    }
+    o[col++] = (float)(y_proj[k] / (double)c.img_h);
+  }
+}
+
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct VisLayout {
@@ -346,6 +565,46 @@ static inline int grid_for(int64_t n) {
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+struct VisBatchLayout {
+  size_t flag, pos, dist_u, xp_u, yp_u, idx1, simg, dist, xp, yp, splat, seen, cnt, zbuf, pixmap, pixflag, pixpos,
+      temp, temp_bytes, total;
+};
+
+static int vis_batch_layout(const dva_camera* c, int64_t n, int64_t B, VisBatchLayout* L) {
+  const int64_t Hc = (int64_t)c->img_h - c->crop_top - c->crop_bottom;
+  if (c->img_w <= 0 || Hc <= 0 || B < 1) return DVA_ERR_INVALID;
+  const size_t npix = (size_t)c->img_w * (size_t)Hc * (size_t)B, nc = (size_t)n * (size_t)B;
+  const size_t big = nc > npix ? nc : npix;
+  size_t scan_tmp = 0;
+  int32_t* nul = nullptr;
+  if (rocprim::exclusive_scan(nullptr, scan_tmp, nul, nul, 0, big, rocprim::plus<int32_t>(), (hipStream_t)0) !=
+      hipSuccess)
+    return DVA_ERR_LAUNCH;
+  size_t o = 0;
+  L->flag = o;    o += al(nc * 4);
+  L->pos = o;     o += al(nc * 4);
+  L->dist_u = o;  o += al(nc * 4);
+  L->xp_u = o;    o += al(nc * 8);
+  L->yp_u = o;    o += al(nc * 8);
+  L->idx1 = o;    o += al(nc * 4);
+  L->simg = o;    o += al(nc * 4);
+  L->dist = o;    o += al(nc * 4);
+  L->xp = o;      o += al(nc * 8);
+  L->yp = o;      o += al(nc * 8);
+  L->splat = o;   o += al(nc * 16);
+  L->seen = o;    o += al(nc);
+  L->cnt = o;     o += al(sizeof(MapCounters));
+  L->zbuf = o;    o += al(npix * 8);
+  L->pixmap = o;  o += al(npix * 4);
+  L->pixflag = o; o += al(npix * 4);
+  L->pixpos = o;  o += al(npix * 4);
+  L->temp = o;
+  L->temp_bytes = scan_tmp;
+  o += al(scan_tmp);
+  L->total = o;
+  return DVA_OK;
 }
 
 }  // namespace dva
@@ -433,6 +692,115 @@ int dva_visibility(const float* xyz, int64_t n, const dva_camera* cam, const uin
     return DVA_ERR_LAUNCH;
   hipLaunchKernelGGL(emit_kernel, dim3(grid_for(npix)), dim3(256), 0, s, pixmap, pixflag, pixpos, npix, Hc,
                      c.crop_top, idx1, dist, xp, yp, idx, x_pix, y_pix, depth, x_proj, y_proj, n_out_dev);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int64_t dva_visibility_batch_workspace_bytes(const dva_camera* cam, int64_t n, int32_t n_images) {
+  if (!cam || n < 0 || n_images < 1) return DVA_ERR_INVALID;
+  VisBatchLayout L;
+  int rc = vis_batch_layout(cam, n > 0 ? n : 1, n_images, &L);
+  if (rc) return rc;
+  return (int64_t)L.total;
+}
+
+int dva_visibility_batch(const float* xyz, int64_t n, const dva_camera* cam0, const dva_camera* cams_dev,
+                         int32_t n_images, const uint8_t* mask, int64_t* idx, int64_t* x_pix, int64_t* y_pix,
+                         float* depth, double* x_proj, double* y_proj, int64_t* row_ptr, int64_t* n_out_dev,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!cam0 || !cams_dev || n < 0 || n_images < 1 || !n_out_dev || !row_ptr) return DVA_ERR_INVALID;
+  if (cam0->model < DVA_CAM_EQUIRECT || cam0->model > DVA_CAM_FISHEYE_KITTI) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const int B = n_images;
+  if (n == 0) {
+    if (hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), s) != hipSuccess) return DVA_ERR_LAUNCH;
+    if (hipMemsetAsync(row_ptr, 0, sizeof(int64_t) * (B + 1), s) != hipSuccess) return DVA_ERR_LAUNCH;
+    return DVA_OK;
+  }
+  const int Hc = cam0->img_h - cam0->crop_top - cam0->crop_bottom;
+  const int64_t npix = (int64_t)cam0->img_w * Hc;
+  if (n * B > 0x7fffffffLL || npix * B > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (!xyz || !idx || !x_pix || !y_pix || !depth || !x_proj || !y_proj || !workspace) return DVA_ERR_INVALID;
+  VisBatchLayout L;
+  int rc = vis_batch_layout(cam0, n, B, &L);
+  if (rc) return rc;
+  if ((int64_t)L.total > workspace_bytes) return DVA_ERR_INVALID;
+  char* ws = (char*)workspace;
+  int32_t* flag = (int32_t*)(ws + L.flag);
+  int32_t* pos = (int32_t*)(ws + L.pos);
+  float* dist_u = (float*)(ws + L.dist_u);
+  double* xp_u = (double*)(ws + L.xp_u);
+  double* yp_u = (double*)(ws + L.yp_u);
+  int32_t* idx1 = (int32_t*)(ws + L.idx1);
+  int32_t* simg = (int32_t*)(ws + L.simg);
+  float* dist = (float*)(ws + L.dist);
+  double* xp = (double*)(ws + L.xp);
+  double* yp = (double*)(ws + L.yp);
+  int4* splat = (int4*)(ws + L.splat);
+  uint8_t* seen = (uint8_t*)(ws + L.seen);
+  MapCounters* cnt = (MapCounters*)(ws + L.cnt);
+  unsigned long long* zbuf = (unsigned long long*)(ws + L.zbuf);
+  int32_t* pixmap = (int32_t*)(ws + L.pixmap);
+  int32_t* pixflag = (int32_t*)(ws + L.pixflag);
+  int32_t* pixpos = (int32_t*)(ws + L.pixpos);
+  const int64_t nc = n * B, npt = npix * B;
+
+  {
+    int gx = grid_for(n);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(project_batch_kernel, dim3(gx, B), dim3(256), 0, s, xyz, n, cams_dev, mask, flag, dist_u, xp_u,
+                       yp_u);
+  }
+  size_t tmp = L.temp_bytes;
+  if (rocprim::exclusive_scan(ws + L.temp, tmp, flag, pos, 0, (size_t)nc, rocprim::plus<int32_t>(), s) != hipSuccess)
+    return DVA_ERR_LAUNCH;
+  hipLaunchKernelGGL(compact_batch_kernel, dim3(grid_for(nc)), dim3(256), 0, s, n, B, flag, pos, dist_u, xp_u, yp_u,
+                     idx1, simg, dist, xp, yp, cnt);
+  hipLaunchKernelGGL(splat_batch_kernel, dim3(grid_for(nc)), dim3(256), 0, s, xyz, idx1, simg, dist, xp, yp, cams_dev,
+                     cnt, splat);
+  if (hipMemsetAsync(zbuf, 0xFF, (size_t)npt * 8, s) != hipSuccess) return DVA_ERR_LAUNCH;
+  {
+    int64_t blocks = (nc + 15) / 16;          // 4 wavefronts x 4 survivors per block iteration
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(zbuffer_batch_kernel, dim3((int)blocks), dim3(256), 0, s, splat, simg, dist, cnt, zbuf, Hc,
+                       npix);
+  }
+  if (cam0->exact) {
+    if (hipMemsetAsync(seen, 0, (size_t)nc, s) != hipSuccess) return DVA_ERR_LAUNCH;
+    if (hipMemsetAsync(pixmap, 0xFF, (size_t)npt * 4, s) != hipSuccess) return DVA_ERR_LAUNCH;
+    hipLaunchKernelGGL(seen_kernel, dim3(grid_for(npt)), dim3(256), 0, s, zbuf, npt, seen);
+    hipLaunchKernelGGL(resplat_batch_kernel, dim3(grid_for(nc)), dim3(256), 0, s, seen, simg, xp, yp, cnt, pixmap, Hc,
+                       cam0->crop_top, npix);
+  } else {
+    hipLaunchKernelGGL(winners_kernel, dim3(grid_for(npt)), dim3(256), 0, s, zbuf, npt, pixmap);
+  }
+  // output position of every mapped pixel: exclusive scan of (pixmap >= 0) read through a transform iterator (no flag
+  // array: one write + two reads of the B x map-sized plane less than the single-image build)
+  tmp = L.temp_bytes;
+  if (rocprim::exclusive_scan(ws + L.temp, tmp, rocprim::make_transform_iterator(pixmap, IsMapped()), pixpos, 0,
+                              (size_t)npt, rocprim::plus<int32_t>(), s) != hipSuccess)
+    return DVA_ERR_LAUNCH;
+  (void)pixflag;
+  hipLaunchKernelGGL(emit_batch_kernel, dim3(grid_for(npt)), dim3(256), 0, s, pixmap, pixpos, npix, B, Hc,
+                     cam0->crop_top, idx1, dist, xp, yp, idx, x_pix, y_pix, depth, x_proj, y_proj, row_ptr, n_out_dev);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_mapping_features_batch(const float* xyz, const int64_t* idx, const float* depth, const double* y_proj,
+                               const float* linearity, const float* planarity, const float* scattering,
+                               const float* normals, const dva_camera* cams_dev, const int64_t* row_ptr,
+                               int32_t n_images, int64_t q, float* features, int32_t* row_image, int32_t* n_cols,
+                               void* stream) {
+  if (!cams_dev || !row_ptr || q < 0 || n_images < 1) return DVA_ERR_INVALID;
+  const int ncol = 2 + (linearity != nullptr) + (planarity != nullptr) + (scattering != nullptr) +
+                   (normals != nullptr);
+  if (n_cols) *n_cols = ncol;
+  if (q == 0) return DVA_OK;
+  if (!xyz || !idx || !depth || !y_proj || !features) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(features_batch_kernel, dim3(grid_for(q)), dim3(256), 0, (hipStream_t)stream, xyz, idx, depth,
+                     y_proj, linearity, planarity, scattering, normals, cams_dev, row_ptr, (int)n_images, q, ncol,
+                     features, row_image);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -686,6 +686,25 @@ int dva_visibility(const float* xyz, int64_t n, const dva_camera* cam, const uin
                    double* y_proj, int64_t* n_out_dev, void* workspace, int64_t workspace_bytes,
                    void* stream);
 
+/* B images of ONE setting in one set of launches (reference core/data_transform/multimodal/image.py:192-428 loops
+ * over the images; core/multimodal/visibility.py:1073-1195 per image).  cam0 (host) = the camera of image 0: projection
+ * size, crops, model, exact, splatting parameters must be the same for all images; cams_dev = device array of the
+ * n_images cameras (poses / intrinsics per image).  Outputs as dva_visibility, rows of all images concatenated
+ * image-major (capacity n_images x the single-image capacity), row_ptr int64 [n_images + 1] = first row of every
+ * image (device), *n_out_dev = total.  No host synchronisation inside. */
+int64_t dva_visibility_batch_workspace_bytes(const dva_camera* cam0, int64_t n, int32_t n_images);
+int dva_visibility_batch(const float* xyz, int64_t n, const dva_camera* cam0, const dva_camera* cams_dev,
+                         int32_t n_images, const uint8_t* mask, int64_t* idx, int64_t* x_pix, int64_t* y_pix,
+                         float* depth, double* x_proj, double* y_proj, int64_t* row_ptr, int64_t* n_out_dev,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+/* dva_mapping_features for the rows of dva_visibility_batch (the camera of a row follows from row_ptr);
+ * row_image int32 [q] nullable receives the image of every row. */
+int dva_mapping_features_batch(const float* xyz, const int64_t* idx, const float* depth, const double* y_proj,
+                               const float* linearity, const float* planarity, const float* scattering,
+                               const float* normals, const dva_camera* cams_dev, const int64_t* row_ptr,
+                               int32_t n_images, int64_t q, float* features, int32_t* row_image, int32_t* n_cols,
+                               void* stream);
+
 /* Mapping features of the q surviving points (visibility.py:1548-1582); nullable inputs drop
  * their column exactly like the reference. features fp32 [q, n_cols], column order:
  * depth, linearity, planarity, scattering, orientation, pixel height. Returns n_cols via *n_cols. */

@@ -115,3 +115,91 @@ def test_lex_ops_golden_and_random():
     # empty input
     e = torch.zeros(0, dtype=torch.long, device=DEV)
     assert U.lexargunique(e, e).shape == (0,)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Batched build (dva_visibility_batch): B images of one setting in one set of launches
+# ---------------------------------------------------------------------------------------------------------------
+def _batch_inputs(g, B, slot, dev):
+    """B cameras of the fixture's setting: the fixture's own camera at position ``slot``, the others perturbed."""
+    rng = np.random.default_rng(B * 10 + slot)
+    kw = call_kwargs(g, dev)
+    pos = t(g["img_xyz"], dev).float().view(1, 3).repeat(B, 1)
+    pos = pos + torch.from_numpy(rng.normal(0, 0.3, (B, 3)).astype(np.float32)).to(dev)
+    pos[slot] = t(g["img_xyz"], dev).float()
+    out = {}
+    for k, v in kw.items():
+        if k == "img_mask":
+            out[k] = v
+            continue
+        vb = v.float().unsqueeze(0).repeat(B, *([1] * v.dim())).clone()
+        if k == "img_opk":
+            vb += torch.from_numpy(rng.normal(0, 0.2, tuple(vb.shape)).astype(np.float32)).to(dev)
+        elif k == "img_extrinsic":
+            vb[:, :3, 3] += torch.from_numpy(rng.normal(0, 0.3, (B, 3)).astype(np.float32)).to(dev)
+        vb[slot] = v.float()
+        out[k] = vb
+    return pos, out
+
+
+@pytest.mark.parametrize("name", VIS)
+def test_visibility_batch_golden(name):
+    """Every reference fixture through the batched build: the fixture's camera sits among four perturbed cameras of
+    the same setting; its rows must be the fixture's (bit-exact indices, pixels, depths), and every image's rows must
+    equal the single-image build of that camera."""
+    g = load_golden(name)
+    model = model_of(g)
+    B, slot = 5, 3
+    pos, kw = _batch_inputs(g, B, slot, DEV)
+    attrs = dict(linearity=t(g["linearity"], DEV), planarity=t(g["planarity"], DEV),
+                 scattering=t(g["scattering"], DEV), normals=t(g["normals"], DEV))
+    xyz = t(g["xyz"], DEV)
+    out = model.batch(xyz, pos, **attrs, **kw)
+    rp = out["row_ptr"].cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == out["idx"].shape[0] and (np.diff(rp) >= 0).all()
+    assert np.array_equal(out["image"].cpu().numpy(), np.repeat(np.arange(B), np.diff(rp)))
+    a, b = rp[slot], rp[slot + 1]
+    for k in ("idx", "x", "y"):
+        assert out[k].dtype == torch.int64
+        assert np.array_equal(out[k][a:b].cpu().numpy(), g[k]), k
+    assert np.array_equal(out["depth"][a:b].cpu().numpy(), g["depth"])
+    if len(g["idx"]):
+        np.testing.assert_allclose(out["features"][a:b].cpu().numpy(), g["features"], rtol=0, atol=2.5e-7)
+    for i in range(B):
+        kw_i = {k: (v if k == "img_mask" else v[i]) for k, v in kw.items()}
+        one = model(xyz, pos[i], **attrs, **kw_i)
+        a, b = rp[i], rp[i + 1]
+        for k in ("idx", "x", "y", "depth"):
+            assert torch.equal(out[k][a:b], one[k]), (i, k)
+        if b > a:
+            assert torch.equal(out["features"][a:b], one["features"]), i
+            assert torch.equal(out["x_proj"][a:b], one["x_proj"]) and torch.equal(out["y_proj"][a:b], one["y_proj"])
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_visibility_batch_full_size_equals_single(exact):
+    """S3DIS settings (2048 x 1024 projection map, 100 k candidates), 6 cameras: the batch is the concatenation of the
+    single-image builds, bit for bit; image 0 is also held to the C oracle."""
+    from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
+    rng = np.random.default_rng(1)
+    xyz = room_cloud(100_000, rng)
+    cams = np.array([[3.1, 2.2, 1.4], [5.0, 3.0, 1.2], [2.0, 4.5, 1.6], [6.5, 1.5, 1.5], [4.0, 3.0, 2.0], [1.0, 1.0, 1.0]],
+                    dtype=np.float32)
+    opk = rng.normal(0, 0.3, (6, 3)).astype(np.float32)
+    kw = dict(img_size=(2048, 1024), crop_top=0, crop_bottom=0, r_max=8.0, r_min=0.05, voxel=0.02, k_swell=1.0,
+              d_swell=1000, exact=exact)
+    model = SplattingVisibility(camera="s3dis_equirectangular", **kw)
+    xyz_d = torch.from_numpy(xyz).to(DEV)
+    out = model.batch(xyz_d, torch.from_numpy(cams).to(DEV), img_opk=torch.from_numpy(opk).to(DEV))
+    rp = out["row_ptr"].cpu().numpy()
+    for i in range(6):
+        one = model(xyz_d, torch.from_numpy(cams[i]).to(DEV), img_opk=torch.from_numpy(opk[i]).to(DEV))
+        a, b = rp[i], rp[i + 1]
+        assert b - a == one["idx"].shape[0]
+        for k in ("idx", "x", "y", "depth", "features"):
+            assert torch.equal(out[k][a:b], one[k]), (i, k)
+    cam0 = M.make_camera("s3dis_equirectangular", kw["img_size"], cams[0], r_min=kw["r_min"], r_max=kw["r_max"],
+                         voxel=kw["voxel"], k_swell=1.0, d_swell=1000, exact=exact, img_opk=opk[0])
+    ref = M.visibility(xyz, cam0)
+    for k in ("idx", "x", "y"):
+        assert np.array_equal(out[k][rp[0]:rp[1]].cpu().numpy(), ref[k]), k
