@@ -133,7 +133,7 @@ KERNEL_SYMBOL = {
     "chain_attn_bwd": "chain::attn_bwd_kernel<8, 4>",
     "chain_score_stats": "chain::score_stats_kernel",
     "chain_bwd_l6": "chain::layer_bwd_kernel<6, 3>",
-    "chain_bwd_l5": "chain::layer_bwd_kernel<5, 2>",
+    "chain_bwd_l5": "chain::layer_bwd_kernel<5, 3>",
     "chain_bwd_l2": "chain::layer_bwd_kernel<2, 3>",
     "chain_stats2": "chain::stats2_kernel",
     "chain_stats5": "chain::stats_mid_kernel<5>",
@@ -143,6 +143,12 @@ KERNEL_SYMBOL = {
 }
 # what bounds the kernel the roofline object is about (SQ counters: profiles/*sq_counters*)
 ROOFLINE_NOTES = {
+    "view_gather_rows_grad": "rows gradient = segmented reduction over the row plan (deterministic, no atomics): per view "
+                             "a 4-byte plan entry, a 16-byte record and the 128-byte grad_out row of its point, all at "
+                             "random addresses; the records cost a whole cache line each (PMC traffic 1.8 x the "
+                             "algorithmic bytes): bound by random-access throughput of the memory system",
+    "chain_bwd_l5": "layer-5 backward pass (x_map 32 + index 4 + gradient row in 64 + out 64 bytes per view, per-point "
+                    "rows): 166 VGPRs -> 3 wavefronts per SIMD since round 3",
     "chain_attn_bwd": "attention backward from the stored scores (softmax / gate backward, score gradients, view "
                       "records; no chain evaluation): 107 VGPRs -> 4 wavefronts per SIMD; the value rows it re-gathers "
                       "(128 of its ~184 bytes per view) come out of the cache hierarchy",
@@ -413,14 +419,26 @@ def fused_bwd_bytes(V, N, C, es, G=4):
     return V * (C * es + 16 + 8 + 16 + 16) + N * (C * es + 8)
 
 
-def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warmup=1):
-    """One secondary workload of SURVEY.md 8(d) (S2: ragged view counts; F-L: C = 512, value map > MALL):
-    ms/step and the roofline fractions of the fused view kernel (forward) and of the attention backward kernel."""
+def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warmup=1, interpolate=False, C_out=None):
+    """One secondary workload of SURVEY.md 8(d) (S2: ragged view counts; F-L: C = 512, value map > MALL; bilinear:
+    interpolate=True with the mapping at 8 x the map resolution): ms/step and the roofline fractions of the fused view
+    kernel (forward) and of the attention backward kernel."""
     wl = "S2" if name == "S2" else "S1"
     N = 1 << log2_points
-    scene = make_scene(N, views, 32, C, 64, 128, dtype, device, seed=4321, workload=wl)
-    mods = build_modules(C, device)
-    ms, kern = timed_steps(scene, mods, dtype, steps, warmup)
+    scene = make_scene(N, views, 32, C, 64, 128, dtype, device, seed=4321, workload=wl, upscale=8 if interpolate else 1)
+    mods = build_modules(C, device, C_out)
+    ms, kern = timed_steps(scene, mods, dtype, steps, warmup, interpolate=interpolate)
+    if interpolate:
+        # the fused bilinear path against the reference's materialised [V, C] dataflow on the same scene
+        ms_mat, _ = timed_steps(scene, mods, dtype, 2, 1, lazy=False, interpolate=True)
+        top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:6]
+        out = {"points": N, "views": int(scene["x_map"].shape[0]), "channels": C, "out_channels": C_out or C,
+               "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "fused_path": "emod_attn_fwd" in kern,
+               "materialised_ms_per_step": ms_mat, "speedup_vs_materialised": ms_mat / ms,
+               "top_kernels_ms": {n: v["ms"] / v["launches"] for n, v in top}}
+        del scene, mods
+        torch.cuda.empty_cache()
+        return out
     V = int(scene["x_map"].shape[0])
     es = 2 if dtype == torch.bfloat16 else 4
     out = {"points": N, "views": V, "channels": C, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3)}
@@ -688,6 +706,11 @@ def main():
             res["workloads"] = {
                 "S2": secondary_workload("S2", device, dtype, args.log2_points, views, 64),
                 "F-L": secondary_workload("F-L", device, dtype, args.log2_points, views, 512),
+                # interpolate=True (the published KITTI-360 configuration): C = 64 and the KITTI pair l0 128 -> 32
+                "bilinear_C64": secondary_workload("bilinear", device, dtype, args.log2_points, views, 64,
+                                                   interpolate=True),
+                "bilinear_kitti_128_32": secondary_workload("bilinear", device, dtype, args.log2_points, views, 128,
+                                                            interpolate=True, C_out=32),
             }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))

@@ -525,7 +525,6 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
   f32x16 accW = {0}, accS = {0};      // layer weight gradient; P (STAGE 2)
-  f32x16 accU = {0};                  // STAGE 5: per-point sums of dz5 (carried over the fragments of a long point)
   bf16_t* ta = s_ta[wv];
   bf16_t* tb_ = s_tb[wv];
   bf16_t* tc = s_tc[STAGE == 2 ? wv : 0];
@@ -549,12 +548,12 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
     p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
-    if (STAGE == 6) {
-      // (the score gradients are loaded in the body: they are consumed late, and 2 x 4 prefetch registers spilled)
-    } else {
+    if (STAGE == 2) {
       p.dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB);
       p.dhi = ld128(DI, ok ? view * 64u + 32u * h + 16u : OOB);
     }
+    // (stage 6: the score gradients, stage 5: the gradient row are loaded in the body: they are consumed late, and
+    //  keeping two prefetch sets of them costs the occupancy step)
     return p;
   }, [&](const Pre& p) {
     const int nv = p.ti.nv;
@@ -603,6 +602,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       wave_sync();
     } else if constexpr (STAGE == 5) {
       f32x16 uacc = load_u(U, ok, p.vpj, h);
+      const u32x4 dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB), dhi = ld128(DI, ok ? view * 64u + 32u * h + 16u : OOB);
       // forward up to layer 5
       bf16x8 a1[2], a2[2];
       asm volatile("" ::: "memory");
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       }
       {
         const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
-        const f32x16 dy5 = unpack_da(p.dlo, p.dhi);       // stage 6 hands leaky'(y5) da5
+        const f32x16 dy5 = unpack_da(dlo, dhi);           // stage 6 hands leaky'(y5) da5
         bn_bwd_apply(z5, dy5, s_tab[2], h, dz);
       }
       pack16(dz, keep, dzp);
@@ -645,17 +645,23 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       wave_sync();
       accW = wgrad(ta, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
       const int frag = p.ti.frag;
-      if (frag == 0 || frag == 1) accU = zero;
-      accU = wgrad(ta, ind, j, h, accU);      // du[c][local point j]
+      const f32x16 accU = wgrad(ta, ind, j, h, zero);      // du[c][local point j] of this tile
       if (h == 0 && ok) ind[lpj * TSB + j] = 0;           // leave the indicator tile clean for the next tile
-      if (frag == 0 || frag == 3) {
+      {
         const bool wr = j < nseg;
         const uint32_t pt = wr ? (uint32_t)plp[j] : 0u;
-        const __amdgpu_buffer_rsrc_t DU = make_rsrc(du, (uint64_t)N * 128);
+        if (frag == 0) {
+          const __amdgpu_buffer_rsrc_t DU = make_rsrc(du, (uint64_t)N * 128);
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-          st128(DU, wr ? pt * 128u + (8u * qq + 4u * h) * 4u : OOB,
-                as_u4(accU[4 * qq], accU[4 * qq + 1], accU[4 * qq + 2], accU[4 * qq + 3]));
+          for (int qq = 0; qq < 4; ++qq)
+            st128(DU, wr ? pt * 128u + (8u * qq + 4u * h) * 4u : OOB,
+                  as_u4(accU[4 * qq], accU[4 * qq + 1], accU[4 * qq + 2], accU[4 * qq + 3]));
+        } else if (wr) {
+          // a point with more than 32 views: its fragments add up in the (caller-zeroed) row -- no accumulator carried
+          // across the tiles (16 registers for the sake of the rare long point cost the third wavefront per SIMD)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(&du[(size_t)pt * D + chan(r, h)], accU[r]);
+        }
       }
       wave_sync();
     } else {
@@ -944,9 +950,10 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
                      grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, \
                      n_views, n_points)
-  // stage 5 at two wavefronts per SIMD: with the 168 registers of three it spills 13 and runs 2.13 instead of 1.46 ms
+  static const int occ5 = tune_int("DVA_STAGE5_OCC", 3);
   if (stage == 6) DVA_LAYER_BWD(6, 3);
-  else if (stage == 5) DVA_LAYER_BWD(5, 2);
+  else if (stage == 5 && occ5 == 2) DVA_LAYER_BWD(5, 2);
+  else if (stage == 5) DVA_LAYER_BWD(5, 3);
   else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD
   DVA_CHECK_LAUNCH();
