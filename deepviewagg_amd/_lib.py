@@ -118,7 +118,7 @@ SIGNATURES = {
     "dva_chain_prep": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "dva_chain_tile_count": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "dva_chain_tile_build": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
-    "dva_chain_moments": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "dva_chain_moments": (ctypes.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "dva_chain_stats2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_pooled": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_stats": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
@@ -146,11 +146,21 @@ SIGNATURES = {
     "dva_chain_tile_chunks": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "dva_chain_tile_offsets": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "dva_bn_bwd_consts": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),
-    "dva_chain_stats1": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
-    "dva_chain_dw1": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dva_chain3_prep": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "dva_chain3_stats2": (ctypes.c_int, [_vp] * 10 + [_i64, _vp]),
+    "dva_chain3_stats": (ctypes.c_int, [_i32] + [_vp] * 10 + [_i64, _i64, _vp]),
+    "dva_chain3_scores": (ctypes.c_int, [_vp] * 11 + [_i32, _vp, _i64, _i64, _vp]),
+    "dva_chain3_score_stats": (ctypes.c_int, [_vp] * 14 + [_i32, _i64, _i64, _vp]),
+    "dva_chain3_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i64, _i64, _vp]),
+    "dva_chain_stats1": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "dva_chain_dw1": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dva_chain_set_prep": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "dva_chain_set_fwd": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_set_bwd": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                         _i64, _vp]),
+    "dva_chain3_set_prep": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "dva_chain3_set_fwd": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dva_chain3_set_bwd": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
                                          _i64, _vp]),
     "dva_voxel_parent_workspace_bytes": (ctypes.c_int64, [_i64]),
     "dva_voxel_parent_index": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),

@@ -832,14 +832,15 @@ __global__ void bn_bwd_consts_kernel(double* __restrict__ stats, const float* __
 // of x_map (mom fp64 [44] = SX [8] | upper triangle of XX, row-major).  One thread per entry, fp64.
 // P fp32 [32][20] = sum_v dy1 [x_hi (8) | x_lo (8) | 1 | .]^T from stage 2.
 __global__ void dw1_kernel(const float* __restrict__ P, const double* __restrict__ mom, const float* __restrict__ W1,
-                           const float* __restrict__ bn1, const float* __restrict__ sm1, float* __restrict__ dW1) {
+                           int exact_w1, const float* __restrict__ bn1, const float* __restrict__ sm1,
+                           float* __restrict__ dW1) {
   const int i = threadIdx.x >> 3, k = threadIdx.x & 7;
   double acc = 0.0;
 #pragma unroll
   for (int l = 0; l < 8; ++l) {
     const int a = l < k ? l : k, b = l < k ? k : l;
     const double xx = mom[8 + a * 8 - a * (a - 1) / 2 + (b - a)];
-    acc += (double)bf2f(f2bf(W1[i * 8 + l])) * xx;
+    acc += (exact_w1 ? (double)W1[i * 8 + l] : (double)bf2f(f2bf(W1[i * 8 + l]))) * xx;
   }
   const double mean = bn1[i], inv = bn1[D + i], gam = bn1[2 * D + i], sx = mom[k];
   const double q = inv * (acc - mean * sx);
@@ -848,14 +849,15 @@ __global__ void dw1_kernel(const float* __restrict__ P, const double* __restrict
 }
 
 // statistics of the BatchNorm-1 backward from P: S1 = sum dy1 = P[:, 16]; sum dy1 z1 with z1 = bf16(W1) x
-__global__ void stats1_from_p_kernel(const float* __restrict__ P, const float* __restrict__ W1,
+__global__ void stats1_from_p_kernel(const float* __restrict__ P, const float* __restrict__ W1, int exact_w1,
                                      double* __restrict__ stats) {
   const int n = threadIdx.x;
   if (n >= D) return;
   double s2 = 0.0;
 #pragma unroll
   for (int f = 0; f < 8; ++f)
-    s2 += (double)bf2f(f2bf(W1[n * 8 + f])) * ((double)P[n * 20 + f] + (double)P[n * 20 + 8 + f]);
+    s2 += (exact_w1 ? (double)W1[n * 8 + f] : (double)bf2f(f2bf(W1[n * 8 + f]))) *
+          ((double)P[n * 20 + f] + (double)P[n * 20 + 8 + f]);
   stats[n] = (double)P[n * 20 + 16];
   stats[D + n] = s2;
 }
@@ -982,17 +984,17 @@ int dva_bn_bwd_consts(double* stats, const float* bn, double inv_m, int32_t do_h
   return DVA_OK;
 }
 
-int dva_chain_stats1(const float* P, const float* W1, double* stats, void* stream) {
+int dva_chain_stats1(const float* P, const float* W1, int32_t exact_w1, double* stats, void* stream) {
   if (!P || !W1 || !stats) return DVA_ERR_INVALID;
-  hipLaunchKernelGGL(stats1_from_p_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P, W1, stats);
+  hipLaunchKernelGGL(stats1_from_p_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P, W1, (int)exact_w1, stats);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
 
-int dva_chain_dw1(const float* P, const double* mom, const float* W1, const float* bn1, const float* sm1, float* dW1,
-                  void* stream) {
+int dva_chain_dw1(const float* P, const double* mom, const float* W1, int32_t exact_w1, const float* bn1,
+                  const float* sm1, float* dW1, void* stream) {
   if (!P || !mom || !W1 || !bn1 || !sm1 || !dW1) return DVA_ERR_INVALID;
-  hipLaunchKernelGGL(dw1_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P, mom, W1, bn1, sm1, dW1);
+  hipLaunchKernelGGL(dw1_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, P, mom, W1, (int)exact_w1, bn1, sm1, dW1);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -955,7 +955,6 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
     const uint32_t keep = ok ? 0xffffffffu : 0u;
-    const uint32_t view = (uint32_t)(p.ti.v0 + j);
     // the handed-over gradient [V][CO] reaches 4 GiB at the headline size (V = 2^25, CO = 64): one descriptor per tile
     const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)p.ti.v0 * CO, (uint64_t)p.ti.nv * CO * 2);
     f32x16 za[NB];

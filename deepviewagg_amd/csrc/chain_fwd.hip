@@ -242,12 +242,13 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
 }
 
 // statistics of z1 = bf16(W1) x from the moments: stats = sum z1 | sum z1^2 (the form dva_bn_finalize takes)
-__global__ void stats1_kernel(const double* __restrict__ mom, const float* __restrict__ W1,
+// exact_w1: the fp32 chain (chain_f32.hip) multiplies with W1 itself (hi + lo), the bf16 chain with bf16(W1)
+__global__ void stats1_kernel(const double* __restrict__ mom, const float* __restrict__ W1, int exact_w1,
                               double* __restrict__ stats) {
   const int c = threadIdx.x;
   if (c >= D) return;
   double w[8];
-  for (int f = 0; f < 8; ++f) w[f] = (double)bf2f(f2bf(W1[c * 8 + f]));
+  for (int f = 0; f < 8; ++f) w[f] = exact_w1 ? (double)W1[c * 8 + f] : (double)bf2f(f2bf(W1[c * 8 + f]));
   double s = 0, q = 0;
   int k = 0;
   for (int i = 0; i < 8; ++i) {
@@ -889,8 +890,8 @@ int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_
   return DVA_OK;
 }
 
-int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, double* moments, double* stats1,
-                      void* stream) {
+int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, int32_t exact_w1, double* moments,
+                      double* stats1, void* stream) {
   if (n_views < 0 || !moments || !stats1 || !W1) return DVA_ERR_INVALID;
   if (n_views > 0) {
     if (!x_map) return DVA_ERR_INVALID;
@@ -901,7 +902,7 @@ int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, doub
                        x_map, n_views, moments);
     DVA_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(stats1_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments, W1, stats1);
+  hipLaunchKernelGGL(stats1_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments, W1, (int)exact_w1, stats1);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

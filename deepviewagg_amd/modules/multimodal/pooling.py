@@ -332,7 +332,11 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
                         and fused_deepset.applicable(self.E_map, self.E_score, x_map))
         if fused_scores:
             # DeepSetFeat + E_score in the fused row-streaming kernels (fp32, hand-written backward)
-            compatibilities = fused_deepset.deepset_linear(self.E_map, self.E_score, x_map, csr_idx)
+            if fused_chain.scores_applicable(self.E_map, self.E_score, x_map, csr_idx):
+                # fp32-class recompute chain (csrc/chain_f32.hip): no stored [V, 32] activation
+                compatibilities = fused_chain.chain_scores(self.E_map, self.E_score, x_map, csr_idx)
+            else:
+                compatibilities = fused_deepset.deepset_linear(self.E_map, self.E_score, x_map, csr_idx)
         else:
             x_map = self.E_map(x_map, csr_idx)
         if isinstance(x_mod, ops.GatheredFeatures) and not self.use_mod:

@@ -394,9 +394,10 @@ int dva_chain_tile_count(const int64_t* ptr, const int64_t* chunk_points, int32_
 int dva_chain_tile_build(const int64_t* ptr, const int64_t* chunk_points, int32_t n_chunks,
                          const int64_t* offsets, void* tiles, void* stream);
 /* moments double[44] (caller-zeroed) += sum_v x | sum_v x_i x_j (i <= j, row-major upper triangle);
- * stats1 double[64] = sum z1 | sum z1^2 of z1 = bf16(W1) x, derived from the moments. */
-int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, double* moments, double* stats1,
-                      void* stream);
+ * stats1 double[64] = sum z1 | sum z1^2 of z1 = bf16(W1) x, derived from the moments (exact_w1 != 0: of z1 = W1 x,
+ * the first layer of the fp32-class chain dva_chain3_*; the same flag on dva_chain_stats1 / dva_chain_dw1). */
+int dva_chain_moments(const float* x_map, int64_t n_views, const float* W1, int32_t exact_w1, double* moments,
+                      double* stats1, void* stream);
 /* stats double[96] (caller-zeroed) += sum z2 | sum z2^2 | sum a1 (the layer's input: what dva_chain_bn_consts needs
  * for the folded shift); zstar fp32 [N][32] / arg int32 [N][32] = value / first view of the per-point extremum of
  * sign(gamma2) z2 (the view that max-pools a2 = leaky(BN2(z2))). */
@@ -479,12 +480,12 @@ int dva_bn_bwd_consts(double* stats, const float* bn, double inv_m, int32_t do_h
 /* Statistics of the BatchNorm-1 backward from P (stage 2 of dva_chain_bwd_layer): P fp32 [32][20] = sum_v dy1
  * [x_hi (8) | x_lo (8) | 1 | unused (3)]^T; stats fp64 [64] = sum dy1 (= P[:, 16]) | sum dy1 z1 with z1 = bf16(W1) x
  * (= sum_f bf16(W1)[:, f] (P[:, f] + P[:, 8 + f]): z1 is linear in x).  Raw-z form like every other "stats". */
-int dva_chain_stats1(const float* P, const float* W1, double* stats, void* stream);
+int dva_chain_stats1(const float* P, const float* W1, int32_t exact_w1, double* stats, void* stream);
 /* First-layer weight gradient without another view pass: BatchNorm-1 backward is linear in its statistics and
  * z1 = W1 x is linear in x, so dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q), Q = sum_v z1_hat x^T from the moments.
  * P fp32 [32][20] (dva_chain_bwd_layer stage 2: x_map as hi | lo columns), mom fp64 [44] (dva_chain_moments), sm1 = S/M of layer 1. */
-int dva_chain_dw1(const float* P, const double* mom, const float* W1, const float* bn1, const float* sm1, float* dW1,
-                  void* stream);
+int dva_chain_dw1(const float* P, const double* mom, const float* W1, int32_t exact_w1, const float* bn1,
+                  const float* sm1, float* dW1, void* stream);
 /* Per-point set branch of DeepSetFeat on the chain (pooling.py:660-664): pooled fp32 [N][32] (+ the set-size
  * feature sqrt(1 / (n + 1e-3)) when w33 = Wsa[:, 32] is given) -> mlp_set = MLP[32(+1), 32, 32] -> u = Wc[:, 32:] . s,
  * the per-point half of the concatenation layer.  Every pass re-evaluates the branch from pooled (three-term bf16
@@ -542,6 +543,54 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
                         const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream);
+/* ---- The recompute chain in fp32-class arithmetic: DeepSetFeat + E_score for fp32 features OUTSIDE torch.autocast
+ * (the reference's default, models/base_model.py:244), replacing the stored-activation passes dva_deepset_*.
+ * Same passes, tiles, statistics and hand-over rules as dva_chain_* above; every product is the three-term bf16 split
+ * W x ~ W_hi x_hi + W_lo x_hi + W_hi x_lo (hi + lo = 16 mantissa bits, dropped term < 2^-16 relative), BatchNorm +
+ * LeakyReLU in fp32 on the fp32 accumulators (no BatchNorm folding; leaky' follows the sign of the plain
+ * pre-activation), gradient rows between the passes fp32 [V][32].  bn tables: fp32 [>= 4][32] mean | invstd | gamma | beta.
+ * The attention (softmax, value gather, weighted sum, gate) stays in dva_view_gather_attention_*; these entries
+ * produce the scores fp32 [V][4] (columns >= G zero) and consume their gradient fp32 [V][4].
+ *   dva_chain3_prep         ops: 32 KiB device buffer (32 operand blocks: per matrix hi | lo)
+ *   dva_chain3_stats2       as dva_chain_stats2; stats double[64] (no input sums)
+ *   dva_chain3_stats        layer 5 / 6, stats double[64]
+ *   dva_chain3_scores       x_map -> scores
+ *   dva_chain3_score_stats  as dva_chain_score_stats
+ *   dva_chain3_bwd_layer    as dva_chain_bwd_layer, da_in / da_out fp32 [V][32]
+ * The per-point set branch (dva_chain_set_*), dva_chain_moments / dva_chain_stats1 / dva_chain_dw1 (exact_w1 = 1),
+ * dva_chain_pooled and dva_chain_route_stats are shared with the bf16 chain. */
+int dva_chain3_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6, const float* Ws,
+                    int32_t G, void* ops, void* stream);
+int dva_chain3_stats2(const float* x_map, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                      const void* ops, const float* bn1, const float* gamma2, double* stats, float* zstar,
+                      int32_t* arg, int64_t n_views, void* stream);
+int dva_chain3_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                     const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                     double* stats, int64_t n_views, int64_t n_points, void* stream);
+int dva_chain3_scores(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                      const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                      const float* bn6, const float* score_bias, int32_t G, float* scores, int64_t n_views,
+                      int64_t n_points, void* stream);
+int dva_chain3_score_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                           const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
+                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream);
+int dva_chain3_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
+                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
+                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
+                         const float* da_in, float* da_out, float* dW, float* du, float* P, double* stats,
+                         int64_t n_views, int64_t n_points, void* stream);
+/* The per-point set branch of the fp32 chain: dva_chain_set_* on the fp32 matrix cores (ops: 24 KiB). */
+int dva_chain3_set_prep(const float* Wsa, int32_t ld_sa, const float* Wsb, const float* Wc, int32_t ld_c, void* ops,
+                        void* stream);
+int dva_chain3_set_fwd(int32_t stage, const float* pooled, const int64_t* ptr, const float* w33, const void* ops,
+                       const float* bn_s1, const float* bn_s2, float* u, double* stats, int64_t n_points,
+                       void* stream);
+int dva_chain3_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, const float* w33, const void* ops,
+                       const float* bn_s1, const float* bn_s2, const float* sm_s1, const float* sm_s2,
+                       const float* du, float* dpooled, float* dW, int32_t ld_dw, float* dw33, double* stats,
+                       int64_t n_points, void* stream);
 /* stats += S1 | S2 of layer 2, per-point part: sum over the seen points of leaky'(BN2(zstar)) dpooled (x z_hat);
  * dpooled_dy fp32 [N][32] = leaky'(BN2(zstar)) dpooled (0 for unseen points): the `dpooled` of stage 2. */
 int dva_chain_route_stats(const float* zstar, const float* dpooled, const float* bn2, const int64_t* ptr,

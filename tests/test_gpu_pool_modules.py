@@ -17,6 +17,16 @@ POOL_CASES = ["pool_group_default_train", "pool_group_default_eval", "pool_group
               "pool_qkv_default", "pool_qkv_modqk"]
 
 
+@pytest.fixture
+def stored_activation_passes():
+    """Pin the fp32 scores to the stored-activation kernels of fused_deepset (the default for <= 4 scores per view is
+    the fp32-class recompute chain, covered by tests/test_gpu_chain3.py)."""
+    from deepviewagg_amd import fused_chain
+    fused_chain.SCORES_CHAIN = False
+    yield
+    fused_chain.SCORES_CHAIN = True
+
+
 def close(a, b, rtol=1e-4, atol=1e-5):
     if isinstance(b, np.ndarray):
         b = t(b)
@@ -180,7 +190,7 @@ def test_lazy_gather_path_matches_oracle(cls_name, train):
 
 
 @pytest.mark.parametrize("name", ["pool_group_default_train", "pool_group_default_eval", "pool_qkv_default"])
-def test_fused_deepset_matches_reference(name):
+def test_fused_deepset_matches_reference(name, stored_activation_passes):
     """Same golden cases, but through the fused DeepSetFeat kernels (x_map without grad, no save_last)."""
     from deepviewagg_amd.modules.multimodal import pooling as P
     from deepviewagg_amd import fused_deepset
@@ -211,7 +221,7 @@ def test_fused_deepset_matches_reference(name):
             assert int(v) == int(g["sd_after/" + k])
 
 
-def test_fused_deepset_large_vs_generic():
+def test_fused_deepset_large_vs_generic(stored_activation_passes):
     """V ~ 300k views with ragged / empty segments: fused kernels vs the generic composition."""
     from deepviewagg_amd.modules.multimodal import pooling as P
     from deepviewagg_amd import fused_deepset
@@ -247,7 +257,7 @@ def test_fused_deepset_large_vs_generic():
             close(a, b, rtol=1e-4, atol=1e-5)
 
 
-def test_deepset_mfma_equals_valu_generation():
+def test_deepset_mfma_equals_valu_generation(stored_activation_passes):
     """The fp32-MFMA layer kernels (algo 0) against the first-generation VALU kernels (algo 1): both are
     exact fp32 fma chains, only the summation order differs."""
     from deepviewagg_amd.modules.multimodal import pooling as P
@@ -278,7 +288,7 @@ def test_deepset_mfma_equals_valu_generation():
         assert float((a - b).abs().max()) / scale < 2e-3, (n, float((a - b).abs().max()), scale)
 
 
-def test_deepset_bf16_activation_storage():
+def test_deepset_bf16_activation_storage(stored_activation_passes):
     """bf16 STORAGE of the [V, 32] activations / gradients between the DeepSet kernels (what the fused path
     selects inside torch.autocast(bfloat16)); arithmetic, statistics and parameters stay fp32.
     Tolerance: the error against the fp32 reference maths must not exceed the error of the reference maths
@@ -338,7 +348,7 @@ def test_deepset_bf16_activation_storage():
 
 
 
-def test_deepset_recompute_equals_stored_activations():
+def test_deepset_recompute_equals_stored_activations(stored_activation_passes):
     """bf16 storage with RECOMPUTE (a4 never stored, layer outputs rebuilt from the layer inputs in the
     backward passes) against the stored-activation variant: same maths, the recomputed values are the fp32
     ones instead of their bf16 roundings -> relative L2 differences at the 2^-9 level."""
