@@ -147,11 +147,11 @@ SIGNATURES = {
     "dva_chain_tile_offsets": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "dva_bn_bwd_consts": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),
     "dva_chain3_prep": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
-    "dva_chain3_stats2": (ctypes.c_int, [_vp] * 10 + [_i64, _vp]),
-    "dva_chain3_stats": (ctypes.c_int, [_i32] + [_vp] * 10 + [_i64, _i64, _vp]),
-    "dva_chain3_scores": (ctypes.c_int, [_vp] * 11 + [_i32, _vp, _i64, _i64, _vp]),
-    "dva_chain3_score_stats": (ctypes.c_int, [_vp] * 14 + [_i32, _i64, _i64, _vp]),
-    "dva_chain3_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i64, _i64, _vp]),
+    "dva_chain3_stats2": (ctypes.c_int, [_vp] * 11 + [_i64, _vp]),
+    "dva_chain3_stats": (ctypes.c_int, [_i32] + [_vp] * 9 + [_i64, _i64, _vp]),
+    "dva_chain3_scores": (ctypes.c_int, [_vp] * 7 + [_i32, _vp, _i64, _vp]),
+    "dva_chain3_score_stats": (ctypes.c_int, [_vp] * 10 + [_i32, _i64, _vp]),
+    "dva_chain3_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 19 + [_i64, _i64, _vp]),
     "dva_chain_stats1": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "dva_chain_dw1": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dva_chain_set_prep": (ctypes.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),

@@ -608,6 +608,29 @@ __device__ __forceinline__ float seg_scan_max(float v, const SegInfo& s, int lan
 __device__ __forceinline__ float seg_scan_sum(float v, const SegInfo& s, int lane) {
   return seg_scan(v, s, [](float a, float b) { return a + b; });
 }
+// the sum scan with float masks (1 / 0 per step) instead of selects: v += shifted(v) * mask -- a DPP move (lanes without
+// a source read 0) and one fma per step, which hipcc may fold into a single v_fmac_f32_dpp
+struct SegMaskF {
+  float pd[4], pb;
+};
+__device__ __forceinline__ SegMaskF seg_mask_f(const SegInfo& s) {
+  SegMaskF m;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m.pd[k] = s.pd[k] ? 1.f : 0.f;
+  m.pb = s.pb ? 1.f : 0.f;
+  return m;
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_zero(float x) {       // lanes without a source lane (or outside ROW_MASK) read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float seg_scan_sum_f(float v, const SegMaskF& m) {
+  v = __builtin_fmaf(dpp_zero<0x111>(v), m.pd[0], v);
+  v = __builtin_fmaf(dpp_zero<0x112>(v), m.pd[1], v);
+  v = __builtin_fmaf(dpp_zero<0x114>(v), m.pd[2], v);
+  v = __builtin_fmaf(dpp_zero<0x118>(v), m.pd[3], v);
+  return __builtin_fmaf(dpp_zero<0x142, 0xa>(v), m.pb, v);     // row_bcast:15 into rows 1, 3
+}
 // value of the segment's last lane, in every lane of the segment
 __device__ __forceinline__ float seg_total(float scanned, const SegInfo& s, int h) {
   return shfl(scanned, 32 * h + s.se);

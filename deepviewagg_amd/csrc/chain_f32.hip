@@ -1,29 +1,34 @@
-// Recompute chain in fp32: the DeepSetFeat scores and their backward for fp32 features outside torch.autocast -- the
-// reference's default arithmetic (models/base_model.py:244 `enabled=is_mixed_precision()`).
+// The DeepSetFeat chain in fp32: scores and their backward for fp32 features outside torch.autocast -- the reference's
+// default arithmetic (models/base_model.py:244 `enabled=is_mixed_precision()`).
 //
-// Same passes, same tile geometry, same statistics / hand-over rules and the same per-point set branch (chain_set.hip) as
-// the bf16 chain of chain_fwd.hip / chain_bwd.hip; what differs is the arithmetic: every product runs on the fp32 matrix
-// cores (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain, 64 cycles per instruction and SIMD = the fp32 vector rate),
+// Same tile geometry, statistics / hand-over rules and per-point set branch as the bf16 chain of chain_fwd.hip /
+// chain_bwd.hip; what differs is the arithmetic: every product runs on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain, 64 cycles per instruction and SIMD = the fp32 vector rate),
 // BatchNorm + LeakyReLU in fp32 on the accumulators (no BatchNorm folding; leaky' follows the sign of the plain
 // pre-activation), and the gradient rows handed between the backward passes are fp32 [V, 32] (128 bytes per view).
+//
+// Balance.  A 32 x 32 x 32 product costs 16 instructions x 64 cycles per tile: a pass that re-evaluates the chain from
+// x_map is bound by the matrix pipe at a third of the HBM bandwidth (measured: 21.2 ms for the eight passes, 71 - 83 %
+// matrix-pipe utilisation).  So two raw layer outputs stay in HBM -- z2 (written by the layer-2 statistics pass) and z5
+// (written by the layer-5 statistics pass), fp32 [V, 32] each -- and every later pass starts from one of them: one
+// 128-byte row per view read back replaces the 20 .. 52 instructions that would recompute it.  (The stored-activation
+// kernels of deepset_mfma.hip keep thirteen such tensors and are HBM-bound at 24.5 ms.)
 //
 // Layout.  One wavefront owns a 32-view tile; lane (j, h) = view j, half h.  D[i][j] += sum_{kk<2} A[i][kk] B[kk][j] with
 // lane l supplying A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31]; register r of lane (j, h) holds
 // D[chan(r, h)][j].  A layer D = W a takes i = output channel, j = view and pairs, in k-step s, the input channels
-// (chan(s, 0), chan(s, 1)) -- which is register s of the two half-waves of the previous layer's accumulators: the chain
-// runs in registers, the B operand of step s IS accumulator s.  The A operands (weights, one float per lane and step)
-// come from an LDS table: per matrix 4 blocks of 64 float4 (steps 4q .. 4q + 3 of lane l at block q, entry l).
+// (chan(s, 0), chan(s, 1)) -- which is register s of the two half-waves of the previous layer's accumulators (and of
+// a stored row loaded in the same order): the B operand of step s IS entry s.  The A operands (weights, one float per
+// lane and step) come from an LDS table: per matrix 4 blocks of 64 float4 (steps 4q .. 4q + 3 of lane l at block q).
 // Weight gradients dW[n][k] = sum_v dz[v][n] a[v][k] pair the views (2s, 2s + 1) in step s; both operands come from
 // [view][channel] fp32 tiles in LDS (row stride 36 floats: float4 row writes and column reads without bank conflicts).
-//
-// The passes are bound by the matrix pipe, not by HBM: 16 instructions x 64 cycles per 32 x 32 x 32 product and tile.
 //   dva_chain3_prep         operand table (27 KiB)
-//   dva_chain3_stats2       statistics of layer 2 + per-point extremum (set pooling)
-//   dva_chain3_stats        statistics of layer 5 / 6
-//   dva_chain3_scores       x_map -> scores fp32 [V, 4]  (score layer on the vector units: 4 rows of 32)
-//   dva_chain3_score_stats  dWs, dbs, S of layer 6 from the score gradients
-//   dva_chain3_bwd_layer    stages 6, 5, 2 (as dva_chain_bwd_layer; hand-offs fp32)
-// Replaces the 13 stored-activation passes of deepset_mfma.hip (24.5 of the 35.0 ms of the fp32 step).
+//   dva_chain3_stats2       x_map -> z2 (stored), statistics of layer 2 + per-point extremum (set pooling)
+//   dva_chain3_stats        layer 5: z2 -> z5 (stored) + statistics; layer 6: z5 -> statistics of z6
+//   dva_chain3_scores       z5 -> scores fp32 [V, 4]  (score layer on the vector units: 4 rows of 32)
+//   dva_chain3_score_stats  z5, score gradients -> dWs, dbs, S of layer 6
+//   dva_chain3_bwd_layer    stages 6 (from z5), 5 (from z2), 2 (from x_map + z2); hand-offs fp32
+//   dva_chain3_set_*        the per-point set branch (chain_set.hip) on the fp32 matrix cores
 #include "chain_split.h"
 
 namespace dva {
@@ -111,14 +116,42 @@ __device__ __forceinline__ f32x16 mm_x(const float4* s_w, int q0, int lane, cons
   c = F32_MFMA(w.w, x.w, c);
   return c;
 }
-// da6 = Ws^T dc: 2 steps; dc of the view in both half-waves
-__device__ __forceinline__ f32x16 mm_dc(const float4* s_w, int q0, int lane, const float4& dc, int h) {
-  asm volatile("" ::: "memory");
-  const float4 w = s_w[q0 * 64 + lane];
-  f32x16 c = {0};
-  c = F32_MFMA(w.x, h ? dc.y : dc.x, c);
-  c = F32_MFMA(w.y, h ? dc.w : dc.z, c);
-  return c;
+// Score layer + BatchNorm-6 backwards on the vector units, four channels at a time (chain_common.h layer_bwd with
+// da6 = Ws^T dc folded in: 4 fma per value from the Q_WSV block, entry 2r + h = Ws[0..3][chan(r, h)]):
+//   dy = leaky'(y6) da6;  STATS: st[0] += dy, st[1] += dy z6;  APPLY: dz = G dy - K1 - K2 z6
+// keep = ~0 / 0: zeroes dz in the lanes without a view (an AND: the select form of the mask made hipcc spill)
+template <bool STATS, bool APPLY>
+__device__ __forceinline__ void score_layer_bwd(const f32x16& z, const float4& dc, const float4* wsv, const float* tab,
+                                                int h, uint32_t keep, float (&st)[2][16], float (&dz)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    asm volatile("" ::: "memory");
+    const int o = 16 * h + 4 * q;
+    const float4 g4 = *reinterpret_cast<const float4*>(tab + T_G * D + o);
+    const float4 b4 = *reinterpret_cast<const float4*>(tab + T_B * D + o);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+    float k1[4] = {0.f, 0.f, 0.f, 0.f}, k2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (APPLY) {
+      const float4 a4 = *reinterpret_cast<const float4*>(tab + T_K1 * D + o);
+      const float4 c4 = *reinterpret_cast<const float4*>(tab + T_K2 * D + o);
+      k1[0] = a4.x; k1[1] = a4.y; k1[2] = a4.z; k1[3] = a4.w;
+      k2[0] = c4.x; k2[1] = c4.y; k2[2] = c4.z; k2[3] = c4.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      const float4 w = wsv[2 * r + h];
+      const float da = __builtin_fmaf(w.w, dc.w, __builtin_fmaf(w.z, dc.z, __builtin_fmaf(w.y, dc.y, w.x * dc.x)));
+      const float y = __builtin_fmaf(z[r], g[e], b[e]);
+      const float dy = y > 0.f ? da : SLOPE * da;
+      if (STATS) {
+        st[0][r] += dy;
+        st[1][r] = __builtin_fmaf(dy, z[r], st[1][r]);
+      }
+      if (APPLY)
+        dz[r] = __uint_as_float(__float_as_uint(__builtin_fmaf(-k2[e], z[r], __builtin_fmaf(g[e], dy, -k1[e]))) & keep);
+    }
+  }
 }
 // BatchNorm + LeakyReLU in fp32: a = leaky(z G + B)
 template <typename Z16>
@@ -130,26 +163,42 @@ __device__ __forceinline__ void act(const Z16& z, const float* tab, int h, float
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = leaky(__builtin_fmaf(z[r], g[r], b[r]));
 }
-// [view][channel] fp32 tile, row stride TS
+// [channel][view] fp32 tile, row stride TS: lane (j, h) = view j writes its 16 channels as 16 ds_write_b32 (bank =
+// 4 chan + j: no conflicts), lane (n, h) reads views 16h .. 16h + 15 of channel n as 4 ds_read_b128
 constexpr int TS = 36;
 template <typename A16>
 __device__ __forceinline__ void tile_put(float* tile, int j, int h, const A16& x, bool ok) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<float4*>(tile + j * TS + 8 * q + 4 * h) =
-        ok ? make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < 16; ++r) tile[chan(r, h) * TS + j] = ok ? x[r] : 0.f;
 }
-// acc[r] += sum_v A[v][chan(r, h)] B[v][j]: lane (j, h) reads column j of both tiles, views (2s + h)
+// acc[r] += sum_v A[chan(r, h)][v] B[j][v]: k-step s pairs the views (s, 16 + s); four steps per pair of LDS reads
 __device__ __forceinline__ f32x16 wgradf(const float* ta, const float* tb, int j, int h, f32x16 acc) {
 #pragma unroll
-  for (int s = 0; s < 16; ++s) acc = F32_MFMA(ta[(2 * s + h) * TS + j], tb[(2 * s + h) * TS + j], acc);
+  for (int c = 0; c < 4; ++c) {
+    asm volatile("" ::: "memory");      // one chunk of operands in flight: 8 registers, not 32
+    const float4 a = *reinterpret_cast<const float4*>(ta + j * TS + 16 * h + 4 * c);
+    const float4 b = *reinterpret_cast<const float4*>(tb + j * TS + 16 * h + 4 * c);
+    acc = F32_MFMA(a.x, b.x, acc);
+    acc = F32_MFMA(a.y, b.y, acc);
+    acc = F32_MFMA(a.z, b.z, acc);
+    acc = F32_MFMA(a.w, b.w, acc);
+  }
   return acc;
 }
-// the same with a narrow second tile (row stride tsb, column jb: columns past the data are one shared zero column)
-__device__ __forceinline__ f32x16 wgradf_short(const float* ta, const float* tb, int tsb, int j, int jb, int h,
+// the same with a short second tile: its rows >= jb_max are one shared zero row (row jb_max)
+__device__ __forceinline__ f32x16 wgradf_short(const float* ta, const float* tb, int j, int jb_max, int h,
                                                 f32x16 acc) {
+  const int jb = j < jb_max ? j : jb_max;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) acc = F32_MFMA(ta[(2 * s + h) * TS + j], tb[(2 * s + h) * tsb + jb], acc);
+  for (int c = 0; c < 4; ++c) {
+    asm volatile("" ::: "memory");
+    const float4 a = *reinterpret_cast<const float4*>(ta + j * TS + 16 * h + 4 * c);
+    const float4 b = *reinterpret_cast<const float4*>(tb + jb * TS + 16 * h + 4 * c);
+    acc = F32_MFMA(a.x, b.x, acc);
+    acc = F32_MFMA(a.y, b.y, acc);
+    acc = F32_MFMA(a.z, b.z, acc);
+    acc = F32_MFMA(a.w, b.w, acc);
+  }
   return acc;
 }
 __device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int vpj, int h) {
@@ -158,31 +207,6 @@ __device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int 
   return u;
 }
 
-// The forward chain up to layer LAST (1, 2, 5, 6): raw outputs and activations of every layer.
-struct Fwd {
-  f32x16 z1, z2, z5, z6;
-  float a1[16], a2[16], a5[16], a6[16];
-};
-// local table positions of the forward operands: W1 at 0, W2 at 1, W5 at 5, W6 at 9 (as in the global table)
-template <int LAST>
-__device__ __forceinline__ void forward(const float4* s_w, int lane, const float (*tabs)[TAB_FLOATS], int h,
-                                        const float4& x, const f32x16& uacc, Fwd& k) {
-  const f32x16 zero = {0};
-  k.z1 = mm_x(s_w, Q_W1, lane, x);
-  act(k.z1, tabs[0], h, k.a1);
-  if (LAST >= 2) {
-    k.z2 = mmf(s_w, Q_W2, lane, k.a1, zero);
-    act(k.z2, tabs[1], h, k.a2);
-  }
-  if (LAST >= 5) {
-    k.z5 = mmf(s_w, Q_W5, lane, k.a2, uacc);
-    act(k.z5, tabs[2], h, k.a5);
-  }
-  if (LAST >= 6) {
-    k.z6 = mmf(s_w, Q_W6, lane, k.a5, zero);
-    act(k.z6, tabs[3], h, k.a6);
-  }
-}
 template <typename Z16>
 __device__ __forceinline__ void add_stats(const Z16& z, bool ok, float (&st)[2][16]) {
 #pragma unroll
@@ -193,29 +217,29 @@ __device__ __forceinline__ void add_stats(const Z16& z, bool ok, float (&st)[2][
   }
 }
 
-struct Pre {
+// a [V][32] fp32 row tensor reaches 4 GiB at V = 2^25: one buffer descriptor per tile (rows of the tile only)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, const TileInfo& ti) {
+  return make_rsrc(base ? base + (int64_t)ti.v0 * D : nullptr, base ? (uint64_t)ti.nv * 128 : 0);
+}
+__device__ __forceinline__ f32x16 load_tile_rows(const float* base, const TileInfo& ti, int j, int h) {
+  f32x16 r;
+  load_rows16(tile_rsrc(base, ti), j < ti.nv, (uint32_t)j, h, r);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer 2: statistics + per-point extremum of sign(gamma2) z2 (chain_fwd.hip stats2_kernel in fp32); z2 stays in HBM
+// ------------------------------------------------------------------------------------------------
+struct PreX {
   TileInfo ti;
   float4 x;
   int vpj;
 };
-#define DVA_C3_LOAD                                                                                 \
-  [&](const TileInfo& ti, int t) {                                                                 \
-    Pre p;                                                                                          \
-    p.ti = ti;                                                                                      \
-    const bool ok = j < p.ti.nv;                                                                    \
-    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));                      \
-    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);                                  \
-    return p;                                                                                       \
-  }
-
-// ------------------------------------------------------------------------------------------------
-// layer 2: statistics + per-point extremum of sign(gamma2) z2 (chain_fwd.hip stats2_kernel in fp32)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void stats2_kernel(
+__global__ __launch_bounds__(256, 4) void stats2_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
     const int32_t* __restrict__ n_tiles_dev, const float4* __restrict__ ops, const float* __restrict__ bn1,
     const float* __restrict__ gamma2, double* __restrict__ stats, float* __restrict__ zstar,
-    int32_t* __restrict__ arg, int64_t V) {
+    int32_t* __restrict__ arg, float* __restrict__ z2_out, int64_t V) {
   __shared__ __attribute__((aligned(16))) float s_tab[1][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float4 s_w[Q_W5 * 64];
   __shared__ __attribute__((aligned(16))) float s_tile[4][32 * TS];
@@ -235,14 +259,22 @@ __global__ __launch_bounds__(256, 2) void stats2_kernel(
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
-  run_tiles<Pre>(tiles, ta, tb, DVA_C3_LOAD, [&](const Pre& p) {
+  run_tiles<PreX>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    PreX p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const PreX& p) {
     const int nv = p.ti.nv;
     const bool ok = j < nv;
     const f32x16 zero = {0};
-    Fwd k;
-    forward<1>(s_w, lane, s_tab, h, p.x, zero, k);
-    const f32x16 z2 = mmf(s_w, Q_W2, lane, k.a1, zero);
+    float a1[16];
+    act(mm_x(s_w, Q_W1, lane, p.x), s_tab[0], h, a1);
+    const f32x16 z2 = mmf(s_w, Q_W2, lane, a1, zero);
     add_stats(z2, ok, st);
+    store_rows16(tile_rsrc(z2_out, p.ti), ok, (uint32_t)j, h, z2);
     tile_put(tz, j, h, z2, true);
     const int nxt = shfl(p.vpj, lane + 1);
     const bool is_end = ok && (j == nv - 1 || nxt != p.vpj);
@@ -251,7 +283,13 @@ __global__ __launch_bounds__(256, 2) void stats2_kernel(
     wave_sync();
     float xv[32];
 #pragma unroll
-    for (int v = 0; v < 32; ++v) xv[v] = __uint_as_float(__float_as_uint(tz[v * TS + j]) ^ flip);
+    for (int q = 0; q < 8; ++q) {
+      const float4 t4 = *reinterpret_cast<const float4*>(tz + j * TS + 4 * q);      // channel j, views 4q .. 4q + 3
+      xv[4 * q] = __uint_as_float(__float_as_uint(t4.x) ^ flip);
+      xv[4 * q + 1] = __uint_as_float(__float_as_uint(t4.y) ^ flip);
+      xv[4 * q + 2] = __uint_as_float(__float_as_uint(t4.z) ^ flip);
+      xv[4 * q + 3] = __uint_as_float(__float_as_uint(t4.w) ^ flip);
+    }
 #pragma unroll
     for (int v = 0; v < 32; ++v) {
       if (v < nv) {                      // uniform
@@ -274,87 +312,99 @@ __global__ __launch_bounds__(256, 2) void stats2_kernel(
   flush_stats<2>(st, stats, s_red);
 }
 
-// statistics of layer 5 (z5 = W5a a2 + u[point]) or layer 6
+// rows of one stored layer output (z2 or z5) per view, prefetched one tile ahead
+struct PreR {
+  TileInfo ti;
+  f32x16 row;
+  float4 dc;
+  int vpj;
+};
+
+// L = 5: z2 -> a2 -> z5 = W5a a2 + u[point]: statistics of layer 5, z5 stays in HBM
+// L = 6: z5 -> a5 -> z6 = W6 a5: statistics of layer 6
 template <int L>
-__global__ __launch_bounds__(256, 2) void stats_mid_kernel(
-    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+__global__ __launch_bounds__(256, L == 5 ? 3 : 4) void stats_mid_kernel(
+    const float* __restrict__ rows_in, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const float4* __restrict__ ops,
-    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    double* __restrict__ stats, int64_t V, int64_t N) {
-  __shared__ __attribute__((aligned(16))) float s_tab[3][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) float4 s_w[Q_W6T * 64];
+    const float* __restrict__ bn, float* __restrict__ rows_out, double* __restrict__ stats, int64_t V, int64_t N) {
+  __shared__ __attribute__((aligned(16))) float s_tab[1][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float4 s_w[4 * 64];
   __shared__ float s_red[STATS_RED_FLOATS];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  stage_q(s_w, 0, ops, 0, L == 6 ? Q_W6T : Q_W6);
-  stage_tab(s_tab[0], bn1, nullptr, false);
-  stage_tab(s_tab[1], bn2, nullptr, false);
-  if (L == 6) stage_tab(s_tab[2], bn5, nullptr, false);
+  stage_q(s_w, 0, ops, L == 5 ? Q_W5 : Q_W6, 4);
+  stage_tab(s_tab[0], bn, nullptr, false);
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128);
+  const __amdgpu_buffer_rsrc_t P = make_rsrc(vp, (uint64_t)V * 4), U = make_rsrc(u, (uint64_t)N * 128);
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
-  run_tiles<Pre>(tiles, ta, tb, DVA_C3_LOAD, [&](const Pre& p) {
+  run_tiles<PreR>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    PreR p;
+    p.ti = ti;
+    p.row = load_tile_rows(rows_in, ti, j, h);
+    if (L == 5) p.vpj = (int)ld32(P, j < ti.nv ? (uint32_t)(ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const PreR& p) {
     const bool ok = j < p.ti.nv;
-    const f32x16 uacc = load_u(U, ok, p.vpj, h);
-    Fwd k;
-    forward<2>(s_w, lane, s_tab, h, p.x, uacc, k);
-    f32x16 z = mmf(s_w, Q_W5, lane, k.a2, uacc);
-    if (L == 6) {
-      float a5[16];
-      act(z, s_tab[2], h, a5);
-      const f32x16 zero = {0};
-      z = mmf(s_w, Q_W6, lane, a5, zero);
-    }
+    // (the per-point row is a dependent load: it is added after the product, which therefore does not wait for it;
+    //  stage 5 of the backward evaluates z5 in the same order)
+    f32x16 uacc = {0};
+    if (L == 5) uacc = load_u(U, ok, p.vpj, h);
+    float a[16];
+    act(p.row, s_tab[0], h, a);
+    const f32x16 zero = {0};
+    f32x16 z = mmf(s_w, 0, lane, a, zero);
+    if (L == 5) z += uacc;
     add_stats(z, ok, st);
+    if (L == 5) store_rows16(tile_rsrc(rows_out, p.ti), ok, (uint32_t)j, h, z);
   });
   flush_stats<2>(st, stats, s_red);
 }
 
-// x_map -> scores [V][4] (columns >= G zero): the whole chain, then the score layer on the vector units
-__global__ __launch_bounds__(256, 2) void scores_kernel(
-    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
-    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const float4* __restrict__ ops,
-    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    const float* __restrict__ bn6, const float* __restrict__ bs, int G, float* __restrict__ scores, int64_t V,
-    int64_t N) {
-  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) float4 s_w[(Q_W6T + 1) * 64];
+// z5 -> scores [V][4] (columns >= G zero): layers 5 (activation), 6, then the score layer on the vector units
+__global__ __launch_bounds__(256, 4) void scores_kernel(
+    const float* __restrict__ z5, const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev,
+    const float4* __restrict__ ops, const float* __restrict__ bn5, const float* __restrict__ bn6,
+    const float* __restrict__ bs, int G, float* __restrict__ scores, int64_t V) {
+  __shared__ __attribute__((aligned(16))) float s_tab[2][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float4 s_w[5 * 64];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  stage_q(s_w, 0, ops, 0, Q_W6T);
-  stage_q(s_w, Q_W6T, ops, Q_WSV, 1);
-  stage_tab(s_tab[0], bn1, nullptr, false);
-  stage_tab(s_tab[1], bn2, nullptr, false);
-  stage_tab(s_tab[2], bn5, nullptr, false);
-  stage_tab(s_tab[3], bn6, nullptr, false);
+  stage_q(s_w, 0, ops, Q_W6, 4);
+  stage_q(s_w, 4, ops, Q_WSV, 1);
+  stage_tab(s_tab[0], bn5, nullptr, false);
+  stage_tab(s_tab[1], bn6, nullptr, false);
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), SC = make_rsrc(scores, (uint64_t)V * 16);
+  const __amdgpu_buffer_rsrc_t SC = make_rsrc(scores, (uint64_t)V * 16);
   float bias[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bias[g] = g < G ? bs[g] : 0.f;
-  const float4* wsv = s_w + Q_W6T * 64;
+  const float4* wsv = s_w + 4 * 64;
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
-  run_tiles<Pre>(tiles, ta, tb, DVA_C3_LOAD, [&](const Pre& p) {
+  run_tiles<PreR>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    PreR p;
+    p.ti = ti;
+    p.row = load_tile_rows(z5, ti, j, h);
+    return p;
+  }, [&](const PreR& p) {
     const bool ok = j < p.ti.nv;
-    const f32x16 uacc = load_u(U, ok, p.vpj, h);
-    Fwd k;
-    forward<6>(s_w, lane, s_tab, h, p.x, uacc, k);
+    const f32x16 zero = {0};
+    float a5[16], a6[16];
+    act(p.row, s_tab[0], h, a5);
+    act(mmf(s_w, 0, lane, a5, zero), s_tab[1], h, a6);
     asm volatile("" ::: "memory");
     float sc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float4 w = wsv[2 * r + h];
-      sc[0] = __builtin_fmaf(k.a6[r], w.x, sc[0]);
-      sc[1] = __builtin_fmaf(k.a6[r], w.y, sc[1]);
-      sc[2] = __builtin_fmaf(k.a6[r], w.z, sc[2]);
-      sc[3] = __builtin_fmaf(k.a6[r], w.w, sc[3]);
+      sc[0] = __builtin_fmaf(a6[r], w.x, sc[0]);
+      sc[1] = __builtin_fmaf(a6[r], w.y, sc[1]);
+      sc[2] = __builtin_fmaf(a6[r], w.z, sc[2]);
+      sc[3] = __builtin_fmaf(a6[r], w.w, sc[3]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) sc[g] += __shfl_xor(sc[g], 32);
@@ -363,30 +413,25 @@ __global__ __launch_bounds__(256, 2) void scores_kernel(
   });
 }
 
-// score layer backward + statistics of the BatchNorm-6 backward
-constexpr int TDC = 8;      // row stride of the score-gradient tile [view][4 (+ a zero column)]
-__global__ __launch_bounds__(256, 2) void score_stats_kernel(
-    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
-    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const float4* __restrict__ ops,
-    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    const float* __restrict__ bn6, const float* __restrict__ dc, double* __restrict__ stats6,
-    float* __restrict__ dWs, float* __restrict__ dbs, int G, int64_t V, int64_t N) {
-  constexpr int L_WST = Q_W6T;
-  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) float4 s_w[(L_WST + 1) * 64];
-  __shared__ __attribute__((aligned(16))) float s_ta[4][32 * TS], s_td[4][32 * TDC];
+// score layer backward + statistics of the BatchNorm-6 backward (from z5)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void score_stats_kernel(
+    const float* __restrict__ z5, const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev,
+    const float4* __restrict__ ops, const float* __restrict__ bn5, const float* __restrict__ bn6,
+    const float* __restrict__ dc, double* __restrict__ stats6, float* __restrict__ dWs, float* __restrict__ dbs,
+    int G, int64_t V) {
+  constexpr int L_WST = 4;
+  __shared__ __attribute__((aligned(16))) float s_tab[2][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float4 s_w[5 * 64];
+  __shared__ __attribute__((aligned(16))) float s_ta[4][32 * TS], s_td[4][5 * TS];      // a6 | dc (4 rows + a zero row)
   float* s_red = &s_ta[0][0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < 4 * 32 * TDC; i += blockDim.x) (&s_td[0][0])[i] = 0.f;
-  stage_q(s_w, 0, ops, 0, Q_W6T);
-  stage_q(s_w, L_WST, ops, Q_WST, 1);
-  stage_tab(s_tab[0], bn1, nullptr, false);
-  stage_tab(s_tab[1], bn2, nullptr, false);
-  stage_tab(s_tab[2], bn5, nullptr, false);
-  stage_tab(s_tab[3], bn6, nullptr, false);
+  for (int i = threadIdx.x; i < 4 * 5 * TS; i += blockDim.x) (&s_td[0][0])[i] = 0.f;
+  stage_q(s_w, 0, ops, Q_W6, 4);
+  stage_q(s_w, L_WST, ops, Q_WSV, 1);
+  stage_tab(s_tab[0], bn5, nullptr, false);
+  stage_tab(s_tab[1], bn6, nullptr, false);
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16);
+  const __amdgpu_buffer_rsrc_t DC = make_rsrc(dc, (uint64_t)V * 16);
   float* ta_ = s_ta[wv];
   float* td = s_td[wv];
   f32x16 accS = {0};
@@ -397,23 +442,28 @@ __global__ __launch_bounds__(256, 2) void score_stats_kernel(
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
-  run_tiles<Pre>(tiles, ta, tb, DVA_C3_LOAD, [&](const Pre& p) {
+  run_tiles<PreR>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    PreR p;
+    p.ti = ti;
+    p.row = load_tile_rows(z5, ti, j, h);
+    p.dc = as_f4(ld128(DC, j < ti.nv ? (uint32_t)(ti.v0 + j) * 16u : OOB));      // zeros in the lanes without a view
+    return p;
+  }, [&](const PreR& p) {
     const bool ok = j < p.ti.nv;
-    const uint32_t view = (uint32_t)(p.ti.v0 + j);
-    const f32x16 uacc = load_u(U, ok, p.vpj, h);
-    const float4 dcv = as_f4(ld128(DC, ok ? view * 16u : OOB));      // zeros in the lanes without a view
-    Fwd k;
-    forward<6>(s_w, lane, s_tab, h, p.x, uacc, k);
-    tile_put(ta_, j, h, k.a6, ok);
+    const f32x16 zero = {0};
+    float a5[16], a6[16];
+    act(p.row, s_tab[0], h, a5);
+    const f32x16 z6 = mmf(s_w, 0, lane, a5, zero);
+    act(z6, s_tab[1], h, a6);
+    tile_put(ta_, j, h, a6, ok);
     if (h == 0) {
-      *reinterpret_cast<float4*>(td + j * TDC) = dcv;
-      dbsum[0] += dcv.x; dbsum[1] += dcv.y; dbsum[2] += dcv.z; dbsum[3] += dcv.w;
+      td[0 * TS + j] = p.dc.x; td[1 * TS + j] = p.dc.y; td[2 * TS + j] = p.dc.z; td[3 * TS + j] = p.dc.w;
+      dbsum[0] += p.dc.x; dbsum[1] += p.dc.y; dbsum[2] += p.dc.z; dbsum[3] += p.dc.w;
     }
-    const f32x16 da6 = mm_dc(s_w, L_WST, lane, dcv, h);
-    float dy[16];
-    layer_bwd<true, false>(k.z6, da6, s_tab[3], h, ok, st, dy);      // da6 = 0 in the lanes without a view
+    float unused[16];
+    score_layer_bwd<true, false>(z6, p.dc, s_w + L_WST * 64, s_tab[1], h, 0xffffffffu, st, unused);   // dc = 0 in the lanes without a view
     wave_sync();
-    accS = wgradf_short(ta_, td, TDC, j, j < 4 ? j : 4, h, accS);    // dWs^T[c][g] = sum_v a6[v][c] dc[v][g]
+    accS = wgradf_short(ta_, td, j, 4, h, accS);      // dWs^T[c][g] = sum_v a6[v][c] dc[v][g]
     wave_sync();
   });
   flush_matrix(accS, dWs, D, G, true, s_red);
@@ -428,47 +478,53 @@ __global__ __launch_bounds__(256, 2) void score_stats_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer passes (chain_bwd.hip layer_bwd_kernel in fp32; hand-offs fp32 [V][32])
+// layer passes (chain_bwd.hip layer_bwd_kernel in fp32; hand-offs fp32 [V][32]).  Every pass starts from the stored
+// output of its own layer's input side (stage 6: z5, stage 5: z2, stage 2: x_map + z2) instead of re-evaluating
+// the chain from x_map: these kernels are bound by the matrix pipe while HBM idles, so one 128-byte row per view read
+// back is cheaper than the 16 .. 36 instructions that recompute it.
+//   stage 6: z5, dc -> dz6 -> dW6, S5; hands dy5.   stage 5: z2, dy5 -> dz5 -> dW5, du, S2 (view part); hands dy2.
+//   stage 2: x_map, z2, dy2 + the routed set-pooling gradient -> dz2 -> dW2, P.
 // ------------------------------------------------------------------------------------------------
+struct PreB {
+  TileInfo ti;
+  f32x16 row, din;
+  float4 x;       // stage 2: x_map; stage 6: dc
+  int vpj;
+};
 template <int STAGE>
-__global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
-    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
-    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const float4* __restrict__ ops,
-    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    const float* __restrict__ bn6, const float* __restrict__ sm2, const float* __restrict__ sm5,
-    const float* __restrict__ sm6, const float* __restrict__ dc, const int32_t* __restrict__ arg,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void layer_bwd_kernel(
+    const float* __restrict__ x_map, const float* __restrict__ zrows, const int32_t* __restrict__ vp,
+    const float* __restrict__ u, const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev,
+    const float4* __restrict__ ops, const float* __restrict__ bn_lo, const float* __restrict__ bn_hi,
+    const float* __restrict__ sm, const float* __restrict__ dc, const int32_t* __restrict__ arg,
     const float* __restrict__ dpooled, const float* __restrict__ da_in, float* __restrict__ da_out,
     float* __restrict__ dW, float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int64_t V,
     int64_t N) {
-  // local operand table: the forward operands at their global positions, then the pass's transposed operand(s)
-  //   stage 6: W1 W2 W5 W6 | W6T at 13 | WST at 17;  stage 5: W1 W2 W5 | W5T at 9;  stage 2: W1 W2 | W2T at 5
-  constexpr int NQ = STAGE == 6 ? 18 : (STAGE == 5 ? 13 : 9);
-  constexpr int L_T = STAGE == 6 ? Q_W6T : (STAGE == 5 ? Q_W6 : Q_W5), L_WST = 17;
-  constexpr int TX = 20;        // stage 2: row stride of the [view][x (8) | 0 (8) | 1 | 0] tile (the P layout of dva_chain_dw1)
-  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  // bn_lo / bn_hi: the BatchNorm tables of the lower / upper layer of the pass (6: bn5, bn6; 5: bn2, bn5; 2: bn1, bn2);
+  // sm = S / M of the upper layer.  local operand table:
+  //   stage 6: W6 at 0, W6T at 4, WSV at 8;   stage 5: W5 at 0, W5T at 4;   stage 2: W1 at 0, W2T at 1
+  constexpr int NQ = STAGE == 6 ? 9 : (STAGE == 5 ? 8 : 5);
+  constexpr int TXR = 18;       // stage 2: rows of the [x (8) | 0 (8) | 1 | 0][view] tile (the P layout of dva_chain_dw1)
+  __shared__ __attribute__((aligned(16))) float s_tab[2][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float4 s_w[NQ * 64];
   __shared__ __attribute__((aligned(16))) float s_ta[4][32 * TS], s_tb[4][32 * TS];
-  // stage 5: the [view][local point] indicator; stage 2: the x_map tile
-  __shared__ __attribute__((aligned(16))) float s_tc[STAGE == 6 ? 1 : 4][STAGE == 6 ? 4 : (STAGE == 5 ? 32 * TS : 32 * TX)];
-  __shared__ int s_plp[STAGE == 5 ? 4 : 1][32];
+  __shared__ __attribute__((aligned(16))) float s_tc[STAGE == 2 ? 4 : 1][STAGE == 2 ? TXR * TS : 4];
   float* s_red = &s_ta[0][0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (STAGE == 6) {
-    stage_q(s_w, 0, ops, 0, 17);            // W1 .. W6T are contiguous in the global table
-    stage_q(s_w, L_WST, ops, Q_WST, 1);
+    stage_q(s_w, 0, ops, Q_W6, 8);            // W6, W6T are contiguous in the global table
+    stage_q(s_w, 8, ops, Q_WSV, 1);
   } else if (STAGE == 5) {
-    stage_q(s_w, 0, ops, 0, Q_W6);
-    stage_q(s_w, L_T, ops, Q_W5T, 4);
+    stage_q(s_w, 0, ops, Q_W5, 4);
+    stage_q(s_w, 4, ops, Q_W5T, 4);
   } else {
-    stage_q(s_w, 0, ops, 0, Q_W5);
-    stage_q(s_w, L_T, ops, Q_W2T, 4);
+    stage_q(s_w, 0, ops, Q_W1, 1);
+    stage_q(s_w, 1, ops, Q_W2T, 4);
   }
-  stage_tab(s_tab[0], bn1, nullptr, false);
-  stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr, false);
-  stage_tab(s_tab[2], bn5, STAGE == 5 ? sm5 : nullptr, false);
-  stage_tab(s_tab[3], bn6, STAGE == 6 ? sm6 : nullptr, false);
-  if (STAGE != 6) {
-    for (int i = threadIdx.x; i < 4 * (STAGE == 5 ? 32 * TS : 32 * TX); i += blockDim.x) (&s_tc[0][0])[i] = 0.f;
+  stage_tab(s_tab[0], bn_lo, nullptr, false);
+  stage_tab(s_tab[1], bn_hi, sm, false);
+  if (STAGE == 2) {
+    for (int i = threadIdx.x; i < 4 * TXR * TS; i += blockDim.x) (&s_tc[0][0])[i] = 0.f;
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
@@ -480,90 +536,84 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
   f32x16 accW = {0}, accS = {0};
   float* ta_ = s_ta[wv];
   float* tb_ = s_tb[wv];
-  float* tc = s_tc[STAGE == 6 ? 0 : wv];
-  int* plp = s_plp[STAGE == 5 ? wv : 0];
+  float* tc = s_tc[STAGE == 2 ? wv : 0];
   const int n_tiles = n_tiles_dev[0];
   int t0, t1;
   wave_tile_range(tiles, n_tiles, t0, t1);
-  run_tiles<Pre>(tiles, t0, t1, DVA_C3_LOAD, [&](const Pre& p) {
+  run_tiles<PreB>(tiles, t0, t1, [&](const TileInfo& ti, int t) {
+    PreB p;
+    p.ti = ti;
+    const bool ok = j < ti.nv;
+    const uint32_t view = (uint32_t)(ti.v0 + j);
+    p.row = load_tile_rows(zrows, ti, j, h);
+    if (STAGE != 6) p.din = load_tile_rows(da_in, ti, j, h);
+    if (STAGE == 6) p.x = as_f4(ld128(DC, ok ? view * 16u : OOB));
+    if (STAGE == 2) p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    if (STAGE != 6) p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
+    return p;
+  }, [&](const PreB& p) {
     const int nv = p.ti.nv;
     const bool ok = j < nv;
-    const uint32_t view = (uint32_t)(p.ti.v0 + j);
-    // the fp32 gradient rows [V][32] reach 4 GiB at V = 2^25: one descriptor per tile
-    const __amdgpu_buffer_rsrc_t DI = make_rsrc(da_in ? da_in + (int64_t)p.ti.v0 * D : nullptr,
-                                                da_in ? (uint64_t)nv * 128 : 0),
-                                 DO = make_rsrc(da_out ? da_out + (int64_t)p.ti.v0 * D : nullptr,
-                                                da_out ? (uint64_t)nv * 128 : 0);
     const f32x16 zero = {0};
     float dz[16];
     if constexpr (STAGE == 6) {
-      const f32x16 uacc = load_u(U, ok, p.vpj, h);
-      const float4 dcv = as_f4(ld128(DC, ok ? view * 16u : OOB));
-      Fwd k;
-      forward<5>(s_w, lane, s_tab, h, p.x, uacc, k);
-      tile_put(tb_, j, h, k.a5, ok);
+      // p.row = z5
+      float a5[16];
+      act(p.row, s_tab[0], h, a5);
+      tile_put(tb_, j, h, a5, ok);
       {
-        const f32x16 z6 = mmf(s_w, Q_W6, lane, k.a5, zero);
-        const f32x16 da6 = mm_dc(s_w, L_WST, lane, dcv, h);
+        const f32x16 z6 = mmf(s_w, 0, lane, a5, zero);
         float unused[2][16];
-        layer_bwd<false, true>(z6, da6, s_tab[3], h, ok, unused, dz);
+        score_layer_bwd<false, true>(z6, p.x, s_w + 8 * 64, s_tab[1], h, ok ? 0xffffffffu : 0u, unused, dz);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dz[r] = ok ? dz[r] : 0.f;
       tile_put(ta_, j, h, dz, true);
-      const f32x16 da5 = mmf(s_w, L_T, lane, dz, zero);
+      const f32x16 da5 = mmf(s_w, 4, lane, dz, zero);
       float dy5[16];
-      layer_bwd<true, false>(k.z5, da5, s_tab[2], h, ok, st, dy5);
-      store_rows16(DO, ok, (uint32_t)j, h, dy5);
+      layer_bwd<true, false>(p.row, da5, s_tab[0], h, ok, st, dy5);
+      store_rows16(tile_rsrc(da_out, p.ti), ok, (uint32_t)j, h, dy5);
       wave_sync();
       accW = wgradf(ta_, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
       wave_sync();
     } else if constexpr (STAGE == 5) {
+      // p.row = z2, p.din = dy5
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
-      f32x16 dy5;
-      load_rows16(DI, ok, (uint32_t)j, h, dy5);
-      Fwd k;
-      forward<2>(s_w, lane, s_tab, h, p.x, uacc, k);
+      float a2[16];
+      act(p.row, s_tab[0], h, a2);
+      tile_put(tb_, j, h, a2, ok);
       {
-        const f32x16 z5 = mmf(s_w, Q_W5, lane, k.a2, uacc);
-        bn_bwd_apply(z5, dy5, s_tab[2], h, dz);
+        f32x16 z5 = mmf(s_w, 0, lane, a2, zero);
+        z5 += uacc;
+        bn_bwd_apply(z5, p.din, s_tab[1], h, dz);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dz[r] = ok ? dz[r] : 0.f;
       tile_put(ta_, j, h, dz, true);
-      tile_put(tb_, j, h, k.a2, ok);
-      // du[p][c] = sum of dz5 over the views of point p = dz5^T . indicator[view][local point]
-      const int prv = shfl(p.vpj, lane - 1);
-      const bool is_start = ok && (j == 0 || prv != p.vpj);
-      const uint32_t smask = (uint32_t)__ballot(is_start);
-      const int lpj = __popc(smask & (0xffffffffu >> (31 - j))) - 1;
-      const int nseg = __popc(smask);
-      if (h == 0 && ok) {
-        tc[j * TS + lpj] = 1.f;
-        if (is_start) plp[lpj] = p.vpj;
-      }
-      const f32x16 da2 = mmf(s_w, L_T, lane, dz, zero);
+      const f32x16 da2 = mmf(s_w, 4, lane, dz, zero);
       float dy2[16];
-      layer_bwd<true, false>(k.z2, da2, s_tab[1], h, ok, st, dy2);
-      store_rows16(DO, ok, (uint32_t)j, h, dy2);
-      wave_sync();
-      accW = wgradf(ta_, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
-      const f32x16 accU = wgradf(ta_, tc, j, h, zero);
-      if (h == 0 && ok) tc[j * TS + lpj] = 0.f;
+      layer_bwd<true, false>(p.row, da2, s_tab[0], h, ok, st, dy2);
+      store_rows16(tile_rsrc(da_out, p.ti), ok, (uint32_t)j, h, dy2);
+      // du[p][c] = sum of dz5 over the views of point p: segmented scan over the lanes of each half-wave, the last view
+      // of a point stores its 16 channels (a point in several tiles: its fragments add up in the caller-zeroed row)
       {
-        const int frag = p.ti.frag;
-        const bool wr = j < nseg;
-        const uint32_t pt = wr ? (uint32_t)plp[j] : 0u;
-        if (frag == 0) {
+        const SegInfo sg = seg_setup(p.vpj, j, lane, nv);
+        const SegMaskF sm_ = seg_mask_f(sg);
+        float tot[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[r] = seg_scan_sum_f(dz[r], sm_);
+        const bool wr = ok && ((sg.emask >> j) & 1u);
+        if (p.ti.frag == 0) {
           const __amdgpu_buffer_rsrc_t DU = make_rsrc(du, (uint64_t)N * 128);
-          store_rows16(DU, wr, pt, h, accU);
+          store_rows16(DU, wr, (uint32_t)p.vpj, h, tot);
         } else if (wr) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) atomicAdd(&du[(size_t)pt * D + chan(r, h)], accU[r]);
+          for (int r = 0; r < 16; ++r) atomicAdd(&du[(size_t)p.vpj * D + chan(r, h)], tot[r]);
         }
       }
       wave_sync();
+      accW = wgradf(ta_, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
+      wave_sync();
     } else {
+      // p.row = z2, p.din = dy2 (view path), p.x = x_map
       u32x4 arq[4], dpq[4];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
@@ -571,8 +621,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
         arq[qq] = ld128(AR, off);
         dpq[qq] = ld128(DP, off);
       }
-      f32x16 dy;
-      load_rows16(DI, ok, (uint32_t)j, h, dy);
+      const f32x16 z1 = mm_x(s_w, 0, lane, p.x);
+      float a1[16];
+      act(z1, s_tab[0], h, a1);
+      tile_put(tb_, j, h, a1, ok);
+      f32x16 dy = p.din;
       {
         const int vg = p.ti.v0 + j;
 #pragma unroll
@@ -583,17 +636,11 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
           for (int e = 0; e < 4; ++e) dy[4 * qq + e] += (int)ai[e] == vg ? __uint_as_float(di[e]) : 0.f;
         }
       }
-      Fwd k;
-      forward<1>(s_w, lane, s_tab, h, p.x, zero, k);
-      {
-        const f32x16 z2 = mmf(s_w, Q_W2, lane, k.a1, zero);
-        bn_bwd_apply(z2, dy, s_tab[1], h, dz);
-      }
+      bn_bwd_apply(p.row, dy, s_tab[1], h, dz);
 #pragma unroll
       for (int r = 0; r < 16; ++r) dz[r] = ok ? dz[r] : 0.f;
       tile_put(ta_, j, h, dz, true);
-      tile_put(tb_, j, h, k.a1, ok);
-      const f32x16 da1 = mmf(s_w, L_T, lane, dz, zero);
+      const f32x16 da1 = mmf(s_w, 1, lane, dz, zero);
       float dy1[16];
       {
         asm volatile("" ::: "memory");
@@ -601,17 +648,20 @@ __global__ __launch_bounds__(256, 2) void layer_bwd_kernel(
         tab16(s_tab[0], T_G, h, g_);
         tab16(s_tab[0], T_B, h, b_);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dy1[r] = da1[r] * dleaky(__builtin_fmaf(k.z1[r], g_[r], b_[r]));
+        for (int r = 0; r < 16; ++r) dy1[r] = da1[r] * dleaky(__builtin_fmaf(z1[r], g_[r], b_[r]));
       }
       wave_sync();
       accW = wgradf(ta_, tb_, j, h, accW);       // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
       wave_sync();
       // P[n][f] = sum_v dy1[v][n] [x | 0 | 1][v][f]: the first-layer weight gradient and the statistics of layer 1
       tile_put(ta_, j, h, dy1, true);            // (lanes without a view: da1 = 0)
-      *reinterpret_cast<float4*>(tc + j * TX + 4 * h) = p.x;      // lanes without a view: zeros
-      if (h == 0) tc[j * TX + 16] = ok ? 1.f : 0.f;
+      tc[(4 * h + 0) * TS + j] = p.x.x;      // lanes without a view: zeros
+      tc[(4 * h + 1) * TS + j] = p.x.y;
+      tc[(4 * h + 2) * TS + j] = p.x.z;
+      tc[(4 * h + 3) * TS + j] = p.x.w;
+      if (h == 0) tc[16 * TS + j] = ok ? 1.f : 0.f;
       wave_sync();
-      accS = wgradf_short(ta_, tc, TX, j, j < 17 ? j : 17, h, accS);
+      accS = wgradf_short(ta_, tc, j, 17, h, accS);
       wave_sync();
     }
   });
@@ -784,96 +834,88 @@ int dva_chain3_prep(const float* W1, const float* W2, const float* W5, int32_t l
 
 int dva_chain3_stats2(const float* x_map, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
                       const void* ops, const float* bn1, const float* gamma2, double* stats, float* zstar,
-                      int32_t* arg, int64_t n_views, void* stream) {
+                      int32_t* arg, float* z2, int64_t n_views, void* stream) {
   if (n_views < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !tiles || !n_tiles || !ops || !bn1 || !gamma2 || !stats || !zstar || !arg)
+  if (!x_map || !view_point || !tiles || !n_tiles || !ops || !bn1 || !gamma2 || !stats || !zstar || !arg || !z2)
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(chain3::stats2_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map, view_point,
-                     (const int2*)tiles, n_tiles, (const float4*)ops, bn1, gamma2, stats, zstar, arg, n_views);
+  hipLaunchKernelGGL(chain3::stats2_kernel, dim3(chain_grid(4)), dim3(256), 0, (hipStream_t)stream, x_map, view_point,
+                     (const int2*)tiles, n_tiles, (const float4*)ops, bn1, gamma2, stats, zstar, arg, z2, n_views);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
 
-int dva_chain3_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                     const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+int dva_chain3_stats(int32_t layer, const float* rows_in, const int32_t* view_point, const float* u,
+                     const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn, float* z5,
                      double* stats, int64_t n_views, int64_t n_points, void* stream) {
   if (n_views < 0 || (layer != 5 && layer != 6)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !stats || (layer == 6 && !bn5))
+  if (!rows_in || !tiles || !n_tiles || !ops || !bn || !stats || (layer == 5 && (!view_point || !u || !z5)))
     return DVA_ERR_INVALID;
-  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(2)), block(256);
+  if (n_views * 16 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(layer == 5 ? 3 : 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layer == 5)
-    hipLaunchKernelGGL((chain3::stats_mid_kernel<5>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
-                       n_tiles, (const float4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
+    hipLaunchKernelGGL((chain3::stats_mid_kernel<5>), grid, block, 0, s, rows_in, view_point, u, (const int2*)tiles,
+                       n_tiles, (const float4*)ops, bn, z5, stats, n_views, n_points);
   else
-    hipLaunchKernelGGL((chain3::stats_mid_kernel<6>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
-                       n_tiles, (const float4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
+    hipLaunchKernelGGL((chain3::stats_mid_kernel<6>), grid, block, 0, s, rows_in, view_point, u, (const int2*)tiles,
+                       n_tiles, (const float4*)ops, bn, (float*)nullptr, stats, n_views, n_points);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
 
-int dva_chain3_scores(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                      const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+int dva_chain3_scores(const float* z5, const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn5,
                       const float* bn6, const float* score_bias, int32_t G, float* scores, int64_t n_views,
-                      int64_t n_points, void* stream) {
+                      void* stream) {
   if (n_views < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
-      !scores)
-    return DVA_ERR_INVALID;
-  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(chain3::scores_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map, view_point,
-                     u, (const int2*)tiles, n_tiles, (const float4*)ops, bn1, bn2, bn5, bn6, score_bias, (int)G, scores,
-                     n_views, n_points);
+  if (!z5 || !tiles || !n_tiles || !ops || !bn5 || !bn6 || !score_bias || !scores) return DVA_ERR_INVALID;
+  if (n_views * 16 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(chain3::scores_kernel, dim3(chain_grid(4)), dim3(256), 0, (hipStream_t)stream, z5,
+                     (const int2*)tiles, n_tiles, (const float4*)ops, bn5, bn6, score_bias, (int)G, scores, n_views);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
 
-int dva_chain3_score_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+int dva_chain3_score_stats(const float* z5, const void* tiles, const int32_t* n_tiles, const void* ops,
                            const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
-                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
-  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+                           float* dbs, int32_t G, int64_t n_views, void* stream) {
+  if (n_views < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !grad_scores ||
-      !stats6 || !dWs || !dbs)
+  if (!z5 || !tiles || !n_tiles || !ops || !bn5 || !bn6 || !grad_scores || !stats6 || !dWs || !dbs)
     return DVA_ERR_INVALID;
-  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(chain3::score_stats_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map,
-                     view_point, u, (const int2*)tiles, n_tiles, (const float4*)ops, bn1, bn2, bn5, bn6, grad_scores,
-                     stats6, dWs, dbs, (int)G, n_views, n_points);
+  if (n_views * 16 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(chain3::score_stats_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, z5,
+                     (const int2*)tiles, n_tiles, (const float4*)ops, bn5, bn6, grad_scores, stats6, dWs, dbs, (int)G,
+                     n_views);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
 
-int dva_chain3_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
-                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
-                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
-                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
-                         const float* da_in, float* da_out, float* dW, float* du, float* P, double* stats,
-                         int64_t n_views, int64_t n_points, void* stream) {
+int dva_chain3_bwd_layer(int32_t stage, const float* x_map, const float* z_rows, const int32_t* view_point,
+                         const float* u, const void* tiles, const int32_t* n_tiles, const void* ops,
+                         const float* bn_lo, const float* bn_hi, const float* sm, const float* grad_scores,
+                         const int32_t* arg, const float* dpooled, const float* da_in, float* da_out, float* dW,
+                         float* du, float* P, double* stats, int64_t n_views, int64_t n_points, void* stream) {
   if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW ||
-      (stage != 2 && !stats))
+  if (!z_rows || !tiles || !n_tiles || !ops || !bn_lo || !bn_hi || !sm || !dW || (stage != 2 && !stats))
     return DVA_ERR_INVALID;
-  if (stage == 6 && (!sm6 || !grad_scores || !da_out)) return DVA_ERR_INVALID;
-  if (stage == 5 && (!sm5 || !du || !da_in || !da_out)) return DVA_ERR_INVALID;
-  if (stage == 2 && (!sm2 || !arg || !dpooled || !P || !da_in)) return DVA_ERR_INVALID;
+  if (stage == 6 && (!grad_scores || !da_out)) return DVA_ERR_INVALID;
+  if (stage == 5 && (!view_point || !u || !du || !da_in || !da_out)) return DVA_ERR_INVALID;
+  if (stage == 2 && (!x_map || !view_point || !arg || !dpooled || !P || !da_in)) return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
-#define DVA_L3(ST_, BPC_)                                                                                        \
-  hipLaunchKernelGGL((chain3::layer_bwd_kernel<ST_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u, \
-                     (const int2*)tiles, n_tiles, (const float4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,           \
-                     grad_scores, arg, dpooled, da_in, da_out, dW, du, P, stats, n_views, n_points)
-  if (stage == 6) DVA_L3(6, 2);
-  else if (stage == 5) DVA_L3(5, 2);
-  else DVA_L3(2, 2);
+#define DVA_L3(ST_)                                                                                               \
+  hipLaunchKernelGGL((chain3::layer_bwd_kernel<ST_>), dim3(chain_grid(2)), block, 0, s, x_map, z_rows, view_point, u, \
+                     (const int2*)tiles, n_tiles, (const float4*)ops, bn_lo, bn_hi, sm, grad_scores, arg, dpooled,    \
+                     da_in, da_out, dW, du, P, stats, n_views, n_points)
+  if (stage == 6) DVA_L3(6);
+  else if (stage == 5) DVA_L3(5);
+  else DVA_L3(2);
 #undef DVA_L3
   DVA_CHECK_LAUNCH();
   return DVA_OK;

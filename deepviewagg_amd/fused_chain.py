@@ -23,9 +23,6 @@ from .fused_deepset import D, _bn_of, _bn_consts
 FORCE = None
 VIEWS_PER_CHUNK = 512       # tile-table construction granularity (one lane walks one chunk)
 OPS_BYTES = 16 * 64 * 16 + 7 * 64 * 32       # bf16 operand blocks + the fp32 copy of the forward operands
-OPS3_BYTES = 27 * 1024                       # the fp32 chain: 27 blocks of 64 float4 (dva_chain3_prep)
-# scores of fp32 features outside autocast on the fp32-class chain (False: the stored-activation passes of fused_deepset)
-SCORES_CHAIN = True
 
 
 def enabled():
@@ -156,12 +153,11 @@ def _set_branch_backward(saved, dt, dWc, training, zstats, arena):
     return dpooled, [dWsa, g1, b1, dWsb, g2, b2]
 
 
-def chain_prologue(module, x_map, csr_idx, prec3=False):
+def chain_prologue(module, x_map, csr_idx):
     """Everything of a chain forward that does not depend on the values: tile table, view -> point index, weight
     operands, the statistics passes of the four BatchNorm layers of DeepSetFeat (train mode), the set branch.
     Returns a namespace with the tensors the fused view kernel and the backward need (shared by the nearest path
-    below and the bilinear path of fused_bilinear.py).  ``prec3``: the fp32-class chain (csrc/chain_f32.hip: three-term
-    bf16 split, no BatchNorm folding) that ``chain_scores`` runs outside autocast."""
+    below and the bilinear path of fused_bilinear.py)."""
     from types import SimpleNamespace
     lib = _lib.load()
     e_map, e_score, gate = module.E_map, module.E_score, module.G
@@ -188,46 +184,43 @@ def chain_prologue(module, x_map, csr_idx, prec3=False):
         tiles, n_tiles = build_tiles(csr_idx, V)
         vp = torch.empty(V, dtype=torch.int32, device=dev)
         check(lib.dva_csr_expand(ptr(csr_idx), N, ptr(vp), st), "dva_csr_expand")
-    wops = torch.empty(OPS3_BYTES if prec3 else OPS_BYTES, dtype=torch.uint8, device=dev)
-    prep = lib.dva_chain3_prep if prec3 else lib.dva_chain_prep
-    check(prep(ptr(W1), ptr(W2), ptr(W5), W5.shape[1], ptr(W6), ptr(Ws), G, ptr(wops), st), "dva_chain_prep")
-    stats2 = lib.dva_chain3_stats2 if prec3 else lib.dva_chain_stats2
-    stats_mid = lib.dva_chain3_stats if prec3 else lib.dva_chain_stats
-    fold = not prec3           # the bf16 passes evaluate layers 1, 2, 6 with BatchNorm folded into the operand
+    wops = torch.empty(OPS_BYTES, dtype=torch.uint8, device=dev)
+    check(lib.dva_chain_prep(ptr(W1), ptr(W2), ptr(W5), W5.shape[1], ptr(W6), ptr(Ws), G, ptr(wops), st),
+          "dva_chain_prep")
     # ---- layer 1: statistics from the moments of x_map
     s1 = zstats()
     mom = torch.zeros(44, dtype=torch.float64, device=dev)
     if training:
         with ops._timed("chain_moments", V * 32):
-            check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), 1 if prec3 else 0, ptr(mom), ptr(s1), st),
-                      "dva_chain_moments")
-    bn1 = _chain_bn(s1, V, bns[0], training, W1 if fold else None, 8, mom)           # mom[:8] = sum of x_map
+            check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), 0, ptr(mom), ptr(s1), st), "dva_chain_moments")
+    bn1 = _chain_bn(s1, V, bns[0], training, W1, 8, mom)           # mom[:8] = sum of x_map
     # ---- layer 2: statistics + set pooling
     s2 = zstats()
     zstar = torch.empty((N, D), dtype=torch.float32, device=dev)
     arg = torch.empty((N, D), dtype=torch.int32, device=dev)
     with ops._timed("chain_stats2", V * 36 + N * 256):
-        check(stats2(ptr(x_map), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1),
-                     ptr(bns[1].weight.detach()), ptr(s2), ptr(zstar), ptr(arg), V, st), "dva_chain_stats2")
-    bn2 = _chain_bn(s2, V, bns[1], training, W2 if fold else None, D, s2[2 * D:])    # stats2 also sums the layer's input a1
+        check(lib.dva_chain_stats2(ptr(x_map), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1),
+                                   ptr(bns[1].weight.detach()), ptr(s2), ptr(zstar), ptr(arg), V, st),
+              "dva_chain_stats2")
+    bn2 = _chain_bn(s2, V, bns[1], training, W2, D, s2[2 * D:])    # stats2 also sums the layer's input a1
     pooled = torch.empty((N, D), dtype=torch.float32, device=dev)
     check(lib.dva_chain_pooled(ptr(zstar), ptr(bn2), ptr(csr_idx), ptr(pooled), N, st), "dva_chain_pooled")
-    t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats, prec3)
+    t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats)
     # ---- layers 5, 6: statistics (train mode)
     s5, s6 = zstats(), zstats()
     if training:
         with ops._timed("chain_stats5", V * 36 + N * 128):
-            check(stats_mid(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                            ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
+            check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                      ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
     bn5 = _chain_bn(s5, V, bns[2], training)                       # layer 5 is not folded
     if training:
         with ops._timed("chain_stats6", V * 36 + N * 128):
-            check(stats_mid(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                            ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
-    bn6 = _chain_bn(s6, V, bns[3], training, W6 if fold else None, D, s6[2 * D:])
+            check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                      ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
+    bn6 = _chain_bn(s6, V, bns[3], training, W6, D, s6[2 * D:])
     return SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
                            bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, bs=bs, gw=gw, gb=gb, W1=W1, G=G, training=training,
-                           set_saved=set_saved, prec3=prec3)
+                           set_saved=set_saved)
 
 
 # order of the chain's tensors in ctx.saved_tensors (after the path's own): tests/test_gpu_chain.py reads bn1 ..., scores
@@ -294,68 +287,3 @@ def chain_pool(module, x_mod, x_map, csr_idx):
     csr_idx = ops._check_ptr(csr_idx)
     return _ChainPool.apply(x_mod.rows, x_mod.row_idx.contiguous(), x_mod.plan, x_map, csr_idx, module,
                             module.group_scaling, 1e-12, *chain_params(module))
-
-
-class _ChainScores(torch.autograd.Function):
-    """``linear(E_map(x_map, csr_idx))`` [V, G <= 4] on the fp32-class recompute chain (csrc/chain_f32.hip): no [V, 32]
-    activation is stored, the backward re-evaluates the chain from x_map.  params as chain_params (gate = None)."""
-
-    @staticmethod
-    def forward(ctx, x_map, csr_idx, shim, *params):
-        lib = _lib.load()
-        require_device(x_map, csr_idx)
-        x_map = x_map.contiguous()
-        dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
-        st = stream_of(x_map)
-        S = chain_prologue(shim, x_map, csr_idx, prec3=True)
-        scores = torch.empty((V, 4), dtype=torch.float32, device=dev)
-        # per view: x_map 32 + view -> point 4 in, scores 16 out; per point the set-branch row
-        with ops._timed("chain3_scores", V * (32 + 4 + 16) + N * 128):
-            check(lib.dva_chain3_scores(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
-                                        ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), S.G, ptr(scores), V,
-                                        N, st), "dva_chain3_scores")
-        ctx.save_for_backward(x_map, csr_idx, S.vp, S.tiles, S.n_tiles, S.wops, S.t_add, S.zstar, S.arg, S.mom,
-                              S.bn1, S.bn2, S.bn5, S.bn6, S.W1)
-        ctx.shim = shim
-        ctx.set_saved = S.set_saved
-        ctx.training = S.training
-        ctx.G = S.G
-        return scores if S.G == 4 else scores[:, :S.G].contiguous()
-
-    @staticmethod
-    def backward(ctx, dscores):
-        from types import SimpleNamespace
-        from .fused_chain_bwd import Arena, chain_epilogue
-        lib = _lib.load()
-        if ctx.set_saved is None:
-            raise RuntimeError("the recompute chain's backward ran twice on the same graph: its per-step workspaces "
-                               "are released after the first backward (retain_graph is not supported on this path)")
-        (x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, W1) = ctx.saved_tensors
-        G = ctx.G
-        dc = dscores.contiguous().float()
-        if G < 4:
-            dc = torch.nn.functional.pad(dc, (0, 4 - G))
-        S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
-                            bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G, training=ctx.training, prec3=True)
-        arena = Arena(x_map.device)
-        grads = chain_epilogue(lib, arena, S, ctx.shim, x_map, csr_idx, dc, None, ctx.set_saved)
-        ctx.set_saved = None
-        return (None, None, None) + tuple(grads)
-
-
-def scores_applicable(e_map, linear, x_map, csr_idx):
-    """Can ``linear(e_map(x_map, csr_idx))`` run on the fp32-class chain?  (fused_deepset.applicable + at most 4 scores
-    per view + 32-bit buffer addressing of x_map and the per-point rows.)"""
-    if not SCORES_CHAIN or not fused_deepset.applicable(e_map, linear, x_map) or linear.out_features > 4:
-        return False
-    V, N = x_map.shape[0], csr_idx.shape[0] - 1
-    return 0 < V and V * 32 < (1 << 32) - 16 and N * 128 < (1 << 32) - 16
-
-
-def chain_scores(e_map, linear, x_map, csr_idx):
-    """DeepSetFeat + score layer for fp32 features (reference pooling.py:658-669 then :282), the drop-in of
-    ``fused_deepset.deepset_linear`` for at most 4 scores per view."""
-    from types import SimpleNamespace
-    csr_idx = ops._check_ptr(csr_idx)
-    shim = SimpleNamespace(E_map=e_map, E_score=linear, G=None)
-    return _ChainScores.apply(x_map, csr_idx, shim, *chain_params(shim))

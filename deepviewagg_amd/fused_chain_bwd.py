@@ -45,8 +45,6 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
     e_map, gate = module.E_map, module.G
     dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
     G, training = S.G, S.training
-    prec3 = getattr(S, "prec3", False)       # the fp32-class chain (csrc/chain_f32.hip): fp32 hand-over rows
-    HB = 128 if prec3 else 64                # bytes of one gradient row handed between two passes
     vp, tiles, n_tiles, wops, t_add = S.vp, S.tiles, S.n_tiles, S.wops, S.t_add
     bn1, bn2, bn5, bn6 = S.bn1, S.bn2, S.bn5, S.bn6
     st = stream_of(x_map)
@@ -65,36 +63,32 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
     s6 = zstats()
     dWs, dbs = arena.take(G, D), arena.take(G)
     with ops._timed("chain_score_stats", V * (32 + 4 + 16) + N * 128):
-        score_stats = lib.dva_chain3_score_stats if prec3 else lib.dva_chain_score_stats
-        check(score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1), ptr(bn2),
-                          ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs), G, V, N, st),
-              "dva_chain_score_stats")
+        check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                        ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
+                                        G, V, N, st), "dva_chain_score_stats")
 
     def layer(stage, sm2, sm5, sm6, arg_, dpooled_, da_in, da_out, dW, du, P, stats, name, nbytes):
-        args = (stage, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn1), ptr(bn2),
-                ptr(bn5), ptr(bn6), ptr(sm2), ptr(sm5), ptr(sm6), ptr(dc), ptr(arg_), ptr(dpooled_), ptr(da_in),
-                ptr(da_out), ptr(dW), ptr(du), ptr(P), ptr(stats))
-        with ops._timed(("chain3" + name[5:]) if prec3 else name, nbytes):
-            if prec3:
-                check(lib.dva_chain3_bwd_layer(*args, V, N, st), "dva_chain3_bwd_layer")
-            else:
-                check(lib.dva_chain_bwd_layer(*args, G, V, N, st), "dva_chain_bwd_layer")
+        with ops._timed(name, nbytes):
+            check(lib.dva_chain_bwd_layer(stage, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                          ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm2), ptr(sm5), ptr(sm6),
+                                          ptr(dc), ptr(arg_), ptr(dpooled_), ptr(da_in), ptr(da_out), ptr(dW),
+                                          ptr(du), ptr(P), ptr(stats), G, V, N, st),
+                  "dva_chain_bwd_layer")
 
     # per view: x_map 32 + view->point 4 (+ score gradients 16) + the 64-byte gradient row handed between the passes
     sm6, g6, b6 = consts(s6, bn6)
     dW6 = arena.take(D, D)
     s5 = zstats()
-    row_dtype = torch.float32 if prec3 else torch.bfloat16
-    da5 = torch.empty((V, D), dtype=row_dtype, device=dev)
+    da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
     layer(6, None, None, sm6, None, None, None, da5, dW6, None, None, s5, "chain_bwd_l6",
-          V * (32 + 4 + 16 + HB) + N * 128)
+          V * (32 + 4 + 16 + 64) + N * 128)
     sm5, g5, b5 = consts(s5, bn5)
     dW5 = arena.take(D, 2 * D)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
     s2 = zstats()
-    da2 = torch.empty((V, D), dtype=row_dtype, device=dev)
+    da2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
     layer(5, None, sm5, None, None, None, da5, da2, dW5, du, None, s2, "chain_bwd_l5",
-          V * (32 + 4 + 2 * HB) + N * 256)
+          V * (32 + 4 + 64 + 64) + N * 256)
     del da5
     # ---- per-point set branch
     dpooled, d_set = _set_branch_backward(set_saved, du, dW5, training, zstats, arena)
@@ -106,16 +100,14 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
     dW2, P = arena.take(D, D), arena.take(D, 20)       # P = sum dy1 [x_hi | x_lo | 1]^T
     s1 = zstats()
     layer(2, sm2, None, None, S.arg, dpooled_dy, da2, None, dW2, None, P, None, "chain_bwd_l2",
-          V * (32 + 4 + HB) + N * 256)
+          V * (32 + 4 + 64) + N * 256)
     del da2
-    exact_w1 = 1 if prec3 else 0          # z1 = W1 x (fp32-class chain) or bf16(W1) x
-    check(lib.dva_chain_stats1(ptr(P), ptr(S.W1), exact_w1, ptr(s1), st), "dva_chain_stats1")    # layer 1 is linear in x_map
+    check(lib.dva_chain_stats1(ptr(P), ptr(S.W1), 0, ptr(s1), st), "dva_chain_stats1")    # layer 1 is linear in x_map
     sm1, g1, b1 = consts(s1, bn1)
     # ---- first layer: BatchNorm-1 backward is linear in its statistics and z1 = W1 x is linear in x, so
     #      dW1 = G1 (P - (S1/M) SX^T - (S2/M) . Q) with Q = sum_v z1_hat x^T from the moments of x_map
     dW1 = arena.take(D, 8)
-    check(lib.dva_chain_dw1(ptr(P), ptr(S.mom), ptr(S.W1), exact_w1, ptr(bn1), ptr(sm1), ptr(dW1), st),
-          "dva_chain_dw1")
+    check(lib.dva_chain_dw1(ptr(P), ptr(S.mom), ptr(S.W1), 0, ptr(bn1), ptr(sm1), ptr(dW1), st), "dva_chain_dw1")
     if gate is not None:
         dgw, dgb = gwb[:G].reshape(gate.weight.shape), gwb[G:].reshape(gate.bias.shape)
     else:

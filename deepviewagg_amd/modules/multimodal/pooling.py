@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from ...core.common_modules import MLP
 from ... import ops
-from ... import fused_deepset, fused_chain, fused_bilinear
+from ... import fused_deepset, fused_chain, fused_chain_f32, fused_bilinear
 from ...ops import (segment_csr, gather_csr, segment_gather_csr,  # noqa: F401 (re-exported)
                     segment_softmax_csr)
 
@@ -332,9 +332,9 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
                         and fused_deepset.applicable(self.E_map, self.E_score, x_map))
         if fused_scores:
             # DeepSetFeat + E_score in the fused row-streaming kernels (fp32, hand-written backward)
-            if fused_chain.scores_applicable(self.E_map, self.E_score, x_map, csr_idx):
-                # fp32-class recompute chain (csrc/chain_f32.hip): no stored [V, 32] activation
-                compatibilities = fused_chain.chain_scores(self.E_map, self.E_score, x_map, csr_idx)
+            if fused_chain_f32.applicable(self.E_map, self.E_score, x_map, csr_idx):
+                # fp32 chain on the fp32 matrix cores (csrc/chain_f32.hip): two stored [V, 32] tensors instead of thirteen
+                compatibilities = fused_chain_f32.chain_scores(self.E_map, self.E_score, x_map, csr_idx)
             else:
                 compatibilities = fused_deepset.deepset_linear(self.E_map, self.E_score, x_map, csr_idx)
         else:

@@ -543,44 +543,50 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
                         const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream);
-/* ---- The recompute chain in fp32-class arithmetic: DeepSetFeat + E_score for fp32 features OUTSIDE torch.autocast
- * (the reference's default, models/base_model.py:244), replacing the stored-activation passes dva_deepset_*.
- * Same passes, tiles, statistics and hand-over rules as dva_chain_* above; every product is the three-term bf16 split
- * W x ~ W_hi x_hi + W_lo x_hi + W_hi x_lo (hi + lo = 16 mantissa bits, dropped term < 2^-16 relative), BatchNorm +
- * LeakyReLU in fp32 on the fp32 accumulators (no BatchNorm folding; leaky' follows the sign of the plain
- * pre-activation), gradient rows between the passes fp32 [V][32].  bn tables: fp32 [>= 4][32] mean | invstd | gamma | beta.
- * The attention (softmax, value gather, weighted sum, gate) stays in dva_view_gather_attention_*; these entries
- * produce the scores fp32 [V][4] (columns >= G zero) and consume their gradient fp32 [V][4].
- *   dva_chain3_prep         ops: 32 KiB device buffer (32 operand blocks: per matrix hi | lo)
- *   dva_chain3_stats2       as dva_chain_stats2; stats double[64] (no input sums)
- *   dva_chain3_stats        layer 5 / 6, stats double[64]
- *   dva_chain3_scores       x_map -> scores
- *   dva_chain3_score_stats  as dva_chain_score_stats
- *   dva_chain3_bwd_layer    as dva_chain_bwd_layer, da_in / da_out fp32 [V][32]
- * The per-point set branch (dva_chain_set_*), dva_chain_moments / dva_chain_stats1 / dva_chain_dw1 (exact_w1 = 1),
- * dva_chain_pooled and dva_chain_route_stats are shared with the bf16 chain. */
+/* ---- The chain in fp32: DeepSetFeat + E_score for fp32 features OUTSIDE torch.autocast (the reference's default,
+ * models/base_model.py:244), replacing the stored-activation passes dva_deepset_* (13 stored [V, 32] tensors).
+ * Same tiles, statistics and hand-over rules as dva_chain_* above; every product runs on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact fp32 fma chains), BatchNorm + LeakyReLU in fp32 on the accumulators (no BatchNorm
+ * folding; leaky' follows the sign of the plain pre-activation), gradient rows between the passes fp32 [V][32].
+ * These passes are bound by the matrix pipe, not by HBM: the raw outputs of layers 2 and 5 (z2, z5: fp32 [V][32])
+ * stay in HBM and every pass starts from them instead of re-evaluating the chain from x_map.
+ * bn tables: fp32 [>= 4][32] mean | invstd | gamma | beta.  The attention (softmax, value gather, weighted sum, gate)
+ * stays in dva_view_gather_attention_*; these entries produce the scores fp32 [V][4] (columns >= G zero) and consume
+ * their gradient fp32 [V][4].
+ *   dva_chain3_prep         ops: 27 KiB device buffer (27 operand blocks of 64 float4)
+ *   dva_chain3_stats2       x_map -> z2 (stored); stats double[64] += sum z2 | sum z2^2; zstar / arg as dva_chain_stats2
+ *   dva_chain3_stats        layer 5: rows_in = z2 (bn = bn2) -> z5 = W5a act(BN2(z2)) + u[point] (stored), stats of z5;
+ *                           layer 6: rows_in = z5 (bn = bn5) -> stats of z6 (view_point, u, z5 unused, may be NULL)
+ *   dva_chain3_scores       z5 -> scores
+ *   dva_chain3_score_stats  z5, grad_scores -> dWs [G][32], dbs [G], stats6 (S of the BatchNorm-6 backward)
+ *   dva_chain3_bwd_layer    bn_lo / bn_hi = tables of the lower / upper layer of the pass, sm = S / M of the upper one
+ *     stage 6: z_rows = z5, grad_scores -> dW (= dW6 [32][32]), stats (S of layer 5), da_out = dy5      (bn5, bn6)
+ *     stage 5: z_rows = z2, da_in = dy5, view_point, u -> dW (= dW5 [32][64], view half), du [N][32] (caller-zeroed),
+ *              stats (S of layer 2, view part), da_out = dy2                                              (bn2, bn5)
+ *     stage 2: x_map, z_rows = z2, da_in = dy2, view_point, arg, dpooled (dva_chain_route_stats) -> dW (= dW2),
+ *              P fp32 [32][20] = sum dy1 [x (8) | 0 (8) | 1 | 0]^T (dva_chain_stats1 / dva_chain_dw1, exact_w1 = 1)
+ *                                                                                                          (bn1, bn2)
+ * dva_chain_moments / dva_chain_stats1 / dva_chain_dw1 (exact_w1 = 1), dva_chain_pooled and dva_chain_route_stats
+ * are shared with the bf16 chain. */
 int dva_chain3_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6, const float* Ws,
                     int32_t G, void* ops, void* stream);
 int dva_chain3_stats2(const float* x_map, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
                       const void* ops, const float* bn1, const float* gamma2, double* stats, float* zstar,
-                      int32_t* arg, int64_t n_views, void* stream);
-int dva_chain3_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                     const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                      int32_t* arg, float* z2, int64_t n_views, void* stream);
+int dva_chain3_stats(int32_t layer, const float* rows_in, const int32_t* view_point, const float* u,
+                     const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn, float* z5,
                      double* stats, int64_t n_views, int64_t n_points, void* stream);
-int dva_chain3_scores(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                      const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+int dva_chain3_scores(const float* z5, const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn5,
                       const float* bn6, const float* score_bias, int32_t G, float* scores, int64_t n_views,
-                      int64_t n_points, void* stream);
-int dva_chain3_score_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                      void* stream);
+int dva_chain3_score_stats(const float* z5, const void* tiles, const int32_t* n_tiles, const void* ops,
                            const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
-                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream);
-int dva_chain3_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_point, const float* u,
-                         const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
-                         const float* bn2, const float* bn5, const float* bn6, const float* sm2, const float* sm5,
-                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
-                         const float* da_in, float* da_out, float* dW, float* du, float* P, double* stats,
-                         int64_t n_views, int64_t n_points, void* stream);
+                           float* dbs, int32_t G, int64_t n_views, void* stream);
+int dva_chain3_bwd_layer(int32_t stage, const float* x_map, const float* z_rows, const int32_t* view_point,
+                         const float* u, const void* tiles, const int32_t* n_tiles, const void* ops,
+                         const float* bn_lo, const float* bn_hi, const float* sm, const float* grad_scores,
+                         const int32_t* arg, const float* dpooled, const float* da_in, float* da_out, float* dW,
+                         float* du, float* P, double* stats, int64_t n_views, int64_t n_points, void* stream);
 /* The per-point set branch of the fp32 chain: dva_chain_set_* on the fp32 matrix cores (ops: 24 KiB). */
 int dva_chain3_set_prep(const float* Wsa, int32_t ld_sa, const float* Wsb, const float* Wc, int32_t ld_c, void* ops,
                         void* stream);

@@ -1,4 +1,4 @@
-"""-m gpu: the fp32 recompute chain (csrc/chain_f32.hip, fused_chain.chain_scores) -- DeepSetFeat + E_score for fp32
+"""-m gpu: the fp32 recompute chain (csrc/chain_f32.hip, fused_chain_f32.chain_scores) -- DeepSetFeat + E_score for fp32
 features outside autocast -- against the reference's golden vectors, an fp64 evaluation of the oracle module and the
 stored-activation fp32 kernels it replaces (fused_deepset.deepset_linear).
 
@@ -49,10 +49,10 @@ def _modules(gen, G, use_num, train, scale=0.4):
 def test_chain3_matches_reference_fixtures(name, monkeypatch):
     """The reference's golden GroupBimodalCSRPool cases through the fp32-class chain (the default fp32 path)."""
     from deepviewagg_amd.modules.multimodal import pooling as P
-    from deepviewagg_amd import fused_chain
+    from deepviewagg_amd import fused_chain_f32
     calls = []
-    real = fused_chain.chain_scores
-    monkeypatch.setattr(fused_chain, "chain_scores", lambda *a: (calls.append(1), real(*a))[1])
+    real = fused_chain_f32.chain_scores
+    monkeypatch.setattr(fused_chain_f32, "chain_scores", lambda *a: (calls.append(1), real(*a))[1])
     g = load_golden(name)
     kwargs = ast.literal_eval(str(g["kwargs"]))
     m = P.GroupBimodalCSRPool(**kwargs)
@@ -60,7 +60,7 @@ def test_chain3_matches_reference_fixtures(name, monkeypatch):
     m = m.to(DEV).train(bool(g["train"]))
     csr = t(g["csr"], DEV)
     x_mod, x_map = t(g["x_mod"], DEV).requires_grad_(), t(g["x_map"], DEV)
-    assert fused_chain.scores_applicable(m.E_map, m.E_score, x_map, csr)
+    assert fused_chain_f32.applicable(m.E_map, m.E_score, x_map, csr)
     out = m(None, x_mod, x_map, csr)
     assert calls, "the module did not take the fp32-class chain"
     close(out, t(g["out"]), rtol=1e-4, atol=1e-5)
@@ -83,7 +83,7 @@ def test_chain3_matches_reference_fixtures(name, monkeypatch):
 def test_chain3_scores_vs_fp64(G, use_num, train):
     """Scores and every parameter gradient against the oracle module evaluated in fp64; the stored-activation fp32
     kernels run beside it on the same inputs (their error is printed with -s: 1e-4 .. 2e-3 on the gradients)."""
-    from deepviewagg_amd import fused_chain, fused_deepset
+    from deepviewagg_amd import fused_chain_f32, fused_deepset
     gen = torch.Generator().manual_seed(11 + G)
     N = 6000
     csr = _ragged(gen, N, 9, long_points=20, empty_head=3)
@@ -99,9 +99,9 @@ def test_chain3_scores_vs_fp64(G, use_num, train):
         s = fn(em, el, x_map.to(DEV), csr.to(DEV))
         gr = torch.autograd.grad((s * w.to(DEV)).sum(), list(em.parameters()) + list(el.parameters()))
         return s, gr
-    assert fused_chain.scores_applicable(e_map, e_lin, x_map.to(DEV), csr.to(DEV))
+    assert fused_chain_f32.applicable(e_map, e_lin, x_map.to(DEV), csr.to(DEV))
     e_map2, e_lin2 = copy.deepcopy(e_map), copy.deepcopy(e_lin)
-    s3, g3 = run(fused_chain.chain_scores, e_map, e_lin)
+    s3, g3 = run(fused_chain_f32.chain_scores, e_map, e_lin)
     s1, g1 = run(fused_deepset.deepset_linear, e_map2, e_lin2)
     assert s3.shape == (V, G)
     close(s3, s64, rtol=1e-5, atol=1e-5)
@@ -125,7 +125,7 @@ def test_chain3_large_ragged_vs_fp64():
     the yardstick -- at this size every fp32 evaluation flips leaky' on a handful of the 1.7e8 pre-activations that lie
     within rounding of zero, each flip worth ~1e-3 of a gradient entry (the 6000-point cases above have none and hold
     2e-5); bit-identical scores on a second evaluation."""
-    from deepviewagg_amd import fused_chain
+    from deepviewagg_amd import fused_chain_f32
     gen = torch.Generator().manual_seed(21)
     N = 60000
     csr = _ragged(gen, N, 40, long_points=7, long_len=500, empty_head=50)
@@ -137,7 +137,7 @@ def test_chain3_large_ragged_vs_fp64():
     s64 = lin64(ref64(x_map.double(), csr))
     g64 = torch.autograd.grad((s64 * w.double()).sum(), list(ref64.parameters()) + list(lin64.parameters()))
     xd, cd = x_map.to(DEV), csr.to(DEV)
-    s3 = fused_chain.chain_scores(e_map, e_lin, xd, cd)
+    s3 = fused_chain_f32.chain_scores(e_map, e_lin, xd, cd)
     close(s3, s64, rtol=1e-5, atol=1e-5)
     g3 = torch.autograd.grad((s3 * w.to(DEV)).sum(), list(e_map.parameters()) + list(e_lin.parameters()))
     s32 = lin(ref(x_map, csr))
@@ -150,27 +150,27 @@ def test_chain3_large_ragged_vs_fp64():
     print("chain", max(errs.values()), "oracle fp32", max(errs32.values()))
     assert max(errs.values()) < 5e-5 + 3 * max(errs32.values()), (errs, errs32)
     # same inputs, second evaluation: bit-identical scores (deterministic statistics)
-    s3b = fused_chain.chain_scores(e_map, e_lin, xd, cd)
+    s3b = fused_chain_f32.chain_scores(e_map, e_lin, xd, cd)
     assert torch.equal(s3.detach(), s3b.detach())
 
 
 def test_chain3_edge_cases():
-    from deepviewagg_amd import fused_chain
+    from deepviewagg_amd import fused_chain_f32
     gen = torch.Generator().manual_seed(5)
     _, _, e_map, e_lin = _modules(gen, 4, True, False)
     # no views at all: left to the stored-activation kernels
     csr = torch.zeros(6, dtype=torch.long, device=DEV)
-    assert not fused_chain.scores_applicable(e_map, e_lin, torch.zeros(0, 8, device=DEV), csr)
+    assert not fused_chain_f32.applicable(e_map, e_lin, torch.zeros(0, 8, device=DEV), csr)
     # one point with one view; a second backward is refused
     e_map.train()
     csr = torch.tensor([0, 0, 3, 3, 4], dtype=torch.long, device=DEV)
     x = torch.rand(4, 8, generator=gen).to(DEV)
-    s = fused_chain.chain_scores(e_map, e_lin, x, csr)
+    s = fused_chain_f32.chain_scores(e_map, e_lin, x, csr)
     assert s.shape == (4, 4) and bool(torch.isfinite(s).all())
     s.sum().backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="ran twice"):
         s.sum().backward()
     # x_map that needs a gradient is not taken (the generic composition produces it)
-    assert not fused_chain.scores_applicable(e_map, e_lin, x.clone().requires_grad_(), csr)
+    assert not fused_chain_f32.applicable(e_map, e_lin, x.clone().requires_grad_(), csr)
     # more than 4 scores per view stay on the stored-activation kernels
-    assert not fused_chain.scores_applicable(e_map, torch.nn.Linear(32, 8).to(DEV), x, csr)
+    assert not fused_chain_f32.applicable(e_map, torch.nn.Linear(32, 8).to(DEV), x, csr)

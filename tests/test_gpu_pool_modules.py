@@ -21,10 +21,10 @@ POOL_CASES = ["pool_group_default_train", "pool_group_default_eval", "pool_group
 def stored_activation_passes():
     """Pin the fp32 scores to the stored-activation kernels of fused_deepset (the default for <= 4 scores per view is
     the fp32-class recompute chain, covered by tests/test_gpu_chain3.py)."""
-    from deepviewagg_amd import fused_chain
-    fused_chain.SCORES_CHAIN = False
+    from deepviewagg_amd import fused_chain_f32
+    fused_chain_f32.ENABLED = False
     yield
-    fused_chain.SCORES_CHAIN = True
+    fused_chain_f32.ENABLED = True
 
 
 def close(a, b, rtol=1e-4, atol=1e-5):

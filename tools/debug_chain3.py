@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from oracle import pooling_oracle as O
-from deepviewagg_amd import fused_chain, fused_deepset
+from deepviewagg_amd import fused_chain_f32, fused_deepset
 from deepviewagg_amd.modules.multimodal import pooling as P
 
 DEV = "cuda:0"
@@ -40,7 +40,7 @@ def run(fn, em, el):
     return s, gr
 
 
-s3, g3 = run(fused_chain.chain_scores, e_map, e_lin)
+s3, g3 = run(fused_chain_f32.chain_scores, e_map, e_lin)
 s1, g1 = run(fused_deepset.deepset_linear, e_map2, e_lin2)
 print("V", V, "scores: chain3 max err %.3e  stored %.3e  (max |s| %.3f)" % (
     float((s3.double().cpu() - s64).abs().max()), float((s1.double().cpu() - s64).abs().max()), float(s64.abs().max())))
