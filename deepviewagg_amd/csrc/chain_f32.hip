@@ -22,7 +22,7 @@
 // lane and step) come from an LDS table: per matrix 4 blocks of 64 float4 (steps 4q .. 4q + 3 of lane l at block q).
 // Weight gradients dW[n][k] = sum_v dz[v][n] a[v][k] pair the views (2s, 2s + 1) in step s; both operands come from
 // [view][channel] fp32 tiles in LDS (row stride 36 floats: float4 row writes and column reads without bank conflicts).
-//   dva_chain3_prep         operand table (27 KiB)
+//   dva_chain3_prep         operand table (26 KiB)
 //   dva_chain3_stats2       x_map -> z2 (stored), statistics of layer 2 + per-point extremum (set pooling)
 //   dva_chain3_stats        layer 5: z2 -> z5 (stored) + statistics; layer 6: z5 -> statistics of z6
 //   dva_chain3_scores       z5 -> scores fp32 [V, 4]  (score layer on the vector units: 4 rows of 32)
@@ -46,9 +46,8 @@ enum {
   Q_W6T = 13,   // transposed: step s = W[chan(s, h)][i]
   Q_W5T = 17,
   Q_W2T = 21,
-  Q_WST = 25,   // 1 block: steps 0, 1 = Ws[2s + h][i] (the score gradient of lane (j, h) in step s is dc[j][2s + h])
-  Q_WSV = 26,   // score layer for the vector units: entry 2r + h = Ws[0..3][chan(r, h)]
-  N_Q = 27
+  Q_WSV = 25,   // score layer (forward and backward) for the vector units: entry 2r + h = Ws[0..3][chan(r, h)]
+  N_Q = 26
 };
 
 __global__ __launch_bounds__(64) void prep3_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
@@ -60,9 +59,6 @@ __global__ __launch_bounds__(64) void prep3_kernel(const float* __restrict__ W1,
   if (q == Q_W1) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = W1[i * 8 + 4 * h + e];
-  } else if (q == Q_WST) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) w[e] = 2 * e + h < G ? Ws[(2 * e + h) * D + i] : 0.f;
   } else if (q == Q_WSV) {
     if (lane < 32) {
       const int r = lane >> 1, hh = lane & 1;
@@ -419,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float4* __restrict__ ops, const float* __restrict__ bn5, const float* __restrict__ bn6,
     const float* __restrict__ dc, double* __restrict__ stats6, float* __restrict__ dWs, float* __restrict__ dbs,
     int G, int64_t V) {
-  constexpr int L_WST = 4;
+  constexpr int L_WSV = 4;
   __shared__ __attribute__((aligned(16))) float s_tab[2][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float4 s_w[5 * 64];
   __shared__ __attribute__((aligned(16))) float s_ta[4][32 * TS], s_td[4][5 * TS];      // a6 | dc (4 rows + a zero row)
@@ -427,7 +423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < 4 * 5 * TS; i += blockDim.x) (&s_td[0][0])[i] = 0.f;
   stage_q(s_w, 0, ops, Q_W6, 4);
-  stage_q(s_w, L_WST, ops, Q_WSV, 1);
+  stage_q(s_w, L_WSV, ops, Q_WSV, 1);
   stage_tab(s_tab[0], bn5, nullptr, false);
   stage_tab(s_tab[1], bn6, nullptr, false);
   __syncthreads();
@@ -461,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       dbsum[0] += p.dc.x; dbsum[1] += p.dc.y; dbsum[2] += p.dc.z; dbsum[3] += p.dc.w;
     }
     float unused[16];
-    score_layer_bwd<true, false>(z6, p.dc, s_w + L_WST * 64, s_tab[1], h, 0xffffffffu, st, unused);   // dc = 0 in the lanes without a view
+    score_layer_bwd<true, false>(z6, p.dc, s_w + L_WSV * 64, s_tab[1], h, 0xffffffffu, st, unused);   // dc = 0 in the lanes without a view
     wave_sync();
     accS = wgradf_short(ta_, td, j, 4, h, accS);      // dWs^T[c][g] = sum_v a6[v][c] dc[v][g]
     wave_sync();
@@ -491,6 +487,9 @@ struct PreB {
   float4 x;       // stage 2: x_map; stage 6: dc
   int vpj;
 };
+// Two wavefronts per SIMD with the row tensors of the next tile prefetched (two register sets).  Measured alternative:
+// rows loaded at the start of the tile's own body, 168 registers, three wavefronts per SIMD -- the same time (stage 6:
+// 2.72 vs 2.69 ms), the passes are bound by the dependent VALU / LDS latency between the products, not by occupancy.
 template <int STAGE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void layer_bwd_kernel(
     const float* __restrict__ x_map, const float* __restrict__ zrows, const int32_t* __restrict__ vp,

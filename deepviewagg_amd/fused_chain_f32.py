@@ -22,7 +22,7 @@ from .fused_chain_bwd import Arena, bn_bwd_consts
 
 # False: the stored-activation passes of fused_deepset (tests, A/B)
 ENABLED = True
-OPS_BYTES = 27 * 1024          # 27 blocks of 64 float4 (dva_chain3_prep)
+OPS_BYTES = 26 * 1024          # 26 blocks of 64 float4 (dva_chain3_prep)
 ROW = 128                      # bytes of one fp32 [., 32] row
 
 

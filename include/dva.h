@@ -553,7 +553,7 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
  * bn tables: fp32 [>= 4][32] mean | invstd | gamma | beta.  The attention (softmax, value gather, weighted sum, gate)
  * stays in dva_view_gather_attention_*; these entries produce the scores fp32 [V][4] (columns >= G zero) and consume
  * their gradient fp32 [V][4].
- *   dva_chain3_prep         ops: 27 KiB device buffer (27 operand blocks of 64 float4)
+ *   dva_chain3_prep         ops: 26 KiB device buffer (26 operand blocks of 64 float4)
  *   dva_chain3_stats2       x_map -> z2 (stored); stats double[64] += sum z2 | sum z2^2; zstar / arg as dva_chain_stats2
  *   dva_chain3_stats        layer 5: rows_in = z2 (bn = bn2) -> z5 = W5a act(BN2(z2)) + u[point] (stored), stats of z5;
  *                           layer 6: rows_in = z5 (bn = bn5) -> stats of z6 (view_point, u, z5 unused, may be NULL)
