@@ -448,8 +448,11 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warm
             t = k["ms"] / k["launches"]
             out[key] = {"avg_launch_ms": t, "algorithmic_bytes": nbytes, "GBps": nbytes / (t * 1e-3) / 1e9,
                         "frac_of_hbm_peak": nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:4]
+    top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:4 if name != "f32" else 12]
     out["top_kernels_ms"] = {n: v["ms"] / v["launches"] for n, v in top}
+    if name == "f32":
+        out["dtype"] = "f32"
+        out["scores_path"] = "chain3" if any(k.startswith("chain3_") for k in kern) else "stored activations"
     del scene, mods
     torch.cuda.empty_cache()
     return out
@@ -711,6 +714,8 @@ def main():
                                                    interpolate=True),
                 "bilinear_kitti_128_32": secondary_workload("bilinear", device, dtype, args.log2_points, views, 128,
                                                             interpolate=True, C_out=32),
+                # the reference's default arithmetic (no autocast, fp32 features): S1 shapes on the fp32 chain
+                "f32": secondary_workload("f32", device, torch.float32, args.log2_points, views, 64),
             }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))

@@ -529,11 +529,6 @@ __device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restric
 }
 
 
-// experiment switches of the kernels' launch configuration (environment, read once)
-static inline int tune_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 static inline int chain_grid(int blocks_per_cu) {
   static int cus = 0;
   if (cus == 0) {

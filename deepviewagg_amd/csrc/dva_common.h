@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../include/dva.h"
 
 #define DVA_WAVE 64
@@ -14,6 +16,12 @@
   } while (0)
 
 namespace dva {
+
+// experiment switches of the kernels' launch configuration (environment, read once by the caller)
+static inline int tune_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 
