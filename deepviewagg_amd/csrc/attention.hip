@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
   // Software pipeline over the points of a team, three stages deep, so that the three dependent loads of
   // a point (CSR pointers -> row indices + scores -> value rows) of three consecutive points are in flight
   // together: one memory latency per point instead of three.
-  constexpr int U = 4;
+  // U views per row slot on the short-segment path; 8 where a row takes 16 lanes (fp32, C = 64: 4 row slots), so that the
+  // 32-view points of the headline shape stay on it (with U = 4 they took the chunked long-segment path: 2.24 ms)
+  constexpr int U = (LPR == 16 && ROWS == 4 && sizeof(T) == 4) ? 8 : 4;
   struct StageB {          // row indices and scores of a short segment (n <= U * rows): 8 registers
     int32_t ri[U];
     float cg[U];
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void att_fwd_team_kernel(
 // layout so that one atomic instruction covers whole contiguous rows (2 cache lines per 64 atomics
 // instead of 16 with the 16-byte-per-lane layout: measured 8.7x on the first version).
 template <typename T, int LPR, int ROWS>   // LPR > 0: compile-time team geometry (LPR lanes per row x ROWS rows)
-__global__ __launch_bounds__(256, 3) void att_bwd_team_kernel(
+__global__ __launch_bounds__(256, (LPR == 16 && ROWS == 4 && sizeof(T) == 4) ? 2 : 3) void att_bwd_team_kernel(
     const T* __restrict__ gout, const T* __restrict__ val, const int32_t* __restrict__ row_idx,
     float* __restrict__ grows, const float* __restrict__ compat,
     const float* __restrict__ att, const float* __restrict__ gate, const int32_t* __restrict__ amax,
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256, 3) void att_bwd_team_kernel(
   // Three-stage software pipeline over the points of a team (same scheme as the forward kernel): CSR
   // pointers of point i+2, row indices / attentions / grad_out row / gate of point i+1 and the value rows of
   // point i are in flight together.
-  constexpr int U = 4;
+  constexpr int U = (LPR == 16 && ROWS == 4 && sizeof(T) == 4) ? 8 : 4;      // see the forward kernel
   struct StageB {
     int32_t ri[U];
     float av[U];
