@@ -210,3 +210,50 @@ def test_chain_full_size_agrees_with_stored_activation_path_on_a_slice(chain_sce
         assert rel(g_sl[0], g_b[0]) < 5e-2, rel(g_sl[0], g_b[0])
     finally:
         m.train()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The fp32 chain (fused_chain_f32.chain_scores -> dva_chain3_*) at the size `bench.py --dtype f32` times it:
+# N = 2^20 points x 32 views, V = 33.5 M -- the fp32 row tensors z2 / z5 / dy5 / dy2 are exactly 4 GiB there (one buffer
+# descriptor per tile).
+# ---------------------------------------------------------------------------------------------------------------
+def test_chain3_full_size_properties():
+    import copy
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import fused_chain_f32, fused_deepset
+    g = torch.Generator(device=DEV).manual_seed(17)
+    V = N * VIEWS
+    csr = torch.arange(0, V + 1, VIEWS, device=DEV)
+    x_map = torch.rand(V, 8, generator=g, device=DEV)
+    torch.manual_seed(5)
+    m = P.GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=G, use_num=True).to(DEV).train()
+    assert fused_chain_f32.applicable(m.E_map, m.E_score, x_map, csr)
+
+    def run(mod):
+        s = fused_chain_f32.chain_scores(mod.E_map, mod.E_score, x_map, csr)
+        # a loss whose score gradients differ per view and per group
+        wgt = torch.linspace(-1.0, 1.0, 4 * 97, device=DEV).view(97, 4)[torch.arange(V, device=DEV) % 97]
+        grads = torch.autograd.grad((s * wgt).sum() / V, list(mod.E_map.parameters()) + list(mod.E_score.parameters()))
+        return s.detach(), grads
+    m2 = copy.deepcopy(m)
+    s1, g1 = run(m)
+    s2, g2 = run(m2)
+    assert s1.shape == (V, G) and bool(torch.isfinite(s1).all())
+    assert torch.equal(s1, s2)                                   # deterministic statistics: bit-identical forward
+    for a, b in zip(g1, g2):
+        assert bool(torch.isfinite(a).all())
+        # weight gradients go through fp32 atomics of per-wavefront partial sums: equal to rounding
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7 + 1e-5 * float(a.abs().max()))
+    # DeepSetFeat pools with a max: permuting the views inside every point permutes the scores the same way
+    m.eval()
+    perm_in = torch.argsort(torch.rand(N, VIEWS, generator=g, device=DEV), dim=1)
+    flat = (perm_in + torch.arange(N, device=DEV).view(-1, 1) * VIEWS).view(-1)
+    with torch.no_grad():
+        e1 = fused_chain_f32.chain_scores(m.E_map, m.E_score, x_map, csr)
+        e2 = fused_chain_f32.chain_scores(m.E_map, m.E_score, x_map[flat].contiguous(), csr)
+        assert torch.equal(e1[flat], e2)
+        # against the stored-activation fp32 kernels on a 2^16-point slice of the same scene (eval mode: running statistics)
+        n_s = 1 << 16
+        sl = slice(0, n_s * VIEWS)
+        ref = fused_deepset.deepset_linear(m.E_map, m.E_score, x_map[sl].contiguous(), csr[:n_s + 1].contiguous())
+    torch.testing.assert_close(e1[sl], ref, rtol=1e-4, atol=1e-5)
