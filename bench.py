@@ -280,6 +280,45 @@ def cpu_gather_attention_twin(log2_points, views, C, G=4):
                                     "view_gather_rows_grad + row_plan (kernels table) minus the encoder recompute")
 
 
+def cpu_full_path_twin(log2_points, views, C, G=4):
+    """C + OpenMP twin of the WHOLE pooling step on all host cores: the mapping-feature encoder (DeepSetFeat + E_score,
+    train-mode BatchNorm: oracle/deepset_oracle.c) feeding the view gather + attention tail (oracle/attention_oracle.c),
+    forward + backward incl. the rows scatter-add and every parameter gradient.  Bounded sample of S1."""
+    import numpy as np
+    from oracle import attention_oracle as A
+    from oracle import deepset_oracle as DS
+    from oracle import pooling_oracle as O
+    n = 1 << log2_points
+    rng = np.random.default_rng(0)
+    V, R = n * views, 32 * 64 * 128
+    csr = np.arange(0, V + 1, views, dtype=np.int64)
+    row_idx = rng.integers(0, R, V, dtype=np.int32)
+    rows = rng.standard_normal((R, C), dtype=np.float32)
+    x_map = rng.random((V, 8), dtype=np.float32)
+    gw, gb = np.ones(G, np.float32), np.zeros(G, np.float32)
+    gout = rng.standard_normal((n, C), dtype=np.float32)
+    torch.manual_seed(0)
+    e_map, lin = O.DeepSetFeat(8, 32, use_num=True), torch.nn.Linear(32, G)
+    P = DS.params_from_state_dict({k: v.detach().numpy() for k, v in e_map.state_dict().items()},
+                                  lin.weight.detach().numpy(), lin.bias.detach().numpy())
+
+    def one():
+        scores, cache = DS.forward(P, x_map, csr, True)
+        out, att, gate, amax = A.forward(rows, row_idx, scores, csr, gw, gb, True)
+        _, g_compat, _, _ = A.backward(gout, rows, row_idx, scores, csr, att, gate, amax, gw, gb, True)
+        DS.backward(P, cache, g_compat)
+    one()
+    reps, t0 = 2, time.perf_counter()
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=n / dt, unit="points/s", cores=DS.num_threads(), kind="port",
+                sample=f"oracle/deepset_oracle.c + oracle/attention_oracle.c (C + OpenMP, fp32): DeepSetFeat + E_score "
+                       f"(train-mode BatchNorm) -> view gather + attention, forward + backward, N=2^{log2_points} "
+                       f"points x {views} views, C={C}, G={G}, {reps} steps, {dt:.3f} s/step (E_mod on the map rows "
+                       f"and the fusion are not included: < 1 % of the work)")
+
+
 def mapping_build_bench(device, n_images=32, n_points=200_000):
     """Secondary measurement: mapping build at the S3DIS settings (2048x1024 projection map,
     voxel 2 cm, r_max 8 m, exact=True), B = 32 cameras of one setting against a 200 k-point room: images/s of the
@@ -722,6 +761,7 @@ def main():
             try:
                 res["cpu_baseline"]["gather_attention_openmp_twin"] = cpu_gather_attention_twin(
                     min(args.log2_points, 18), views, C)
+                res["cpu_baseline"]["full_path_openmp_twin"] = cpu_full_path_twin(min(args.log2_points, 17), views, C)
             except OSError as e:         # the oracle library is built by __graft_entry__.build()
                 res["cpu_baseline"]["gather_attention_openmp_twin"] = {"error": str(e)}
         os.write(json_fd, (json.dumps(res) + "\n").encode())

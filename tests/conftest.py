@@ -19,7 +19,8 @@ def pytest_sessionstart(session):
     """A fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the C oracle
     once (hipcc cross-compiles gfx950 without a GPU) so that neither suite depends on a previous build step."""
     need = [os.path.join(ROOT, "deepviewagg_amd", "csrc", "libdva_hip.so"),
-            os.path.join(ROOT, "oracle", "liboracle_mapping.so")]
+            os.path.join(ROOT, "oracle", "liboracle_mapping.so"),
+            os.path.join(ROOT, "oracle", "liboracle_deepset.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
         __graft_entry__.build()
