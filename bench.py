@@ -384,8 +384,9 @@ def mapping_build_bench(device, n_images=32, n_points=200_000):
     return {"roofline": {"bound": "hbm", "algorithmic_bytes_per_image": per_image,
                          "splat_box_pixels_per_image": area / len(cams), "achieved": per_image / batch_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_image / batch_s / 1e9 / HBM_PEAK_GBS,
-                         "note": "64-bit atomics on a cache-resident z-buffer plane per image, scans and compaction: "
-                                 "bound by atomic throughput and launch count, not by HBM bandwidth"},
+                         "note": "tiled z-buffer (survivors binned into 32 x 32 screen tiles, one workgroup per tile, "
+                                 "z-buffer in LDS), exact re-splat, block-count emit: bound by the scattered atomics of "
+                                 "binning / re-splat and the fixed map-sized passes, not by HBM bandwidth"},
             "images_per_s": 1.0 / batch_s, "ms_per_image": batch_s * 1e3, "batch": n_images,
             "single_image_calls": {"images_per_s": 1.0 / gpu_s, "ms_per_image": gpu_s * 1e3},
             "candidates_per_image": n_points, "proj_map": [W, H], "mapped_points_image0": int(ref["idx"].shape[0]),

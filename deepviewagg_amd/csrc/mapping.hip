@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void zbuffer_batch_kernel(const int4* __restri
                                                              const float* __restrict__ dist,
                                                              const MapCounters* __restrict__ cnt,
                                                              unsigned long long* __restrict__ zbuf, int Hc,
-                                                             int64_t npix, int mode) {
+                                                             int64_t npix) {
   const int m = cnt->m;
   const int lane = threadIdx.x & 63, quarter = lane >> 4, ql = lane & 15;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -412,30 +412,10 @@ __global__ __launch_bounds__(256) void zbuffer_batch_kernel(const int4* __restri
         const int bh = sq.w - sq.z;
         const unsigned long long key = ((unsigned long long)__float_as_uint(dist[jq]) << 32) | (unsigned)jq;
         unsigned long long* plane = zbuf + (size_t)simg[jq] * (size_t)npix;
-        if (mode == 1) {               // every pixel test is an atomic (no dependent load in front of it)
-          for (int t = ql; t < area_q; t += 16) {
-            const int bx = t / bh, by = t - bx * bh;
-            atomicMin(plane + (size_t)(sq.x + bx) * Hc + (sq.z + by), key);
-          }
-        } else if (mode == 2) {        // all cells of the box first (8 loads in flight per lane), then the atomics
-          unsigned long long* cells[8];
-          unsigned long long cur[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int t = ql + 16 * i;
-            const int bx = t / bh, by = t - bx * bh;
-            cells[i] = plane + (size_t)(sq.x + bx) * Hc + (sq.z + by);
-            cur[i] = t < area_q ? __builtin_nontemporal_load(cells[i]) : 0ull;
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (key < cur[i]) atomicMin(cells[i], key);
-        } else {
-          for (int t = ql; t < area_q; t += 16) {
-            const int bx = t / bh, by = t - bx * bh;
-            unsigned long long* cell = plane + (size_t)(sq.x + bx) * Hc + (sq.z + by);
-            if (key < *cell) atomicMin(cell, key);
-          }
+        for (int t = ql; t < area_q; t += 16) {
+          const int bx = t / bh, by = t - bx * bh;
+          unsigned long long* cell = plane + (size_t)(sq.x + bx) * Hc + (sq.z + by);
+          if (key < *cell) atomicMin(cell, key);
         }
       }
     } else {
@@ -665,36 +645,72 @@ __global__ __launch_bounds__(256) void resplat_batch_kernel(const uint8_t* __res
   }
 }
 
-struct IsMapped {
-  __host__ __device__ int32_t operator()(int32_t v) const { return v >= 0 ? 1 : 0; }
-};
+// Output order of the batched build without a map-sized scan: mapped pixels (pixmap >= 0) are counted per block of
+// EB_PIX consecutive pixels, the (few) block counts are scanned, and the emit kernel re-derives the position of a pixel
+// inside its block from ballots: the plane is read twice (2 x 4 bytes per pixel) instead of read / written / read twice.
+constexpr int EB_PER_THREAD = 8, EB_PIX = 256 * EB_PER_THREAD;
 
-__global__ __launch_bounds__(256) void emit_batch_kernel(
-    const int32_t* __restrict__ pixmap, const int32_t* __restrict__ pixpos,
-    int64_t npix, int B, int Hc, int crop_top, const int32_t* __restrict__ idx1, const float* __restrict__ dist,
+__global__ __launch_bounds__(256) void pix_block_count_kernel(const int32_t* __restrict__ pixmap, int64_t total,
+                                                               int32_t* __restrict__ block_count) {
+  __shared__ int s_c[4];
+  const int64_t k0 = (int64_t)blockIdx.x * EB_PIX;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < EB_PER_THREAD; ++i) {
+    const int64_t k = k0 + (int64_t)i * 256 + threadIdx.x;
+    c += (k < total && pixmap[k] >= 0) ? 1 : 0;
+  }
+  for (int off = 1; off < 64; off <<= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+__global__ __launch_bounds__(256) void emit_blocks_kernel(
+    const int32_t* __restrict__ pixmap, const int32_t* __restrict__ block_off, int64_t n_blocks, int64_t npix, int B,
+    int Hc, int crop_top, const int32_t* __restrict__ idx1, const float* __restrict__ dist,
     const double* __restrict__ xp, const double* __restrict__ yp, int64_t* __restrict__ idx,
     int64_t* __restrict__ x_pix, int64_t* __restrict__ y_pix, float* __restrict__ depth, double* __restrict__ x_proj,
     double* __restrict__ y_proj, int64_t* __restrict__ row_ptr, int64_t* __restrict__ n_out) {
+  __shared__ int s_w[4];
   const int64_t total = npix * B;
-  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(k / npix);
-    const int64_t kk = k - (int64_t)b * npix;
-    if (kk == 0) row_ptr[b] = pixpos[k];
-    const int32_t j = pixmap[k];
-    if (j >= 0) {
-      const int32_t o = pixpos[k];
-      idx[o] = idx1[j];
-      x_pix[o] = kk / Hc;
-      y_pix[o] = kk % Hc + crop_top;
-      depth[o] = dist[j];
-      x_proj[o] = xp[j];
-      y_proj[o] = yp[j];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t k0 = (int64_t)blockIdx.x * EB_PIX;
+  int run = block_off[blockIdx.x];             // rows before the pixels of this pass
+#pragma unroll 1
+  for (int i = 0; i < EB_PER_THREAD; ++i) {
+    const int64_t k = k0 + (int64_t)i * 256 + threadIdx.x;
+    const int32_t j = k < total ? pixmap[k] : -1;
+    const unsigned long long bal = __ballot(j >= 0);
+    if (lane == 0) s_w[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      before += w < wv ? s_w[w] : 0;
+      all += s_w[w];
     }
-    if (k == total - 1) {
-      const int64_t q = (int64_t)pixpos[k] + (j >= 0 ? 1 : 0);
-      row_ptr[B] = q;
-      *n_out = q;
+    const int o = run + before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (k < total) {
+      const int b = (int)(k / npix);
+      const int64_t kk = k - (int64_t)b * npix;
+      if (kk == 0) row_ptr[b] = o;                 // rows of the images before b
+      if (j >= 0) {
+        idx[o] = idx1[j];
+        x_pix[o] = kk / Hc;
+        y_pix[o] = kk % Hc + crop_top;
+        depth[o] = dist[j];
+        x_proj[o] = xp[j];
+        y_proj[o] = yp[j];
+      }
+      if (k == total - 1) {
+        const int64_t q = (int64_t)o + (j >= 0 ? 1 : 0);
+        row_ptr[B] = q;
+        *n_out = q;
+      }
     }
+    run += all;
+    __syncthreads();
   }
 }
 
@@ -1027,9 +1043,8 @@ int dva_visibility_batch(const float* xyz, int64_t n, const dva_camera* cam0, co
     {
       int64_t blocks = (nc + 15) / 16;          // 4 wavefronts x 4 survivors per block iteration
       if (blocks > 256 * 32) blocks = 256 * 32;
-      static const int zmode = tune_int("DVA_ZBUF_MODE", 0);
       hipLaunchKernelGGL(zbuffer_batch_kernel, dim3((int)blocks), dim3(256), 0, s, splat, simg, dist, cnt, zbuf, Hc,
-                         npix, zmode);
+                         npix);
     }
     if (cam0->exact) {
       if (hipMemsetAsync(seen, 0, (size_t)nc, s) != hipSuccess) return DVA_ERR_LAUNCH;
@@ -1041,15 +1056,21 @@ int dva_visibility_batch(const float* xyz, int64_t n, const dva_camera* cam0, co
       hipLaunchKernelGGL(winners_kernel, dim3(grid_for(npt)), dim3(256), 0, s, zbuf, npt, pixmap);
     }
 }
-  // output position of every mapped pixel: exclusive scan of (pixmap >= 0) read through a transform iterator (no flag
-  // array: one write + two reads of the B x map-sized plane less than the single-image build)
-  tmp = L.temp_bytes;
-  if (rocprim::exclusive_scan(ws + L.temp, tmp, rocprim::make_transform_iterator(pixmap, IsMapped()), pixpos, 0,
-                              (size_t)npt, rocprim::plus<int32_t>(), s) != hipSuccess)
-    return DVA_ERR_LAUNCH;
-  (void)pixflag;
-  hipLaunchKernelGGL(emit_batch_kernel, dim3(grid_for(npt)), dim3(256), 0, s, pixmap, pixpos, npix, B, Hc,
-                     cam0->crop_top, idx1, dist, xp, yp, idx, x_pix, y_pix, depth, x_proj, y_proj, row_ptr, n_out_dev);
+  // output position of every mapped pixel: per-block counts, a scan over the blocks, positions inside a block from
+  // ballots (the map-sized exclusive scan of round 3a: one write + one read of a B x map-sized plane more)
+  {
+    const int64_t n_blocks = (npt + EB_PIX - 1) / EB_PIX;
+    int32_t* block_count = pixflag;                       // [n_blocks] (the flag plane is otherwise unused here)
+    int32_t* block_off = pixpos;
+    hipLaunchKernelGGL(pix_block_count_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, pixmap, npt, block_count);
+    tmp = L.temp_bytes;
+    if (rocprim::exclusive_scan(ws + L.temp, tmp, block_count, block_off, 0, (size_t)n_blocks,
+                                rocprim::plus<int32_t>(), s) != hipSuccess)
+      return DVA_ERR_LAUNCH;
+    hipLaunchKernelGGL(emit_blocks_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, pixmap, block_off, n_blocks, npix,
+                       B, Hc, cam0->crop_top, idx1, dist, xp, yp, idx, x_pix, y_pix, depth, x_proj, y_proj, row_ptr,
+                       n_out_dev);
+  }
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -203,3 +203,55 @@ def test_visibility_batch_full_size_equals_single(exact):
     ref = M.visibility(xyz, cam0)
     for k in ("idx", "x", "y"):
         assert np.array_equal(out[k][rp[0]:rp[1]].cpu().numpy(), ref[k]), k
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_visibility_batch_tiled_zbuffer_fallbacks(exact):
+    """The tiled z-buffer of the batched build under stress: camera 0 stands inside a dense cluster of points (thousands
+    of splat boxes cover more than 16 screen tiles -- beyond the 4096 slots of the per-image large-box list -- and the
+    mid-sized ones overflow the tile lists' capacity of 4 entries per candidate): those survivors fall back to the
+    atomic plane, which the tile kernel merges.  Every image must still equal its single-image build (the plain atomic
+    z-buffer) bit for bit, and image 0 the C oracle."""
+    from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
+    rng = np.random.default_rng(7)
+    cams = np.array([[3.1, 2.2, 1.4], [5.0, 3.0, 1.2], [2.0, 4.5, 1.6]], dtype=np.float32)
+
+
+    def shell(n, r0, r1):
+        u = rng.normal(0, 1, (n, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        return (cams[0] + u * rng.uniform(r0, r1, (n, 1))).astype(np.float32)
+    near = shell(6000, 0.20, 0.30)           # boxes of 5 .. 8 tiles per axis: "large"
+    mid = shell(20000, 0.40, 0.48)           # boxes of 3 .. 4 tiles per axis: 9 .. 16 list entries each
+    xyz = np.concatenate([room_cloud(20_000, rng), near, mid]).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    opk = rng.normal(0, 0.3, (3, 3)).astype(np.float32)
+    kw = dict(img_size=(1024, 512), crop_top=0, crop_bottom=0, r_max=8.0, r_min=0.05, voxel=0.15, k_swell=1.0,
+              d_swell=1000, exact=exact)
+    # the scene really exercises the fallbacks (lower bounds from the splat formula, SURVEY.md A.1 step 4: w_y = a H / pi,
+    # w_x >= a W / (2 pi 1.001), a = (1 + k exp(-d / ln d_swell)) voxel / d): large boxes of image 0 and list entries
+    d = np.linalg.norm(xyz - cams[0], axis=1)
+    d = d[(d > 0.05) & (d < 8.0)]
+    ang = (1 + np.exp(-d / np.log(1000))) * 0.15 / d
+    ty, tx = np.maximum(ang * 512 / np.pi / 32, 1), np.maximum(ang * 1024 / (2 * np.pi * 1.001) / 32, 1)
+    assert int((tx * ty > 16).sum()) > 4096                      # more than ZT_BIGCAP large boxes
+    assert float(np.where(tx * ty <= 16, tx * ty, 0).sum()) > 4 * len(xyz)      # more entries than one image's capacity
+    model = SplattingVisibility(camera="s3dis_equirectangular", **kw)
+    xyz_d = torch.from_numpy(xyz).to(DEV)
+    out = model.batch(xyz_d, torch.from_numpy(cams).to(DEV), img_opk=torch.from_numpy(opk).to(DEV))
+    rp = out["row_ptr"].cpu().numpy()
+    for i in range(3):
+        one = model(xyz_d, torch.from_numpy(cams[i]).to(DEV), img_opk=torch.from_numpy(opk[i]).to(DEV))
+        a, b = rp[i], rp[i + 1]
+        assert b - a == one["idx"].shape[0] and b > a
+        for k in ("idx", "x", "y", "depth"):
+            assert torch.equal(out[k][a:b], one[k]), (i, k)
+    # a batch of ONE image: its list capacity (4 entries per candidate) overflows as well
+    solo = model.batch(xyz_d, torch.from_numpy(cams[:1]).to(DEV), img_opk=torch.from_numpy(opk[:1]).to(DEV))
+    for k in ("idx", "x", "y", "depth"):
+        assert torch.equal(solo[k], out[k][rp[0]:rp[1]]), k
+    cam0 = M.make_camera("s3dis_equirectangular", kw["img_size"], cams[0], r_min=kw["r_min"], r_max=kw["r_max"],
+                         voxel=kw["voxel"], k_swell=1.0, d_swell=1000, exact=exact, img_opk=opk[0])
+    ref = M.visibility(xyz, cam0)
+    for k in ("idx", "x", "y"):
+        assert np.array_equal(out[k][rp[0]:rp[1]].cpu().numpy(), ref[k]), k
