@@ -1,6 +1,8 @@
 """Backward of fused_chain._ChainPool: four view passes (attention, layer 6, layer 5, layer 2), each re-evaluating
 the DeepSetFeat chain from x_map, separated by the BatchNorm-backward statistics; the per-point set branch in
 between runs on csrc/chain_set.hip (fused_chain._set_branch_backward)."""
+import os
+
 import torch
 
 from . import _lib, ops
@@ -115,6 +117,21 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
     return [dW1, g1, b1, dW2, g2, b2, dW5, g5, b5, dW6, g6, b6, dWs, dbs, dgw, dgb] + d_set
 
 
+# DVA_OVERLAP_ROWS_GRAD=1: the rows gradient (random line fetches, few vector instructions) on a side stream,
+# concurrently with the first passes of the chain epilogue (vector-unit bound) on the caller's stream: both only need the
+# attention backward's outputs.  Measured on S1 (same box, A/B): 11.60 -> 11.43 ms/step -- the two share the CUs, each
+# stretches (rows gradient 1.32 -> 2.12 ms, stage 6 1.22 -> 2.18 ms), the sum shrinks by 0.16 ms.  Off by default: the
+# per-kernel durations of the bench line (and its roofline object) are only meaningful when kernels do not overlap.
+OVERLAP_ROWS_GRAD = os.environ.get('DVA_OVERLAP_ROWS_GRAD', '0') == '1'
+_SIDE = {}
+
+
+def _side_stream(dev):
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
 def backward(ctx, gout):
     from types import SimpleNamespace
     lib = _lib.load()
@@ -147,15 +164,31 @@ def backward(ctx, gout):
     del scores
     # ---- rows gradient: segmented reduction over the row plan (deterministic, no atomics)
     grows = None
+    side = None
     if ctx.needs_input_grad[0]:
         plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
         perm, row_ptr = plan
-        grows = torch.empty((R, C), dtype=torch.float32, device=dev)
-        with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
-            check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), R, V, C,
-                                                      G, _lib.DVA_BF16, st), "dva_view_gather_rows_grad_rec16")
-        grows = grows.to(rows.dtype)
+
+        def rows_grad(stream):
+            g = torch.empty((R, C), dtype=torch.float32, device=dev)
+            with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
+                check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(g), R, V, C,
+                                                          G, _lib.DVA_BF16, stream), "dva_view_gather_rows_grad_rec16")
+            return g.to(rows.dtype)
+        if OVERLAP_ROWS_GRAD:
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)                       # records of the attention backward
+            with torch.cuda.stream(side):
+                grows = rows_grad(stream_of(x_map))
+            for t_ in (gout, perm, row_ptr, rec):
+                t_.record_stream(side)
+        else:
+            grows = rows_grad(st)
     del rec
     grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        grows.record_stream(torch.cuda.current_stream(dev))
     ctx.set_saved = None
     return (grows, None, None, None, None, None, None, None) + tuple(grads)
