@@ -456,8 +456,9 @@ __device__ __forceinline__ int4 tile_entry(int j, float d, const int4& s) {
 }
 
 // FILL = false: tile_count += entries per tile.  FILL = true: the entries themselves (tile_off = exclusive scan of
-// tile_count).  One block per chunk of ZT_CHUNK consecutive survivors (image-major: a chunk touches the tiles of n_img
-// <= 2 images, whose counters are in LDS: hist / base [n_img * T]; survivors of further images use the global counters).
+// tile_count).  One block per chunk of ZT_CHUNK consecutive survivors.  The compaction is image-major (simg is
+// non-decreasing), so a chunk mostly touches the tiles of the image of its first survivor and the next one: their
+// counters are in LDS (hist / base [n_img * T], n_img <= 2); survivors of any other image use the global counters.
 template <bool FILL>
 __global__ __launch_bounds__(ZT_BLOCK) void tile_bin_kernel(
     const int4* __restrict__ splat, const int32_t* __restrict__ simg, const float* __restrict__ dist,
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(ZT_BLOCK) void tile_bin_kernel(
       const int b = simg[j];
       const int tx0 = s.x / ZT, tx1 = (s.y - 1) / ZT, ty0 = s.z / ZT, ty1 = (s.w - 1) / ZT;
       if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > ZT_BIG) continue;
-      const bool local = b - b_lo < n_img;
+      const bool local = (unsigned)(b - b_lo) < (unsigned)n_img;
       for (int tx = tx0; tx <= tx1; ++tx)
         for (int ty = ty0; ty <= ty1; ++ty) {
           if (local) atomicAdd(&hist[(b - b_lo) * T + tx * Ty + ty], 1);
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(ZT_BLOCK) void tile_bin_kernel(
           if (slot < ZT_BIGCAP) big_list[(int64_t)b * ZT_BIGCAP + slot] = ent;
           else fb = true;
         } else {
-          const bool local = b - b_lo < n_img;
+          const bool local = (unsigned)(b - b_lo) < (unsigned)n_img;
           for (int tx = tx0; tx <= tx1; ++tx)
             for (int ty = ty0; ty <= ty1; ++ty) {
               const int g = (b * Tx + tx) * Ty + ty;
