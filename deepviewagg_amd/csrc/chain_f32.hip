@@ -7,12 +7,15 @@
 // BatchNorm + LeakyReLU in fp32 on the accumulators (no BatchNorm folding; leaky' follows the sign of the plain
 // pre-activation), and the gradient rows handed between the backward passes are fp32 [V, 32] (128 bytes per view).
 //
-// Balance.  A 32 x 32 x 32 product costs 16 instructions x 64 cycles per tile: a pass that re-evaluates the chain from
-// x_map is bound by the matrix pipe at a third of the HBM bandwidth (measured: 21.2 ms for the eight passes, 71 - 83 %
-// matrix-pipe utilisation).  So two raw layer outputs stay in HBM -- z2 (written by the layer-2 statistics pass) and z5
-// (written by the layer-5 statistics pass), fp32 [V, 32] each -- and every later pass starts from one of them: one
-// 128-byte row per view read back replaces the 20 .. 52 instructions that would recompute it.  (The stored-activation
-// kernels of deepset_mfma.hip keep thirteen such tensors and are HBM-bound at 24.5 ms.)
+// Balance.  A 32 x 32 x 32 product costs 16 instructions x 64 cycles per tile, and this instruction does not overlap
+// with vector instructions of the SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0: a pass costs matrix time + vector time): a pass
+// that re-evaluates the chain from x_map ran at a third of the HBM bandwidth (measured: 21.2 ms for the eight passes).
+// So two raw layer outputs stay in HBM -- z2 (written by the layer-2 statistics pass) and z5 (written by the layer-5
+// statistics pass), fp32 [V, 32] each -- and every later pass starts from one of them: one 128-byte row per view read
+// back replaces the 20 .. 52 instructions that would recompute it (15.8 ms; the passes that hand rows over then sit
+// near the device's read + write copy ceiling).  The stored-activation kernels of deepset_mfma.hip keep thirteen such
+// tensors and are HBM-bound at 24.5 ms.  A fp32-equivalent six-term bf16 product (operands split into three bf16 parts)
+// was measured at the same step time and dropped.
 //
 // Layout.  One wavefront owns a 32-view tile; lane (j, h) = view j, half h.  D[i][j] += sum_{kk<2} A[i][kk] B[kk][j] with
 // lane l supplying A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31]; register r of lane (j, h) holds
@@ -20,8 +23,8 @@
 // (chan(s, 0), chan(s, 1)) -- which is register s of the two half-waves of the previous layer's accumulators (and of
 // a stored row loaded in the same order): the B operand of step s IS entry s.  The A operands (weights, one float per
 // lane and step) come from an LDS table: per matrix 4 blocks of 64 float4 (steps 4q .. 4q + 3 of lane l at block q).
-// Weight gradients dW[n][k] = sum_v dz[v][n] a[v][k] pair the views (2s, 2s + 1) in step s; both operands come from
-// [view][channel] fp32 tiles in LDS (row stride 36 floats: float4 row writes and column reads without bank conflicts).
+// Weight gradients dW[n][k] = sum_v dz[v][n] a[v][k] pair the views (s, 16 + s) in step s; both operands come from
+// [channel][view] fp32 tiles in LDS (row stride 36 floats: conflict-free scalar writes, ds_read_b128 of four steps).
 //   dva_chain3_prep         operand table (26 KiB)
 //   dva_chain3_stats2       x_map -> z2 (stored), statistics of layer 2 + per-point extremum (set pooling)
 //   dva_chain3_stats        layer 5: z2 -> z5 (stored) + statistics; layer 6: z5 -> statistics of z6
