@@ -79,7 +79,7 @@ def test_chain3_matches_reference_fixtures(name, monkeypatch):
 
 
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("G,use_num", [(4, True), (2, False), (1, True)])
+@pytest.mark.parametrize("G,use_num", [(4, True), (3, False), (2, False), (1, True)])
 def test_chain3_scores_vs_fp64(G, use_num, train):
     """Scores and every parameter gradient against the oracle module evaluated in fp64; the stored-activation fp32
     kernels run beside it on the same inputs (their error is printed with -s: 1e-4 .. 2e-3 on the gradients)."""
