@@ -394,8 +394,8 @@ def mapping_build_bench(device, n_images=32, n_points=200_000):
 
 
 def copy_ceiling(device, nbytes=1 << 32, reps=5):
-    """Practical HBM ceiling: read + write rate of the library's float4 grid-stride copy kernel
-    (dva_copy_ceiling) over `nbytes`; MI355X_MICROARCH.md measures 6.29 TB/s for this pattern."""
+    """Practical HBM ceiling: read + write rate of the library's device copy (dva_copy_ceiling: a chunk per
+    block, non-temporal 16-byte loads / stores) over `nbytes`; MI355X_MICROARCH.md measures 6.29 TB/s for this pattern."""
     from deepviewagg_amd import _lib
     lib = _lib.load()
     src = torch.empty(nbytes, dtype=torch.uint8, device=device)

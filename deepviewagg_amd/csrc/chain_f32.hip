@@ -12,8 +12,7 @@
 // that re-evaluates the chain from x_map ran at a third of the HBM bandwidth (measured: 21.2 ms for the eight passes).
 // So two raw layer outputs stay in HBM -- z2 (written by the layer-2 statistics pass) and z5 (written by the layer-5
 // statistics pass), fp32 [V, 32] each -- and every later pass starts from one of them: one 128-byte row per view read
-// back replaces the 20 .. 52 instructions that would recompute it (15.8 ms; the passes that hand rows over then sit
-// near the device's read + write copy ceiling).  The stored-activation kernels of deepset_mfma.hip keep thirteen such
+// back replaces the 20 .. 52 instructions that would recompute it (15.8 ms, 15.0 with tile-native rows).  The stored-activation kernels of deepset_mfma.hip keep thirteen such
 // tensors and are HBM-bound at 24.5 ms.  A fp32-equivalent six-term bf16 product (operands split into three bf16 parts)
 // was measured at the same step time and dropped.
 //
@@ -216,14 +215,34 @@ __device__ __forceinline__ void add_stats(const Z16& z, bool ok, float (&st)[2][
   }
 }
 
-// a [V][32] fp32 row tensor reaches 4 GiB at V = 2^25: one buffer descriptor per tile (rows of the tile only)
+// a [V][32] fp32 row tensor reaches 4 GiB at V = 2^25: one buffer descriptor per tile (rows of the tile only).
+// The rows of a tile are stored in the order the lanes hold them ("tile-native": element (view j, half h, quad q) at
+// byte q (32 nv) + 32 j + 16 h of the tile's nv x 128 bytes), so that every load / store instruction of a wavefront
+// covers one contiguous run of 32 nv bytes instead of 32 separate 32-byte pieces.  Producers and consumers of these
+// tensors (z2, z5, dy5, dy2) are the kernels of this file, all walking the same tile table.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* base, const TileInfo& ti) {
   return make_rsrc(base ? base + (int64_t)ti.v0 * D : nullptr, base ? (uint64_t)ti.nv * 128 : 0);
 }
 __device__ __forceinline__ f32x16 load_tile_rows(const float* base, const TileInfo& ti, int j, int h) {
+  const __amdgpu_buffer_rsrc_t R = tile_rsrc(base, ti);
+  const bool ok = j < ti.nv;
+  const uint32_t o = (uint32_t)j * 32u + 16u * h, qs = (uint32_t)ti.nv * 32u;
   f32x16 r;
-  load_rows16(tile_rsrc(base, ti), j < ti.nv, (uint32_t)j, h, r);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = as_f4(ld128(R, ok ? o + q * qs : OOB));
+    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+  }
   return r;
+}
+template <typename A16>
+__device__ __forceinline__ void store_tile_rows(float* base, const TileInfo& ti, int j, int h, const A16& x) {
+  const __amdgpu_buffer_rsrc_t R = tile_rsrc(base, ti);
+  const bool ok = j < ti.nv;
+  const uint32_t o = (uint32_t)j * 32u + 16u * h, qs = (uint32_t)ti.nv * 32u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    st128(R, ok ? o + q * qs : OOB, as_u4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(256, 4) void stats2_kernel(
     act(mm_x(s_w, Q_W1, lane, p.x), s_tab[0], h, a1);
     const f32x16 z2 = mmf(s_w, Q_W2, lane, a1, zero);
     add_stats(z2, ok, st);
-    store_rows16(tile_rsrc(z2_out, p.ti), ok, (uint32_t)j, h, z2);
+    store_tile_rows(z2_out, p.ti, j, h, z2);
     tile_put(tz, j, h, z2, true);
     const int nxt = shfl(p.vpj, lane + 1);
     const bool is_end = ok && (j == nv - 1 || nxt != p.vpj);
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(256, L == 5 ? 3 : 4) void stats_mid_kernel(
     f32x16 z = mmf(s_w, 0, lane, a, zero);
     if (L == 5) z += uacc;
     add_stats(z, ok, st);
-    if (L == 5) store_rows16(tile_rsrc(rows_out, p.ti), ok, (uint32_t)j, h, z);
+    if (L == 5) store_tile_rows(rows_out, p.ti, j, h, z);
   });
   flush_stats<2>(st, stats, s_red);
 }
@@ -572,7 +591,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const f32x16 da5 = mmf(s_w, 4, lane, dz, zero);
       float dy5[16];
       layer_bwd<true, false>(p.row, da5, s_tab[0], h, ok, st, dy5);
-      store_rows16(tile_rsrc(da_out, p.ti), ok, (uint32_t)j, h, dy5);
+      store_tile_rows(da_out, p.ti, j, h, dy5);
       wave_sync();
       accW = wgradf(ta_, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
       wave_sync();
@@ -593,7 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const f32x16 da2 = mmf(s_w, 4, lane, dz, zero);
       float dy2[16];
       layer_bwd<true, false>(p.row, da2, s_tab[0], h, ok, st, dy2);
-      store_rows16(tile_rsrc(da_out, p.ti), ok, (uint32_t)j, h, dy2);
+      store_tile_rows(da_out, p.ti, j, h, dy2);
       // du[p][c] = sum of dz5 over the views of point p: segmented scan over the lanes of each half-wave, the last view
       // of a point stores its 16 channels (a point in several tiles: its fragments add up in the caller-zeroed row)
       {
