@@ -82,14 +82,31 @@ __device__ __forceinline__ f32x16 score_bwd(const uint4* s_ops, int lane, const 
 // score-layer weight gradient -- is the separate pass score_stats_kernel below: 253 VGPRs / 2 wavefronts per SIMD became
 // two kernels that each fit a register budget with twice the occupancy.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int G>
-__global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
+// T = bf16_t (the chain path: 8 channels per 16-byte lane, 16-byte records with bf16 weights) or float (the fp32 path of
+// ops.view_gather_attention: 4 channels per lane, 32-byte records {point | fp32 gate * attention per group | pad} as
+// dva_view_gather_rows_grad reads them).
+template <typename T>
+__device__ __forceinline__ float dotv(const u32x4& a, const u32x4& b);
+template <>
+__device__ __forceinline__ float dotv<bf16_t>(const u32x4& a, const u32x4& b) { return dot8(a, b); }
+template <>
+__device__ __forceinline__ float dotv<float>(const u32x4& a, const u32x4& b) {
+  return __builtin_fmaf(__uint_as_float(a.w), __uint_as_float(b.w),
+                        __builtin_fmaf(__uint_as_float(a.z), __uint_as_float(b.z),
+                                       __builtin_fmaf(__uint_as_float(a.y), __uint_as_float(b.y),
+                                                      __uint_as_float(a.x) * __uint_as_float(b.x))));
+}
+
+template <typename T, int LPR, int G>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void attn_bwd_kernel(
     const float* __restrict__ compat, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
-    const int32_t* __restrict__ n_tiles_dev, const bf16_t* __restrict__ rows, const int32_t* __restrict__ row_idx,
+    const int32_t* __restrict__ n_tiles_dev, const T* __restrict__ rows, const int32_t* __restrict__ row_idx,
     const int64_t* __restrict__ ptr, const float* __restrict__ gw, const float* __restrict__ gb,
-    const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out, float* __restrict__ dc_out,
+    const T* __restrict__ gout, const T* __restrict__ out, float* __restrict__ dc_out,
     uint32_t* __restrict__ rec, float* __restrict__ gwb, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
-  constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
+  constexpr int VEC = 16 / (int)sizeof(T), C = LPR * VEC, ROWS = 64 / LPR, KV = 32 / ROWS;
+  constexpr uint32_t RB = C * sizeof(T);       // bytes of a value / gradient row
+  constexpr bool F32 = sizeof(T) == 4;
   constexpr int KB = KV < 4 ? KV : 4, NB = KV / KB;
   constexpr int NE = G == 1 ? 1 : 2;
   constexpr int LPG = LPR / G;                 // lanes per channel group inside a row
@@ -99,9 +116,9 @@ __global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const __amdgpu_buffer_rsrc_t CP = make_rsrc(compat, (uint64_t)V * 16), P = make_rsrc(vp, (uint64_t)V * 4),
                                RI = make_rsrc(row_idx, (uint64_t)V * 4),
-                               RW = make_rsrc(rows, (uint64_t)R * C * 2), GO = make_rsrc(gout, (uint64_t)N * C * 2),
-                               OU = make_rsrc(out, (uint64_t)N * C * 2), DC = make_rsrc(dc_out, (uint64_t)V * 16),
-                               RC = make_rsrc(rec, (uint64_t)V * 16);
+                               RW = make_rsrc(rows, (uint64_t)R * RB), GO = make_rsrc(gout, (uint64_t)N * RB),
+                               OU = make_rsrc(out, (uint64_t)N * RB), DC = make_rsrc(dc_out, (uint64_t)V * 16),
+                               RC = make_rsrc(rec, (uint64_t)V * (F32 ? 32 : 16));
   // softmax side: lane (j, h) owns the groups gl[e] of view j (G = 4: 2 h, 2 h + 1; G <= 2: the h = 0 lanes)
   const bool s_active = G == 4 || h == 0;
   const uint32_t coff = G == 4 ? 8u * h : 0u;
@@ -157,8 +174,8 @@ __global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk) {
         const int vt = sv0 + b * KB + kk;
-        xr[b & 1][kk] = ld128(RW, (uint32_t)ri_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u);
-        go[b & 1][kk] = ld128(GO, vt < nv ? (uint32_t)pid_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u : OOB);
+        xr[b & 1][kk] = ld128(RW, (uint32_t)ri_t[vt] * RB + (uint32_t)q * 16u);
+        go[b & 1][kk] = ld128(GO, vt < nv ? (uint32_t)pid_t[vt] * RB + (uint32_t)q * 16u : OOB);
       }
     };
     issue_rows(0);
@@ -206,9 +223,9 @@ __global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
         if (t2i.frag == 3) break;
       }
       const uint32_t pid0 = (uint32_t)__builtin_amdgcn_readfirstlane(p.vpj);
-      const u32x4 go0 = ld128(GO, pid0 * (uint32_t)(C * 2) + (uint32_t)q * 16u);
-      const u32x4 ou0 = ld128(OU, pid0 * (uint32_t)(C * 2) + (uint32_t)q * 16u);
-      float d = dot8(go0, ou0);
+      const u32x4 go0 = ld128(GO, pid0 * RB + (uint32_t)q * 16u);
+      const u32x4 ou0 = ld128(OU, pid0 * RB + (uint32_t)q * 16u);
+      float d = dotv<T>(go0, ou0);
 #pragma unroll
       for (int off = 1; off < LPG; off <<= 1) d += __shfl_xor(d, off);
       if (slot == 0 && (q % LPG) == 0) s_E[wv][tg] = d;
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk) {
         const int vt = sv0 + b * KB + kk;
-        float d = dot8(go[b & 1][kk], xr[b & 1][kk]);
+        float d = dotv<T>(go[b & 1][kk], xr[b & 1][kk]);
 #pragma unroll
         for (int off = 1; off < LPG; off <<= 1) d += __shfl_xor(d, off);
         if ((q % LPG) == 0) q_t[tg * 32 + vt] = d;
@@ -304,7 +321,12 @@ __global__ __launch_bounds__(256, LPR <= 8 ? 4 : 3) void attn_bwd_kernel(
     const bool wr = ok && h == 0;
     const uint32_t vg = (uint32_t)(p.ti.v0 + j);
     st128(DC, wr ? vg * 16u : OOB, as_u4(dc4[0], dc4[1], dc4[2], dc4[3]));
-    {   // 16-byte record: the rows gradient is rounded to bf16 anyway, its weights travel as bf16
+    if constexpr (F32) {   // 32-byte record: point | gate * attention per group (fp32) | pad
+      const u32x4 r0 = {(uint32_t)p.vpj, __float_as_uint(ga4[0]), __float_as_uint(ga4[1]), __float_as_uint(ga4[2])};
+      const u32x4 r1 = {__float_as_uint(ga4[3]), 0u, 0u, 0u};
+      st128(RC, wr ? vg * 32u : OOB, r0);
+      st128(RC, wr ? vg * 32u + 16u : OOB, r1);
+    } else {   // 16-byte record: the rows gradient is rounded to bf16 anyway, its weights travel as bf16
       const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), 0u};
       st128(RC, wr ? vg * 16u : OOB, r);
     }
@@ -884,11 +906,11 @@ int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const voi
     return DVA_ERR_UNSUPPORTED;
   const dim3 grid(chain_grid(C <= 64 ? 4 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define DVA_ATTN_BWD(LPR_, G_)                                                                                   \
-  hipLaunchKernelGGL((attn_bwd_kernel<LPR_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,    \
-                     n_tiles, (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b, (const bf16_t*)grad_out,        \
-                     (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, scaling, eps, n_views,  \
-                     n_points, n_rows)
+#define DVA_ATTN_BWD(LPR_, G_)                                                                                    \
+  hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, LPR_, G_>), grid, block, 0, s, scores, view_point,                  \
+                     (const int2*)tiles, n_tiles, (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b,              \
+                     (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, \
+                     scaling, eps, n_views, n_points, n_rows)
   const int key = C * 8 + G;
   switch (key) {
     case 32 * 8 + 1: DVA_ATTN_BWD(4, 1); break;
@@ -909,6 +931,45 @@ int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const voi
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_ATTN_BWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_attn_bwd_f32(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                           const float* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                           const float* gate_b, const float* grad_out, const float* out, float* grad_scores,
+                           float* view_rec, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
+                           int32_t C, int32_t G, int32_t scaling, float eps, void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!scores || !view_point || !tiles || !n_tiles || !rows || !row_idx || !ptr || !grad_out || !out ||
+      !grad_scores || !view_rec || ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_rows * C * 4 > 0xfffffff0ll || n_points * C * 4 > 0xfffffff0ll)
+    return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(3)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_ATTN_BWD32(LPR_, G_)                                                                                  \
+  hipLaunchKernelGGL((attn_bwd_kernel<float, LPR_, G_>), grid, block, 0, s, scores, view_point,                   \
+                     (const int2*)tiles, n_tiles, rows, row_idx, ptr, gate_w, gate_b, grad_out, out, grad_scores, \
+                     (uint32_t*)view_rec, grad_gate_wb, scaling, eps, n_views, n_points, n_rows)
+  const int key = C * 8 + G;
+  switch (key) {
+    case 32 * 8 + 1: DVA_ATTN_BWD32(8, 1); break;
+    case 32 * 8 + 2: DVA_ATTN_BWD32(8, 2); break;
+    case 32 * 8 + 4: DVA_ATTN_BWD32(8, 4); break;
+    case 64 * 8 + 1: DVA_ATTN_BWD32(16, 1); break;
+    case 64 * 8 + 2: DVA_ATTN_BWD32(16, 2); break;
+    case 64 * 8 + 4: DVA_ATTN_BWD32(16, 4); break;
+    case 128 * 8 + 1: DVA_ATTN_BWD32(32, 1); break;
+    case 128 * 8 + 2: DVA_ATTN_BWD32(32, 2); break;
+    case 128 * 8 + 4: DVA_ATTN_BWD32(32, 4); break;
+    case 256 * 8 + 1: DVA_ATTN_BWD32(64, 1); break;
+    case 256 * 8 + 2: DVA_ATTN_BWD32(64, 2); break;
+    case 256 * 8 + 4: DVA_ATTN_BWD32(64, 4); break;
+    default: return DVA_ERR_UNSUPPORTED;
+  }
+#undef DVA_ATTN_BWD32
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -718,6 +718,10 @@ def _team_records_ok(C, G, dtype):
     return pow2(lpr) and lpr <= 64 and pow2(G) and G <= 32 and C % G == 0 and (C // G) % vec == 0
 
 
+# fp32 rows with four score groups: the lean tile-based attention backward (False: the team kernel; tests A/B)
+LEAN_ATTENTION_BWD = True
+
+
 class _ViewGatherAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, row_idx, compat, csr_idx, gate_w, gate_b, scaling, eps, plan):
@@ -744,16 +748,17 @@ class _ViewGatherAttention(torch.autograd.Function):
                 ptr(gate), ptr(amax), N, V, C, G, int(scaling), float(eps), dtype_code(rows),
                 ATTENTION_ALGO, stream_of(rows)), "dva_view_gather_attention_fwd")
         ctx.save_for_backward(rows, row_idx, compat, csr_idx, att, gate, amax,
-                              gw if gw is not None else csr_idx, gb if gb is not None else csr_idx)
+                              gw if gw is not None else csr_idx, gb if gb is not None else csr_idx, out)
         ctx.meta = (int(scaling), gw is not None,
                     None if gate_w is None else gate_w.shape, None if gate_b is None else gate_b.shape)
+        ctx.eps = float(eps)
         ctx.mark_non_differentiable(att, gate)
         return out, att, gate
 
     @staticmethod
     def backward(ctx, gout, _gatt, _ggate):
         lib = _lib.load()
-        rows, row_idx, compat, csr_idx, att, gate, amax, gw, gb = ctx.saved_tensors
+        rows, row_idx, compat, csr_idx, att, gate, amax, gw, gb, out = ctx.saved_tensors
         scaling, has_gate, w_shape, b_shape = ctx.meta
         gout = gout.contiguous()
         N, V, (R, C), G = csr_idx.shape[0] - 1, row_idx.shape[0], rows.shape, compat.shape[1]
@@ -762,6 +767,31 @@ class _ViewGatherAttention(torch.autograd.Function):
         es = rows.element_size()
         need_rows = ctx.needs_input_grad[0]
         use_plan = need_rows and ROWS_GRAD_ALGO == 0
+        if (LEAN_ATTENTION_BWD and use_plan and ATTENTION_ALGO != 1 and rows.dtype == torch.float32
+                and gout.dtype == torch.float32 and G == 4 and C in (32, 64, 128, 256) and V > 0
+                and V * 32 < (1 << 32) - 16 and max(R, N) * C * 4 < (1 << 32) - 16):
+            # fp32 rows, four score groups (the no-autocast headline shape): the tile-based attention backward of the
+            # chain path (csrc/chain_bwd.hip attn_bwd_kernel<float, ...>: scores in, score gradients + 32-byte view
+            # records out) instead of the team kernel: 2.8 -> 2.0 ms at V = 33.5 M
+            from .fused_chain import build_tiles
+            tiles, n_tiles = build_tiles(csr_idx, V)
+            vp = csr_expand(csr_idx, V)
+            rec = torch.empty((V, 8), dtype=torch.float32, device=rows.device)
+            with _timed("view_gather_attention_bwd", V * (C * 4 + 16 + 8 + 16 + 32) + N * (C * 4 + 8)):
+                check(lib.dva_chain_attn_bwd_f32(
+                    ptr(compat), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx), ptr(csr_idx),
+                    ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(gout), ptr(out), ptr(gcompat),
+                    ptr(rec), ptr(gwb), N, V, R, C, G, scaling, ctx.eps, stream_of(rows)), "dva_chain_attn_bwd_f32")
+            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
+            perm, row_ptr = plan
+            grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
+            with _timed("view_gather_rows_grad", V * (4 + 32 + C * es) + R * (C * 4 + 4)):
+                check(lib.dva_view_gather_rows_grad(
+                    ptr(gout), ptr(att), ptr(gate) if has_gate else None, None, ptr(perm), ptr(row_ptr), ptr(rec), 8,
+                    ptr(grows), R, V, C, G, dtype_code(rows), stream_of(rows)), "dva_view_gather_rows_grad")
+            g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
+            g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
+            return grows, None, gcompat, None, g_w, g_b, None, None, None
         if need_rows and not use_plan:
             grows = torch.zeros((R, C), dtype=torch.float32, device=rows.device)
         else:

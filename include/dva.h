@@ -516,6 +516,14 @@ int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const voi
                        const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
                        float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
                        int32_t scaling, float eps, void* stream);
+/* dva_chain_attn_bwd for fp32 value rows (the no-autocast path: ops.view_gather_attention backward when the scores
+ * are fp32 [V][4]): rows / grad_out / out fp32, C in {32, 64, 128, 256}, view_rec = fp32 [V][8] records
+ * {point id (int bits) | gate * attention per group | pad} as dva_view_gather_rows_grad reads them (rec_stride 8). */
+int dva_chain_attn_bwd_f32(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                           const float* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                           const float* gate_b, const float* grad_out, const float* out, float* grad_scores,
+                           float* view_rec, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
+                           int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
 /* Score layer backward + the statistics of the BatchNorm-6 backward (one chain evaluation per view):
  * stats6 += S1 | S2 of layer 6 with dy6 = leaky'(t6) Ws^T grad_scores (t6 = the folded layer-6 product, the
  * pre-activation the forward's activation saw), dWs fp32 [G][32] / dbs fp32 [G] (caller-zeroed) += the gradient of the

@@ -505,3 +505,55 @@ def test_mapping_row_index_equals_pack_then_row_index(pix_dtype, ratio):
     img_of_atom = images.repeat_interleave(sizes)
     expect = (img_of_atom * H + (pixels[:, 1].long() // int(ratio))) * W + pixels[:, 0].long() // int(ratio)
     assert torch.equal(row_idx.cpu().long(), expect)
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+@pytest.mark.parametrize("gating,scaling", [(True, True), (False, False)])
+def test_lean_attention_backward_fp32_equals_team_kernel(C, gating, scaling):
+    """fp32 rows, four score groups: the tile-based attention backward (chain_bwd.hip attn_bwd_kernel<float>) against
+    the team kernel on ragged points incl. empty ones, a 90-view point and a 400-view point (fragments), ties in the
+    maximal score; and both against the PyTorch oracle."""
+    from deepviewagg_amd import ops
+    from oracle import pooling_oracle as O
+    gen = torch.Generator().manual_seed(100 + C)
+    N, G, R = 700, 4, 509
+    sizes = torch.randint(0, 12, (N,), generator=gen)
+    sizes[10], sizes[300] = 90, 400
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    rows = torch.randn(R, C, generator=gen)
+    row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    compat = torch.randn(V, G, generator=gen)
+    compat[csr[20]:csr[20] + 2] = compat[csr[20]]                 # a tie: the first maximal view takes the gate path
+    w = torch.randn(N, C, generator=gen)
+    gw = torch.randn(1, G, generator=gen) if gating else None
+    gb = torch.randn(1, G, generator=gen) if gating else None
+
+    def run(lean):
+        ops.LEAN_ATTENTION_BWD = lean
+        try:
+            r = rows.to(DEV).requires_grad_()
+            c = compat.to(DEV).requires_grad_()
+            pw = gw.to(DEV).requires_grad_() if gating else None
+            pb = gb.to(DEV).requires_grad_() if gating else None
+            out, att, gate = ops.view_gather_attention(r, row_idx.to(DEV), c, csr.to(DEV), pw, pb, scaling=scaling)
+            grads = torch.autograd.grad((out * w.to(DEV)).sum(), [r, c] + ([pw, pb] if gating else []))
+            return [out.detach()] + [g_.detach() for g_ in grads]
+        finally:
+            ops.LEAN_ATTENTION_BWD = True
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-5)
+    # oracle
+    gate_m = O.Gating(G) if gating else None
+    if gating:
+        with torch.no_grad():
+            gate_m.weight.copy_(gw)
+            gate_m.bias.copy_(gb)
+    r0, c0 = rows.clone().requires_grad_(), compat.clone().requires_grad_()
+    out_ref, _, _ = O.attention_tail(r0[row_idx.long()], c0, csr, gate_m, G, C, scaling)
+    g_ref = torch.autograd.grad((out_ref * w).sum(), [r0, c0] + (list(gate_m.parameters()) if gating else []))
+    torch.testing.assert_close(a[0].cpu(), out_ref.detach(), rtol=1e-4, atol=1e-5)
+    for x, y in zip(a[1:], g_ref):
+        torch.testing.assert_close(x.cpu().reshape(y.shape), y, rtol=1e-3, atol=1e-4)
