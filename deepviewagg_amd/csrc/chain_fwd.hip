@@ -510,7 +510,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_alpha[4][4], s_scg[4][4];
   // several points per tile: one private row [C] per row slot for the partial sums of points split over slots
   __shared__ __attribute__((aligned(16))) float s_acc[4][ROWS * C];
-  __shared__ __attribute__((aligned(16))) int s_ss[4][32], s_se[4][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < OP_W6T * 64; i += blockDim.x) s_ops[i] = ops[i];
   stage_tab_fwd(s_tab[0], bn1);
@@ -545,8 +544,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   const int rs_ch = 4 * (1 - ((lane >> 5) & 1)) + 2 * (1 - ((lane >> 4) & 1)) + (1 - ((lane >> 3) & 1));
   float* ev_t = s_ev[wv];
   float* sc_t = s_sc[wv];
-  int* ss_t = s_ss[wv];
-  int* se_t = s_se[wv];
   int* pid_t = s_pid[wv];
   int* ri_t = s_ri[wv];
   float* acc_t = s_acc[wv];
@@ -751,11 +748,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
           sc_t[gl[e] * 32 + j] = gt * __builtin_amdgcn_rcpf(s + eps);
         }
       }
-      if (h == 0) {
-        ss_t[j] = ok ? sg.ss : 64 + j;
-        se_t[j] = sg.se;
-        pid_t[j] = p.vpj;
-      }
+      if (h == 0) pid_t[j] = p.vpj;
+      // where the points of the tile start / end: two wave-uniform masks (views without a point = one-view segments)
+      const uint32_t inv = nv < 32 ? 0xffffffffu << nv : 0u;
+      const uint32_t smx = sg.smask | inv, emx = sg.emask | inv;
       wave_sync();
       float hp[8];
       bool has_head = false;
@@ -768,11 +764,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
         for (int kk = 0; kk < KB; ++kk) {
           const int k = b * KB + kk, vt = sv0 + k;
           fma_row(xr[b & 1][kk], ev_t[tg * 32 + vt]);
-          const int ssk = ss_t[vt];
-          const bool last = (k == KV - 1) || (ss_t[vt + 1] != ssk);
+          const bool last = (k == KV - 1) || ((smx >> (vt + 1)) & 1u);
           if (last) {
             if (vt < nv) {
-              const int sek = se_t[vt];
+              const int ssk = 31 - __clz((int)(smx & (0xffffffffu >> (31 - vt))));     // first view of vt's point
+              const int sek = vt + __ffs((int)(emx >> vt)) - 1;                        // its last view
               if (sek >= sv0 + KV) {
                 // the point continues in the next slot: park the partial sum
                 *reinterpret_cast<float4*>(mine) = make_float4(acc[0], acc[1], acc[2], acc[3]);
