@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     ChainKeep k;
     chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
     const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};      // zeros in the lanes without a view and for h = 1
-    tileT_put_packed(tc, j, h, k.a6);
+    tileN_put_packed(tc, j, h, k.a6);
     if (h == 0) {
       const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
       td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     dleaky_mul(k.t6, dy6);
     bn_bwd_stats(k.z6, dy6, st);
     wave_sync();
-    accS = wgrad_short(tc, td, j, 4, h, accS);
+    accS = wgradN_T(tc, td, lane, j, 4, h, accS);
     wave_sync();
   });
-  flush_matrix(accS, dWs, D, G, true, s_red);
+  flush_matrix_nat(accS, dWs, D, G, true, s_red, false);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float v = dbsum[g];
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
         act_pack(z5, s_tab[2], h, keep, a5);
       }
-      tileT_put_packed(tb_, j, h, a5);
+      tileN_put_packed(tb_, j, h, a5);
       const float dc4[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
       {
         // dy6 = leaky'(t6) Ws^T dc with the sign the forward's activation saw (the folded product), one 16-register
@@ -615,12 +615,12 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         bn_bwd_apply(z6, dy6, s_tab[3], h, dz);
       }
       pack16(dz, keep, dzp);
-      tileT_put_packed(ta, j, h, dzp);
+      tileN_put_packed(ta, j, h, dzp);
       const f32x16 da5 = mm32_lds(s_ops, L6_W6T, lane, dzp, zero);
       layer_bwd<true, false>(z5, da5, s_tab[2], h, ok, st, dz);        // layer 5 is evaluated plain: sign of G5 z5 + B5
       store_da(DO, ok, view, h, dz);                                    // dy5
       wave_sync();
-      accW = wgrad(ta, tb_, j, h, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
+      accW = wgradN(ta, tb_, lane, accW);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
       wave_sync();
     } else if constexpr (STAGE == 5) {
       f32x16 uacc = load_u(U, ok, p.vpj, h);
@@ -640,8 +640,8 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         bn_bwd_apply(z5, dy5, s_tab[2], h, dz);
       }
       pack16(dz, keep, dzp);
-      tileT_put_packed(ta, j, h, dzp);
-      tileT_put_packed(tb_, j, h, a2);
+      tileN_put_packed(ta, j, h, dzp);
+      tileN_put_packed(tb_, j, h, a2);
       // du[p][c] = sum of dz5 over the views of point p = dz5^T . indicator: one more product on the matrix cores
       // (operands: the transposed dz5 tile and a [local point][view] indicator tile of 1.0 / 0)
       const int prv = shfl(p.vpj, lane - 1);
@@ -665,9 +665,9 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         bn_bwd_stats(z2, dy2, st);
       }
       wave_sync();
-      accW = wgrad(ta, tb_, j, h, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
+      accW = wgradN(ta, tb_, lane, accW);      // dW5a[n][k] = sum_v dz5[v][n] a2[v][k]
       const int frag = p.ti.frag;
-      const f32x16 accU = wgrad(ta, ind, j, h, zero);      // du[c][local point j] of this tile
+      const f32x16 accU = wgradN_T(ta, ind, lane, j, 32, h, zero);      // du[image column][local point j] of this tile
       if (h == 0 && ok) ind[lpj * TSB + j] = 0;           // leave the indicator tile clean for the next tile
       {
         const bool wr = j < nseg;
@@ -675,14 +675,14 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         if (frag == 0) {
           const __amdgpu_buffer_rsrc_t DU = make_rsrc(du, (uint64_t)N * 128);
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            st128(DU, wr ? pt * 128u + (8u * qq + 4u * h) * 4u : OOB,
+          for (int qq = 0; qq < 4; ++qq)      // registers 4 qq .. 4 qq + 3 = image columns -> channels cperm(chan(4 qq, h)) ..
+            st128(DU, wr ? pt * 128u + (uint32_t)(4 * (qq >> 1) + 8 * h + 16 * (qq & 1)) * 4u : OOB,
                   as_u4(accU[4 * qq], accU[4 * qq + 1], accU[4 * qq + 2], accU[4 * qq + 3]));
         } else if (wr) {
           // a point with more than 32 views: its fragments add up in the (caller-zeroed) row -- no accumulator carried
           // across the tiles (16 registers for the sake of the rare long point cost the third wavefront per SIMD)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) atomicAdd(&du[(size_t)pt * D + chan(r, h)], accU[r]);
+          for (int r = 0; r < 16; ++r) atomicAdd(&du[(size_t)pt * D + cperm(chan(r, h))], accU[r]);
         }
       }
       wave_sync();
@@ -724,8 +724,8 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         bn_bwd_apply(z2, da2t, s_tab[1], h, dz);
       }
       pack16(dz, keep, dzp);
-      tileT_put_packed(ta, j, h, dzp);
-      tileT_put_packed(tb_, j, h, a1);
+      tileN_put_packed(ta, j, h, dzp);
+      tileN_put_packed(tb_, j, h, a1);
       const f32x16 da1 = mm32_lds(s_ops, L_W2T, lane, dzp, zero);
       {
         // dy1 = leaky'(y1) da1 with the sign of the folded product (what the forward's activation saw), evaluated
@@ -736,7 +736,11 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       }
       // P = sum_v dy1 [x_hi | x_lo | 1]^T: the first-layer weight gradient AND (BatchNorm-1 backward being linear in
       // z1 = W1 x) the statistics of layer 1: S1 = P[:, 16], sum dy1 z1 = sum_f W1[:, f] (P[:, f] + P[:, 8 + f])
-      tileT_put_acc(tc, j, h, dz);
+      {
+        bf16x8 dy1p[2];
+        pack16(dz, 0xffffffffu, dy1p);
+        tileN_put_packed(tc, j, h, dy1p);
+      }
       {
         const float xs[4] = {p.x.x, p.x.y, p.x.z, p.x.w};      // features 4 h .. 4 h + 3; lanes without a view: zeros
 #pragma unroll
@@ -749,13 +753,13 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         if (h == 0) td[16 * TSB + j] = ok ? (bf16_t)0x3f80 : (bf16_t)0;
       }
       wave_sync();
-      accW = wgrad(ta, tb_, j, h, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
-      accS = wgrad_short(tc, td, j, TD_ROWS, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
+      accW = wgradN(ta, tb_, lane, accW);        // dW2[n][k] = sum_v dz2[v][n] a1[v][k]
+      accS = wgradN_T(tc, td, lane, j, TD_ROWS, h, accS);         // P[n][f] = sum_v dy1[v][n] x[v][f]
       wave_sync();
     }
   });
-  flush_matrix(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red);
-  if (STAGE == 2) flush_matrix(accS, Pm, 20, 17, false, s_red);
+  flush_matrix_nat(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red, true);
+  if (STAGE == 2) flush_matrix_nat(accS, Pm, 20, 17, false, s_red, false);
   else flush_stats<2>(st, stats, s_red);
 }
 

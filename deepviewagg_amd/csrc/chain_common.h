@@ -510,6 +510,62 @@ __device__ __forceinline__ f32x16 wgrad_short(const bf16_t* ta, const bf16_t* tb
   acc = CH_MFMA(tileT_get(ta, j, h, 1), tileT_get(tb, jb, h, 1), acc);
   return acc;
 }
+// ---- natural tiles + LDS transpose read (gfx950 ds_read_b64_tr_b16) ---------------------------------------------------
+// [view][column] bf16 tile, row stride TSB: a lane writes its packed operand (columns 16 h .. 16 h + 15 = its
+// accumulator registers in order) as two 16-byte stores instead of sixteen 2-byte ones; the MFMA operand of a k-block
+// (lane l: row / column n = 16 (g & 1) + (l & 15), views 16 m + 8 (g >> 1) .. + 7, g = l >> 4) comes back through the
+// transpose read: within a 16-lane group, lane (a, b) = 4 a + b receives element b of the 8-byte chunks addressed by the
+// lanes (0, a) .. (3, a), so the lane 4 i + a points at the four columns 4 a .. 4 a + 3 of view i of the group's four.
+// Column n of the image holds channel chan(n & 15, n >> 4) = cperm(n): outputs indexed by image columns go through it.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int cperm(int n) { return chan(n & 15, n >> 4); }
+__device__ __forceinline__ void tileN_put_packed(bf16_t* tile, int v, int h, const bf16x8 (&a)[2]) {
+  *reinterpret_cast<bf16x8*>(tile + v * TSB + 16 * h) = a[0];
+  *reinterpret_cast<bf16x8*>(tile + v * TSB + 16 * h + 8) = a[1];
+}
+__device__ __forceinline__ bf16x8 tileN_get(const bf16_t* tile, int lane, int m) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int ip = lane & 15, g = lane >> 4;
+  const bf16_t* base = tile + (16 * m + 8 * (g >> 1) + (ip >> 2)) * TSB + 16 * (g & 1) + 4 * (ip & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)base);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * TSB));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  const u32x4 v = {l2.x, l2.y, h2.x, h2.y};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// acc[r] += sum_v A[v][chan(r, h)] B[v][j] over image columns, both tiles natural
+__device__ __forceinline__ f32x16 wgradN(const bf16_t* ta, const bf16_t* tb, int lane, f32x16 acc) {
+  acc = CH_MFMA(tileN_get(ta, lane, 0), tileN_get(tb, lane, 0), acc);
+  acc = CH_MFMA(tileN_get(ta, lane, 1), tileN_get(tb, lane, 1), acc);
+  return acc;
+}
+// first tile natural, second a transposed tile ([row][view]: indicator / short tiles; rows >= jb_max share row jb_max)
+__device__ __forceinline__ f32x16 wgradN_T(const bf16_t* ta, const bf16_t* tb, int lane, int j, int jb_max, int h,
+                                           f32x16 acc) {
+  const int jb = j < jb_max ? j : jb_max;
+  acc = CH_MFMA(tileN_get(ta, lane, 0), tileT_get(tb, jb, h, 0), acc);
+  acc = CH_MFMA(tileN_get(ta, lane, 1), tileT_get(tb, jb, h, 1), acc);
+  return acc;
+}
+// flush_matrix for accumulators whose rows (and, cols_nat, columns) are image columns of natural tiles
+__device__ __forceinline__ void flush_matrix_nat(const f32x16& acc, float* __restrict__ out, int ld, int ncol,
+                                                 bool transpose, float* s_red, bool cols_nat) {
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) s_red[i] = 0.f;
+  __syncthreads();
+  if (j < ncol) {
+    const int col = cols_nat ? cperm(j) : j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(&s_red[cperm(chan(r, h)) * D + col], acc[r]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
+    const int row = i / D, col = i % D;
+    if (col < ncol) atomicAdd(&out[transpose ? col * ld + row : row * ld + col], s_red[i]);
+  }
+}
+
 // acc[r] = M[chan(r, h)][j] of every wavefront -> out[row * ld + col] (fp32 atomics), cols < ncol only
 __device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restrict__ out, int ld, int ncol,
                                              bool transpose, float* s_red) {
