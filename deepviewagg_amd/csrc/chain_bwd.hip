@@ -332,14 +332,25 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void att
     }
     wave_sync();
   });
-  if (gw) {
+  if (gw) {      // (uniform: a kernel argument)
+    // one atomic per block and address: the wavefronts' sums meet in LDS first (every block adds to the same 2 G
+    // addresses; per-wavefront atomics queue up 4 x grid deep on each of them at the end of the kernel)
+    __syncthreads();
+    float* s_wb = &s_q[0][0];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const float dw = half_sum(dwa[e]), db = half_sum(dba[e]);
       if (j == 0 && s_active && ((G == 4 ? 2 * h : 0) + e) < G) {
-        atomicAdd(&gwb[gl[e]], dw);
-        atomicAdd(&gwb[G + gl[e]], db);
+        s_wb[wv * 8 + gl[e]] = dw;
+        s_wb[wv * 8 + 4 + gl[e]] = db;
       }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * G) {
+      const int which = threadIdx.x / G, g = threadIdx.x % G;
+      float v = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_wb[w * 8 + 4 * which + g];
+      atomicAdd(&gwb[which * G + g], v);
     }
   }
 }
@@ -427,14 +438,18 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     wave_sync();
   });
   flush_matrix_nat(accS, dWs, D, G, true, s_red, false);
+  flush_stats<2>(st, stats6, s_red);
+  __syncthreads();       // dbs: one atomic per block and group (see the attention backward)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float v = dbsum[g];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
+    if (lane == 0) s_red[wv * 4 + g] = v;
   }
-  flush_stats<2>(st, stats6, s_red);
+  __syncthreads();
+  if ((int)threadIdx.x < G) atomicAdd(&dbs[threadIdx.x], (s_red[threadIdx.x] + s_red[4 + threadIdx.x]) +
+                                                           (s_red[8 + threadIdx.x] + s_red[12 + threadIdx.x]));
 }
 
 // ------------------------------------------------------------------------------------------------

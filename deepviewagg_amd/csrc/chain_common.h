@@ -547,6 +547,19 @@ __device__ __forceinline__ f32x16 wgradN_T(const bf16_t* ta, const bf16_t* tb, i
   acc = CH_MFMA(tileN_get(ta, lane, 1), tileT_get(tb, jb, h, 1), acc);
   return acc;
 }
+// The block's D x D sums in s_red ([row][col], cols < ncol) -> global fp32 atomics.  Atomic REQUESTS (one per wavefront
+// instruction and cache line touched) are served one after the other per line, ~4-9 ns each, by every block of the
+// grid at the end of the kernel: the lanes of an instruction therefore cover consecutive addresses (measured on the
+// [D][G] score-weight gradient: 8 scattered lanes per instruction = 64 requests per block = 113 us of a 254 us kernel;
+// per-wavefront scalar atomics of the attention backward: 180 us of 340).
+__device__ __forceinline__ void flush_red(float* __restrict__ out, int ld, int ncol, bool transpose,
+                                          const float* s_red) {
+  for (int i = threadIdx.x; i < ncol * D; i += blockDim.x) {
+    const int row = transpose ? i % D : i / ncol, col = transpose ? i / D : i % ncol;
+    atomicAdd(&out[transpose ? col * ld + row : row * ld + col], s_red[row * D + col]);
+  }
+}
+
 // flush_matrix for accumulators whose rows (and, cols_nat, columns) are image columns of natural tiles
 __device__ __forceinline__ void flush_matrix_nat(const f32x16& acc, float* __restrict__ out, int ld, int ncol,
                                                  bool transpose, float* s_red, bool cols_nat) {
@@ -560,10 +573,7 @@ __device__ __forceinline__ void flush_matrix_nat(const f32x16& acc, float* __res
     for (int r = 0; r < 16; ++r) atomicAdd(&s_red[cperm(chan(r, h)) * D + col], acc[r]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
-    const int row = i / D, col = i % D;
-    if (col < ncol) atomicAdd(&out[transpose ? col * ld + row : row * ld + col], s_red[i]);
-  }
+  flush_red(out, ld, ncol, transpose, s_red);
 }
 
 // acc[r] = M[chan(r, h)][j] of every wavefront -> out[row * ld + col] (fp32 atomics), cols < ncol only
@@ -578,10 +588,7 @@ __device__ __forceinline__ void flush_matrix(const f32x16& acc, float* __restric
     for (int r = 0; r < 16; ++r) atomicAdd(&s_red[chan(r, h) * D + j], acc[r]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
-    const int row = i / D, col = i % D;
-    if (col < ncol) atomicAdd(&out[transpose ? col * ld + row : row * ld + col], s_red[i]);
-  }
+  flush_red(out, ld, ncol, transpose, s_red);
 }
 
 

@@ -874,14 +874,22 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
     const float a0 = sb1[mb] + other_half(sb1[mb]), a1 = sb2[mb] + other_half(sb2[mb]);
     flush_lane_stats(a0, a1, stats_b, stats_b + CO, 32 * mb, s_red);
   }
-  if (gw) {
+  if (gw) {      // one atomic per block and address (chain_common.h flush_red)
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const float dw = half_sum(dwa[e]), db = half_sum(dba[e]);
       if (j == 0 && s_active && ((G == 4 ? 2 * h : 0) + e) < G) {
-        atomicAdd(&gwb[gl[e]], dw);
-        atomicAdd(&gwb[G + gl[e]], db);
+        s_red[wv * 8 + gl[e]] = dw;
+        s_red[wv * 8 + 4 + gl[e]] = db;
       }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * G) {
+      const int which = threadIdx.x / G, g = threadIdx.x % G;
+      float v = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_red[w * 8 + 4 * which + g];
+      atomicAdd(&gwb[which * G + g], v);
     }
   }
 }

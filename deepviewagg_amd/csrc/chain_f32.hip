@@ -485,14 +485,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wave_sync();
   });
   flush_matrix(accS, dWs, D, G, true, s_red);
+  flush_stats<2>(st, stats6, s_red);
+  __syncthreads();       // dbs: one atomic per block and group (chain_common.h flush_red)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float v = dbsum[g];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    if (lane == 0 && g < G) atomicAdd(&dbs[g], v);
+    if (lane == 0) s_red[wv * 4 + g] = v;
   }
-  flush_stats<2>(st, stats6, s_red);
+  __syncthreads();
+  if ((int)threadIdx.x < G) atomicAdd(&dbs[threadIdx.x], (s_red[threadIdx.x] + s_red[4 + threadIdx.x]) +
+                                                           (s_red[8 + threadIdx.x] + s_red[12 + threadIdx.x]));
 }
 
 // ------------------------------------------------------------------------------------------------
