@@ -424,12 +424,18 @@ __global__ __launch_bounds__(256) void dsf_bwd_score_kernel(
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) atomicAdd(&st[i], (double)s_red[i]);
   for (int i = threadIdx.x; i < G * D; i += blockDim.x) atomicAdd(&dWs[i], s_red[2 * D + i]);
-  // bias gradient: lanes n == 0 of both halves hold complete per-row sums
+  // bias gradient: lanes n == 0 of both halves hold complete per-row sums; they meet in LDS, one global atomic per
+  // block and group (atomic requests to one cache line are served one after the other)
+  __syncthreads();
+  if (threadIdx.x < GMAX) s_red[threadIdx.x] = 0.f;
+  __syncthreads();
   if (nn == 0) {
 #pragma unroll
     for (int g = 0; g < GMAX; ++g)
-      if (g < G && dbacc[g] != 0.f) atomicAdd(&dbs[g], dbacc[g]);
+      if (g < G && dbacc[g] != 0.f) atomicAdd(&s_red[g], dbacc[g]);
   }
+  __syncthreads();
+  if ((int)threadIdx.x < G && s_red[threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], s_red[threadIdx.x]);
 }
 
 // Generic layer backward.  Given dz_L (gradient w.r.t. the BN_L output), a_L, W_L and the layer input

@@ -1187,8 +1187,12 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
     if (acc_chan(r, h) < G) atomicAdd(&s_red[acc_chan(r, h) * DM + j], accW[r]);
   __syncthreads();
   for (int i = threadIdx.x; i < G * DM; i += blockDim.x) atomicAdd(&dWs[i], s_red[i]);
+  __syncthreads();       // dbs: the wavefronts' sums meet in LDS, one global atomic per block and group
+  if (threadIdx.x < 16) s_red[threadIdx.x] = 0.f;
   __syncthreads();
-  if (j < G && db != 0.f) atomicAdd(&dbs[j], db);
+  if (j < G && db != 0.f) atomicAdd(&s_red[j], db);
+  __syncthreads();
+  if ((int)threadIdx.x < G && s_red[threadIdx.x] != 0.f) atomicAdd(&dbs[threadIdx.x], s_red[threadIdx.x]);
   flush_stats<2>(stv, st, s_red, lane);
 }
 
