@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void dsm_bwd_score_kernel(
   __syncthreads();
   for (int i = threadIdx.x; i < G * DM; i += blockDim.x) atomicAdd(&dWs[i], s_red[i]);
   __syncthreads();       // dbs: the wavefronts' sums meet in LDS, one global atomic per block and group
-  if (threadIdx.x < 16) s_red[threadIdx.x] = 0.f;
+  if (threadIdx.x < DM) s_red[threadIdx.x] = 0.f;      // G <= DM
   __syncthreads();
   if (j < G && db != 0.f) atomicAdd(&s_red[j], db);
   __syncthreads();
