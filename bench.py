@@ -463,7 +463,7 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warm
     """One secondary workload of SURVEY.md 8(d) (S2: ragged view counts; F-L: C = 512, value map > MALL; bilinear:
     interpolate=True with the mapping at 8 x the map resolution): ms/step and the roofline fractions of the fused view
     kernel (forward) and of the attention backward kernel."""
-    wl = "S2" if name == "S2" else "S1"
+    wl = name if name in ("S2", "S1c") else "S1"
     N = 1 << log2_points
     scene = make_scene(N, views, 32, C, 64, 128, dtype, device, seed=4321, workload=wl, upscale=8 if interpolate else 1)
     mods = build_modules(C, device, C_out)
@@ -490,6 +490,11 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warm
                         "frac_of_hbm_peak": nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
     top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:4 if name != "f32" else 12]
     out["top_kernels_ms"] = {n: v["ms"] / v["launches"] for n, v in top}
+    if name == "S1c":
+        k = kern.get("view_gather_rows_grad")
+        out["view_gather_rows_grad_ms"] = k["ms"] / k["launches"] if k else None
+        out["note"] = ("locality probe, not a SURVEY workload: S1 with projection-like pixels (neighbouring points hit "
+                       "neighbouring pixels, as in a real scan) -- what the random-pixel S1 costs the rows gradient")
     if name == "f32":
         out["dtype"] = "f32"
         out["scores_path"] = "chain3" if any(k.startswith("chain3_") for k in kern) else "stored activations"
@@ -749,6 +754,7 @@ def main():
             res["workloads"] = {
                 "S2": secondary_workload("S2", device, dtype, args.log2_points, views, 64),
                 "F-L": secondary_workload("F-L", device, dtype, args.log2_points, views, 512),
+                "S1c": secondary_workload("S1c", device, dtype, args.log2_points, views, 64),
                 # interpolate=True (the published KITTI-360 configuration): C = 64 and the KITTI pair l0 128 -> 32
                 "bilinear_C64": secondary_workload("bilinear", device, dtype, args.log2_points, views, 64,
                                                    interpolate=True),

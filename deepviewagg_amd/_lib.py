@@ -131,11 +131,13 @@ SIGNATURES = {
     "dva_anchor_rows_sum": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dva_anchor_combine": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dva_anchor_fixup": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dva_anchor_rows_sum_bn": (ctypes.c_int, [_vp] * 8 + [_i64, _i64, _i32, _vp]),
+    "dva_anchor_fixup_bn": (ctypes.c_int, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_emod_prep": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
-    "dva_emod_stats": (ctypes.c_int, [_i32] + [_vp] * 8 + [_i64, _i64, _i32, _vp]),
-    "dva_emod_attn_fwd": (ctypes.c_int, [_vp] * 22 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
-    "dva_emod_attn_bwd": (ctypes.c_int, [_vp] * 19 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
-    "dva_emod_bwd": (ctypes.c_int, [_i32] + [_vp] * 15 + [_i64, _i64, _i64, _i32, _i32, _vp]),
+    "dva_emod_stats": (ctypes.c_int, [_i32] + [_vp] * 9 + [_i64, _i64, _i32, _vp]),
+    "dva_emod_attn_fwd": (ctypes.c_int, [_vp] * 23 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_emod_attn_bwd": (ctypes.c_int, [_vp] * 20 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_emod_bwd": (ctypes.c_int, [_i32] + [_vp] * 16 + [_i64, _i64, _i64, _i32, _i32, _vp]),
     "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_copy_ceiling": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "dva_chain_bn_consts": (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,

@@ -1147,18 +1147,39 @@ __global__ __launch_bounds__(256) void rows_sum_team_kernel(const T* __restrict_
 // S[a][k][:] = sum over the views v of anchor a of weights[v][k] * gout[v, :]  for the four taps k -- every view row
 // is read ONCE (the plan over the 4 V tap entries reads it four times and sorts four times as many keys); the map
 // gradient follows from S by dva_anchor_combine.  Deterministic, no atomics.
-template <typename T>
+// AFF (the fused bilinear path, csrc/chain_emod.hip): the rows are dy_a in the chain kernels' position order and the
+// BatchNorm_a backward dz_a = G dy_a - K1 - K2 z_a (constants as chain_emod.hip stage_tab_c builds them from bn =
+// mean | invstd | gamma | beta and sm = S1 / M | S2_hat / M, natural channel order) is applied to every row on the
+// fly from the stored z_a: the separate in-place pass over [V][C] (read 2 rows, write 1) disappears.
+__device__ __forceinline__ int position_channel(int p) {      // position 32 b + 16 h + r holds channel 32 b + chan(r, h)
+  const int r = p & 15, h = (p >> 4) & 1;
+  return (p & ~31) + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+template <typename T, bool AFF>
 __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restrict__ gout,
                                                                const int32_t* __restrict__ perm,
                                                                const int32_t* __restrict__ row_ptr,
                                                                const float4* __restrict__ weights,
-                                                               float* __restrict__ S, int64_t R, int C, int lpr) {
+                                                               float* __restrict__ S, int64_t R, int C, int lpr,
+                                                               const T* __restrict__ zrows, const float* __restrict__ bn,
+                                                               const float* __restrict__ sm) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int U = 2;
   typedef typename Vec16<T>::raw raw_t;
   const int lane = threadIdx.x & 63;
   const int lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
   const int64_t col = (int64_t)lane_r * VEC;
+  float cg[AFF ? VEC : 1], ck1[AFF ? VEC : 1], ck2[AFF ? VEC : 1];
+  if (AFF) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = position_channel((int)col + e);
+      const float mean = bn[c], inv = bn[C + c], g = bn[2 * C + c] * inv, s1 = sm[c], s2 = sm[C + c];
+      cg[e] = g;
+      ck1[e] = g * (s1 - mean * inv * s2);
+      ck2[e] = g * inv * s2;
+    }
+  }
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < R; r += n_waves) {
@@ -1172,7 +1193,7 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
     for (int i0 = beg; i0 < end; i0 += slots * U) {
       int v[U];
       bool ok[U];
-      raw_t raw[U];
+      raw_t raw[U], zraw[AFF ? U : 1];
       float4 wu[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1183,12 +1204,19 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)v[u] * C + col);
+        if (AFF) zraw[u] = *reinterpret_cast<const raw_t*>(zrows + (int64_t)v[u] * C + col);
         wu[u] = ok[u] ? weights[v[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float f[VEC];
         Vec16<T>::unpack(raw[u], f);
+        if (AFF) {
+          float zf[VEC];
+          Vec16<T>::unpack(zraw[u], zf);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) f[e] = fmaf(-ck2[e], zf[e], fmaf(cg[e], f[e], -ck1[e]));
+        }
         const float ww[4] = {wu[u].x, wu[u].y, wu[u].z, wu[u].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1431,16 +1459,34 @@ int dva_anchor_rows_sum(const void* grad_out, const int32_t* perm, const int32_t
   if (dtype == DVA_BF16) {
     const int lpr = C / 8;
     if ((C % 8) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)grad_out % 16) || ((uintptr_t)S % 16)) return DVA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
-                       (const bf16_t*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr);
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, false>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
+                       (const bf16_t*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr,
+                       (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else if (dtype == DVA_F32) {
     const int lpr = C / 4;
     if ((C % 4) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)grad_out % 16) || ((uintptr_t)S % 16)) return DVA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((anchor_rows_sum_kernel<float>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
-                       (const float*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr);
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<float, false>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
+                       (const float*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   } else {
     return DVA_ERR_INVALID;
   }
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_anchor_rows_sum_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* perm,
+                           const int32_t* row_ptr, const float* weights, float* S, int64_t n_anchors, int64_t n_views,
+                           int32_t C, void* stream) {
+  if (n_anchors < 0 || n_views < 0 || C <= 0) return DVA_ERR_INVALID;
+  if (n_anchors == 0) return DVA_OK;
+  if (!row_ptr || !S || !bn_a || !sm_a || (n_views > 0 && (!dy_a || !z_a || !perm || !weights))) return DVA_ERR_INVALID;
+  const int lpr = C / 8;
+  if ((C % 32) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)dy_a % 16) || ((uintptr_t)z_a % 16) || ((uintptr_t)S % 16))
+    return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, true>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)dy_a, perm, row_ptr, (const float4*)weights, S, n_anchors,
+                     (int)C, lpr, (const bf16_t*)z_a, bn_a, sm_a);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -8,12 +8,15 @@
 // interpolation) -- but its first Linear can: interp(x) W_a^T = interp(x W_a^T).  So Y = x W_a^T is one GEMM on the
 // R map rows (host side), and per view remains: 4 taps of Y (C_o channels, bf16) -> z_a -> BatchNorm_a -> LeakyReLU ->
 // Linear_b (C_o x C_o on the matrix cores, in registers) -> BatchNorm_b -> LeakyReLU -> value of the view, consumed
-// by the softmax-weighted sum in the same kernel.  No [V, C] tensor exists in the forward.  Train-mode BatchNorm
-// adds one statistics pass per layer, the backward one pass per BatchNorm barrier, exactly as for the DeepSetFeat
-// chain (chain_fwd.hip / chain_bwd.hip, whose kernels evaluate the scores here as there):
+// by the softmax-weighted sum in the same kernel.  Eval mode is that one kernel.  Train-mode BatchNorm adds one
+// statistics pass per layer, the backward one pass per BatchNorm barrier, exactly as for the DeepSetFeat chain
+// (chain_fwd.hip / chain_bwd.hip, whose kernels evaluate the scores here as there); the first of them keeps the
+// interpolated row z_a as bf16 [V][C_o] (the rounding of Linear_a's output under autocast) and the five later passes
+// of the step read it -- 2 C_o contiguous bytes per view instead of 4 gathered taps (8 C_o + 32 bytes): the tap gathers
+// were what bounded every pass (C_o = 64: 33.8 -> 27.4 ms/step; 128 -> 32: 22.2 -> 19.2):
 //   dva_emod_prep        weight operands of Linear_b (bf16, MFMA k-slot order)
-//   dva_emod_stats       layer 1: sum z_a | sum z_a^2;  layer 2: sum z_b | sum z_b^2
-//   dva_emod_attn_fwd    x_map + taps of Y -> pooled features (DeepSetFeat scores, softmax, E_mod, weighted sum, gate)
+//   dva_emod_stats       layer 1: taps of Y -> z_a (stored), sum z_a | sum z_a^2;  layer 2: sum z_b | sum z_b^2
+//   dva_emod_attn_fwd    x_map + z_a (eval: taps of Y) -> pooled features (DeepSetFeat scores, softmax, E_mod, weighted sum, gate)
 //   dva_emod_attn_bwd    attention + gate backward from the stored scores: score gradients, view records, S of BatchNorm_b
 //   dva_emod_bwd         stage 2: dW_b, dy_a = leaky'(y_a) W_b^T dz_b handed over as bf16 [V, C_o], S of BatchNorm_a
 //                        stage 1: dz_a in place -> the weighted scatter over the row plan (dva_gather_rows_sum) gives dY
@@ -119,6 +122,64 @@ __device__ __forceinline__ void eval_za(__amdgpu_buffer_rsrc_t Y, const TapRec& 
     load_taps<CO>(Y, t, ok, b, h, x);
     interp16(x, t.w, za[b]);
   }
+}
+// ---- stored z_a (train mode) -----------------------------------------------------------------------------------
+// The first statistics pass rounds z_a to bf16 (what the output of Linear_a is under autocast in the reference) and
+// keeps it as [V][CO] in position order; every later pass of the step reads 2 CO bytes per view, contiguous, instead
+// of 4 taps x 2 CO bytes gathered (+ the 32-byte tap record): the tap gathers were what bounded those passes
+// (statistics pass of layer 1: 17 GB in 2.6 ms at C_o = 64).  The tensor reaches 4 GiB at the headline size: one
+// descriptor per tile, as for the handed-over gradient.
+template <int NB>
+struct ZaRows {
+  u32x4 q[NB][2];
+};
+template <int CO>
+__device__ __forceinline__ ZaRows<CO / 32> load_za(const bf16_t* __restrict__ zst, const TileInfo& ti, int j, int h) {
+  const bool ok = j < ti.nv;
+  const __amdgpu_buffer_rsrc_t Z = make_rsrc(zst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
+  ZaRows<CO / 32> z;
+#pragma unroll
+  for (int b = 0; b < CO / 32; ++b) {
+    const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+    z.q[b][0] = ld128(Z, off);
+    z.q[b][1] = ld128(Z, ok ? off + 16u : OOB);
+  }
+  return z;
+}
+template <int NB>
+__device__ __forceinline__ void unpack_za(const ZaRows<NB>& z, f32x16 (&za)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t v[4] = {z.q[b][q].x, z.q[b][q].y, z.q[b][q].z, z.q[b][q].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        za[b][8 * q + 2 * i] = __uint_as_float(v[i] << 16);
+        za[b][8 * q + 2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+      }
+    }
+  }
+}
+// za <- bf16(za), stored for the later passes (lanes without a view store nothing)
+template <int CO>
+__device__ __forceinline__ void round_store_za(bf16_t* __restrict__ zst, const TileInfo& ti, int j, int h,
+                                               f32x16 (&za)[CO / 32]) {
+  const bool ok = j < ti.nv;
+  const __amdgpu_buffer_rsrc_t Z = make_rsrc(zst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
+  ZaRows<CO / 32> z;
+#pragma unroll
+  for (int b = 0; b < CO / 32; ++b) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = za[b][r];
+    z.q[b][0] = __builtin_bit_cast(u32x4, pack8(&t[0]));
+    z.q[b][1] = __builtin_bit_cast(u32x4, pack8(&t[8]));
+    const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+    st128(Z, off, z.q[b][0]);          // (non-temporal stores measured slower: 4.6 vs 4.1 ms at C_o = 64)
+    st128(Z, ok ? off + 16u : OOB, z.q[b][1]);
+  }
+  unpack_za<CO / 32>(z, za);
 }
 // Linear_b, flipped: zb[mb][r] = z_b[view_of(r, h)][channel 32 mb + (lane & 31)]
 template <int NB>
@@ -249,7 +310,7 @@ template <int CO, int L>
 __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
     const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
-    const float* __restrict__ bna, double* __restrict__ stats, int64_t V, int64_t R) {
+    const float* __restrict__ bna, double* __restrict__ stats, bf16_t* __restrict__ zst, int64_t V, int64_t R) {
   constexpr int NB = CO / 32;
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_eops[L == 2 ? NB * NB * 2 * 64 : 1];
@@ -278,21 +339,31 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
   wave_tile_range(tiles, n_tiles, ta, tb);
   struct Pre {
     TileInfo ti;
-    TapRec t;
+    TapRec t;            // L = 1
+    ZaRows<NB> z;        // L = 2: the stored z_a
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
     p.ti = ti;
-    const bool ok = j < p.ti.nv;
-    const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 16u : OOB;
-    p.t.rows = __builtin_bit_cast(int4, ld128(R4, off));
-    p.t.w = as_f4(ld128(W4, off));
+    if constexpr (L == 1) {
+      const bool ok = j < p.ti.nv;
+      const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 16u : OOB;
+      p.t.rows = __builtin_bit_cast(int4, ld128(R4, off));
+      p.t.w = as_f4(ld128(W4, off));
+    } else {
+      p.z = load_za<CO>(zst, ti, j, h);
+    }
     return p;
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
     const uint32_t keep = ok ? 0xffffffffu : 0u;
     f32x16 za[NB];
-    eval_za<CO>(Y, p.t, ok, h, za);         // lanes without a view: weights and taps read 0 -> z_a = 0
+    if constexpr (L == 1) {
+      eval_za<CO>(Y, p.t, ok, h, za);         // lanes without a view: weights and taps read 0 -> z_a = 0
+      if (zst) round_store_za<CO>(zst, p.ti, j, h, za);     // the statistics are those of the stored values
+    } else {
+      unpack_za<NB>(p.z, za);
+    }
     if constexpr (L == 1) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -332,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
 // ------------------------------------------------------------------------------------------------
 // the fused view kernel of the bilinear path
 // ------------------------------------------------------------------------------------------------
-template <int CO, int G>
+template <int CO, int G, int ZM>      // ZM = 0: z_a from the taps of Y (eval mode), 1: the stored z_a (train mode)
 __global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
@@ -341,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
     const int4* __restrict__ rows4, const float4* __restrict__ w4, const uint4* __restrict__ eops,
     const float* __restrict__ bna, const float* __restrict__ bnb, const int64_t* __restrict__ ptr,
     const float* __restrict__ gw, const float* __restrict__ gb, bf16_t* __restrict__ out,
-    float* __restrict__ scores_out, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+    float* __restrict__ scores_out, const bf16_t* __restrict__ zst, int scaling, float eps, int64_t V, int64_t N,
+    int64_t R) {
   constexpr int NB = CO / 32, NE = G == 1 ? 1 : 2, GS = CO / G;
   static_assert(GS % 8 == 0, "whole 8-lane groups");
   __shared__ __attribute__((aligned(16))) float s_tab[4][2 * D];
@@ -402,7 +474,8 @@ __global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
     TileInfo ti;
     float4 x;
     int vpj;
-    TapRec t;
+    TapRec t;            // ZM = 0
+    ZaRows<NB> z;        // ZM = 1
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
@@ -411,8 +484,12 @@ __global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
     p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
-    p.t.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
-    p.t.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    if constexpr (ZM == 0) {
+      p.t.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
+      p.t.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    } else {
+      p.z = load_za<CO>(zst, ti, j, h);
+    }
     return p;
   }, [&](const Pre& p) {
     const int nv = p.ti.nv, frag = p.ti.frag;
@@ -514,7 +591,8 @@ __global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
     f32x16 zb[NB];
     {
       f32x16 za[NB];
-      eval_za<CO>(Y, p.t, ok, h, za);
+      if constexpr (ZM == 0) eval_za<CO>(Y, p.t, ok, h, za);
+      else unpack_za<NB>(p.z, za);
       bf16x8 a[NB][2];
       act_a<NB>(za, s_taba, h, keepv, a);
       linear_b_flipped<NB>(s_eops, lane, a, zb);
@@ -588,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
     const float* __restrict__ bnb, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
     const float* __restrict__ gb, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ out,
     float* __restrict__ dc_out, uint32_t* __restrict__ rec, float* __restrict__ gwb, double* __restrict__ stats_b,
-    int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+    const bf16_t* __restrict__ zst, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
   constexpr int NB = CO / 32, NE = G == 1 ? 1 : 2, GS = CO / G;
   constexpr int GL = GS < 32 ? GS : 32;           // lanes of a group inside one block
   __shared__ __attribute__((aligned(16))) uint4 s_eops[NB * NB * 2 * 64];
@@ -603,8 +681,7 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
   for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
   __syncthreads();
   const __amdgpu_buffer_rsrc_t CP = make_rsrc(compat, (uint64_t)V * 16), P = make_rsrc(vp, (uint64_t)V * 4),
-                               Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
-                               W4 = make_rsrc(w4, (uint64_t)V * 16), GO = make_rsrc(gout, (uint64_t)N * CO * 2),
+                               GO = make_rsrc(gout, (uint64_t)N * CO * 2),
                                OU = make_rsrc(out, (uint64_t)N * CO * 2), DC = make_rsrc(dc_out, (uint64_t)V * 16),
                                RC = make_rsrc(rec, (uint64_t)V * 16);
   const bool s_active = G == 4 || h == 0;
@@ -644,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
     int t;
     u32x2 cc;
     int vpj;
-    TapRec tr;
+    ZaRows<NB> z;        // the stored z_a
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
@@ -654,8 +731,7 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
     p.cc = ld64(CP, ok ? view * 16u + coff : OOB);
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
-    p.tr.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
-    p.tr.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    p.z = load_za<CO>(zst, ti, j, h);
     return p;
   }, [&](const Pre& p) {
     const int nv = p.ti.nv, frag = p.ti.frag;
@@ -756,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
     f32x16 zb[NB];
     {
       f32x16 za[NB];
-      eval_za<CO>(Y, p.tr, ok, h, za);
+      unpack_za<NB>(p.z, za);
       bf16x8 aa[NB][2];
       act_a<NB>(za, s_taba, h, keepv, aa);
       linear_b_flipped<NB>(s_eops, lane, aa, zb);
@@ -907,7 +983,8 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ sma,
     const float* __restrict__ smb, const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout,
-    bf16_t* __restrict__ da, float* __restrict__ dWb, double* __restrict__ stats_a, int64_t V, int64_t N, int64_t R) {
+    bf16_t* __restrict__ da, float* __restrict__ dWb, double* __restrict__ stats_a, const bf16_t* __restrict__ zst,
+    int64_t V, int64_t N, int64_t R) {
   constexpr int NB = CO / 32, GS = CO / G;
   constexpr int NT = STAGE == 2 ? NB : 1;
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
@@ -926,8 +1003,7 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
 #pragma unroll
   for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, STAGE == 1 ? sma : nullptr);
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
-                               W4 = make_rsrc(w4, (uint64_t)V * 16), RC = make_rsrc(rec, (uint64_t)V * 16),
+  const __amdgpu_buffer_rsrc_t RC = make_rsrc(rec, (uint64_t)V * 16),
                                GO = make_rsrc(gout, (uint64_t)N * CO * 2);
   float st[STAGE == 2 ? NB : 1][2][16];
   f32x16 accW[STAGE == 2 ? NB : 1][STAGE == 2 ? NB : 1];
@@ -948,7 +1024,7 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
   wave_tile_range(tiles, n_tiles, ta, tb);
   struct Pre {
     TileInfo ti;
-    TapRec t;
+    ZaRows<NB> z;        // the stored z_a
     u32x4 rc;
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
@@ -956,8 +1032,7 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
     p.ti = ti;
     const bool ok = j < p.ti.nv;
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
-    p.t.rows = __builtin_bit_cast(int4, ld128(R4, ok ? view * 16u : OOB));
-    p.t.w = as_f4(ld128(W4, ok ? view * 16u : OOB));
+    p.z = load_za<CO>(zst, ti, j, h);
     if (STAGE == 2) p.rc = ld128(RC, ok ? view * 16u : OOB);
     return p;
   }, [&](const Pre& p) {
@@ -966,7 +1041,7 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
     // the handed-over gradient [V][CO] reaches 4 GiB at the headline size (V = 2^25, CO = 64): one descriptor per tile
     const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)p.ti.v0 * CO, (uint64_t)p.ti.nv * CO * 2);
     f32x16 za[NB];
-    eval_za<CO>(Y, p.t, ok, h, za);
+    unpack_za<NB>(p.z, za);
     if constexpr (STAGE == 1) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -1098,19 +1173,20 @@ int dva_emod_prep(const float* Wb, int32_t C_out, void* ops, void* stream) {
   if (n_rows * (int64_t)C_out * 2 > 0xfffffff0ll || n_views * 32 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED
 
 int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
-                   const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, int64_t n_views,
-                   int64_t n_rows, int32_t C_out, void* stream) {
+                   const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, void* z_a,
+                   int64_t n_views, int64_t n_rows, int32_t C_out, void* stream) {
   if (n_views < 0 || (layer != 1 && layer != 2) || (C_out != 32 && C_out != 64)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!Y || !tap_rows || !tap_weights || !tiles || !n_tiles || !stats || (layer == 2 && (!eops || !bn_a)))
-    return DVA_ERR_INVALID;
+  if (!tiles || !n_tiles || !stats) return DVA_ERR_INVALID;
+  if (layer == 1 && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
+  if (layer == 2 && (!eops || !bn_a || !z_a)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
-  const dim3 grid(chain_grid(2)), block(256);
+  const dim3 grid(chain_grid(2)), block(256);      // (layer 1 at 3 blocks per CU: no gain, the pass is bandwidth-bound)
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_STATS(CO_, L_)                                                                              \
   hipLaunchKernelGGL((emod_stats_kernel<CO_, L_>), grid, block, 0, s, (const bf16_t*)Y, (const int4*)tap_rows, \
                      (const float4*)tap_weights, (const int2*)tiles, n_tiles, (const uint4*)eops, bn_a, stats,  \
-                     n_views, n_rows)
+                     (bf16_t*)z_a, n_views, n_rows)
   if (C_out == 32 && layer == 1) DVA_EMOD_STATS(32, 1);
   else if (C_out == 32) DVA_EMOD_STATS(32, 2);
   else if (layer == 1) DVA_EMOD_STATS(64, 1);
@@ -1125,23 +1201,29 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
                       const float* bn6, const float* score_bias, const void* Y, const int32_t* tap_rows,
                       const float* tap_weights, const void* eops, const float* bn_a, const float* bn_b,
                       const int64_t* ptr, const float* gate_w, const float* gate_b, void* out, float* scores_out,
-                      int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling,
-                      float eps, void* stream) {
+                      const void* z_a, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G,
+                      int32_t scaling, float eps, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias || !Y ||
-      !tap_rows || !tap_weights || !eops || !bn_a || !bn_b || !ptr || !out ||
-      ((gate_w == nullptr) != (gate_b == nullptr)))
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !score_bias ||
+      !eops || !bn_a || !bn_b || !ptr || !out || ((gate_w == nullptr) != (gate_b == nullptr)))
     return DVA_ERR_INVALID;
+  if (!z_a && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * 128 > 0xfffffff0ll || n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const dim3 grid(chain_grid(2)), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define DVA_EMOD_FWD(CO_, G_)                                                                                    \
-  hipLaunchKernelGGL((emod_attn_fwd_kernel<CO_, G_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, \
-                     n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)Y,                 \
-                     (const int4*)tap_rows, (const float4*)tap_weights, (const uint4*)eops, bn_a, bn_b, ptr,       \
-                     gate_w, gate_b, (bf16_t*)out, scores_out, scaling, eps, n_views, n_points, n_rows)
+#define DVA_EMOD_FWD_Z(CO_, G_, ZM_)                                                                                  \
+  hipLaunchKernelGGL((emod_attn_fwd_kernel<CO_, G_, ZM_>), grid, block, 0, s, x_map, view_point, u,                    \
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, score_bias, (const bf16_t*)Y, \
+                     (const int4*)tap_rows, (const float4*)tap_weights, (const uint4*)eops, bn_a, bn_b, ptr,           \
+                     gate_w, gate_b, (bf16_t*)out, scores_out, (const bf16_t*)z_a, scaling, eps, n_views, n_points,    \
+                     n_rows)
+#define DVA_EMOD_FWD(CO_, G_)          \
+  do {                                 \
+    if (z_a) DVA_EMOD_FWD_Z(CO_, G_, 1); \
+    else DVA_EMOD_FWD_Z(CO_, G_, 0);     \
+  } while (0)
   switch (C_out * 8 + G) {
     case 32 * 8 + 1: DVA_EMOD_FWD(32, 1); break;
     case 32 * 8 + 2: DVA_EMOD_FWD(32, 2); break;
@@ -1152,6 +1234,7 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_EMOD_FWD
+#undef DVA_EMOD_FWD_Z
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
@@ -1160,11 +1243,11 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
                       const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* eops,
                       const float* bn_a, const float* bn_b, const int64_t* ptr, const float* gate_w,
                       const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
-                      float* grad_gate_wb, double* stats_b, int64_t n_points, int64_t n_views, int64_t n_rows,
-                      int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream) {
+                      float* grad_gate_wb, double* stats_b, const void* z_a, int64_t n_points, int64_t n_views,
+                      int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!scores || !view_point || !tiles || !n_tiles || !Y || !tap_rows || !tap_weights || !eops || !bn_a || !bn_b ||
+  if (!scores || !view_point || !tiles || !n_tiles || !z_a || !eops || !bn_a || !bn_b ||
       !ptr || !grad_out || !out || !grad_scores || !view_rec || !stats_b ||
       ((gate_w == nullptr) != (gate_b == nullptr)) || (gate_w && !grad_gate_wb))
     return DVA_ERR_INVALID;
@@ -1176,8 +1259,8 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
   hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \
                      n_tiles, (const bf16_t*)Y, (const int4*)tap_rows, (const float4*)tap_weights,                   \
                      (const uint4*)eops, bn_a, bn_b, ptr, gate_w, gate_b, (const bf16_t*)grad_out,                   \
-                     (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, stats_b, scaling, eps,       \
-                     n_views, n_points, n_rows)
+                     (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, stats_b,                     \
+                     (const bf16_t*)z_a, scaling, eps, n_views, n_points, n_rows)
   switch (C_out * 8 + G) {
     case 32 * 8 + 1: DVA_EMOD_BWD(32, 1); break;
     case 32 * 8 + 2: DVA_EMOD_BWD(32, 2); break;
@@ -1195,11 +1278,12 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
 int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
                  const int32_t* n_tiles, const void* eops, const float* bn_a, const float* bn_b, const float* sm_a,
                  const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,
-                 int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, void* stream) {
+                 const void* z_a, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G,
+                 void* stream) {
   if (n_views < 0 || (stage != 1 && stage != 2) || (C_out != 32 && C_out != 64) || (G != 1 && G != 2 && G != 4))
     return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!Y || !tap_rows || !tap_weights || !tiles || !n_tiles || !bn_a || !da) return DVA_ERR_INVALID;
+  if (!z_a || !tiles || !n_tiles || !bn_a || !da) return DVA_ERR_INVALID;
   if (stage == 2 && (!eops || !bn_b || !sm_b || !view_rec || !grad_out || !dWb || !stats_a)) return DVA_ERR_INVALID;
   if (stage == 1 && !sm_a) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
@@ -1210,7 +1294,8 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
   hipLaunchKernelGGL((emod_bwd_kernel<CO_, G_, ST_>), dim3(chain_grid((ST_ == 2 && CO_ > 32) ? 1 : 2)), block, 0, s, \
                      (const bf16_t*)Y, (const int4*)tap_rows, (const float4*)tap_weights, (const int2*)tiles,         \
                      n_tiles, (const uint4*)eops, bn_a, bn_b, sm_a, sm_b, (const uint32_t*)view_rec,                   \
-                     (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, n_views, n_points, n_rows)
+                     (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points,       \
+                     n_rows)
   if (stage == 1) {
     if (C_out == 32) DVA_EMOD_L(32, 1, 1);
     else DVA_EMOD_L(64, 1, 1);

@@ -252,17 +252,28 @@ __global__ __launch_bounds__(256) void anchor_combine_kernel(const float* __rest
 
 // views without the 2 x 2 structure (dummy anchor): their four taps, one by one (fp32 atomics: there are none on real
 // data, see bilinear_taps)
+// z != nullptr: the rows are dy_a in position order and get the BatchNorm_a backward of dva_anchor_rows_sum_bn first
 template <typename T>
 __global__ __launch_bounds__(256) void anchor_fixup_kernel(const T* __restrict__ grad, const int32_t* __restrict__ rows,
                                                             const float* __restrict__ weights,
                                                             const int32_t* __restrict__ anchors, int32_t dummy,
-                                                            float* __restrict__ dY, int64_t n_atoms, int C) {
+                                                            float* __restrict__ dY, int64_t n_atoms, int C,
+                                                            const T* __restrict__ z, const float* __restrict__ bn,
+                                                            const float* __restrict__ sm) {
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_atoms; p += (int64_t)gridDim.x * blockDim.x) {
     if (anchors[p] != dummy) continue;
     for (int k = 0; k < 4; ++k) {
       const float w = weights[4 * p + k];
       const int64_t r = rows[4 * p + k];
-      for (int c = 0; c < C; ++c) atomicAdd(&dY[r * C + c], w * Elt<T>::ld(grad, p * C + c));
+      for (int c = 0; c < C; ++c) {
+        float g = Elt<T>::ld(grad, p * C + c);
+        if (z) {
+          const int rr = c & 15, hh = (c >> 4) & 1, ch = (c & ~31) + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+          const float mean = bn[ch], inv = bn[C + ch], gg = bn[2 * C + ch] * inv, s1 = sm[ch], s2 = sm[C + ch];
+          g = fmaf(-(gg * inv * s2), Elt<T>::ld(z, p * C + c), fmaf(gg, g, -(gg * (s1 - mean * inv * s2))));
+        }
+        atomicAdd(&dY[r * C + c], w * g);
+      }
     }
   }
 }
@@ -484,10 +495,26 @@ int dva_anchor_fixup(const void* grad, const int32_t* rows, const float* weights
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DVA_F32)
     hipLaunchKernelGGL((anchor_fixup_kernel<float>), dim3(grid_for(n_atoms)), dim3(256), 0, s, (const float*)grad, rows,
-                       weights, anchors, dummy, grad_rows, n_atoms, (int)C);
+                       weights, anchors, dummy, grad_rows, n_atoms, (int)C, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr);
   else
     hipLaunchKernelGGL((anchor_fixup_kernel<bf16_t>), dim3(grid_for(n_atoms)), dim3(256), 0, s, (const bf16_t*)grad,
-                       rows, weights, anchors, dummy, grad_rows, n_atoms, (int)C);
+                       rows, weights, anchors, dummy, grad_rows, n_atoms, (int)C, (const bf16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_anchor_fixup_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* rows,
+                        const float* weights, const int32_t* anchors, float* grad_rows, int64_t n_atoms, int32_t B,
+                        int32_t H, int32_t W, int32_t C, void* stream) {
+  if (n_atoms < 0 || C <= 0 || (C % 32)) return DVA_ERR_INVALID;
+  if (n_atoms == 0) return DVA_OK;
+  if (!dy_a || !z_a || !bn_a || !sm_a || !rows || !weights || !anchors || !grad_rows) return DVA_ERR_INVALID;
+  const int32_t dummy = (int32_t)((int64_t)B * (H + 1) * (W + 1));
+  hipLaunchKernelGGL((anchor_fixup_kernel<bf16_t>), dim3(grid_for(n_atoms)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy_a, rows, weights, anchors, dummy, grad_rows, n_atoms, (int)C, (const bf16_t*)z_a,
+                     bn_a, sm_a);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -7,7 +7,9 @@ an exact mapping) -> ``GroupBimodalCSRPool.forward`` (modules/multimodal/pooling
 out_mod, out_mod]) on the V rows, DeepSetFeat scores, softmax over the views of a point, weighted sum, gate.
 Here: the first Linear of E_mod commutes with the interpolation and runs as ONE GEMM on the R map rows
 (``Y = rows W_a^T``); BatchNorm_a, LeakyReLU, Linear_b (on the matrix cores), BatchNorm_b, LeakyReLU are evaluated per
-view from the four taps of Y inside every pass that needs the values; no [V, C] tensor exists in the forward.
+view inside every pass that needs the values.  Eval mode is one kernel on the four taps of Y.  In train mode the first
+statistics pass keeps the interpolated row ``z_a`` as bf16 [V, C_out] (the rounding Linear_a's output has under
+autocast) and the later passes read it instead of gathering the taps again (the gathers bounded every pass).
 Train-mode BatchNorm of E_mod adds two statistics passes; the backward hands ONE bf16 [V, C_out] gradient (dy_a -> dz_a
 in place) to the weighted segmented reduction over the row plan of the taps (``dva_gather_rows_sum``: deterministic,
 no atomics; views grouped by the anchor of their 2 x 2 tap block), which yields the gradient of Y; Linear_a's backward is autograd on the map rows.
@@ -92,28 +94,36 @@ class _EmodPool(torch.autograd.Function):
         eops = torch.empty(2 * (C // 32) ** 2 * 2 * 1024, dtype=torch.uint8, device=dev)
         check(lib.dva_emod_prep(ptr(Wb.detach().float().contiguous()), C, ptr(eops), st), "dva_emod_prep")
         tap_bytes = V * (4 * C * 2 + 32)
+        # train mode: z_a (the interpolated Linear_a output, rounded to bf16 like the layer's output under autocast) is
+        # written once by the first statistics pass; every later pass of the step reads these 2 C bytes per view instead
+        # of gathering 4 taps x 2 C bytes again.  Eval mode is one kernel and evaluates the taps itself.
+        za = torch.empty((V, C), dtype=torch.bfloat16, device=dev) if training else None
+        za_bytes = V * C * 2
 
         def stats(layer, tab_a):
             s = torch.zeros(2 * C, dtype=torch.float64, device=dev)
             if training:
-                with ops._timed(f"emod_stats{layer}", tap_bytes):
+                with ops._timed(f"emod_stats{layer}", tap_bytes + za_bytes if layer == 1 else za_bytes):
                     check(lib.dva_emod_stats(layer, ptr(Y), ptr(rows4), ptr(w4), ptr(S.tiles), ptr(S.n_tiles), ptr(eops),
-                                             ptr(tab_a), ptr(s), V, R, C, st), "dva_emod_stats")
+                                             ptr(tab_a), ptr(s), ptr(za), V, R, C, st), "dva_emod_stats")
             return s
         tab_a = ops.bn_table(stats(1, None), float(max(V, 1)), bn_a, training)
         tab_b = ops.bn_table(stats(2, tab_a), float(max(V, 1)), bn_b, training)
         out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
         need_bwd = any(ctx.needs_input_grad)
         scores = torch.empty((V, 4), dtype=torch.float32, device=dev) if need_bwd else None
-        # per view: 4 taps of Y (C s each) + tap record 32 + x_map 32 + view -> point index 4 (+ scores 16 out in training)
-        with ops._timed("emod_attn_fwd", tap_bytes + V * (32 + 4 + (16 if need_bwd else 0)) + N * (C * 2 + 128 + 8)):
+        # per view: z_a (train) or 4 taps of Y (C s each) + tap record 32 (eval), x_map 32, view -> point index 4
+        # (+ scores 16 out in training)
+        with ops._timed("emod_attn_fwd", (za_bytes if training else tap_bytes)
+                        + V * (32 + 4 + (16 if need_bwd else 0)) + N * (C * 2 + 128 + 8)):
             check(lib.dva_emod_attn_fwd(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
                                         ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), ptr(Y), ptr(rows4),
                                         ptr(w4), ptr(eops), ptr(tab_a), ptr(tab_b), ptr(csr_idx), ptr(S.gw), ptr(S.gb),
-                                        ptr(out), ptr(scores), N, V, R, C, G, int(scaling), float(eps), st),
+                                        ptr(out), ptr(scores), ptr(za), N, V, R, C, G, int(scaling), float(eps), st),
                   "dva_emod_attn_fwd")
         ctx.save_for_backward(Y, rows4, w4, x_map, csr_idx, S.vp, S.tiles, S.n_tiles, S.wops, S.t_add, S.zstar, S.arg,
-                              S.mom, S.bn1, S.bn2, S.bn5, S.bn6, out, scores, S.bs, S.gw, S.gb, S.W1, eops, tab_a, tab_b)
+                              S.mom, S.bn1, S.bn2, S.bn5, S.bn6, out, scores, S.bs, S.gw, S.gb, S.W1, eops, tab_a, tab_b,
+                              za)
         ctx.module = module
         ctx.set_saved = S.set_saved
         ctx.training = training
@@ -129,7 +139,7 @@ class _EmodPool(torch.autograd.Function):
             raise RuntimeError("the recompute chain's backward ran twice on the same graph (retain_graph is not "
                                "supported on this path)")
         (Y, rows4, w4, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, out,
-         scores, bs, gw, gb, W1, eops, tab_a, tab_b) = ctx.saved_tensors
+         scores, bs, gw, gb, W1, eops, tab_a, tab_b, za) = ctx.saved_tensors
         module, training = ctx.module, ctx.training
         scaling, eps = ctx.meta
         gate = module.G
@@ -142,7 +152,12 @@ class _EmodPool(torch.autograd.Function):
         S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
                             bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G, training=training)
         arena = Arena(dev)
-        tap_bytes = V * (4 * C * 2 + 32)
+        za_bytes = V * C * 2
+        if za is None:      # forward ran in eval mode: the backward passes read the stored z_a, build it now
+            za = torch.empty((V, C), dtype=torch.bfloat16, device=dev)
+            scratch = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            check(lib.dva_emod_stats(1, ptr(Y), ptr(rows4), ptr(w4), ptr(tiles), ptr(n_tiles), None, None, ptr(scratch),
+                                     ptr(za), V, R, C, st), "dva_emod_stats")
 
         def consts(stats, tab):
             sm, dg, db = arena.take(2 * C), arena.take(C), arena.take(C)
@@ -154,32 +169,30 @@ class _EmodPool(torch.autograd.Function):
         rec = torch.empty((V, 4), dtype=torch.int32, device=dev)
         gwb = arena.take(2 * G) if gate is not None else None
         stats_b = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-        with ops._timed("emod_attn_bwd", tap_bytes + V * (16 + 4 + 16 + 16) + N * (C * 2 + 8)):
-            check(lib.dva_emod_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(Y), ptr(rows4), ptr(w4),
+        with ops._timed("emod_attn_bwd", za_bytes + V * (16 + 4 + 16 + 16) + N * (C * 2 + 8)):
+            check(lib.dva_emod_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), None, None, None,
                                         ptr(eops), ptr(tab_a), ptr(tab_b), ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout),
-                                        ptr(out), ptr(dc), ptr(rec), ptr(gwb), ptr(stats_b), N, V, R, C, G, scaling, eps,
-                                        st), "dva_emod_attn_bwd")
+                                        ptr(out), ptr(dc), ptr(rec), ptr(gwb), ptr(stats_b), ptr(za), N, V, R, C, G,
+                                        scaling, eps, st), "dva_emod_attn_bwd")
         del scores
         sm_b, dg_b, db_b = consts(stats_b, tab_b)
         # ---- E_mod backward: dW_b, dy_a handed over as bf16 [V, C], S of BatchNorm_a; then dz_a in place
         da = torch.empty((V, C), dtype=torch.bfloat16, device=dev)
         dWb = arena.take(C, C)
         stats_a = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-        with ops._timed("emod_bwd_b", tap_bytes + V * (16 + C * 2) + N * C * 2):
-            check(lib.dva_emod_bwd(2, ptr(Y), ptr(rows4), ptr(w4), ptr(tiles), ptr(n_tiles), ptr(eops), ptr(tab_a),
+        with ops._timed("emod_bwd_b", za_bytes + V * (16 + C * 2) + N * C * 2):
+            check(lib.dva_emod_bwd(2, None, None, None, ptr(tiles), ptr(n_tiles), ptr(eops), ptr(tab_a),
                                    ptr(tab_b), None, ptr(sm_b), ptr(rec), ptr(gout), ptr(da), ptr(dWb), ptr(stats_a),
-                                   N, V, R, C, G, st), "dva_emod_bwd")
+                                   ptr(za), N, V, R, C, G, st), "dva_emod_bwd")
         del rec
         sm_a, dg_a, db_a = consts(stats_a, tab_a)
-        with ops._timed("emod_bwd_a", tap_bytes + V * 2 * C * 2):
-            check(lib.dva_emod_bwd(1, ptr(Y), ptr(rows4), ptr(w4), ptr(tiles), ptr(n_tiles), None, ptr(tab_a), None,
-                                   ptr(sm_a), None, None, None, ptr(da), None, None, N, V, R, C, G, st), "dva_emod_bwd")
-        # ---- gradient of Y: the transpose of the interpolation applied to dz_a (views grouped by the anchor of their
-        #      2 x 2 tap block: every dz_a row read once, deterministic; ops.bilinear_scatter)
+        # ---- gradient of Y: the transpose of the interpolation applied to dz_a = BatchNorm_a backward of dy_a (views
+        #      grouped by the anchor of their 2 x 2 tap block: every row read once, deterministic; the BatchNorm
+        #      backward is applied to the rows as they are read: no in-place pass over [V, C])
         dY = None
         if ctx.needs_input_grad[0]:
-            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw).to(Y.dtype)
-        del da
+            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw, bn_backward=(za, tab_a, sm_a)).to(Y.dtype)
+        del da, za
         grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
         ctx.set_saved = None
         return (dY, None, None, None, None, None, None, None, None, None, dg_a, db_a, dWb, dg_b, db_b) + tuple(grads)

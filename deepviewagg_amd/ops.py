@@ -402,11 +402,13 @@ def _anchor_ok(C, dtype):
     return C % vec == 0 and lpr > 0 and (lpr & (lpr - 1)) == 0 and lpr <= 64
 
 
-def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W):
+def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=None):
     """Transpose of the bilinear gather: fp32 [B*H*W, C] = sum over the views and their 4 taps of weight x grad row.
     Views are grouped by ANCHOR (the padded cell of their top-left tap, ``dva_gather_bilinear_taps_anchor``): one
     sort of P keys, every gradient row read once into four per-anchor sums, then a 2 x 2 stencil on the map
-    (csrc/attention.hip anchor_rows_sum_kernel, csrc/gather.hip anchor_combine_kernel).  Deterministic."""
+    (csrc/attention.hip anchor_rows_sum_kernel, csrc/gather.hip anchor_combine_kernel).  Deterministic.
+    ``bn_backward = (z_a, bn_a, sm_a)`` (fused bilinear path): ``grad`` is dy_a (bf16, position order) and every row
+    gets the BatchNorm_a backward ``G dy_a - K1 - K2 z_a`` on the fly instead of in a pass of its own."""
     lib = _lib.load()
     grad = grad.contiguous()
     P, C = grad.shape
@@ -414,14 +416,28 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W):
     (perm, row_ptr), _ = row_plan(anchors, n_anchor, with_counts=False)
     S = torch.empty((n_anchor, 4, C), dtype=torch.float32, device=grad.device)
     st = stream_of(grad)
-    with _timed("bilinear_anchor_sum", P * (C * grad.element_size() + 20) + n_anchor * 4 * C * 4):
-        check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(row_ptr), ptr(tap_weights), ptr(S), n_anchor, P, C,
-                                      dtype_code(grad), st), "dva_anchor_rows_sum")
+    es = grad.element_size()
+    if bn_backward is not None:
+        z_a, bn_a, sm_a = bn_backward
+        if grad.dtype != torch.bfloat16 or z_a.dtype != torch.bfloat16 or z_a.shape != grad.shape or C % 32:
+            raise _lib.DvaError("bilinear_scatter(bn_backward): bf16 [V, C] rows, C a multiple of 32", -1)
+        z_a = z_a.contiguous()
+    with _timed("bilinear_anchor_sum", P * (C * es * (2 if bn_backward is not None else 1) + 20) + n_anchor * 4 * C * 4):
+        if bn_backward is None:
+            check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(row_ptr), ptr(tap_weights), ptr(S), n_anchor, P, C,
+                                          dtype_code(grad), st), "dva_anchor_rows_sum")
+        else:
+            check(lib.dva_anchor_rows_sum_bn(ptr(grad), ptr(z_a), ptr(bn_a), ptr(sm_a), ptr(perm), ptr(row_ptr),
+                                             ptr(tap_weights), ptr(S), n_anchor, P, C, st), "dva_anchor_rows_sum_bn")
     out = torch.empty((B * H * W, C), dtype=torch.float32, device=grad.device)
     with _timed("bilinear_anchor_combine", n_anchor * 4 * C * 4 + B * H * W * C * 4):
         check(lib.dva_anchor_combine(ptr(S), ptr(out), B, H, W, C, st), "dva_anchor_combine")
-        check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, B, H, W, C,
-                                   dtype_code(grad), st), "dva_anchor_fixup")
+        if bn_backward is None:
+            check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, B, H, W, C,
+                                       dtype_code(grad), st), "dva_anchor_fixup")
+        else:
+            check(lib.dva_anchor_fixup_bn(ptr(grad), ptr(z_a), ptr(bn_a), ptr(sm_a), ptr(tap_rows), ptr(tap_weights),
+                                          ptr(anchors), ptr(out), P, B, H, W, C, st), "dva_anchor_fixup_bn")
     return out
 
 

@@ -230,6 +230,16 @@ int dva_anchor_combine(const float* S, float* grad_rows, int32_t B, int32_t H, i
 int dva_anchor_fixup(const void* grad, const int32_t* rows, const float* weights, const int32_t* anchors,
                      float* grad_rows, int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
                      void* stream);
+/* The same two steps for the fused bilinear path (csrc/chain_emod.hip): the rows are dy_a bf16 [V][C] in position order
+ * and the BatchNorm_a backward dz_a = G dy_a - K1 - K2 z_a (bn_a fp32 [4][C] = mean | invstd | gamma | beta,
+ * sm_a fp32 [2][C] = S1 / M | S2_hat / M of dva_bn_bwd_consts, natural channel order; z_a bf16 [V][C]) is applied to
+ * every row on the fly, replacing the in-place pass dva_emod_bwd(stage 1).  C a multiple of 32. */
+int dva_anchor_rows_sum_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* perm,
+                           const int32_t* row_ptr, const float* weights, float* S, int64_t n_anchors, int64_t n_views,
+                           int32_t C, void* stream);
+int dva_anchor_fixup_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* rows,
+                        const float* weights, const int32_t* anchors, float* grad_rows, int64_t n_atoms, int32_t B,
+                        int32_t H, int32_t W, int32_t C, void* stream);
 /* rows int32 [4 * n_atoms], weights fp32 [4 * n_atoms]: corner rows (tl, tr, bl, br) of the [B*H*W, C] map and
  * bilinear weights of every atom, exactly the taps of dva_gather_bilinear_fwd (image.py:138-165). */
 int dva_gather_bilinear_taps(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
@@ -437,31 +447,36 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
  * C_out in {32, 64}, G in {1, 2, 4}.  bn_a / bn_b fp32 [4][C_out] = mean | invstd | gamma | beta (dva_bn_finalize),
  * natural channel order; statistics fp64 [2][C_out] caller-zeroed; tiles / view_point / scores / chain arguments as
  * for the dva_chain_* entries.
+ * z_a bf16 [V][C_out] (position order): the interpolated Linear_a output of every view, rounded to bf16 (what the
+ * layer's output is under autocast in the reference).  Train mode: written by dva_emod_stats(layer 1), read by every
+ * later pass of the step instead of the four taps of Y (those passes ignore Y / tap_rows / tap_weights, which may be
+ * NULL).  Eval mode: dva_emod_attn_fwd with z_a = NULL evaluates the taps itself.
  * ------------------------------------------------------------------------------------------ */
 /* eops: 2 * (C_out / 32)^2 * 2 KiB: Linear_b's weight W_b fp32 [C_out][C_out] as bf16 matrix-core operands
  * (forward blocks, then the transposed blocks of the input gradient). */
 int dva_emod_prep(const float* Wb, int32_t C_out, void* eops, void* stream);
-/* layer 1: stats += sum z_a | sum z_a^2 (eops, bn_a unused);  layer 2: stats += sum z_b | sum z_b^2. */
+/* layer 1: z_a (out, nullable) <- bf16(taps of Y), stats += sum z_a | sum z_a^2 of the stored values (eops, bn_a
+ * unused);  layer 2: stats += sum z_b | sum z_b^2 from z_a (in). */
 int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
-                   const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, int64_t n_views,
-                   int64_t n_rows, int32_t C_out, void* stream);
-/* The fused view kernel: x_map + taps of Y -> out bf16 [N][C_out] (caller-zeroed) = gate * sum_v softmax_v(scores)
- * E_mod(view v); scores_out as dva_chain_attn_fwd. */
+                   const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, void* z_a,
+                   int64_t n_views, int64_t n_rows, int32_t C_out, void* stream);
+/* The fused view kernel: x_map + z_a (or, z_a = NULL, the taps of Y) -> out bf16 [N][C_out] (caller-zeroed) =
+ * gate * sum_v softmax_v(scores) E_mod(view v); scores_out as dva_chain_attn_fwd. */
 int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
                       const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
                       const float* bn6, const float* score_bias, const void* Y, const int32_t* tap_rows,
                       const float* tap_weights, const void* eops, const float* bn_a, const float* bn_b,
                       const int64_t* ptr, const float* gate_w, const float* gate_b, void* out, float* scores_out,
-                      int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling,
-                      float eps, void* stream);
+                      const void* z_a, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G,
+                      int32_t scaling, float eps, void* stream);
 /* Attention + gate backward from the stored scores with E_mod re-evaluated: grad_scores, view_rec, grad_gate_wb as
  * dva_chain_attn_bwd; stats_b += S1 | sum dy_b z_b of the BatchNorm_b backward. */
 int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
                       const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* eops,
                       const float* bn_a, const float* bn_b, const int64_t* ptr, const float* gate_w,
                       const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
-                      float* grad_gate_wb, double* stats_b, int64_t n_points, int64_t n_views, int64_t n_rows,
-                      int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream);
+                      float* grad_gate_wb, double* stats_b, const void* z_a, int64_t n_points, int64_t n_views,
+                      int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream);
 /* E_mod backward.  stage 2: view_rec + grad_out -> dWb fp32 [C_out][C_out] (caller-zeroed) += the gradient of W_b,
  * da bf16 [V][C_out] (position order) = leaky'(y_a) W_b^T dz_b, stats_a += S1 | sum dy_a z_a  (sm_b = S / M of
  * BatchNorm_b).  stage 1: da <- dz_a = BatchNorm_a backward of da in place (sm_a); the gradient of Y follows as
@@ -469,7 +484,8 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
 int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
                  const int32_t* n_tiles, const void* eops, const float* bn_a, const float* bn_b, const float* sm_a,
                  const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,
-                 int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G, void* stream);
+                 const void* z_a, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G,
+                 void* stream);
 
 /* The arithmetic between two BatchNorm-backward passes as one launch.  stats fp64 [2C] = S1 | S2, bn fp32 [4][C] =
  * mean | invstd | gamma | beta.  do_hat: S2 arrives as sum dy z (raw layer output) and becomes

@@ -8,8 +8,8 @@ txt = open(sys.argv[1]).read()
 for m in re.finditer(r'\n(_ZN3dva\S+):', txt):
     name = m.group(1)
     tail = txt[m.end():]
-    meta = tail[tail.index('.Lfunc_end'):][:2500]
-    get = lambda k: re.search(r'; %s: (\d+)' % k, meta).group(1)
+    meta = tail[tail.index('.Lfunc_end'):][:6000]
+    get = lambda k: (re.search(r'; %s: (\d+)' % k, meta) or re.search(r'(\?)', '?')).group(1)
     try:
         dn = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.split('(')[0]
     except FileNotFoundError:
