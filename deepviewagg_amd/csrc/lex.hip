@@ -100,6 +100,13 @@ typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_con
                                                                        rocprim::block_radix_rank_algorithm::match>>
     PlanSort9;
 static inline bool plan_wide_digits(int bits) { return bits == 17 || bits == 18; }
+// 19 / 20 bits (the anchor plan of the bilinear backward: 32 x 65 x 129 padded cells): two passes of 10 bits
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
+                                                                       rocprim::kernel_config<1024, 8>, 10,
+                                                                       rocprim::block_radix_rank_algorithm::match>>
+    PlanSort10;
+static inline bool plan_wider_digits(int bits) { return bits == 19 || bits == 20; }
 
 // values in = the view numbers 0 .. n-1 as a counting iterator (no iota array is written or read)
 static hipError_t plan_sort(void* temp, size_t& tmp, const uint32_t* kin, uint32_t* kout, int32_t* vout, size_t n,
@@ -107,6 +114,8 @@ static hipError_t plan_sort(void* temp, size_t& tmp, const uint32_t* kin, uint32
   rocprim::counting_iterator<int32_t> vin(0);
   if (plan_wide_digits(bits))
     return rocprim::radix_sort_pairs<PlanSort9>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
+  if (plan_wider_digits(bits))
+    return rocprim::radix_sort_pairs<PlanSort10>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
   return rocprim::radix_sort_pairs(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
 }
 

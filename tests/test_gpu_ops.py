@@ -267,9 +267,11 @@ def test_gather_random_vs_oracle(dtype, C):
 # row plan (views grouped by feature-map row) and the rows gradient as a segmented reduction
 # ---------------------------------------------------------------------------------------------
 
-# the last two: above the library's merge-sort limit with 17- / 18-bit row keys (the two-pass 9-bit onesweep instance)
+# above the library's merge-sort limit: 17- / 18-bit row keys take the two-pass 9-bit onesweep instance, 19- / 20-bit
+# keys (the anchor plan of the bilinear backward: 32 x 65 x 129 padded cells + 1) the two-pass 10-bit one
 @pytest.mark.parametrize("V,R", [(0, 5), (1, 1), (1000, 7), (50000, 4096), (300000, 1 << 18),
-                                 (1500000, (1 << 16) + 9), (3000000, (1 << 18) - 3)])
+                                 (1500000, (1 << 16) + 9), (3000000, (1 << 18) - 3),
+                                 (3000000, 32 * 65 * 129 + 1), (2500000, (1 << 20) - 5), (2000000, (1 << 20) + 7)])
 def test_row_plan_is_a_stable_sort(V, R):
     from deepviewagg_amd import ops
     gen = torch.Generator().manual_seed(V + R)
