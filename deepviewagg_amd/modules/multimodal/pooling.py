@@ -74,7 +74,7 @@ def batchnorm_act_rows(y, bn, slope, counts=None, n=None):
                          mean, invstd, n, batch_stats, slope)
 
 
-def mlp_on_gathered_rows(mlp, rows, counts, n_views=None):
+def mlp_on_gathered_rows(mlp, rows, counts, n_views=None, first_linear_done=False):
     """Evaluate ``mlp(rows[row_idx])`` WITHOUT gathering: returns ``out_rows`` such that
     ``out_rows[row_idx] == mlp(rows[row_idx])`` row for row.
 
@@ -84,15 +84,18 @@ def mlp_on_gathered_rows(mlp, rows, counts, n_views=None):
     gather each row).  P/R is ~128 on the headline workload, so the dense layers cost 1/128 of the
     per-view evaluation of the reference (pooling.py:245,275) and no [P, C] tensor is materialised.
     Backward is plain autograd over the [R, C] tensors.
+    ``first_linear_done``: ``rows`` already are the output of the first block's Linear (hoisted by the caller).
     """
     x = rows
     n = None
-    for block in mlp:
+    for i, block in enumerate(mlp):
         lin, bn, act = block[0], block[1].batch_norm, block[2]
         slope = _leaky_slope(act)
         if slope is None or x.dtype not in (torch.float32, torch.bfloat16):
+            if first_linear_done:
+                raise NotImplementedError("hoisted first Linear with an activation the row kernels do not cover")
             return _mlp_on_gathered_rows_torch(mlp, rows, counts)
-        y = ops.tall_linear(x, lin.weight, lin.bias)
+        y = x if (first_linear_done and i == 0) else ops.tall_linear(x, lin.weight, lin.bias)
         if n is None and (bn.training or not bn.track_running_stats):
             # number of gathered rows (views); callers pass it to avoid a device synchronisation
             n = float(n_views if n_views is not None else (counts.sum() if counts is not None else x.shape[0]))
@@ -106,6 +109,23 @@ def _mlp_rows(mlp, x):
     if x.is_cuda and x.dim() == 2 and x.shape[0] > 0:
         return mlp_on_gathered_rows(mlp, x, None, x.shape[0])
     return mlp(x)
+
+
+def _hoisted_first_linear(mlp, x_mod):
+    """E_mod on a lazily BILINEAR-gathered feature map outside the fused path (C_out > 64, fp32 maps, ...): the first
+    Linear (no bias) commutes with the interpolation, so it runs on the R map rows and the gather carries C_out
+    channels instead of C_in -- the per-view GEMM V x C_in x C_out of the reference (pooling.py:245,275 on the output
+    of image.py:105-170) and the [V, C_in] tensor disappear (KITTI-360 pyramid: 256 -> 128, 512 -> 256).  Returns
+    (E_mod(x_mod) as a [V, C_out] tensor, True), or (the materialised [V, C_in] gather, False) when it does not apply."""
+    lin, bn, act = mlp[0][0], mlp[0][1].batch_norm, mlp[0][2]
+    rows = x_mod.rows
+    ok = (x_mod.exact and lin.bias is None and rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16)
+          and all(_leaky_slope(b[2]) is not None for b in mlp))
+    if not ok:
+        return x_mod.materialize(), False
+    y_rows = ops.tall_linear(rows, lin.weight)                 # [R, C_out]
+    z_a = x_mod.materialize(rows=y_rows)                        # [V, C_out]: interp(x) W^T = interp(x W^T)
+    return mlp_on_gathered_rows(mlp, z_a, None, z_a.shape[0], first_linear_done=True), True
 
 
 def _leaky_slope(act):
@@ -316,12 +336,13 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
     def forward(self, x_main, x_mod, x_map, csr_idx):
         """x_main [N, F_main] (unused), x_mod [V, F_mod], x_map [V, F_map], csr_idx [N+1] -> [N, out_mod]."""
         val_rows = None
+        emod_done = False
         if isinstance(x_mod, ops.InterpolatedFeatures):
             # bilinear gather (interpolate=True): E_mod per view inside the chain kernels, its first Linear on the map
             # rows (fused_bilinear.py); anything the fused path does not cover materialises the reference's [V, C]
             if fused_bilinear.applicable(self, x_mod, x_map, csr_idx):
                 return fused_bilinear.pool(self, x_mod, x_map, csr_idx)
-            x_mod = x_mod.materialize()
+            x_mod, emod_done = _hoisted_first_linear(self.E_mod, x_mod)
         if isinstance(x_mod, ops.GatheredFeatures) and fused_chain.applicable(self, x_mod, x_map, csr_idx):
             # bf16 recompute chain: E_mod on the map rows, then ONE view kernel (DeepSetFeat scores, softmax,
             # row gather, weighted sum, gate) -- no [V, .] activation tensor at all (fused_chain.py)
@@ -348,7 +369,8 @@ class GroupBimodalCSRPool(nn.Module, _SaveLast):
                 compatibilities = self.E_score(x_map)
             x_mod = x_mod.with_rows(val_rows)
         else:
-            x_mod = _mlp_rows(self.E_mod, _materialize(x_mod))
+            if not emod_done:
+                x_mod = _mlp_rows(self.E_mod, _materialize(x_mod))
             if self.use_mod:
                 compatibilities = self.E_score(self.E_mix(torch.cat([x_map, x_mod.to(x_map.dtype)], dim=1)))
             elif not fused_scores:

@@ -678,8 +678,13 @@ class InterpolatedFeatures:
     def dim(self):
         return 2
 
-    def materialize(self):
-        return gather_bilinear(self.x, self.packed_idx, self.coords)
+    def materialize(self, rows=None):
+        """The reference's [P, C] tensor; ``rows`` [R, C']: the same interpolation of another per-row tensor (a linear
+        function of the map rows, e.g. the hoisted first Linear of E_mod)."""
+        if rows is None:
+            return gather_bilinear(self.x, self.packed_idx, self.coords)
+        B, _, H, W = self.x.shape
+        return gather_bilinear(rows.view(B, H, W, rows.shape[1]).permute(0, 3, 1, 2), self.packed_idx, self.coords)
 
 
 def lazy_gather_bilinear(x, packed_idx, coords, exact):
