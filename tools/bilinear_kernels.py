@@ -10,7 +10,7 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
 C, Co = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 64)
-scene = bench.make_scene(1 << 20, 32, 32, C, 64, 128, torch.bfloat16, dev, seed=4321, workload="S1", upscale=8)
+scene = bench.make_scene(1 << int(os.environ.get("LOG2N", "20")), 32, 32, C, 64, 128, torch.bfloat16, dev, seed=4321, workload="S1", upscale=8)
 mods = bench.build_modules(C, dev, Co)
 ms, kern = bench.timed_steps(scene, mods, torch.bfloat16, 3, 1, interpolate=True)
 print(f"C {C} -> {Co}: {ms:.2f} ms/step")
