@@ -193,3 +193,38 @@ def test_fused_bilinear_through_the_data_objects():
     assert type(out.grad_fn).__name__ == "_EmodPoolBackward" and out.shape == (N, C)
     out.float().sum().backward()
     assert sd.x.grad is not None and torch.isfinite(sd.x.grad.float()).all()
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_materialised_fallback_hoists_the_first_linear(train):
+    """C_out = 128 (a deeper KITTI-360 pyramid level: 256 -> 128) is outside the fused kernels: the fallback runs
+    E_mod's first Linear on the map rows and interpolates its C_out channels (interp(x) W^T = interp(x W^T)) instead
+    of materialising [V, C_in] and a per-view GEMM.  Checked against the oracle like the fused path, and against the
+    un-hoisted device dataflow."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    case = make_case(31, 1200, 96, ragged)
+    ref, m = build(case, 128, 4, train)
+    w = torch.randn(case["N"], 128, generator=case["gen"])
+    calls = []
+    orig = P._hoisted_first_linear
+
+    def spy(mlp, x_mod):
+        r = orig(mlp, x_mod)
+        calls.append(r[1])
+        return r
+    P._hoisted_first_linear = spy
+    try:
+        out, g, used = run_dev(case, m, w, fused=True)
+        assert calls == [True] and used["fn"] != "_EmodPoolBackward"
+        P._hoisted_first_linear = lambda mlp, x_mod: (x_mod.materialize(), False)
+        _, m2 = build(case, 128, 4, train)
+        out_b, g_b, _ = run_dev(case, m2, w, fused=True)
+    finally:
+        P._hoisted_first_linear = orig
+    out_ref, g_ref = oracle(case, ref, w, autocast=False)
+    out_amp, _ = oracle(case, ref, w, autocast=True)
+    r, r_amp = rel(out, out_ref), rel(out_amp, out_ref)
+    assert r < max(2e-2, 1.5 * r_amp), (r, r_amp)
+    assert rel(out, out_b) < 2e-2, rel(out, out_b)
+    assert rel(g[0], g_b[0]) < 1e-1, rel(g[0], g_b[0])                    # feature-map gradient (two bf16 dataflows)
+    assert rel(g[0], g_ref[0]) < max(5e-2, 2 * rel(g_b[0], g_ref[0]))
