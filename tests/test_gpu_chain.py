@@ -111,7 +111,7 @@ def test_chain_forward_matches_oracle(sizes_fn, N, C, G, train):
     assert r < max(2e-2, 1.5 * r_amp), (r, r_amp)
     # unseen points stay zero
     unseen = (case["csr"][1:] == case["csr"][:-1])
-    assert float(out.float().cpu()[unseen].abs().max() if unseen.any() else 0.0) == 0.0
+    assert float(out.detach().float().cpu()[unseen].abs().max() if unseen.any() else 0.0) == 0.0
     if train:
         for (k, a), b in zip(m.state_dict().items(), ref.state_dict().values()):
             if "running" in k:
