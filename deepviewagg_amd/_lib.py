@@ -131,7 +131,7 @@ SIGNATURES = {
     "dva_anchor_rows_sum": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dva_anchor_combine": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dva_anchor_fixup": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "dva_anchor_rows_sum_bn": (ctypes.c_int, [_vp] * 8 + [_i64, _i64, _i32, _vp]),
+    "dva_anchor_rows_sum_bn": (ctypes.c_int, [_vp] * 10 + [_i64, _i64, _i32, _vp]),
     "dva_anchor_fixup_bn": (ctypes.c_int, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _vp]),
     "dva_emod_prep": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
     "dva_emod_stats": (ctypes.c_int, [_i32] + [_vp] * 9 + [_i64, _i64, _i32, _vp]),

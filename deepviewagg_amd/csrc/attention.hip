@@ -1149,20 +1149,28 @@ __global__ __launch_bounds__(256) void rows_sum_team_kernel(const T* __restrict_
 // gradient follows from S by dva_anchor_combine.  Deterministic, no atomics.
 // AFF (the fused bilinear path, csrc/chain_emod.hip): the rows are dy_a in the chain kernels' position order and the
 // BatchNorm_a backward dz_a = G dy_a - K1 - K2 z_a (constants as chain_emod.hip stage_tab_c builds them from bn =
-// mean | invstd | gamma | beta and sm = S1 / M | S2_hat / M, natural channel order) is applied to every row on the
-// fly from the stored z_a: the separate in-place pass over [V][C] (read 2 rows, write 1) disappears.
+// mean | invstd | gamma | beta and sm = S1 / M | S2_hat / M, natural channel order) is folded into the scatter: the
+// separate in-place pass over [V][C] (read 2 rows, write 1) disappears.
+//   AFF = 1: applied to every row as it is read, from the stored z_a row of the view (a second random row per view);
+//   AFF = 2: at the level of the anchor.  All views of an anchor interpolate the SAME four rows of Y, z_a[v] =
+//            sum_k' w_k'(v) Y[r_k'], so  sum_v w_k(v) z_a[v] = sum_k' M[k][k'] Y[r_k']  with the 4 x 4 Gram matrix
+//            M = sum_v w(v) w(v)^T of the anchor's tap weights -- accumulated here from the weights the kernel reads
+//            anyway -- and  S[a][k] = G sum_v w_k dy_a[v] - K1 sum_v w_k - K2 sum_k' M[k][k'] Y[r_k']:
+//            one random row per view again, plus four rows of Y per anchor.
 __device__ __forceinline__ int position_channel(int p) {      // position 32 b + 16 h + r holds channel 32 b + chan(r, h)
   const int r = p & 15, h = (p >> 4) & 1;
   return (p & ~31) + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
-template <typename T, bool AFF>
+template <typename T, int AFF>
 __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restrict__ gout,
                                                                const int32_t* __restrict__ perm,
                                                                const int32_t* __restrict__ row_ptr,
                                                                const float4* __restrict__ weights,
                                                                float* __restrict__ S, int64_t R, int C, int lpr,
                                                                const T* __restrict__ zrows, const float* __restrict__ bn,
-                                                               const float* __restrict__ sm) {
+                                                               const float* __restrict__ sm,
+                                                               const int4* __restrict__ tap_rows,
+                                                               const T* __restrict__ Y) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int U = 2;
   typedef typename Vec16<T>::raw raw_t;
@@ -1190,10 +1198,17 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc[k][e] = 0.f;
     }
+    float gm[AFF == 2 ? 10 : 1], w1[AFF == 2 ? 4 : 1];      // upper triangle of M, sum of the weights
+    if (AFF == 2) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) gm[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w1[k] = 0.f;
+    }
     for (int i0 = beg; i0 < end; i0 += slots * U) {
       int v[U];
       bool ok[U];
-      raw_t raw[U], zraw[AFF ? U : 1];
+      raw_t raw[U], zraw[AFF == 1 ? U : 1];
       float4 wu[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1204,14 +1219,14 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         raw[u] = *reinterpret_cast<const raw_t*>(gout + (int64_t)v[u] * C + col);
-        if (AFF) zraw[u] = *reinterpret_cast<const raw_t*>(zrows + (int64_t)v[u] * C + col);
+        if (AFF == 1) zraw[u] = *reinterpret_cast<const raw_t*>(zrows + (int64_t)v[u] * C + col);
         wu[u] = ok[u] ? weights[v[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float f[VEC];
         Vec16<T>::unpack(raw[u], f);
-        if (AFF) {
+        if (AFF == 1) {
           float zf[VEC];
           Vec16<T>::unpack(zraw[u], zf);
 #pragma unroll
@@ -1223,6 +1238,15 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
 #pragma unroll
           for (int e = 0; e < VEC; ++e) acc[k][e] = fmaf(ww[k], f[e], acc[k][e]);
         }
+        if (AFF == 2) {
+          int t = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            w1[k] += ww[k];
+#pragma unroll
+            for (int k2 = k; k2 < 4; ++k2, ++t) gm[t] = fmaf(ww[k], ww[k2], gm[t]);
+          }
+        }
       }
     }
     for (int off = lpr; off < 64; off <<= 1) {
@@ -1231,8 +1255,32 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[k][e] += __shfl_xor(acc[k][e], off);
       }
+      if (AFF == 2) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) gm[i] += __shfl_xor(gm[i], off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w1[k] += __shfl_xor(w1[k], off);
+      }
     }
     if (slot == 0) {
+      if (AFF == 2 && end > beg) {
+        // the four rows of Y every view of this anchor interpolates (border-replicated rows may coincide)
+        const int4 tr = tap_rows[perm[beg]];
+        const int rr[4] = {tr.x, tr.y, tr.z, tr.w};
+        float y[4][VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(Y + (int64_t)rr[k] * C + col), y[k]);
+        const float m4[4][4] = {{gm[0], gm[1], gm[2], gm[3]}, {gm[1], gm[4], gm[5], gm[6]},
+                                {gm[2], gm[5], gm[7], gm[8]}, {gm[3], gm[6], gm[8], gm[9]}};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float zs = fmaf(m4[k][0], y[0][e], fmaf(m4[k][1], y[1][e], fmaf(m4[k][2], y[2][e], m4[k][3] * y[3][e])));
+            acc[k][e] = fmaf(-ck2[e], zs, fmaf(cg[e], acc[k][e], -ck1[e] * w1[k]));
+          }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float* dst = S + (r * 4 + k) * C + col;
@@ -1459,15 +1507,17 @@ int dva_anchor_rows_sum(const void* grad_out, const int32_t* perm, const int32_t
   if (dtype == DVA_BF16) {
     const int lpr = C / 8;
     if ((C % 8) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)grad_out % 16) || ((uintptr_t)S % 16)) return DVA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, false>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, 0>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
                        (const bf16_t*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr,
-                       (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                       (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const int4*)nullptr,
+                       (const bf16_t*)nullptr);
   } else if (dtype == DVA_F32) {
     const int lpr = C / 4;
     if ((C % 4) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)grad_out % 16) || ((uintptr_t)S % 16)) return DVA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((anchor_rows_sum_kernel<float, false>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<float, 0>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0, s,
                        (const float*)grad_out, perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const int4*)nullptr,
+                       (const float*)nullptr);
   } else {
     return DVA_ERR_INVALID;
   }
@@ -1476,17 +1526,25 @@ int dva_anchor_rows_sum(const void* grad_out, const int32_t* perm, const int32_t
 }
 
 int dva_anchor_rows_sum_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* perm,
-                           const int32_t* row_ptr, const float* weights, float* S, int64_t n_anchors, int64_t n_views,
-                           int32_t C, void* stream) {
+                           const int32_t* row_ptr, const float* weights, const int32_t* tap_rows, const void* Y,
+                           float* S, int64_t n_anchors, int64_t n_views, int32_t C, void* stream) {
   if (n_anchors < 0 || n_views < 0 || C <= 0) return DVA_ERR_INVALID;
   if (n_anchors == 0) return DVA_OK;
-  if (!row_ptr || !S || !bn_a || !sm_a || (n_views > 0 && (!dy_a || !z_a || !perm || !weights))) return DVA_ERR_INVALID;
+  if (!row_ptr || !S || !bn_a || !sm_a || (n_views > 0 && (!dy_a || !perm || !weights))) return DVA_ERR_INVALID;
+  if ((z_a == nullptr) == (Y == nullptr) || (Y && !tap_rows)) return DVA_ERR_INVALID;      // exactly one of the two forms
   const int lpr = C / 8;
-  if ((C % 32) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)dy_a % 16) || ((uintptr_t)z_a % 16) || ((uintptr_t)S % 16))
+  if ((C % 32) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)dy_a % 16) || ((uintptr_t)z_a % 16) || ((uintptr_t)Y % 16) ||
+      ((uintptr_t)S % 16) || ((uintptr_t)tap_rows % 16))
     return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, true>), dim3(grid_cap((n_anchors + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)dy_a, perm, row_ptr, (const float4*)weights, S, n_anchors,
-                     (int)C, lpr, (const bf16_t*)z_a, bn_a, sm_a);
+  const dim3 grid(grid_cap((n_anchors + 3) / 4)), block(256);
+  if (Y)
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, 2>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy_a,
+                       perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr, (const bf16_t*)nullptr, bn_a,
+                       sm_a, (const int4*)tap_rows, (const bf16_t*)Y);
+  else
+    hipLaunchKernelGGL((anchor_rows_sum_kernel<bf16_t, 1>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy_a,
+                       perm, row_ptr, (const float4*)weights, S, n_anchors, (int)C, lpr, (const bf16_t*)z_a, bn_a,
+                       sm_a, (const int4*)nullptr, (const bf16_t*)nullptr);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -22,6 +22,9 @@ from ._lib import check, ptr, require_device, stream_of
 from .fused_chain_bwd import Arena, chain_epilogue
 
 _POS = {}
+# BatchNorm_a backward inside the anchor scatter: at the level of the anchor (Gram matrix of the tap weights x the four
+# rows of Y: one random row per view) instead of row by row from the stored z_a (two)
+ANCHOR_GRAM = True
 
 
 def position_order(C, device):
@@ -191,7 +194,7 @@ class _EmodPool(torch.autograd.Function):
         #      backward is applied to the rows as they are read: no in-place pass over [V, C])
         dY = None
         if ctx.needs_input_grad[0]:
-            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw, bn_backward=(za, tab_a, sm_a)).to(Y.dtype)
+            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw, bn_backward=(za, tab_a, sm_a, Y if ANCHOR_GRAM else None)).to(Y.dtype)
         del da, za
         grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
         ctx.set_saved = None

@@ -407,8 +407,10 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
     Views are grouped by ANCHOR (the padded cell of their top-left tap, ``dva_gather_bilinear_taps_anchor``): one
     sort of P keys, every gradient row read once into four per-anchor sums, then a 2 x 2 stencil on the map
     (csrc/attention.hip anchor_rows_sum_kernel, csrc/gather.hip anchor_combine_kernel).  Deterministic.
-    ``bn_backward = (z_a, bn_a, sm_a)`` (fused bilinear path): ``grad`` is dy_a (bf16, position order) and every row
-    gets the BatchNorm_a backward ``G dy_a - K1 - K2 z_a`` on the fly instead of in a pass of its own."""
+    ``bn_backward = (z_a, bn_a, sm_a, Y)`` (fused bilinear path): ``grad`` is dy_a (bf16, position order) and the
+    BatchNorm_a backward ``G dy_a - K1 - K2 z_a`` is folded into the scatter instead of a pass of its own: with ``Y``
+    (the interpolated map rows, position order) at the level of the anchor through the Gram matrix of its tap weights
+    (one random row per view), without it from the stored ``z_a`` rows; the dummy-anchor views always use ``z_a``."""
     lib = _lib.load()
     grad = grad.contiguous()
     P, C = grad.shape
@@ -418,17 +420,24 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
     st = stream_of(grad)
     es = grad.element_size()
     if bn_backward is not None:
-        z_a, bn_a, sm_a = bn_backward
+        z_a, bn_a, sm_a, Y = bn_backward
         if grad.dtype != torch.bfloat16 or z_a.dtype != torch.bfloat16 or z_a.shape != grad.shape or C % 32:
             raise _lib.DvaError("bilinear_scatter(bn_backward): bf16 [V, C] rows, C a multiple of 32", -1)
         z_a = z_a.contiguous()
-    with _timed("bilinear_anchor_sum", P * (C * es * (2 if bn_backward is not None else 1) + 20) + n_anchor * 4 * C * 4):
+        if Y is not None:
+            if Y.dtype != torch.bfloat16 or Y.shape[1] != C:
+                raise _lib.DvaError("bilinear_scatter(bn_backward): Y bf16 [R, C]", -1)
+            Y = Y.contiguous()
+    two_rows = bn_backward is not None and bn_backward[3] is None
+    with _timed("bilinear_anchor_sum", P * (C * es * (2 if two_rows else 1) + 20) + n_anchor * 4 * C * 4):
         if bn_backward is None:
             check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(row_ptr), ptr(tap_weights), ptr(S), n_anchor, P, C,
                                           dtype_code(grad), st), "dva_anchor_rows_sum")
         else:
-            check(lib.dva_anchor_rows_sum_bn(ptr(grad), ptr(z_a), ptr(bn_a), ptr(sm_a), ptr(perm), ptr(row_ptr),
-                                             ptr(tap_weights), ptr(S), n_anchor, P, C, st), "dva_anchor_rows_sum_bn")
+            check(lib.dva_anchor_rows_sum_bn(ptr(grad), None if Y is not None else ptr(z_a), ptr(bn_a), ptr(sm_a),
+                                             ptr(perm), ptr(row_ptr), ptr(tap_weights),
+                                             ptr(tap_rows) if Y is not None else None, ptr(Y), ptr(S), n_anchor, P, C,
+                                             st), "dva_anchor_rows_sum_bn")
     out = torch.empty((B * H * W, C), dtype=torch.float32, device=grad.device)
     with _timed("bilinear_anchor_combine", n_anchor * 4 * C * 4 + B * H * W * C * 4):
         check(lib.dva_anchor_combine(ptr(S), ptr(out), B, H, W, C, st), "dva_anchor_combine")

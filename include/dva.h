@@ -232,11 +232,14 @@ int dva_anchor_fixup(const void* grad, const int32_t* rows, const float* weights
                      void* stream);
 /* The same two steps for the fused bilinear path (csrc/chain_emod.hip): the rows are dy_a bf16 [V][C] in position order
  * and the BatchNorm_a backward dz_a = G dy_a - K1 - K2 z_a (bn_a fp32 [4][C] = mean | invstd | gamma | beta,
- * sm_a fp32 [2][C] = S1 / M | S2_hat / M of dva_bn_bwd_consts, natural channel order; z_a bf16 [V][C]) is applied to
- * every row on the fly, replacing the in-place pass dva_emod_bwd(stage 1).  C a multiple of 32. */
+ * sm_a fp32 [2][C] = S1 / M | S2_hat / M of dva_bn_bwd_consts, natural channel order) is folded into the scatter,
+ * replacing the in-place pass dva_emod_bwd(stage 1).  C a multiple of 32.  dva_anchor_rows_sum_bn takes z either as
+ * z_a bf16 [V][C] (applied row by row; Y, tap_rows NULL) or, z_a NULL, as Y bf16 [R][C] (position order) + tap_rows
+ * int32 [V][4]: all views of an anchor interpolate the same four rows of Y, so their z term is a 4 x 4 Gram matrix of
+ * the tap weights (accumulated in the kernel) times those rows -- one random row per view instead of two. */
 int dva_anchor_rows_sum_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* perm,
-                           const int32_t* row_ptr, const float* weights, float* S, int64_t n_anchors, int64_t n_views,
-                           int32_t C, void* stream);
+                           const int32_t* row_ptr, const float* weights, const int32_t* tap_rows, const void* Y,
+                           float* S, int64_t n_anchors, int64_t n_views, int32_t C, void* stream);
 int dva_anchor_fixup_bn(const void* dy_a, const void* z_a, const float* bn_a, const float* sm_a, const int32_t* rows,
                         const float* weights, const int32_t* anchors, float* grad_rows, int64_t n_atoms, int32_t B,
                         int32_t H, int32_t W, int32_t C, void* stream);
