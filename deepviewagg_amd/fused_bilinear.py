@@ -15,6 +15,8 @@ in place) to the weighted segmented reduction over the row plan of the taps (``d
 no atomics; views grouped by the anchor of their 2 x 2 tap block), which yields the gradient of Y; Linear_a's backward is autograd on the map rows.
 The DeepSetFeat chain (scores) is shared with ``fused_chain`` (``chain_prologue`` / ``chain_epilogue``).
 """
+import os
+
 import torch
 
 from . import _lib, ops, fused_chain, fused_deepset
@@ -24,7 +26,7 @@ from .fused_chain_bwd import Arena, chain_epilogue
 _POS = {}
 # BatchNorm_a backward inside the anchor scatter: at the level of the anchor (Gram matrix of the tap weights x the four
 # rows of Y: one random row per view) instead of row by row from the stored z_a (two)
-ANCHOR_GRAM = True
+ANCHOR_GRAM = os.environ.get("DVA_ANCHOR_GRAM", "1") == "1"
 
 
 def position_order(C, device):
