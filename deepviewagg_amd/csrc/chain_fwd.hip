@@ -131,19 +131,8 @@ __global__ __launch_bounds__(64) void tile_walk_kernel(const int64_t* __restrict
   if (p < p_end) {
     int64_t s = ptr[p];            // first view of the open tile
     int64_t e_prev = s;            // end of the last point taken into the open tile
-    // the walk is a chain of dependent 8-byte loads (one lane per chunk: every load instruction touches 64 lines);
-    // four pointer entries are requested at a time, so the latency is paid once per four points
-    int64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, bp = -4;
     while (p < p_end) {
-      if (p - bp >= 4) {
-        bp = p;
-        b0 = ptr[p + 1];
-        b1 = ptr[p + 2 < p_end ? p + 2 : p_end];
-        b2 = ptr[p + 3 < p_end ? p + 3 : p_end];
-        b3 = ptr[p + 4 < p_end ? p + 4 : p_end];
-      }
-      const int k = (int)(p - bp);
-      const int64_t e = k == 0 ? b0 : (k == 1 ? b1 : (k == 2 ? b2 : b3));
+      const int64_t e = ptr[p + 1];
       if (e - s <= 32) {           // the point fits: extend the open tile
         e_prev = e;
         ++p;
