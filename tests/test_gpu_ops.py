@@ -559,3 +559,53 @@ def test_lean_attention_backward_fp32_equals_team_kernel(C, gating, scaling):
     torch.testing.assert_close(a[0].cpu(), out_ref.detach(), rtol=1e-4, atol=1e-5)
     for x, y in zip(a[1:], g_ref):
         torch.testing.assert_close(x.cpu().reshape(y.shape), y, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("C", [32, 64])
+def test_bilinear_scatter_with_batchnorm_backward(C):
+    """ops.bilinear_scatter(bn_backward=...): the BatchNorm_a backward of the fused bilinear path folded into the anchor
+    scatter, row by row from the stored z_a and at the level of the anchor (4 x 4 Gram matrix of the tap weights x the
+    four rows of Y), against index_add of the explicitly transformed rows -- including border views and views without
+    the 2 x 2 tap structure (dummy anchor: fix-up kernel)."""
+    from deepviewagg_amd import ops, fused_bilinear
+    gen = torch.Generator().manual_seed(C)
+    B, H, W, P = 3, 9, 14, 5000
+    x = torch.randn(B, C, H, W, generator=gen).bfloat16()
+    images = torch.randint(0, B, (P,), generator=gen)
+    pixels = torch.zeros(P, 2, dtype=torch.int16)
+    coords = torch.rand(P, 2, generator=gen)
+    coords[:50] = torch.tensor([0.0, 1.0])
+    coords[50:60] = torch.tensor([1.0, 0.0])
+    coords[60:64, 0] = 0.0555555485188961           # floor(q + 1) != floor(q) + 1: no 2 x 2 structure
+    packed = ops.pack_gather_index(images.to(DEV), torch.arange(P + 1, device=DEV), pixels.to(DEV))
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    lazy = ops.lazy_gather_bilinear(xd, packed, coords.to(DEV), exact=True)
+    rows4, w4, anchors = lazy.tap_rows, lazy.tap_weights, lazy.anchors
+    assert int((anchors == B * (H + 1) * (W + 1)).sum()) >= 4, "the case must contain dummy-anchor views"
+    Y = lazy.rows                                                            # bf16 [R, C]: stands for Linear_a(x)
+    z_full = (Y.float()[rows4.long()] * w4.unsqueeze(-1)).sum(1)            # [P, C] fp32
+    z_a = z_full.bfloat16()
+    dy = torch.randn(P, C, generator=gen).bfloat16().to(DEV)
+    bn = torch.stack([torch.randn(C, generator=gen) * 0.2, torch.rand(C, generator=gen) + 0.5,
+                      torch.randn(C, generator=gen) * 0.3 + 1.0, torch.randn(C, generator=gen)]).to(DEV)
+    sm = (torch.randn(2 * C, generator=gen) * 0.05).to(DEV)
+    kappa = fused_bilinear.position_order(C, DEV)                            # channel held by position p
+    mean, inv, gam = bn[0][kappa], bn[1][kappa], bn[2][kappa]
+    s1, s2 = sm[:C][kappa], sm[C:][kappa]
+    g = gam * inv
+    k1, k2 = g * (s1 - mean * inv * s2), g * inv * s2
+
+    def reference(z):
+        dz = g * dy.float() - k1 - k2 * z
+        out = torch.zeros(B * H * W, C, device=DEV)
+        for k in range(4):
+            out.index_add_(0, rows4[:, k].long(), dz * w4[:, k:k + 1])
+        return out
+    got_rows = ops.bilinear_scatter(dy, rows4, w4, anchors, B, H, W, bn_backward=(z_a, bn, sm, None))
+    got_gram = ops.bilinear_scatter(dy, rows4, w4, anchors, B, H, W, bn_backward=(z_a, bn, sm, Y))
+    ref_rows = reference(z_a.float())
+    close(got_rows, ref_rows, rtol=1e-4, atol=1e-4)
+    # the anchor-level form sees the unrounded z_a on the views with the 2 x 2 structure
+    ref_gram = reference(torch.where((anchors == B * (H + 1) * (W + 1)).unsqueeze(1), z_a.float(), z_full))
+    close(got_gram, ref_gram, rtol=1e-4, atol=2e-4)
+    assert float((got_gram - got_rows).norm() / got_rows.norm()) < 5e-3
