@@ -228,3 +228,32 @@ def test_materialised_fallback_hoists_the_first_linear(train):
     assert rel(out, out_b) < 2e-2, rel(out, out_b)
     assert rel(g[0], g_b[0]) < 1e-1, rel(g[0], g_b[0])                    # feature-map gradient (two bf16 dataflows)
     assert rel(g[0], g_ref[0]) < max(5e-2, 2 * rel(g_b[0], g_ref[0]))
+
+
+@pytest.mark.parametrize("C", [32, 64])
+def test_emod_bwd_stage1_in_place_batchnorm_backward(C):
+    """dva_emod_bwd(stage 1) through the C ABI: da <- G dy_a - K1 - K2 z_a in place from the stored z_a (the host path
+    folds this into the anchor scatter since round 3; the entry stays in the ABI)."""
+    from deepviewagg_amd import _lib, fused_chain, fused_bilinear
+    from deepviewagg_amd._lib import check, ptr, stream_of
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(100 + C)
+    sizes = ragged_long(700, gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    tiles, n_tiles = fused_chain.build_tiles(csr, V)
+    z_a = torch.randn(V, C, generator=gen).bfloat16().to(DEV)
+    dy = torch.randn(V, C, generator=gen).bfloat16().to(DEV)
+    bn = torch.stack([torch.randn(C, generator=gen) * 0.2, torch.rand(C, generator=gen) + 0.5,
+                      torch.randn(C, generator=gen) * 0.3 + 1.0, torch.randn(C, generator=gen)]).to(DEV).contiguous()
+    sm = (torch.randn(2 * C, generator=gen) * 0.05).to(DEV)
+    kappa = fused_bilinear.position_order(C, DEV)
+    mean, inv, gam = bn[0][kappa], bn[1][kappa], bn[2][kappa]
+    s1, s2 = sm[:C][kappa], sm[C:][kappa]
+    g = gam * inv
+    ref = (g * dy.float() - g * (s1 - mean * inv * s2) - g * inv * s2 * z_a.float())
+    da = dy.clone()
+    check(lib.dva_emod_bwd(1, None, None, None, ptr(tiles), ptr(n_tiles), None, ptr(bn), None, ptr(sm), None, None, None,
+                           ptr(da), None, None, ptr(z_a), 700, V, 1, C, 1, stream_of(da)), "dva_emod_bwd")
+    torch.testing.assert_close(da.float(), ref, rtol=1e-2, atol=1e-2)          # bf16 output
+    assert float((da.float() - ref).norm() / ref.norm()) < 4e-3
