@@ -403,8 +403,9 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
 // ------------------------------------------------------------------------------------------------
 // the fused view kernel of the bilinear path
 // ------------------------------------------------------------------------------------------------
+// C_o = 128 (eval mode only: 356 registers, one wavefront per SIMD; the backward kernels do not exist at that width)
 template <int CO, int G, int ZM>      // ZM = 0: z_a from the taps of Y (eval mode), 1: the stored z_a (train mode)
-__global__ __launch_bounds__(256, 2) void emod_attn_fwd_kernel(
+__global__ __launch_bounds__(256, CO > 64 ? 1 : 2) void emod_attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -1161,7 +1162,7 @@ using namespace dva::emod;
 extern "C" {
 
 int dva_emod_prep(const float* Wb, int32_t C_out, void* ops, void* stream) {
-  if (!Wb || !ops || (C_out != 32 && C_out != 64)) return DVA_ERR_INVALID;
+  if (!Wb || !ops || (C_out != 32 && C_out != 64 && C_out != 128)) return DVA_ERR_INVALID;
   const int NB = C_out / 32;
   hipLaunchKernelGGL(emod_prep_kernel, dim3(2 * NB * NB * 2), dim3(64), 0, (hipStream_t)stream, Wb, (int)C_out,
                      (uint4*)ops);
@@ -1211,7 +1212,8 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
   if (!z_a && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * 128 > 0xfffffff0ll || n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(2)), block(256);
+  if (C_out > 64 && z_a) return DVA_ERR_UNSUPPORTED;       // the train-mode passes stop at C_out = 64
+  const dim3 grid(chain_grid(C_out > 64 ? 1 : 2)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_FWD_Z(CO_, G_, ZM_)                                                                                  \
   hipLaunchKernelGGL((emod_attn_fwd_kernel<CO_, G_, ZM_>), grid, block, 0, s, x_map, view_point, u,                    \
@@ -1231,6 +1233,9 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
     case 64 * 8 + 1: DVA_EMOD_FWD(64, 1); break;
     case 64 * 8 + 2: DVA_EMOD_FWD(64, 2); break;
     case 64 * 8 + 4: DVA_EMOD_FWD(64, 4); break;
+    case 128 * 8 + 1: DVA_EMOD_FWD_Z(128, 1, 0); break;
+    case 128 * 8 + 2: DVA_EMOD_FWD_Z(128, 2, 0); break;
+    case 128 * 8 + 4: DVA_EMOD_FWD_Z(128, 4, 0); break;
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_EMOD_FWD

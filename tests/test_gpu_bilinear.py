@@ -257,3 +257,40 @@ def test_emod_bwd_stage1_in_place_batchnorm_backward(C):
                            ptr(da), None, None, ptr(z_a), 700, V, 1, C, 1, stream_of(da)), "dva_emod_bwd")
     torch.testing.assert_close(da.float(), ref, rtol=1e-2, atol=1e-2)          # bf16 output
     assert float((da.float() - ref).norm() / ref.norm()) < 4e-3
+
+
+@pytest.mark.parametrize("sizes_fn,N,C_in,G", [(ragged, 1500, 256, 4), (ragged_long, 800, 96, 2), (full32, 200, 256, 1)])
+def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G):
+    """C_out = 128 (the KITTI-360 pyramid level 256 -> 128): eval mode under no_grad runs the ONE fused kernel on the
+    taps of Y (356 registers, one wavefront per SIMD); training at that width takes the materialised fallback with
+    the hoisted Linear_a."""
+    from deepviewagg_amd import fused_bilinear
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    case = make_case(41 + G, N, C_in, sizes_fn)
+    ref, m = build(case, 128, G, train=False)
+    w = torch.randn(case["N"], 128, generator=case["gen"])
+    calls = []
+    orig = fused_bilinear.pool
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    fused_bilinear.pool = spy
+    try:
+        with torch.no_grad():
+            out, _, _ = run_dev(case, m, w, fused=True, need_grad=False)
+        assert calls == [1], "the fused eval kernel must be the path that ran"
+        out_grad, _, used = run_dev(case, m, w, fused=True, need_grad=True)       # grad enabled: the fallback
+        assert calls == [1] and used["fn"] != "_EmodPoolBackward"
+    finally:
+        fused_bilinear.pool = orig
+    with torch.no_grad():
+        xm = O.gather_bilinear(case["x"], case["images"], case["pixels"], case["msize"])
+        out_ref = ref(None, xm, case["x_map"], case["csr"])
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out_amp = ref(None, xm, case["x_map"], case["csr"])
+    r, r_amp = rel(out, out_ref), rel(out_amp, out_ref)
+    assert out.dtype == torch.bfloat16 and r < max(2e-2, 1.5 * r_amp), (r, r_amp)
+    assert rel(out, out_grad) < 2e-2
+    unseen = (case["csr"][1:] == case["csr"][:-1])
+    assert float(out.float().cpu()[unseen].abs().max() if unseen.any() else 0.0) == 0.0
