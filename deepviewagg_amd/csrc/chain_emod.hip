@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
 // ------------------------------------------------------------------------------------------------
 // the fused view kernel of the bilinear path
 // ------------------------------------------------------------------------------------------------
-// C_o = 128 (eval mode only: 356 registers, one wavefront per SIMD; the backward kernels do not exist at that width)
+// C_o = 128 / 256 (eval mode only: 356 / 512 registers, one wavefront per SIMD; the backward kernels do not exist at
+// those widths)
 template <int CO, int G, int ZM>      // ZM = 0: z_a from the taps of Y (eval mode), 1: the stored z_a (train mode)
 __global__ __launch_bounds__(256, CO > 64 ? 1 : 2) void emod_attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
@@ -1162,7 +1163,7 @@ using namespace dva::emod;
 extern "C" {
 
 int dva_emod_prep(const float* Wb, int32_t C_out, void* ops, void* stream) {
-  if (!Wb || !ops || (C_out != 32 && C_out != 64 && C_out != 128)) return DVA_ERR_INVALID;
+  if (!Wb || !ops || (C_out != 32 && C_out != 64 && C_out != 128 && C_out != 256)) return DVA_ERR_INVALID;
   const int NB = C_out / 32;
   hipLaunchKernelGGL(emod_prep_kernel, dim3(2 * NB * NB * 2), dim3(64), 0, (hipStream_t)stream, Wb, (int)C_out,
                      (uint4*)ops);
@@ -1236,6 +1237,7 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
     case 128 * 8 + 1: DVA_EMOD_FWD_Z(128, 1, 0); break;
     case 128 * 8 + 2: DVA_EMOD_FWD_Z(128, 2, 0); break;
     case 128 * 8 + 4: DVA_EMOD_FWD_Z(128, 4, 0); break;
+    case 256 * 8 + 4: DVA_EMOD_FWD_Z(256, 4, 0); break;
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_EMOD_FWD

@@ -61,10 +61,10 @@ def applicable(module, x_mod, x_map, csr_idx):
         return False
     lin_a, bn_a, act_a, lin_b, bn_b, act_b = blocks
     C, G = module.out_mod, module.num_groups
-    if C not in (32, 64, 128) or G not in (1, 2, 4) or C % G or (C // G) % 8:
+    if C not in (32, 64, 128, 256) or G not in (1, 2, 4) or C % G or (C // G) % 8 or (C == 256 and G != 4):
         return False
-    if C == 128 and (module.E_map.training or torch.is_grad_enabled()):
-        return False        # C_out = 128 (KITTI-360 pyramid level 256 -> 128): the one-kernel eval path only
+    if C >= 128 and (module.E_map.training or torch.is_grad_enabled()):
+        return False        # C_out = 128 / 256 (KITTI-360 pyramid levels 256 -> 128, 512 -> 256): the one-kernel eval path only
     if lin_a.bias is not None or lin_b.bias is not None or lin_b.in_features != C or lin_b.out_features != C:
         return False
     for bn, act in ((bn_a, act_a), (bn_b, act_b)):

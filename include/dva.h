@@ -447,7 +447,7 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
  * 32 b + (r & 3) + 8 (r >> 2) + 4 h: the 16 channels a lane owns are contiguous).  Per view: the 4 taps
  * tap_rows int32 [V][4] / tap_weights fp32 [V][4] (dva_gather_bilinear_taps) of Y -> z_a -> BatchNorm_a ->
  * LeakyReLU(0.2) -> Linear_b on the matrix cores -> BatchNorm_b -> LeakyReLU = the value of the view.
- * C_out in {32, 64} (dva_emod_prep and the eval form of dva_emod_attn_fwd, z_a = NULL, also 128), G in {1, 2, 4}.  bn_a / bn_b fp32 [4][C_out] = mean | invstd | gamma | beta (dva_bn_finalize),
+ * C_out in {32, 64} (dva_emod_prep and the eval form of dva_emod_attn_fwd, z_a = NULL, also 128 and, G = 4, 256), G in {1, 2, 4}.  bn_a / bn_b fp32 [4][C_out] = mean | invstd | gamma | beta (dva_bn_finalize),
  * natural channel order; statistics fp64 [2][C_out] caller-zeroed; tiles / view_point / scores / chain arguments as
  * for the dva_chain_* entries.
  * z_a bf16 [V][C_out] (position order): the interpolated Linear_a output of every view, rounded to bf16 (what the

@@ -259,16 +259,17 @@ def test_emod_bwd_stage1_in_place_batchnorm_backward(C):
     assert float((da.float() - ref).norm() / ref.norm()) < 4e-3
 
 
-@pytest.mark.parametrize("sizes_fn,N,C_in,G", [(ragged, 1500, 256, 4), (ragged_long, 800, 96, 2), (full32, 200, 256, 1)])
-def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G):
+@pytest.mark.parametrize("sizes_fn,N,C_in,G,C_out", [(ragged, 1500, 256, 4, 128), (ragged_long, 800, 96, 2, 128),
+                                                     (full32, 200, 256, 1, 128), (ragged_long, 900, 160, 4, 256)])
+def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G, C_out):
     """C_out = 128 (the KITTI-360 pyramid level 256 -> 128): eval mode under no_grad runs the ONE fused kernel on the
     taps of Y (356 registers, one wavefront per SIMD); training at that width takes the materialised fallback with
     the hoisted Linear_a."""
     from deepviewagg_amd import fused_bilinear
     from deepviewagg_amd.modules.multimodal import pooling as P
     case = make_case(41 + G, N, C_in, sizes_fn)
-    ref, m = build(case, 128, G, train=False)
-    w = torch.randn(case["N"], 128, generator=case["gen"])
+    ref, m = build(case, C_out, G, train=False)
+    w = torch.randn(case["N"], C_out, generator=case["gen"])
     calls = []
     orig = fused_bilinear.pool
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Eval-mode (no_grad) forward of the bilinear pooling at C_out = 128 (KITTI-360 level 256 -> 128): the one fused kernel
-against the materialised fallback.  python tools/bilinear_eval_c128.py [log2_points]"""
+against the materialised fallback.  python tools/bilinear_eval_c128.py [log2_points [C_in C_out]]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ from deepviewagg_amd import fused_chain, ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 19
-C, Co = 256, 128
+C, Co = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 128)
 scene = bench.make_scene(1 << L, 32, 32, C, 64, 128, torch.bfloat16, dev, seed=4321, workload="S1", upscale=8)
 mods = bench.build_modules(C, dev, Co)
 for m in mods:
