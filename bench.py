@@ -503,6 +503,56 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warm
     return out
 
 
+def kitti360_pyramid_eval(device, log2_points, views, steps=3):
+    """Inference (eval mode, no_grad) of the view pooling over the five pyramid levels of the reference's published
+    KITTI-360 model (conf/models/segmentation/multimodal/sparseconv3d.yaml:7281-7290: in_mod -> out_mod = 128 -> 32,
+    64 -> 32, 128 -> 64, 256 -> 128, 512 -> 256, interpolate=True, G = 4) at the S1 scene size: ms per forward and
+    level, all five on the one fused kernel (bilinear taps of Linear_a(x) -> E_mod -> attention -> pooled features)."""
+    from deepviewagg_amd import ops, fused_bilinear
+    N = 1 << log2_points
+    out = {"points": N, "views": N * views, "levels": {}}
+    total = 0.0
+    for C, Co in ((128, 32), (64, 32), (128, 64), (256, 128), (512, 256)):
+        scene = make_scene(N, views, 32, C, 64, 128, torch.bfloat16, device, seed=4321, workload="S1", upscale=8)
+        atomic_pool, view_pool, fusion = build_modules(C, device, Co)
+        view_pool.eval()
+        used = []
+        orig = fused_bilinear.pool
+
+        def spy(*a, **k):
+            used.append(1)
+            return orig(*a, **k)
+
+        def forward():
+            x = scene["x"]
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                packed = ops.pack_gather_index(scene["images"], scene["atom_ptr"], scene["pixels"], ratio=1.0)
+                res = torch.tensor([scene["mapping_size"]], dtype=torch.float32, device=x.device)
+                coords = (scene["pixels"] / (res - 1))[:, [1, 0]]
+                x_mod = ops.lazy_gather_bilinear(x, packed, coords, True)
+                x_mod = atomic_pool(None, x_mod, None, scene["atom_ptr"])
+                return fusion(scene["x_3d"], view_pool(scene["x_3d"], x_mod, scene["x_map"], scene["csr"]))
+        fused_bilinear.pool = spy
+        try:
+            with torch.no_grad():
+                forward()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    forward()
+                torch.cuda.synchronize()
+        finally:
+            fused_bilinear.pool = orig
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        total += ms
+        out["levels"][f"{C}_to_{Co}"] = {"ms": ms, "fused_kernel": len(used) == steps + 1}
+        del scene, atomic_pool, view_pool, fusion
+        torch.cuda.empty_cache()
+    out["ms_all_levels"] = total
+    out["points_per_s"] = N / (total * 1e-3)
+    return out
+
+
 def neighborhood_bench(device, n_points=1 << 20, k=50, n_images=32, views_per_point=8):
     """Secondary measurement: K-NN (k = 50, the S3DIS setting) over a 1M-point
     surface cloud + per-view occlusion, next to an exact KD-tree (scipy, 1 host core) on a 2^15-point sample
@@ -762,6 +812,7 @@ def main():
                                                             interpolate=True, C_out=32),
                 # the reference's default arithmetic (no autocast, fp32 features): S1 shapes on the fp32 chain
                 "f32": secondary_workload("f32", device, torch.float32, args.log2_points, views, 64),
+                "kitti360_pyramid_eval": kitti360_pyramid_eval(device, args.log2_points, views),
             }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
