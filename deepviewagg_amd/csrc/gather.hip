@@ -184,6 +184,74 @@ __global__ __launch_bounds__(256) void gather_bilinear_fwd_kernel(
   }
 }
 
+// The same gather with 16-byte accesses: `lpr` = C / VEC lanes (a power of two) cover one atom's row, the taps are
+// evaluated once per lane instead of once per element, the arithmetic per element is the scalar kernel's (same
+// operation order, no fma: bit-identical output).  The scalar kernel moved 2.8 TB/s at C = 256 (bf16): 2-byte loads,
+// a 64-bit division and the tap arithmetic per element.
+template <typename T>
+struct GVec;
+template <>
+struct GVec<float> {
+  static constexpr int N = 4;
+  typedef float4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+  static __device__ __forceinline__ raw pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <>
+struct GVec<bf16_t> {
+  static constexpr int N = 8;
+  typedef uint4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float* f) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ raw pack(const float* f) {
+    uint4 r;
+    r.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    r.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    r.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    r.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    return r;
+  }
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bilinear_fwd_vec_kernel(
+    const T* __restrict__ x, const PackedIdx* __restrict__ idx, const float* __restrict__ coords,
+    T* __restrict__ out, int64_t n_atoms, int H, int W, int C, int lpr) {
+  constexpr int VEC = GVec<T>::N;
+  typedef typename GVec<T>::raw raw_t;
+  const int lane = threadIdx.x & 63, lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
+  const int64_t col = (int64_t)lane_r * VEC;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p0 = wave * slots; p0 < n_atoms; p0 += n_waves * slots) {
+    const int64_t p = p0 + slot;
+    if (p >= n_atoms) continue;
+    const Taps tp = bilinear_taps(idx[p], coords[2 * p], coords[2 * p + 1], H, W);
+    const raw_t r0 = *reinterpret_cast<const raw_t*>(x + tp.tl * C + col);
+    const raw_t r1 = *reinterpret_cast<const raw_t*>(x + tp.tr * C + col);
+    const raw_t r2 = *reinterpret_cast<const raw_t*>(x + tp.bl * C + col);
+    const raw_t r3 = *reinterpret_cast<const raw_t*>(x + tp.br * C + col);
+    float a[VEC], b[VEC], c[VEC], d[VEC], o[VEC];
+    GVec<T>::unpack(r0, a);
+    GVec<T>::unpack(r1, b);
+    GVec<T>::unpack(r2, c);
+    GVec<T>::unpack(r3, d);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float acc = __fmul_rn(tp.w_tl, a[e]);
+      acc = __fadd_rn(acc, __fmul_rn(tp.w_tr, b[e]));
+      acc = __fadd_rn(acc, __fmul_rn(tp.w_bl, c[e]));
+      o[e] = __fadd_rn(acc, __fmul_rn(tp.w_br, d[e]));
+    }
+    *reinterpret_cast<raw_t*>(out + p * C + col) = GVec<T>::pack(o);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_bilinear_bwd_kernel(
     const T* __restrict__ gout, const PackedIdx* __restrict__ idx, const float* __restrict__ coords,
@@ -425,6 +493,21 @@ int dva_gather_bilinear_fwd(const void* x, const void* packed_idx, const float* 
   if (!x || !packed_idx || !coords || !out) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   const PackedIdx* idx = (const PackedIdx*)packed_idx;
+  const int vec = dtype == DVA_F32 ? 4 : 8, lpr = C / vec;
+  const bool vec_ok = (C % vec) == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 &&
+                      ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (vec_ok) {
+    const int slots = 64 / lpr;
+    const int gridv = grid_for(((n_atoms + slots - 1) / slots) * 64);
+    if (dtype == DVA_F32)
+      hipLaunchKernelGGL((gather_bilinear_fwd_vec_kernel<float>), dim3(gridv), dim3(256), 0, s, (const float*)x, idx,
+                         coords, (float*)out, n_atoms, H, W, C, lpr);
+    else
+      hipLaunchKernelGGL((gather_bilinear_fwd_vec_kernel<bf16_t>), dim3(gridv), dim3(256), 0, s, (const bf16_t*)x, idx,
+                         coords, (bf16_t*)out, n_atoms, H, W, C, lpr);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   const int grid = grid_for(n_atoms * (int64_t)C);
   if (dtype == DVA_F32)
     hipLaunchKernelGGL((gather_bilinear_fwd_kernel<float>), dim3(grid), dim3(256), 0, s,

@@ -609,3 +609,31 @@ def test_bilinear_scatter_with_batchnorm_backward(C):
     ref_gram = reference(torch.where((anchors == B * (H + 1) * (W + 1)).unsqueeze(1), z_a.float(), z_full))
     close(got_gram, ref_gram, rtol=1e-4, atol=2e-4)
     assert float((got_gram - got_rows).norm() / got_rows.norm()) < 5e-3
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.bfloat16, 64), (torch.bfloat16, 256), (torch.float32, 32), (torch.bfloat16, 20),
+                                     (torch.float32, 24), (torch.float32, 6)])
+def test_gather_bilinear_forward_is_bitwise_the_reference_expression(dtype, C):
+    """dva_gather_bilinear_fwd, vectorised (C / VEC a power of two: 16-byte accesses, taps once per lane) and scalar
+    kernels: out = ((w_tl X_tl + w_tr X_tr) + w_bl X_bl) + w_br X_br evaluated in fp32 in this order without fma, rounded
+    once to the feature dtype -- bit-identical to the same expression in torch on the taps of dva_gather_bilinear_taps."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C)
+    B, H, W, P = 3, 9, 14, 7001
+    x = torch.randn(B, C, H, W, generator=gen).to(dtype)
+    images = torch.randint(0, B, (P,), generator=gen)
+    pixels = torch.zeros(P, 2, dtype=torch.int16)
+    coords = torch.rand(P, 2, generator=gen)
+    coords[:50] = torch.tensor([0.0, 1.0])
+    coords[50:60] = torch.tensor([1.0, 0.0])
+    packed = ops.pack_gather_index(images.to(DEV), torch.arange(P + 1, device=DEV), pixels.to(DEV))
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.gather_bilinear(xd, packed, coords.to(DEV))
+    lazy = ops.lazy_gather_bilinear(xd, packed, coords.to(DEV), exact=True)
+    rows = lazy.rows.float()
+    r4, w4 = lazy.tap_rows.long(), lazy.tap_weights
+    acc = w4[:, 0:1] * rows[r4[:, 0]]
+    acc = acc + w4[:, 1:2] * rows[r4[:, 1]]
+    acc = acc + w4[:, 2:3] * rows[r4[:, 2]]
+    acc = acc + w4[:, 3:4] * rows[r4[:, 3]]
+    assert torch.equal(out, acc.to(dtype))
