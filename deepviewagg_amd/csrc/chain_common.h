@@ -188,6 +188,21 @@ __device__ __forceinline__ void run_tiles(const int2* __restrict__ tiles, int ta
   }
 }
 
+// the same loop without the prefetch (one register set): for kernels whose register budget decides the occupancy
+template <typename Pre, typename LoadF, typename BodyF>
+__device__ __forceinline__ void run_tiles_single(const int2* __restrict__ tiles, int ta, int tb, LoadF&& load,
+                                                 BodyF&& body) {
+  if (ta >= tb) return;
+  const int lane = threadIdx.x & 63;
+  const int last = tb - 1;
+  TileWindow tw;
+  tw.base = ta - 64;
+  for (int t = ta; t < tb; ++t) {
+    const Pre a = load(window_tile(tw, tiles, t, last, lane), t);
+    body(a);
+  }
+}
+
 // ---- layer pieces --------------------------------------------------------------------------------------------
 struct WOp {
   bf16x8 m[2];

@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
 //   the weighted segmented reduction over the row plan of the taps (dva_gather_rows_sum).
 // ------------------------------------------------------------------------------------------------
 template <int CO, int G, int STAGE>
-__global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void emod_bwd_kernel(
     const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ sma,
@@ -1029,7 +1029,11 @@ __global__ __launch_bounds__(256, (STAGE == 2 && CO > 32) ? 1 : 2) void emod_bwd
     ZaRows<NB> z;        // the stored z_a
     u32x4 rc;
   };
-  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+  auto loop = [&](auto&& ld, auto&& bd) {
+    if constexpr (STAGE == 2 && CO > 32) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
+    else run_tiles<Pre>(tiles, ta, tb, ld, bd);
+  };
+  loop([&](const TileInfo& ti, int t) {
     Pre p;
     p.ti = ti;
     const bool ok = j < p.ti.nv;
@@ -1298,7 +1302,7 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_L(CO_, G_, ST_)                                                                                     \
-  hipLaunchKernelGGL((emod_bwd_kernel<CO_, G_, ST_>), dim3(chain_grid((ST_ == 2 && CO_ > 32) ? 1 : 2)), block, 0, s, \
+  hipLaunchKernelGGL((emod_bwd_kernel<CO_, G_, ST_>), dim3(chain_grid(2)), block, 0, s, \
                      (const bf16_t*)Y, (const int4*)tap_rows, (const float4*)tap_weights, (const int2*)tiles,         \
                      n_tiles, (const uint4*)eops, bn_a, bn_b, sm_a, sm_b, (const uint32_t*)view_rec,                   \
                      (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points,       \
