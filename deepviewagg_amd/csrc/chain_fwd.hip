@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void pooled_kernel(const float* __restrict__ z
 // statistics of layer 5 (z5 = W5a a2 + u[point]) or layer 6 (train mode)
 // ------------------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256, 3) void stats_mid_kernel(
+__global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -938,7 +938,8 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
       (layer == 6 && !bn5))
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(3)), block(256);
+  // layer 5 fits 116 VGPRs: four blocks per CU; layer 6 (150) three
+  const dim3 grid(chain_grid(layer == 5 ? tune_int("DVA_STATS5_BPC", 4) : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layer == 5)
     hipLaunchKernelGGL((stats_mid_kernel<5>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
