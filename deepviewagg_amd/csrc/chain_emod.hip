@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, CO > 64 ? 1 : 2) void emod_attn_fwd_kernel(
 //   (S1 = sum dy_b | sum dy_b z_b with dy_b = leaky'(y_b) gate attention grad_out)
 // ------------------------------------------------------------------------------------------------
 template <int CO, int G>
-__global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
+__global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
     const float* __restrict__ compat, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
     const int32_t* __restrict__ n_tiles_dev, const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4,
     const float4* __restrict__ w4, const uint4* __restrict__ eops, const float* __restrict__ bna,
@@ -725,7 +725,12 @@ __global__ __launch_bounds__(256, 2) void emod_attn_bwd_kernel(
     int vpj;
     ZaRows<NB> z;        // the stored z_a
   };
-  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+  // C_o = 32: without the prefetch register set the kernel fits four wavefronts per SIMD
+  auto loop = [&](auto&& ld, auto&& bd) {
+    if constexpr (CO == 32) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
+    else run_tiles<Pre>(tiles, ta, tb, ld, bd);
+  };
+  loop([&](const TileInfo& ti, int t) {
     Pre p;
     p.ti = ti;
     p.t = t;
@@ -1264,7 +1269,7 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
     return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(2)), block(256);
+  const dim3 grid(chain_grid(C_out == 32 ? tune_int("DVA_EMOD_ABWD_BPC", 4) : 2)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_BWD(CO_, G_)                                                                                      \
   hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \
