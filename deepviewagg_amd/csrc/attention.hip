@@ -1177,8 +1177,11 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
   const int lane = threadIdx.x & 63;
   const int lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
   const int64_t col = (int64_t)lane_r * VEC;
-  float cg[AFF ? VEC : 1], ck1[AFF ? VEC : 1], ck2[AFF ? VEC : 1];
-  if (AFF) {
+  // AFF = 1: the constants of the lane's VEC positions live in registers (used per row); AFF = 2: they are needed
+  // once per anchor, by the slot-0 lanes: an LDS table [3][C] instead of 24 registers (118 -> 94 VGPRs)
+  float cg[AFF == 1 ? VEC : 1], ck1[AFF == 1 ? VEC : 1], ck2[AFF == 1 ? VEC : 1];
+  __shared__ float s_aff[AFF == 2 ? 3 * 512 : 1];
+  if (AFF == 1) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const int c = position_channel((int)col + e);
@@ -1187,6 +1190,16 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
       ck1[e] = g * (s1 - mean * inv * s2);
       ck2[e] = g * inv * s2;
     }
+  }
+  if (AFF == 2) {
+    for (int p = threadIdx.x; p < C; p += blockDim.x) {
+      const int c = position_channel(p);
+      const float mean = bn[c], inv = bn[C + c], g = bn[2 * C + c] * inv, s1 = sm[c], s2 = sm[C + c];
+      s_aff[p] = g;
+      s_aff[512 + p] = g * (s1 - mean * inv * s2);
+      s_aff[1024 + p] = g * inv * s2;
+    }
+    __syncthreads();
   }
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -1267,17 +1280,24 @@ __global__ __launch_bounds__(256) void anchor_rows_sum_kernel(const T* __restric
         // the four rows of Y every view of this anchor interpolates (border-replicated rows may coincide)
         const int4 tr = tap_rows[perm[beg]];
         const int rr[4] = {tr.x, tr.y, tr.z, tr.w};
-        float y[4][VEC];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(Y + (int64_t)rr[k] * C + col), y[k]);
         const float m4[4][4] = {{gm[0], gm[1], gm[2], gm[3]}, {gm[1], gm[4], gm[5], gm[6]},
                                 {gm[2], gm[5], gm[7], gm[8]}, {gm[3], gm[6], gm[8], gm[9]}};
+        float k2_[VEC];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int e = 0; e < VEC; ++e) {
+          const float g_ = s_aff[col + e], k1_ = s_aff[512 + col + e];
+          k2_[e] = s_aff[1024 + col + e];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float zs = fmaf(m4[k][0], y[0][e], fmaf(m4[k][1], y[1][e], fmaf(m4[k][2], y[2][e], m4[k][3] * y[3][e])));
-            acc[k][e] = fmaf(-ck2[e], zs, fmaf(cg[e], acc[k][e], -ck1[e] * w1[k]));
+          for (int k = 0; k < 4; ++k) acc[k][e] = fmaf(g_, acc[k][e], -k1_ * w1[k]);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {       // one row of Y at a time: 8 registers instead of 32
+          float y[VEC];
+          Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(Y + (int64_t)rr[k2] * C + col), y);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[k][e] = fmaf(-k2_[e] * m4[k][k2], y[e], acc[k][e]);
           }
         }
       }
@@ -1533,7 +1553,7 @@ int dva_anchor_rows_sum_bn(const void* dy_a, const void* z_a, const float* bn_a,
   if (!row_ptr || !S || !bn_a || !sm_a || (n_views > 0 && (!dy_a || !perm || !weights))) return DVA_ERR_INVALID;
   if ((z_a == nullptr) == (Y == nullptr) || (Y && !tap_rows)) return DVA_ERR_INVALID;      // exactly one of the two forms
   const int lpr = C / 8;
-  if ((C % 32) || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)dy_a % 16) || ((uintptr_t)z_a % 16) || ((uintptr_t)Y % 16) ||
+  if ((C % 32) || C > 512 || !is_pow2(lpr) || lpr > 64 || ((uintptr_t)dy_a % 16) || ((uintptr_t)z_a % 16) || ((uintptr_t)Y % 16) ||
       ((uintptr_t)S % 16) || ((uintptr_t)tap_rows % 16))
     return DVA_ERR_UNSUPPORTED;
   const dim3 grid(grid_cap((n_anchors + 3) / 4)), block(256);
