@@ -440,11 +440,22 @@ def timed_steps(scene, mods, dtype, steps, warmup, lazy=True, interpolate=False)
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(scene, None, mods, dtype, lazy=lazy, interpolate=interpolate)
+        out = step(scene, None, mods, dtype, lazy=lazy, interpolate=interpolate)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     timer, ops.TIMER = ops.TIMER, None
-    return ms, timer.summary()
+    kern = timer.summary()
+    kern["__sanity__"] = sanity_values(out, scene["x"].grad)
+    return ms, kern
+
+
+def sanity_values(out, x_grad):
+    """What the last timed step computed (a timing of an unverified computation is not a measurement):
+    mean |.| and finiteness of the fused features and of the feature-map gradient, outside the timed region."""
+    o, g = out.float(), x_grad.float()
+    return {"out_abs_mean": float(o.abs().mean()), "out_finite": bool(torch.isfinite(o).all()),
+            "grad_x_abs_mean": float(g.abs().mean()), "grad_x_finite": bool(torch.isfinite(g).all()),
+            "grad_x_rows_nonzero_frac": float((g.abs().sum(1) > 0).float().mean()) if g.dim() == 4 else None}
 
 
 def fused_fwd_bytes(V, N, C, es):
@@ -459,7 +470,7 @@ def fused_bwd_bytes(V, N, C, es, G=4):
     return V * (C * es + 16 + 8 + 16 + 16) + N * (C * es + 8)
 
 
-def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warmup=1, interpolate=False, C_out=None):
+def secondary_workload(name, device, dtype, log2_points, views, C, steps=10, warmup=2, interpolate=False, C_out=None):
     """One secondary workload of SURVEY.md 8(d) (S2: ragged view counts; F-L: C = 512, value map > MALL; bilinear:
     interpolate=True with the mapping at 8 x the map resolution): ms/step and the roofline fractions of the fused view
     kernel (forward) and of the attention backward kernel."""
@@ -468,20 +479,25 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warm
     scene = make_scene(N, views, 32, C, 64, 128, dtype, device, seed=4321, workload=wl, upscale=8 if interpolate else 1)
     mods = build_modules(C, device, C_out)
     ms, kern = timed_steps(scene, mods, dtype, steps, warmup, interpolate=interpolate)
+    sanity = kern.pop("__sanity__")
     if interpolate:
-        # the fused bilinear path against the reference's materialised [V, C] dataflow on the same scene
-        ms_mat, _ = timed_steps(scene, mods, dtype, 2, 1, lazy=False, interpolate=True)
+        # the fused bilinear path against the reference's materialised [V, C] dataflow on the same scene (same
+        # parameters: its sanity values are the yardstick of the fused path's)
+        ms_mat, kern_mat = timed_steps(scene, mods, dtype, 3, 1, lazy=False, interpolate=True)
+        sanity_mat = kern_mat.pop("__sanity__")
         top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:6]
         out = {"points": N, "views": int(scene["x_map"].shape[0]), "channels": C, "out_channels": C_out or C,
                "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "fused_path": "emod_attn_fwd" in kern,
                "materialised_ms_per_step": ms_mat, "speedup_vs_materialised": ms_mat / ms,
+               "steps": steps, "sanity": sanity, "sanity_materialised": sanity_mat,
                "top_kernels_ms": {n: v["ms"] / v["launches"] for n, v in top}}
         del scene, mods
         torch.cuda.empty_cache()
         return out
     V = int(scene["x_map"].shape[0])
     es = 2 if dtype == torch.bfloat16 else 4
-    out = {"points": N, "views": V, "channels": C, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3)}
+    out = {"points": N, "views": V, "channels": C, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "steps": steps,
+           "sanity": sanity}
     for key, nbytes in (("chain_attn_fwd", fused_fwd_bytes(V, N, C, es)), ("chain_attn_bwd", fused_bwd_bytes(V, N, C, es))):
         k = kern.get(key)
         if k is not None:
@@ -503,7 +519,7 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=3, warm
     return out
 
 
-def kitti360_pyramid_eval(device, log2_points, views, steps=3):
+def kitti360_pyramid_eval(device, log2_points, views, steps=10):
     """Inference (eval mode, no_grad) of the view pooling over the five pyramid levels of the reference's published
     KITTI-360 model (conf/models/segmentation/multimodal/sparseconv3d.yaml:7281-7290: in_mod -> out_mod = 128 -> 32,
     64 -> 32, 128 -> 64, 256 -> 128, 512 -> 256, interpolate=True, G = 4) at the S1 scene size: ms per forward and
@@ -539,13 +555,17 @@ def kitti360_pyramid_eval(device, log2_points, views, steps=3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(steps):
-                    forward()
+                    o = forward()
                 torch.cuda.synchronize()
         finally:
             fused_bilinear.pool = orig
         ms = (time.perf_counter() - t0) / steps * 1e3
         total += ms
-        out["levels"][f"{C}_to_{Co}"] = {"ms": ms, "fused_kernel": len(used) == steps + 1}
+        o = o.float()
+        out["levels"][f"{C}_to_{Co}"] = {"ms": ms, "fused_kernel": len(used) == steps + 1, "steps": steps,
+                                         "out_abs_mean": float(o.abs().mean()),
+                                         "out_finite": bool(torch.isfinite(o).all())}
+        del o
         del scene, atomic_pool, view_pool, fusion
         torch.cuda.empty_cache()
     out["ms_all_levels"] = total

@@ -13,6 +13,7 @@ cloud's own order (one admissible KD-tree order; tie-breaks depend on it, see vi
 """
 import torch
 
+from ...._lib import DvaError
 from ....utils.multimodal import MAPPING_KEY, lexargunique
 from ...multimodal import visibility as visibility_module
 from ...multimodal.image import ImageMapping, SameSettingImageData
@@ -34,13 +35,20 @@ class MapImages:
         return self._process(data, images)
 
     @staticmethod
-    def _batch_size(visi_model, n_points, n_images, budget_bytes=8 << 30):
+    def _batch_size(visi_model, n_points, n_images, budget_bytes=None):
         """Images per visibility batch: what fits ``budget_bytes`` of workspace + outputs (a 2048 x 1024 projection map
-        costs 42 MB of z-buffer / pixel maps per image, a candidate 100 bytes)."""
+        costs 42 MB of z-buffer / pixel maps per image, a candidate 100 bytes).  Default budget: a third of the
+        device memory that is free right now, at most 8 GiB (the preprocessing may share the GPU with a training
+        process).  ``dva_visibility_batch`` indexes candidates and map pixels of a batch with int32."""
+        if budget_bytes is None:
+            budget_bytes = 8 << 30
+            if torch.cuda.is_available():
+                budget_bytes = min(budget_bytes, torch.cuda.mem_get_info()[0] // 3)
         w, h = visi_model.img_size
         per_image = w * h * 20 + n_points * 100 + (n_points if getattr(visi_model, 'exact', False)
                                                    else max(n_points, w * h)) * 48
-        return int(max(1, min(n_images, budget_bytes // max(per_image, 1), 64)))
+        int32_cap = (2 ** 31 - 1) // max(n_points, w * h, 1)
+        return int(max(1, min(n_images, budget_bytes // max(per_image, 1), 64, int32_cap)))
 
     def _process(self, data, images: SameSettingImageData):
         assert hasattr(data, self.key)
@@ -71,21 +79,35 @@ class MapImages:
         image_ids, point_ids, features, pixels = [], [], [], []
         n_img = images.num_views
         step = self._batch_size(visi_model, xyz.shape[0], n_img)
-        for i0 in range(0, n_img, step):
-            sel = slice(i0, min(i0 + step, n_img))
 
+        def run_batch(sel):
             def part(attr):
                 return attr[sel].float() if attr is not None else None
-            out = visi_model.batch(
+            return visi_model.batch(
                 xyz, images.pos[sel].float(),
                 img_opk=part(images.opk) if images.has_opk else None,
                 img_intrinsic_pinhole=images.intrinsic_pinhole[sel].float() if images.is_pinhole else None,
                 img_intrinsic_fisheye=images.intrinsic_fisheye[sel].float() if images.is_fisheye else None,
                 img_extrinsic=part(images.extrinsic) if images.has_extrinsic else None,
                 img_mask=mask, linearity=lin, planarity=pla, scattering=sca, normals=nrm)
+        i0 = 0
+        while i0 < n_img:
+            sel = slice(i0, min(i0 + step, n_img))
+            try:
+                out = run_batch(sel)
+            except (DvaError, torch.cuda.OutOfMemoryError):
+                # the batch does not fit (workspace allocation, or more candidates x images than the kernels index):
+                # halve it, down to the reference's one image at a time (:238)
+                if step == 1:
+                    raise
+                step = max(1, step // 2)
+                torch.cuda.empty_cache()
+                continue
+            i0 = sel.stop
             if out['idx'].shape[0] == 0:
                 continue
-            img = out['image'] + i0
+            i0_batch = sel.start
+            img = out['image'] + i0_batch
             pid = point_index[out['idx']]
             off = images.crop_offsets.to(device)[img]
             px = out['x'].long() // images.proj_upscale - off[:, 0]

@@ -727,7 +727,11 @@ class SameSettingImageData:
         the gather is NOT materialised: an ``ops.GatheredFeatures`` is returned, which the pooling
         modules of this package consume directly (E_mod on the map rows, gather fused into the
         attention kernel); call ``.materialize()`` to obtain the reference's [P, C] tensor.
-        bilinear (``interpolate=True``): ``sparse_interpolation`` semantics -> [P, C] tensor."""
+        bilinear (``interpolate=True`` on a feature map below the mapping resolution): ``sparse_interpolation``
+        semantics.  With ``lazy=True`` and an exact mapping (one pixel per view) an ``ops.InterpolatedFeatures`` is
+        returned -- the four taps and weights of every view, no [P, C] tensor: ``GroupBimodalCSRPool`` evaluates E_mod
+        per view inside its kernels (``fused_bilinear``), everything else calls ``.materialize()``.  ``lazy=False``
+        (or a mapping with several pixels per view) returns the reference's [P, C] tensor."""
         scale = 1 / self.downscale
         if interpolate and scale != 1:
             dev = self.device

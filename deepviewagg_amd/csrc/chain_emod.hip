@@ -1275,7 +1275,8 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
     return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(C_out == 32 ? tune_int("DVA_EMOD_ABWD_BPC", 4) : 2)), block(256);
+  static const int bpc32 = tune_int("DVA_EMOD_ABWD_BPC", 4);      // read once (getenv), like the other switches
+  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : 2)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_BWD(CO_, G_)                                                                                      \
   hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(ZT_BLOCK) void tile_bin_kernel(
                 slot = atomicAdd(&tile_cursor[g], 1);
               }
               const int64_t pos = (int64_t)tile_off[g] + slot;
-              if (pos < cap) list[pos] = ent;
+              if (pos >= 0 && pos < cap) list[pos] = ent;      // (pos < 0: the int32 scan of the counts wrapped)
               else fb = true;
             }
         }
@@ -610,7 +610,8 @@ __global__ __launch_bounds__(256) void tile_raster_kernel(
   {
     const int64_t off = tile_off[tile];
     int64_t len = tile_count[tile];
-    if (off + len > cap) len = cap > off ? cap - off : 0;
+    if (off < 0) len = 0;
+    else if (off + len > cap) len = cap > off ? cap - off : 0;
     walk(list + off, len);
     int nb = ctl[b];
     if (nb > ZT_BIGCAP) nb = ZT_BIGCAP;
@@ -1006,7 +1007,9 @@ int dva_visibility_batch(const float* xyz, int64_t n, const dva_camera* cam0, co
   hipLaunchKernelGGL(splat_batch_kernel, dim3(grid_for(nc)), dim3(256), 0, s, xyz, idx1, simg, dist, xp, yp, cams_dev,
                      cnt, splat);
   static const int tiled = tune_int("DVA_ZBUF_TILED", 1);
-  if (tiled && cam0->img_w < 65536 && Hc < 65536) {      // (box corners are packed into 16 bits)
+  // (box corners are packed into 16 bits; tile_off is an int32 scan of up to ZT_BIG entries per candidate: beyond
+  //  2^31 - 1 possible entries the whole batch takes the atomic plane)
+  if (tiled && cam0->img_w < 65536 && Hc < 65536 && nc * ZT_BIG <= 0x7fffffffLL) {
     int32_t* tile_count = (int32_t*)(ws + L.tile_count);
     int32_t* tile_cursor = (int32_t*)(ws + L.tile_cursor);
     int32_t* ctl = (int32_t*)(ws + L.ctl);

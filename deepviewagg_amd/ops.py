@@ -402,6 +402,20 @@ def _anchor_ok(C, dtype):
     return C % vec == 0 and lpr > 0 and (lpr & (lpr - 1)) == 0 and lpr <= 64
 
 
+ANCHOR_WS_BYTES = None     # test hook: workspace budget of bilinear_scatter in bytes (None: from the free device memory)
+
+
+def _anchor_chunk_images(B, bytes_per_image, device):
+    """Images per pass of ``bilinear_scatter`` so that the per-anchor sums stay within the workspace budget."""
+    budget = ANCHOR_WS_BYTES
+    if budget is None:
+        if B * bytes_per_image <= (1 << 30):
+            return B                                   # small: no driver query on the common path
+        free, _ = torch.cuda.mem_get_info(device)
+        budget = max(min(free // 4, 8 << 30), 256 << 20)
+    return max(1, min(B, budget // max(bytes_per_image, 1)))
+
+
 def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=None):
     """Transpose of the bilinear gather: fp32 [B*H*W, C] = sum over the views and their 4 taps of weight x grad row.
     Views are grouped by ANCHOR (the padded cell of their top-left tap, ``dva_gather_bilinear_taps_anchor``): one
@@ -414,9 +428,9 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
     lib = _lib.load()
     grad = grad.contiguous()
     P, C = grad.shape
-    n_anchor = B * (H + 1) * (W + 1) + 1            # + the dummy anchor of views without the 2 x 2 structure
+    per_image = (H + 1) * (W + 1)
+    n_anchor = B * per_image + 1                    # + the dummy anchor of views without the 2 x 2 structure
     (perm, row_ptr), _ = row_plan(anchors, n_anchor, with_counts=False)
-    S = torch.empty((n_anchor, 4, C), dtype=torch.float32, device=grad.device)
     st = stream_of(grad)
     es = grad.element_size()
     if bn_backward is not None:
@@ -429,24 +443,33 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
                 raise _lib.DvaError("bilinear_scatter(bn_backward): Y bf16 [R, C]", -1)
             Y = Y.contiguous()
     two_rows = bn_backward is not None and bn_backward[3] is None
-    with _timed("bilinear_anchor_sum", P * (C * es * (2 if two_rows else 1) + 20) + n_anchor * 4 * C * 4):
-        if bn_backward is None:
-            check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(row_ptr), ptr(tap_weights), ptr(S), n_anchor, P, C,
-                                          dtype_code(grad), st), "dva_anchor_rows_sum")
-        else:
-            check(lib.dva_anchor_rows_sum_bn(ptr(grad), None if Y is not None else ptr(z_a), ptr(bn_a), ptr(sm_a),
-                                             ptr(perm), ptr(row_ptr), ptr(tap_weights),
-                                             ptr(tap_rows) if Y is not None else None, ptr(Y), ptr(S), n_anchor, P, C,
-                                             st), "dva_anchor_rows_sum_bn")
+    # The per-anchor sums S [anchors, 4, C] fp32 are 4 x the map gradient: bounded workspace, the images
+    # go through in chunks when it would exceed the budget (anchors are image-major, so a chunk of images is a
+    # contiguous range of the plan; the dummy anchor's views are added tap by tap by the fix-up below)
+    imgs = _anchor_chunk_images(B, per_image * 4 * C * 4, grad.device)
     out = torch.empty((B * H * W, C), dtype=torch.float32, device=grad.device)
-    with _timed("bilinear_anchor_combine", n_anchor * 4 * C * 4 + B * H * W * C * 4):
-        check(lib.dva_anchor_combine(ptr(S), ptr(out), B, H, W, C, st), "dva_anchor_combine")
-        if bn_backward is None:
-            check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, B, H, W, C,
-                                       dtype_code(grad), st), "dva_anchor_fixup")
-        else:
-            check(lib.dva_anchor_fixup_bn(ptr(grad), ptr(z_a), ptr(bn_a), ptr(sm_a), ptr(tap_rows), ptr(tap_weights),
-                                          ptr(anchors), ptr(out), P, B, H, W, C, st), "dva_anchor_fixup_bn")
+    S = torch.empty((min(imgs, B) * per_image + 1, 4, C), dtype=torch.float32, device=grad.device)
+    for b0 in range(0, B, imgs):
+        nb = min(imgs, B - b0)
+        a0, na = b0 * per_image, nb * per_image
+        rp = row_ptr[a0:a0 + na + 1]
+        with _timed("bilinear_anchor_sum", P * (C * es * (2 if two_rows else 1) + 20) * nb // B + na * 4 * C * 4):
+            if bn_backward is None:
+                check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(rp), ptr(tap_weights), ptr(S), na, P, C,
+                                              dtype_code(grad), st), "dva_anchor_rows_sum")
+            else:
+                check(lib.dva_anchor_rows_sum_bn(ptr(grad), None if Y is not None else ptr(z_a), ptr(bn_a), ptr(sm_a),
+                                                 ptr(perm), ptr(rp), ptr(tap_weights),
+                                                 ptr(tap_rows) if Y is not None else None, ptr(Y), ptr(S), na, P, C,
+                                                 st), "dva_anchor_rows_sum_bn")
+        with _timed("bilinear_anchor_combine", na * 4 * C * 4 + nb * H * W * C * 4):
+            check(lib.dva_anchor_combine(ptr(S), ptr(out[b0 * H * W:]), nb, H, W, C, st), "dva_anchor_combine")
+    if bn_backward is None:
+        check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, B, H, W, C,
+                                   dtype_code(grad), st), "dva_anchor_fixup")
+    else:
+        check(lib.dva_anchor_fixup_bn(ptr(grad), ptr(z_a), ptr(bn_a), ptr(sm_a), ptr(tap_rows), ptr(tap_weights),
+                                      ptr(anchors), ptr(out), P, B, H, W, C, st), "dva_anchor_fixup_bn")
     return out
 
 

@@ -229,6 +229,63 @@ def gen_pools_headline():
         save(name, **res)
 
 
+def gen_pools_bilinear():
+    """The fused bilinear path's shape (KITTI-360 level 0: C_in = 128 -> C_o = 32, G = 4; sparseconv3d.yaml:7281-7290)
+    run by the reference's own `sparse_interpolation` (core/multimodal/image.py:105-170, called as in
+    `get_mapped_features`, image.py:1278-1283) + `GroupBimodalCSRPool` (modules/multimodal/pooling.py:263-315): forward
+    + backward in train and eval mode on a ragged set with 32-view points, points with 40 / 70 views (> one tile),
+    unseen points and views on the image border (replicated padding).  Inputs lie on the bf16 grid so that the device
+    holds exactly the same values.  Held by tests/test_gpu_bilinear.py::test_fused_bilinear_against_reference_fixture
+    and tests/test_oracle_golden.py."""
+    print("sparse_interpolation + GroupBimodalCSRPool, fused bilinear shape (128 -> 32, G = 4)")
+    gen = torch.Generator().manual_seed(23)
+    B, C_in, H, W, C_o, UP = 3, 128, 8, 12, 32, 8
+    kwargs = dict(in_map=8, in_mod=C_in, out_mod=C_o, num_groups=4, use_mod=False, map_encoder='DeepSetFeat',
+                  use_num=True)
+    msize = (W * UP, H * UP)
+    for name, train in (("pool_group_bilinear_train", True), ("pool_group_bilinear_eval", False)):
+        n = 96
+        sizes = torch.randint(1, 9, (n,), generator=gen)
+        sizes[torch.rand(n, generator=gen) < 0.2] = 0
+        sizes[:8] = 32
+        sizes[8], sizes[9] = 40, 70
+        sizes = sizes[torch.randperm(n, generator=gen)]
+        csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+        V = int(csr[-1])
+        images = torch.randint(0, B, (V,), generator=gen)
+        pixels = torch.stack([torch.randint(0, msize[0], (V,), generator=gen),
+                              torch.randint(0, msize[1], (V,), generator=gen)], 1).short()
+        pixels[:8, 0] = torch.tensor([0, 0, msize[0] - 1, msize[0] - 1, 1, msize[0] - 2, 0, 5])
+        pixels[:8, 1] = torch.tensor([0, msize[1] - 1, 0, msize[1] - 1, 1, msize[1] - 2, 7, 0])
+        module = ref_pooling.GroupBimodalCSRPool(**kwargs)
+        randomize(module, gen)
+        with torch.no_grad():                 # E_mod's Linears at fan-in scale: activations stay O(1) over 128 inputs
+            for nme, p in module.named_parameters():
+                if nme.startswith('E_mod') and p.dim() == 2:
+                    p.mul_(2.0 / p.shape[1] ** 0.5)
+        module.train(train)
+        sd = state(module)
+        x = torch.randn(B, C_in, H, W, generator=gen).bfloat16().float().requires_grad_()
+        x_map = torch.rand(V, 8, generator=gen)
+        # image.py:1278-1283 (get_mapped_features, interpolate=True)
+        resolution = torch.Tensor([msize])
+        coords = (pixels / (resolution - 1))[:, [1, 0]]
+        x_mod = ref_image.sparse_interpolation(x, coords, images)
+        module.save_last = True
+        out = module(None, x_mod, x_map, csr)
+        w = torch.randn(out.shape, generator=gen)
+        params = [p for p in module.parameters()]
+        grads = torch.autograd.grad((out * w).sum(), [x] + params, allow_unused=True)
+        res = dict(csr=csr, images=images, pixels=pixels, mapping_size=np.array(msize), x=x, x_map=x_map, w=w,
+                   out=out, x_interp_head=x_mod[:64], train=np.array(int(train)), grad_x=grads[0], last_A=module._last_A)
+        for (nme, p), g in zip(module.named_parameters(), grads[1:]):
+            res['gp/' + nme] = g if g is not None else torch.zeros_like(p)
+        res.update(state(module, prefix='sd_after/'))
+        res.update(sd)
+        res['kwargs'] = np.array(repr(kwargs))
+        save(name, **res)
+
+
 # ------------------------------------------------------------------------------------------------
 def gen_gather():
     print("get_mapped_features: nearest (after downscale) and bilinear (sparse_interpolation)")
@@ -816,6 +873,7 @@ if __name__ == "__main__":
     np.random.seed(0)
     only = set(sys.argv[1:])
     jobs = dict(softmax=gen_softmax, segment=gen_segment, pools=gen_pools, pools_headline=gen_pools_headline,
+                pools_bilinear=gen_pools_bilinear,
                 gather=gen_gather,
                 branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
                 transforms=gen_transforms, cylinder=gen_mapping_cylinder,

@@ -295,3 +295,107 @@ def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G, C_out):
     assert rel(out, out_grad) < 2e-2
     unseen = (case["csr"][1:] == case["csr"][:-1])
     assert float(out.float().cpu()[unseen].abs().max() if unseen.any() else 0.0) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The fused bilinear path against a fixture written by the REFERENCE's own sparse_interpolation +
+# GroupBimodalCSRPool (oracle/gen_golden.py pools_bilinear; core/multimodal/image.py:105-170,1278-1283,
+# modules/multimodal/pooling.py:263-315): C_in 128 -> C_o 32, G = 4, points with 32 / 40 / 70 views, unseen points,
+# border pixels, train and eval mode.  Gates as in test_chain_against_reference_fixture.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pool_group_bilinear_train", "pool_group_bilinear_eval"])
+def test_fused_bilinear_against_reference_fixture(name):
+    import ast
+    from conftest import load_golden, t, state_dict_from
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    g = load_golden(name)
+    kwargs = ast.literal_eval(str(g["kwargs"]))
+    train = bool(g["train"])
+    msize = tuple(int(v) for v in g["mapping_size"])
+    case = dict(csr=t(g["csr"]), V=int(g["csr"][-1]), images=t(g["images"]), pixels=t(g["pixels"]), x=t(g["x"]),
+                x_map=t(g["x_map"]), N=len(g["csr"]) - 1, C=kwargs["in_mod"], msize=msize)
+    w = t(g["w"])
+    m = P.GroupBimodalCSRPool(**kwargs)
+    m.load_state_dict(state_dict_from(g), strict=True)
+    m = m.to(DEV).train(train)
+    out, grads, used = run_dev(case, m, w, fused=True)
+    assert used["fn"] == "_EmodPoolBackward", f"the fused bilinear path must be the one that ran ({used})"
+    # yardstick: the oracle under autocast against the same fixture
+    ref = O.GroupBimodalCSRPool(**kwargs)
+    ref.load_state_dict(state_dict_from(g), strict=True)
+    ref.train(train)
+    out_amp, g_amp = oracle(case, ref, w, autocast=True)
+    r, r_amp = rel(out, t(g["out"])), rel(out_amp, t(g["out"]))
+    print(f"fused bilinear vs reference fixture {name}: out {r:.4f} (oracle under autocast {r_amp:.4f})")
+    assert r < max(2e-2, 1.5 * r_amp), (r, r_amp)
+    unseen = case["csr"][1:] == case["csr"][:-1]
+    assert float(out.detach().float().cpu()[unseen].abs().max()) == 0.0
+    names = ["x"] + [n for n, _ in m.named_parameters()]
+    refs = [t(g["grad_x"])] + [t(g["gp/" + n]) for n in names[1:]]
+    amps = sorted(rel(c, b) for n, b, c in zip(names, refs, g_amp)
+                  if c is not None and (n.startswith("E_map") or n.startswith("E_mod")))
+    med = amps[len(amps) // 2]
+    bad, report = [], []
+    for n, a, b, c in zip(names, grads, refs, g_amp):
+        assert a is not None, f"no gradient for {n}"
+        if float(b.abs().max()) == 0:
+            assert float(a.abs().max()) == 0, n
+            continue
+        ours, amp = rel(a, b), (rel(c, b) if c is not None else 0.0)
+        report.append((n, round(ours, 4), round(amp, 4)))
+        if n.startswith("E_map") or n.startswith("E_mod"):
+            amp = max(amp, med)
+        loose = n.startswith("G.") or n.startswith("E_score")
+        if ours > max((4.0 if loose else 2.0) * amp, 5e-2):
+            bad.append(report[-1])
+    print("fused bilinear vs reference fixture, gradients (ours, oracle under autocast):", report)
+    assert not bad, (bad, report)
+    if train:
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                torch.testing.assert_close(v.cpu(), t(g["sd_after/" + k]), rtol=2e-2, atol=2e-3)
+
+
+def test_anchor_scatter_workspace_chunks_and_gram_form():
+    """(a) the per-anchor workspace of ``ops.bilinear_scatter`` is bounded -- with a budget of one image per
+    pass the map gradient is bit-identical to the one-pass result; (b) the BatchNorm_a backward at the level of the
+    anchor (Gram matrix of the tap weights x unrounded interpolation of Y, ``DVA_ANCHOR_GRAM=1``, the default) against
+    the row-by-row form on the stored bf16 z_a: equal to bf16 rounding of z_a (2^-9 relative per value)."""
+    from deepviewagg_amd import ops, fused_bilinear
+    case = make_case(9, 1800, 64, ragged, B=4)
+    w = torch.randn(1800, 64, generator=case["gen"])
+    _, m = build(case, 64, 4, True)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def gx(budget, gram):
+        m.load_state_dict(sd)
+        ops.ANCHOR_WS_BYTES, old = budget, fused_bilinear.ANCHOR_GRAM
+        fused_bilinear.ANCHOR_GRAM = gram
+        try:
+            _, g, used = run_dev(case, m, w, fused=True)
+        finally:
+            ops.ANCHOR_WS_BYTES, fused_bilinear.ANCHOR_GRAM = None, old
+        assert used["fn"] == "_EmodPoolBackward"
+        return g[0]
+    g_one = gx(None, True)
+    g_chunks = gx(13 * 21 * 4 * 64 * 4 * 1 + 8, True)        # one image of (H + 1)(W + 1) anchors per pass
+    assert torch.equal(g_one, g_chunks)
+    g_rows = gx(None, False)
+    assert rel(g_one, g_rows) < 5e-3, rel(g_one, g_rows)
+    # the materialised gather's backward goes through the same scatter (fp32 and bf16 rows)
+    for dt in (torch.float32, torch.bfloat16):
+        x = case["x"].to(DEV).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_()
+        V = case["V"]
+        packed = ops.pack_gather_index(case["images"].to(DEV), torch.arange(V + 1, device=DEV), case["pixels"].to(DEV))
+        res = torch.tensor([case["msize"]], dtype=torch.float32, device=DEV)
+        coords = (case["pixels"].to(DEV) / (res - 1))[:, [1, 0]]
+        go = torch.randn(V, 64, device=DEV, dtype=dt)
+        outs = []
+        for budget in (None, 13 * 21 * 4 * 64 * 4 * 2):
+            ops.ANCHOR_WS_BYTES = budget
+            try:
+                (g_,) = torch.autograd.grad(ops.gather_bilinear(x, packed, coords), x, go)
+            finally:
+                ops.ANCHOR_WS_BYTES = None
+            outs.append(g_)
+        assert torch.equal(outs[0], outs[1])

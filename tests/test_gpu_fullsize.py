@@ -257,3 +257,148 @@ def test_chain3_full_size_properties():
         sl = slice(0, n_s * VIEWS)
         ref = fused_deepset.deepset_linear(m.E_map, m.E_score, x_map[sl].contiguous(), csr[:n_s + 1].contiguous())
     torch.testing.assert_close(e1[sl], ref, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The fused bilinear path (fused_bilinear._EmodPool -> dva_emod_*, interpolate=True) at the size bench.py times it
+# (VERDICT r3 "next 1a"): N = 2^20 points x 32 views = 33.5 M views for 64 -> 64 (z_a / dy_a are exactly 4 GiB there:
+# one buffer descriptor per tile) and for the KITTI-360 pair 128 -> 32, and one scene just below the 32-bit limits
+# `fused_bilinear.applicable` guards.
+# ---------------------------------------------------------------------------------------------------------------
+UP = 8
+
+
+def _bilinear_scene(n_points, C_in, C_out, seed, unseen_frac=0.05):
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    k = torch.full((n_points,), VIEWS, device=DEV, dtype=torch.int64)
+    k[torch.rand(n_points, generator=g, device=DEV) < unseen_frac] = 0           # unseen points: output exactly 0
+    csr = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), k.cumsum(0)])
+    V = int(csr[-1])
+    images = torch.randint(0, B, (V,), generator=g, device=DEV)
+    pixels = torch.stack([torch.randint(0, W * UP, (V,), generator=g, device=DEV),
+                          torch.randint(0, H * UP, (V,), generator=g, device=DEV)], 1).to(torch.int16)
+    x = torch.randn(B, C_in, H, W, generator=g, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    x_map = torch.rand(V, 8, generator=g, device=DEV)
+    w = (torch.randn(n_points, C_out, generator=g, device=DEV) / n_points).bfloat16()
+    torch.manual_seed(seed)
+    m = P.GroupBimodalCSRPool(in_map=8, in_mod=C_in, out_mod=C_out, num_groups=G, use_num=True).to(DEV).train()
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if "batch_norm" in n_ or n_.startswith("G."):
+                p.add_(0.2 * torch.randn_like(p))
+    return dict(csr=csr, V=V, N=n_points, images=images, pixels=pixels, x=x, x_map=x_map, w=w, m=m, unseen=(k == 0),
+                C_in=C_in, C_out=C_out)
+
+
+def _bilinear_step(s, sl=None, fused=True, need_grad=True):
+    """forward + backward of interpolate=True through the data-flow objects; `sl`: the first `sl` points only."""
+    from deepviewagg_amd import ops, fused_chain
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    if sl is None:
+        csr, V, w = s["csr"], s["V"], s["w"]
+    else:
+        csr = s["csr"][:sl + 1].contiguous()
+        V, w = int(csr[-1]), s["w"][:sl].contiguous()
+    images, pixels, x_map = s["images"][:V], s["pixels"][:V].contiguous(), s["x_map"][:V].contiguous()
+    x = s["x"].clone().requires_grad_(need_grad)
+    atom_ptr = torch.arange(V + 1, device=DEV)
+    packed = ops.pack_gather_index(images, atom_ptr, pixels)
+    res = torch.tensor([[W * UP, H * UP]], dtype=torch.float32, device=DEV)
+    coords = (pixels / (res - 1))[:, [1, 0]]
+    fused_chain.FORCE = None if fused else False
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lazy = ops.lazy_gather_bilinear(x, packed, coords, exact=True)
+            lazy = P.BimodalCSRPool(mode='max')(None, lazy, None, atom_ptr)
+            out = s["m"](None, lazy, x_map, csr)
+        fn = type(out.grad_fn).__name__ if out.grad_fn is not None else None
+        if fused and need_grad:
+            assert fn == "_EmodPoolBackward", f"the fused bilinear path must be the one that ran ({fn})"
+        grads = None
+        if need_grad:
+            grads = torch.autograd.grad(out, [x] + list(s["m"].parameters()), grad_outputs=w.to(out.dtype),
+                                        allow_unused=True)
+    finally:
+        fused_chain.FORCE = None
+    return out, grads
+
+
+@pytest.mark.parametrize("C_in,C_out", [(64, 64), (128, 32)])
+def test_fused_bilinear_full_size_properties(C_in, C_out):
+    """Determinism, exact zeros on unseen points, finite parameter gradients, and the conservation law of the train-mode
+    feature-map gradient: BatchNorm_a's backward removes the batch mean of dz_a, the interpolation weights of a view sum
+    to one, so the gradient of Y = x W_a^T sums to ~0 over the map rows per channel -- and with it the gradient of x
+    (a statement about the anchor plan + Gram-matrix BatchNorm backward at V = 31.9 M)."""
+    s = _bilinear_scene(N, C_in, C_out, seed=29)
+    assert s["V"] * C_out * 2 > (1 << 31), "the view-sized rows of this case need more than 31 offset bits"
+    state = {k: v.clone() for k, v in s["m"].state_dict().items()}
+    out1, g1 = _bilinear_step(s)
+    s["m"].load_state_dict(state)
+    out2, g2 = _bilinear_step(s)
+    s["m"].load_state_dict(state)
+    assert out1.dtype == torch.bfloat16 and out1.shape == (N, C_out)
+    assert bool(torch.isfinite(out1.float()).all())
+    assert torch.equal(out1, out2)                         # no atomics on the outputs, deterministic statistics
+    assert torch.equal(g1[0], g2[0])                       # anchor plan: segmented reduction in a fixed order
+    assert float(out1[s["unseen"]].float().abs().max()) == 0.0
+    seen_norm = out1[~s["unseen"]].float().abs().mean()
+    assert float(seen_norm) > 1e-3                         # the seen points carry a signal
+    for (n_, _), a, b in zip(s["m"].named_parameters(), g1[1:], g2[1:]):
+        assert a is not None and bool(torch.isfinite(a).all()), n_
+        assert float((a - b).norm() / (a.norm() + 1e-30)) < 1e-3, n_
+    gx = g1[0].float()
+    assert bool(torch.isfinite(gx).all()) and float(gx.abs().sum()) > 0
+    per_channel = gx.sum(dim=(0, 2, 3)).abs() / (gx.abs().sum(dim=(0, 2, 3)) + 1e-30)
+    assert float(per_channel.max()) < 2e-3, float(per_channel.max())
+
+
+@pytest.mark.parametrize("C_in,C_out", [(64, 64), (128, 32)])
+def test_fused_bilinear_full_size_slice(C_in, C_out):
+    """Eval mode (running statistics: a point's output depends on its own views only): the first 2^16 points of the
+    full-size run are bit-identical to a run on that slice alone, and the slice agrees with the materialised dataflow
+    (gather_bilinear -> [V, C] -> E_mod rows -> first-generation attention kernels) within 2e-2 / 5e-2."""
+    s = _bilinear_scene(N, C_in, C_out, seed=31)
+    s["m"].eval()
+    sl = 1 << 16
+    out_full, g_full = _bilinear_step(s)
+    out_sl, g_sl = _bilinear_step(s, sl=sl)
+    assert torch.equal(out_full[:sl], out_sl)
+    out_b, g_b = _bilinear_step(s, sl=sl, fused=False)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+    assert rel(out_sl, out_b) < 2e-2, rel(out_sl, out_b)
+    assert rel(g_sl[0], g_b[0]) < 5e-2, rel(g_sl[0], g_b[0])
+    assert float(out_full[s["unseen"]].float().abs().max()) == 0.0
+
+
+def test_fused_bilinear_just_below_the_applicable_limits():
+    """`fused_bilinear.applicable` admits V x 64 < 2^32 - 16 (the chain's 64-byte handed rows / 32-byte x_map rows use
+    32-bit buffer offsets): a 128 -> 32 scene with V = 2^26 - 64 x 32 views runs on the fused path, is deterministic and
+    keeps the slice property; one more point and the module takes the materialised path instead of overflowing."""
+    from deepviewagg_amd import fused_bilinear, ops
+    n = (1 << 21) - 64
+    s = _bilinear_scene(n, 128, 32, seed=37, unseen_frac=0.0)
+    assert s["V"] == n * VIEWS and s["V"] * 64 < (1 << 32) - 16 and (s["V"] + 33 * VIEWS) * 64 >= (1 << 32) - 16
+    s["m"].eval()
+    out, g = _bilinear_step(s)
+    assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(g[0].float()).all())
+    sl = 1 << 14
+    out_sl, _ = _bilinear_step(s, sl=sl)
+    assert torch.equal(out[:sl], out_sl)
+    # the last tile of the scene (the highest 32-bit offsets) against a run on the last points alone
+    tail = 1 << 12
+    t = dict(s)
+    V0 = int(s["csr"][n - tail])
+    t.update(csr=(s["csr"][n - tail:] - V0).contiguous(), V=s["V"] - V0, N=tail, images=s["images"][V0:],
+             pixels=s["pixels"][V0:], x_map=s["x_map"][V0:], w=s["w"][n - tail:])
+    out_t, _ = _bilinear_step(t)
+    assert torch.equal(out[n - tail:], out_t)
+    # the guard itself
+    fake = ops.InterpolatedFeatures.__new__(ops.InterpolatedFeatures)
+    fake.exact, fake.rows = True, s["x"].permute(0, 2, 3, 1).reshape(-1, 128)
+    csr_fake = torch.zeros(n + 1, dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        for lim, ok in ((s["V"], True), (1 << 26, False)):
+            fake.tap_rows = torch.empty((1, 4), dtype=torch.int32, device=DEV).expand(lim, 4)
+            x_map_fake = torch.empty((1, 8), device=DEV).expand(lim, 8)
+            assert fused_bilinear.applicable(s["m"], fake, x_map_fake, csr_fake) == ok, (lim, ok)

@@ -127,6 +127,31 @@ def test_pool_headline_shape(name):
             close(v, g["sd_after/" + k], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["pool_group_bilinear_train", "pool_group_bilinear_eval"])
+def test_pool_bilinear_shape(name):
+    """The fused bilinear path's shape (sparse_interpolation -> E_mod 128 -> 32 per view -> view attention; points with
+    32 / 40 / 70 views, border pixels): the oracle against the reference's own forward + backward
+    (oracle/gen_golden.py pools_bilinear)."""
+    g = load_golden(name)
+    m, _ = build_oracle_pool(name, g)
+    csr = t(g["csr"])
+    x = t(g["x"]).requires_grad_()
+    x_mod = O.gather_bilinear(x, t(g["images"]), t(g["pixels"]), tuple(int(v) for v in g["mapping_size"]))
+    close(x_mod[:64], g["x_interp_head"], rtol=1e-5, atol=1e-6)
+    out = m(None, x_mod, t(g["x_map"]), csr)
+    close(out, g["out"], rtol=1e-4, atol=1e-5)
+    names = [n for n, _ in m.named_parameters()]
+    grads = torch.autograd.grad((out * t(g["w"])).sum(), [x] + list(m.parameters()), allow_unused=True)
+    close(grads[0], g["grad_x"], rtol=1e-3, atol=1e-5)
+    for n, gr in zip(names, grads[1:]):
+        ref = t(g["gp/" + n])
+        gr = gr if gr is not None else torch.zeros_like(ref)
+        close(gr, ref, rtol=2e-3, atol=5e-5)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g["sd_after/" + k], rtol=1e-4, atol=1e-6)
+
+
 def test_simple_pools_and_fusion():
     g = load_golden("pool_simple")
     csr, x_mod, x_map = t(g["csr"]), t(g["x_mod"]), t(g["x_map"])
