@@ -977,7 +977,9 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
     const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
     const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ row_ptr, const float* __restrict__ rec, int rs,
-    float* __restrict__ grows, int64_t R, int C, int G, int lpr, int lpg) {
+    float* __restrict__ grows, int64_t R, int C, int G, int lpr, int lpg, int c0 = 0) {
+  // C = row stride in elements; a launch covers the channels [c0, c0 + lpr * VEC) of every row (c0 = 0, lpr * VEC = C:
+  // whole rows; channel slabs: dva_view_gather_rows_grad_rec16)
   constexpr int VEC = Vec16<T>::N;
   constexpr int U = 4;
   typedef typename Vec16<T>::raw raw_t;
@@ -985,8 +987,8 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
   const int lane_r = lane & (lpr - 1);
   const int slot = lane / lpr;
   const int slots = 64 / lpr;
-  const int g_lane = lane_r / lpg;
-  const int64_t col = (int64_t)lane_r * VEC;
+  const int g_lane = (c0 / VEC + lane_r) / lpg;
+  const int64_t col = (int64_t)c0 + (int64_t)lane_r * VEC;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < R; r += n_waves) {
@@ -1484,10 +1486,18 @@ int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, c
   if ((C % 8) || !is_pow2(lpr) || lpr > 64 || (C % G) || ((C / G) % 8) || ((uintptr_t)grad_out % 16) ||
       ((uintptr_t)grad_rows % 16))
     return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true>), dim3(grid_cap((n_rows + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr, (const float*)nullptr,
-                     (const int32_t*)nullptr, perm, row_ptr, (const float*)view_rec16, 4, grad_rows, n_rows, (int)C,
-                     (int)G, lpr, lpr / G);
+  // wide rows in channel slabs (one launch per slab: the slab of grad_out, n_points x slab x 2 bytes, is what the
+  // 32 re-reads of a point's row hit): DVA_ROWS_GRAD_SLAB = channels per slab, 0 = whole rows (A/B in profiles/r04*)
+  static const int slab_env = tune_int("DVA_ROWS_GRAD_SLAB", 0);
+  int slab = slab_env;
+  if (slab <= 0 || slab >= C || (slab % 8) || !is_pow2(slab / 8) || (C % slab)) slab = C;
+  const int lpr_s = slab / 8;
+  for (int c0 = 0; c0 < C; c0 += slab) {
+    hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true>), dim3(grid_cap((n_rows + 3) / 4)),
+                       dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr,
+                       (const float*)nullptr, (const int32_t*)nullptr, perm, row_ptr, (const float*)view_rec16, 4,
+                       grad_rows, n_rows, (int)C, (int)G, lpr_s, lpr / G, c0);
+  }
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -212,6 +212,95 @@ __device__ __forceinline__ void linear_b_std(const uint4* s_eops, int lane, cons
     zb[mb] = acc;
   }
 }
+// ---- wide rows (C_o >= 128: NB >= 4 blocks) ---------------------------------------------------------------------------
+// The register-resident forms above hold every block of a view at once (z_a, z_b: 2 x 16 NB fp32 registers); from four
+// blocks on the passes go OUTPUT BLOCK BY OUTPUT BLOCK: the packed activation of all input blocks (8 NB registers) stays,
+// one 32 x 32 product is live at a time and its epilogue runs before the next one starts.
+template <int NB>
+__device__ __forceinline__ f32x16 linear_b_flipped_blk(const uint4* s_eops, int lane, const bf16x8 (&a)[NB][2], int mb) {
+  asm volatile("" ::: "memory");
+  f32x16 acc = {0};
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc = CH_MFMA(a[b][m], lds_op(s_eops, op_fwd<NB>(mb, b, m), lane), acc);
+  }
+  return acc;
+}
+template <int NB>
+__device__ __forceinline__ f32x16 linear_b_std_blk(const uint4* s_eops, int lane, const bf16x8 (&a)[NB][2], int mb) {
+  asm volatile("" ::: "memory");
+  f32x16 acc = {0};
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc = CH_MFMA(lds_op(s_eops, op_fwd<NB>(mb, b, m), lane), a[b][m], acc);
+  }
+  return acc;
+}
+template <int NB>
+__device__ __forceinline__ void unpack_za_blk(const ZaRows<NB>& z, int b, f32x16& za) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t v[4] = {z.q[b][q].x, z.q[b][q].y, z.q[b][q].z, z.q[b][q].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      za[8 * q + 2 * i] = __uint_as_float(v[i] << 16);
+      za[8 * q + 2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+  }
+}
+// BatchNorm_a + LeakyReLU + bf16 packing straight from the packed rows, one block at a time
+template <int NB>
+__device__ __forceinline__ void act_a_rows(const ZaRows<NB>& z, const float (*taba)[TAB_FLOATS], int h, uint32_t keep,
+                                           bf16x8 (&a)[NB][2]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    f32x16 za;
+    unpack_za_blk<NB>(z, b, za);
+    act_pack(za, taba[b], h, keep, a[b]);
+  }
+}
+// Sums over the 32 views of a tile in the lane = view layout, without 32 accumulator registers per block: the wavefront
+// writes the packed block as a natural [view][column] tile (tileN_put_packed: column 16 h + r = accumulator register r
+// of half h, i.e. channel cperm(column)) and reads it back through the transpose read: lane (n, hh) receives the views
+// 8 hh .. 8 hh + 7 and 16 + 8 hh .. of column n -- 16 in-lane additions; the two half-waves hold the two halves of the
+// column sum (added at the flush).  x, y: values as stored (bf16).
+__device__ __forceinline__ void unpack8(const bf16x8& v, float (&f)[8]) {
+  const u32x4 u = __builtin_bit_cast(u32x4, v);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void col_sums(const bf16_t* tx, int lane, float& s, float& ss) {        // sum x | sum x^2
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float x[8];
+    unpack8(tileN_get(tx, lane, m), x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s += x[i];
+      ss = __builtin_fmaf(x[i], x[i], ss);
+    }
+  }
+}
+__device__ __forceinline__ void col_sums2(const bf16_t* tx, const bf16_t* ty, int lane, float& sx, float& sxy) {   // sum x | sum x y
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float x[8], y[8];
+    unpack8(tileN_get(tx, lane, m), x);
+    unpack8(tileN_get(ty, lane, m), y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sx += x[i];
+      sxy = __builtin_fmaf(x[i], y[i], sxy);
+    }
+  }
+}
+
 // per-lane BatchNorm constants of the flipped layer: channel 32 mb + (lane & 31)
 template <int NB>
 struct LaneBN {
@@ -253,8 +342,9 @@ __device__ __forceinline__ float other_half(float v) {     // value of lane ^ 32
 
 // deterministic block reduction of per-lane partials (one LDS slot per wavefront, fixed order, fp64) -> fp64 atomics
 // (v0, v1 of the lanes h = 0: channel base + (lane & 31)); s_red: 4 x 2 x 32 floats
+// nat: lane n holds image column n of a natural tile = channel base + cperm(n)
 __device__ __forceinline__ void flush_lane_stats(float v0, float v1, double* __restrict__ out0, double* __restrict__ out1,
-                                                 int base, float* s_red) {
+                                                 int base, float* s_red, bool nat = false) {
   const int wv = threadIdx.x >> 6, n = threadIdx.x & 31;
   __syncthreads();
   if ((threadIdx.x & 32) == 0) {
@@ -266,7 +356,8 @@ __device__ __forceinline__ void flush_lane_stats(float v0, float v1, double* __r
     const int which = threadIdx.x >> 5;
     double acc = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) acc += (double)s_red[(w * 2 + which) * 32 + n];
-    atomicAdd(which ? &out1[base + n] : &out0[base + n], acc);
+    const int c = base + (nat ? cperm(n) : n);
+    atomicAdd(which ? &out1[c] : &out0[c], acc);
   }
 }
 

@@ -263,13 +263,20 @@ def gen_pools_bilinear():
             for nme, p in module.named_parameters():
                 if nme.startswith('E_mod') and p.dim() == 2:
                     p.mul_(2.0 / p.shape[1] ** 0.5)
-        module.train(train)
-        sd = state(module)
         x = torch.randn(B, C_in, H, W, generator=gen).bfloat16().float().requires_grad_()
         x_map = torch.rand(V, 8, generator=gen)
         # image.py:1278-1283 (get_mapped_features, interpolate=True)
         resolution = torch.Tensor([msize])
         coords = (pixels / (resolution - 1))[:, [1, 0]]
+        if not train:
+            # an eval-mode model has running statistics that describe its data: twenty train-mode forwards of the
+            # reference module on this batch (momentum 0.1) bring the randomised buffers to within 12 % of them
+            module.train(True)
+            with torch.no_grad():
+                for _ in range(20):
+                    module(None, ref_image.sparse_interpolation(x, coords, images), x_map, csr)
+        module.train(train)
+        sd = state(module)
         x_mod = ref_image.sparse_interpolation(x, coords, images)
         module.save_last = True
         out = module(None, x_mod, x_map, csr)

@@ -331,7 +331,8 @@ def test_fused_bilinear_full_size_properties(C_in, C_out):
     to one, so the gradient of Y = x W_a^T sums to ~0 over the map rows per channel -- and with it the gradient of x
     (a statement about the anchor plan + Gram-matrix BatchNorm backward at V = 31.9 M)."""
     s = _bilinear_scene(N, C_in, C_out, seed=29)
-    assert s["V"] * C_out * 2 > (1 << 31), "the view-sized rows of this case need more than 31 offset bits"
+    if C_out == 64:
+        assert s["V"] * C_out * 2 > (1 << 31), "the view-sized rows of this case need more than 31 offset bits"
     state = {k: v.clone() for k, v in s["m"].state_dict().items()}
     out1, g1 = _bilinear_step(s)
     s["m"].load_state_dict(state)
@@ -341,7 +342,7 @@ def test_fused_bilinear_full_size_properties(C_in, C_out):
     assert bool(torch.isfinite(out1.float()).all())
     assert torch.equal(out1, out2)                         # no atomics on the outputs, deterministic statistics
     assert torch.equal(g1[0], g2[0])                       # anchor plan: segmented reduction in a fixed order
-    assert float(out1[s["unseen"]].float().abs().max()) == 0.0
+    assert float(out1.detach()[s["unseen"]].float().abs().max()) == 0.0
     seen_norm = out1[~s["unseen"]].float().abs().mean()
     assert float(seen_norm) > 1e-3                         # the seen points carry a signal
     for (n_, _), a, b in zip(s["m"].named_parameters(), g1[1:], g2[1:]):
@@ -373,12 +374,12 @@ def test_fused_bilinear_full_size_slice(C_in, C_out):
 
 def test_fused_bilinear_just_below_the_applicable_limits():
     """`fused_bilinear.applicable` admits V x 64 < 2^32 - 16 (the chain's 64-byte handed rows / 32-byte x_map rows use
-    32-bit buffer offsets): a 128 -> 32 scene with V = 2^26 - 64 x 32 views runs on the fused path, is deterministic and
+    32-bit buffer offsets): a 128 -> 32 scene with V = 2^26 - 32 views runs on the fused path, is deterministic and
     keeps the slice property; one more point and the module takes the materialised path instead of overflowing."""
     from deepviewagg_amd import fused_bilinear, ops
-    n = (1 << 21) - 64
+    n = (1 << 21) - 1
     s = _bilinear_scene(n, 128, 32, seed=37, unseen_frac=0.0)
-    assert s["V"] == n * VIEWS and s["V"] * 64 < (1 << 32) - 16 and (s["V"] + 33 * VIEWS) * 64 >= (1 << 32) - 16
+    assert s["V"] == n * VIEWS and s["V"] * 64 < (1 << 32) - 16 and (s["V"] + VIEWS) * 64 >= (1 << 32) - 16
     s["m"].eval()
     out, g = _bilinear_step(s)
     assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(g[0].float()).all())
