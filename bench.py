@@ -519,6 +519,97 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=10, war
     return out
 
 
+def make_s3dis_batch_scene(device, dtype=torch.bfloat16, samples=4, points_per_sample=75_000, images_per_sample=4,
+                           C=512, H=64, W=128, seed=77):
+    """A batch the size the reference actually trains S3DIS on (BASELINE config 1): `batch_size: 4` spheres
+    (conf/data/segmentation/multimodal/s3disfused-sparse.yaml:108-109 sample_per_epoch / scripts/train_s3dis.sh:23-24),
+    pixel credit of 4 images per sample (:153-156), ADE20K ResNet18 layer-4 feature maps [512, 64, 128] -- so a point is seen
+    by at most the 4 images of its own sphere: k_i = 0 (10 % unseen) or 1 + Binomial(3, 3/4), V ~ 8.8e5 views over
+    3e5 points, 16 feature maps.  Exact mapping (one pixel per view), pixels uniform."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = samples * points_per_sample
+    k = 1 + (torch.rand(n, 3, generator=g, device=device) < 0.75).sum(1)
+    k[torch.rand(n, generator=g, device=device) < 0.1] = 0
+    csr = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), k.cumsum(0)])
+    V = int(csr[-1])
+    pt = torch.arange(n, device=device).repeat_interleave(k)
+    rank = torch.arange(V, device=device) - csr[:-1].repeat_interleave(k)
+    # the k_i images of a point: a random cyclic run of its sphere's images, sorted inside the point (from_dense order)
+    start = torch.randint(0, images_per_sample, (n,), generator=g, device=device)[pt]
+    img_local = (start + rank) % images_per_sample
+    images = (pt // points_per_sample) * images_per_sample + img_local
+    images = images[torch.argsort(pt * (samples * images_per_sample) + images)]
+    pixels = torch.stack([torch.randint(0, W, (V,), generator=g, device=device),
+                          torch.randint(0, H, (V,), generator=g, device=device)], 1).to(torch.int16)
+    x = torch.randn(samples * images_per_sample, C, H, W, generator=g, device=device).to(dtype)
+    x = x.contiguous(memory_format=torch.channels_last)
+    return dict(csr=csr, images=images.long(), pixels=pixels, atom_ptr=torch.arange(V + 1, dtype=torch.int64, device=device),
+                x=x, x_map=torch.rand(V, 8, generator=g, device=device), x_3d=torch.randn(n, 4, generator=g, device=device),
+                mapping_size=(W, H))
+
+
+def s3dis_batch_workload(device, steps=30, warmup=5, graph=True):
+    """the hot path at the reference's own training-batch size, where the Python front end -- not the
+    GPU -- could be the bottleneck: eager ms/step, the host's enqueue time per step, and the same step captured once in a
+    torch.cuda.CUDAGraph (= hipGraph) and replayed (the GPU-bound time of the identical kernel sequence)."""
+    dtype = torch.bfloat16
+    scene = make_s3dis_batch_scene(device, dtype)
+    mods = build_modules(512, device)
+    N, V = scene["x_3d"].shape[0], scene["x_map"].shape[0]
+
+    def one():
+        return step(scene, None, mods, dtype, lazy=True)
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    enq = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        out = one()
+        enq += time.perf_counter() - t1
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / steps * 1e3
+    g_eager = scene["x"].grad.clone()
+    res = {"points": N, "views": V, "feature_maps": list(scene["x"].shape), "ms_per_step_eager": eager,
+           "host_enqueue_ms_per_step": enq / steps * 1e3, "points_per_s_eager": N / (eager * 1e-3), "steps": steps,
+           "sanity": sanity_values(out, scene["x"].grad)}
+    if not graph:
+        return res
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        scene["x"].grad = None
+        with torch.cuda.graph(graph):
+            one()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        replay = (time.perf_counter() - t0) / steps * 1e3
+        g_cap = scene["x"].grad
+        res.update({"ms_per_step_graph_replay": replay, "points_per_s_graph_replay": N / (replay * 1e-3),
+                    "graph_vs_eager_max_rel_grad_difference":
+                        float((g_cap.float() - g_eager.float()).abs().max() / (g_eager.float().abs().max() + 1e-30)),
+                    "host_bound_eager": eager > 1.15 * replay})
+        del graph
+    except Exception as e:                                  # capture is an optimisation: the eager number stands
+        res["graph_error"] = f"{type(e).__name__}: {e}"[:300]
+    del scene, mods
+    torch.cuda.empty_cache()
+    return res
+
+
 def kitti360_pyramid_eval(device, log2_points, views, steps=10):
     """Inference (eval mode, no_grad) of the view pooling over the five pyramid levels of the reference's published
     KITTI-360 model (conf/models/segmentation/multimodal/sparseconv3d.yaml:7281-7290: in_mod -> out_mod = 128 -> 32,
@@ -567,6 +658,37 @@ def kitti360_pyramid_eval(device, log2_points, views, steps=10):
                                          "out_finite": bool(torch.isfinite(o).all())}
         del o
         del scene, atomic_pool, view_pool, fusion
+        torch.cuda.empty_cache()
+    out["ms_all_levels"] = total
+    out["points_per_s"] = N / (total * 1e-3)
+    return out
+
+
+def kitti360_pyramid_train(device, log2_points, views, steps=5):
+    """Training step (train mode, forward + backward) of the view pooling over the five pyramid levels of the reference's
+    published KITTI-360 model (conf/models/segmentation/multimodal/sparseconv3d.yaml:7281-7290, interpolate=True, G = 4)
+    at the S1 scene size.  Levels up to C_out = 128 run the fused bilinear path (C_out = 128: the block-by-block kernels
+    of round 4); 512 -> 256 trains on the materialised dataflow with the hoisted Linear_a.  Per level: ms/step, whether
+    the fused path ran, sanity values; for the two wide levels also the materialised dataflow on the same scene."""
+    N = 1 << log2_points
+    out = {"points": N, "views": N * views, "levels": {}}
+    total = 0.0
+    for C, Co in ((128, 32), (64, 32), (128, 64), (256, 128), (512, 256)):
+        scene = make_scene(N, views, 32, C, 64, 128, torch.bfloat16, device, seed=4321, workload="S1", upscale=8)
+        mods = build_modules(C, device, Co)
+        ms, kern = timed_steps(scene, mods, torch.bfloat16, steps, 2, interpolate=True)
+        sanity = kern.pop("__sanity__")
+        top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]
+        lvl = {"ms_per_step": ms, "fused_path": "emod_attn_fwd" in kern, "steps": steps, "sanity": sanity,
+               "top_kernels_ms": {n: v["ms"] / v["launches"] for n, v in top}}
+        if Co >= 128:
+            ms_mat, kern_mat = timed_steps(scene, mods, torch.bfloat16, 2, 1, lazy=False, interpolate=True)
+            lvl["materialised_ms_per_step"] = ms_mat
+            lvl["speedup_vs_materialised"] = ms_mat / ms
+            lvl["sanity_materialised"] = kern_mat.pop("__sanity__")
+        out["levels"][f"{C}_to_{Co}"] = lvl
+        total += ms
+        del scene, mods
         torch.cuda.empty_cache()
     out["ms_all_levels"] = total
     out["points_per_s"] = N / (total * 1e-3)
@@ -833,6 +955,8 @@ def main():
                 # the reference's default arithmetic (no autocast, fp32 features): S1 shapes on the fp32 chain
                 "f32": secondary_workload("f32", device, torch.float32, args.log2_points, views, 64),
                 "kitti360_pyramid_eval": kitti360_pyramid_eval(device, args.log2_points, views),
+                "kitti360_pyramid_train": kitti360_pyramid_train(device, args.log2_points, views),
+                "s3dis_batch": s3dis_batch_workload(device),
             }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))

@@ -403,10 +403,12 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, double* __restrict__ stats, bf16_t* __restrict__ zst, int64_t V, int64_t R) {
   constexpr int NB = CO / 32;
+  constexpr bool WIDE = NB >= 4;          // block by block, sums over the views through a natural LDS tile
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_eops[L == 2 ? NB * NB * 2 * 64 : 1];
+  __shared__ __attribute__((aligned(16))) bf16_t s_tile[WIDE && L == 1 ? 4 : 1][WIDE && L == 1 ? 32 * TSB : 8];
   __shared__ float s_red[STATS_RED_FLOATS];
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (L == 2) {
     for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
 #pragma unroll
@@ -415,12 +417,12 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
   __syncthreads();
   const __amdgpu_buffer_rsrc_t Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
                                W4 = make_rsrc(w4, (uint64_t)V * 16);
-  float st[L == 1 ? NB : 1][2][16];
+  float st[L == 1 && !WIDE ? NB : 1][2][16];
   float s1[NB], s2[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     s1[b] = s2[b] = 0.f;
-    if (L == 1) {
+    if (L == 1 && !WIDE) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[b][0][r] = st[b][1][r] = 0.f;
     }
@@ -448,14 +450,32 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
     const uint32_t keep = ok ? 0xffffffffu : 0u;
-    f32x16 za[NB];
-    if constexpr (L == 1) {
+    if constexpr (L == 1 && WIDE) {
+      // one block at a time: taps -> z_a block -> bf16 (stored) -> natural tile -> column sums of the stored values
+      const __amdgpu_buffer_rsrc_t Z = make_rsrc(zst + (int64_t)p.ti.v0 * CO, zst ? (uint64_t)p.ti.nv * CO * 2 : 0);
+      bf16_t* tile = s_tile[wv];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        u32x4 x[4][2];
+        load_taps<CO>(Y, p.t, ok, b, h, x);       // lanes without a view: weights and taps read 0 -> z_a = 0
+        f32x16 z;
+        interp16(x, p.t.w, z);
+        float t16[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t16[r] = z[r];
+        bf16x8 pk[2] = {pack8(&t16[0]), pack8(&t16[8])};
+        const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+        st128(Z, off, __builtin_bit_cast(u32x4, pk[0]));
+        st128(Z, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pk[1]));
+        tileN_put_packed(tile, j, h, pk);
+        wave_sync();
+        col_sums(tile, lane, s1[b], s2[b]);
+        wave_sync();
+      }
+    } else if constexpr (L == 1) {
+      f32x16 za[NB];
       eval_za<CO>(Y, p.t, ok, h, za);         // lanes without a view: weights and taps read 0 -> z_a = 0
       if (zst) round_store_za<CO>(zst, p.ti, j, h, za);     // the statistics are those of the stored values
-    } else {
-      unpack_za<NB>(p.z, za);
-    }
-    if constexpr (L == 1) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -464,7 +484,21 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
           st[b][1][r] = __builtin_fmaf(za[b][r], za[b][r], st[b][1][r]);
         }
       }
+    } else if constexpr (WIDE) {
+      bf16x8 a[NB][2];
+      act_a_rows<NB>(p.z, s_taba, h, keep, a);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const f32x16 zb = linear_b_flipped_blk<NB>(s_eops, lane, a, mb);   // views without a lane: a = 0 -> z_b = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s1[mb] += zb[r];
+          s2[mb] = __builtin_fmaf(zb[r], zb[r], s2[mb]);
+        }
+      }
     } else {
+      f32x16 za[NB];
+      unpack_za<NB>(p.z, za);
       bf16x8 a[NB][2];
       act_a<NB>(za, s_taba, h, keep, a);
       f32x16 zb[NB];
@@ -479,14 +513,14 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
       }
     }
   });
-  if constexpr (L == 1) {
+  if constexpr (L == 1 && !WIDE) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) flush_stats_c<2>(st[b], stats, CO, 32 * b, s_red);
   } else {
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
       const float a0 = s1[mb] + other_half(s1[mb]), a1 = s2[mb] + other_half(s2[mb]);
-      flush_lane_stats(a0, a1, stats, stats + CO, 32 * mb, s_red);
+      flush_lane_stats(a0, a1, stats, stats + CO, 32 * mb, s_red, L == 1);
     }
   }
 }
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void emod_stats_kernel(
 // C_o = 128 / 256 (eval mode only: 356 / 512 registers, one wavefront per SIMD; the backward kernels do not exist at
 // those widths)
 template <int CO, int G, int ZM>      // ZM = 0: z_a from the taps of Y (eval mode), 1: the stored z_a (train mode)
-__global__ __launch_bounds__(256, CO > 64 ? 1 : (CO == 32 && ZM == 1 ? (G == 1 ? 3 : 4) : 2)) void emod_attn_fwd_kernel(
+__global__ __launch_bounds__(256, CO > 64 ? (CO == 128 ? 2 : 1) : (CO == 32 && ZM == 1 ? (G == 1 ? 3 : 4) : 2)) void emod_attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -687,19 +721,9 @@ __global__ __launch_bounds__(256, CO > 64 ? 1 : (CO == 32 && ZM == 1 ? (G == 1 ?
       if (h == 0) pid_t[j] = p.vpj;
     }
     // ---- E_mod of the 32 views: taps of Y -> z_a -> BatchNorm_a, LeakyReLU -> Linear_b (flipped) -> value
-    f32x16 zb[NB];
-    {
-      f32x16 za[NB];
-      if constexpr (ZM == 0) eval_za<CO>(Y, p.t, ok, h, za);
-      else unpack_za<NB>(p.z, za);
-      bf16x8 a[NB][2];
-      act_a<NB>(za, s_taba, h, keepv, a);
-      linear_b_flipped<NB>(s_eops, lane, a, zb);
-    }
-    wave_sync();
-    // ---- softmax-weighted sum over the views of a point: in-lane (the lane owns channel 32 mb + j, its registers
-    //      16 of the 32 views; the other 16 sit in lane ^ 32)
-    auto weighted = [&](int mb, int lo, int hi, bool masked) {       // sum over the views [lo, hi] of the tile
+    // softmax-weighted sum over the views of a point: in-lane (the lane owns channel 32 mb + j, its registers
+    // 16 of the 32 views; the other 16 sit in lane ^ 32)
+    auto weighted = [&](const f32x16& zbm, int mb, int lo, int hi, bool masked) {   // sum over the views [lo, hi] of the tile
       float acc = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -708,18 +732,18 @@ __global__ __launch_bounds__(256, CO > 64 ? 1 : (CO == 32 && ZM == 1 ? (G == 1 ?
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * q + i, v = 8 * q + 4 * h + i;       // = view_of(r, h)
-          const float val = leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
+          const float val = leaky06(__builtin_fmaf(zbm[r], kb.g6[mb], kb.b6[mb]));
           const float wv_ = (!masked || (v >= lo && v <= hi)) ? ww[i] : 0.f;
           acc = __builtin_fmaf(wv_, val, acc);
         }
       }
       return acc + other_half(acc);
     };
-    if (single) {
-      const bool done = frag == 0 || frag == 3;
-#pragma unroll
-      for (int mb = 0; mb < NB; ++mb) {
-        float acc = weighted(mb, 0, 31, false);        // views without a lane carry weight 0
+    // the epilogue of output block mb
+    auto pool_block = [&](const f32x16& zbm, int mb) {
+      if (single) {
+        const bool done = frag == 0 || frag == 3;
+        float acc = weighted(zbm, mb, 0, 31, false);        // views without a lane carry weight 0
         const float sc = s_scg[wv][gch[mb]], al = s_alpha[wv][gch[mb]];
         if (frag != 0) {
           acc = __builtin_fmaf(run_acc[mb], al, acc);
@@ -729,22 +753,75 @@ __global__ __launch_bounds__(256, CO > 64 ? 1 : (CO == 32 && ZM == 1 ? (G == 1 ?
           __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(acc * sc), O,
                                                 h == 0 ? (int)((uint32_t)vp0 * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB,
                                                 0, 0);
-      }
-    } else {
-      // several points in the tile: one pass per point (uniform loop over the segments)
-      uint32_t sm_ = sg.smask, em_ = sg.emask;
-      while (sm_) {
-        const int lo = __builtin_ctz(sm_), hi = __builtin_ctz(em_);
-        sm_ &= sm_ - 1;
-        em_ &= em_ - 1;
-        const uint32_t pid = (uint32_t)pid_t[lo];
-#pragma unroll
-        for (int mb = 0; mb < NB; ++mb) {
-          const float acc = weighted(mb, lo, hi, true);
+      } else {
+        // several points in the tile: one pass per point (uniform loop over the segments)
+        uint32_t sm_ = sg.smask, em_ = sg.emask;
+        while (sm_) {
+          const int lo = __builtin_ctz(sm_), hi = __builtin_ctz(em_);
+          sm_ &= sm_ - 1;
+          em_ &= em_ - 1;
+          const uint32_t pid = (uint32_t)pid_t[lo];
+          const float acc = weighted(zbm, mb, lo, hi, true);
           const float sc = sc_t[gch[mb] * 32 + lo];
           __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(acc * sc), O,
                                                 h == 0 ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB,
                                                 0, 0);
+        }
+      }
+    };
+    if constexpr (NB >= 4 && !(NB == 8 && ZM == 0)) {
+      // wide rows (C_o = 256 eval keeps the all-blocks form below: with one wavefront per SIMD the taps of all blocks in
+      // flight matter more than the registers: 14.9 against 18.2 ms): the packed activation of every input block first (taps of one block in flight at a time), then one
+      // output block at a time: product -> weighted sum -> store
+      bf16x8 a[NB][2];
+      if constexpr (ZM == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          u32x4 x[4][2];
+          load_taps<CO>(Y, p.t, ok, b, h, x);
+          f32x16 za;
+          interp16(x, p.t.w, za);
+          act_pack(za, s_taba[b], h, keepv, a[b]);
+        }
+      } else {
+        act_a_rows<NB>(p.z, s_taba, h, keepv, a);
+      }
+      wave_sync();
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const f32x16 zbm = linear_b_flipped_blk<NB>(s_eops, lane, a, mb);
+        pool_block(zbm, mb);
+      }
+    } else {
+      f32x16 zb[NB];
+      {
+        f32x16 za[NB];
+        if constexpr (ZM == 0) eval_za<CO>(Y, p.t, ok, h, za);
+        else unpack_za<NB>(p.z, za);
+        bf16x8 a[NB][2];
+        act_a<NB>(za, s_taba, h, keepv, a);
+        linear_b_flipped<NB>(s_eops, lane, a, zb);
+      }
+      wave_sync();
+      if (single) {
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) pool_block(zb[mb], mb);
+      } else {
+        // several points in the tile: one pass per point (uniform loop over the segments)
+        uint32_t sm_ = sg.smask, em_ = sg.emask;
+        while (sm_) {
+          const int lo = __builtin_ctz(sm_), hi = __builtin_ctz(em_);
+          sm_ &= sm_ - 1;
+          em_ &= em_ - 1;
+          const uint32_t pid = (uint32_t)pid_t[lo];
+#pragma unroll
+          for (int mb = 0; mb < NB; ++mb) {
+            const float acc = weighted(zb[mb], mb, lo, hi, true);
+            const float sc = sc_t[gch[mb] * 32 + lo];
+            __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(acc * sc), O,
+                                                  h == 0 ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB,
+                                                  0, 0);
+          }
         }
       }
     }
@@ -757,8 +834,8 @@ __global__ __launch_bounds__(256, CO > 64 ? 1 : (CO == 32 && ZM == 1 ? (G == 1 ?
 //   dc [V, 4], view records {point | gate * attention (bf16 x 4) | pad}, statistics of the BatchNorm_b backward
 //   (S1 = sum dy_b | sum dy_b z_b with dy_b = leaky'(y_b) gate attention grad_out)
 // ------------------------------------------------------------------------------------------------
-template <int CO, int G>
-__global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
+template <int CO, int G, int OCC = (CO == 32 ? 4 : (CO >= 128 ? 1 : 2))>
+__global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
     const float* __restrict__ compat, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
     const int32_t* __restrict__ n_tiles_dev, const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4,
     const float4* __restrict__ w4, const uint4* __restrict__ eops, const float* __restrict__ bna,
@@ -768,6 +845,7 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
     const bf16_t* __restrict__ zst, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
   constexpr int NB = CO / 32, NE = G == 1 ? 1 : 2, GS = CO / G;
   constexpr int GL = GS < 32 ? GS : 32;           // lanes of a group inside one block
+  constexpr int BPG = GS >= 32 ? GS / 32 : 1;     // blocks of a channel group
   __shared__ __attribute__((aligned(16))) uint4 s_eops[NB * NB * 2 * 64];
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) float s_q[4][4 * 32], s_ga[4][4 * 32];
@@ -822,9 +900,10 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
     int vpj;
     ZaRows<NB> z;        // the stored z_a
   };
-  // C_o = 32: without the prefetch register set the kernel fits four wavefronts per SIMD
+  // C_o = 32: without the prefetch register set the kernel fits four wavefronts per SIMD (C_o >= 128 at one wavefront per
+  // SIMD lives on the prefetch: 9.0 -> see DESIGN)
   auto loop = [&](auto&& ld, auto&& bd) {
-    if constexpr (CO == 32) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
+    if constexpr (CO == 32 || (CO >= 128 && OCC == 2)) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
     else run_tiles<Pre>(tiles, ta, tb, ld, bd);
   };
   loop([&](const TileInfo& ti, int t) {
@@ -897,15 +976,17 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
         const float ou = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
             OU, (int)((uint32_t)vp0 * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u), 0, 0));
         const float d = go1[mb] * ou;
-        if (GS >= 64) dsum += d;
-        else {
+        if (GS >= 64) {
+          dsum += d;
+          if ((mb % BPG) == BPG - 1) {          // the last block of the group
+            const float r = group_reduce(dsum);
+            if (j == 0 && h == 0) s_E[wv][mb / BPG] = r;
+            dsum = 0.f;
+          }
+        } else {
           const float r = group_reduce(d);
           if ((j % GL) == 0 && h == 0) s_E[wv][gch[mb]] = r;
         }
-      }
-      if (GS >= 64) {
-        const float r = group_reduce(dsum);
-        if (j == 0 && h == 0) s_E[wv][0] = r;
       }
       wave_sync();
 #pragma unroll
@@ -932,15 +1013,6 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
       pre[e] = __builtin_fmaf(gwl[e], m[e], gbl[e]);
       gt[e] = gw ? tanh_pos(fmaxf(pre[e], 0.f)) : 1.f;
     }
-    // ---- E_mod of the views (flipped): raw z_b stays for the statistics
-    f32x16 zb[NB];
-    {
-      f32x16 za[NB];
-      unpack_za<NB>(p.z, za);
-      bf16x8 aa[NB][2];
-      act_a<NB>(za, s_taba, h, keepv, aa);
-      linear_b_flipped<NB>(s_eops, lane, aa, zb);
-    }
     // grad_out value of (block mb, register r): the point of view view_of(r, h)
     auto go_of = [&](int mb, int r) {
       if (single) return go1[mb];
@@ -949,25 +1021,86 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
       return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
           GO, v < nv ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB, 0, 0));
     };
-    // ---- q[v][g] = sum_{ch in g} grad_out[p(v)][ch] value[v][ch]: reduce over the lanes of the group
-    if (GS >= 64) {
+    // ---- E_mod of the views (flipped): raw z_b stays for the statistics
+    f32x16 zb[NB < 4 ? NB : 1];
+    if constexpr (NB >= 4) {
+      // wide rows, one output block at a time: product -> its share of q[v][g] AND of the BatchNorm_b statistics (they
+      // need gate * attention of the views, which does not depend on q: written to the LDS table before the products)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float d = 0.f;
-#pragma unroll
-        for (int mb = 0; mb < NB; ++mb)
-          d = __builtin_fmaf(go_of(mb, r), leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb])), d);
-        d = group_reduce(d);
-        if (j == 0) q_t[view_of(r, h)] = d;
+      for (int e = 0; e < NE; ++e) {
+        if (s_active) ga_t[gl[e] * 32 + j] = ok ? gt[e] * a[e] : 0.f;
       }
-    } else {
+      bf16x8 aa[NB][2];
+      act_a_rows<NB>(p.z, s_taba, h, keepv, aa);
+      wave_sync();
+      float dq[16];
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) {
+        const f32x16 zbm = linear_b_flipped_blk<NB>(s_eops, lane, aa, mb);
+        if ((mb % BPG) == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w = *reinterpret_cast<const float4*>(ga_t + gch[mb] * 32 + 8 * q + 4 * h);
+          const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * q + i;
+            const float go = go_of(mb, r);
+            const float t = __builtin_fmaf(zbm[r], kb.g6[mb], kb.b6[mb]);
+            const float d = go * leaky06(t);
+            if (GS >= 64) {
+              dq[r] += d;
+            } else {
+              const float dr = group_reduce(d);
+              if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = dr;
+            }
+            // the records carry gate * attention as bf16: the later passes see the rounded weight
+            const float gar = bf2f(f2bf(ww[i]));
+            const float dval = gar * go;
+            const float dy = t > 0.f ? dval : SLOPE * dval;
+            sb1[mb] += dy;
+            sb2[mb] = __builtin_fmaf(dy, zbm[r], sb2[mb]);
+          }
+        }
+        if (GS >= 64 && (mb % BPG) == BPG - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float dr = group_reduce(dq[r]);
+            if (j == 0) q_t[(mb / BPG) * 32 + view_of(r, h)] = dr;
+          }
+        }
+      }
+    } else {
+      {
+        f32x16 za[NB];
+        unpack_za<NB>(p.z, za);
+        bf16x8 aa[NB][2];
+        act_a<NB>(za, s_taba, h, keepv, aa);
+        linear_b_flipped<NB>(s_eops, lane, aa, zb);
+      }
+      // ---- q[v][g] = sum_{ch in g} grad_out[p(v)][ch] value[v][ch]: reduce over the lanes of the group
+      if (GS >= 64) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float d = go_of(mb, r) * leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
+          float d = 0.f;
+#pragma unroll
+          for (int mb = 0; mb < NB; ++mb)
+            d = __builtin_fmaf(go_of(mb, r), leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb])), d);
           d = group_reduce(d);
-          if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = d;
+          if (j == 0) q_t[view_of(r, h)] = d;
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float d = go_of(mb, r) * leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
+            d = group_reduce(d);
+            if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = d;
+          }
         }
       }
     }
@@ -997,7 +1130,7 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
         dwa[e] += dpre * m[e];
         dba[e] += dpre;
       }
-      if (s_active) ga_t[gl[e] * 32 + j] = ok ? gav[e] : 0.f;
+      if (NB < 4 && s_active) ga_t[gl[e] * 32 + j] = ok ? gav[e] : 0.f;
     }
     float dc4[4] = {0.f, 0.f, 0.f, 0.f}, ga4[4] = {0.f, 0.f, 0.f, 0.f};
     if (G == 4) {
@@ -1028,8 +1161,9 @@ __global__ __launch_bounds__(256, CO == 32 ? 4 : 2) void emod_attn_bwd_kernel(
     }
     wave_sync();
     // ---- statistics of the BatchNorm_b backward: d value = gate attention grad_out, dy_b = leaky'(y_b) d value
+    //      (wide rows: accumulated block by block above)
 #pragma unroll
-    for (int mb = 0; mb < NB; ++mb) {
+    for (int mb = 0; mb < (NB < 4 ? NB : 0); ++mb) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 w = *reinterpret_cast<const float4*>(ga_t + gch[mb] * 32 + 8 * q + 4 * h);
@@ -1259,6 +1393,184 @@ __global__ __launch_bounds__(256, 2) void emod_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// E_mod backward for wide rows (C_o >= 128): stage 2 of emod_bwd_kernel split into the two things its registers cannot
+// hold together at this width (16 blocks of dW_b = 256 accumulator registers):
+//   MODE 1 (8 wavefronts per block, two per SIMD): z_b block by block -> dy_b -> dz_b (packed: the B operands of the
+//          second product) -> dy_a = leaky'(y_a) W_b^T dz_b block by block, written as bf16 [V][CO] (position order), S of
+//          BatchNorm_a = column sums of the stored rows through a natural LDS tile (col_sums2: no per-lane accumulators);
+//   MODE 2 (one wavefront per SIMD, all of dW_b in registers): the same dz_b again -> natural LDS tiles of dz_b and y_a
+//          -> dW_b += dz_b^T y_a through the transpose read (wgradN).
+// One more evaluation of Linear_b (2 V CO^2 flop) against 8 CO more bytes per view for handing dz_b over.
+// ------------------------------------------------------------------------------------------------
+template <int CO, int G, int MODE>
+__global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
+    const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ smb,
+    const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout, bf16_t* __restrict__ da, float* __restrict__ dWb,
+    double* __restrict__ stats_a, const bf16_t* __restrict__ zst, int64_t V, int64_t N) {
+  constexpr int NB = CO / 32, GS = CO / G, NW = MODE == 1 ? 8 : 4;
+  constexpr int NT = MODE == 2 ? NB : 1;
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_tabb[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) uint4 s_eops[(MODE == 1 ? 2 : 1) * NB * NB * 2 * 64];
+  // MODE 1: [0] = the dy_a block, [1] = the z_a block;  MODE 2: NB tiles of dz_b, NB tiles of y_a
+  __shared__ __attribute__((aligned(16))) bf16_t s_ta[NW][NT][32 * TSB], s_tb[NW][NT][32 * TSB];
+  float* s_red = reinterpret_cast<float*>(&s_ta[0][0][0]);     // epilogue: D x D floats | NW x 64 floats
+  static_assert(sizeof(bf16_t) * NW * NT * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < (MODE == 1 ? 2 : 1) * NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    stage_tab_c(s_tabb[b], bnb, CO, 32 * b, smb);
+    stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t RC = make_rsrc(rec, (uint64_t)V * 16), GO = make_rsrc(gout, (uint64_t)N * CO * 2);
+  float sa1[MODE == 1 ? NB : 1], sa2[MODE == 1 ? NB : 1];
+  f32x16 accW[MODE == 2 ? NB : 1][MODE == 2 ? NB : 1];
+  if (MODE == 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) sa1[b] = sa2[b] = 0.f;
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const f32x16 zero = {0};
+        accW[mb][b] = zero;
+      }
+    }
+  }
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    ZaRows<NB> z;        // the stored z_a
+    u32x4 rc;
+  };
+  auto loop = [&](auto&& ld, auto&& bd) {
+    // (MODE 2 with the prefetch register set: 772 bytes of scratch next to the 256 accumulator registers -- dropped)
+    run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
+  };
+  loop([&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    p.z = load_za<CO>(zst, ti, j, h);
+    p.rc = ld128(RC, ok ? (uint32_t)(p.ti.v0 + j) * 16u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    bf16x8 a[NB][2];
+    act_a_rows<NB>(p.z, s_taba, h, keep, a);
+    if (MODE == 2) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) tileN_put_packed(s_tb[wv][b], j, h, a[b]);
+    }
+    // d value[ch] = (gate attention)[g(ch)] grad_out[point][ch] for the lane's channels 32 mb + chan(r, h)
+    const uint32_t pid = p.rc.x;
+    const float ga4[4] = {__uint_as_float(p.rc.y << 16), __uint_as_float(p.rc.y & 0xffff0000u),
+                          __uint_as_float(p.rc.z << 16), __uint_as_float(p.rc.z & 0xffff0000u)};
+    bf16x8 dzp[MODE == 1 ? NB : 1][2];
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+      const f32x16 zb = linear_b_std_blk<NB>(s_eops, lane, a, mb);
+      f32x16 dy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 32 * mb + 8 * q + 4 * h;            // channels c0 .. c0 + 3 = chan(4 q + i, h) + 32 mb
+        const u32x2 gv = ld64(GO, ok ? pid * (uint32_t)(CO * 2) + (uint32_t)c0 * 2u : OOB);
+        const float gg = ga4[G == 1 ? 0 : c0 / GS];
+        dy[4 * q] = gg * __uint_as_float(gv.x << 16);
+        dy[4 * q + 1] = gg * __uint_as_float(gv.x & 0xffff0000u);
+        dy[4 * q + 2] = gg * __uint_as_float(gv.y << 16);
+        dy[4 * q + 3] = gg * __uint_as_float(gv.y & 0xffff0000u);
+      }
+      // dy_b = leaky'(y_b) d value, y_b = G_b z_b + B_b;  dz_b = G_b dy_b - K1 - K2 z_b
+      float dz[16];
+      {
+        asm volatile("" ::: "memory");
+        float g_[16], b_[16];
+        tab16(s_tabb[mb], T_G, h, g_);
+        tab16(s_tabb[mb], T_B, h, b_);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dy[r] = __builtin_fmaf(zb[r], g_[r], b_[r]) > 0.f ? dy[r] : SLOPE * dy[r];
+      }
+      bn_bwd_apply(zb, dy, s_tabb[mb], h, dz);
+      if (MODE == 1) {
+        pack16(dz, keep, dzp[mb]);
+      } else {
+        bf16x8 t2[2];
+        pack16(dz, keep, t2);
+        tileN_put_packed(s_ta[wv][mb], j, h, t2);
+      }
+    }
+    if constexpr (MODE == 1) {
+      // da = W_b^T dz_b, dy_a = leaky'(y_a) da, handed over as bf16 (position order);  S of BatchNorm_a from the stored rows
+      // (the handed-over gradient [V][CO] exceeds 4 GiB at the headline size: one descriptor per tile)
+      const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)p.ti.v0 * CO, (uint64_t)p.ti.nv * CO * 2);
+      bf16_t* tdy = s_ta[wv][0];
+      bf16_t* tz = s_tb[wv][0];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        f32x16 dya = {0};
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) dya = CH_MFMA(lds_op(s_eops, op_bwd<NB>(b, mb, m), lane), dzp[mb][m], dya);
+        }
+        f32x16 za;
+        unpack_za_blk<NB>(p.z, b, za);
+        float t[16];
+        {
+          asm volatile("" ::: "memory");
+          float g_[16], b_[16];
+          tab16(s_taba[b], T_G, h, g_);
+          tab16(s_taba[b], T_B, h, b_);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = __builtin_fmaf(za[r], g_[r], b_[r]) > 0.f ? dya[r] : SLOPE * dya[r];
+        }
+        bf16x8 pk[2] = {pack8(&t[0]), pack8(&t[8])};     // lanes without a view: dz_b = 0 -> dy_a = 0
+        const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
+        st128(DA, off, __builtin_bit_cast(u32x4, pk[0]));
+        st128(DA, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pk[1]));
+        bf16x8 zk[2] = {__builtin_bit_cast(bf16x8, p.z.q[b][0]), __builtin_bit_cast(bf16x8, p.z.q[b][1])};
+        tileN_put_packed(tdy, j, h, pk);
+        tileN_put_packed(tz, j, h, zk);
+        wave_sync();
+        col_sums2(tdy, tz, lane, sa1[b], sa2[b]);
+        wave_sync();
+      }
+    } else {
+      wave_sync();
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) accW[mb][b] = wgradN(s_ta[wv][mb], s_tb[wv][b], lane, accW[mb][b]);   // dW_b[out][in]
+      }
+      wave_sync();
+    }
+  });
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float a0 = sa1[b] + other_half(sa1[b]), a1 = sa2[b] + other_half(sa2[b]);
+      flush_lane_stats(a0, a1, stats_a, stats_a + CO, 32 * b, s_red, true);
+    }
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        flush_matrix_nat(accW[mb][b], dWb + (32 * mb) * CO + 32 * b, CO, D, false, s_red, true);
+    }
+  }
+}
+
 }  // namespace emod
 }  // namespace dva
 
@@ -1283,7 +1595,7 @@ int dva_emod_prep(const float* Wb, int32_t C_out, void* ops, void* stream) {
 int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
                    const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, void* z_a,
                    int64_t n_views, int64_t n_rows, int32_t C_out, void* stream) {
-  if (n_views < 0 || (layer != 1 && layer != 2) || (C_out != 32 && C_out != 64)) return DVA_ERR_INVALID;
+  if (n_views < 0 || (layer != 1 && layer != 2) || (C_out != 32 && C_out != 64 && C_out != 128)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!tiles || !n_tiles || !stats) return DVA_ERR_INVALID;
   if (layer == 1 && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
@@ -1297,8 +1609,10 @@ int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const 
                      (bf16_t*)z_a, n_views, n_rows)
   if (C_out == 32 && layer == 1) DVA_EMOD_STATS(32, 1);
   else if (C_out == 32) DVA_EMOD_STATS(32, 2);
-  else if (layer == 1) DVA_EMOD_STATS(64, 1);
-  else DVA_EMOD_STATS(64, 2);
+  else if (C_out == 64 && layer == 1) DVA_EMOD_STATS(64, 1);
+  else if (C_out == 64) DVA_EMOD_STATS(64, 2);
+  else if (layer == 1) DVA_EMOD_STATS(128, 1);
+  else DVA_EMOD_STATS(128, 2);
 #undef DVA_EMOD_STATS
   DVA_CHECK_LAUNCH();
   return DVA_OK;
@@ -1319,8 +1633,8 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
   if (!z_a && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * 128 > 0xfffffff0ll || n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  if (C_out > 64 && z_a) return DVA_ERR_UNSUPPORTED;       // the train-mode passes stop at C_out = 64
-  const dim3 grid(chain_grid(C_out > 64 ? 1 : (C_out == 32 && z_a ? (G == 1 ? 3 : 4) : 2))), block(256);
+  if (C_out > 128 && z_a) return DVA_ERR_UNSUPPORTED;      // the train-mode passes stop at C_out = 128
+  const dim3 grid(chain_grid(C_out > 64 ? (C_out == 128 ? 2 : 1) : (C_out == 32 && z_a ? (G == 1 ? 3 : 4) : 2))), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_FWD_Z(CO_, G_, ZM_)                                                                                  \
   hipLaunchKernelGGL((emod_attn_fwd_kernel<CO_, G_, ZM_>), grid, block, 0, s, x_map, view_point, u,                    \
@@ -1340,9 +1654,9 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
     case 64 * 8 + 1: DVA_EMOD_FWD(64, 1); break;
     case 64 * 8 + 2: DVA_EMOD_FWD(64, 2); break;
     case 64 * 8 + 4: DVA_EMOD_FWD(64, 4); break;
-    case 128 * 8 + 1: DVA_EMOD_FWD_Z(128, 1, 0); break;
-    case 128 * 8 + 2: DVA_EMOD_FWD_Z(128, 2, 0); break;
-    case 128 * 8 + 4: DVA_EMOD_FWD_Z(128, 4, 0); break;
+    case 128 * 8 + 1: DVA_EMOD_FWD(128, 1); break;
+    case 128 * 8 + 2: DVA_EMOD_FWD(128, 2); break;
+    case 128 * 8 + 4: DVA_EMOD_FWD(128, 4); break;
     case 256 * 8 + 4: DVA_EMOD_FWD_Z(256, 4, 0); break;
     default: return DVA_ERR_UNSUPPORTED;
   }
@@ -1367,7 +1681,8 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
   DVA_EMOD_CHECK_SIZES();
   if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   static const int bpc32 = tune_int("DVA_EMOD_ABWD_BPC", 4);      // read once (getenv), like the other switches
-  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : 2)), block(256);
+  static const int occ128 = tune_int("DVA_EMOD_ABWD128_OCC", 1);  // C_out = 128: 1 = 512 registers, 2 = 256 with spills
+  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : (C_out >= 128 ? occ128 : 2))), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_BWD(CO_, G_)                                                                                      \
   hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \
@@ -1382,6 +1697,22 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
     case 64 * 8 + 1: DVA_EMOD_BWD(64, 1); break;
     case 64 * 8 + 2: DVA_EMOD_BWD(64, 2); break;
     case 64 * 8 + 4: DVA_EMOD_BWD(64, 4); break;
+#define DVA_EMOD_BWD_O(CO_, G_, O_)                                                                                \
+  hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_, O_>), grid, block, 0, s, scores, view_point, (const int2*)tiles, \
+                     n_tiles, (const bf16_t*)Y, (const int4*)tap_rows, (const float4*)tap_weights,                   \
+                     (const uint4*)eops, bn_a, bn_b, ptr, gate_w, gate_b, (const bf16_t*)grad_out,                   \
+                     (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, stats_b,                     \
+                     (const bf16_t*)z_a, scaling, eps, n_views, n_points, n_rows)
+#define DVA_EMOD_BWD128(G_)                    \
+  do {                                         \
+    if (occ128 == 2) DVA_EMOD_BWD_O(128, G_, 2); \
+    else DVA_EMOD_BWD_O(128, G_, 1);             \
+  } while (0)
+    case 128 * 8 + 1: DVA_EMOD_BWD128(1); break;
+    case 128 * 8 + 2: DVA_EMOD_BWD128(2); break;
+    case 128 * 8 + 4: DVA_EMOD_BWD128(4); break;
+#undef DVA_EMOD_BWD128
+#undef DVA_EMOD_BWD_O
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_EMOD_BWD
@@ -1394,11 +1725,19 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
                  const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,
                  const void* z_a, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G,
                  void* stream) {
-  if (n_views < 0 || (stage != 1 && stage != 2) || (C_out != 32 && C_out != 64) || (G != 1 && G != 2 && G != 4))
+  if (n_views < 0 || stage < 1 || stage > 4 || (C_out != 32 && C_out != 64 && C_out != 128) ||
+      (G != 1 && G != 2 && G != 4))
     return DVA_ERR_INVALID;
+  if (stage == 1 && C_out > 64) return DVA_ERR_UNSUPPORTED;     // (the in-place form; the anchor scatter applies it)
+  if (stage > 2 && C_out < 128) return DVA_ERR_UNSUPPORTED;     // the halves of stage 2 exist for wide rows only
+  const bool do_dya = stage != 4, do_wgrad = stage != 3;
+  if (stage >= 2) {
+    if (!eops || !bn_b || !sm_b || !view_rec || !grad_out) return DVA_ERR_INVALID;
+    if (do_dya && !stats_a) return DVA_ERR_INVALID;
+    if (do_wgrad && !dWb) return DVA_ERR_INVALID;
+  }
   if (n_views == 0) return DVA_OK;
   if (!z_a || !tiles || !n_tiles || !bn_a || !da) return DVA_ERR_INVALID;
-  if (stage == 2 && (!eops || !bn_b || !sm_b || !view_rec || !grad_out || !dWb || !stats_a)) return DVA_ERR_INVALID;
   if (stage == 1 && !sm_a) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
@@ -1413,6 +1752,8 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
   if (stage == 1) {
     if (C_out == 32) DVA_EMOD_L(32, 1, 1);
     else DVA_EMOD_L(64, 1, 1);
+  } else if (C_out < 128 && stage != 2) {
+    return DVA_ERR_UNSUPPORTED;
   } else {
     switch (C_out * 8 + G) {
       case 32 * 8 + 1: DVA_EMOD_L(32, 1, 2); break;
@@ -1421,6 +1762,22 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
       case 64 * 8 + 1: DVA_EMOD_L(64, 1, 2); break;
       case 64 * 8 + 2: DVA_EMOD_L(64, 2, 2); break;
       case 64 * 8 + 4: DVA_EMOD_L(64, 4, 2); break;
+      // wide rows: dy_a + S of BatchNorm_a (8 wavefronts per block), then dW_b (one wavefront per SIMD)
+#define DVA_EMODW(G_)                                                                                                 \
+  do {                                                                                                                \
+    if (do_dya)                                                                                                       \
+      hipLaunchKernelGGL((emodw_bwd_kernel<128, G_, 1>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles,      \
+                         n_tiles, (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec,                      \
+                         (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);    \
+    if (do_wgrad)                                                                                                     \
+      hipLaunchKernelGGL((emodw_bwd_kernel<128, G_, 2>), dim3(chain_grid(1)), dim3(256), 0, s, (const int2*)tiles,      \
+                         n_tiles, (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec,                      \
+                         (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);    \
+  } while (0)
+      case 128 * 8 + 1: DVA_EMODW(1); break;
+      case 128 * 8 + 2: DVA_EMODW(2); break;
+      case 128 * 8 + 4: DVA_EMODW(4); break;
+#undef DVA_EMODW
       default: return DVA_ERR_UNSUPPORTED;
     }
   }

@@ -63,8 +63,10 @@ def applicable(module, x_mod, x_map, csr_idx):
     C, G = module.out_mod, module.num_groups
     if C not in (32, 64, 128, 256) or G not in (1, 2, 4) or C % G or (C // G) % 8 or (C == 256 and G != 4):
         return False
-    if C >= 128 and (module.E_map.training or torch.is_grad_enabled()):
-        return False        # C_out = 128 / 256 (KITTI-360 pyramid levels 256 -> 128, 512 -> 256): the one-kernel eval path only
+    if C >= 256 and (module.E_map.training or torch.is_grad_enabled()):
+        # C_out = 256 (KITTI-360 pyramid level 512 -> 256): the one-kernel eval path only.  C_out = 128 (256 -> 128) trains
+        # on the block-by-block kernels since round 4 (chain_emod.hip "wide rows")
+        return False
     if lin_a.bias is not None or lin_b.bias is not None or lin_b.in_features != C or lin_b.out_features != C:
         return False
     for bn, act in ((bn_a, act_a), (bn_b, act_b)):
@@ -77,8 +79,16 @@ def applicable(module, x_mod, x_map, csr_idx):
         return False
     V, R = x_mod.shape[0], x_mod.rows.shape[0]
     N = csr_idx.shape[0] - 1
-    return V == x_map.shape[0] and 4 * V < (1 << 31) and V * 64 < (1 << 32) - 16 \
-        and R * C * 2 < (1 << 32) - 16 and N * max(C * 2, 128) < (1 << 32) - 16
+    return V == x_map.shape[0] and size_limits_ok(V, R, N, C)
+
+
+def size_limits_ok(V, R, N, C):
+    """The kernels address the view-sized arrays of a step with 32-bit byte offsets into one buffer descriptor: the tap
+    table [V, 4] int32, the 64-byte rows the DeepSetFeat chain hands between its backward passes (x_map rows are 32
+    bytes), the map rows Y [R, C] bf16 and the per-point rows [N, max(2 C, 128)].  z_a / dy_a [V, C] bf16 take one
+    descriptor per TILE and have no such limit (4 GiB at V = 2^25, C = 64)."""
+    lim = (1 << 32) - 16
+    return 4 * V < (1 << 31) and V * 64 < lim and R * C * 2 < lim and N * max(C * 2, 128) < lim
 
 
 class _EmodPool(torch.autograd.Function):
@@ -187,10 +197,16 @@ class _EmodPool(torch.autograd.Function):
         da = torch.empty((V, C), dtype=torch.bfloat16, device=dev)
         dWb = arena.take(C, C)
         stats_a = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-        with ops._timed("emod_bwd_b", za_bytes + V * (16 + C * 2) + N * C * 2):
-            check(lib.dva_emod_bwd(2, None, None, None, ptr(tiles), ptr(n_tiles), ptr(eops), ptr(tab_a),
-                                   ptr(tab_b), None, ptr(sm_b), ptr(rec), ptr(gout), ptr(da), ptr(dWb), ptr(stats_a),
-                                   ptr(za), N, V, R, C, G, st), "dva_emod_bwd")
+        def emod_bwd(stage, name, nbytes):
+            with ops._timed(name, nbytes):
+                check(lib.dva_emod_bwd(stage, None, None, None, ptr(tiles), ptr(n_tiles), ptr(eops), ptr(tab_a),
+                                       ptr(tab_b), None, ptr(sm_b), ptr(rec), ptr(gout), ptr(da), ptr(dWb),
+                                       ptr(stats_a), ptr(za), N, V, R, C, G, st), "dva_emod_bwd")
+        if C >= 128:      # wide rows: dy_a + S of BatchNorm_a, then dW_b (Linear_b evaluated once more), two kernels
+            emod_bwd(3, "emod_bwd_dya", za_bytes + V * (16 + C * 2) + N * C * 2)
+            emod_bwd(4, "emod_bwd_wgrad", za_bytes + V * 16 + N * C * 2)
+        else:
+            emod_bwd(2, "emod_bwd_b", za_bytes + V * (16 + C * 2) + N * C * 2)
         del rec
         sm_a, dg_a, db_a = consts(stats_a, tab_a)
         # ---- gradient of Y: the transpose of the interpolation applied to dz_a = BatchNorm_a backward of dy_a (views

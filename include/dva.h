@@ -482,8 +482,10 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
                       int64_t n_rows, int32_t C_out, int32_t G, int32_t scaling, float eps, void* stream);
 /* E_mod backward.  stage 2: view_rec + grad_out -> dWb fp32 [C_out][C_out] (caller-zeroed) += the gradient of W_b,
  * da bf16 [V][C_out] (position order) = leaky'(y_a) W_b^T dz_b, stats_a += S1 | sum dy_a z_a  (sm_b = S / M of
- * BatchNorm_b).  stage 1: da <- dz_a = BatchNorm_a backward of da in place (sm_a); the gradient of Y follows as
- * dva_gather_rows_sum(da, row plan of tap_rows, tap_weights, atom_shift 2). */
+ * BatchNorm_b).  stage 1: da <- dz_a = BatchNorm_a backward of da in place (sm_a; C_out <= 64); the gradient of Y follows as
+ * dva_gather_rows_sum(da, row plan of tap_rows, tap_weights, atom_shift 2).
+ * C_out in {32, 64, 128}.  C_out = 128 ("wide rows", round 4) evaluates stage 2 as two kernels that can also be called
+ * on their own: stage 3 = da + stats_a only (dWb may be NULL), stage 4 = dWb only (stats_a may be NULL). */
 int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
                  const int32_t* n_tiles, const void* eops, const float* bn_a, const float* bn_b, const float* sm_a,
                  const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,

@@ -103,6 +103,11 @@ CASES = [
     (ragged_long, 1200, 64, 32, 2, False),
     (ragged, 900, 48, 64, 1, True),
     (ragged_long, 1000, 64, 64, 2, True),
+    # wide rows (round 4): C_o = 128 trains on the block-by-block kernels (KITTI-360 pyramid level 256 -> 128)
+    (ragged_long, 1200, 256, 128, 4, True),
+    (ragged, 900, 96, 128, 2, True),
+    (full32, 512, 64, 128, 1, True),
+    (ragged_long, 700, 128, 128, 4, False),
 ]
 
 
@@ -197,14 +202,15 @@ def test_fused_bilinear_through_the_data_objects():
 
 @pytest.mark.parametrize("train", [True, False])
 def test_materialised_fallback_hoists_the_first_linear(train):
-    """C_out = 128 (a deeper KITTI-360 pyramid level: 256 -> 128) is outside the fused kernels: the fallback runs
-    E_mod's first Linear on the map rows and interpolates its C_out channels (interp(x) W^T = interp(x W^T)) instead
-    of materialising [V, C_in] and a per-view GEMM.  Checked against the oracle like the fused path, and against the
-    un-hoisted device dataflow."""
+    """Training at C_out = 256 (the deepest KITTI-360 pyramid level: 512 -> 256) is outside the fused kernels (C_out = 128
+    trains on them since round 4): the fallback runs E_mod's first Linear on the map rows and interpolates its C_out
+    channels (interp(x) W^T = interp(x W^T)) instead of materialising [V, C_in] and a per-view GEMM.  Checked against
+    the oracle like the fused path, and against the un-hoisted device dataflow."""
     from deepviewagg_amd.modules.multimodal import pooling as P
+    CO = 256
     case = make_case(31, 1200, 96, ragged)
-    ref, m = build(case, 128, 4, train)
-    w = torch.randn(case["N"], 128, generator=case["gen"])
+    ref, m = build(case, CO, 4, train)
+    w = torch.randn(case["N"], CO, generator=case["gen"])
     calls = []
     orig = P._hoisted_first_linear
 
@@ -217,7 +223,7 @@ def test_materialised_fallback_hoists_the_first_linear(train):
         out, g, used = run_dev(case, m, w, fused=True)
         assert calls == [True] and used["fn"] != "_EmodPoolBackward"
         P._hoisted_first_linear = lambda mlp, x_mod: (x_mod.materialize(), False)
-        _, m2 = build(case, 128, 4, train)
+        _, m2 = build(case, CO, 4, train)
         out_b, g_b, _ = run_dev(case, m2, w, fused=True)
     finally:
         P._hoisted_first_linear = orig
@@ -262,9 +268,10 @@ def test_emod_bwd_stage1_in_place_batchnorm_backward(C):
 @pytest.mark.parametrize("sizes_fn,N,C_in,G,C_out", [(ragged, 1500, 256, 4, 128), (ragged_long, 800, 96, 2, 128),
                                                      (full32, 200, 256, 1, 128), (ragged_long, 900, 160, 4, 256)])
 def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G, C_out):
-    """C_out = 128 (the KITTI-360 pyramid level 256 -> 128): eval mode under no_grad runs the ONE fused kernel on the
-    taps of Y (356 registers, one wavefront per SIMD); training at that width takes the materialised fallback with
-    the hoisted Linear_a."""
+    """C_out = 128 / 256 (the KITTI-360 pyramid levels 256 -> 128, 512 -> 256): eval mode under no_grad runs the ONE fused
+    kernel on the taps of Y (block by block since round 4: 183 - 203 registers at 128, no spills at 256).  With grad
+    enabled C_out = 128 stays on the fused path (its backward kernels exist since round 4), C_out = 256 takes the
+    materialised fallback with the hoisted Linear_a."""
     from deepviewagg_amd import fused_bilinear
     from deepviewagg_amd.modules.multimodal import pooling as P
     case = make_case(41 + G, N, C_in, sizes_fn)
@@ -281,8 +288,11 @@ def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G, C_out):
         with torch.no_grad():
             out, _, _ = run_dev(case, m, w, fused=True, need_grad=False)
         assert calls == [1], "the fused eval kernel must be the path that ran"
-        out_grad, _, used = run_dev(case, m, w, fused=True, need_grad=True)       # grad enabled: the fallback
-        assert calls == [1] and used["fn"] != "_EmodPoolBackward"
+        out_grad, _, used = run_dev(case, m, w, fused=True, need_grad=True)       # grad enabled
+        if C_out == 128:
+            assert calls == [1, 1] and used["fn"] == "_EmodPoolBackward"
+        else:
+            assert calls == [1] and used["fn"] != "_EmodPoolBackward"
     finally:
         fused_bilinear.pool = orig
     with torch.no_grad():

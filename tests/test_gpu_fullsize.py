@@ -394,12 +394,6 @@ def test_fused_bilinear_just_below_the_applicable_limits():
              pixels=s["pixels"][V0:], x_map=s["x_map"][V0:], w=s["w"][n - tail:])
     out_t, _ = _bilinear_step(t)
     assert torch.equal(out[n - tail:], out_t)
-    # the guard itself
-    fake = ops.InterpolatedFeatures.__new__(ops.InterpolatedFeatures)
-    fake.exact, fake.rows = True, s["x"].permute(0, 2, 3, 1).reshape(-1, 128)
-    csr_fake = torch.zeros(n + 1, dtype=torch.int64, device=DEV)
-    with torch.no_grad():
-        for lim, ok in ((s["V"], True), (1 << 26, False)):
-            fake.tap_rows = torch.empty((1, 4), dtype=torch.int32, device=DEV).expand(lim, 4)
-            x_map_fake = torch.empty((1, 8), device=DEV).expand(lim, 8)
-            assert fused_bilinear.applicable(s["m"], fake, x_map_fake, csr_fake) == ok, (lim, ok)
+    # the guard itself: this scene is admitted, one more point is not (CPU test of the arithmetic: test_size_limits.py)
+    assert fused_bilinear.size_limits_ok(s["V"], B * H * W, n, 32)
+    assert not fused_bilinear.size_limits_ok(s["V"] + VIEWS, B * H * W, n + 1, 32)

@@ -26,6 +26,14 @@ elif name == "bilinear_kitti":
     r = bench.secondary_workload("bilinear", dev, bf, 20, 32, 128, steps=steps, interpolate=True, C_out=32)
 elif name == "f32":
     r = bench.secondary_workload("f32", dev, torch.float32, 20, 32, 64, steps=steps)
+elif name == "s3dis":
+    r = bench.s3dis_batch_workload(dev, steps=steps)
+elif name == "s3dis_eager":
+    r = bench.s3dis_batch_workload(dev, steps=steps, warmup=0, graph=False)
+elif name == "pyramid_eval":
+    r = bench.kitti360_pyramid_eval(dev, 20, 32, steps=steps)
+elif name == "pyramid_train":
+    r = bench.kitti360_pyramid_train(dev, 20, 32, steps=steps)
 else:
     raise SystemExit(f"unknown workload {name}")
 r["env"] = {k: v for k, v in os.environ.items() if k.startswith("DVA_")}
