@@ -125,6 +125,8 @@ SIGNATURES = {
     "dva_chain_attn_fwd": (ctypes.c_int, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd_f32": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_chain_attn_bwd_planrec": (ctypes.c_int, [_vp] * 15 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_plan_inverse": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "dva_chain_score_stats": (ctypes.c_int, [_vp] * 14 + [_i32, _i64, _i64, _vp]),
     "dva_chain_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i32, _i64, _i64, _vp]),
     "dva_gather_bilinear_taps_anchor": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

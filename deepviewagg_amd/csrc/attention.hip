@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
       for (int u = 0; u < U; ++u) {
         const int i = i0 + u * slots + slot;
         ok[u] = i < end;
-        v[u] = perm[ok[u] ? i : beg];
+        v[u] = (REC16 && !perm) ? (ok[u] ? i : beg) : perm[ok[u] ? i : beg];   // perm == NULL: records in plan order
       }
       if (REC16) {
         // one 16-byte record per view: point id | gate * attention per group as bf16
@@ -1480,7 +1480,7 @@ int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, c
   if (n_views > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
   if (n_rows == 0) return DVA_OK;
   if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
-  if (n_views > 0 && (!grad_out || !perm || !view_rec16)) return DVA_ERR_INVALID;
+  if (n_views > 0 && (!grad_out || !view_rec16)) return DVA_ERR_INVALID;     // perm NULL: records in plan order
   if (dtype != DVA_BF16) return DVA_ERR_UNSUPPORTED;
   const int lpr = C / 8;
   if ((C % 8) || !is_pow2(lpr) || lpr > 64 || (C % G) || ((C / G) % 8) || ((uintptr_t)grad_out % 16) ||

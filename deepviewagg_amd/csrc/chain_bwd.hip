@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void att
     const int32_t* __restrict__ n_tiles_dev, const T* __restrict__ rows, const int32_t* __restrict__ row_idx,
     const int64_t* __restrict__ ptr, const float* __restrict__ gw, const float* __restrict__ gb,
     const T* __restrict__ gout, const T* __restrict__ out, float* __restrict__ dc_out,
-    uint32_t* __restrict__ rec, float* __restrict__ gwb, int scaling, float eps, int64_t V, int64_t N, int64_t R) {
+    uint32_t* __restrict__ rec, float* __restrict__ gwb, int scaling, float eps, int64_t V, int64_t N, int64_t R,
+    const int32_t* __restrict__ rec_pos = nullptr) {
+  // rec_pos (nullable, 16-byte records only): the record of view v goes to slot rec_pos[v] (= its position in the row
+  // plan: dva_plan_inverse) instead of slot v -- the rows-gradient pass then streams the records (A/B of round 4)
   constexpr int VEC = 16 / (int)sizeof(T), C = LPR * VEC, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr uint32_t RB = C * sizeof(T);       // bytes of a value / gradient row
   constexpr bool F32 = sizeof(T) == 4;
@@ -328,7 +331,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void att
       st128(RC, wr ? vg * 32u + 16u : OOB, r1);
     } else {   // 16-byte record: the rows gradient is rounded to bf16 anyway, its weights travel as bf16
       const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), 0u};
-      st128(RC, wr ? vg * 16u : OOB, r);
+      uint32_t slot = vg;
+      if (rec_pos) slot = wr ? (uint32_t)rec_pos[vg] : 0u;       // (uniform branch: a kernel argument)
+      st128(RC, wr ? slot * 16u : OOB, r);
     }
     wave_sync();
   });
@@ -911,7 +916,7 @@ using namespace dva::chain;
 
 extern "C" {
 
-int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+static int chain_attn_bwd_impl(const int32_t* rec_pos, const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
                        const void* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
                        const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
                        float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
@@ -929,7 +934,7 @@ int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const voi
   hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, LPR_, G_>), grid, block, 0, s, scores, view_point,                  \
                      (const int2*)tiles, n_tiles, (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b,              \
                      (const bf16_t*)grad_out, (const bf16_t*)out, grad_scores, (uint32_t*)view_rec, grad_gate_wb, \
-                     scaling, eps, n_views, n_points, n_rows)
+                     scaling, eps, n_views, n_points, n_rows, rec_pos)
   const int key = C * 8 + G;
   switch (key) {
     case 32 * 8 + 1: DVA_ATTN_BWD(4, 1); break;
@@ -952,6 +957,25 @@ int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const voi
 #undef DVA_ATTN_BWD
   DVA_CHECK_LAUNCH();
   return DVA_OK;
+}
+
+int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,
+                       const void* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                       const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
+                       float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
+                       int32_t scaling, float eps, void* stream) {
+  return chain_attn_bwd_impl(nullptr, scores, view_point, tiles, n_tiles, rows, row_idx, ptr, gate_w, gate_b, grad_out, out,
+                             grad_scores, view_rec, grad_gate_wb, n_points, n_views, n_rows, C, G, scaling, eps, stream);
+}
+
+int dva_chain_attn_bwd_planrec(const int32_t* rec_pos, const float* scores, const int32_t* view_point, const void* tiles,
+                               const int32_t* n_tiles, const void* rows, const int32_t* row_idx, const int64_t* ptr,
+                               const float* gate_w, const float* gate_b, const void* grad_out, const void* out,
+                               float* grad_scores, void* view_rec, float* grad_gate_wb, int64_t n_points, int64_t n_views,
+                               int64_t n_rows, int32_t C, int32_t G, int32_t scaling, float eps, void* stream) {
+  if (!rec_pos && n_views > 0) return DVA_ERR_INVALID;
+  return chain_attn_bwd_impl(rec_pos, scores, view_point, tiles, n_tiles, rows, row_idx, ptr, gate_w, gate_b, grad_out, out,
+                             grad_scores, view_rec, grad_gate_wb, n_points, n_views, n_rows, C, G, scaling, eps, stream);
 }
 
 int dva_chain_attn_bwd_f32(const float* scores, const int32_t* view_point, const void* tiles, const int32_t* n_tiles,

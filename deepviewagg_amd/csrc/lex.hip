@@ -221,6 +221,21 @@ int64_t dva_row_plan_workspace_bytes(int64_t n_views, int64_t n_rows) {
   return (int64_t)L.total;
 }
 
+__global__ __launch_bounds__(256) void plan_inverse_kernel(const int32_t* __restrict__ perm, int32_t* __restrict__ inv,
+                                                           int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    inv[perm[i]] = (int32_t)i;
+}
+
+int dva_plan_inverse(const int32_t* perm, int32_t* inv, int64_t n_views, void* stream) {
+  if (n_views < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!perm || !inv) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(plan_inverse_kernel, dim3(grid_for(n_views)), dim3(256), 0, (hipStream_t)stream, perm, inv, n_views);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
 int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_t* perm,
                  int32_t* row_ptr, int32_t* counts, void* workspace, int64_t workspace_bytes,
                  void* stream) {

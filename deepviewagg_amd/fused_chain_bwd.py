@@ -123,6 +123,10 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
 # stretches (rows gradient 1.32 -> 2.12 ms, stage 6 1.22 -> 2.18 ms), the sum shrinks by 0.16 ms.  Off by default: the
 # per-kernel durations of the bench line (and its roofline object) are only meaningful when kernels do not overlap.
 OVERLAP_ROWS_GRAD = os.environ.get('DVA_OVERLAP_ROWS_GRAD', '0') == '1'
+# A/B of round 4: the attention backward writes its 16-byte view records in PLAN order (slot =
+# position of the view in the row plan, through dva_plan_inverse) so that the rows gradient streams them.  Measured
+# (profiles/r04*_rows_grad_planrec_ab.json); off by default.
+PLAN_ORDER_RECORDS = os.environ.get('DVA_ROWS_GRAD_PLANREC', '0') == '1'
 _SIDE = {}
 
 
@@ -157,23 +161,38 @@ def backward(ctx, gout):
     gwb = arena.take(2 * G) if gate is not None else None
     # per view: value row + scores 16 + view->point / row index 8 in, score gradients 16 + record 16 out; per point
     # grad_out row (+ out row for points with more than 32 views)
+    plan = None
+    if ctx.needs_input_grad[0]:
+        plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
+    planrec = PLAN_ORDER_RECORDS and plan is not None
+    if planrec:
+        # A/B (round 4): records written in plan order through the inverse of the plan permutation
+        inv = torch.empty(V, dtype=torch.int32, device=dev)
+        with ops._timed("plan_inverse", V * 8):
+            check(lib.dva_plan_inverse(ptr(plan[0]), ptr(inv), V, st), "dva_plan_inverse")
     with ops._timed("chain_attn_bwd", V * (C * 2 + 16 + 8 + 16 + 16) + N * (C * 2 + 8)):
-        check(lib.dva_chain_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx),
-                                     ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
-                                     ptr(gwb), N, V, R, C, G, scaling, eps, st), "dva_chain_attn_bwd")
+        if planrec:
+            check(lib.dva_chain_attn_bwd_planrec(ptr(inv), ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows),
+                                                 ptr(row_idx), ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out),
+                                                 ptr(dc), ptr(rec), ptr(gwb), N, V, R, C, G, scaling, eps, st),
+                  "dva_chain_attn_bwd_planrec")
+        else:
+            check(lib.dva_chain_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx),
+                                         ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout), ptr(out), ptr(dc), ptr(rec),
+                                         ptr(gwb), N, V, R, C, G, scaling, eps, st), "dva_chain_attn_bwd")
     del scores
     # ---- rows gradient: segmented reduction over the row plan (deterministic, no atomics)
     grows = None
     side = None
     if ctx.needs_input_grad[0]:
-        plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
         perm, row_ptr = plan
 
         def rows_grad(stream):
             g = torch.empty((R, C), dtype=torch.float32, device=dev)
             with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
-                check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(g), R, V, C,
-                                                          G, _lib.DVA_BF16, stream), "dva_view_gather_rows_grad_rec16")
+                check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), None if planrec else ptr(perm), ptr(row_ptr),
+                                                          ptr(rec), ptr(g), R, V, C, G, _lib.DVA_BF16, stream),
+                      "dva_view_gather_rows_grad_rec16")
             return g.to(rows.dtype)
         if OVERLAP_ROWS_GRAD:
             main = torch.cuda.current_stream(dev)

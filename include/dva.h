@@ -202,6 +202,8 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
 
 /* The same reduction over packed 16-byte view records {int32 point | 4 x bf16 weight | pad} (dva_chain_attn_bwd):
  * bf16 grad_out, G in {1, 2, 4}, C / 8 a power of two <= 64, (C / G) % 8 == 0. */
+/* (perm may be NULL: the records then lie in plan order -- record i belongs to plan entry i -- as
+ * dva_chain_attn_bwd_planrec writes them.) */
 int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
                                     const void* view_rec16, float* grad_rows, int64_t n_rows, int64_t n_views,
                                     int32_t C, int32_t G, int32_t dtype, void* stream);
@@ -537,6 +539,16 @@ int dva_chain_attn_bwd(const float* scores, const int32_t* view_point, const voi
                        const float* gate_b, const void* grad_out, const void* out, float* grad_scores, void* view_rec,
                        float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C, int32_t G,
                        int32_t scaling, float eps, void* stream);
+/* A/B variant of round 4 (profiles/r04*_rows_grad_planrec_ab.json): dva_chain_attn_bwd that writes the
+ * 16-byte record of view v to slot rec_pos[v] -- its position in the row plan, rec_pos = dva_plan_inverse(perm) -- so that
+ * dva_view_gather_rows_grad_rec16(perm = NULL) streams the records instead of gathering them. */
+int dva_chain_attn_bwd_planrec(const int32_t* rec_pos, const float* scores, const int32_t* view_point, const void* tiles,
+                               const int32_t* n_tiles, const void* rows, const int32_t* row_idx, const int64_t* ptr,
+                               const float* gate_w, const float* gate_b, const void* grad_out, const void* out,
+                               float* grad_scores, void* view_rec, float* grad_gate_wb, int64_t n_points, int64_t n_views,
+                               int64_t n_rows, int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
+/* inv[perm[i]] = i for a permutation of n_views entries (the row plan's `perm`). */
+int dva_plan_inverse(const int32_t* perm, int32_t* inv, int64_t n_views, void* stream);
 /* dva_chain_attn_bwd for fp32 value rows (the no-autocast path: ops.view_gather_attention backward when the scores
  * are fp32 [V][4]): rows / grad_out / out fp32, C in {32, 64, 128, 256}, view_rec = fp32 [V][8] records
  * {point id (int bits) | gate * attention per group | pad} as dva_view_gather_rows_grad reads them (rec_stride 8). */
