@@ -14,6 +14,7 @@ Tie-breaks depend on the ORDER of the candidate points in ``xyz`` (first point w
 highest index wins a shared centre pixel in exact mode), exactly as in the reference.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -22,6 +23,9 @@ from ... import _lib
 from ..._lib import DvaCamera, check, ptr, stream_of
 
 CAMERAS = ('s3dis_equirectangular', 'scannet', 'kitti360_perspective', 'kitti360_fisheye')
+# a single-camera call runs as a batch of one (tiled LDS z-buffer); 0: the single-image kernels of dva_visibility (64-bit
+# atomic z-buffer plane), kept as the A/B and as the tiled build's independent check
+SINGLE_VIA_BATCH = os.environ.get('DVA_VIS_SINGLE_VIA_BATCH', '1') == '1'
 
 
 def _np32(x):
@@ -95,6 +99,23 @@ class VisibilityModel:
         :return: dict(idx LongTensor[q] (index into xyz), x, y LongTensor[q] pixel coordinates in the
           non-cropped projection map, depth FloatTensor[q], features FloatTensor[q, F])
         """
+        if SINGLE_VIA_BATCH:
+            # one camera = a batch of one: the tiled LDS z-buffer of dva_visibility_batch instead of the 64-bit atomic plane
+            # of dva_visibility (round 4; rows identical: tests/test_gpu_mapping.py)
+            def one(a):
+                return None if a is None else torch.as_tensor(a)[None]
+            out = self.batch(xyz, torch.as_tensor(img_xyz)[None], linearity=linearity, planarity=planarity,
+                             scattering=scattering, normals=normals, img_opk=one(img_opk),
+                             img_intrinsic_pinhole=one(img_intrinsic_pinhole),
+                             img_intrinsic_fisheye=one(img_intrinsic_fisheye), img_extrinsic=one(img_extrinsic),
+                             img_mask=img_mask)
+            out.pop('image')
+            out.pop('row_ptr')
+            if out['idx'].shape[0] == 0:       # visibility.py:1721-1729
+                out.pop('x_proj')
+                out.pop('y_proj')
+                out['features'] = torch.empty((0,), dtype=torch.float, device=xyz.device)
+            return out
         lib = _lib.load()
         in_device = xyz.device
         if not torch.cuda.is_available():

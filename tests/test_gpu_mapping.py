@@ -34,6 +34,21 @@ def call_kwargs(g, dev):
     return kw
 
 
+@pytest.fixture
+def single_image_kernels():
+    """Single-camera calls on the single-image kernels of dva_visibility (64-bit atomic z-buffer plane) instead of a batch
+    of one on the tiled build: the two implementations check each other."""
+    from deepviewagg_amd.core.multimodal import visibility as V
+    old, V.SINGLE_VIA_BATCH = V.SINGLE_VIA_BATCH, False
+    yield
+    V.SINGLE_VIA_BATCH = old
+
+
+@pytest.mark.parametrize("name", VIS)
+def test_visibility_golden_single_image_kernels(name, single_image_kernels):
+    test_visibility_golden(name)
+
+
 @pytest.mark.parametrize("name", VIS)
 def test_visibility_golden(name):
     g = load_golden(name)
@@ -143,7 +158,7 @@ def _batch_inputs(g, B, slot, dev):
 
 
 @pytest.mark.parametrize("name", VIS)
-def test_visibility_batch_golden(name):
+def test_visibility_batch_golden(name, single_image_kernels):
     """Every reference fixture through the batched build: the fixture's camera sits among four perturbed cameras of
     the same setting; its rows must be the fixture's (bit-exact indices, pixels, depths), and every image's rows must
     equal the single-image build of that camera."""
@@ -177,7 +192,7 @@ def test_visibility_batch_golden(name):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-def test_visibility_batch_full_size_equals_single(exact):
+def test_visibility_batch_full_size_equals_single(exact, single_image_kernels):
     """S3DIS settings (2048 x 1024 projection map, 100 k candidates), 6 cameras: the batch is the concatenation of the
     single-image builds, bit for bit; image 0 is also held to the C oracle."""
     from deepviewagg_amd.core.multimodal.visibility import SplattingVisibility
@@ -206,7 +221,7 @@ def test_visibility_batch_full_size_equals_single(exact):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-def test_visibility_batch_tiled_zbuffer_fallbacks(exact):
+def test_visibility_batch_tiled_zbuffer_fallbacks(exact, single_image_kernels):
     """The tiled z-buffer of the batched build under stress: camera 0 stands inside a dense cluster of points (thousands
     of splat boxes cover more than 16 screen tiles -- beyond the 4096 slots of the per-image large-box list -- and the
     mid-sized ones overflow the tile lists' capacity of 4 entries per candidate): those survivors fall back to the

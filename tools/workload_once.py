@@ -26,6 +26,8 @@ elif name == "bilinear_kitti":
     r = bench.secondary_workload("bilinear", dev, bf, 20, 32, 128, steps=steps, interpolate=True, C_out=32)
 elif name == "f32":
     r = bench.secondary_workload("f32", dev, torch.float32, 20, 32, 64, steps=steps)
+elif name == "qkv":
+    r = bench.secondary_workload("qkv", dev, bf, 20, 32, 64, steps=steps)
 elif name == "s3dis":
     r = bench.s3dis_batch_workload(dev, steps=steps)
 elif name == "s3dis_eager":
