@@ -26,6 +26,8 @@
 // Two orientations of Linear_b: "standard" D[out channel][view] (lane = view: chains into further products) and
 // "flipped" D[view][out channel] (the same operands in swapped roles: lane = channel, registers = views), in which
 // BatchNorm constants are per-lane scalars and a reduction over the views of a point is in-lane arithmetic.
+#include <type_traits>
+
 #include "chain_common.h"
 
 namespace dva {
@@ -398,7 +400,7 @@ __device__ __forceinline__ void act_a(const f32x16 (&za)[NB], const float (*taba
 // stats fp64 [2][CO] = sum | sum of squares, natural channel order
 // ------------------------------------------------------------------------------------------------
 template <int CO, int L>
-__global__ __launch_bounds__(256, 2) void emod_stats_kernel(
+__global__ __launch_bounds__(256, CO >= 256 ? 1 : 2) void emod_stats_kernel(
     const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, double* __restrict__ stats, bf16_t* __restrict__ zst, int64_t V, int64_t R) {
@@ -872,7 +874,19 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
     gwl[e] = gw ? gw[gl[e]] : 0.f;
     gbl[e] = gw ? gb[gl[e]] : 0.f;
   }
-  const LaneBN<NB> kb = lane_bn<NB>(bnb, CO, lane);
+  // per-lane BatchNorm_b constants of the flipped layer: registers up to four blocks, an LDS table from eight on (16
+  // registers less in a kernel that spills at that width)
+  constexpr bool KB_LDS = NB >= 8;
+  __shared__ float s_kb[KB_LDS ? 2 * CO : 1];
+  if (KB_LDS) {
+    for (int c = threadIdx.x; c < CO; c += blockDim.x) {
+      const float g = bnb[2 * CO + c] * bnb[CO + c];
+      s_kb[c] = 0.6f * g;
+      s_kb[CO + c] = 0.6f * (bnb[3 * CO + c] - bnb[c] * g);
+    }
+    __syncthreads();
+  }
+  const LaneBN<KB_LDS ? 1 : NB> kb = lane_bn<KB_LDS ? 1 : NB>(bnb, CO, lane);
   int gch[NB];
 #pragma unroll
   for (int mb = 0; mb < NB; ++mb) gch[mb] = (32 * mb + j) / GS;
@@ -903,7 +917,7 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
   // C_o = 32: without the prefetch register set the kernel fits four wavefronts per SIMD (C_o >= 128 at one wavefront per
   // SIMD lives on the prefetch: 9.0 -> see DESIGN)
   auto loop = [&](auto&& ld, auto&& bd) {
-    if constexpr (CO == 32 || (CO >= 128 && OCC == 2)) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
+    if constexpr (CO == 32 || (CO >= 128 && OCC == 2) || CO >= 256) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
     else run_tiles<Pre>(tiles, ta, tb, ld, bd);
   };
   loop([&](const TileInfo& ti, int t) {
@@ -1037,34 +1051,52 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) {
         const f32x16 zbm = linear_b_flipped_blk<NB>(s_eops, lane, aa, mb);
+        const float g6m = KB_LDS ? s_kb[32 * mb + j] : kb.g6[KB_LDS ? 0 : mb];
+        const float b6m = KB_LDS ? s_kb[CO + 32 * mb + j] : kb.b6[KB_LDS ? 0 : mb];
         if ((mb % BPG) == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) dq[r] = 0.f;
         }
+        // the epilogue of the block in two instances behind ONE wave-uniform branch: with the per-value select inside
+        // (go_of) hipcc issues the 16 gathered grad_out loads of the several-points case for every tile and keeps them
+        // in flight across the blocks
+        auto epilogue = [&](auto single_tag) {
+          constexpr bool SINGLE = decltype(single_tag)::value;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 w = *reinterpret_cast<const float4*>(ga_t + gch[mb] * 32 + 8 * q + 4 * h);
-          const float ww[4] = {w.x, w.y, w.z, w.w};
+          for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(ga_t + gch[mb] * 32 + 8 * q + 4 * h);
+            const float ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * q + i;
-            const float go = go_of(mb, r);
-            const float t = __builtin_fmaf(zbm[r], kb.g6[mb], kb.b6[mb]);
-            const float d = go * leaky06(t);
-            if (GS >= 64) {
-              dq[r] += d;
-            } else {
-              const float dr = group_reduce(d);
-              if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = dr;
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * q + i;
+              float go;
+              if constexpr (SINGLE) {
+                go = go1[mb];
+              } else {
+                const int v = view_of(r, h);
+                const uint32_t pid = (uint32_t)pid_t[v];
+                go = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
+                    GO, v < nv ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB, 0, 0));
+              }
+              const float t = __builtin_fmaf(zbm[r], g6m, b6m);
+              const float d = go * leaky06(t);
+              if (GS >= 64) {
+                dq[r] += d;
+              } else {
+                const float dr = group_reduce(d);
+                if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = dr;
+              }
+              // the records carry gate * attention as bf16: the later passes see the rounded weight
+              const float gar = bf2f(f2bf(ww[i]));
+              const float dval = gar * go;
+              const float dy = t > 0.f ? dval : SLOPE * dval;
+              sb1[mb] += dy;
+              sb2[mb] = __builtin_fmaf(dy, zbm[r], sb2[mb]);
             }
-            // the records carry gate * attention as bf16: the later passes see the rounded weight
-            const float gar = bf2f(f2bf(ww[i]));
-            const float dval = gar * go;
-            const float dy = t > 0.f ? dval : SLOPE * dval;
-            sb1[mb] += dy;
-            sb2[mb] = __builtin_fmaf(dy, zbm[r], sb2[mb]);
           }
-        }
+        };
+        if (single) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         if (GS >= 64 && (mb % BPG) == BPG - 1) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -1403,6 +1435,10 @@ __global__ __launch_bounds__(256, 2) void emod_bwd_kernel(
 //          -> dW_b += dz_b^T y_a through the transpose read (wgradN).
 // One more evaluation of Linear_b (2 V CO^2 flop) against 8 CO more bytes per view for handing dz_b over.
 // ------------------------------------------------------------------------------------------------
+//   MODE 3 / MODE 4 (C_o = 256, one wavefront per SIMD): MODE 1 cut in two, because the operands of W_b (128 KB per
+//          orientation) do not fit LDS together: MODE 3 = z_b -> dz_b, written as bf16 [V][CO] into the buffer that will hold
+//          dy_a; MODE 4 = the stored dz_b -> dy_a IN PLACE (a lane reads and writes the same 32-byte pieces of its view) + S of
+//          BatchNorm_a.  Between the two, emodw_wgrad_coop_kernel takes dW_b from the stored dz_b.
 template <int CO, int G, int MODE>
 __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
@@ -1410,29 +1446,36 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
     const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout, bf16_t* __restrict__ da, float* __restrict__ dWb,
     double* __restrict__ stats_a, const bf16_t* __restrict__ zst, int64_t V, int64_t N) {
   constexpr int NB = CO / 32, GS = CO / G, NW = MODE == 1 ? 8 : 4;
+  constexpr bool FWD = MODE != 4;                    // evaluates z_b -> dz_b
+  constexpr bool DYA = MODE == 1 || MODE == 4;       // evaluates dy_a
   constexpr int NT = MODE == 2 ? NB : 1;
+  constexpr int N_EOPS = (MODE == 1 ? 2 : 1) * NB * NB * 2 * 64;
+  constexpr int BWD_BASE = MODE == 4 ? NB * NB * 2 : 0;      // MODE 4 holds the second half of the table only
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) float s_tabb[NB][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) uint4 s_eops[(MODE == 1 ? 2 : 1) * NB * NB * 2 * 64];
-  // MODE 1: [0] = the dy_a block, [1] = the z_a block;  MODE 2: NB tiles of dz_b, NB tiles of y_a
-  __shared__ __attribute__((aligned(16))) bf16_t s_ta[NW][NT][32 * TSB], s_tb[NW][NT][32 * TSB];
+  __shared__ __attribute__((aligned(16))) float s_tabb[FWD ? NB : 1][FWD ? TAB_FLOATS : 8];
+  __shared__ __attribute__((aligned(16))) uint4 s_eops[N_EOPS];
+  // MODE 1 / 4: [0] = the dy_a block, [1] = the z_a block;  MODE 2: NB tiles of dz_b, NB tiles of y_a;  MODE 3: unused
+  __shared__ __attribute__((aligned(16))) bf16_t s_ta[MODE == 3 ? 1 : NW][NT][MODE == 3 ? 8 : 32 * TSB],
+      s_tb[MODE == 3 ? 1 : NW][NT][MODE == 3 ? 8 : 32 * TSB];
   float* s_red = reinterpret_cast<float*>(&s_ta[0][0][0]);     // epilogue: D x D floats | NW x 64 floats
-  static_assert(sizeof(bf16_t) * NW * NT * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
+  static_assert(MODE == 3 || sizeof(bf16_t) * NW * NT * 32 * TSB >= sizeof(float) * (MODE == 2 ? D * D : NW * 64),
+                "epilogue buffer");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < (MODE == 1 ? 2 : 1) * NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
+  for (int i = threadIdx.x; i < N_EOPS; i += blockDim.x) s_eops[i] = eops[BWD_BASE * 64 + i];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    stage_tab_c(s_tabb[b], bnb, CO, 32 * b, smb);
+    if (FWD) stage_tab_c(s_tabb[b], bnb, CO, 32 * b, smb);
     stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t RC = make_rsrc(rec, (uint64_t)V * 16), GO = make_rsrc(gout, (uint64_t)N * CO * 2);
-  float sa1[MODE == 1 ? NB : 1], sa2[MODE == 1 ? NB : 1];
+  float sa1[DYA ? NB : 1], sa2[DYA ? NB : 1];
   f32x16 accW[MODE == 2 ? NB : 1][MODE == 2 ? NB : 1];
-  if (MODE == 1) {
+  if (DYA) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) sa1[b] = sa2[b] = 0.f;
-  } else {
+  }
+  if (MODE == 2) {
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
 #pragma unroll
@@ -1448,6 +1491,7 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
   struct Pre {
     TileInfo ti;
     ZaRows<NB> z;        // the stored z_a
+    ZaRows<MODE == 4 ? NB : 1> dz;      // MODE 4: the stored dz_b
     u32x4 rc;
   };
   auto loop = [&](auto&& ld, auto&& bd) {
@@ -1459,59 +1503,74 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
     p.ti = ti;
     const bool ok = j < p.ti.nv;
     p.z = load_za<CO>(zst, ti, j, h);
-    p.rc = ld128(RC, ok ? (uint32_t)(p.ti.v0 + j) * 16u : OOB);
+    if constexpr (MODE == 4) p.dz = load_za<CO>(da, ti, j, h);
+    else p.rc = ld128(RC, ok ? (uint32_t)(p.ti.v0 + j) * 16u : OOB);
     return p;
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
     const uint32_t keep = ok ? 0xffffffffu : 0u;
-    bf16x8 a[NB][2];
-    act_a_rows<NB>(p.z, s_taba, h, keep, a);
-    if (MODE == 2) {
+    // (the handed-over gradient [V][CO] exceeds 4 GiB at the headline size: one descriptor per tile)
+    const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)p.ti.v0 * CO, (uint64_t)p.ti.nv * CO * 2);
+    bf16x8 dzp[(MODE == 1 || MODE == 4) ? NB : 1][2];
+    if constexpr (FWD) {
+      bf16x8 a[NB][2];
+      act_a_rows<NB>(p.z, s_taba, h, keep, a);
+      if (MODE == 2) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) tileN_put_packed(s_tb[wv][b], j, h, a[b]);
+        for (int b = 0; b < NB; ++b) tileN_put_packed(s_tb[wv][b], j, h, a[b]);
+      }
+      // d value[ch] = (gate attention)[g(ch)] grad_out[point][ch] for the lane's channels 32 mb + chan(r, h)
+      const uint32_t pid = p.rc.x;
+      const float ga4[4] = {__uint_as_float(p.rc.y << 16), __uint_as_float(p.rc.y & 0xffff0000u),
+                            __uint_as_float(p.rc.z << 16), __uint_as_float(p.rc.z & 0xffff0000u)};
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const f32x16 zb = linear_b_std_blk<NB>(s_eops, lane, a, mb);
+        f32x16 dy;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * mb + 8 * q + 4 * h;            // channels c0 .. c0 + 3 = chan(4 q + i, h) + 32 mb
+          const u32x2 gv = ld64(GO, ok ? pid * (uint32_t)(CO * 2) + (uint32_t)c0 * 2u : OOB);
+          const float gg = ga4[G == 1 ? 0 : c0 / GS];
+          dy[4 * q] = gg * __uint_as_float(gv.x << 16);
+          dy[4 * q + 1] = gg * __uint_as_float(gv.x & 0xffff0000u);
+          dy[4 * q + 2] = gg * __uint_as_float(gv.y << 16);
+          dy[4 * q + 3] = gg * __uint_as_float(gv.y & 0xffff0000u);
+        }
+        // dy_b = leaky'(y_b) d value, y_b = G_b z_b + B_b;  dz_b = G_b dy_b - K1 - K2 z_b
+        float dz[16];
+        {
+          asm volatile("" ::: "memory");
+          float g_[16], b_[16];
+          tab16(s_tabb[mb], T_G, h, g_);
+          tab16(s_tabb[mb], T_B, h, b_);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dy[r] = __builtin_fmaf(zb[r], g_[r], b_[r]) > 0.f ? dy[r] : SLOPE * dy[r];
+        }
+        bn_bwd_apply(zb, dy, s_tabb[mb], h, dz);
+        if (MODE == 1) {
+          pack16(dz, keep, dzp[mb]);
+        } else {
+          bf16x8 t2[2];
+          pack16(dz, keep, t2);
+          if (MODE == 2) {
+            tileN_put_packed(s_ta[wv][mb], j, h, t2);
+          } else {      // MODE 3: hand dz_b over (position order, the lane's 32 bytes of block mb)
+            const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + 16 * h) * 2u : OOB;
+            st128(DA, off, __builtin_bit_cast(u32x4, t2[0]));
+            st128(DA, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, t2[1]));
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        dzp[mb][0] = __builtin_bit_cast(bf16x8, p.dz.q[mb][0]);
+        dzp[mb][1] = __builtin_bit_cast(bf16x8, p.dz.q[mb][1]);
+      }
     }
-    // d value[ch] = (gate attention)[g(ch)] grad_out[point][ch] for the lane's channels 32 mb + chan(r, h)
-    const uint32_t pid = p.rc.x;
-    const float ga4[4] = {__uint_as_float(p.rc.y << 16), __uint_as_float(p.rc.y & 0xffff0000u),
-                          __uint_as_float(p.rc.z << 16), __uint_as_float(p.rc.z & 0xffff0000u)};
-    bf16x8 dzp[MODE == 1 ? NB : 1][2];
-#pragma unroll
-    for (int mb = 0; mb < NB; ++mb) {
-      const f32x16 zb = linear_b_std_blk<NB>(s_eops, lane, a, mb);
-      f32x16 dy;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 32 * mb + 8 * q + 4 * h;            // channels c0 .. c0 + 3 = chan(4 q + i, h) + 32 mb
-        const u32x2 gv = ld64(GO, ok ? pid * (uint32_t)(CO * 2) + (uint32_t)c0 * 2u : OOB);
-        const float gg = ga4[G == 1 ? 0 : c0 / GS];
-        dy[4 * q] = gg * __uint_as_float(gv.x << 16);
-        dy[4 * q + 1] = gg * __uint_as_float(gv.x & 0xffff0000u);
-        dy[4 * q + 2] = gg * __uint_as_float(gv.y << 16);
-        dy[4 * q + 3] = gg * __uint_as_float(gv.y & 0xffff0000u);
-      }
-      // dy_b = leaky'(y_b) d value, y_b = G_b z_b + B_b;  dz_b = G_b dy_b - K1 - K2 z_b
-      float dz[16];
-      {
-        asm volatile("" ::: "memory");
-        float g_[16], b_[16];
-        tab16(s_tabb[mb], T_G, h, g_);
-        tab16(s_tabb[mb], T_B, h, b_);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dy[r] = __builtin_fmaf(zb[r], g_[r], b_[r]) > 0.f ? dy[r] : SLOPE * dy[r];
-      }
-      bn_bwd_apply(zb, dy, s_tabb[mb], h, dz);
-      if (MODE == 1) {
-        pack16(dz, keep, dzp[mb]);
-      } else {
-        bf16x8 t2[2];
-        pack16(dz, keep, t2);
-        tileN_put_packed(s_ta[wv][mb], j, h, t2);
-      }
-    }
-    if constexpr (MODE == 1) {
+    if constexpr (DYA) {
       // da = W_b^T dz_b, dy_a = leaky'(y_a) da, handed over as bf16 (position order);  S of BatchNorm_a from the stored rows
-      // (the handed-over gradient [V][CO] exceeds 4 GiB at the headline size: one descriptor per tile)
-      const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)p.ti.v0 * CO, (uint64_t)p.ti.nv * CO * 2);
       bf16_t* tdy = s_ta[wv][0];
       bf16_t* tz = s_tb[wv][0];
 #pragma unroll
@@ -1521,7 +1580,8 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m) dya = CH_MFMA(lds_op(s_eops, op_bwd<NB>(b, mb, m), lane), dzp[mb][m], dya);
+          for (int m = 0; m < 2; ++m)
+            dya = CH_MFMA(lds_op(s_eops, op_bwd<NB>(b, mb, m) - BWD_BASE, lane), dzp[mb][m], dya);
         }
         f32x16 za;
         unpack_za_blk<NB>(p.z, b, za);
@@ -1545,7 +1605,7 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
         col_sums2(tdy, tz, lane, sa1[b], sa2[b]);
         wave_sync();
       }
-    } else {
+    } else if constexpr (MODE == 2) {
       wave_sync();
 #pragma unroll
       for (int mb = 0; mb < NB; ++mb) {
@@ -1555,19 +1615,88 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
       wave_sync();
     }
   });
-  if constexpr (MODE == 1) {
+  if constexpr (DYA) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float a0 = sa1[b] + other_half(sa1[b]), a1 = sa2[b] + other_half(sa2[b]);
       flush_lane_stats(a0, a1, stats_a, stats_a + CO, 32 * b, s_red, true);
     }
-  } else {
+  } else if constexpr (MODE == 2) {
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
 #pragma unroll
       for (int b = 0; b < NB; ++b)
         flush_matrix_nat(accW[mb][b], dWb + (32 * mb) * CO + 32 * b, CO, D, false, s_red, true);
     }
+  }
+}
+
+// dW_b += dz_b^T y_a from the STORED dz_b (emodw_bwd MODE 3) and z_a, for widths whose 16 NB^2 accumulator registers no
+// wavefront can hold (C_o = 256: 1024): the NB wavefronts of a block work on the SAME 32-view tile -- wavefront w loads
+// block w of z_a and of dz_b, applies BatchNorm_a + LeakyReLU, writes both as natural LDS tiles, and owns the rows of
+// dW_b of output block w (NB accumulator blocks = 128 registers at C_o = 256): after the block barrier it reads its own
+// dz_b tile and the y_a tiles of all input blocks through the transpose read.  No weight operands in LDS at all.
+template <int CO>
+__global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const float* __restrict__ bna,
+    const bf16_t* __restrict__ dzst, const bf16_t* __restrict__ zst, float* __restrict__ dWb) {
+  constexpr int NB = CO / 32;
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) bf16_t s_ta[2][NB][32 * TSB], s_tb[2][NB][32 * TSB];     // double-buffered tiles
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
+  __syncthreads();
+  f32x16 accW[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const f32x16 zero = {0};
+    accW[b] = zero;
+  }
+  const int n_tiles = n_tiles_dev[0];
+  const int t0 = (int)((int64_t)n_tiles * blockIdx.x / gridDim.x), t1 = (int)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  auto fetch = [&](int t, u32x4 (&z)[2], u32x4 (&d)[2], bool& ok) {
+    const TileInfo ti = get_tile(tiles, t);
+    ok = j < ti.nv;
+    const __amdgpu_buffer_rsrc_t Z = make_rsrc(zst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2),
+                                 DZ = make_rsrc(dzst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
+    const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * w + 16 * h) * 2u : OOB;
+    z[0] = ld128(Z, off);
+    z[1] = ld128(Z, ok ? off + 16u : OOB);
+    d[0] = ld128(DZ, off);
+    d[1] = ld128(DZ, ok ? off + 16u : OOB);
+  };
+  u32x4 zq[2], dq[2];
+  bool ok = false;
+  if (t0 < t1) fetch(t0, zq, dq, ok);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    {
+      // this wavefront's block of the tile: y_a = leaky(BatchNorm_a(z_a)) (0 for lanes without a view), dz_b as stored
+      f32x16 za;
+      const uint32_t v[8] = {zq[0].x, zq[0].y, zq[0].z, zq[0].w, zq[1].x, zq[1].y, zq[1].z, zq[1].w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        za[2 * i] = __uint_as_float(v[i] << 16);
+        za[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+      }
+      bf16x8 a[2];
+      act_pack(za, s_taba[w], h, ok ? 0xffffffffu : 0u, a);
+      const bf16x8 dzk[2] = {__builtin_bit_cast(bf16x8, dq[0]), __builtin_bit_cast(bf16x8, dq[1])};
+      tileN_put_packed(s_tb[buf][w], j, h, a);
+      tileN_put_packed(s_ta[buf][w], j, h, dzk);
+    }
+    if (t + 1 < t1) fetch(t + 1, zq, dq, ok);       // the next tile's loads fly during the products
+    __syncthreads();       // tiles of all blocks written (the other buffer is free: its readers passed this barrier once more)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) accW[b] = wgradN(s_ta[buf][w], s_tb[buf][b], lane, accW[b]);      // dW_b[32 w ..][32 b ..]
+  }
+  // rows of the accumulator = image columns of the dz_b tile, columns = image columns of the y_a tile (cperm)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      atomicAdd(&dWb[(size_t)(32 * w + cperm(chan(r, h))) * CO + 32 * b + cperm(j)], accW[b][r]);
   }
 }
 
@@ -1595,13 +1724,15 @@ int dva_emod_prep(const float* Wb, int32_t C_out, void* ops, void* stream) {
 int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
                    const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, void* z_a,
                    int64_t n_views, int64_t n_rows, int32_t C_out, void* stream) {
-  if (n_views < 0 || (layer != 1 && layer != 2) || (C_out != 32 && C_out != 64 && C_out != 128)) return DVA_ERR_INVALID;
+  if (n_views < 0 || (layer != 1 && layer != 2) || (C_out != 32 && C_out != 64 && C_out != 128 && C_out != 256))
+    return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!tiles || !n_tiles || !stats) return DVA_ERR_INVALID;
   if (layer == 1 && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
   if (layer == 2 && (!eops || !bn_a || !z_a)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
-  const dim3 grid(chain_grid(2)), block(256);      // (layer 1 at 3 blocks per CU: no gain, the pass is bandwidth-bound)
+  // (layer 1 at 3 blocks per CU: no gain, the pass is bandwidth-bound; C_out = 256: W_b alone is 128 KB of LDS)
+  const dim3 grid(chain_grid(C_out >= 256 && layer == 2 ? 1 : 2)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_STATS(CO_, L_)                                                                              \
   hipLaunchKernelGGL((emod_stats_kernel<CO_, L_>), grid, block, 0, s, (const bf16_t*)Y, (const int4*)tap_rows, \
@@ -1611,8 +1742,10 @@ int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const 
   else if (C_out == 32) DVA_EMOD_STATS(32, 2);
   else if (C_out == 64 && layer == 1) DVA_EMOD_STATS(64, 1);
   else if (C_out == 64) DVA_EMOD_STATS(64, 2);
-  else if (layer == 1) DVA_EMOD_STATS(128, 1);
-  else DVA_EMOD_STATS(128, 2);
+  else if (C_out == 128 && layer == 1) DVA_EMOD_STATS(128, 1);
+  else if (C_out == 128) DVA_EMOD_STATS(128, 2);
+  else if (layer == 1) DVA_EMOD_STATS(256, 1);
+  else DVA_EMOD_STATS(256, 2);
 #undef DVA_EMOD_STATS
   DVA_CHECK_LAUNCH();
   return DVA_OK;
@@ -1633,7 +1766,6 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
   if (!z_a && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * 128 > 0xfffffff0ll || n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  if (C_out > 128 && z_a) return DVA_ERR_UNSUPPORTED;      // the train-mode passes stop at C_out = 128
   const dim3 grid(chain_grid(C_out > 64 ? (C_out == 128 ? 2 : 1) : (C_out == 32 && z_a ? (G == 1 ? 3 : 4) : 2))), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_FWD_Z(CO_, G_, ZM_)                                                                                  \
@@ -1657,7 +1789,7 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
     case 128 * 8 + 1: DVA_EMOD_FWD(128, 1); break;
     case 128 * 8 + 2: DVA_EMOD_FWD(128, 2); break;
     case 128 * 8 + 4: DVA_EMOD_FWD(128, 4); break;
-    case 256 * 8 + 4: DVA_EMOD_FWD_Z(256, 4, 0); break;
+    case 256 * 8 + 4: DVA_EMOD_FWD(256, 4); break;
     default: return DVA_ERR_UNSUPPORTED;
   }
 #undef DVA_EMOD_FWD
@@ -1681,8 +1813,8 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
   DVA_EMOD_CHECK_SIZES();
   if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   static const int bpc32 = tune_int("DVA_EMOD_ABWD_BPC", 4);      // read once (getenv), like the other switches
-  static const int occ128 = tune_int("DVA_EMOD_ABWD128_OCC", 1);  // C_out = 128: 1 = 512 registers, 2 = 256 with spills
-  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : (C_out >= 128 ? occ128 : 2))), block(256);
+  static const int occ128 = tune_int("DVA_EMOD_ABWD128_OCC", 2);  // C_out = 128: two wavefronts per SIMD (206 - 215 VGPRs)
+  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : (C_out == 128 ? occ128 : (C_out == 256 ? 1 : 2)))), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_BWD(CO_, G_)                                                                                      \
   hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \
@@ -1711,6 +1843,7 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
     case 128 * 8 + 1: DVA_EMOD_BWD128(1); break;
     case 128 * 8 + 2: DVA_EMOD_BWD128(2); break;
     case 128 * 8 + 4: DVA_EMOD_BWD128(4); break;
+    case 256 * 8 + 4: DVA_EMOD_BWD_O(256, 4, 1); break;
 #undef DVA_EMOD_BWD128
 #undef DVA_EMOD_BWD_O
     default: return DVA_ERR_UNSUPPORTED;
@@ -1725,9 +1858,10 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
                  const float* sm_b, const void* view_rec, const void* grad_out, void* da, float* dWb, double* stats_a,
                  const void* z_a, int64_t n_points, int64_t n_views, int64_t n_rows, int32_t C_out, int32_t G,
                  void* stream) {
-  if (n_views < 0 || stage < 1 || stage > 4 || (C_out != 32 && C_out != 64 && C_out != 128) ||
+  if (n_views < 0 || stage < 1 || stage > 4 || (C_out != 32 && C_out != 64 && C_out != 128 && C_out != 256) ||
       (G != 1 && G != 2 && G != 4))
     return DVA_ERR_INVALID;
+  if (C_out == 256 && (stage != 2 || G != 4)) return DVA_ERR_UNSUPPORTED;    // (dz_b lives in `da` between its three kernels)
   if (stage == 1 && C_out > 64) return DVA_ERR_UNSUPPORTED;     // (the in-place form; the anchor scatter applies it)
   if (stage > 2 && C_out < 128) return DVA_ERR_UNSUPPORTED;     // the halves of stage 2 exist for wide rows only
   const bool do_dya = stage != 4, do_wgrad = stage != 3;
@@ -1778,6 +1912,17 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
       case 128 * 8 + 2: DVA_EMODW(2); break;
       case 128 * 8 + 4: DVA_EMODW(4); break;
 #undef DVA_EMODW
+      case 256 * 8 + 4:
+        // W_b (128 KB per orientation) does not fit LDS twice: dz_b -> `da`, dW_b from the stored dz_b, dy_a in place
+        hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 3>), dim3(chain_grid(1)), dim3(256), 0, s, (const int2*)tiles, n_tiles,
+                           (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
+                           (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
+        hipLaunchKernelGGL((emodw_wgrad_coop_kernel<256>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
+                           bn_a, (const bf16_t*)da, (const bf16_t*)z_a, dWb);
+        hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 4>), dim3(chain_grid(1)), dim3(256), 0, s, (const int2*)tiles, n_tiles,
+                           (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
+                           (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
+        break;
       default: return DVA_ERR_UNSUPPORTED;
     }
   }

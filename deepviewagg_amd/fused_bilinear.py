@@ -63,10 +63,8 @@ def applicable(module, x_mod, x_map, csr_idx):
     C, G = module.out_mod, module.num_groups
     if C not in (32, 64, 128, 256) or G not in (1, 2, 4) or C % G or (C // G) % 8 or (C == 256 and G != 4):
         return False
-    if C >= 256 and (module.E_map.training or torch.is_grad_enabled()):
-        # C_out = 256 (KITTI-360 pyramid level 512 -> 256): the one-kernel eval path only.  C_out = 128 (256 -> 128) trains
-        # on the block-by-block kernels since round 4 (chain_emod.hip "wide rows")
-        return False
+    # (C_out = 128 / 256 -- the KITTI-360 pyramid levels 256 -> 128, 512 -> 256 -- train on the block-by-block kernels since
+    #  round 4: chain_emod.hip "wide rows")
     if lin_a.bias is not None or lin_b.bias is not None or lin_b.in_features != C or lin_b.out_features != C:
         return False
     for bn, act in ((bn_a, act_a), (bn_b, act_b)):
@@ -168,7 +166,7 @@ class _EmodPool(torch.autograd.Function):
         inv_m = (1.0 / float(max(V, 1))) if training else 0.0
         S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
                             bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G, training=training)
-        arena = Arena(dev)
+        arena = Arena(dev, n_floats=(1 << 15) + C * C)      # + dW_b (65 536 floats at C_out = 256)
         za_bytes = V * C * 2
         if za is None:      # forward ran in eval mode: the backward passes read the stored z_a, build it now
             za = torch.empty((V, C), dtype=torch.bfloat16, device=dev)
@@ -202,9 +200,11 @@ class _EmodPool(torch.autograd.Function):
                 check(lib.dva_emod_bwd(stage, None, None, None, ptr(tiles), ptr(n_tiles), ptr(eops), ptr(tab_a),
                                        ptr(tab_b), None, ptr(sm_b), ptr(rec), ptr(gout), ptr(da), ptr(dWb),
                                        ptr(stats_a), ptr(za), N, V, R, C, G, st), "dva_emod_bwd")
-        if C >= 128:      # wide rows: dy_a + S of BatchNorm_a, then dW_b (Linear_b evaluated once more), two kernels
+        if C == 128:      # wide rows: dy_a + S of BatchNorm_a, then dW_b (Linear_b evaluated once more), two kernels
             emod_bwd(3, "emod_bwd_dya", za_bytes + V * (16 + C * 2) + N * C * 2)
             emod_bwd(4, "emod_bwd_wgrad", za_bytes + V * 16 + N * C * 2)
+        elif C == 256:    # dz_b -> da, dW_b from the stored dz_b, dy_a in place: three kernels behind stage 2
+            emod_bwd(2, "emod_bwd_b", 3 * za_bytes + V * (16 + 4 * C * 2) + N * C * 2)
         else:
             emod_bwd(2, "emod_bwd_b", za_bytes + V * (16 + C * 2) + N * C * 2)
         del rec

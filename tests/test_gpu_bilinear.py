@@ -108,6 +108,10 @@ CASES = [
     (ragged, 900, 96, 128, 2, True),
     (full32, 512, 64, 128, 1, True),
     (ragged_long, 700, 128, 128, 4, False),
+    # C_o = 256 (pyramid level 512 -> 256): dz_b handed over in HBM, dW_b by the block-cooperative kernel
+    (ragged_long, 900, 160, 256, 4, True),
+    (full32, 512, 64, 256, 4, True),
+    (ragged_long, 1200, 96, 256, 4, False),
 ]
 
 
@@ -202,14 +206,14 @@ def test_fused_bilinear_through_the_data_objects():
 
 @pytest.mark.parametrize("train", [True, False])
 def test_materialised_fallback_hoists_the_first_linear(train):
-    """Training at C_out = 256 (the deepest KITTI-360 pyramid level: 512 -> 256) is outside the fused kernels (C_out = 128
-    trains on them since round 4): the fallback runs E_mod's first Linear on the map rows and interpolates its C_out
+    """What the fused kernels do not cover (here: C_out = 256 with two channel groups; the published 512 -> 256 level has
+    four and trains on them since round 4) takes the materialised fallback: it runs E_mod's first Linear on the map rows and interpolates its C_out
     channels (interp(x) W^T = interp(x W^T)) instead of materialising [V, C_in] and a per-view GEMM.  Checked against
     the oracle like the fused path, and against the un-hoisted device dataflow."""
     from deepviewagg_amd.modules.multimodal import pooling as P
-    CO = 256
+    CO, G_ = 256, 2          # (C_out = 256 is fused for G = 4 only)
     case = make_case(31, 1200, 96, ragged)
-    ref, m = build(case, CO, 4, train)
+    ref, m = build(case, CO, G_, train)
     w = torch.randn(case["N"], CO, generator=case["gen"])
     calls = []
     orig = P._hoisted_first_linear
@@ -223,7 +227,7 @@ def test_materialised_fallback_hoists_the_first_linear(train):
         out, g, used = run_dev(case, m, w, fused=True)
         assert calls == [True] and used["fn"] != "_EmodPoolBackward"
         P._hoisted_first_linear = lambda mlp, x_mod: (x_mod.materialize(), False)
-        _, m2 = build(case, CO, 4, train)
+        _, m2 = build(case, CO, G_, train)
         out_b, g_b, _ = run_dev(case, m2, w, fused=True)
     finally:
         P._hoisted_first_linear = orig
@@ -289,10 +293,7 @@ def test_fused_bilinear_eval_c128(sizes_fn, N, C_in, G, C_out):
             out, _, _ = run_dev(case, m, w, fused=True, need_grad=False)
         assert calls == [1], "the fused eval kernel must be the path that ran"
         out_grad, _, used = run_dev(case, m, w, fused=True, need_grad=True)       # grad enabled
-        if C_out == 128:
-            assert calls == [1, 1] and used["fn"] == "_EmodPoolBackward"
-        else:
-            assert calls == [1] and used["fn"] != "_EmodPoolBackward"
+        assert calls == [1, 1] and used["fn"] == "_EmodPoolBackward"      # both widths train on the fused path (round 4)
     finally:
         fused_bilinear.pool = orig
     with torch.no_grad():
