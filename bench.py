@@ -672,9 +672,9 @@ def kitti360_pyramid_eval(device, log2_points, views, steps=10):
 def kitti360_pyramid_train(device, log2_points, views, steps=5):
     """Training step (train mode, forward + backward) of the view pooling over the five pyramid levels of the reference's
     published KITTI-360 model (conf/models/segmentation/multimodal/sparseconv3d.yaml:7281-7290, interpolate=True, G = 4)
-    at the S1 scene size.  Levels up to C_out = 128 run the fused bilinear path (C_out = 128: the block-by-block kernels
-    of round 4); 512 -> 256 trains on the materialised dataflow with the hoisted Linear_a.  Per level: ms/step, whether
-    the fused path ran, sanity values; for the two wide levels also the materialised dataflow on the same scene."""
+    at the S1 scene size: all five levels on the fused bilinear path (C_out = 128 / 256: the block-by-block kernels of round
+    4).  Per level: ms/step, whether the fused path ran, sanity values; for the two wide levels also the reference's
+    materialised dataflow ([V, C_in] gather + per-view E_mod) on the same scene and its sanity values as the yardstick."""
     N = 1 << log2_points
     out = {"points": N, "views": N * views, "levels": {}}
     total = 0.0

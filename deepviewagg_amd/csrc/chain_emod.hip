@@ -400,7 +400,7 @@ __device__ __forceinline__ void act_a(const f32x16 (&za)[NB], const float (*taba
 // stats fp64 [2][CO] = sum | sum of squares, natural channel order
 // ------------------------------------------------------------------------------------------------
 template <int CO, int L>
-__global__ __launch_bounds__(256, CO >= 256 ? 1 : 2) void emod_stats_kernel(
+__global__ __launch_bounds__(CO >= 256 && L == 2 ? 512 : 256, CO >= 256 ? 1 : 2) void emod_stats_kernel(
     const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, double* __restrict__ stats, bf16_t* __restrict__ zst, int64_t V, int64_t R) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, CO >= 256 ? 1 : 2) void emod_stats_kernel(
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_eops[L == 2 ? NB * NB * 2 * 64 : 1];
   __shared__ __attribute__((aligned(16))) bf16_t s_tile[WIDE && L == 1 ? 4 : 1][WIDE && L == 1 ? 32 * TSB : 8];
-  __shared__ float s_red[STATS_RED_FLOATS];
+  __shared__ float s_red[STATS_RED_FLOATS > 8 * 64 ? STATS_RED_FLOATS : 8 * 64];      // (8 wavefronts at C_o = 256, L = 2)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (L == 2) {
     for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
@@ -1027,13 +1027,16 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
       pre[e] = __builtin_fmaf(gwl[e], m[e], gbl[e]);
       gt[e] = gw ? tanh_pos(fmaxf(pre[e], 0.f)) : 1.f;
     }
-    // grad_out value of (block mb, register r): the point of view view_of(r, h)
-    auto go_of = [&](int mb, int r) {
-      if (single) return go1[mb];
-      const int v = view_of(r, h);
-      const uint32_t pid = (uint32_t)pid_t[v];
-      return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
-          GO, v < nv ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB, 0, 0));
+    // grad_out value of (block mb, register r): the point of view view_of(r, h) (tag: the tile is one point)
+    auto go_at = [&](auto tag, int mb, int r) {
+      if constexpr (decltype(tag)::value) {
+        return go1[mb];
+      } else {
+        const int v = view_of(r, h);
+        const uint32_t pid = (uint32_t)pid_t[v];
+        return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(
+            GO, v < nv ? (int)(pid * (uint32_t)(CO * 2) + (uint32_t)(32 * mb + j) * 2u) : (int)OOB, 0, 0));
+      }
     };
     // ---- E_mod of the views (flipped): raw z_b stays for the statistics
     f32x16 zb[NB < 4 ? NB : 1];
@@ -1113,6 +1116,8 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
         act_a<NB>(za, s_taba, h, keepv, aa);
         linear_b_flipped<NB>(s_eops, lane, aa, zb);
       }
+      // (the two grad_out forms behind one wave-uniform branch, as in the wide path: round 4)
+      auto qsec = [&](auto tag) {
       // ---- q[v][g] = sum_{ch in g} grad_out[p(v)][ch] value[v][ch]: reduce over the lanes of the group
       if (GS >= 64) {
 #pragma unroll
@@ -1120,7 +1125,7 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
           float d = 0.f;
 #pragma unroll
           for (int mb = 0; mb < NB; ++mb)
-            d = __builtin_fmaf(go_of(mb, r), leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb])), d);
+            d = __builtin_fmaf(go_at(tag, mb, r), leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb])), d);
           d = group_reduce(d);
           if (j == 0) q_t[view_of(r, h)] = d;
         }
@@ -1129,12 +1134,15 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
         for (int mb = 0; mb < NB; ++mb) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float d = go_of(mb, r) * leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
+            float d = go_at(tag, mb, r) * leaky06(__builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]));
             d = group_reduce(d);
             if ((j % GL) == 0) q_t[gch[mb] * 32 + view_of(r, h)] = d;
           }
         }
       }
+          };
+      if (single) qsec(std::true_type{});
+      else qsec(std::false_type{});
     }
     wave_sync();
     // ---- softmax + gate backward (as chain_bwd.hip attn_bwd_kernel)
@@ -1194,6 +1202,7 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
     wave_sync();
     // ---- statistics of the BatchNorm_b backward: d value = gate attention grad_out, dy_b = leaky'(y_b) d value
     //      (wide rows: accumulated block by block above)
+    auto ssec = [&](auto tag) {
 #pragma unroll
     for (int mb = 0; mb < (NB < 4 ? NB : 0); ++mb) {
 #pragma unroll
@@ -1205,7 +1214,7 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
           const int r = 4 * q + i;
           // the records carry gate * attention as bf16: the later passes see the rounded weight
           const float gar = bf2f(f2bf(ww[i]));
-          const float dval = gar * go_of(mb, r);
+          const float dval = gar * go_at(tag, mb, r);
           const float t = __builtin_fmaf(zb[mb][r], kb.g6[mb], kb.b6[mb]);
           const float dy = t > 0.f ? dval : SLOPE * dval;
           sb1[mb] += dy;
@@ -1213,6 +1222,9 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
         }
       }
     }
+    };
+    if (single) ssec(std::true_type{});
+    else ssec(std::false_type{});
     wave_sync();
   });
 #pragma unroll
@@ -1440,12 +1452,12 @@ __global__ __launch_bounds__(256, 2) void emod_bwd_kernel(
 //          dy_a; MODE 4 = the stored dz_b -> dy_a IN PLACE (a lane reads and writes the same 32-byte pieces of its view) + S of
 //          BatchNorm_a.  Between the two, emodw_wgrad_coop_kernel takes dW_b from the stored dz_b.
 template <int CO, int G, int MODE>
-__global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void emodw_bwd_kernel(
+__global__ __launch_bounds__((MODE == 1 || MODE == 3) ? 512 : 256, 1) void emodw_bwd_kernel(
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ smb,
     const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout, bf16_t* __restrict__ da, float* __restrict__ dWb,
     double* __restrict__ stats_a, const bf16_t* __restrict__ zst, int64_t V, int64_t N) {
-  constexpr int NB = CO / 32, GS = CO / G, NW = MODE == 1 ? 8 : 4;
+  constexpr int NB = CO / 32, GS = CO / G, NW = (MODE == 1 || MODE == 3) ? 8 : 4;
   constexpr bool FWD = MODE != 4;                    // evaluates z_b -> dz_b
   constexpr bool DYA = MODE == 1 || MODE == 4;       // evaluates dy_a
   constexpr int NT = MODE == 2 ? NB : 1;
@@ -1732,7 +1744,7 @@ int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const 
   if (layer == 2 && (!eops || !bn_a || !z_a)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   // (layer 1 at 3 blocks per CU: no gain, the pass is bandwidth-bound; C_out = 256: W_b alone is 128 KB of LDS)
-  const dim3 grid(chain_grid(C_out >= 256 && layer == 2 ? 1 : 2)), block(256);
+  const dim3 grid(chain_grid(C_out >= 256 && layer == 2 ? 1 : 2)), block(C_out >= 256 && layer == 2 ? 512 : 256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_STATS(CO_, L_)                                                                              \
   hipLaunchKernelGGL((emod_stats_kernel<CO_, L_>), grid, block, 0, s, (const bf16_t*)Y, (const int4*)tap_rows, \
@@ -1914,7 +1926,7 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
 #undef DVA_EMODW
       case 256 * 8 + 4:
         // W_b (128 KB per orientation) does not fit LDS twice: dz_b -> `da`, dW_b from the stored dz_b, dy_a in place
-        hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 3>), dim3(chain_grid(1)), dim3(256), 0, s, (const int2*)tiles, n_tiles,
+        hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 3>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
                            (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
                            (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
         hipLaunchKernelGGL((emodw_wgrad_coop_kernel<256>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
