@@ -23,9 +23,11 @@ from ... import _lib
 from ..._lib import DvaCamera, check, ptr, stream_of
 
 CAMERAS = ('s3dis_equirectangular', 'scannet', 'kitti360_perspective', 'kitti360_fisheye')
-# a single-camera call runs as a batch of one (tiled LDS z-buffer); 0: the single-image kernels of dva_visibility (64-bit
-# atomic z-buffer plane), kept as the A/B and as the tiled build's independent check
-SINGLE_VIA_BATCH = os.environ.get('DVA_VIS_SINGLE_VIA_BATCH', '1') == '1'
+# DVA_VIS_SINGLE_VIA_BATCH=1: a single-camera call runs as a batch of one on the tiled LDS z-buffer build.  Measured (round 4,
+# S3DIS setting, 200 k candidates): 0.37 ms per image against 0.28 ms for the single-image kernels of dva_visibility (64-bit
+# atomic z-buffer plane) -- the batched build has more launches (binning, scans) than one image amortises -- so the
+# single-image kernels stay the default; the two implementations check each other in tests/test_gpu_mapping.py.
+SINGLE_VIA_BATCH = os.environ.get('DVA_VIS_SINGLE_VIA_BATCH', '0') == '1'
 
 
 def _np32(x):

@@ -44,8 +44,17 @@ def single_image_kernels():
     V.SINGLE_VIA_BATCH = old
 
 
+@pytest.fixture
+def batch_of_one():
+    """Single-camera calls as a batch of one on the tiled z-buffer build (DVA_VIS_SINGLE_VIA_BATCH=1)."""
+    from deepviewagg_amd.core.multimodal import visibility as V
+    old, V.SINGLE_VIA_BATCH = V.SINGLE_VIA_BATCH, True
+    yield
+    V.SINGLE_VIA_BATCH = old
+
+
 @pytest.mark.parametrize("name", VIS)
-def test_visibility_golden_single_image_kernels(name, single_image_kernels):
+def test_visibility_golden_batch_of_one(name, batch_of_one):
     test_visibility_golden(name)
 
 
