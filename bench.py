@@ -485,6 +485,14 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=10, war
     mods = build_modules(C, device, C_out, pool="qkv" if name == "qkv" else "group")
     ms, kern = timed_steps(scene, mods, dtype, steps, warmup, interpolate=interpolate)
     sanity = kern.pop("__sanity__")
+    retimed = False
+    if ms > 1.25 * sum(v["ms"] for v in kern.values()) / steps + 3.0:
+        # wall time far above the sum of the timed kernels: a warm-up artefact (allocator growth after the previous
+        # workload's buffers were released was seen to double a C = 512 step once) -- time the same steps again
+        ms2, kern2 = timed_steps(scene, mods, dtype, steps, 0, interpolate=interpolate)
+        kern2.pop("__sanity__")
+        if ms2 < ms:
+            ms, kern, retimed = ms2, kern2, True
     if interpolate:
         # the fused bilinear path against the reference's materialised [V, C] dataflow on the same scene (same
         # parameters: its sanity values are the yardstick of the fused path's)
@@ -502,7 +510,7 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=10, war
     V = int(scene["x_map"].shape[0])
     es = 2 if dtype == torch.bfloat16 else 4
     out = {"points": N, "views": V, "channels": C, "ms_per_step": ms, "points_per_s": N / (ms * 1e-3), "steps": steps,
-           "sanity": sanity}
+           "sanity": sanity, "retimed": retimed}
     for key, nbytes in (("chain_attn_fwd", fused_fwd_bytes(V, N, C, es)), ("chain_attn_bwd", fused_bwd_bytes(V, N, C, es))):
         k = kern.get(key)
         if k is not None:
