@@ -139,6 +139,7 @@ SIGNATURES = {
     "dva_emod_stats": (ctypes.c_int, [_i32] + [_vp] * 9 + [_i64, _i64, _i32, _vp]),
     "dva_emod_attn_fwd": (ctypes.c_int, [_vp] * 23 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_emod_attn_bwd": (ctypes.c_int, [_vp] * 20 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_emod_stats1_plan": (ctypes.c_int, [_vp] * 6 + [_i64, _i64, _i32, _vp]),
     "dva_emod_bwd": (ctypes.c_int, [_i32] + [_vp] * 16 + [_i64, _i64, _i64, _i32, _i32, _vp]),
     "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_copy_ceiling": (ctypes.c_int, [_vp, _vp, _i64, _vp]),

@@ -528,6 +528,92 @@ __global__ __launch_bounds__(CO >= 256 && L == 2 ? 512 : 256, CO >= 256 ? 1 : 2)
 }
 
 // ------------------------------------------------------------------------------------------------
+// layer-1 statistics pass in ANCHOR order (round 4).  The four taps of a view are the 2 x 2 block of map rows under its
+// anchor, and the backward already sorts the views by anchor (the anchor plan of the transposed interpolation).  Walking
+// the views in that order -- a tile = 32 consecutive plan entries, the view of a lane = perm[position] -- makes
+// neighbouring lanes and consecutive tiles read the SAME four rows of Y: the tap gathers (8 C_o bytes per view out of a
+// map that only fits the last-level cache) become L1 / L2 hits, and what is left per view is the plan entry (4 B), its tap
+// record (2 x 16 B at a random address) and the z_a row it writes (2 C_o B, a whole row at a random address).
+// No point structure is needed here: the pass only stores rows and sums columns.  One form for every width: block by
+// block, column sums of the stored values through the natural LDS tile.
+// ------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256, CO >= 128 ? 3 : 4) void emod_stats1_plan_kernel(
+    const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4, const float4* __restrict__ w4,
+    const int32_t* __restrict__ perm, double* __restrict__ stats, bf16_t* __restrict__ zst, int64_t V, int64_t R) {
+  constexpr int NB = CO / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t s_tile[4][32 * TSB];
+  __shared__ float s_red[4 * 2 * 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t Y = make_rsrc(Yp, (uint64_t)R * CO * 2), R4 = make_rsrc(rows4, (uint64_t)V * 16),
+                               W4 = make_rsrc(w4, (uint64_t)V * 16), PM = make_rsrc(perm, (uint64_t)V * 4);
+  float s1[NB], s2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) s1[b] = s2[b] = 0.f;
+  const int64_t n_tiles = (V + 31) / 32;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t ta = n_tiles * wave / n_waves, tb = n_tiles * (wave + 1) / n_waves;
+  bf16_t* tile = s_tile[wv];
+  struct Pre {
+    int view;
+    bool ok;
+    TapRec t;
+  };
+  auto fetch = [&](int64_t t) {
+    Pre p;
+    const int64_t pos = 32 * t + j;
+    p.ok = t < tb && pos < V;
+    p.view = (int)ld32(PM, p.ok ? (uint32_t)pos * 4u : OOB);
+    return p;
+  };
+  auto fetch_taps = [&](Pre& p) {
+    const uint32_t off = p.ok ? (uint32_t)p.view * 16u : OOB;
+    p.t.rows = __builtin_bit_cast(int4, ld128(R4, off));
+    p.t.w = as_f4(ld128(W4, off));
+  };
+  if (ta >= tb) {
+    // (still takes part in the block-level flush below)
+  }
+  Pre cur = fetch(ta);
+  fetch_taps(cur);
+  for (int64_t t = ta; t < tb; ++t) {
+    Pre nxt = fetch(t + 1);          // the next tile's plan entries and tap records fly during this tile
+    fetch_taps(nxt);
+    const bool ok = cur.ok;
+    bf16_t* zrow = zst + (int64_t)cur.view * CO + 16 * h;
+    // the taps of block b + 1 are requested before block b is interpolated, stored and summed (the LDS round trip of the
+    // column sums is a scheduling barrier: without the second register set every block exposed a memory latency)
+    u32x4 xx[2][4][2];
+    load_taps<CO>(Y, cur.t, ok, 0, h, xx[0]);       // lanes without a view: weights and taps read 0 -> z_a = 0
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) load_taps<CO>(Y, cur.t, ok, b + 1, h, xx[(b + 1) & 1]);
+      const u32x4 (&x)[4][2] = xx[b & 1];
+      f32x16 z;
+      interp16(x, cur.t.w, z);
+      float t16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t16[r] = z[r];
+      bf16x8 pk[2] = {pack8(&t16[0]), pack8(&t16[8])};
+      if (ok && zst) {      // rows at random addresses beyond 4 GiB: flat 64-bit stores
+        *reinterpret_cast<u32x4*>(zrow + 32 * b) = __builtin_bit_cast(u32x4, pk[0]);
+        *reinterpret_cast<u32x4*>(zrow + 32 * b + 8) = __builtin_bit_cast(u32x4, pk[1]);
+      }
+      tileN_put_packed(tile, j, h, pk);
+      wave_sync();
+      col_sums(tile, lane, s1[b], s2[b]);
+      wave_sync();
+    }
+    cur = nxt;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float a0 = s1[b] + other_half(s1[b]), a1 = s2[b] + other_half(s2[b]);
+    flush_lane_stats(a0, a1, stats, stats + CO, 32 * b, s_red, true);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the fused view kernel of the bilinear path
 // ------------------------------------------------------------------------------------------------
 // C_o = 128 / 256 (eval mode only: 356 / 512 registers, one wavefront per SIMD; the backward kernels do not exist at
@@ -1759,6 +1845,26 @@ int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const 
   else if (layer == 1) DVA_EMOD_STATS(256, 1);
   else DVA_EMOD_STATS(256, 2);
 #undef DVA_EMOD_STATS
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_emod_stats1_plan(const void* Y, const int32_t* tap_rows, const float* tap_weights, const int32_t* perm,
+                         double* stats, void* z_a, int64_t n_views, int64_t n_rows, int32_t C_out, void* stream) {
+  if (n_views < 0 || (C_out != 32 && C_out != 64 && C_out != 128 && C_out != 256)) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!Y || !tap_rows || !tap_weights || !perm || !stats) return DVA_ERR_INVALID;
+  if (n_rows * (int64_t)C_out * 2 > 0xfffffff0ll || n_views * 16 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(C_out >= 128 ? 3 : 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_EMOD_S1P(CO_)                                                                                          \
+  hipLaunchKernelGGL((emod_stats1_plan_kernel<CO_>), grid, block, 0, s, (const bf16_t*)Y, (const int4*)tap_rows,    \
+                     (const float4*)tap_weights, perm, stats, (bf16_t*)z_a, n_views, n_rows)
+  if (C_out == 32) DVA_EMOD_S1P(32);
+  else if (C_out == 64) DVA_EMOD_S1P(64);
+  else if (C_out == 128) DVA_EMOD_S1P(128);
+  else DVA_EMOD_S1P(256);
+#undef DVA_EMOD_S1P
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -27,6 +27,8 @@ _POS = {}
 # BatchNorm_a backward inside the anchor scatter: at the level of the anchor (Gram matrix of the tap weights x the four
 # rows of Y: one random row per view) instead of row by row from the stored z_a (two)
 ANCHOR_GRAM = os.environ.get("DVA_ANCHOR_GRAM", "1") == "1"
+# the first statistics pass (taps of Y -> z_a) in anchor order (round 4): 0 = in view order over the tile table (round 3)
+ANCHOR_ORDER_STATS = os.environ.get("DVA_ANCHOR_ORDER_STATS", "1") == "1"
 
 
 def position_order(C, device):
@@ -115,9 +117,18 @@ class _EmodPool(torch.autograd.Function):
         za = torch.empty((V, C), dtype=torch.bfloat16, device=dev) if training else None
         za_bytes = V * C * 2
 
+        # train mode: the first statistics pass walks the views in ANCHOR order (the plan the backward scatters through,
+        # built here once): neighbouring lanes then read the same four rows of Y and the tap gathers become cache hits
+        # (C_out = 32: one block per view, nothing to overlap the random record reads with -- 2.4 against 1.9 ms in view order)
+        plan = ops.anchor_plan(anchors, *bhw) if (training and ANCHOR_ORDER_STATS and C >= 64) else None
+
         def stats(layer, tab_a):
             s = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-            if training:
+            if training and layer == 1 and plan is not None:
+                with ops._timed("emod_stats1", V * (4 + 32 + C * 2)):
+                    check(lib.dva_emod_stats1_plan(ptr(Y), ptr(rows4), ptr(w4), ptr(plan[0]), ptr(s), ptr(za), V, R, C,
+                                                   st), "dva_emod_stats1_plan")
+            elif training:
                 with ops._timed(f"emod_stats{layer}", tap_bytes + za_bytes if layer == 1 else za_bytes):
                     check(lib.dva_emod_stats(layer, ptr(Y), ptr(rows4), ptr(w4), ptr(S.tiles), ptr(S.n_tiles), ptr(eops),
                                              ptr(tab_a), ptr(s), ptr(za), V, R, C, st), "dva_emod_stats")
@@ -144,6 +155,7 @@ class _EmodPool(torch.autograd.Function):
         ctx.training = training
         ctx.meta = (int(scaling), float(eps))
         ctx.anchors, ctx.bhw = anchors, bhw
+        ctx.anchor_plan = plan
         return out
 
     @staticmethod
@@ -214,7 +226,8 @@ class _EmodPool(torch.autograd.Function):
         #      backward is applied to the rows as they are read: no in-place pass over [V, C])
         dY = None
         if ctx.needs_input_grad[0]:
-            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw, bn_backward=(za, tab_a, sm_a, Y if ANCHOR_GRAM else None)).to(Y.dtype)
+            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw, plan=ctx.anchor_plan,
+                                      bn_backward=(za, tab_a, sm_a, Y if ANCHOR_GRAM else None)).to(Y.dtype)
         del da, za
         grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
         ctx.set_saved = None

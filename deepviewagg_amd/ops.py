@@ -416,7 +416,13 @@ def _anchor_chunk_images(B, bytes_per_image, device):
     return max(1, min(B, budget // max(bytes_per_image, 1)))
 
 
-def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=None):
+def anchor_plan(anchors, B, H, W):
+    """The row plan over the ANCHORS of the views (``dva_gather_bilinear_taps_anchor``): ``(perm, row_ptr)`` with
+    B (H + 1) (W + 1) + 1 anchors (the last one = views without the 2 x 2 tap structure)."""
+    return row_plan(anchors, B * (H + 1) * (W + 1) + 1, with_counts=False)[0]
+
+
+def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=None, plan=None):
     """Transpose of the bilinear gather: fp32 [B*H*W, C] = sum over the views and their 4 taps of weight x grad row.
     Views are grouped by ANCHOR (the padded cell of their top-left tap, ``dva_gather_bilinear_taps_anchor``): one
     sort of P keys, every gradient row read once into four per-anchor sums, then a 2 x 2 stencil on the map
@@ -430,7 +436,7 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
     P, C = grad.shape
     per_image = (H + 1) * (W + 1)
     n_anchor = B * per_image + 1                    # + the dummy anchor of views without the 2 x 2 structure
-    (perm, row_ptr), _ = row_plan(anchors, n_anchor, with_counts=False)
+    perm, row_ptr = plan if plan is not None else anchor_plan(anchors, B, H, W)
     st = stream_of(grad)
     es = grad.element_size()
     if bn_backward is not None:

@@ -465,6 +465,12 @@ int dva_emod_prep(const float* Wb, int32_t C_out, void* eops, void* stream);
 int dva_emod_stats(int32_t layer, const void* Y, const int32_t* tap_rows, const float* tap_weights, const void* tiles,
                    const int32_t* n_tiles, const void* eops, const float* bn_a, double* stats, void* z_a,
                    int64_t n_views, int64_t n_rows, int32_t C_out, void* stream);
+/* Layer-1 statistics pass of dva_emod_stats in ANCHOR order (round 4): perm = the permutation of the anchor plan
+ * (dva_row_plan of the views' anchors, the plan the backward scatters through).  A tile is 32 consecutive plan entries, so
+ * neighbouring lanes read the same four rows of Y (cache hits instead of 8 C_out gathered bytes per view); z_a rows are
+ * written to their view's position, stats as dva_emod_stats(layer 1).  C_out in {32, 64, 128, 256}; z_a may be NULL. */
+int dva_emod_stats1_plan(const void* Y, const int32_t* tap_rows, const float* tap_weights, const int32_t* perm,
+                         double* stats, void* z_a, int64_t n_views, int64_t n_rows, int32_t C_out, void* stream);
 /* The fused view kernel: x_map + z_a (or, z_a = NULL, the taps of Y) -> out bf16 [N][C_out] (caller-zeroed) =
  * gate * sum_v softmax_v(scores) E_mod(view v); scores_out as dva_chain_attn_fwd. */
 int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
