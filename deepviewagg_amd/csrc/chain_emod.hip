@@ -289,6 +289,15 @@ __device__ __forceinline__ void col_sums(const bf16_t* tx, int lane, float& s, f
     }
   }
 }
+__device__ __forceinline__ void col_sum1(const bf16_t* tx, int lane, float& s) {        // sum x
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float x[8];
+    unpack8(tileN_get(tx, lane, m), x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+  }
+}
 __device__ __forceinline__ void col_sums2(const bf16_t* tx, const bf16_t* ty, int lane, float& sx, float& sxy) {   // sum x | sum x y
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -619,7 +628,7 @@ __global__ __launch_bounds__(256, CO >= 128 ? 3 : 4) void emod_stats1_plan_kerne
 // C_o = 128 / 256 (eval mode only: 356 / 512 registers, one wavefront per SIMD; the backward kernels do not exist at
 // those widths)
 template <int CO, int G, int ZM>      // ZM = 0: z_a from the taps of Y (eval mode), 1: the stored z_a (train mode)
-__global__ __launch_bounds__(256, CO > 64 ? (CO == 128 ? 2 : 1) : (CO == 32 && ZM == 1 ? (G == 1 ? 3 : 4) : 2)) void emod_attn_fwd_kernel(
+__global__ __launch_bounds__((CO >= 256 && ZM == 1) ? 512 : 256, CO > 64 ? (CO == 128 ? 2 : 1) : (CO == 32 && ZM == 1 ? (G == 1 ? 3 : 4) : 2)) void emod_attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -635,10 +644,11 @@ __global__ __launch_bounds__(256, CO > 64 ? (CO == 128 ? 2 : 1) : (CO == 32 && Z
   __shared__ __attribute__((aligned(16))) uint4 s_ops[OP_W6T * 64];
   __shared__ __attribute__((aligned(16))) uint4 s_eops[NB * NB * 2 * 64];
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) float s_ev[4][4 * 32];     // exp(.) per [group][view]
-  __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][view]
-  __shared__ __attribute__((aligned(16))) int s_pid[4][32];
-  __shared__ __attribute__((aligned(16))) float s_alpha[4][4], s_scg[4][4];
+  constexpr int NW = (CO >= 256 && ZM == 1) ? 8 : 4;     // wavefronts per block (C_o = 256 from the stored z_a: two per SIMD)
+  __shared__ __attribute__((aligned(16))) float s_ev[NW][4 * 32];     // exp(.) per [group][view]
+  __shared__ __attribute__((aligned(16))) float s_sc[NW][4 * 32];     // gate / (sum + eps) per [group][view]
+  __shared__ __attribute__((aligned(16))) int s_pid[NW][32];
+  __shared__ __attribute__((aligned(16))) float s_alpha[NW][4], s_scg[NW][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < OP_W6T * 64; i += blockDim.x) s_ops[i] = ops[i];
   for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
@@ -695,7 +705,7 @@ __global__ __launch_bounds__(256, CO > 64 ? (CO == 128 ? 2 : 1) : (CO == 32 && Z
   // C_o = 32, train mode: without the prefetch register set the kernel fits four wavefronts per SIMD (G = 1: three):
   // 1.39 -> 1.12 ms on the KITTI pair
   auto loop = [&](auto&& ld, auto&& bd) {
-    if constexpr (CO == 32 && ZM == 1) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
+    if constexpr ((CO == 32 || CO >= 256) && ZM == 1) run_tiles_single<Pre>(tiles, ta, tb, ld, bd);
     else run_tiles<Pre>(tiles, ta, tb, ld, bd);
   };
   loop([&](const TileInfo& ti, int t) {
@@ -923,7 +933,7 @@ __global__ __launch_bounds__(256, CO > 64 ? (CO == 128 ? 2 : 1) : (CO == 32 && Z
 //   (S1 = sum dy_b | sum dy_b z_b with dy_b = leaky'(y_b) gate attention grad_out)
 // ------------------------------------------------------------------------------------------------
 template <int CO, int G, int OCC = (CO == 32 ? 4 : (CO >= 128 ? 1 : 2))>
-__global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
+__global__ __launch_bounds__(CO >= 256 ? 512 : 256, OCC) void emod_attn_bwd_kernel(
     const float* __restrict__ compat, const int32_t* __restrict__ vp, const int2* __restrict__ tiles,
     const int32_t* __restrict__ n_tiles_dev, const bf16_t* __restrict__ Yp, const int4* __restrict__ rows4,
     const float4* __restrict__ w4, const uint4* __restrict__ eops, const float* __restrict__ bna,
@@ -936,10 +946,11 @@ __global__ __launch_bounds__(256, OCC) void emod_attn_bwd_kernel(
   constexpr int BPG = GS >= 32 ? GS / 32 : 1;     // blocks of a channel group
   __shared__ __attribute__((aligned(16))) uint4 s_eops[NB * NB * 2 * 64];
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
-  __shared__ __attribute__((aligned(16))) float s_q[4][4 * 32], s_ga[4][4 * 32];
-  __shared__ __attribute__((aligned(16))) int s_pid[4][32];
-  __shared__ __attribute__((aligned(16))) float s_E[4][4];
-  __shared__ float s_red[4 * 2 * 32];
+  constexpr int NW = CO >= 256 ? 8 : 4;            // wavefronts per block (C_o = 256: W_b fills LDS once per CU -> 8, two per SIMD)
+  __shared__ __attribute__((aligned(16))) float s_q[NW][4 * 32], s_ga[NW][4 * 32];
+  __shared__ __attribute__((aligned(16))) int s_pid[NW][32];
+  __shared__ __attribute__((aligned(16))) float s_E[NW][4];
+  __shared__ float s_red[NW * 2 * 32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < NB * NB * 2 * 64; i += blockDim.x) s_eops[i] = eops[i];
 #pragma unroll
@@ -1538,12 +1549,12 @@ __global__ __launch_bounds__(256, 2) void emod_bwd_kernel(
 //          dy_a; MODE 4 = the stored dz_b -> dy_a IN PLACE (a lane reads and writes the same 32-byte pieces of its view) + S of
 //          BatchNorm_a.  Between the two, emodw_wgrad_coop_kernel takes dW_b from the stored dz_b.
 template <int CO, int G, int MODE>
-__global__ __launch_bounds__((MODE == 1 || MODE == 3) ? 512 : 256, 1) void emodw_bwd_kernel(
+__global__ __launch_bounds__(MODE == 2 ? 256 : 512, 1) void emodw_bwd_kernel(
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
     const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ smb,
     const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout, bf16_t* __restrict__ da, float* __restrict__ dWb,
     double* __restrict__ stats_a, const bf16_t* __restrict__ zst, int64_t V, int64_t N) {
-  constexpr int NB = CO / 32, GS = CO / G, NW = (MODE == 1 || MODE == 3) ? 8 : 4;
+  constexpr int NB = CO / 32, GS = CO / G, NW = MODE == 2 ? 4 : 8;
   constexpr bool FWD = MODE != 4;                    // evaluates z_b -> dz_b
   constexpr bool DYA = MODE == 1 || MODE == 4;       // evaluates dy_a
   constexpr int NT = MODE == 2 ? NB : 1;
@@ -1553,8 +1564,10 @@ __global__ __launch_bounds__((MODE == 1 || MODE == 3) ? 512 : 256, 1) void emodw
   __shared__ __attribute__((aligned(16))) float s_tabb[FWD ? NB : 1][FWD ? TAB_FLOATS : 8];
   __shared__ __attribute__((aligned(16))) uint4 s_eops[N_EOPS];
   // MODE 1 / 4: [0] = the dy_a block, [1] = the z_a block;  MODE 2: NB tiles of dz_b, NB tiles of y_a;  MODE 3: unused
+  // (MODE 4: ONE tile per wavefront, used twice per block -- dy_a, then the products dy_a z_a: with W_b^T filling 128 KB there
+  //  is room for 8 x 1 tiles, not 8 x 2)
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[MODE == 3 ? 1 : NW][NT][MODE == 3 ? 8 : 32 * TSB],
-      s_tb[MODE == 3 ? 1 : NW][NT][MODE == 3 ? 8 : 32 * TSB];
+      s_tb[(MODE == 3 || MODE == 4) ? 1 : NW][NT][(MODE == 3 || MODE == 4) ? 8 : 32 * TSB];
   float* s_red = reinterpret_cast<float*>(&s_ta[0][0][0]);     // epilogue: D x D floats | NW x 64 floats
   static_assert(MODE == 3 || sizeof(bf16_t) * NW * NT * 32 * TSB >= sizeof(float) * (MODE == 2 ? D * D : NW * 64),
                 "epilogue buffer");
@@ -1670,7 +1683,7 @@ __global__ __launch_bounds__((MODE == 1 || MODE == 3) ? 512 : 256, 1) void emodw
     if constexpr (DYA) {
       // da = W_b^T dz_b, dy_a = leaky'(y_a) da, handed over as bf16 (position order);  S of BatchNorm_a from the stored rows
       bf16_t* tdy = s_ta[wv][0];
-      bf16_t* tz = s_tb[wv][0];
+      bf16_t* tz = s_tb[MODE == 4 ? 0 : wv][0];      // (MODE 4 has no second tile)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         f32x16 dya = {0};
@@ -1696,12 +1709,29 @@ __global__ __launch_bounds__((MODE == 1 || MODE == 3) ? 512 : 256, 1) void emodw
         const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * b + 16 * h) * 2u : OOB;
         st128(DA, off, __builtin_bit_cast(u32x4, pk[0]));
         st128(DA, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pk[1]));
-        bf16x8 zk[2] = {__builtin_bit_cast(bf16x8, p.z.q[b][0]), __builtin_bit_cast(bf16x8, p.z.q[b][1])};
-        tileN_put_packed(tdy, j, h, pk);
-        tileN_put_packed(tz, j, h, zk);
-        wave_sync();
-        col_sums2(tdy, tz, lane, sa1[b], sa2[b]);
-        wave_sync();
+        if constexpr (MODE == 4) {
+          tileN_put_packed(tdy, j, h, pk);
+          wave_sync();
+          col_sum1(tdy, lane, sa1[b]);
+          wave_sync();
+          float dyr[16], pr[16];      // the stored (rounded) dy_a times the stored z_a, rounded once more for the tile
+          unpack8(pk[0], reinterpret_cast<float(&)[8]>(dyr[0]));
+          unpack8(pk[1], reinterpret_cast<float(&)[8]>(dyr[8]));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pr[r] = dyr[r] * za[r];
+          bf16x8 pp[2] = {pack8(&pr[0]), pack8(&pr[8])};
+          tileN_put_packed(tdy, j, h, pp);
+          wave_sync();
+          col_sum1(tdy, lane, sa2[b]);
+          wave_sync();
+        } else {
+          bf16x8 zk[2] = {__builtin_bit_cast(bf16x8, p.z.q[b][0]), __builtin_bit_cast(bf16x8, p.z.q[b][1])};
+          tileN_put_packed(tdy, j, h, pk);
+          tileN_put_packed(tz, j, h, zk);
+          wave_sync();
+          col_sums2(tdy, tz, lane, sa1[b], sa2[b]);
+          wave_sync();
+        }
       }
     } else if constexpr (MODE == 2) {
       wave_sync();
@@ -1884,7 +1914,8 @@ int dva_emod_attn_fwd(const float* x_map, const int32_t* view_point, const float
   if (!z_a && (!Y || !tap_rows || !tap_weights)) return DVA_ERR_INVALID;
   DVA_EMOD_CHECK_SIZES();
   if (n_points * 128 > 0xfffffff0ll || n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  const dim3 grid(chain_grid(C_out > 64 ? (C_out == 128 ? 2 : 1) : (C_out == 32 && z_a ? (G == 1 ? 3 : 4) : 2))), block(256);
+  const dim3 grid(chain_grid(C_out > 64 ? (C_out == 128 ? 2 : 1) : (C_out == 32 && z_a ? (G == 1 ? 3 : 4) : 2))),
+      block(C_out >= 256 && z_a ? 512 : 256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_FWD_Z(CO_, G_, ZM_)                                                                                  \
   hipLaunchKernelGGL((emod_attn_fwd_kernel<CO_, G_, ZM_>), grid, block, 0, s, x_map, view_point, u,                    \
@@ -1932,7 +1963,7 @@ int dva_emod_attn_bwd(const float* scores, const int32_t* view_point, const void
   if (n_points * (int64_t)C_out * 2 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   static const int bpc32 = tune_int("DVA_EMOD_ABWD_BPC", 4);      // read once (getenv), like the other switches
   static const int occ128 = tune_int("DVA_EMOD_ABWD128_OCC", 2);  // C_out = 128: two wavefronts per SIMD (206 - 215 VGPRs)
-  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : (C_out == 128 ? occ128 : (C_out == 256 ? 1 : 2)))), block(256);
+  const dim3 grid(chain_grid(C_out == 32 ? bpc32 : (C_out == 128 ? occ128 : (C_out == 256 ? 1 : 2)))), block(C_out == 256 ? 512 : 256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_EMOD_BWD(CO_, G_)                                                                                      \
   hipLaunchKernelGGL((emod_attn_bwd_kernel<CO_, G_>), grid, block, 0, s, scores, view_point, (const int2*)tiles,     \
@@ -2037,7 +2068,7 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
                            (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
         hipLaunchKernelGGL((emodw_wgrad_coop_kernel<256>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
                            bn_a, (const bf16_t*)da, (const bf16_t*)z_a, dWb);
-        hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 4>), dim3(chain_grid(1)), dim3(256), 0, s, (const int2*)tiles, n_tiles,
+        hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 4>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
                            (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
                            (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
         break;
