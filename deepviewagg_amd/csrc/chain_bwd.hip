@@ -367,23 +367,28 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void att
 //   S6 = sum dy6 | sum dy6 z6;   dWs^T[k][g] = sum_v a6[v][k] dc[v][g];   dbs = sum_v dc
 // LDS operand table: chain positions 0..6 (W1', W2', W5, W6), 7..8 = W6' (folded), 9 = Ws^T.
 // ------------------------------------------------------------------------------------------------
+// KEYS (G = 32: the key layer of QKVBimodalCSRPool): the gradient of the last layer arrives as a bf16 [V][32] row in
+// accumulator order (dc) instead of 4 scores: da6 = W_k^T dK through the full transposed operand OP_WKT, dW_k [32][32] =
+// dK^T a6 from two natural tiles, db_k = column sums of the dK tile.
+template <bool KEYS>
 __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     const float* __restrict__ bn6, const float* __restrict__ dc, double* __restrict__ stats6,
     float* __restrict__ dWs, float* __restrict__ dbs, int G, int64_t V, int64_t N) {
-  constexpr int L_W6F = 7, L_WST = 9, NOPS = 10;
+  constexpr int L_W6F = 7, L_WST = 9, NOPS = KEYS ? 11 : 10;
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   // transposed a6 tile + a 4-row score-gradient tile (+ one shared zero row), as in the layer passes
-  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_td[4][5 * TSB];
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_td[4][(KEYS ? 32 : 5) * TSB];
   float* s_red = reinterpret_cast<float*>(&s_tc[0][0]);        // epilogue only (D x D floats <= the tile buffers)
   static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < 4 * 5 * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < 4 * (KEYS ? 32 : 5) * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
   for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) s_ops[OP_W5 * 64 + i] = ops[OP_W5 * 64 + i];   // W5, W6
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_ops[L_WST * 64 + i] = ops[OP_WST * 64 + i];
+  for (int i = threadIdx.x; i < (KEYS ? 128 : 64); i += blockDim.x)
+    s_ops[L_WST * 64 + i] = ops[(KEYS ? OP_WKT : OP_WST) * 64 + i];
   fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
   fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
   fold_ops(s_ops, L_W6F, ops, OP_W6, 2, bn6);
@@ -393,11 +398,11 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
   stage_tab(s_tab[3], bn6, nullptr);
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16);
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * (KEYS ? 64 : 16));
   bf16_t* tc = s_tc[wv];
   bf16_t* td = s_td[wv];
   f32x16 accS = {0};
-  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};      // KEYS: [0] = this lane's share of the column sum of the dK tile
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
   struct Pre {
     TileInfo ti;
     float4 x, dc;
+    u32x4 dk2;         // KEYS: the second 16 bytes of the lane's half of the dK row (the first in dc)
     int vpj;
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
@@ -416,7 +422,12 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
     p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
-    p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+    if constexpr (KEYS) {
+      p.dc = as_f4(ld128(DC, ok ? view * 64u + 32u * h : OOB));
+      p.dk2 = ld128(DC, ok ? view * 64u + 32u * h + 16u : OOB);
+    } else {
+      p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+    }
     return p;
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
@@ -424,6 +435,21 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const f32x16 uacc = load_u(U, ok, p.vpj, h);
     ChainKeep k;
     chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    if constexpr (KEYS) {
+      // dK of the view as the packed B operand it was stored as (zeros for lanes without a view)
+      const bf16x8 dkp[2] = {__builtin_bit_cast(bf16x8, p.dc), __builtin_bit_cast(bf16x8, p.dk2)};
+      tileN_put_packed(tc, j, h, k.a6);
+      tileN_put_packed(td, j, h, dkp);
+      const f32x16 zero = {0};
+      f32x16 dy6 = mm32_lds(s_ops, L_WST, lane, dkp, zero);       // da6 = W_k^T dK
+      dleaky_mul(k.t6, dy6);
+      bn_bwd_stats(k.z6, dy6, st);
+      wave_sync();
+      accS = wgradN(td, tc, lane, accS);          // dW_k[row][k] = sum_v dK[v][row] a6[v][k]
+      col_sum1(td, lane, dbsum[0]);
+      wave_sync();
+      return;
+    }
     const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};      // zeros in the lanes without a view and for h = 1
     tileN_put_packed(tc, j, h, k.a6);
     if (h == 0) {
@@ -442,6 +468,22 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     accS = wgradN_T(tc, td, lane, j, 4, h, accS);
     wave_sync();
   });
+  if constexpr (KEYS) {
+    flush_matrix_nat(accS, dWs, D, D, false, s_red, true);
+    flush_stats<2>(st, stats6, s_red);
+    __syncthreads();     // db_k: the two half-waves hold the two halves of a column sum; column n = key channel cperm(n)
+    {
+      uint32_t a = __float_as_uint(dbsum[0]), b = a;
+      swap_halves(a, b);
+      const float tot = dbsum[0] + __uint_as_float((threadIdx.x & 32) ? a : b);
+      if (h == 0) s_red[wv * 32 + j] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32)
+      atomicAdd(&dbs[cperm(threadIdx.x)], (s_red[threadIdx.x] + s_red[32 + threadIdx.x]) +
+                                             (s_red[64 + threadIdx.x] + s_red[96 + threadIdx.x]));
+    return;
+  }
   flush_matrix_nat(accS, dWs, D, G, true, s_red, false);
   flush_stats<2>(st, stats6, s_red);
   __syncthreads();       // dbs: one atomic per block and group (see the attention backward)
@@ -488,7 +530,7 @@ __device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
   return d;
 }
 
-template <int STAGE, int OCC>
+template <int STAGE, int OCC, bool KEYS = false>
 __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
@@ -516,8 +558,8 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   // place, W2 as a second operand (the raw z2 feeds the statistics) -> local 7, 8; stage 2: W1 as a second operand
   // -> local 5
   // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9; W6' (folded) -> 10, 11
-  constexpr int NOPS = STAGE == 6 ? 12 : (STAGE == 5 ? 9 : 6);
-  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9, L6_W6F = 10;
+  constexpr int NOPS = STAGE == 6 ? (KEYS ? 13 : 12) : (STAGE == 5 ? 9 : 6);      // (KEYS: W_k^T takes two blocks at L6_WST, the folded W6 moves up one)
+  constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9, L6_W6F = KEYS ? 11 : 10;
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (STAGE == 6) {
@@ -525,7 +567,10 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       const int blk = i >> 6, l = i & 63;
       if (blk < 2) s_ops[(OP_W5 + blk) * 64 + l] = ops[(OP_W5 + blk) * 64 + l];
       else if (blk < 4) s_ops[(OP_W6 + blk - 2) * 64 + l] = ops[(OP_W6 + blk - 2) * 64 + l];
-      else s_ops[L6_WST * 64 + l] = ops[OP_WST * 64 + l];
+      else if (!KEYS) s_ops[L6_WST * 64 + l] = ops[OP_WST * 64 + l];
+    }
+    if (KEYS) {
+      for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_WST * 64 + i] = ops[OP_WKT * 64 + i];
     }
     for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_W6T * 64 + i] = ops[OP_W6T * 64 + i];
     fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
@@ -560,7 +605,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16),
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * (KEYS ? 64 : 16)),
                                AR = make_rsrc(arg, (uint64_t)N * 128), DP = make_rsrc(dpooled, (uint64_t)N * 128),
                                DI = make_rsrc(da_in, (uint64_t)V * 64), DO = make_rsrc(da_out, (uint64_t)V * 64);
   float st[2][16];
@@ -607,7 +652,9 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     bf16x8 dzp[2];
     if constexpr (STAGE == 6) {
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
-      const float4 dcv = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+      const float4 dcv = as_f4(ld128(DC, KEYS ? (ok ? view * 64u + 32u * h : OOB) : (ok && h == 0 ? view * 16u : OOB)));
+      u32x4 dk2 = {0u, 0u, 0u, 0u};
+      if (KEYS) dk2 = ld128(DC, ok ? view * 64u + 32u * h + 16u : OOB);
       // forward up to a5 (layers 1, 2 folded, layer 5 plain); z5 stays for the statistics of layer 5
       bf16x8 a5[2];
       f32x16 z5;
@@ -626,7 +673,13 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       {
         // dy6 = leaky'(t6) Ws^T dc with the sign the forward's activation saw (the folded product), one 16-register
         // block at a time: t6, then the raw z6 for the BatchNorm backward
-        f32x16 dy6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
+        f32x16 dy6;
+        if constexpr (KEYS) {
+          const bf16x8 dkp[2] = {__builtin_bit_cast(bf16x8, dcv), __builtin_bit_cast(bf16x8, dk2)};
+          dy6 = mm32_lds(s_ops, L6_WST, lane, dkp, zero);       // da6 = W_k^T dK (the stored bf16 row is the B operand)
+        } else {
+          dy6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
+        }
         {
           const f32x16 t6 = mm32_lds(s_ops, L6_W6F, lane, a5, bias_acc(s_tab[3], T_B6, h));
           dleaky_mul(t6, dy6);
@@ -1021,15 +1074,22 @@ int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const f
                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                           const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
-  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views < 0 || n_points < 0 || G < 1 || (G > 4 && G != D)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !grad_scores ||
       !stats6 || !dWs || !dbs)
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(score_stats_kernel, dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
-                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores, stats6, dWs, dbs,
-                     (int)G, n_views, n_points);
+  if (G == D) {      // key layer: grad_scores = bf16 [V][32] rows in accumulator order, dWs [32][32], dbs [32]
+    if (n_views * 64 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((score_stats_kernel<true>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
+                       view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores,
+                       stats6, dWs, dbs, (int)G, n_views, n_points);
+  } else {
+    hipLaunchKernelGGL((score_stats_kernel<false>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
+                       view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores,
+                       stats6, dWs, dbs, (int)G, n_views, n_points);
+  }
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
@@ -1040,7 +1100,7 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
                         const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
-  if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || (G > 4 && G != D)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW || (stage != 2 && !stats))
     return DVA_ERR_INVALID;
@@ -1057,7 +1117,11 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                      grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, \
                      n_views, n_points)
   static const int occ5 = tune_int("DVA_STAGE5_OCC", 3);
-  if (stage == 6) DVA_LAYER_BWD(6, 3);
+  if (stage == 6 && G == D)       // key layer: grad_scores = bf16 [V][32] rows
+    hipLaunchKernelGGL((layer_bwd_kernel<6, 3, true>), dim3(chain_grid(3)), block, 0, s, x_map, view_point, u,
+                       (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6, grad_scores, arg,
+                       dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, n_views, n_points);
+  else if (stage == 6) DVA_LAYER_BWD(6, 3);
   else if (stage == 5 && occ5 == 2) DVA_LAYER_BWD(5, 2);
   else if (stage == 5) DVA_LAYER_BWD(5, 3);
   else DVA_LAYER_BWD(2, 3);

@@ -43,7 +43,9 @@ enum {
   OP_W5T = 11,
   OP_W2T = 13,
   OP_WST = 15,  // Ws^T for da6 = Ws^T dc: h = 0: slots 0..3 = Ws[s][c], 4..7 = the same (dc enters as hi | lo)
-  N_OPS = 16
+  OP_WKT = 16,  // +m: the FULL transposed last layer Ws[chan(8m + s, h)][c] (G = 32: the key layer of QKVBimodalCSRPool,
+                //     whose gradient arrives as a 32-wide row instead of 4 scores; zero otherwise)
+  N_OPS = 18
 };
 
 // per-layer constant table in LDS, accumulator-permuted (index 16 h + r <-> channel chan(r, h)):
@@ -553,6 +555,27 @@ __device__ __forceinline__ f32x16 wgradN(const bf16_t* ta, const bf16_t* tb, int
   acc = CH_MFMA(tileN_get(ta, lane, 0), tileN_get(tb, lane, 0), acc);
   acc = CH_MFMA(tileN_get(ta, lane, 1), tileN_get(tb, lane, 1), acc);
   return acc;
+}
+// Sums over the 32 views of a natural tile this wavefront has just written (tileN_put_packed): lane (n, hh) receives the
+// views 8 hh .. 8 hh + 7 and 16 + 8 hh .. of column n through the transpose read -- 16 in-lane additions; the two
+// half-waves hold the two halves of the column sum (added at the flush).  Values as stored (bf16).
+__device__ __forceinline__ void unpack8(const bf16x8& v, float (&f)[8]) {
+  const u32x4 u = __builtin_bit_cast(u32x4, v);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void col_sum1(const bf16_t* tx, int lane, float& s) {        // sum x
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float x[8];
+    unpack8(tileN_get(tx, lane, m), x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+  }
 }
 // first tile natural, second a transposed tile ([row][view]: indicator / short tiles; rows >= jb_max share row jb_max)
 __device__ __forceinline__ f32x16 wgradN_T(const bf16_t* ta, const bf16_t* tb, int lane, int j, int jb_max, int h,

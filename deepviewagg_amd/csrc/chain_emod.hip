@@ -268,15 +268,6 @@ __device__ __forceinline__ void act_a_rows(const ZaRows<NB>& z, const float (*ta
 // of half h, i.e. channel cperm(column)) and reads it back through the transpose read: lane (n, hh) receives the views
 // 8 hh .. 8 hh + 7 and 16 + 8 hh .. of column n -- 16 in-lane additions; the two half-waves hold the two halves of the
 // column sum (added at the flush).  x, y: values as stored (bf16).
-__device__ __forceinline__ void unpack8(const bf16x8& v, float (&f)[8]) {
-  const u32x4 u = __builtin_bit_cast(u32x4, v);
-  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(w[i] << 16);
-    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-  }
-}
 __device__ __forceinline__ void col_sums(const bf16_t* tx, int lane, float& s, float& ss) {        // sum x | sum x^2
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -287,15 +278,6 @@ __device__ __forceinline__ void col_sums(const bf16_t* tx, int lane, float& s, f
       s += x[i];
       ss = __builtin_fmaf(x[i], x[i], ss);
     }
-  }
-}
-__device__ __forceinline__ void col_sum1(const bf16_t* tx, int lane, float& s) {        // sum x
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    float x[8];
-    unpack8(tileN_get(tx, lane, m), x);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += x[i];
   }
 }
 __device__ __forceinline__ void col_sums2(const bf16_t* tx, const bf16_t* ty, int lane, float& sx, float& sxy) {   // sum x | sum x y

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void prep_kernel(const float* __restrict__ W1, 
       for (int s = 0; s < 4; ++s) w[s] = w[s + 4] = s < G ? Ws[s * D + j] : 0.f;
     }
   } else {
-    const int m = (op - 1) & 1;
+    const int m = op >= OP_WKT ? op - OP_WKT : (op - 1) & 1;      // (the two-block operands below OP_WST start at odd indices)
     const int base = op - m;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64) void prep_kernel(const float* __restrict__ W1, 
       else if (base == OP_W6T) v = W6[c * D + j];
       else if (base == OP_W5T) v = W5[c * ld5 + j];
       else if (base == OP_W2T) v = W2[c * D + j];
+      else if (base == OP_WKT) v = G == D ? Ws[c * D + j] : 0.f;
       w[s] = v;
     }
   }
@@ -477,6 +478,81 @@ __global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// key layer of QKVBimodalCSRPool (reference modules/multimodal/pooling.py:454-547: keys = K(E_map(x_map)), a Linear
+// 32 -> nc_qk G = 32 behind DeepSetFeat): the chain evaluated exactly as the fused view kernel evaluates it (layers 1, 2, 6
+// with BatchNorm folded into the operand), then one more 32 x 32 product with the rows of W_k (operand OP_WS prepared with
+// G = 32) + bias, written as ONE bf16 row per view in accumulator order (position 16 h + r = channel chan(r, h): the 32
+// bytes a lane holds are contiguous) -- the layout in which the backward hands gradient rows between its passes, and in
+// which dva_chain_score_stats / dva_chain_bwd_layer(6) take d keys back (G = 32).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void keys_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ bk, bf16_t* __restrict__ keys, int64_t V, int64_t N) {
+  __shared__ __attribute__((aligned(16))) float s_tab[4][2 * D];      // G | B rows only
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[OP_W6T * 64];   // forward operands only
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < OP_W6T * 64; i += blockDim.x) s_ops[i] = ops[i];
+  stage_tab_fwd(s_tab[0], bn1);
+  stage_tab_fwd(s_tab[1], bn2);
+  stage_tab_fwd(s_tab[2], bn5);
+  stage_tab_fwd(s_tab[3], bn6);
+  __syncthreads();
+  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  fold_ops(s_ops, OP_W6, ops, OP_W6, 2, bn6);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), KO = make_rsrc(keys, (uint64_t)V * 64);
+  f32x16 kb;            // the bias of this lane's 16 key channels
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kb[r] = bk[chan(r, h)];
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x;
+    int vpj;
+  };
+  run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    f32x16 uacc;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const float4 v = as_f4(ld128(U, ok ? (uint32_t)p.vpj * 128u + (8u * qq + 4u * h) * 4u : OOB));
+      uacc[4 * qq] = v.x; uacc[4 * qq + 1] = v.y; uacc[4 * qq + 2] = v.z; uacc[4 * qq + 3] = v.w;
+    }
+    const uint32_t keep = 0xffffffffu;
+    bf16x8 a[2], a2[2];
+    asm volatile("" ::: "memory");
+    f32x16 z = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], 1, h));
+    act_fold(z, keep, a);
+    z = mm32_lds(s_ops, OP_W2, lane, a, bias_acc(s_tab[1], 1, h));
+    act_fold(z, keep, a2);
+    z = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
+    act_pack(z, s_tab[2], h, keep, a, 0, 1);
+    z = mm32_lds(s_ops, OP_W6, lane, a, bias_acc(s_tab[3], 1, h));
+    act_fold(z, keep, a2);
+    z = mm32_lds(s_ops, OP_WS, lane, a2, kb);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = z[r];
+    const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 64u + 32u * h : OOB;
+    st128(KO, off, __builtin_bit_cast(u32x4, pack8(&t[0])));
+    st128(KO, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pack8(&t[8])));
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
 // the fused view kernel
 // ------------------------------------------------------------------------------------------------
 // Team layout of the value rows: LPR = C / 8 lanes cover one bf16 row with 16-byte loads, ROWS = 64 / LPR row
@@ -823,7 +899,7 @@ extern "C" {
 
 int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6,
                    const float* Ws, int32_t G, void* ops, void* stream) {
-  if (!W1 || !W2 || !W5 || !W6 || !Ws || !ops || G < 1 || G > 4 || ld5 < D) return DVA_ERR_INVALID;
+  if (!W1 || !W2 || !W5 || !W6 || !Ws || !ops || G < 1 || (G > 4 && G != D) || ld5 < D) return DVA_ERR_INVALID;
   hipLaunchKernelGGL(prep_kernel, dim3(N_OPS), dim3(64), 0, (hipStream_t)stream, W1, W2, W5, ld5, W6, Ws, G,
                      (uint4*)ops);
   DVA_CHECK_LAUNCH();
@@ -947,6 +1023,21 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
   else
     hipLaunchKernelGGL((stats_mid_kernel<6>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
                        n_tiles, (const uint4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                   const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                   const float* bn6, const float* key_bias, void* keys, int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !key_bias || !keys)
+    return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(keys_kernel, dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, key_bias, (bf16_t*)keys, n_views,
+                     n_points);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

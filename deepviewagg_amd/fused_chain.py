@@ -22,7 +22,7 @@ from .fused_deepset import D, _bn_of, _bn_consts
 # None = auto (inside torch.autocast(bfloat16) only); True / False pin the choice (tests, bench A/B)
 FORCE = None
 VIEWS_PER_CHUNK = 512       # tile-table construction granularity (one lane walks one chunk)
-OPS_BYTES = 16 * 64 * 16 + 7 * 64 * 32       # bf16 operand blocks + the fp32 copy of the forward operands
+OPS_BYTES = 18 * 64 * 16 + 7 * 64 * 32       # bf16 operand blocks + the fp32 copy of the forward operands
 
 
 def enabled():
@@ -287,3 +287,127 @@ def chain_pool(module, x_mod, x_map, csr_idx):
     csr_idx = ops._check_ptr(csr_idx)
     return _ChainPool.apply(x_mod.rows, x_mod.row_idx.contiguous(), x_mod.plan, x_map, csr_idx, module,
                             module.group_scaling, 1e-12, *chain_params(module))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# QKVBimodalCSRPool on the chain (round 4): the keys K(E_map(x_map)) are one more 32 x 32 layer behind DeepSetFeat,
+# written as ONE bf16 [V, 32] row per view (accumulator order); compatibilities, attention and the rows gradient run on
+# the attention kernels that take the scores as an input (ops.view_gather_attention); d keys goes back into the chain's
+# backward as a 32-wide row instead of 4 score gradients (dva_chain_score_stats / dva_chain_bwd_layer(6), G = 32).
+# ---------------------------------------------------------------------------------------------------------------------
+_KEY_POS = {}
+
+
+def key_position_order(device):
+    """kappa [32]: key channel held by position i of a key row (i = 16 h + r -> (r & 3) + 8 (r >> 2) + 4 h)."""
+    k = str(device)
+    if k not in _KEY_POS:
+        i = torch.arange(D)
+        r, h = i % 16, i // 16
+        _KEY_POS[k] = ((r & 3) + 8 * (r >> 2) + 4 * h).to(device)
+    return _KEY_POS[k]
+
+
+def keys_applicable(module, x_mod, x_map, csr_idx):
+    """Can ``module`` (a QKVBimodalCSRPool) take its keys from the recompute chain?"""
+    if not enabled() or module.use_mod_k or module.use_mod_q or module.save_last or module.debug:
+        return False
+    if not isinstance(x_mod, ops.GatheredFeatures) or x_mod.rows.dtype != torch.bfloat16:
+        return False
+    if module.K.out_features != D or module.num_groups not in (1, 2, 4) or module.nc_qk * module.num_groups != D:
+        return False
+    if not fused_deepset.applicable(module.E_map, module.K, x_map):
+        return False
+    V, N = x_map.shape[0], csr_idx.shape[0] - 1
+    return V * 64 < (1 << 32) - 16 and N * 128 < (1 << 32) - 16
+
+
+class _KeyAdapter:
+    """What chain_prologue / chain_epilogue read of a pooling module, for the key layer of a QKVBimodalCSRPool."""
+
+    def __init__(self, module):
+        self.E_map, self.E_score, self.G = module.E_map, module.K, None
+
+
+class _ChainKeys(torch.autograd.Function):
+    """keys' bf16 [V, 32] (position order) = K(E_map(x_map)); params in fused_chain.chain_params(adapter) order."""
+
+    @staticmethod
+    def forward(ctx, x_map, csr_idx, adapter, *params):
+        lib = _lib.load()
+        require_device(x_map, csr_idx)
+        x_map = x_map.contiguous()
+        dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
+        st = stream_of(x_map)
+        S = chain_prologue(adapter, x_map, csr_idx)
+        keys = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
+        with ops._timed("chain_keys", V * (32 + 4 + 64) + N * 128):
+            check(lib.dva_chain_keys(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
+                                     ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), ptr(keys), V, N, st),
+                  "dva_chain_keys")
+        ctx.save_for_backward(x_map, csr_idx, S.vp, S.tiles, S.n_tiles, S.wops, S.t_add, S.zstar, S.arg, S.mom, S.bn1,
+                              S.bn2, S.bn5, S.bn6, S.W1)
+        ctx.adapter, ctx.set_saved, ctx.training = adapter, S.set_saved, S.training
+        ctx.mark_non_differentiable(S.vp)
+        return keys, S.vp
+
+    @staticmethod
+    def backward(ctx, dkeys, _dvp):
+        from types import SimpleNamespace
+        from .fused_chain_bwd import Arena, chain_epilogue
+        lib = _lib.load()
+        if ctx.set_saved is None:
+            raise RuntimeError("the recompute chain's backward ran twice on the same graph (retain_graph is not "
+                               "supported on this path)")
+        x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, W1 = ctx.saved_tensors
+        S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
+                            bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=D, training=ctx.training)
+        dkeys = dkeys.contiguous().to(torch.bfloat16)
+        grads = chain_epilogue(lib, Arena(x_map.device), S, ctx.adapter, x_map, csr_idx, dkeys, None, ctx.set_saved)
+        ctx.set_saved = None
+        return (None, None, None) + tuple(grads)
+
+
+class _QKCompat(torch.autograd.Function):
+    """compat [V, G] from key rows (position order) and per-point queries (position order)."""
+
+    @staticmethod
+    def forward(ctx, keys, Qp, csr_idx, vp, G, scale):
+        lib = _lib.load()
+        V = keys.shape[0]
+        Qp = Qp.float().contiguous()
+        compat = torch.empty((V, G), dtype=torch.float32, device=keys.device)
+        with ops._timed("qkv_compat", V * (64 + 128 + 4 * G)):
+            check(lib.dva_qkv_compat(ptr(keys), ptr(Qp), ptr(vp), ptr(compat), V, G, float(scale), stream_of(keys)),
+                  "dva_qkv_compat")
+        ctx.save_for_backward(keys, Qp, csr_idx, vp)
+        ctx.meta = (G, float(scale))
+        return compat
+
+    @staticmethod
+    def backward(ctx, dcompat):
+        lib = _lib.load()
+        keys, Qp, csr_idx, vp = ctx.saved_tensors
+        G, scale = ctx.meta
+        V, N = keys.shape[0], Qp.shape[0]
+        dcompat = dcompat.float().contiguous()
+        dkeys = torch.empty((V, D), dtype=torch.bfloat16, device=keys.device)
+        dQ = torch.empty((N, D), dtype=torch.float32, device=keys.device)
+        with ops._timed("qkv_compat_bwd", V * (64 + 64 + 128 + 8 * G) + N * 128):
+            check(lib.dva_qkv_compat_bwd(ptr(dcompat), ptr(keys), ptr(Qp), ptr(vp), ptr(csr_idx), ptr(dkeys), ptr(dQ), N, V,
+                                         G, scale, stream_of(keys)), "dva_qkv_compat_bwd")
+        return dkeys, dQ, None, None, None, None
+
+
+def qkv_compatibilities(module, x_main, x_map, csr_idx):
+    """``compatibilities`` of QKVBimodalCSRPool.forward (pooling.py:520-531) for point-wise queries and mapping-feature
+    keys: ``x_main`` = E_main(x_main) [N, nc_inner]."""
+    import math
+    csr_idx = ops._check_ptr(csr_idx)
+    adapter = _KeyAdapter(module)
+    kappa = key_position_order(x_map.device)
+    keys, vp = _ChainKeys.apply(x_map, csr_idx, adapter, *chain_params(adapter))
+    # the point's queries in the key rows' position order: the permutation goes onto the [32, 32] weight, not onto [N, 32]
+    Qp = ops.tall_linear(x_main, module.Q.weight[kappa], module.Q.bias[kappa]).float()
+    scale = 1.0 / math.sqrt(module.nc_qk) if module.dim_scaling else 1.0
+    return _QKCompat.apply(keys, Qp, csr_idx, vp.detach(), module.num_groups, scale)

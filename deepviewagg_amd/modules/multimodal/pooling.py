@@ -439,6 +439,15 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
                 (idx_destroyed.shape[0], *(x_mod.shape[1:])), device=device)
 
         n_views = x_mod.shape[0]
+        if fused_chain.keys_applicable(self, x_mod, x_map, csr_idx):
+            # bf16 under autocast (round 4): the keys are one more layer of the recompute chain (one bf16 [V, 32] row per
+            # view), compatibilities from them and the point's query row in one kernel; E_mod on the map rows, E_main
+            # on the N point rows through the row kernels (split-K weight gradients: the library's are skinny GEMMs)
+            x_main = _mlp_rows(self.E_main, x_main)
+            x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0]))
+            compatibilities = fused_chain.qkv_compatibilities(self, x_main, x_map, csr_idx)
+            x_pool, _, _ = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
+            return x_pool
         x_main = self.E_main(x_main)
         fused_keys = (not self.use_mod_k and not self.save_last and not self.debug
                       and fused_deepset.applicable(self.E_map, self.K, x_map))

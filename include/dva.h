@@ -376,11 +376,13 @@ int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* s
  * (dva_bn_finalize), "stats" caller-zeroed double[64].  All per-point outputs are only written for points
  * that have views: the caller zero-fills them.
  * ------------------------------------------------------------------------------------------ */
-/* ops: DVA_CHAIN_OPS_BYTES (30 KiB) device buffer receiving the weight operands (16 bf16 matrix-core operand
+/* ops: DVA_CHAIN_OPS_BYTES (32 KiB) device buffer receiving the weight operands (18 bf16 matrix-core operand
  * blocks + an fp32 copy of the forward ones, from which the kernels build BatchNorm-folded operands
  * bf16(0.6 gamma invstd W) for the layers whose raw output a pass does not need).  W1 [32][8], W2 [32][32],
- * W5 [32][ld5] (the first 32 columns: the per-view half of the concatenation layer), W6 [32][32], Ws [G][32], G <= 4. */
-#define DVA_CHAIN_OPS_BYTES (16 * 64 * 16 + 7 * 64 * 32)
+ * W5 [32][ld5] (the first 32 columns: the per-view half of the concatenation layer), W6 [32][32], Ws [G][32], G <= 4 -- or
+ * G = 32: the last layer is the KEY layer of QKVBimodalCSRPool (dva_chain_keys; its gradient enters dva_chain_score_stats /
+ * dva_chain_bwd_layer(6) as a bf16 [V][32] row instead of 4 scores). */
+#define DVA_CHAIN_OPS_BYTES (18 * 64 * 16 + 7 * 64 * 32)
 int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6,
                    const float* Ws, int32_t G, void* ops, void* stream);
 /* BatchNorm bookkeeping of one chain layer: dva_bn_finalize (C = 32) + a fifth table row, bn fp32 [5][32] =
@@ -429,6 +431,22 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
                     const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                     const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
                     void* stream);
+/* Key layer of QKVBimodalCSRPool on the recompute chain (round 4; reference modules/multimodal/pooling.py:454-547:
+ * keys = K(E_map(x_map))): ops prepared by dva_chain_prep with Ws = K.weight [32][32], G = 32.  keys bf16 [V][32] in
+ * ACCUMULATOR order: position 16 h + r holds key channel (r & 3) + 8 (r >> 2) + 4 h (the layout of the rows the chain's
+ * backward passes hand to each other).  The gradient of the keys goes back in the same layout as the grad_scores argument of
+ * dva_chain_score_stats (dWs [32][32], dbs [32]) and dva_chain_bwd_layer(stage 6) with G = 32. */
+int dva_chain_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                   const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                   const float* bn6, const float* key_bias, void* keys, int64_t n_views, int64_t n_points, void* stream);
+/* compat fp32 [V][G] = scale * sum over the nc_qk = 32 / G key channels of group g of keys[v] * queries[point(v)]
+ * (pooling.py:520-531), keys as dva_chain_keys writes them, queries fp32 [N][32] in the same position order; G in {1, 2, 4}.
+ * _bwd: grad_keys bf16 [V][32] (position order, for the chain backward), grad_queries fp32 [N][32] (written). */
+int dva_qkv_compat(const void* keys, const float* queries, const int32_t* view_point, float* compat, int64_t n_views,
+                   int32_t G, float scale, void* stream);
+int dva_qkv_compat_bwd(const float* grad_compat, const void* keys, const float* queries, const int32_t* view_point,
+                       const int64_t* ptr, void* grad_keys, float* grad_queries, int64_t n_points, int64_t n_views,
+                       int32_t G, float scale, void* stream);
 /* out bf16 [N][C] (caller-zeroed) = gate * sum_v softmax_v(scores) * rows[row_idx[v]]:
  * x_map + rows in -> pooled features out.  rows bf16 [n_rows][C], C in {32, 64, 128, 256, 512},
  * G in {1, 2, 4} with (C / G) % 8 == 0; gate_w / gate_b fp32 [G] nullable together.
