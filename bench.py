@@ -978,7 +978,7 @@ def main():
                 # the reference's default arithmetic (no autocast, fp32 features): S1 shapes on the fp32 chain
                 "f32": secondary_workload("f32", device, torch.float32, args.log2_points, views, 64),
                 "kitti360_pyramid_eval": kitti360_pyramid_eval(device, args.log2_points, views),
-                # QKVBimodalCSRPool (pooling.py:454-547) at the S1 shapes: keys on the stored-activation DeepSet kernels
+                # QKVBimodalCSRPool (pooling.py:454-547) at the S1 shapes: keys = one more layer of the recompute chain (round 4)
                 "qkv": secondary_workload("qkv", device, dtype, args.log2_points, views, 64),
                 "kitti360_pyramid_train": kitti360_pyramid_train(device, args.log2_points, views),
                 "s3dis_batch": s3dis_batch_workload(device),
