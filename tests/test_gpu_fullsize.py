@@ -324,14 +324,14 @@ def _bilinear_step(s, sl=None, fused=True, need_grad=True):
     return out, grads
 
 
-@pytest.mark.parametrize("C_in,C_out", [(64, 64), (128, 32)])
+@pytest.mark.parametrize("C_in,C_out", [(64, 64), (128, 32), (256, 128), (512, 256)])
 def test_fused_bilinear_full_size_properties(C_in, C_out):
     """Determinism, exact zeros on unseen points, finite parameter gradients, and the conservation law of the train-mode
     feature-map gradient: BatchNorm_a's backward removes the batch mean of dz_a, the interpolation weights of a view sum
     to one, so the gradient of Y = x W_a^T sums to ~0 over the map rows per channel -- and with it the gradient of x
     (a statement about the anchor plan + Gram-matrix BatchNorm backward at V = 31.9 M)."""
     s = _bilinear_scene(N, C_in, C_out, seed=29)
-    if C_out == 64:
+    if C_out >= 64:
         assert s["V"] * C_out * 2 > (1 << 31), "the view-sized rows of this case need more than 31 offset bits"
     state = {k: v.clone() for k, v in s["m"].state_dict().items()}
     out1, g1 = _bilinear_step(s)
@@ -354,7 +354,7 @@ def test_fused_bilinear_full_size_properties(C_in, C_out):
     assert float(per_channel.max()) < 2e-3, float(per_channel.max())
 
 
-@pytest.mark.parametrize("C_in,C_out", [(64, 64), (128, 32)])
+@pytest.mark.parametrize("C_in,C_out", [(64, 64), (128, 32), (256, 128)])
 def test_fused_bilinear_full_size_slice(C_in, C_out):
     """Eval mode (running statistics: a point's output depends on its own views only): the first 2^16 points of the
     full-size run are bit-identical to a run on that slice alone, and the slice agrees with the materialised dataflow
@@ -397,3 +397,63 @@ def test_fused_bilinear_just_below_the_applicable_limits():
     # the guard itself: this scene is admitted, one more point is not (CPU test of the arithmetic: test_size_limits.py)
     assert fused_bilinear.size_limits_ok(s["V"], B * H * W, n, 32)
     assert not fused_bilinear.size_limits_ok(s["V"] + VIEWS, B * H * W, n + 1, 32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# QKVBimodalCSRPool with its keys on the recompute chain (round 4) at the size bench.py times it.
+# ---------------------------------------------------------------------------------------------------------------
+def test_qkv_chain_full_size_properties():
+    """N = 2^20 points x 32 views: two runs bit-identical (output and feature-map gradient), unseen points exactly 0,
+    finite parameter gradients; eval mode: the first 2^16 points equal a run on that slice alone bit for bit."""
+    from deepviewagg_amd import ops, fused_chain
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    g = torch.Generator(device=DEV).manual_seed(41)
+    k = torch.full((N,), VIEWS, device=DEV, dtype=torch.int64)
+    k[torch.rand(N, generator=g, device=DEV) < 0.05] = 0
+    csr = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), k.cumsum(0)])
+    V, R = int(csr[-1]), B * H * W
+    row_idx = torch.randint(0, R, (V,), generator=g, device=DEV, dtype=torch.int32)
+    rows = torch.randn(R, C, generator=g, device=DEV).bfloat16()
+    x_map = torch.rand(V, 8, generator=g, device=DEV)
+    x_main = torch.randn(N, 4, generator=g, device=DEV)
+    w = (torch.randn(N, C, generator=g, device=DEV) / N).bfloat16()
+    torch.manual_seed(9)
+    m = P.QKVBimodalCSRPool(in_main=4, in_map=8, in_mod=C, num_groups=G, nc_qk=8, use_num=True).to(DEV).train()
+    state = {kk: v.clone() for kk, v in m.state_dict().items()}
+
+    def step(n=None):
+        nn_ = N if n is None else n
+        c = csr[:nn_ + 1].contiguous()
+        v = int(c[-1])
+        r = rows.clone().requires_grad_()
+        gf = ops.GatheredFeatures(r, row_idx[:v].contiguous(), None, True, None)
+        calls = []
+        orig = fused_chain.qkv_compatibilities
+
+        def spy(*a, **kw):
+            calls.append(1)
+            return orig(*a, **kw)
+        fused_chain.qkv_compatibilities = spy
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(x_main[:nn_].contiguous(), gf, x_map[:v].contiguous(), c)
+        finally:
+            fused_chain.qkv_compatibilities = orig
+        assert calls == [1], "the key layer must have run on the recompute chain"
+        grads = torch.autograd.grad(out, [r] + list(m.parameters()), grad_outputs=w[:nn_].to(out.dtype), allow_unused=True)
+        return out, grads
+    out1, g1 = step()
+    m.load_state_dict(state)
+    out2, g2 = step()
+    m.load_state_dict(state)
+    assert out1.dtype == torch.bfloat16 and bool(torch.isfinite(out1.float()).all())
+    assert torch.equal(out1, out2) and torch.equal(g1[0], g2[0])
+    assert float(out1.detach()[k == 0].float().abs().max()) == 0.0
+    for (n_, _), a, b in zip(m.named_parameters(), g1[1:], g2[1:]):
+        assert a is not None and bool(torch.isfinite(a).all()), n_
+        assert float((a - b).norm() / (a.norm() + 1e-30)) < 1e-3, n_
+    m.eval()
+    sl = 1 << 16
+    out_full, _ = step()
+    out_sl, _ = step(sl)
+    assert torch.equal(out_full[:sl], out_sl)
