@@ -584,8 +584,14 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_sc[4][4 * 32];     // gate / (sum + eps) per [group][local point]
   __shared__ __attribute__((aligned(16))) int s_pid[4][32], s_ri[4][32];
   __shared__ __attribute__((aligned(16))) float s_alpha[4][4], s_scg[4][4];
-  // several points per tile: one private row [C] per row slot for the partial sums of points split over slots
-  __shared__ __attribute__((aligned(16))) float s_acc[4][ROWS * C];
+  // several points per tile.  C <= 128 (round 4): the gathered rows of the tile staged in LDS ([view][C] bf16, row
+  // pitch C * 2 + 32 bytes), lane l owns the C / 64 channels from l * C / 64 and walks the views in order -- the point
+  // boundaries are wave-uniform (a ballot), so the walk is straight-line code with a scalar-tested flush per view.
+  // Wider rows: one private row [C] per row slot for the partial sums of points split over slots.
+  constexpr bool STAGED = C <= 128 && C >= 64;
+  constexpr int CPL = STAGED ? C / 64 : 1, PITCH = C + 16;     // PITCH in bf16 elements
+  __shared__ __attribute__((aligned(16))) float s_acc[4][STAGED ? 4 : ROWS * C];
+  __shared__ __attribute__((aligned(16))) bf16_t s_rows[4][STAGED ? 32 * PITCH : 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < OP_W6T * 64; i += blockDim.x) s_ops[i] = ops[i];
   stage_tab_fwd(s_tab[0], bn1);
@@ -820,69 +826,118 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
         const float s = seg_total(seg_scan_sum(ev, sg, lane), sg, h);
         const float gt = gw ? tanh_pos(vmaxf(__builtin_fmaf(gwl[e], m, gbl[e]), 0.f)) : 1.f;
         if (s_active) {
-          ev_t[gl[e] * 32 + j] = ev;
-          sc_t[gl[e] * 32 + j] = gt * __builtin_amdgcn_rcpf(s + eps);
+          const float sc1 = gt * __builtin_amdgcn_rcpf(s + eps);
+          ev_t[gl[e] * 32 + j] = STAGED ? (ok ? ev * sc1 : 0.f) : ev;       // staged walk: the scaled weight
+          sc_t[gl[e] * 32 + j] = sc1;
         }
       }
-      if (h == 0) pid_t[j] = p.vpj;
-      // where the points of the tile start / end: two wave-uniform masks (views without a point = one-view segments)
-      const uint32_t inv = nv < 32 ? 0xffffffffu << nv : 0u;
-      const uint32_t smx = sg.smask | inv, emx = sg.emask | inv;
-      wave_sync();
-      float hp[8];
-      bool has_head = false;
-      int head_view = 0, head_slot0 = 0;
-      float* mine = acc_t + slot * C + q * 8;
+      if constexpr (STAGED) {
+        bf16_t* rt = s_rows[wv];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (b + 1 < NB) issue_rows(b + 1);
+        for (int kk = 0; kk < KV; ++kk)
+          *reinterpret_cast<u32x4*>(rt + (sv0 + kk) * PITCH + q * 8) = xr[0][kk];
+        const uint32_t emx = sg.emask | (nv < 32 ? 0xffffffffu << nv : 0u);
+        wave_sync();
+        const int c0 = lane * CPL, tgc = c0 / (C / G);
+        float av[CPL];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-          const int k = b * KB + kk, vt = sv0 + k;
-          fma_row(xr[b & 1][kk], ev_t[tg * 32 + vt]);
-          const bool last = (k == KV - 1) || ((smx >> (vt + 1)) & 1u);
-          if (last) {
-            if (vt < nv) {
-              const int ssk = 31 - __clz((int)(smx & (0xffffffffu >> (31 - vt))));     // first view of vt's point
-              const int sek = vt + __ffs((int)(emx >> vt)) - 1;                        // its last view
-              if (sek >= sv0 + KV) {
-                // the point continues in the next slot: park the partial sum
-                *reinterpret_cast<float4*>(mine) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                *reinterpret_cast<float4*>(mine + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-              } else if (ssk >= sv0) {
-                const float s1 = sc_t[tg * 32 + vt];
-                const u32x4 o = {pack_bf16x2(acc[0] * s1, acc[1] * s1), pack_bf16x2(acc[2] * s1, acc[3] * s1),
-                                 pack_bf16x2(acc[4] * s1, acc[5] * s1), pack_bf16x2(acc[6] * s1, acc[7] * s1)};
-                st128(O, (uint32_t)pid_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
-              } else {
-                // the point started in an earlier slot and ends here
-                has_head = true;
-                head_view = vt;
-                head_slot0 = ssk / KV;
+        for (int i = 0; i < CPL; ++i) av[i] = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) hp[i] = acc[i];
-              }
+        for (int ch = 0; ch < 4; ++ch) {
+          if (8 * ch < nv) {
+            const float4 wa = *reinterpret_cast<const float4*>(ev_t + tgc * 32 + 8 * ch);
+            const float4 wb = *reinterpret_cast<const float4*>(ev_t + tgc * 32 + 8 * ch + 4);
+            const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            uint32_t rv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if (CPL == 1) rv[i] = *reinterpret_cast<const uint16_t*>(rt + (8 * ch + i) * PITCH + c0);
+              else rv[i] = *reinterpret_cast<const uint32_t*>(rt + (8 * ch + i) * PITCH + c0);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-          }
-        }
-      }
-      wave_sync();
-      if (has_head) {
+            for (int i = 0; i < 8; ++i) {
+              const int v = 8 * ch + i;
+              if (CPL == 1) {
+                av[0] = __builtin_fmaf(w8[i], __uint_as_float(rv[i] << 16), av[0]);
+              } else {
+                av[0] = __builtin_fmaf(w8[i], __uint_as_float(rv[i] << 16), av[0]);
+                av[CPL - 1] = __builtin_fmaf(w8[i], __uint_as_float(rv[i] & 0xffff0000u), av[CPL - 1]);
+              }
+              if ((emx >> v) & 1u) {           // wave-uniform: view v ends its point
+                if (v < nv) {
+                  const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane(p.vpj, v);
+                  const uint32_t oo = pid * (uint32_t)(C * 2) + (uint32_t)c0 * 2u;
+                  if (CPL == 1) __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(av[0]), O, (int)oo, 0, 0);
+                  else st32(O, oo, pack_bf16x2(av[0], av[CPL - 1]));
+                }
 #pragma unroll
-        for (int d = 1; d < ROWS; ++d) {
-          if (slot - d >= head_slot0) {
-            const float* src = acc_t + (slot - d) * C + q * 8;
-            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-            hp[0] += lo.x; hp[1] += lo.y; hp[2] += lo.z; hp[3] += lo.w;
-            hp[4] += hi.x; hp[5] += hi.y; hp[6] += hi.z; hp[7] += hi.w;
+                for (int k2 = 0; k2 < CPL; ++k2) av[k2] = 0.f;
+              }
+            }
           }
         }
-        const float s1 = sc_t[tg * 32 + head_view];
-        const u32x4 o = {pack_bf16x2(hp[0] * s1, hp[1] * s1), pack_bf16x2(hp[2] * s1, hp[3] * s1),
-                         pack_bf16x2(hp[4] * s1, hp[5] * s1), pack_bf16x2(hp[6] * s1, hp[7] * s1)};
-        st128(O, (uint32_t)pid_t[head_view] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
+      } else {
+        if (h == 0) pid_t[j] = p.vpj;
+        // where the points of the tile start / end: two wave-uniform masks (views without a point = one-view segments)
+        const uint32_t inv = nv < 32 ? 0xffffffffu << nv : 0u;
+        const uint32_t smx = sg.smask | inv, emx = sg.emask | inv;
+        wave_sync();
+        float hp[8];
+        bool has_head = false;
+        int head_view = 0, head_slot0 = 0;
+        float* mine = acc_t + slot * C + q * 8;
+  #pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (b + 1 < NB) issue_rows(b + 1);
+  #pragma unroll
+          for (int kk = 0; kk < KB; ++kk) {
+            const int k = b * KB + kk, vt = sv0 + k;
+            fma_row(xr[b & 1][kk], ev_t[tg * 32 + vt]);
+            const bool last = (k == KV - 1) || ((smx >> (vt + 1)) & 1u);
+            if (last) {
+              if (vt < nv) {
+                const int ssk = 31 - __clz((int)(smx & (0xffffffffu >> (31 - vt))));     // first view of vt's point
+                const int sek = vt + __ffs((int)(emx >> vt)) - 1;                        // its last view
+                if (sek >= sv0 + KV) {
+                  // the point continues in the next slot: park the partial sum
+                  *reinterpret_cast<float4*>(mine) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                  *reinterpret_cast<float4*>(mine + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                } else if (ssk >= sv0) {
+                  const float s1 = sc_t[tg * 32 + vt];
+                  const u32x4 o = {pack_bf16x2(acc[0] * s1, acc[1] * s1), pack_bf16x2(acc[2] * s1, acc[3] * s1),
+                                   pack_bf16x2(acc[4] * s1, acc[5] * s1), pack_bf16x2(acc[6] * s1, acc[7] * s1)};
+                  st128(O, (uint32_t)pid_t[vt] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
+                } else {
+                  // the point started in an earlier slot and ends here
+                  has_head = true;
+                  head_view = vt;
+                  head_slot0 = ssk / KV;
+  #pragma unroll
+                  for (int i = 0; i < 8; ++i) hp[i] = acc[i];
+                }
+              }
+  #pragma unroll
+              for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            }
+          }
+        }
+        wave_sync();
+        if (has_head) {
+  #pragma unroll
+          for (int d = 1; d < ROWS; ++d) {
+            if (slot - d >= head_slot0) {
+              const float* src = acc_t + (slot - d) * C + q * 8;
+              const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+              hp[0] += lo.x; hp[1] += lo.y; hp[2] += lo.z; hp[3] += lo.w;
+              hp[4] += hi.x; hp[5] += hi.y; hp[6] += hi.z; hp[7] += hi.w;
+            }
+          }
+          const float s1 = sc_t[tg * 32 + head_view];
+          const u32x4 o = {pack_bf16x2(hp[0] * s1, hp[1] * s1), pack_bf16x2(hp[2] * s1, hp[3] * s1),
+                           pack_bf16x2(hp[4] * s1, hp[5] * s1), pack_bf16x2(hp[6] * s1, hp[7] * s1)};
+          st128(O, (uint32_t)pid_t[head_view] * (uint32_t)(C * 2) + (uint32_t)q * 16u, o);
+        }
+    
       }
     }
     wave_sync();
@@ -1056,7 +1111,8 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
       n_points * C * 2 > 0xfffffff0ll)
     return DVA_ERR_UNSUPPORTED;
-  const bool dense = C <= 64 && n_views >= 24 * n_points;   // mostly one point per tile
+  static const int occ_env = getenv("DVA_ATTN_FWD_OCC") ? atoi(getenv("DVA_ATTN_FWD_OCC")) : 0;   // A/B: 3 or 4
+  const bool dense = occ_env ? (occ_env == 4 && C <= 64) : (C <= 64 && n_views >= 24 * n_points);   // mostly one point per tile
   const dim3 grid(chain_grid(dense ? 4 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_ATTN_FWD_O(LPR_, G_, OCC_)                                                                          \
