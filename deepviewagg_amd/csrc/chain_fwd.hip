@@ -1070,7 +1070,8 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   // layer 5 fits 116 VGPRs: four blocks per CU; layer 6 (150) three
-  const dim3 grid(chain_grid(layer == 5 ? tune_int("DVA_STATS5_BPC", 4) : 3)), block(256);
+  static const int bpc5 = tune_int("DVA_STATS5_BPC", 4);      // read once
+  const dim3 grid(chain_grid(layer == 5 ? bpc5 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layer == 5)
     hipLaunchKernelGGL((stats_mid_kernel<5>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,

@@ -561,6 +561,63 @@ def test_lean_attention_backward_fp32_equals_team_kernel(C, gating, scaling):
         torch.testing.assert_close(x.cpu().reshape(y.shape), y, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("C,G", [(32, 4), (64, 4), (64, 2), (128, 1), (512, 4)])
+@pytest.mark.parametrize("gating,scaling", [(True, True), (False, False)])
+def test_lean_attention_backward_bf16_equals_team_kernel(C, G, gating, scaling):
+    """bf16 rows, 1 / 2 / 4 score groups (round 4: the attention backward of QKVBimodalCSRPool on the chain): the chain
+    path's tile-based attention backward + 16-byte-record rows gradient against the team kernels (same bf16 inputs: the
+    differences are the bf16 gate x attention weights of the records and summation orders) and against the fp32 PyTorch
+    oracle evaluated on the same bf16-rounded rows."""
+    from deepviewagg_amd import ops
+    from oracle import pooling_oracle as O
+    gen = torch.Generator().manual_seed(200 + C + G)
+    N, R = 700, 509
+    sizes = torch.randint(0, 12, (N,), generator=gen)
+    sizes[10], sizes[300] = 90, 400
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    V = int(csr[-1])
+    rows = torch.randn(R, C, generator=gen).bfloat16()
+    row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    compat = torch.randn(V, G, generator=gen)
+    compat[csr[20]:csr[20] + 2] = compat[csr[20]]
+    w = torch.randn(N, C, generator=gen).bfloat16()
+    gw = torch.randn(1, G, generator=gen) if gating else None
+    gb = torch.randn(1, G, generator=gen) if gating else None
+
+    def run(lean):
+        ops.LEAN_ATTENTION_BWD = lean
+        try:
+            r = rows.to(DEV).requires_grad_()
+            c = compat.to(DEV).requires_grad_()
+            pw = gw.to(DEV).requires_grad_() if gating else None
+            pb = gb.to(DEV).requires_grad_() if gating else None
+            out, att, gate = ops.view_gather_attention(r, row_idx.to(DEV), c, csr.to(DEV), pw, pb, scaling=scaling)
+            assert out.dtype == torch.bfloat16
+            grads = torch.autograd.grad((out.float() * w.to(DEV).float()).sum(), [r, c] + ([pw, pb] if gating else []))
+            return [out.detach()] + [g_.detach() for g_ in grads]
+        finally:
+            ops.LEAN_ATTENTION_BWD = True
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    rel = lambda x, y: float((x.float() - y.float()).norm() / y.float().norm().clamp_min(1e-20))
+    assert rel(a[1], b[1]) < 6e-3, rel(a[1], b[1])                   # rows gradient: bf16 weights in the records
+    for x, y in zip(a[2:], b[2:]):
+        assert rel(x, y) < 2e-3, rel(x, y)
+    # oracle (fp32 on the bf16-rounded rows; the pooled output is rounded to bf16 by the kernels)
+    gate_m = O.Gating(G) if gating else None
+    if gating:
+        with torch.no_grad():
+            gate_m.weight.copy_(gw)
+            gate_m.bias.copy_(gb)
+    r0, c0 = rows.float().clone().requires_grad_(), compat.clone().requires_grad_()
+    out_ref, _, _ = O.attention_tail(r0[row_idx.long()], c0, csr, gate_m, G, C, scaling)
+    g_ref = torch.autograd.grad((out_ref * w.float()).sum(), [r0, c0] + (list(gate_m.parameters()) if gating else []))
+    assert rel(a[0].cpu(), out_ref.detach()) < 4e-3
+    assert rel(a[1].cpu(), g_ref[0]) < 8e-3
+    for x, y in zip(a[2:], g_ref[1:]):
+        assert rel(x.cpu().reshape(y.shape), y) < 4e-3, rel(x.cpu().reshape(y.shape), y)
+
+
 @pytest.mark.parametrize("C", [32, 64])
 def test_bilinear_scatter_with_batchnorm_backward(C):
     """ops.bilinear_scatter(bn_backward=...): the BatchNorm_a backward of the fused bilinear path folded into the anchor
