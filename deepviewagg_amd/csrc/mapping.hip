@@ -23,6 +23,17 @@
 
 namespace dva {
 
+// Column of element t of a box of height d (t / d) without an integer division: (t + 0.5) * fl(1 / d) truncated is exact for
+// t < 2^22 (the quotient lies at least 0.5 / d from an integer, the two roundings move it by less than (t + 0.5) 2^-23 / d);
+// larger boxes divide.  A 32-bit integer division is ~20 instructions per pixel test, this is 4.
+struct BoxDiv {
+  float rinv;
+  int d;
+  bool fast;
+  __device__ __forceinline__ BoxDiv(int d_, int area) : rinv(1.0f / (float)d_), d(d_), fast(area < (1 << 22)) {}
+  __device__ __forceinline__ int col(int t) const { return fast ? (int)(((float)t + 0.5f) * rinv) : t / d; }
+};
+
 struct MapCounters {
   int32_t m;  // candidates surviving projection
   int32_t pad;
@@ -223,8 +234,9 @@ __global__ __launch_bounds__(256) void zbuffer_kernel(const int4* __restrict__ s
     const int bw = s.y - s.x, bh = s.w - s.z;
     const int area = bw * bh;
     const unsigned long long key = ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)j;
+    const BoxDiv bd(bh, area);
     for (int t = lane; t < area; t += 64) {
-      const int bx = t / bh, by = t - bx * bh;
+      const int bx = bd.col(t), by = t - bx * bh;
       unsigned long long* cell = zbuf + (size_t)(s.x + bx) * Hc + (s.z + by);
       if (key < *cell) atomicMin(cell, key);  // cheap pre-test; atomicMin decides
     }
@@ -412,8 +424,9 @@ __global__ __launch_bounds__(256) void zbuffer_batch_kernel(const int4* __restri
         const int bh = sq.w - sq.z;
         const unsigned long long key = ((unsigned long long)__float_as_uint(dist[jq]) << 32) | (unsigned)jq;
         unsigned long long* plane = zbuf + (size_t)simg[jq] * (size_t)npix;
+        const BoxDiv bd(bh, area_q);
         for (int t = ql; t < area_q; t += 16) {
-          const int bx = t / bh, by = t - bx * bh;
+          const int bx = bd.col(t), by = t - bx * bh;
           unsigned long long* cell = plane + (size_t)(sq.x + bx) * Hc + (sq.z + by);
           if (key < *cell) atomicMin(cell, key);
         }
@@ -426,8 +439,9 @@ __global__ __launch_bounds__(256) void zbuffer_batch_kernel(const int4* __restri
         const int area = (s.y - s.x) * bh;
         const unsigned long long key = ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)j;
         unsigned long long* plane = zbuf + (size_t)simg[j] * (size_t)npix;
+        const BoxDiv bd(bh, area);
         for (int t = lane; t < area; t += 64) {
-          const int bx = t / bh, by = t - bx * bh;
+          const int bx = bd.col(t), by = t - bx * bh;
           unsigned long long* cell = plane + (size_t)(s.x + bx) * Hc + (s.z + by);
           if (key < *cell) atomicMin(cell, key);
         }
@@ -560,8 +574,9 @@ __global__ __launch_bounds__(256) void zbuffer_fallback_kernel(const int32_t* __
     const int bh = s.w - s.z, area = (s.y - s.x) * bh;
     const unsigned long long key = ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)j;
     unsigned long long* plane = zbuf + (size_t)simg[j] * (size_t)npix;
+    const BoxDiv bd(bh, area);
     for (int t = lane; t < area; t += 64) {
-      const int bx = t / bh, by = t - bx * bh;
+      const int bx = bd.col(t), by = t - bx * bh;
       atomicMin(plane + (size_t)(s.x + bx) * Hc + (s.z + by), key);
     }
   }
@@ -574,22 +589,35 @@ __global__ __launch_bounds__(256) void tile_raster_kernel(
     int64_t cap, const int32_t* __restrict__ ctl, const int4* __restrict__ big_list,
     const unsigned long long* __restrict__ zbuf, uint8_t* __restrict__ seen, int32_t* __restrict__ pixmap, int W,
     int Hc, int Tx, int Ty, int B, int exact) {
-  __shared__ unsigned long long z[ZT * ZT];
+  // column pitch ZP = 40 entries (8 bytes each): the 16 lanes that rasterise one box touch up to four columns of <= 8 rows, which
+  // land on different LDS banks (a pitch of 32 put every column of a box on the same banks: a 5-way conflict per ds_min_u64)
+  constexpr int ZP = 40;
+  __shared__ unsigned long long z[ZT * ZP];
   __shared__ int4 ent[256];
   const int tile = blockIdx.x, b = tile / (Tx * Ty), r = tile - b * Tx * Ty, tx = r / Ty, ty = r - tx * Ty;
   const int x0 = tx * ZT, y0 = ty * ZT;
   const int64_t npix = (int64_t)W * Hc;
+  // the tile's list: its first 256 entries are requested before anything else (round 4: a tile holds ~130 entries, so this
+  // one load was the exposed latency of the block)
+  const int64_t off = tile_off[tile];
+  int64_t len = tile_count[tile];
+  if (off < 0) len = 0;
+  else if (off + len > cap) len = cap > off ? cap - off : 0;
+  int4 first = make_int4(0, 0, 0, 0);
+  if ((int64_t)threadIdx.x < len) first = list[off + threadIdx.x];
   const bool merge = ctl[B] > 0;
+  int nb = ctl[b];
+  if (nb > ZT_BIGCAP) nb = ZT_BIGCAP;
   for (int i = threadIdx.x; i < ZT * ZT; i += blockDim.x) {
     const int gx = x0 + (i >> 5), gy = y0 + (i & 31);
-    z[i] = (merge && gx < W && gy < Hc) ? zbuf[(size_t)b * npix + (size_t)gx * Hc + gy] : ~0ull;
+    z[(i >> 5) * ZP + (i & 31)] = (merge && gx < W && gy < Hc) ? zbuf[(size_t)b * npix + (size_t)gx * Hc + gy] : ~0ull;
   }
   const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-  auto walk = [&](const int4* src, int64_t len) {
-    for (int64_t e0 = 0; e0 < len; e0 += 256) {
-      const int n = (int)(len - e0 < 256 ? len - e0 : 256);
+  auto walk = [&](const int4* src, int64_t len_, bool have_first) {
+    for (int64_t e0 = 0; e0 < len_; e0 += 256) {
+      const int n = (int)(len_ - e0 < 256 ? len_ - e0 : 256);
       __syncthreads();                       // z initialised / the previous batch of entries consumed
-      if ((int)threadIdx.x < n) ent[threadIdx.x] = src[e0 + threadIdx.x];
+      if ((int)threadIdx.x < n) ent[threadIdx.x] = (have_first && e0 == 0) ? first : src[e0 + threadIdx.x];
       __syncthreads();
       for (int e = grp; e < n; e += 16) {
         const int4 en = ent[e];
@@ -599,33 +627,32 @@ __global__ __launch_bounds__(256) void tile_raster_kernel(
         const int w = cx1 - cx0, hh = cy1 - cy0;
         if (w <= 0 || hh <= 0) continue;
         const unsigned long long key = ((unsigned long long)(uint32_t)en.y << 32) | (uint32_t)en.x;
-        const int area = w * hh;
+        const int area = w * hh;                     // <= 1024: the multiply form of t / hh is exact even with the 1-ulp
+        const float rinv = __builtin_amdgcn_rcpf((float)hh);       // reciprocal (see BoxDiv), 24-bit products suffice
+        const int base = (cx0 - x0) * ZP + (cy0 - y0);
         for (int t = gl; t < area; t += 16) {
-          const int bx = t / hh, by = t - bx * hh;
-          atomicMin(&z[(cx0 - x0 + bx) * ZT + (cy0 - y0 + by)], key);
+          const int bx = (int)(((float)t + 0.5f) * rinv), by = t - (int)__umul24((uint32_t)bx, (uint32_t)hh);
+          atomicMin(&z[base + bx * ZP + by], key);
         }
       }
     }
   };
-  {
-    const int64_t off = tile_off[tile];
-    int64_t len = tile_count[tile];
-    if (off < 0) len = 0;
-    else if (off + len > cap) len = cap > off ? cap - off : 0;
-    walk(list + off, len);
-    int nb = ctl[b];
-    if (nb > ZT_BIGCAP) nb = ZT_BIGCAP;
-    walk(big_list + (int64_t)b * ZT_BIGCAP, nb);
-  }
+  walk(list + off, len, true);
+  walk(big_list + (int64_t)b * ZT_BIGCAP, nb, false);
   __syncthreads();
   for (int i = threadIdx.x; i < ZT * ZT; i += blockDim.x) {
     const int gx = x0 + (i >> 5), gy = y0 + (i & 31);
     if (gx >= W || gy >= Hc) continue;
-    const unsigned long long k = z[i];
+    const int zi = (i >> 5) * ZP + (i & 31);
+    const unsigned long long k = z[zi];
     const int32_t win = k == ~0ull ? -1 : (int32_t)(uint32_t)k;
     if (exact) {
       pixmap[(size_t)b * npix + (size_t)gx * Hc + gy] = -1;
-      if (win >= 0) seen[win] = 1;
+      // a winner covers ~20 pixels of the tile: only the pixels whose upper / left neighbour in the tile has another
+      // winner mark it (round 4: one scattered byte store per visible region instead of one per pixel)
+      if (win >= 0 && !(((i & 31) && (int32_t)(uint32_t)z[zi - 1] == win && z[zi - 1] != ~0ull) ||
+                        ((i >> 5) && (int32_t)(uint32_t)z[zi - ZP] == win && z[zi - ZP] != ~0ull)))
+        seen[win] = 1;
     } else {
       pixmap[(size_t)b * npix + (size_t)gx * Hc + gy] = win;
     }
@@ -674,33 +701,53 @@ __global__ __launch_bounds__(256) void emit_blocks_kernel(
     const double* __restrict__ xp, const double* __restrict__ yp, int64_t* __restrict__ idx,
     int64_t* __restrict__ x_pix, int64_t* __restrict__ y_pix, float* __restrict__ depth, double* __restrict__ x_proj,
     double* __restrict__ y_proj, int64_t* __restrict__ row_ptr, int64_t* __restrict__ n_out) {
-  __shared__ int s_w[4];
+  __shared__ int s_w[EB_PER_THREAD][4];
   const int64_t total = npix * B;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t k0 = (int64_t)blockIdx.x * EB_PIX;
-  int run = block_off[blockIdx.x];             // rows before the pixels of this pass
-#pragma unroll 1
+  // round 4: the eight pixel loads of a thread are issued together and the block synchronises once (the loop of rounds
+  // 2-3 had a dependent load -> ballot -> barrier -> gather chain per pass: 353 us per batch of 32 images, latency bound)
+  int32_t jv[EB_PER_THREAD];
+  unsigned long long bal[EB_PER_THREAD];
+#pragma unroll
   for (int i = 0; i < EB_PER_THREAD; ++i) {
     const int64_t k = k0 + (int64_t)i * 256 + threadIdx.x;
-    const int32_t j = k < total ? pixmap[k] : -1;
-    const unsigned long long bal = __ballot(j >= 0);
-    if (lane == 0) s_w[wv] = __popcll(bal);
-    __syncthreads();
+    jv[i] = k < total ? pixmap[k] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < EB_PER_THREAD; ++i) {
+    bal[i] = __ballot(jv[i] >= 0);
+    if (lane == 0) s_w[i][wv] = __popcll(bal[i]);
+  }
+  __syncthreads();
+  int run = block_off[blockIdx.x];             // rows before the pixels of this pass
+  const int b0 = (int)(k0 / npix);
+#pragma unroll
+  for (int i = 0; i < EB_PER_THREAD; ++i) {
+    const int64_t k = k0 + (int64_t)i * 256 + threadIdx.x;
+    const int32_t j = jv[i];
     int before = 0, all = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      before += w < wv ? s_w[w] : 0;
-      all += s_w[w];
+      before += w < wv ? s_w[i][w] : 0;
+      all += s_w[i][w];
     }
-    const int o = run + before + __popcll(bal & ((1ull << lane) - 1ull));
+    const int o = run + before + __popcll(bal[i] & ((1ull << lane) - 1ull));
     if (k < total) {
-      const int b = (int)(k / npix);
-      const int64_t kk = k - (int64_t)b * npix;
+      // image / pixel of k: one 64-bit division per block (b0), then at most a few subtractions -- not a 64-bit division
+      // per pixel; the 32-bit column division only for mapped pixels (npix B <= 2^31 - 1 is the entry's precondition)
+      int b = b0;
+      int64_t kk = k - (int64_t)b0 * npix;
+      while (kk >= npix) {
+        kk -= npix;
+        ++b;
+      }
       if (kk == 0) row_ptr[b] = o;                 // rows of the images before b
       if (j >= 0) {
+        const uint32_t xc = (uint32_t)kk / (uint32_t)Hc;
         idx[o] = idx1[j];
-        x_pix[o] = kk / Hc;
-        y_pix[o] = kk % Hc + crop_top;
+        x_pix[o] = xc;
+        y_pix[o] = (int64_t)((uint32_t)kk - xc * (uint32_t)Hc) + crop_top;
         depth[o] = dist[j];
         x_proj[o] = xp[j];
         y_proj[o] = yp[j];
@@ -712,7 +759,6 @@ __global__ __launch_bounds__(256) void emit_blocks_kernel(
       }
     }
     run += all;
-    __syncthreads();
   }
 }
 
