@@ -126,6 +126,10 @@ SIGNATURES = {
     "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd_f32": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_keys": (ctypes.c_int, [_vp] * 12 + [_i64, _i64, _vp]),
+    "dva_chain_keys_compat": (ctypes.c_int, [_vp] * 14 + [_i32, _f32, _i64, _i64, _vp]),
+    "dva_qkv_dquery": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
+    "dva_chain_score_stats_keys": (ctypes.c_int, [_vp] * 15 + [_i32, _f32, _i64, _i64, _vp]),
+    "dva_chain_bwd_layer6_keys": (ctypes.c_int, [_vp] * 16 + [_i32, _f32, _i64, _i64, _vp]),
     "dva_qkv_compat": (ctypes.c_int, [_vp] * 4 + [_i64, _i32, _f32, _vp]),
     "dva_qkv_compat_bwd": (ctypes.c_int, [_vp] * 7 + [_i64, _i64, _i32, _f32, _vp]),
     "dva_chain_attn_bwd_planrec": (ctypes.c_int, [_vp] * 15 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),

@@ -367,16 +367,40 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void att
 //   S6 = sum dy6 | sum dy6 z6;   dWs^T[k][g] = sum_v a6[v][k] dc[v][g];   dbs = sum_v dc
 // LDS operand table: chain positions 0..6 (W1', W2', W5, W6), 7..8 = W6' (folded), 9 = Ws^T.
 // ------------------------------------------------------------------------------------------------
-// KEYS (G = 32: the key layer of QKVBimodalCSRPool): the gradient of the last layer arrives as a bf16 [V][32] row in
-// accumulator order (dc) instead of 4 scores: da6 = W_k^T dK through the full transposed operand OP_WKT, dW_k [32][32] =
-// dK^T a6 from two natural tiles, db_k = column sums of the dK tile.
+// KEYS (the key layer of QKVBimodalCSRPool): the gradient of the last layer is a [32]-row dK per view, built in registers
+// from the compatibility gradient dc [V][4] and the point's query row (dkeys_operand; a stored bf16 [V][32] row until
+// round 4): da6 = W_k^T dK through the full transposed operand OP_WKT, dW_k [32][32] = dK^T a6 from two natural tiles,
+// db_k = column sums of the dK tile.  G = the number of query-key groups (1, 2, 4).
+// KEYS: dK' of (view, half h) as the packed B operand, from the compatibility gradient dc [V][4] and the point's query row
+// Q' fp32 [N][32] (position order): dK'[16 h + r] = (scale dc[g(r)]) Q'[p][16 h + r], g(r) = (r >> 2) G / 4 -- the product
+// qkv.hip's dkeys kernel stored as a bf16 [V][32] row until round 4 (same roundings: scale first, one bf16 rounding).
+__device__ __forceinline__ void dkeys_operand(const float4& dcv, __amdgpu_buffer_rsrc_t QP, bool ok, int vpj, int h, int G,
+                                              float scale, bf16x8 (&dkp)[2]) {
+  const float d4[4] = {dcv.x * scale, dcv.y * scale, dcv.z * scale, dcv.w * scale};
+  float dq[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) dq[qd] = G == 4 ? d4[qd] : (G == 2 ? d4[qd >> 1] : d4[0]);
+  float d[16];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const float4 q = as_f4(ld128(QP, ok ? (uint32_t)vpj * 128u + 64u * h + 16u * qq : OOB));
+    d[4 * qq] = dq[qq] * q.x;
+    d[4 * qq + 1] = dq[qq] * q.y;
+    d[4 * qq + 2] = dq[qq] * q.z;
+    d[4 * qq + 3] = dq[qq] * q.w;
+  }
+  dkp[0] = pack8(&d[0]);
+  dkp[1] = pack8(&d[8]);
+}
+
 template <bool KEYS>
 __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     const float* __restrict__ bn6, const float* __restrict__ dc, double* __restrict__ stats6,
-    float* __restrict__ dWs, float* __restrict__ dbs, int G, int64_t V, int64_t N) {
+    float* __restrict__ dWs, float* __restrict__ dbs, int G, int64_t V, int64_t N, const float* __restrict__ qp,
+    float qscale) {
   constexpr int L_W6F = 7, L_WST = 9, NOPS = KEYS ? 11 : 10;
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
@@ -398,7 +422,8 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
   stage_tab(s_tab[3], bn6, nullptr);
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * (KEYS ? 64 : 16));
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16),
+                               QP = make_rsrc(qp, KEYS ? (uint64_t)N * 128 : 0);
   bf16_t* tc = s_tc[wv];
   bf16_t* td = s_td[wv];
   f32x16 accS = {0};
@@ -412,7 +437,6 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
   struct Pre {
     TileInfo ti;
     float4 x, dc;
-    u32x4 dk2;         // KEYS: the second 16 bytes of the lane's half of the dK row (the first in dc)
     int vpj;
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
@@ -422,12 +446,7 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
     p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
-    if constexpr (KEYS) {
-      p.dc = as_f4(ld128(DC, ok ? view * 64u + 32u * h : OOB));
-      p.dk2 = ld128(DC, ok ? view * 64u + 32u * h + 16u : OOB);
-    } else {
-      p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
-    }
+    p.dc = as_f4(ld128(DC, ok && (KEYS || h == 0) ? view * 16u : OOB));      // KEYS: both halves need the four groups
     return p;
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
@@ -436,8 +455,9 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     ChainKeep k;
     chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
     if constexpr (KEYS) {
-      // dK of the view as the packed B operand it was stored as (zeros for lanes without a view)
-      const bf16x8 dkp[2] = {__builtin_bit_cast(bf16x8, p.dc), __builtin_bit_cast(bf16x8, p.dk2)};
+      // dK of the view as the packed B operand (zeros for lanes without a view)
+      bf16x8 dkp[2];
+      dkeys_operand(p.dc, QP, ok, p.vpj, h, G, qscale, dkp);
       tileN_put_packed(tc, j, h, k.a6);
       tileN_put_packed(td, j, h, dkp);
       const f32x16 zero = {0};
@@ -539,7 +559,8 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const float* __restrict__ sm6, const float* __restrict__ dc, const int32_t* __restrict__ arg,
     const float* __restrict__ dpooled, const bf16_t* __restrict__ da_in, bf16_t* __restrict__ da_out,
     float* __restrict__ dW,
-    float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N) {
+    float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N,
+    const float* __restrict__ qp, float qscale) {
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
   // second operand tile of the small products: 4 (score gradients) / 17 (x_map hi | lo | ones) rows + one shared zero row
@@ -605,7 +626,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   }
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * (KEYS ? 64 : 16)),
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16), QP = make_rsrc(qp, KEYS ? (uint64_t)N * 128 : 0),
                                AR = make_rsrc(arg, (uint64_t)N * 128), DP = make_rsrc(dpooled, (uint64_t)N * 128),
                                DI = make_rsrc(da_in, (uint64_t)V * 64), DO = make_rsrc(da_out, (uint64_t)V * 64);
   float st[2][16];
@@ -652,9 +673,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     bf16x8 dzp[2];
     if constexpr (STAGE == 6) {
       const f32x16 uacc = load_u(U, ok, p.vpj, h);
-      const float4 dcv = as_f4(ld128(DC, KEYS ? (ok ? view * 64u + 32u * h : OOB) : (ok && h == 0 ? view * 16u : OOB)));
-      u32x4 dk2 = {0u, 0u, 0u, 0u};
-      if (KEYS) dk2 = ld128(DC, ok ? view * 64u + 32u * h + 16u : OOB);
+      const float4 dcv = as_f4(ld128(DC, ok && (KEYS || h == 0) ? view * 16u : OOB));
       // forward up to a5 (layers 1, 2 folded, layer 5 plain); z5 stays for the statistics of layer 5
       bf16x8 a5[2];
       f32x16 z5;
@@ -675,8 +694,9 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         // block at a time: t6, then the raw z6 for the BatchNorm backward
         f32x16 dy6;
         if constexpr (KEYS) {
-          const bf16x8 dkp[2] = {__builtin_bit_cast(bf16x8, dcv), __builtin_bit_cast(bf16x8, dk2)};
-          dy6 = mm32_lds(s_ops, L6_WST, lane, dkp, zero);       // da6 = W_k^T dK (the stored bf16 row is the B operand)
+          bf16x8 dkp[2];
+          dkeys_operand(dcv, QP, ok, p.vpj, h, G, qscale, dkp);
+          dy6 = mm32_lds(s_ops, L6_WST, lane, dkp, zero);       // da6 = W_k^T dK
         } else {
           dy6 = score_bwd<L6_WST>(s_ops, lane, dc4, h);
         }
@@ -1074,22 +1094,35 @@ int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const f
                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                           const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
-  if (n_views < 0 || n_points < 0 || G < 1 || (G > 4 && G != D)) return DVA_ERR_INVALID;
+  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !grad_scores ||
       !stats6 || !dWs || !dbs)
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  if (G == D) {      // key layer: grad_scores = bf16 [V][32] rows in accumulator order, dWs [32][32], dbs [32]
-    if (n_views * 64 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((score_stats_kernel<true>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
-                       view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores,
-                       stats6, dWs, dbs, (int)G, n_views, n_points);
-  } else {
-    hipLaunchKernelGGL((score_stats_kernel<false>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
-                       view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores,
-                       stats6, dWs, dbs, (int)G, n_views, n_points);
-  }
+  hipLaunchKernelGGL((score_stats_kernel<false>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
+                     view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores,
+                     stats6, dWs, dbs, (int)G, n_views, n_points, (const float*)nullptr, 0.f);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// key layer of QKVBimodalCSRPool as the chain's last layer: grad_compat fp32 [V][4] (G = 1, 2, 4 query-key groups used),
+// queries fp32 [N][32] in position order, scale = 1 / sqrt(nc_qk) or 1; dWk [32][32], dbk [32]
+int dva_chain_score_stats_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                               const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                               const float* bn5, const float* bn6, const float* grad_compat, const float* queries,
+                               double* stats6, float* dWk, float* dbk, int32_t G, float scale, int64_t n_views,
+                               int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0 || (G != 1 && G != 2 && G != 4)) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !grad_compat ||
+      !queries || !stats6 || !dWk || !dbk || ((uintptr_t)queries & 15) || ((uintptr_t)grad_compat & 15))
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((score_stats_kernel<true>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
+                     view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_compat,
+                     stats6, dWk, dbk, (int)G, n_views, n_points, queries, scale);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
@@ -1100,7 +1133,7 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
                         const float* sm6, const float* grad_scores, const int32_t* arg, const float* dpooled,
                         const void* da_in, void* da_out, float* dW, float* du, float* P,
                         double* stats, int32_t G, int64_t n_views, int64_t n_points, void* stream) {
-  if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || (G > 4 && G != D)) return DVA_ERR_INVALID;
+  if (n_views < 0 || (stage != 6 && stage != 5 && stage != 2) || G < 1 || G > 4) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !dW || (stage != 2 && !stats))
     return DVA_ERR_INVALID;
@@ -1115,17 +1148,34 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
   hipLaunchKernelGGL((layer_bwd_kernel<ST_, BPC_>), dim3(chain_grid(BPC_)), block, 0, s, x_map, view_point, u,  \
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6,          \
                      grad_scores, arg, dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, \
-                     n_views, n_points)
+                     n_views, n_points, (const float*)nullptr, 0.f)
   static const int occ5 = tune_int("DVA_STAGE5_OCC", 3);
-  if (stage == 6 && G == D)       // key layer: grad_scores = bf16 [V][32] rows
-    hipLaunchKernelGGL((layer_bwd_kernel<6, 3, true>), dim3(chain_grid(3)), block, 0, s, x_map, view_point, u,
-                       (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, sm2, sm5, sm6, grad_scores, arg,
-                       dpooled, (const bf16_t*)da_in, (bf16_t*)da_out, dW, du, P, stats, G, n_views, n_points);
-  else if (stage == 6) DVA_LAYER_BWD(6, 3);
+  if (stage == 6) DVA_LAYER_BWD(6, 3);
   else if (stage == 5 && occ5 == 2) DVA_LAYER_BWD(5, 2);
   else if (stage == 5) DVA_LAYER_BWD(5, 3);
   else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// stage 6 of the chain backward below the key layer (see dva_chain_score_stats_keys): dy5 rows out, dW6, statistics of layer 5
+int dva_chain_bwd_layer6_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                              const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                              const float* bn5, const float* bn6, const float* sm6, const float* grad_compat,
+                              const float* queries, void* da_out, float* dW, double* stats, int32_t G, float scale,
+                              int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0 || (G != 1 && G != 2 && G != 4)) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !sm6 || !grad_compat ||
+      !queries || !da_out || !dW || !stats || ((uintptr_t)queries & 15) || ((uintptr_t)grad_compat & 15))
+    return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((layer_bwd_kernel<6, 3, true>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
+                     view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6,
+                     (const float*)nullptr, (const float*)nullptr, sm6, grad_compat, (const int32_t*)nullptr,
+                     (const float*)nullptr, (const bf16_t*)nullptr, (bf16_t*)da_out, dW, (float*)nullptr,
+                     (float*)nullptr, stats, (int)G, n_views, n_points, queries, scale);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

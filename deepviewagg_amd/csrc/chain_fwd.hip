@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256, 3) void keys_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    const float* __restrict__ bn6, const float* __restrict__ bk, bf16_t* __restrict__ keys, int64_t V, int64_t N) {
+    const float* __restrict__ bn6, const float* __restrict__ bk, bf16_t* __restrict__ keys, int64_t V, int64_t N,
+    const float* __restrict__ qp, float* __restrict__ compat, int G, float qscale) {
   __shared__ __attribute__((aligned(16))) float s_tab[4][2 * D];      // G | B rows only
   __shared__ __attribute__((aligned(16))) uint4 s_ops[OP_W6T * 64];   // forward operands only
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -504,7 +505,9 @@ __global__ __launch_bounds__(256, 3) void keys_kernel(
   fold_ops(s_ops, OP_W6, ops, OP_W6, 2, bn6);
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128), KO = make_rsrc(keys, (uint64_t)V * 64);
+                               U = make_rsrc(u, (uint64_t)N * 128), KO = make_rsrc(keys, (uint64_t)V * 64),
+                               QP = make_rsrc(qp, qp ? (uint64_t)N * 128 : 0),
+                               CO = make_rsrc(compat, compat ? (uint64_t)V * 16 : 0);
   f32x16 kb;            // the bias of this lane's 16 key channels
 #pragma unroll
   for (int r = 0; r < 16; ++r) kb[r] = bk[chan(r, h)];
@@ -547,8 +550,37 @@ __global__ __launch_bounds__(256, 3) void keys_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = z[r];
     const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 64u + 32u * h : OOB;
-    st128(KO, off, __builtin_bit_cast(u32x4, pack8(&t[0])));
-    st128(KO, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, pack8(&t[8])));
+    const bf16x8 k0 = pack8(&t[0]), k1 = pack8(&t[8]);
+    st128(KO, off, __builtin_bit_cast(u32x4, k0));
+    st128(KO, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, k1));
+    if (qp) {
+      // compatibilities (round 4: no second pass over the key rows): the lane's 16 positions are four quads of one group
+      // each (group of position 16 h + r = (r >> 2) G / 4); products of the ROUNDED key (what the backward reads back)
+      // with the point's query row, the two half-waves added, [V][4] fp32 out (unused groups 0)
+      float ka[8], kc[8], kk[16], s4[4];
+      unpack8(k0, ka);
+      unpack8(k1, kc);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { kk[r] = ka[r]; kk[8 + r] = kc[r]; }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const float4 q = as_f4(ld128(QP, ok ? (uint32_t)p.vpj * 128u + 64u * h + 16u * qq : OOB));
+        s4[qq] = __builtin_fmaf(kk[4 * qq + 3], q.w, __builtin_fmaf(kk[4 * qq + 2], q.z,
+                 __builtin_fmaf(kk[4 * qq + 1], q.y, kk[4 * qq] * q.x)));
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        uint32_t a_ = __float_as_uint(s4[qq]), b_ = a_;
+        swap_halves(a_, b_);                       // the other half-wave's share of the same view
+        s4[qq] += __uint_as_float(h ? a_ : b_);
+      }
+      float4 c;
+      if (G == 4) c = make_float4(s4[0], s4[1], s4[2], s4[3]);
+      else if (G == 2) c = make_float4(s4[0] + s4[1], s4[2] + s4[3], 0.f, 0.f);
+      else c = make_float4((s4[0] + s4[1]) + (s4[2] + s4[3]), 0.f, 0.f, 0.f);
+      c.x *= qscale; c.y *= qscale; c.z *= qscale; c.w *= qscale;
+      st128(CO, ok && h == 0 ? (uint32_t)(p.ti.v0 + j) * 16u : OOB, as_u4(c.x, c.y, c.z, c.w));
+    }
   });
 }
 
@@ -1083,9 +1115,10 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
   return DVA_OK;
 }
 
-int dva_chain_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
-                   const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
-                   const float* bn6, const float* key_bias, void* keys, int64_t n_views, int64_t n_points, void* stream) {
+static int chain_keys_impl(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                           const float* bn6, const float* key_bias, void* keys, const float* queries, float* compat,
+                           int32_t G, float scale, int64_t n_views, int64_t n_points, void* stream) {
   if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
   if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !key_bias || !keys)
@@ -1093,9 +1126,27 @@ int dva_chain_keys(const float* x_map, const int32_t* view_point, const float* u
   if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(keys_kernel, dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, key_bias, (bf16_t*)keys, n_views,
-                     n_points);
+                     n_points, queries, compat, (int)G, scale);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
+}
+
+int dva_chain_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                   const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                   const float* bn6, const float* key_bias, void* keys, int64_t n_views, int64_t n_points, void* stream) {
+  return chain_keys_impl(x_map, view_point, u, tiles, n_tiles, ops, bn1, bn2, bn5, bn6, key_bias, keys, nullptr, nullptr, 1,
+                         0.f, n_views, n_points, stream);
+}
+
+// keys + compatibilities in one pass: queries fp32 [N][32] in position order, compat fp32 [V][4] (G = 1, 2, 4 groups used)
+int dva_chain_keys_compat(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                          const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                          const float* bn6, const float* key_bias, void* keys, const float* queries, float* compat,
+                          int32_t G, float scale, int64_t n_views, int64_t n_points, void* stream) {
+  if (G != 1 && G != 2 && G != 4) return DVA_ERR_INVALID;
+  if (n_views > 0 && (!queries || !compat || ((uintptr_t)queries & 15) || ((uintptr_t)compat & 15))) return DVA_ERR_INVALID;
+  return chain_keys_impl(x_map, view_point, u, tiles, n_tiles, ops, bn1, bn2, bn5, bn6, key_bias, keys, queries, compat, G,
+                         scale, n_views, n_points, stream);
 }
 
 int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,

@@ -8,7 +8,7 @@
 // dva_chain_score_stats / dva_chain_bwd_layer(6) (G = 32).  The group of position i is chan(i & 15, i >> 4) / nc_qk
 // (G nc_qk = 32).  Q' fp32 [N][32] = the queries in the same position order (host: Q[:, channel_of_position]).
 //   dva_qkv_compat      compat[v][g] = scale sum_{i in g} K'[v][i] Q'[p(v)][i]
-//   dva_qkv_compat_bwd  dK'[v][i] = scale dcompat[v][g(i)] Q'[p][i] (bf16 row, handed to the chain backward);
+//   dva_qkv_compat_bwd  dK'[v][i] = scale dcompat[v][g(i)] Q'[p][i] (bf16 row; optional: the chain backward builds it itself);
 //                       dQ'[p][i] = scale sum_{v in p} dcompat[v][g(i)] K'[v][i]
 #include "dva_common.h"
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void dkeys_kernel(const float* __restrict__ dc
 // one half-wave per point: lane i <-> position i, loop over the views of the point
 __global__ __launch_bounds__(256) void dquery_kernel(const float* __restrict__ dcompat, const bf16_t* __restrict__ keys,
                                                      const int64_t* __restrict__ ptr, float* __restrict__ dQp, int64_t N,
-                                                     int G, float scale) {
+                                                     int G, float scale, int ldc) {
   const int i = threadIdx.x & 31;
   const int g = chan_of(i) / (32 / G);
   const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5, n_hw = ((int64_t)gridDim.x * blockDim.x) >> 5;
@@ -105,12 +105,12 @@ __global__ __launch_bounds__(256) void dquery_kernel(const float* __restrict__ d
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         k[u] = bf2f(keys[(v + u) * 32 + i]);
-        d[u] = dcompat[(v + u) * G + g];
+        d[u] = dcompat[(v + u) * ldc + g];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = fmaf(d[u], k[u], acc);
     }
-    for (; v < v1; ++v) acc = fmaf(dcompat[v * G + g], bf2f(keys[v * 32 + i]), acc);
+    for (; v < v1; ++v) acc = fmaf(dcompat[v * ldc + g], bf2f(keys[v * 32 + i]), acc);
     dQp[p * 32 + i] = acc * scale;
   }
 }
@@ -142,14 +142,29 @@ int dva_qkv_compat_bwd(const float* grad_compat, const void* keys, const float* 
   if (!ptr || !grad_queries) return DVA_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   if (n_views > 0) {
-    if (!grad_compat || !keys || !queries || !view_point || !grad_keys || ((uintptr_t)grad_keys & 15) ||
-        ((uintptr_t)queries & 15))
-      return DVA_ERR_INVALID;
-    hipLaunchKernelGGL(qkv::dkeys_kernel, dim3(qkv::grid_for(n_views)), dim3(256), 0, s, grad_compat, queries, view_point,
-                       (bf16_t*)grad_keys, n_views, (int)G, scale);
+    if (!grad_compat || !keys) return DVA_ERR_INVALID;
+    // grad_keys == NULL (round 4, the chain path): the chain backward builds dK' in registers from grad_compat and the
+    // query rows (dva_chain_score_stats_keys / dva_chain_bwd_layer6_keys); only dQ' is produced here
+    if (grad_keys) {
+      if (!queries || !view_point || ((uintptr_t)grad_keys & 15) || ((uintptr_t)queries & 15)) return DVA_ERR_INVALID;
+      hipLaunchKernelGGL(qkv::dkeys_kernel, dim3(qkv::grid_for(n_views)), dim3(256), 0, s, grad_compat, queries, view_point,
+                         (bf16_t*)grad_keys, n_views, (int)G, scale);
+    }
   }
   hipLaunchKernelGGL(qkv::dquery_kernel, dim3(qkv::grid_for(n_points * 32)), dim3(256), 0, s, grad_compat, (const bf16_t*)keys,
-                     ptr, grad_queries, n_points, (int)G, scale);
+                     ptr, grad_queries, n_points, (int)G, scale, (int)G);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// dQ' alone, grad_compat with a leading dimension (the chain path's [V][4] layout: ld = 4)
+int dva_qkv_dquery(const float* grad_compat, int32_t ld, const void* keys, const int64_t* ptr, float* grad_queries,
+                   int64_t n_points, int64_t n_views, int32_t G, float scale, void* stream) {
+  if (n_views < 0 || n_points < 0 || (G != 1 && G != 2 && G != 4) || ld < G) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  if (!ptr || !grad_queries || (n_views > 0 && (!grad_compat || !keys))) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(qkv::dquery_kernel, dim3(qkv::grid_for(n_points * 32)), dim3(256), 0, (hipStream_t)stream, grad_compat,
+                     (const bf16_t*)keys, ptr, grad_queries, n_points, (int)G, scale, (int)ld);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

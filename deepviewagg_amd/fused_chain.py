@@ -329,47 +329,61 @@ class _KeyAdapter:
         self.E_map, self.E_score, self.G = module.E_map, module.K, None
 
 
-class _ChainKeys(torch.autograd.Function):
-    """keys' bf16 [V, 32] (position order) = K(E_map(x_map)); params in fused_chain.chain_params(adapter) order."""
+class _ChainCompat(torch.autograd.Function):
+    """compatibilities fp32 [V, 4] (the first ``groups`` columns used) = scale * group sums of K(E_map(x_map)) * Q'[point]:
+    the key layer as one more layer of the recompute chain, the products with the point's query row in the same kernel
+    (dva_chain_keys_compat); the bf16 key rows [V, 32] (position order) stay for dQ'.  ``Qp`` fp32 [N, 32] = the queries in
+    position order; params in fused_chain.chain_params(adapter) order."""
 
     @staticmethod
-    def forward(ctx, x_map, csr_idx, adapter, *params):
+    def forward(ctx, x_map, csr_idx, Qp, adapter, groups, scale, *params):
         lib = _lib.load()
-        require_device(x_map, csr_idx)
+        require_device(x_map, csr_idx, Qp)
         x_map = x_map.contiguous()
+        Qp = Qp.float().contiguous()
         dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
         st = stream_of(x_map)
         S = chain_prologue(adapter, x_map, csr_idx)
         keys = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
-        with ops._timed("chain_keys", V * (32 + 4 + 64) + N * 128):
-            check(lib.dva_chain_keys(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
-                                     ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), ptr(keys), V, N, st),
-                  "dva_chain_keys")
+        compat = torch.empty((V, 4), dtype=torch.float32, device=dev)
+        with ops._timed("chain_keys", V * (32 + 4 + 64 + 16) + N * 256):
+            check(lib.dva_chain_keys_compat(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
+                                            ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), ptr(keys), ptr(Qp),
+                                            ptr(compat), int(groups), float(scale), V, N, st), "dva_chain_keys_compat")
         ctx.save_for_backward(x_map, csr_idx, S.vp, S.tiles, S.n_tiles, S.wops, S.t_add, S.zstar, S.arg, S.mom, S.bn1,
-                              S.bn2, S.bn5, S.bn6, S.W1)
+                              S.bn2, S.bn5, S.bn6, S.W1, keys, Qp)
         ctx.adapter, ctx.set_saved, ctx.training = adapter, S.set_saved, S.training
-        ctx.mark_non_differentiable(S.vp)
-        return keys, S.vp
+        ctx.meta = (int(groups), float(scale))
+        return compat
 
     @staticmethod
-    def backward(ctx, dkeys, _dvp):
+    def backward(ctx, dcompat):
         from types import SimpleNamespace
         from .fused_chain_bwd import Arena, chain_epilogue
         lib = _lib.load()
         if ctx.set_saved is None:
             raise RuntimeError("the recompute chain's backward ran twice on the same graph (retain_graph is not "
                                "supported on this path)")
-        x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, W1 = ctx.saved_tensors
+        (x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, W1, keys,
+         Qp) = ctx.saved_tensors
+        groups, scale = ctx.meta
+        V, N = x_map.shape[0], csr_idx.shape[0] - 1
+        dcompat = dcompat.float().contiguous()
+        dQ = torch.empty((N, D), dtype=torch.float32, device=x_map.device)
+        with ops._timed("qkv_dquery", V * (64 + 16) + N * 136):
+            check(lib.dva_qkv_dquery(ptr(dcompat), 4, ptr(keys), ptr(csr_idx), ptr(dQ), N, V, groups, scale,
+                                     stream_of(x_map)), "dva_qkv_dquery")
         S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
                             bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=D, training=ctx.training)
-        dkeys = dkeys.contiguous().to(torch.bfloat16)
-        grads = chain_epilogue(lib, Arena(x_map.device), S, ctx.adapter, x_map, csr_idx, dkeys, None, ctx.set_saved)
+        grads = chain_epilogue(lib, Arena(x_map.device), S, ctx.adapter, x_map, csr_idx, dcompat, None, ctx.set_saved,
+                               keys=(Qp, groups, scale))
         ctx.set_saved = None
-        return (None, None, None) + tuple(grads)
+        return (None, None, dQ if ctx.needs_input_grad[2] else None, None, None, None) + tuple(grads)
 
 
 class _QKCompat(torch.autograd.Function):
-    """compat [V, G] from key rows (position order) and per-point queries (position order)."""
+    """compat [V, G] from key rows (position order) and per-point queries (position order): the stand-alone kernels of
+    csrc/qkv.hip (the chain path computes the compatibilities inside dva_chain_keys_compat; kept for A/B and tests)."""
 
     @staticmethod
     def forward(ctx, keys, Qp, csr_idx, vp, G, scale):
@@ -406,8 +420,9 @@ def qkv_compatibilities(module, x_main, x_map, csr_idx):
     csr_idx = ops._check_ptr(csr_idx)
     adapter = _KeyAdapter(module)
     kappa = key_position_order(x_map.device)
-    keys, vp = _ChainKeys.apply(x_map, csr_idx, adapter, *chain_params(adapter))
     # the point's queries in the key rows' position order: the permutation goes onto the [32, 32] weight, not onto [N, 32]
     Qp = ops.tall_linear(x_main, module.Q.weight[kappa], module.Q.bias[kappa]).float()
     scale = 1.0 / math.sqrt(module.nc_qk) if module.dim_scaling else 1.0
-    return _QKCompat.apply(keys, Qp, csr_idx, vp.detach(), module.num_groups, scale)
+    G = module.num_groups
+    compat = _ChainCompat.apply(x_map, csr_idx, Qp, adapter, G, scale, *chain_params(adapter))
+    return compat if G == 4 else compat[:, :G]

@@ -37,11 +37,13 @@ def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=Tru
     return sm, dg, db
 
 
-def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
+def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, keys=None):
     """Everything of a chain backward behind the attention backward (which is specific to how the values are
     produced): score layer + BatchNorm-6 statistics, the three layer passes, the per-point set branch, layer 1.
     ``S``: namespace with vp, tiles, n_tiles, wops, t_add, zstar, arg, mom, bn1, bn2, bn5, bn6, W1, G, training.
     ``dc`` fp32 [V, 4] score gradients (consumed), ``gwb`` fp32 [2 G] gate gradients or None.
+    ``keys`` = (Qp fp32 [N, 32], groups, scale): the last layer is the KEY layer of a QKVBimodalCSRPool (S.G = 32) and
+    ``dc`` the gradient of the compatibilities [V, 4]; the passes build dK' = scale dc[g] Q'[point] in registers.
     Returns the gradients in the order of fused_chain.chain_params(module)."""
     from .fused_chain import _set_branch_backward
     e_map, gate = module.E_map, module.G
@@ -64,17 +66,30 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved):
     # ---- score layer: dWs, dbs, and the statistics of the BatchNorm-6 backward (one chain evaluation)
     s6 = zstats()
     dWs, dbs = arena.take(G, D), arena.take(G)
-    with ops._timed("chain_score_stats", V * (32 + 4 + 16) + N * 128):
-        check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                        ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
-                                        G, V, N, st), "dva_chain_score_stats")
+    with ops._timed("chain_score_stats", V * (32 + 4 + 16) + N * (128 if keys is None else 256)):
+        if keys is None:
+            check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                            ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
+                                            G, V, N, st), "dva_chain_score_stats")
+        else:
+            Qp, qk_groups, qk_scale = keys
+            check(lib.dva_chain_score_stats_keys(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                                 ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(Qp), ptr(s6),
+                                                 ptr(dWs), ptr(dbs), qk_groups, qk_scale, V, N, st),
+                  "dva_chain_score_stats_keys")
 
     def layer(stage, sm2, sm5, sm6, arg_, dpooled_, da_in, da_out, dW, du, P, stats, name, nbytes):
         with ops._timed(name, nbytes):
+            if keys is not None and stage == 6:
+                check(lib.dva_chain_bwd_layer6_keys(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                                    ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm6), ptr(dc), ptr(keys[0]),
+                                                    ptr(da_out), ptr(dW), ptr(stats), keys[1], keys[2], V, N, st),
+                      "dva_chain_bwd_layer6_keys")
+                return
             check(lib.dva_chain_bwd_layer(stage, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                           ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm2), ptr(sm5), ptr(sm6),
                                           ptr(dc), ptr(arg_), ptr(dpooled_), ptr(da_in), ptr(da_out), ptr(dW),
-                                          ptr(du), ptr(P), ptr(stats), G, V, N, st),
+                                          ptr(du), ptr(P), ptr(stats), min(G, 4), V, N, st),
                   "dva_chain_bwd_layer")
 
     # per view: x_map 32 + view->point 4 (+ score gradients 16) + the 64-byte gradient row handed between the passes

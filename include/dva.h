@@ -380,8 +380,8 @@ int dva_scale_f64(const double* in, double scale, float* out, int32_t n, void* s
  * blocks + an fp32 copy of the forward ones, from which the kernels build BatchNorm-folded operands
  * bf16(0.6 gamma invstd W) for the layers whose raw output a pass does not need).  W1 [32][8], W2 [32][32],
  * W5 [32][ld5] (the first 32 columns: the per-view half of the concatenation layer), W6 [32][32], Ws [G][32], G <= 4 -- or
- * G = 32: the last layer is the KEY layer of QKVBimodalCSRPool (dva_chain_keys; its gradient enters dva_chain_score_stats /
- * dva_chain_bwd_layer(6) as a bf16 [V][32] row instead of 4 scores). */
+ * G = 32: the last layer is the KEY layer of QKVBimodalCSRPool (dva_chain_keys / dva_chain_keys_compat; its backward runs
+ * through dva_chain_score_stats_keys / dva_chain_bwd_layer6_keys). */
 #define DVA_CHAIN_OPS_BYTES (18 * 64 * 16 + 7 * 64 * 32)
 int dva_chain_prep(const float* W1, const float* W2, const float* W5, int32_t ld5, const float* W6,
                    const float* Ws, int32_t G, void* ops, void* stream);
@@ -434,19 +434,29 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
 /* Key layer of QKVBimodalCSRPool on the recompute chain (round 4; reference modules/multimodal/pooling.py:454-547:
  * keys = K(E_map(x_map))): ops prepared by dva_chain_prep with Ws = K.weight [32][32], G = 32.  keys bf16 [V][32] in
  * ACCUMULATOR order: position 16 h + r holds key channel (r & 3) + 8 (r >> 2) + 4 h (the layout of the rows the chain's
- * backward passes hand to each other).  The gradient of the keys goes back in the same layout as the grad_scores argument of
- * dva_chain_score_stats (dWs [32][32], dbs [32]) and dva_chain_bwd_layer(stage 6) with G = 32. */
+ * backward passes hand to each other).
+ * dva_chain_keys_compat: the same pass also writes the compatibilities (pooling.py:520-531) compat fp32 [V][4] =
+ * scale * sum over the 32 / G key channels of group g of the (bf16-rounded) key * queries[point(v)][.] -- queries fp32 [N][32]
+ * in the keys' position order, G in {1, 2, 4} query-key groups (columns >= G are written as 0), 16-byte aligned. */
 int dva_chain_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
                    const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
                    const float* bn6, const float* key_bias, void* keys, int64_t n_views, int64_t n_points, void* stream);
+int dva_chain_keys_compat(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                          const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2, const float* bn5,
+                          const float* bn6, const float* key_bias, void* keys, const float* queries, float* compat,
+                          int32_t G, float scale, int64_t n_views, int64_t n_points, void* stream);
 /* compat fp32 [V][G] = scale * sum over the nc_qk = 32 / G key channels of group g of keys[v] * queries[point(v)]
  * (pooling.py:520-531), keys as dva_chain_keys writes them, queries fp32 [N][32] in the same position order; G in {1, 2, 4}.
- * _bwd: grad_keys bf16 [V][32] (position order, for the chain backward), grad_queries fp32 [N][32] (written). */
+ * _bwd: grad_keys bf16 [V][32] (position order; NULL: skipped -- the chain backward builds it in registers),
+ * grad_queries fp32 [N][32] (written).  dva_qkv_dquery: grad_queries alone, grad_compat with leading dimension ld >= G
+ * (the [V][4] layout of dva_chain_keys_compat / dva_chain_attn_bwd: ld = 4). */
 int dva_qkv_compat(const void* keys, const float* queries, const int32_t* view_point, float* compat, int64_t n_views,
                    int32_t G, float scale, void* stream);
 int dva_qkv_compat_bwd(const float* grad_compat, const void* keys, const float* queries, const int32_t* view_point,
                        const int64_t* ptr, void* grad_keys, float* grad_queries, int64_t n_points, int64_t n_views,
                        int32_t G, float scale, void* stream);
+int dva_qkv_dquery(const float* grad_compat, int32_t ld, const void* keys, const int64_t* ptr, float* grad_queries,
+                   int64_t n_points, int64_t n_views, int32_t G, float scale, void* stream);
 /* out bf16 [N][C] (caller-zeroed) = gate * sum_v softmax_v(scores) * rows[row_idx[v]]:
  * x_map + rows in -> pooled features out.  rows bf16 [n_rows][C], C in {32, 64, 128, 256, 512},
  * G in {1, 2, 4} with (C / G) % 8 == 0; gate_w / gate_b fp32 [G] nullable together.
@@ -589,6 +599,21 @@ int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const f
                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                           const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream);
+/* The same pass below the KEY layer of QKVBimodalCSRPool (ops prepared with G = 32): the gradient of a view's key row is
+ * built in registers, dK'[v][i] = scale grad_compat[v][g(i)] queries[point(v)][i] (grad_compat fp32 [V][4], queries fp32
+ * [N][32] in position order, G in {1, 2, 4} query-key groups); dWk fp32 [32][32] / dbk fp32 [32] (caller-zeroed) += the
+ * gradient of the key layer.  dva_chain_bwd_layer6_keys: stage 6 of dva_chain_bwd_layer below that layer
+ * (da_out = dy5 bf16 [V][32], dW = dW6, stats += S of layer 5). */
+int dva_chain_score_stats_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                               const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                               const float* bn5, const float* bn6, const float* grad_compat, const float* queries,
+                               double* stats6, float* dWk, float* dbk, int32_t G, float scale, int64_t n_views,
+                               int64_t n_points, void* stream);
+int dva_chain_bwd_layer6_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                              const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                              const float* bn5, const float* bn6, const float* sm6, const float* grad_compat,
+                              const float* queries, void* da_out, float* dW, double* stats, int32_t G, float scale,
+                              int64_t n_views, int64_t n_points, void* stream);
 /* One backward pass of the chain between two BatchNorm-backward barriers ("sm" = fp32 [2][32] = S1/M | S2/M of
  * the pass's own layer, zeros with running statistics; dW / P / stats caller-zeroed, accumulated with
  * atomics).  Each pass re-evaluates the chain from x_map up to its own layer; the gradient w.r.t. the BatchNorm

@@ -162,3 +162,12 @@ def test_qkv_compat_kernels_against_torch():
         inv = torch.argsort(kappa)
         assert rel(dk.float()[:, inv], dk_r) < 6e-3            # bf16 rows
         torch.testing.assert_close(dq, dq_r, rtol=1e-4, atol=1e-4)
+        # dQ' alone from the padded [V, 4] gradient layout of the chain path (dva_qkv_dquery, ld = 4)
+        from deepviewagg_amd import _lib
+        from deepviewagg_amd._lib import check, ptr, stream_of
+        w4 = torch.zeros((V, 4), device=DEV)
+        w4[:, :G] = w
+        dq4 = torch.empty((N, 32), device=DEV)
+        check(_lib.load().dva_qkv_dquery(ptr(w4), 4, ptr(keys_p.detach()), ptr(csr), ptr(dq4), N, V, G, scale,
+                                         stream_of(w4)), "dva_qkv_dquery")
+        torch.testing.assert_close(dq4[:, inv], dq_r, rtol=1e-4, atol=1e-4)
