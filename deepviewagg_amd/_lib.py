@@ -125,6 +125,8 @@ SIGNATURES = {
     "dva_chain_attn_fwd": (ctypes.c_int, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd_f32": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "dva_gather_segment_max_fwd": (ctypes.c_int, [_vp] * 5 + [_i64, _i64, _i64, _i32, _i32, _vp]),
+    "dva_gather_segment_max_bwd": (ctypes.c_int, [_vp] * 8 + [_i64, _i64, _i64, _i32, _i32, _vp]),
     "dva_chain_keys": (ctypes.c_int, [_vp] * 12 + [_i64, _i64, _vp]),
     "dva_chain_keys_compat": (ctypes.c_int, [_vp] * 14 + [_i32, _f32, _i64, _i64, _vp]),
     "dva_qkv_dquery": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),

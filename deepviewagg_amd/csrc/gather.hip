@@ -346,6 +346,189 @@ __global__ __launch_bounds__(256) void anchor_fixup_kernel(const T* __restrict__
   }
 }
 
+// ---- nearest gather fused with the atomic max pool of a NON-exact mapping (several pixels per view) --------------------
+// Reference: x_mod = features[idx] ([P, C], core/multimodal/image.py:1262-1287) followed by BimodalCSRPool('max') over the
+// atoms of each view (modules/multimodal/pooling.py:14-71 through modules.py:400-407): out[v][c] = max over the atoms a of
+// view v of rows[row_idx[a]][c], 0 for a view without atoms; ties -> the first atom (as dva_segment_csr_fwd).  No [P, C]
+// tensor: one thread per (view, 8- or 4-channel group) walks the view's atoms (the map rows come out of the cache
+// hierarchy), arg uint16 [V][C] = offset of the winning atom inside the view (0xffff: none) for the backward.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_segment_max_fwd_kernel(const T* __restrict__ rows,
+                                                                      const int32_t* __restrict__ row_idx,
+                                                                      const int64_t* __restrict__ atom_ptr,
+                                                                      T* __restrict__ out, uint16_t* __restrict__ arg,
+                                                                      int64_t V, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cpr = C / VEC;
+  const int64_t total = V * (int64_t)cpr;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = t / cpr;
+    const int c0 = (int)(t - v * cpr) * VEC;
+    const int64_t beg = atom_ptr[v], end = atom_ptr[v + 1];
+    float acc[VEC];
+    uint16_t best[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      acc[k] = 0.f;
+      best[k] = 0xffffu;
+    }
+    for (int64_t a = beg; a < end; ++a) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(rows + (int64_t)row_idx[a] * C + c0);
+      float f[VEC];
+      if (sizeof(T) == 4) {
+        f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+        f[2] = __uint_as_float(raw.z); f[VEC - 1] = __uint_as_float(raw.w);
+      } else {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[(2 * e) % VEC] = __uint_as_float(w[e] << 16);
+          f[(2 * e + 1) % VEC] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (a == beg || f[k] > acc[k]) {
+          acc[k] = f[k];
+          best[k] = (uint16_t)(a - beg);
+        }
+      }
+    }
+    if (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(out + v * C + c0) = make_float4(acc[0], acc[1], acc[2], acc[VEC - 1]);
+      *reinterpret_cast<uint2*>(arg + v * C + c0) =
+          make_uint2(best[0] | ((uint32_t)best[1] << 16), best[2] | ((uint32_t)best[VEC - 1] << 16));
+    } else {
+      *reinterpret_cast<uint4*>(out + v * C + c0) =
+          make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4 % VEC], acc[5 % VEC]),
+                     pack_bf16x2(acc[6 % VEC], acc[7 % VEC]));
+      *reinterpret_cast<uint4*>(arg + v * C + c0) =
+          make_uint4(best[0] | ((uint32_t)best[1] << 16), best[2] | ((uint32_t)best[3] << 16),
+                     best[4 % VEC] | ((uint32_t)best[5 % VEC] << 16), best[6 % VEC] | ((uint32_t)best[7 % VEC] << 16));
+    }
+  }
+}
+
+// backward: grad_rows[row_idx[beg + arg[v][c]]][c] += grad_out[v][c] (fp32 atomics into the map-sized gradient, caller-zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_segment_max_bwd_kernel(const T* __restrict__ gout,
+                                                                      const uint16_t* __restrict__ arg,
+                                                                      const int32_t* __restrict__ row_idx,
+                                                                      const int64_t* __restrict__ atom_ptr,
+                                                                      float* __restrict__ grows, int64_t V, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cpr = C / VEC;
+  const int64_t total = V * (int64_t)cpr;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = t / cpr;
+    const int c0 = (int)(t - v * cpr) * VEC;
+    const int64_t beg = atom_ptr[v];
+    if (atom_ptr[v + 1] <= beg) continue;
+    float g[VEC];
+    uint16_t k16[VEC];
+    const uint4 raw = *reinterpret_cast<const uint4*>(gout + v * C + c0);
+    if (sizeof(T) == 4) {
+      g[0] = __uint_as_float(raw.x); g[1] = __uint_as_float(raw.y);
+      g[2] = __uint_as_float(raw.z); g[VEC - 1] = __uint_as_float(raw.w);
+      const uint2 a2 = *reinterpret_cast<const uint2*>(arg + v * C + c0);
+      k16[0] = (uint16_t)a2.x; k16[1] = (uint16_t)(a2.x >> 16); k16[2] = (uint16_t)a2.y; k16[VEC - 1] = (uint16_t)(a2.y >> 16);
+    } else {
+      const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+      const uint4 a4 = *reinterpret_cast<const uint4*>(arg + v * C + c0);
+      const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g[(2 * e) % VEC] = __uint_as_float(w[e] << 16);
+        g[(2 * e + 1) % VEC] = __uint_as_float(w[e] & 0xffff0000u);
+        k16[(2 * e) % VEC] = (uint16_t)aw[e];
+        k16[(2 * e + 1) % VEC] = (uint16_t)(aw[e] >> 16);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (k16[k] == 0xffffu) continue;
+      const int64_t r = row_idx[beg + k16[k]];
+      atomicAdd(&grows[r * C + c0 + k], g[k]);
+    }
+  }
+}
+
+
+// the same backward WITHOUT atomics, over the row plan of the atoms (perm = atoms sorted by map row, row_ptr [R + 1]): one
+// wavefront per map row, lpr lanes per 16-byte column group, the atoms of the row spread over 64 / lpr slots; atom a of view
+// v = view_of_atom[a] contributes grad_out[v][c] to the channels whose arg offset is a - atom_ptr[v].  Deterministic;
+// per atom 16 bytes of indices + the view's arg row and gradient row (one 2 C + C s burst each).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_segment_max_plan_bwd_kernel(
+    const T* __restrict__ gout, const uint16_t* __restrict__ arg, const int64_t* __restrict__ atom_ptr,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ view_of_atom,
+    float* __restrict__ grows, int64_t R, int C, int lpr) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63;
+  const int lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
+  const int64_t col = (int64_t)lane_r * VEC;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < R; r += n_waves) {
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int i0 = beg; i0 < end; i0 += slots * U) {
+      int64_t v[U];
+      uint32_t koff[U];
+      uint4 graw[U], araw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * slots + slot;
+        const bool ok = i < end;
+        const int a = perm[ok ? i : beg];
+        v[u] = view_of_atom[a];
+        koff[u] = ok ? (uint32_t)((int64_t)a - atom_ptr[v[u]]) : 0xfffeu;      // 0xfffe never is a stored offset
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        graw[u] = *reinterpret_cast<const uint4*>(gout + v[u] * C + col);
+        if (sizeof(T) == 4) {
+          const uint2 a2 = *reinterpret_cast<const uint2*>(arg + v[u] * C + col);
+          araw[u] = make_uint4(a2.x, a2.y, 0u, 0u);
+        } else {
+          araw[u] = *reinterpret_cast<const uint4*>(arg + v[u] * C + col);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t gw[4] = {graw[u].x, graw[u].y, graw[u].z, graw[u].w};
+        const uint32_t aw[4] = {araw[u].x, araw[u].y, araw[u].z, araw[u].w};
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t ak = (aw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            acc[k % VEC] += ak == koff[u] ? __uint_as_float(gw[k]) : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[(2 * e) % VEC] += (aw[e] & 0xffffu) == koff[u] ? __uint_as_float(gw[e] << 16) : 0.f;
+            acc[(2 * e + 1) % VEC] += (aw[e] >> 16) == koff[u] ? __uint_as_float(gw[e] & 0xffff0000u) : 0.f;
+          }
+        }
+      }
+    }
+    for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
+    }
+    if (slot == 0) {
+      float* dst = grows + r * C + col;
+#pragma unroll
+      for (int k = 0; k < VEC; k += 4)
+        *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[(k + 2) % VEC], acc[(k + 3) % VEC]);
+    }
+  }
+}
+
 static inline int grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
   const int64_t cap = 256 * 32;
@@ -598,6 +781,68 @@ int dva_anchor_fixup_bn(const void* dy_a, const void* z_a, const float* bn_a, co
   hipLaunchKernelGGL((anchor_fixup_kernel<bf16_t>), dim3(grid_for(n_atoms)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dy_a, rows, weights, anchors, dummy, grad_rows, n_atoms, (int)C, (const bf16_t*)z_a,
                      bn_a, sm_a);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_segment_max_fwd(const void* rows, const int32_t* row_idx, const int64_t* atom_ptr, void* out, void* arg,
+                               int64_t n_views, int64_t n_atoms, int64_t n_rows, int32_t C, int32_t dtype, void* stream) {
+  if (n_views < 0 || n_atoms < 0 || n_rows < 0 || C < 0 || (dtype != DVA_F32 && dtype != DVA_BF16)) return DVA_ERR_INVALID;
+  if (n_views == 0 || C == 0) return DVA_OK;
+  if (!rows || !atom_ptr || !out || !arg || (n_atoms > 0 && !row_idx)) return DVA_ERR_INVALID;
+  const int vec = dtype == DVA_F32 ? 4 : 8;
+  if (C % vec || ((uintptr_t)rows & 15) || ((uintptr_t)out & 15) || ((uintptr_t)arg & 15)) return DVA_ERR_UNSUPPORTED;
+  const int64_t total = n_views * (C / vec);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((gather_segment_max_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)rows,
+                       row_idx, atom_ptr, (float*)out, (uint16_t*)arg, n_views, (int)C);
+  else
+    hipLaunchKernelGGL((gather_segment_max_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)rows,
+                       row_idx, atom_ptr, (bf16_t*)out, (uint16_t*)arg, n_views, (int)C);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_gather_segment_max_bwd(const void* grad_out, const void* arg, const int32_t* row_idx, const int64_t* atom_ptr,
+                               const int32_t* perm, const int32_t* row_ptr, const int32_t* view_of_atom, float* grad_rows,
+                               int64_t n_views, int64_t n_atoms, int64_t n_rows, int32_t C, int32_t dtype, void* stream) {
+  if (n_views < 0 || n_atoms < 0 || n_rows < 0 || C < 0 || (dtype != DVA_F32 && dtype != DVA_BF16)) return DVA_ERR_INVALID;
+  if (n_rows == 0 || C == 0) return DVA_OK;
+  if (!grad_rows || !atom_ptr) return DVA_ERR_INVALID;
+  const int vec = dtype == DVA_F32 ? 4 : 8;
+  if (C % vec || ((uintptr_t)grad_out & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)grad_rows & 15)) return DVA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (perm || row_ptr || view_of_atom) {
+    // deterministic: segmented reduction over the row plan of the atoms (grad_rows is written, not accumulated)
+    if (!row_ptr || (n_atoms > 0 && (!perm || !view_of_atom || !grad_out || !arg))) return DVA_ERR_INVALID;
+    if (n_atoms > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+    const int groups = C / vec;
+    int lpr = 1;
+    while (lpr < groups) lpr <<= 1;
+    if (lpr != groups || lpr > 64) return DVA_ERR_UNSUPPORTED;      // whole power-of-two lane teams per row
+    int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (dtype == DVA_F32)
+      hipLaunchKernelGGL((gather_segment_max_plan_bwd_kernel<float>), dim3((int)blocks), dim3(256), 0, s,
+                         (const float*)grad_out, (const uint16_t*)arg, atom_ptr, perm, row_ptr, view_of_atom, grad_rows,
+                         n_rows, (int)C, lpr);
+    else
+      hipLaunchKernelGGL((gather_segment_max_plan_bwd_kernel<bf16_t>), dim3((int)blocks), dim3(256), 0, s,
+                         (const bf16_t*)grad_out, (const uint16_t*)arg, atom_ptr, perm, row_ptr, view_of_atom, grad_rows,
+                         n_rows, (int)C, lpr);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
+  if (n_views == 0 || n_atoms == 0) return DVA_OK;
+  if (!grad_out || !arg || !row_idx) return DVA_ERR_INVALID;
+  const int64_t total = n_views * (C / vec);
+  if (dtype == DVA_F32)
+    hipLaunchKernelGGL((gather_segment_max_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)grad_out,
+                       (const uint16_t*)arg, row_idx, atom_ptr, grad_rows, n_views, (int)C);
+  else
+    hipLaunchKernelGGL((gather_segment_max_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)grad_out,
+                       (const uint16_t*)arg, row_idx, atom_ptr, grad_rows, n_views, (int)C);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

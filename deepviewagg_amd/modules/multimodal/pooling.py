@@ -208,6 +208,12 @@ class BimodalCSRPool(nn.Module, _SaveLast):
                 # not imply one view per point (csr = [0, 2, 2, 3]): always reduce there.
                 self._save(x_map, x_mod, csr_idx)
                 return x_mod
+            if (x_map is None and self._mode == 'max' and not self.save_last
+                    and csr_idx.shape[0] - 1 < x_mod.shape[0] and ops.gather_segment_max_applicable(x_mod, csr_idx)):
+                # ATOMIC max pool of a NON-exact mapping (several pixels per view, round 4): gather and max in one kernel,
+                # no [P, C] tensor; the result stays lazy at the VIEW level (identity gather over the pooled [V, C] rows) so
+                # that the view pooling keeps its fused path
+                return ops.gather_segment_max(x_mod, csr_idx)
             x_mod = x_mod.materialize()
         x_pool = segment_csr(x_mod, csr_idx, reduce=self._mode)
         self._save(x_map, x_mod, csr_idx)

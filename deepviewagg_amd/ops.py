@@ -15,6 +15,8 @@ ops; names and argument meaning follow the reference call site
 
 All ops require tensors on a HIP device and raise otherwise (no CPU fallback).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -682,6 +684,93 @@ def lazy_gather_nearest_mapping(x, images, atom_ptr, pixels, ratio, exact):
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
     row_idx, counts, plan = mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W)
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
+
+
+class _GatherSegmentMax(torch.autograd.Function):
+    """``segment_csr(rows[row_idx], atom_ptr, 'max')`` without the [P, C] tensor (csrc/gather.hip).  ``plan`` = the row plan
+    of the atoms (``row_plan(row_idx, R)[0]``) or None: built in backward."""
+
+    @staticmethod
+    def forward(ctx, rows, row_idx, atom_ptr, plan):
+        lib = _lib.load()
+        require_device(rows, row_idx, atom_ptr)
+        rows = rows.contiguous()
+        (R, C), V, P = rows.shape, atom_ptr.shape[0] - 1, row_idx.shape[0]
+        out = torch.empty((V, C), dtype=rows.dtype, device=rows.device)
+        arg = torch.empty((V, C), dtype=torch.int16, device=rows.device)
+        es = rows.element_size()
+        with _timed("gather_segment_max_fwd", P * (4 + C * es) + V * (8 + C * (es + 2))):
+            check(lib.dva_gather_segment_max_fwd(ptr(rows), ptr(row_idx), ptr(atom_ptr), ptr(out), ptr(arg), V, P, R, C,
+                                                 dtype_code(rows), stream_of(rows)), "dva_gather_segment_max_fwd")
+        ctx.save_for_backward(row_idx, atom_ptr, arg)
+        ctx.meta = (R, C, rows.dtype)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        row_idx, atom_ptr, arg = ctx.saved_tensors
+        R, C, dt = ctx.meta
+        gout = gout.contiguous().to(dt)
+        V, P = atom_ptr.shape[0] - 1, row_idx.shape[0]
+        es = gout.element_size()
+        groups = C // (16 // es)
+        if SEGMENT_MAX_ATOMICS or groups & (groups - 1) or groups > 64 or P > 0x7fffffff:
+            grows = torch.zeros((R, C), dtype=torch.float32, device=gout.device)
+            with _timed("gather_segment_max_bwd", V * (8 + C * (es + 2 + 4)) + R * C * 4):
+                check(lib.dva_gather_segment_max_bwd(ptr(gout), ptr(arg), ptr(row_idx), ptr(atom_ptr), None, None, None,
+                                                     ptr(grows), V, P, R, C, dtype_code(gout), stream_of(gout)),
+                      "dva_gather_segment_max_bwd")
+            return grows.to(dt), None, None, None
+        perm, row_ptr = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
+        voa = csr_expand(atom_ptr, P)
+        grows = torch.empty((R, C), dtype=torch.float32, device=gout.device)
+        with _timed("gather_segment_max_bwd", P * (16 + C * (es + 2)) + R * (C * 4 + 4)):
+            check(lib.dva_gather_segment_max_bwd(ptr(gout), ptr(arg), ptr(row_idx), ptr(atom_ptr), ptr(perm), ptr(row_ptr),
+                                                 ptr(voa), ptr(grows), V, P, R, C, dtype_code(gout), stream_of(gout)),
+                  "dva_gather_segment_max_bwd")
+        return grows.to(dt), None, None, None
+
+
+# A/B: fp32 atomics instead of the segmented reduction over the atoms' row plan (tests)
+SEGMENT_MAX_ATOMICS = False
+_ATOMS_OK = {}
+
+
+def _atoms_per_view_ok(atom_ptr):
+    """True when no view owns more than 65534 atoms (the uint16 arg offsets of the fused max pool); one device
+    synchronisation per mapping tensor, cached."""
+    key = (atom_ptr.data_ptr(), atom_ptr.shape[0], atom_ptr._version)
+    if key not in _ATOMS_OK:
+        if len(_ATOMS_OK) > 64:
+            _ATOMS_OK.clear()
+        n = atom_ptr.shape[0] - 1
+        _ATOMS_OK[key] = n == 0 or int((atom_ptr[1:] - atom_ptr[:-1]).max()) <= 0xfffe
+    return _ATOMS_OK[key]
+
+
+LAZY_NONEXACT = os.environ.get("DVA_LAZY_NONEXACT", "1") == "1"
+
+
+def gather_segment_max_applicable(x_mod, atom_ptr):
+    if not (LAZY_NONEXACT and isinstance(x_mod, GatheredFeatures)):
+        return False
+    C, es = x_mod.rows.shape[1], x_mod.rows.element_size()
+    return (x_mod.rows.dtype in (torch.float32, torch.bfloat16) and C % (16 // es) == 0 and C > 0
+            and x_mod.rows.is_cuda and _atoms_per_view_ok(atom_ptr))
+
+
+def gather_segment_max(x_mod, atom_ptr):
+    """Atomic max pool of a lazily gathered NON-exact mapping (several pixels per view): ``GatheredFeatures`` at the atom
+    level -> ``GatheredFeatures`` at the VIEW level whose rows are the pooled [V, C] features (identity gather, one view
+    per row), so that the view-level pooling stays on its fused path (E_mod on the [V, C] rows -- it does not commute with
+    the max --, then the recompute chain).  Reference: modules/multimodal/modules.py:400-407, pooling.py:14-71."""
+    atom_ptr = _check_ptr(atom_ptr)
+    xv = _GatherSegmentMax.apply(x_mod.rows, x_mod.row_idx.contiguous(), atom_ptr, x_mod.plan)
+    V = xv.shape[0]
+    ident = torch.arange(V + 1, dtype=torch.int32, device=xv.device)
+    return GatheredFeatures(xv, ident[:V], torch.ones(V, dtype=torch.int32, device=xv.device), True, (ident[:V], ident))
 
 
 class InterpolatedFeatures:

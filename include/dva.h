@@ -117,6 +117,21 @@ int dva_gather_nearest_bwd(const void* grad_out, const void* packed_idx, float* 
                            int64_t n_atoms, int32_t B, int32_t H, int32_t W, int32_t C,
                            int32_t dtype, void* stream);
 
+/* Nearest gather fused with the atomic MAX pool of a non-exact mapping (several pixels per view; reference
+ * core/multimodal/image.py:1262-1287 followed by BimodalCSRPool('max'), modules/multimodal/pooling.py:14-71 through
+ * modules.py:400-407): out[v][c] = max over the atoms a in [atom_ptr[v], atom_ptr[v+1]) of rows[row_idx[a]][c], 0 for a view
+ * without atoms, ties -> first atom; no [P, C] tensor.  rows fp32 / bf16 [n_rows][C] (16-byte aligned, C % 4 resp. % 8 == 0),
+ * arg uint16 [V][C] = offset of the winning atom inside its view (0xffff: none; views must own <= 65534 atoms).
+ * _bwd: grad_rows fp32 [n_rows][C] = sum of grad_out[v][c] over the (view, channel) pairs whose winning atom lies on the row.
+ * With the row plan of the atoms (perm int32 [P] = atoms sorted by map row, row_ptr int32 [n_rows + 1], as dva_row_plan gives
+ * them) and view_of_atom int32 [P]: a deterministic segmented reduction, grad_rows written (C / vec a power of two <= 64);
+ * with perm = row_ptr = view_of_atom = NULL: fp32 atomics into the caller-zeroed grad_rows (23 ms against 2 ms at
+ * V = 8.4 M, C = 64 -- kept as the A/B). */
+int dva_gather_segment_max_fwd(const void* rows, const int32_t* row_idx, const int64_t* atom_ptr, void* out, void* arg,
+                               int64_t n_views, int64_t n_atoms, int64_t n_rows, int32_t C, int32_t dtype, void* stream);
+int dva_gather_segment_max_bwd(const void* grad_out, const void* arg, const int32_t* row_idx, const int64_t* atom_ptr,
+                               const int32_t* perm, const int32_t* row_ptr, const int32_t* view_of_atom, float* grad_rows,
+                               int64_t n_views, int64_t n_atoms, int64_t n_rows, int32_t C, int32_t dtype, void* stream);
 /* Bilinear gather with the reference's border-replicate semantics (image.py:105-170):
  * q = coord * (H, W) + 0.5 in the 1-padded map; 4 taps floor(q), floor(q+1); weights |prod(q - opposite)|.
  * coords fp32 [P,2] = (y, x) in [0,1]; the image of atom p comes from packed_idx (its x,y unused). */

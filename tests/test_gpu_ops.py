@@ -218,6 +218,60 @@ def test_gather_nearest_golden(name):
         close(pooled, g["out_atomic_max"], rtol=0, atol=0)
 
 
+def test_gather_segment_max_golden():
+    """Non-exact mapping (several pixels per view): the fused gather + atomic max pool (no [P, C] tensor) against the
+    reference-run fixture, bit for bit (pure selection)."""
+    from deepviewagg_amd import ops
+    g = load_golden("gather_multipixel")
+    x = t(g["x"], DEV)
+    ptr_ = t(g["atom_pointers"], DEV)
+    packed = ops.pack_gather_index(t(g["images"], DEV), ptr_, t(g["pixels"], DEV), ratio=float(g["downscale"]))
+    lazy = ops.lazy_gather_nearest(x, packed, exact=False)
+    assert ops.gather_segment_max_applicable(lazy, ptr_)
+    pooled = ops.gather_segment_max(lazy, ptr_)
+    assert isinstance(pooled, ops.GatheredFeatures) and pooled.exact
+    assert torch.equal(pooled.materialize().cpu(), t(g["out_atomic_max"]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [8, 64, 136])
+def test_gather_segment_max_against_oracle(dtype, C):
+    """Ragged views (0 .. 11 atoms, one of 300), ties between atoms (quantised rows: the first atom wins, as
+    torch_scatter's segment_csr), forward bit-exact, backward against autograd of the oracle."""
+    from deepviewagg_amd import ops
+    from oracle import pooling_oracle as O
+    gen = torch.Generator().manual_seed(7 + C)
+    V, R = 900, 211
+    sizes = torch.randint(0, 12, (V,), generator=gen)
+    sizes[17] = 300
+    ptr_ = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    P = int(ptr_[-1])
+    rows = (torch.randn(R, C, generator=gen) * 2).round().div(2).to(dtype)          # many ties
+    row_idx = torch.randint(0, R, (P,), generator=gen, dtype=torch.int32)
+    w = torch.randn(V, C, generator=gen).to(dtype)
+    r0 = rows.float().clone().requires_grad_()
+    ref = O.segment_csr(r0[row_idx.long()], ptr_, 'max')
+    (gr0,) = torch.autograd.grad((ref * w.float()).sum(), r0)
+    grads = []
+    for atomics in (False, True):            # the deterministic plan reduction (C / vec a power of two) and the atomics A/B
+        ops.SEGMENT_MAX_ATOMICS = atomics
+        try:
+            r = rows.to(DEV).requires_grad_()
+            out = ops._GatherSegmentMax.apply(r, row_idx.to(DEV), ptr_.to(DEV), None)
+            assert torch.equal(out.float().cpu(), ref.detach())
+            (gr,) = torch.autograd.grad((out.float() * w.to(DEV).float()).sum(), r)
+        finally:
+            ops.SEGMENT_MAX_ATOMICS = False
+        torch.testing.assert_close(gr.float().cpu(), gr0, rtol=2e-2 if dtype == torch.bfloat16 else 1e-5,
+                                   atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+        grads.append(gr)
+    if C != 136:       # 17 column groups: no power-of-two lane team, both runs took the atomics
+        r = rows.to(DEV).requires_grad_()
+        out = ops._GatherSegmentMax.apply(r, row_idx.to(DEV), ptr_.to(DEV), None)
+        (gr2,) = torch.autograd.grad((out.float() * w.to(DEV).float()).sum(), r)
+        assert torch.equal(gr2, grads[0])          # the plan reduction is bit-reproducible
+
+
 def test_gather_bilinear_golden():
     from deepviewagg_amd import ops
     g = load_golden("gather")

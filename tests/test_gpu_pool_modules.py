@@ -408,6 +408,64 @@ def test_view_level_pool_with_equal_counts_is_not_the_identity():
     assert isinstance(P.BimodalCSRPool()(None, lazy, None, torch.arange(V + 1, device=DEV)), ops.GatheredFeatures)
 
 
+def test_non_exact_mapping_stays_lazy_through_the_atomic_max_pool():
+    """VERDICT r3 missing 3: a mapping with several pixels per view (exact=False) through BimodalCSRPool('max') at the atomic
+    level + GroupBimodalCSRPool at the view level: the fused gather + max pool (no [P, C] tensor, lazily gathered [V, C] rows
+    handed to the recompute chain) against the materialised route (DVA_LAZY_NONEXACT off) under autocast, and the pooled
+    rows bit-exact against segment_csr of the materialised gather."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    B, C, H, W, N = 4, 64, 16, 24, 1500
+    k = torch.randint(0, 7, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), k.cumsum(0)])
+    V = int(csr[-1])
+    atoms = torch.randint(1, 10, (V,), generator=gen)
+    atom_ptr = torch.cat([torch.zeros(1, dtype=torch.long), atoms.cumsum(0)])
+    Pn = int(atom_ptr[-1])
+    images = torch.randint(0, B, (V,), generator=gen)
+    pixels = torch.stack([torch.randint(0, W, (Pn,), generator=gen), torch.randint(0, H, (Pn,), generator=gen)], 1)
+    x0 = torch.randn(B, C, H, W, generator=gen)
+    x_map = torch.rand(V, 8, generator=gen).to(DEV)
+    wout = torch.randn(N, C, generator=gen).to(DEV)
+    torch.manual_seed(5)
+    view_pool = P.GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=4, use_mod=False, map_encoder='DeepSetFeat',
+                                      use_num=True).to(DEV).train()
+    sd = {k_: v.clone() for k_, v in view_pool.state_dict().items()}
+    atomic = P.BimodalCSRPool(mode='max')
+
+    def run(lazy_nonexact):
+        ops.LAZY_NONEXACT = lazy_nonexact
+        try:
+            view_pool.load_state_dict(sd)
+            for p_ in view_pool.parameters():
+                p_.grad = None
+            x = x0.to(DEV).to(memory_format=torch.channels_last).requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                xb = x.to(torch.bfloat16)
+                lazy = ops.lazy_gather_nearest_mapping(xb, images.to(DEV), atom_ptr.to(DEV), pixels.to(DEV).to(torch.int16),
+                                                       1.0, exact=False)
+                pooled = atomic(None, lazy, None, atom_ptr.to(DEV))
+                out = view_pool(None, pooled, x_map, csr.to(DEV))
+            (out.float() * wout).sum().backward()
+            return pooled, out.detach().float(), x.grad.detach().float(), \
+                [p.grad.detach().float().clone() for p in view_pool.parameters()]
+        finally:
+            ops.LAZY_NONEXACT = True
+    pooled_l, out_l, gx_l, gp_l = run(True)
+    pooled_m, out_m, gx_m, gp_m = run(False)
+    assert isinstance(pooled_l, ops.GatheredFeatures) and isinstance(pooled_m, torch.Tensor)
+    assert torch.equal(pooled_l.materialize().detach(), pooled_m.detach())          # the max pool itself: bit-exact
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-20))
+    assert rel(out_l, out_m) < 2e-2, rel(out_l, out_m)
+    assert rel(gx_l, gx_m) < 6e-2, rel(gx_l, gx_m)
+    # parameters: the lazy route runs the recompute chain (bf16), the materialised one the stored-activation kernels; measured
+    # against the fp32 oracle (tools/debug_nonexact.py): E_mod 3-9 e-2 on both, encoder 7-17 e-2 (chain) / 5e-3
+    for (n, _), a, b in zip(view_pool.named_parameters(), gp_l, gp_m):
+        assert torch.isfinite(a).all(), n
+        assert rel(a, b) < 2.5e-1, (n, rel(a, b))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,Ca,Cb", [(1000, 4, 64), (37, 8, 512), (5, 4, 4), (0, 4, 64)])
 def test_concatenation_fusion_kernel_equals_torch_cat(N, Ca, Cb, dtype):
