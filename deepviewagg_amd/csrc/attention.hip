@@ -1060,6 +1060,46 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
   }
 }
 
+// Sparse row plans (at most ~2 views per row: the identity gather of a view-level tensor, ops.gather_segment_max): one
+// lane team per ROW instead of one wavefront per row -- 64 / lpr rows per wavefront, no cross-slot reduction.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_grad_short_rec16_kernel(const T* __restrict__ gout,
+                                                                     const int32_t* __restrict__ perm,
+                                                                     const int32_t* __restrict__ row_ptr,
+                                                                     const uint32_t* __restrict__ rec,
+                                                                     float* __restrict__ grows, int64_t R, int C, int lpr,
+                                                                     int lpg) {
+  constexpr int VEC = Vec16<T>::N;
+  typedef typename Vec16<T>::raw raw_t;
+  const int lane = threadIdx.x & 63;
+  const int lane_r = lane & (lpr - 1), slot = lane / lpr, slots = 64 / lpr;
+  const int g_lane = lane_r / lpg;
+  const int64_t col = (int64_t)lane_r * VEC;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave * slots + slot; r < R; r += n_waves * slots) {
+    const int beg = row_ptr[r], end = row_ptr[r + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int i = beg; i < end; ++i) {
+      const int64_t v = perm ? perm[i] : i;
+      const uint32_t* rv = rec + v * 4;
+      const int64_t p = (int)rv[0];
+      const uint32_t w2 = rv[1 + (g_lane >> 1)];
+      const float sc = __uint_as_float((g_lane & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+      float f[VEC];
+      Vec16<T>::unpack(*reinterpret_cast<const raw_t*>(gout + p * C + col), f);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = fmaf(f[k], sc, acc[k]);
+    }
+    float* dst = grows + r * C + col;
+#pragma unroll
+    for (int k = 0; k < VEC; k += 4)
+      *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+  }
+}
+
 // any C / G: one thread per (row, channel)
 template <typename T>
 __global__ __launch_bounds__(256) void rows_grad_generic_kernel(
@@ -1492,6 +1532,15 @@ int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, c
   int slab = slab_env;
   if (slab <= 0 || slab >= C || (slab % 8) || !is_pow2(slab / 8) || (C % slab)) slab = C;
   const int lpr_s = slab / 8;
+  if (n_views <= 2 * n_rows && lpr < 64) {
+    // sparse plan (view-level identity gathers): a lane team per row
+    const int64_t waves = (n_rows + (64 / lpr) - 1) / (64 / lpr);
+    hipLaunchKernelGGL((rows_grad_short_rec16_kernel<bf16_t>), dim3(grid_cap((waves + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)grad_out, perm, row_ptr, (const uint32_t*)view_rec16, grad_rows,
+                       n_rows, (int)C, lpr, lpr / G);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   for (int c0 = 0; c0 < C; c0 += slab) {
     hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true>), dim3(grid_cap((n_rows + 3) / 4)),
                        dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr,
