@@ -1,6 +1,7 @@
 #!/bin/bash
 # Full evidence pass on the GPU box: GPU test suite, default bench line, rocprofv3 kernel stats, PMC traffic,
 # SQ counters, torchrun (1 rank, RCCL) run of bench.py.  Usage: tools/gpu_evidence.sh <tag>   (writes gpurun_out/<tag>/)
+exec < /dev/null
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
