@@ -129,6 +129,7 @@ SIGNATURES = {
     "dva_gather_segment_max_bwd": (ctypes.c_int, [_vp] * 8 + [_i64, _i64, _i64, _i32, _i32, _vp]),
     "dva_chain_keys": (ctypes.c_int, [_vp] * 12 + [_i64, _i64, _vp]),
     "dva_chain_keys_compat": (ctypes.c_int, [_vp] * 14 + [_i32, _f32, _i64, _i64, _vp]),
+    "dva_chain_attn_fwd_keys": (ctypes.c_int, [_vp] * 12 + [_f32] + [_vp] * 8 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_qkv_dquery": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "dva_chain_score_stats_keys": (ctypes.c_int, [_vp] * 15 + [_i32, _f32, _i64, _i64, _vp]),
     "dva_chain_bwd_layer6_keys": (ctypes.c_int, [_vp] * 16 + [_i32, _f32, _i64, _i64, _vp]),

@@ -596,7 +596,10 @@ __global__ __launch_bounds__(256, 3) void keys_kernel(
 // the slot it ends in.
 // OCC = waves per SIMD the register budget is cut for: 4 pays when nearly every tile is one point (the single-point
 // path fits 128 VGPRs); the several-points path needs the 168 of OCC = 3.
-template <int LPR, int G, int OCC>
+// KEYS (round 4, QKVBimodalCSRPool): the last layer is the KEY layer (operand OP_WS prepared with G = 32, `bs` = its bias
+// [32]); the scores are the compatibilities scale * <key, query of the point> per group (queries `qp` fp32 [N][32] in
+// position order); the bf16 key rows go to `keys_out` when a backward follows (dQ needs them).
+template <int LPR, int G, int OCC, bool KEYS = false>
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
@@ -604,7 +607,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     const float* __restrict__ bn6, const float* __restrict__ bs, const bf16_t* __restrict__ rows,
     const int32_t* __restrict__ row_idx, const int64_t* __restrict__ ptr, const float* __restrict__ gw,
     const float* __restrict__ gb, bf16_t* __restrict__ out, float* __restrict__ scores_out, int scaling, float eps,
-    int64_t V, int64_t N, int64_t R) {
+    int64_t V, int64_t N, int64_t R, const float* __restrict__ qp = nullptr, float qscale = 0.f,
+    bf16_t* __restrict__ keys_out = nullptr) {
   constexpr int C = LPR * 8, ROWS = 64 / LPR, KV = 32 / ROWS;
   constexpr int KB = KV < 8 ? KV : 8, NB = KV / KB;
   constexpr int NE = G == 1 ? 1 : 2;           // score values per lane on the softmax side
@@ -638,7 +642,14 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), RI = make_rsrc(row_idx, (uint64_t)V * 4),
                                RW = make_rsrc(rows, (uint64_t)R * C * 2), O = make_rsrc(out, (uint64_t)N * C * 2),
-                               SC = make_rsrc(scores_out, scores_out ? (uint64_t)V * 16 : 0);
+                               SC = make_rsrc(scores_out, scores_out ? (uint64_t)V * 16 : 0),
+                               QP = make_rsrc(qp, KEYS ? (uint64_t)N * 128 : 0),
+                               KO = make_rsrc(keys_out, KEYS && keys_out ? (uint64_t)V * 64 : 0);
+  f32x16 kb = {0};        // KEYS: the bias of this lane's 16 key channels
+  if constexpr (KEYS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kb[r] = bs[chan(r, h)];
+  }
   // softmax side: lane (j, h) owns the groups gl[e]
   const bool s_active = G == 4 || h == 0;
   int gl[NE];
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
   for (int e = 0; e < NE; ++e) {
     gl[e] = (G == 4 ? 2 * h : 0) + e;
     if (gl[e] >= G) gl[e] = G - 1;
-    bias[e] = bs[gl[e]];
+    bias[e] = KEYS ? 0.f : bs[gl[e]];
     gwl[e] = gw ? gw[gl[e]] : 0.f;
     gbl[e] = gw ? gb[gl[e]] : 0.f;
   }
@@ -718,8 +729,42 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     act_pack(z, s_tab[2], h, keep, a, 0, 1);
     z = mm32_lds(s_ops, OP_W6, lane, a, bias_acc(s_tab[3], 1, h));
     act_fold(z, keep, a2);
-    z = mm32_lds(s_ops, OP_WS, lane, a2, zero);
     float c[NE];
+    if constexpr (KEYS) {
+      z = mm32_lds(s_ops, OP_WS, lane, a2, kb);
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = z[r];
+      const bf16x8 k0 = pack8(&t[0]), k1 = pack8(&t[8]);
+      const uint32_t koff = ok ? (uint32_t)(p.ti.v0 + j) * 64u + 32u * h : OOB;
+      st128(KO, koff, __builtin_bit_cast(u32x4, k0));          // zero-sized buffer without a backward: dropped
+      st128(KO, ok ? koff + 16u : OOB, __builtin_bit_cast(u32x4, k1));
+      float ka[8], kc[8], s4[4];
+      unpack8(k0, ka);
+      unpack8(k1, kc);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const float4 q4 = as_f4(ld128(QP, ok ? (uint32_t)p.vpj * 128u + 64u * h + 16u * qq : OOB));
+        const float* kq = qq < 2 ? &ka[4 * qq] : &kc[4 * (qq - 2)];
+        s4[qq] = __builtin_fmaf(kq[3], q4.w, __builtin_fmaf(kq[2], q4.z, __builtin_fmaf(kq[1], q4.y, kq[0] * q4.x)));
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        uint32_t a_ = __float_as_uint(s4[qq]), b_ = a_;
+        swap_halves(a_, b_);
+        s4[qq] += __uint_as_float(h ? a_ : b_);
+      }
+      if constexpr (G == 4) {
+        c[0] = (h ? s4[2] : s4[0]) * qscale;
+        c[NE - 1] = (h ? s4[3] : s4[1]) * qscale;
+      } else if constexpr (G == 2) {
+        c[0] = (s4[0] + s4[1]) * qscale;
+        c[NE - 1] = (s4[2] + s4[3]) * qscale;
+      } else {
+        c[0] = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * qscale;
+      }
+    } else {
+    z = mm32_lds(s_ops, OP_WS, lane, a2, zero);
     if constexpr (G == 4) {
       uint32_t A0 = __float_as_uint(z[0]), A2 = __float_as_uint(z[2]);
       uint32_t A1 = __float_as_uint(z[1]), A3 = __float_as_uint(z[3]);
@@ -730,6 +775,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(
     } else {
 #pragma unroll
       for (int e = 0; e < NE; ++e) c[e] = z[e] + bias[e];
+    }
     }
     // training: the scores [V, 4] stay for the attention backward (16 bytes per view instead of a chain evaluation);
     // a null pointer makes a zero-sized buffer: the stores are dropped
@@ -1198,6 +1244,56 @@ int dva_chain_attn_fwd(const float* x_map, const int32_t* view_point, const floa
   }
 #undef DVA_ATTN_FWD
 #undef DVA_ATTN_FWD_O
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// QKVBimodalCSRPool in ONE view kernel (round 4): the fused view kernel with the KEY layer as the chain's last layer (ops
+// prepared with Ws = K.weight, G = 32; key_bias [32]) and the compatibilities scale * <key, queries[point]> per query-key group
+// as the scores (queries fp32 [N][32] in position order, 16-byte aligned; G = groups in {1, 2, 4}); keys_out (nullable;
+// training) bf16 [V][32] receives the key rows (position order) that dva_qkv_dquery reads back.
+int dva_chain_attn_fwd_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                            const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                            const float* bn5, const float* bn6, const float* key_bias, const float* queries, float scale,
+                            const void* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                            const float* gate_b, void* out, float* scores_out, void* keys_out, int64_t n_points,
+                            int64_t n_views, int64_t n_rows, int32_t C, int32_t G, int32_t scaling, float eps,
+                            void* stream) {
+  if (n_views < 0 || n_points < 0) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !key_bias || !queries ||
+      !rows || !row_idx || !ptr || !out || ((gate_w == nullptr) != (gate_b == nullptr)) || ((uintptr_t)queries & 15))
+    return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll || n_rows * C * 2 > 0xfffffff0ll ||
+      n_points * C * 2 > 0xfffffff0ll)
+    return DVA_ERR_UNSUPPORTED;
+  const dim3 grid(chain_grid(3)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DVA_ATTN_FWD_K(LPR_, G_)                                                                                \
+  hipLaunchKernelGGL((attn_fwd_kernel<LPR_, G_, 3, true>), grid, block, 0, s, x_map, view_point, u,             \
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, key_bias,              \
+                     (const bf16_t*)rows, row_idx, ptr, gate_w, gate_b, (bf16_t*)out, scores_out, scaling, eps, \
+                     n_views, n_points, n_rows, queries, scale, (bf16_t*)keys_out)
+  const int key = C * 8 + G;
+  switch (key) {
+    case 32 * 8 + 1: DVA_ATTN_FWD_K(4, 1); break;
+    case 32 * 8 + 2: DVA_ATTN_FWD_K(4, 2); break;
+    case 32 * 8 + 4: DVA_ATTN_FWD_K(4, 4); break;
+    case 64 * 8 + 1: DVA_ATTN_FWD_K(8, 1); break;
+    case 64 * 8 + 2: DVA_ATTN_FWD_K(8, 2); break;
+    case 64 * 8 + 4: DVA_ATTN_FWD_K(8, 4); break;
+    case 128 * 8 + 1: DVA_ATTN_FWD_K(16, 1); break;
+    case 128 * 8 + 2: DVA_ATTN_FWD_K(16, 2); break;
+    case 128 * 8 + 4: DVA_ATTN_FWD_K(16, 4); break;
+    case 256 * 8 + 1: DVA_ATTN_FWD_K(32, 1); break;
+    case 256 * 8 + 2: DVA_ATTN_FWD_K(32, 2); break;
+    case 256 * 8 + 4: DVA_ATTN_FWD_K(32, 4); break;
+    case 512 * 8 + 1: DVA_ATTN_FWD_K(64, 1); break;
+    case 512 * 8 + 2: DVA_ATTN_FWD_K(64, 2); break;
+    case 512 * 8 + 4: DVA_ATTN_FWD_K(64, 4); break;
+    default: return DVA_ERR_UNSUPPORTED;
+  }
+#undef DVA_ATTN_FWD_K
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

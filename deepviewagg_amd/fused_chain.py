@@ -13,6 +13,8 @@ Selected by ``pooling.GroupBimodalCSRPool`` inside ``torch.autocast(bfloat16)`` 
 when ``applicable`` holds; everything else takes the fp32 kernels of ``fused_deepset`` / ``ops``.
 The per-point set branch (``mlp_set`` on N rows) runs on the same kind of kernels (``csrc/chain_set.hip``).
 """
+import os
+
 import torch
 
 from . import _lib, ops, fused_deepset
@@ -325,8 +327,46 @@ def keys_applicable(module, x_mod, x_map, csr_idx):
 class _KeyAdapter:
     """What chain_prologue / chain_epilogue read of a pooling module, for the key layer of a QKVBimodalCSRPool."""
 
-    def __init__(self, module):
-        self.E_map, self.E_score, self.G = module.E_map, module.K, None
+    def __init__(self, module, with_gate=False):
+        self.E_map, self.E_score, self.G = module.E_map, module.K, (module.G if with_gate else None)
+
+
+class _ChainQKVPool(torch.autograd.Function):
+    """QKVBimodalCSRPool.forward (pooling.py:500-547) in ONE view kernel: DeepSetFeat + key layer on the chain, compatibilities
+    with the point's query row, softmax, gathered value rows, weighted sum, gate (dva_chain_attn_fwd_keys).  ``module`` = a
+    _KeyAdapter with the gate; ``Qp`` fp32 [N, 32] = the queries in position order; params as chain_params(adapter)."""
+
+    @staticmethod
+    def forward(ctx, rows, row_idx, plan, x_map, csr_idx, module, scaling, eps, Qp, qk, *params):
+        lib = _lib.load()
+        require_device(rows, row_idx, x_map, csr_idx, Qp)
+        rows, x_map, Qp = rows.contiguous(), x_map.contiguous(), Qp.float().contiguous()
+        dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
+        R, C = rows.shape
+        groups, scale = qk
+        st = stream_of(x_map)
+        S = chain_prologue(module, x_map, csr_idx)
+        out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
+        need_bwd = any(ctx.needs_input_grad)
+        scores = torch.empty((V, 4), dtype=torch.float32, device=dev) if need_bwd else None
+        keys = torch.empty((V, D), dtype=torch.bfloat16, device=dev) if need_bwd else None
+        with ops._timed("chain_attn_fwd", V * (C * 2 + 32 + 8 + (16 + 64 if need_bwd else 0)) + N * (C * 2 + 256 + 8)):
+            check(lib.dva_chain_attn_fwd_keys(ptr(x_map), ptr(S.vp), ptr(S.t_add), ptr(S.tiles), ptr(S.n_tiles), ptr(S.wops),
+                                              ptr(S.bn1), ptr(S.bn2), ptr(S.bn5), ptr(S.bn6), ptr(S.bs), ptr(Qp), float(scale),
+                                              ptr(rows), ptr(row_idx), ptr(csr_idx), ptr(S.gw), ptr(S.gb), ptr(out),
+                                              ptr(scores), ptr(keys), N, V, R, C, int(groups), int(scaling), float(eps), st),
+                  "dva_chain_attn_fwd_keys")
+        ctx.save_for_backward(rows, row_idx, x_map, csr_idx, S.vp, S.tiles, S.n_tiles, S.wops, S.t_add, S.zstar, S.arg,
+                              S.mom, S.bn1, S.bn2, S.bn5, S.bn6, out, scores, S.bs, S.gw, S.gb, S.W1, keys, Qp)
+        ctx.plan, ctx.module, ctx.set_saved, ctx.training = plan, module, S.set_saved, S.training
+        ctx.meta = (int(scaling), float(eps))
+        ctx.qk = (int(groups), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import fused_chain_bwd
+        return fused_chain_bwd.backward(ctx, gout)
 
 
 class _ChainCompat(torch.autograd.Function):
@@ -426,3 +466,20 @@ def qkv_compatibilities(module, x_main, x_map, csr_idx):
     G = module.num_groups
     compat = _ChainCompat.apply(x_map, csr_idx, Qp, adapter, G, scale, *chain_params(adapter))
     return compat if G == 4 else compat[:, :G]
+
+
+# DVA_QKV_ONE_KERNEL=0: keys + compatibilities in one pass, attention in the scores-in kernels (the A/B of round 4)
+QKV_ONE_KERNEL = os.environ.get("DVA_QKV_ONE_KERNEL", "1") == "1"
+
+
+def qkv_pool(module, x_main, x_mod, x_map, csr_idx):
+    """The whole QKVBimodalCSRPool.forward behind E_main / E_mod for point-wise queries and mapping-feature keys:
+    ``x_main`` = E_main(x_main) [N, nc_inner], ``x_mod`` = ops.GatheredFeatures whose rows are already E_mod(rows)."""
+    import math
+    csr_idx = ops._check_ptr(csr_idx)
+    adapter = _KeyAdapter(module, with_gate=True)
+    kappa = key_position_order(x_map.device)
+    Qp = ops.tall_linear(x_main, module.Q.weight[kappa], module.Q.bias[kappa]).float()
+    scale = 1.0 / math.sqrt(module.nc_qk) if module.dim_scaling else 1.0
+    return _ChainQKVPool.apply(x_mod.rows, x_mod.row_idx.contiguous(), x_mod.plan, x_map, csr_idx, adapter,
+                               module.group_scaling, 1e-12, Qp, (module.num_groups, scale), *chain_params(adapter))

@@ -126,7 +126,8 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
     dW1 = arena.take(D, 8)
     check(lib.dva_chain_dw1(ptr(P), ptr(S.mom), ptr(S.W1), 0, ptr(bn1), ptr(sm1), ptr(dW1), st), "dva_chain_dw1")
     if gate is not None:
-        dgw, dgb = gwb[:G].reshape(gate.weight.shape), gwb[G:].reshape(gate.bias.shape)
+        gG = G if keys is None else keys[1]        # gate entries = attention groups (the key layer has 32 outputs)
+        dgw, dgb = gwb[:gG].reshape(gate.weight.shape), gwb[gG:].reshape(gate.bias.shape)
     else:
         dgw = dgb = None
     return [dW1, g1, b1, dW2, g2, b2, dW5, g5, b5, dW6, g6, b6, dWs, dbs, dgw, dgb] + d_set
@@ -157,18 +158,20 @@ def backward(ctx, gout):
     if ctx.set_saved is None:
         raise RuntimeError("the recompute chain's backward ran twice on the same graph: its per-step workspaces are "
                            "released after the first backward (retain_graph is not supported on this path)")
+    qk = getattr(ctx, "qk", None)          # QKVBimodalCSRPool in the view kernel: (groups, scale); two more saved tensors
+    saved = ctx.saved_tensors
     (rows, row_idx, x_map, csr_idx, vp, tiles, n_tiles, wops, t_add, zstar, arg, mom,
-     bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1) = ctx.saved_tensors
+     bn1, bn2, bn5, bn6, out, scores, bs, gw, gb, W1) = saved[:22]
     module, training = ctx.module, ctx.training
     scaling, eps = ctx.meta
     gate = module.G
     dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
     R, C = rows.shape
-    G = module.E_score.weight.shape[0]
+    G = qk[0] if qk is not None else module.E_score.weight.shape[0]
     st = stream_of(x_map)
     gout = gout.contiguous().to(torch.bfloat16)
     S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
-                        bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G, training=training)
+                        bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G if qk is None else D, training=training)
     arena = Arena(dev)          # every small fp32 accumulator / gradient of this backward: one zero fill
     # ---- attention + gate backward from the scores the forward left: score gradients, view records (no chain)
     dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
@@ -220,9 +223,20 @@ def backward(ctx, gout):
         else:
             grows = rows_grad(st)
     del rec
-    grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
+    lead = (grows, None, None, None, None, None, None, None)
+    keys_arg = None
+    if qk is not None:
+        # dQ' from the stored key rows; the key gradient itself is built inside the chain passes (chain_epilogue keys=...)
+        keys_rows, Qp = saved[22], saved[23]
+        dQ = torch.empty((N, D), dtype=torch.float32, device=dev)
+        with ops._timed("qkv_dquery", V * (64 + 16) + N * 136):
+            check(lib.dva_qkv_dquery(ptr(dc), 4, ptr(keys_rows), ptr(csr_idx), ptr(dQ), N, V, G, qk[1], st),
+                  "dva_qkv_dquery")
+        keys_arg = (Qp, G, qk[1])
+        lead = lead + (dQ, None)
+    grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved, keys=keys_arg)
     if side is not None:
         torch.cuda.current_stream(dev).wait_stream(side)
         grows.record_stream(torch.cuda.current_stream(dev))
     ctx.set_saved = None
-    return (grows, None, None, None, None, None, None, None) + tuple(grads)
+    return lead + tuple(grads)

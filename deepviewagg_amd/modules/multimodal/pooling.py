@@ -451,6 +451,9 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
             # on the N point rows through the row kernels (split-K weight gradients: the library's are skinny GEMMs)
             x_main = _mlp_rows(self.E_main, x_main)
             x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0]))
+            if fused_chain.QKV_ONE_KERNEL and x_mod.rows.shape[1] in (32, 64, 128, 256, 512):
+                # keys, compatibilities, softmax, weighted sum and gate in ONE view kernel (dva_chain_attn_fwd_keys)
+                return fused_chain.qkv_pool(self, x_main, x_mod, x_map, csr_idx)
             compatibilities = fused_chain.qkv_compatibilities(self, x_main, x_map, csr_idx)
             x_pool, _, _ = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
             return x_pool

@@ -606,6 +606,18 @@ int dva_chain_attn_bwd_f32(const float* scores, const int32_t* view_point, const
                            const float* gate_b, const float* grad_out, const float* out, float* grad_scores,
                            float* view_rec, float* grad_gate_wb, int64_t n_points, int64_t n_views, int64_t n_rows,
                            int32_t C, int32_t G, int32_t scaling, float eps, void* stream);
+/* QKVBimodalCSRPool in ONE view kernel (round 4): dva_chain_attn_fwd with the KEY layer as the chain's last layer (ops
+ * prepared with Ws = K.weight, G = 32; key_bias fp32 [32]) and the compatibilities scale * <key, queries[point]> per query-key
+ * group as the scores (queries fp32 [N][32] in the keys' position order, 16-byte aligned; G in {1, 2, 4} = query-key groups =
+ * attention groups).  scores_out (nullable) fp32 [V][4] receives the compatibilities, keys_out (nullable) bf16 [V][32] the
+ * key rows (position order) dva_qkv_dquery reads back in the backward; everything else as dva_chain_attn_fwd. */
+int dva_chain_attn_fwd_keys(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                            const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                            const float* bn5, const float* bn6, const float* key_bias, const float* queries, float scale,
+                            const void* rows, const int32_t* row_idx, const int64_t* ptr, const float* gate_w,
+                            const float* gate_b, void* out, float* scores_out, void* keys_out, int64_t n_points,
+                            int64_t n_views, int64_t n_rows, int32_t C, int32_t G, int32_t scaling, float eps,
+                            void* stream);
 /* Score layer backward + the statistics of the BatchNorm-6 backward (one chain evaluation per view):
  * stats6 += S1 | S2 of layer 6 with dy6 = leaky'(t6) Ws^T grad_scores (t6 = the folded layer-6 product, the
  * pre-activation the forward's activation saw), dWs fp32 [G][32] / dbs fp32 [G] (caller-zeroed) += the gradient of the

@@ -428,18 +428,18 @@ def test_qkv_chain_full_size_properties():
         r = rows.clone().requires_grad_()
         gf = ops.GatheredFeatures(r, row_idx[:v].contiguous(), None, True, None)
         calls = []
-        orig = fused_chain.qkv_compatibilities
+        orig = fused_chain.qkv_pool
 
         def spy(*a, **kw):
             calls.append(1)
             return orig(*a, **kw)
-        fused_chain.qkv_compatibilities = spy
+        fused_chain.qkv_pool = spy
         try:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 out = m(x_main[:nn_].contiguous(), gf, x_map[:v].contiguous(), c)
         finally:
-            fused_chain.qkv_compatibilities = orig
-        assert calls == [1], "the key layer must have run on the recompute chain"
+            fused_chain.qkv_pool = orig
+        assert calls == [1], "the whole pooling must have run in the chain's view kernel (dva_chain_attn_fwd_keys)"
         grads = torch.autograd.grad(out, [r] + list(m.parameters()), grad_outputs=w[:nn_].to(out.dtype), allow_unused=True)
         return out, grads
     out1, g1 = step()

@@ -34,7 +34,7 @@ def build(case, G, nc_qk, train, in_main=6, seed=7, wscale=0.3, **kw):
     return ref, m.to(DEV).train(train)
 
 
-def run_dev(case, m, x_main, chain):
+def run_dev(case, m, x_main, chain, one_kernel=True):
     from deepviewagg_amd import ops, fused_chain
     from deepviewagg_amd.modules.multimodal import pooling as P
     V = case["V"]
@@ -43,12 +43,16 @@ def run_dev(case, m, x_main, chain):
     packed = ops.pack_gather_index(case["images"].to(DEV), torch.arange(V + 1, device=DEV), case["pixels"].to(DEV))
     fused_chain.FORCE = None if chain else False
     calls = []
-    orig = fused_chain.qkv_compatibilities
+    orig, orig_pool, orig_flag = fused_chain.qkv_compatibilities, fused_chain.qkv_pool, fused_chain.QKV_ONE_KERNEL
 
     def spy(*a, **k):
         calls.append(1)
         return orig(*a, **k)
-    fused_chain.qkv_compatibilities = spy
+
+    def spy_pool(*a, **k):
+        calls.append(1)
+        return orig_pool(*a, **k)
+    fused_chain.qkv_compatibilities, fused_chain.qkv_pool, fused_chain.QKV_ONE_KERNEL = spy, spy_pool, one_kernel
     try:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             lazy = ops.lazy_gather_nearest(xd, packed, exact=True)
@@ -58,7 +62,7 @@ def run_dev(case, m, x_main, chain):
                                     allow_unused=True)
     finally:
         fused_chain.FORCE = None
-        fused_chain.qkv_compatibilities = orig
+        fused_chain.qkv_compatibilities, fused_chain.qkv_pool, fused_chain.QKV_ONE_KERNEL = orig, orig_pool, orig_flag
     return out, grads, len(calls)
 
 
@@ -132,6 +136,16 @@ def test_qkv_pool_on_the_chain_matches_oracle(sizes_fn, N, C, G, nc_qk, train):
     assert n_b == 0
     assert rel(out, out_b) < 2e-2, rel(out, out_b)
     assert rel(g[0], g_b[0]) < 1e-1, rel(g[0], g_b[0])
+    # A/B of the two chain forms: everything in ONE view kernel (the default above) against keys + compatibilities in one
+    # pass and the scores-in attention kernels -- the same arithmetic up to summation order
+    m.load_state_dict(sd)
+    out_c, g_c, n_c = run_dev(case, m, x_main, chain=True, one_kernel=False)
+    assert n_c == 1
+    assert rel(out, out_c) < 4e-3, rel(out, out_c)
+    assert rel(g[0], g_c[0]) < 2e-2, rel(g[0], g_c[0])
+    for n_, a, c_ in zip(names[2:], g[2:], g_c[2:]):
+        if a is not None and c_ is not None and float(c_.float().norm()) > 0:
+            assert rel(a, c_) < (1.5e-1 if train else 3e-2), (n_, rel(a, c_))
 
 
 def test_qkv_compat_kernels_against_torch():

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r04x2
 mkdir -p $OUT
 cd $ROOT
-timeout 600 python -m pytest tests/test_gpu_qkv_chain.py tests/test_gpu_pool_modules.py tests/test_gpu_chain.py -m gpu -x -q > $OUT/pytest.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_qkv_chain.py tests/test_gpu_pool_modules.py -m gpu -x -q > $OUT/pytest.log 2>&1
 tail -15 $OUT/pytest.log
 timeout 300 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k qkv > $OUT/pytest_full.log 2>&1
 tail -3 $OUT/pytest_full.log
