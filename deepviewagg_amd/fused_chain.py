@@ -292,10 +292,11 @@ def chain_pool(module, x_mod, x_map, csr_idx):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# QKVBimodalCSRPool on the chain (round 4): the keys K(E_map(x_map)) are one more 32 x 32 layer behind DeepSetFeat,
-# written as ONE bf16 [V, 32] row per view (accumulator order); compatibilities, attention and the rows gradient run on
-# the attention kernels that take the scores as an input (ops.view_gather_attention); d keys goes back into the chain's
-# backward as a 32-wide row instead of 4 score gradients (dva_chain_score_stats / dva_chain_bwd_layer(6), G = 32).
+# QKVBimodalCSRPool on the chain (round 4): the keys K(E_map(x_map)) are one more 32 x 32 layer behind DeepSetFeat.  Default
+# (qkv_pool): the whole forward in the chain's view kernel (dva_chain_attn_fwd_keys); the bf16 key rows [V, 32] (accumulator
+# order) and the compatibilities [V, 4] stay for the backward, where dQ comes from the key rows (dva_qkv_dquery) and the key
+# gradient is built in registers inside the chain passes (dva_chain_score_stats_keys / dva_chain_bwd_layer6_keys).
+# qkv_compatibilities: keys + compatibilities in one pass, attention on the scores-in kernels (DVA_QKV_ONE_KERNEL=0, A/B).
 # ---------------------------------------------------------------------------------------------------------------------
 _KEY_POS = {}
 

@@ -1,5 +1,6 @@
-"""-m gpu: QKVBimodalCSRPool with its keys on the bf16 recompute chain (round 4: dva_chain_keys, dva_qkv_compat, the key-layer
-variants of dva_chain_score_stats / dva_chain_bwd_layer(6)) against the CPU oracle (reference modules/multimodal/pooling.py:
+"""-m gpu: QKVBimodalCSRPool on the bf16 recompute chain (round 4: dva_chain_attn_fwd_keys = the whole forward in one view
+kernel, dva_chain_keys_compat + the scores-in attention as its A/B, dva_qkv_dquery, the key-layer entries
+dva_chain_score_stats_keys / dva_chain_bwd_layer6_keys) against the CPU oracle (reference modules/multimodal/pooling.py:
 454-547).  Gates as for the group pooling (tests/test_gpu_chain.py): output <= max(2e-2, 1.5 x the oracle's own error under
 torch.autocast(bfloat16)); gradients <= max(2 x autocast (4 x for gate parameters), 5e-2) per tensor, the yardstick of the
 encoder parameters floored by its median over them; every gradient must exist."""
