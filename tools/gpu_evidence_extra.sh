@@ -2,7 +2,10 @@
 # Round 4: rocprofv3 kernel stats + PMC traffic of the SECONDARY workloads (F-L, S2, fp32, the
 # bilinear workloads, the 256 -> 128 level, the reference-sized batch, the batched mapping build).
 # Usage: tools/gpu_evidence_extra.sh <tag>   (writes gpurun_out/<tag>/)
+exec < /dev/null
 TAG=${1:-r04x}
+ONLY=${2:-all}          # second argument: space-separated subset of the workload names below
+want() { [ "$ONLY" = "all" ] || [[ " $ONLY " == *" $1 "* ]]; }
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -24,12 +27,15 @@ prof() {   # prof <name> <pmc: 0|1> <command...>
   fi
   head -c 300 $OUT/${NAME}.out; echo
 }
-prof FL 1 python $ROOT/tools/workload_once.py F-L 3
-prof S2 1 python $ROOT/tools/workload_once.py S2 3
-prof f32 1 python $ROOT/tools/workload_once.py f32 3
-prof bilinear_128_32 1 python $ROOT/tools/level_once.py 128 32 3 1
-prof bilinear_64_64 1 python $ROOT/tools/level_once.py 64 64 3 1
-prof bilinear_256_128 1 python $ROOT/tools/level_once.py 256 128 3 1
-prof s3dis 0 python $ROOT/tools/workload_once.py s3dis_eager 40
-prof mapping 0 python $ROOT/tools/mapping_bench_once.py
+want FL && prof FL 1 python $ROOT/tools/workload_once.py F-L 3
+want S2 && prof S2 1 python $ROOT/tools/workload_once.py S2 3
+want f32 && prof f32 1 python $ROOT/tools/workload_once.py f32 3
+want qkv && prof qkv 1 python $ROOT/tools/workload_once.py qkv 3
+want nonexact && prof nonexact 0 python $ROOT/tools/workload_once.py nonexact 3
+want bilinear_128_32 && prof bilinear_128_32 1 python $ROOT/tools/level_once.py 128 32 3 1
+want bilinear_64_64 && prof bilinear_64_64 1 python $ROOT/tools/level_once.py 64 64 3 1
+want bilinear_256_128 && prof bilinear_256_128 1 python $ROOT/tools/level_once.py 256 128 3 1
+want bilinear_512_256 && prof bilinear_512_256 1 python $ROOT/tools/level_once.py 512 256 3 1
+want s3dis && prof s3dis 0 python $ROOT/tools/workload_once.py s3dis_eager 40
+want mapping && prof mapping 0 python $ROOT/tools/mapping_bench_once.py
 ls $OUT | head -40
