@@ -366,11 +366,11 @@ __global__ __launch_bounds__(256) void compact_batch_kernel(int64_t n, int B, co
                                                              int32_t* __restrict__ idx1, int32_t* __restrict__ simg,
                                                              float* __restrict__ dist, double* __restrict__ xp,
                                                              double* __restrict__ yp, MapCounters* __restrict__ cnt) {
-  const int64_t total = n * B;
+  const int64_t total = n * B;        // <= 2^31 - 1 (entry precondition): a 32-bit division
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     if (flag[i]) {
       const int32_t j = pos[i];
-      const int b = (int)(i / n);
+      const int b = (int)((uint32_t)i / (uint32_t)n);
       idx1[j] = (int32_t)(i - (int64_t)b * n);
       simg[j] = b;
       dist[j] = dist_u[i];
