@@ -95,6 +95,7 @@ def run_dev(case, m, chain, need_grad=True):
 @pytest.mark.parametrize("sizes_fn,N,C,G", [(ragged, 3000, 64, 4), (ragged_long, 2000, 64, 4), (full32, 300, 64, 4),
                                             (ragged_long, 1500, 32, 2), (ragged, 1500, 128, 1),
                                             (ragged_long, 700, 512, 4), (ragged, 900, 256, 4),
+                                            (ragged, 1200, 128, 4),         # staged several-points walk, two channels per lane
                                             (ragged, 20000, 64, 4)])       # eval: the single fused launch at N = 20 k
 def test_chain_forward_matches_oracle(sizes_fn, N, C, G, train):
     case = make_case(3, N, C, sizes_fn)
@@ -179,6 +180,7 @@ def _oracle_grads(case, ref, autocast):
     (ragged, 3000, 64, 4, False, True),
     (ragged_long, 1500, 32, 2, True, True),
     (ragged, 1500, 128, 1, True, False),
+    (ragged, 3000, 128, 4, True, True),
     (ragged_long, 700, 512, 4, True, True),
 ])
 def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
