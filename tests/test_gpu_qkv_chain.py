@@ -149,6 +149,31 @@ def test_qkv_pool_on_the_chain_matches_oracle(sizes_fn, N, C, G, nc_qk, train):
             assert rel(a, c_) < (1.5e-1 if train else 3e-2), (n_, rel(a, c_))
 
 
+def test_qkv_pool_without_gate_and_without_dim_scaling():
+    """gating=False (no Gating module: NULL gate pointers through the view kernel and the attention backward) and
+    dim_scaling=False (scale 1) on ragged points: forward against the oracle, every existing gradient finite and close."""
+    case = make_case(23, 2500, 64, ragged)
+    x_main = torch.randn(2500, 6, generator=case["gen"])
+    ref, m = build(case, 4, 8, True, gating=False, dim_scaling=False)
+    assert m.G is None
+    out_ref, g_ref = oracle(case, ref, x_main, autocast=False)
+    out, g, n_chain = run_dev(case, m, x_main, chain=True)
+    assert n_chain == 1
+    assert rel(out, out_ref) < 2e-2, rel(out, out_ref)
+    assert rel(g[0], g_ref[0]) < 6e-2, rel(g[0], g_ref[0])                 # feature-map gradient
+    names = ["x", "x_main"] + [n for n, _ in ref.named_parameters()]
+    for n, a, b in zip(names, g, g_ref):
+        if b is None:
+            continue
+        assert a is not None and bool(torch.isfinite(a.float()).all()), n
+        # (K.bias: without a gate the softmax is invariant to a per-point shift of the scores, its true gradient is 0 --
+        #  the oracle's is 1e-6 of rounding noise, ours the bf16 noise of the same cancellation)
+        if n.startswith(("E_mod", "Q.", "K.weight")):
+            assert rel(a, b) < 2.5e-1, (n, rel(a, b))
+        if n == "K.bias":
+            assert float(a.float().norm()) < 0.05 * float(g[names.index("K.weight")].float().norm()), n
+
+
 def test_qkv_compat_kernels_against_torch():
     """dva_qkv_compat / _bwd on random key rows: the position-order bookkeeping (group of a position, query permutation)
     against the module's own expression on channel-order tensors."""
