@@ -243,6 +243,16 @@ class HeuristicBimodalCSRPool(nn.Module, _SaveLast):
         self._init_save_last(save_last)
 
     def forward(self, x_main, x_mod, x_map, csr_idx):
+        if isinstance(x_mod, ops.GatheredFeatures) and not self.save_last:
+            # lazily gathered values (round 4): only the SELECTED view of every point is gathered -- N rows of the map
+            # instead of the [V, C] tensor (x_pool[i] = rows[row_idx[arg_i]], zeros for unseen points)
+            _, arg_idx = ops.segment_csr_arg(x_map[:, self._feat].float(), csr_idx, reduce=self._mode)
+            arg_idx = arg_idx.reshape(-1).long()
+            seen = arg_idx >= 0
+            sel = x_mod.row_idx.long()[arg_idx.clamp(min=0)] if x_mod.row_idx.shape[0] else arg_idx.clamp(min=0)
+            x_pool = ops.gather_rows(x_mod.rows, sel.to(torch.int32)) if x_mod.row_idx.shape[0] else \
+                x_mod.rows.new_zeros((arg_idx.shape[0], x_mod.rows.shape[1]))
+            return x_pool * seen.unsqueeze(1).to(x_pool.dtype)
         x_mod = _materialize(x_mod)
         # arg of the per-group extremum of the heuristic feature (first row on ties, -1 if unseen)
         _, arg_idx = ops.segment_csr_arg(x_map[:, self._feat].float(), csr_idx, reduce=self._mode)

@@ -90,6 +90,37 @@ def test_simple_pools_and_fusion():
         P.BimodalCSRPool(mode="median")
 
 
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_heuristic_pool_on_lazy_features_gathers_only_the_selected_rows(mode):
+    """HeuristicBimodalCSRPool on a lazily gathered map (round 4: N selected rows instead of the [V, C] tensor): output and
+    the feature-map gradient bit-identical to the materialised route, unseen points exactly 0."""
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    B, C, H, W, N = 3, 24, 8, 12, 500
+    k = torch.randint(0, 6, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), k.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    images = torch.randint(0, B, (V,), generator=gen).to(DEV)
+    pixels = torch.stack([torch.randint(0, W, (V,), generator=gen), torch.randint(0, H, (V,), generator=gen)], 1) \
+        .to(torch.int16).to(DEV)
+    x_map = torch.rand(V, 8, generator=gen).to(DEV)
+    x0 = torch.randn(B, C, H, W, generator=gen)
+    w = torch.randn(N, C, generator=gen).to(DEV)
+    pool = P.HeuristicBimodalCSRPool(mode=mode, feat="normalized_depth")
+    res = []
+    for lazy in (True, False):
+        x = x0.to(DEV).to(memory_format=torch.channels_last).requires_grad_()
+        feats = ops.lazy_gather_nearest_mapping(x, images, torch.arange(V + 1, device=DEV), pixels, 1.0, exact=True)
+        out = pool(None, feats if lazy else feats.materialize(), x_map, csr)
+        (g,) = torch.autograd.grad((out * w).sum(), x)
+        res.append((out.detach(), g))
+    assert torch.equal(res[0][0], res[1][0])
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=1e-6)
+    unseen = (csr[1:] == csr[:-1])
+    assert float(res[0][0][unseen].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_group_pool_large_random_vs_oracle(dtype):
     """N=20k points, up to 12 views, C=64: product module vs oracle module with the same weights."""
