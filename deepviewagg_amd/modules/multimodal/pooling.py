@@ -214,6 +214,10 @@ class BimodalCSRPool(nn.Module, _SaveLast):
                 # no [P, C] tensor; the result stays lazy at the VIEW level (identity gather over the pooled [V, C] rows) so
                 # that the view pooling keeps its fused path
                 return ops.gather_segment_max(x_mod, csr_idx)
+            if (x_map is not None and self._mode == 'max' and not self.save_last
+                    and ops.gather_segment_max_applicable(x_mod, csr_idx)):
+                # VIEW-level max pool of lazily gathered values: the same fused kernel, a plain [N, C] tensor out
+                return ops.gather_segment_max(x_mod, csr_idx).rows
             x_mod = x_mod.materialize()
         x_pool = segment_csr(x_mod, csr_idx, reduce=self._mode)
         self._save(x_map, x_mod, csr_idx)

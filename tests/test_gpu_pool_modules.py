@@ -431,10 +431,19 @@ def test_view_level_pool_with_equal_counts_is_not_the_identity():
     csr = torch.tensor([0, 2, 2, 3], device=DEV)
     x_map = torch.rand(V, 8, device=DEV)
     for mode in ("max", "sum"):
-        out = P.BimodalCSRPool(mode=mode)(None, lazy, x_map, csr)
+        out = P.BimodalCSRPool(mode=mode)(None, lazy, x_map, csr)       # max: the fused gather + max kernel (round 4)
         assert isinstance(out, torch.Tensor) and out.shape == (3, C)
         ref = O.segment_csr(lazy.materialize().cpu(), csr.cpu(), mode)
         close(out, ref)
+    # the fused view-level max pool carries gradients to the map like the materialised route
+    xg = x.clone().requires_grad_()
+    lazy_g = ops.lazy_gather_nearest(xg, packed, exact=True)
+    out = P.BimodalCSRPool(mode='max')(None, lazy_g, x_map, csr)
+    (g1,) = torch.autograd.grad(out.sum(), xg)
+    xr = x.clone().requires_grad_()
+    ref = ops.segment_csr(ops.lazy_gather_nearest(xr, packed, exact=True).materialize(), csr, reduce='max')
+    (g2,) = torch.autograd.grad(ref.sum(), xr)
+    assert torch.equal(out, ref) and torch.allclose(g1, g2)
     # atomic level: stays lazy
     assert isinstance(P.BimodalCSRPool()(None, lazy, None, torch.arange(V + 1, device=DEV)), ops.GatheredFeatures)
 
