@@ -1,5 +1,5 @@
 #!/bin/bash
-# mapping build: parity tests, bench entry (both tails), rocprofv3 kernel stats (csv); every command bounded, no stdin reads
+# mapping build: parity tests, bench entry, rocprofv3 kernel stats (csv); every command bounded, no stdin reads
 exec < /dev/null
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r04z
@@ -15,7 +15,6 @@ r = bench.mapping_build_bench(torch.device("cuda:0"))
 print(json.dumps({k: r[k] for k in ("images_per_s", "ms_per_image", "indices_bit_exact_vs_oracle")}))
 PY
 timeout 120 python /tmp/mb.py 2> $OUT/mb.err | tail -1
-DVA_MAP_SORTED_TAIL=1 timeout 120 python /tmp/mb.py 2> $OUT/mb.err | tail -1
 (cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof2 -o mapping --output-format csv -- python /tmp/mb.py > $OUT/prof.log 2>&1)
 f=$(ls $OUT/prof2/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" $OUT/mapping_kernel_stats.csv; fi
