@@ -63,6 +63,11 @@ def parse():
                     help="N > 1: size (MB, fp32) of the stand-in gradient bucket for the parts of the model outside "
                          "the path (2D encoder + 3D backbone, SURVEY.md 8(e): 28.1 M parameters = 112 MB), "
                          "all-reduced on a side stream under the backward of every step; 0 disables")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help=argparse.SUPPRESS)   # gloo: only with --dry-run (the CPU test of the launcher)
+    ap.add_argument("--dry-run", action="store_true",
+                    help=argparse.SUPPRESS)   # launcher + process group + rank/device census only, no HIP work
+    ap.add_argument("--no-standin", action="store_true", help="N > 1: no stand-in bucket (same as --standin-mb 0)")
     ap.add_argument("--workload", default="S1", choices=["S1", "S2", "S1c"],
                     help="S1: every point seen by --views images (headline); S2: ragged view counts "
                          "min(views, 1 + Geom(0.2)), 10 %% of the points unseen (SURVEY.md 8(d))")
@@ -810,8 +815,75 @@ def tile_of_scene(scene, rank, world):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher.
+    It re-executes this same command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1` (one rank per GPU, LOCAL_RANK = device ordinal) and passes the ranks' output and exit
+    code through; rank 0 prints the JSON line.  (The driver's own torchrun launch sets WORLD_SIZE and never gets here.)"""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    print(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rank_census(world, rank, local_rank, device, backend):
+    """All-gather of (rank, device ordinal) over the process group: the ranks really are `world` distinct processes and,
+    under RCCL, sit on `world` distinct devices.  Returns the list of (rank, device) pairs."""
+    assert dist.get_world_size() == world and dist.get_backend() == backend
+    who = torch.tensor([rank, local_rank], device=device, dtype=torch.int64)
+    gathered = [torch.empty_like(who) for _ in range(world)]
+    dist.all_gather(gathered, who)
+    ranks_devices = [tuple(int(v) for v in g.tolist()) for g in gathered]
+    assert sorted(r for r, _ in ranks_devices) == list(range(world)), ranks_devices
+    assert len({d for _, d in ranks_devices}) == world, f"ranks share a device: {ranks_devices}"
+    return ranks_devices
+
+
+def dry_run(args, world, rank, local_rank, json_fd):
+    """Hidden `--dry-run` (tests/test_bench_launcher.py): everything bench.py does to become N ranks -- launcher,
+    rendezvous, process group, rank / device census, the gradient bucket's all-reduce, max-over-ranks timing -- with
+    no HIP work, so that the N > 1 entry is exercised on a box without GPUs (`--backend gloo`)."""
+    from deepviewagg_amd.parallel import GradientBucket
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(args.backend, rank=rank, world_size=world)
+    device = torch.device("cpu")
+    ranks_devices = rank_census(world, rank, local_rank, device, args.backend)
+    p = torch.nn.Parameter(torch.zeros(1000))
+    p.grad = torch.full((1000,), float(rank + 1))
+    bucket = GradientBucket([p])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bucket.reduce(average=False)
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        res = {"metric": "points/sec fused fwd+bwd (1M pts, 32 views)", "value": None, "unit": "points/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "backend": args.backend,
+               "collective": {"ranks_devices": ranks_devices},
+               "allreduce_sum_check": float(p.grad[0].item())}
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     # stdout carries exactly ONE JSON line: everything else that may write to fd 1 (RCCL prints a version
     # banner there at communicator creation) is redirected to stderr for the duration of the run
     sys.stdout.flush()
@@ -820,7 +892,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # --gpus is the contract: the process group this rank sits in must have exactly that many ranks
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python bench.py --gpus N` (spawns the ranks itself) or torch.distributed.run "
+                         f"--nproc-per-node N ... bench.py --gpus N")
+    if args.dry_run:
+        return dry_run(args, world, rank, local_rank, json_fd)
+    if args.backend != "nccl":
+        raise SystemExit("bench.py: --backend gloo exists only for --dry-run; the measured path is RCCL")
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} of {world} (LOCAL_RANK {local_rank}) has no HIP device: "
+                         f"{n_dev} visible, --gpus {args.gpus} needs one per rank")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # one process per GPU over RCCL; a 1-rank torchrun launch (RANK set) also goes through the process group so
@@ -830,13 +914,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         # RCCL really spans `world` ranks, one per device: all-gather of (rank, device ordinal) -- checked in-process
-        assert dist.get_world_size() == world and dist.get_backend() == "nccl"
-        who = torch.tensor([rank, local_rank], device=device, dtype=torch.int64)
-        gathered = [torch.empty_like(who) for _ in range(world)]
-        dist.all_gather(gathered, who)
-        ranks_devices = [tuple(int(v) for v in g.tolist()) for g in gathered]
-        assert sorted(r for r, _ in ranks_devices) == list(range(world)), ranks_devices
-        assert len({d for _, d in ranks_devices}) == world, f"ranks share a device: {ranks_devices}"
+        ranks_devices = rank_census(world, rank, local_rank, device, "nccl")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     from deepviewagg_amd import ops, _lib
@@ -858,7 +936,7 @@ def main():
     # stand-in for the gradients of the model parts outside the path (2D encoder, 3D backbone): all-reduced on a
     # side stream, started when the backward of the path starts, awaited at the end of the step
     standin = None
-    if use_dist and args.standin_mb > 0:
+    if use_dist and args.standin_mb > 0 and not args.no_standin:
         n_el = int(args.standin_mb * 1e6 / 4)
         sp = torch.nn.Parameter(torch.zeros(n_el, device=device))
         sp.grad = torch.full((n_el,), 1e-3, device=device)

@@ -29,7 +29,11 @@ _ERRORS = {
 
 
 class DvaError(RuntimeError):
-    pass
+    """A C-ABI entry returned a DVA_ERR_* code (``.code``; include/dva.h)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 class DvaCamera(ctypes.Structure):
@@ -230,7 +234,7 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        raise DvaError(f"{what} failed: {_ERRORS.get(rc, rc)}")
+        raise DvaError(f"{what} failed: {_ERRORS.get(rc, rc)}", code=rc)
 
 
 def ptr(t):

@@ -35,7 +35,7 @@ class MapImages:
         return self._process(data, images)
 
     @staticmethod
-    def _batch_size(visi_model, n_points, n_images, budget_bytes=None):
+    def _batch_size(visi_model, n_points, n_images, budget_bytes=None, device=None):
         """Images per visibility batch: what fits ``budget_bytes`` of workspace + outputs (a 2048 x 1024 projection map
         costs 42 MB of z-buffer / pixel maps per image, a candidate 100 bytes).  Default budget: a third of the
         device memory that is free right now, at most 8 GiB (the preprocessing may share the GPU with a training
@@ -43,7 +43,7 @@ class MapImages:
         if budget_bytes is None:
             budget_bytes = 8 << 30
             if torch.cuda.is_available():
-                budget_bytes = min(budget_bytes, torch.cuda.mem_get_info()[0] // 3)
+                budget_bytes = min(budget_bytes, torch.cuda.mem_get_info(device)[0] // 3)
         w, h = visi_model.img_size
         per_image = w * h * 20 + n_points * 100 + (n_points if getattr(visi_model, 'exact', False)
                                                    else max(n_points, w * h)) * 48
@@ -78,7 +78,7 @@ class MapImages:
         # per-image post-processing (:294-353) is applied to all rows at once, the image id leading the sort key
         image_ids, point_ids, features, pixels = [], [], [], []
         n_img = images.num_views
-        step = self._batch_size(visi_model, xyz.shape[0], n_img)
+        step = self._batch_size(visi_model, xyz.shape[0], n_img, device=xyz.device)
 
         def run_batch(sel):
             def part(attr):
@@ -95,10 +95,11 @@ class MapImages:
             sel = slice(i0, min(i0 + step, n_img))
             try:
                 out = run_batch(sel)
-            except (DvaError, torch.cuda.OutOfMemoryError):
-                # the batch does not fit (workspace allocation, or more candidates x images than the kernels index):
-                # halve it, down to the reference's one image at a time (:238)
-                if step == 1:
+            except (DvaError, torch.cuda.OutOfMemoryError) as e:
+                # the batch does not fit (workspace allocation, or more candidates x images than the kernels index with
+                # int32 = DVA_ERR_UNSUPPORTED / DVA_ERR_OVERFLOW): halve it, down to the reference's one image at a time
+                # (:238).  Anything else (bad argument, launch error) is a real failure: raise it where it happened
+                if step == 1 or (isinstance(e, DvaError) and e.code not in (-2, -4)):
                     raise
                 step = max(1, step // 2)
                 torch.cuda.empty_cache()

@@ -325,6 +325,18 @@ def keys_applicable(module, x_mod, x_map, csr_idx):
     return V * 64 < (1 << 32) - 16 and N * 128 < (1 << 32) - 16
 
 
+def keys_rows_ok(module, x_mod):
+    """Second half of ``keys_applicable``, on the rows E_mod RETURNED: bf16, a width the view kernel is instantiated for
+    per group, fp32 gate parameters (the kernels read them as float)."""
+    rows = x_mod.rows
+    C, G = rows.shape[1], module.num_groups
+    if rows.dtype != torch.bfloat16 or C % G or (C // G) % 8:
+        return False
+    if module.G is not None and any(t is not None and t.dtype != torch.float32 for t in (module.G.weight, module.G.bias)):
+        return False
+    return rows.shape[0] * C * 2 < (1 << 32) - 16
+
+
 class _KeyAdapter:
     """What chain_prologue / chain_epilogue read of a pooling module, for the key layer of a QKVBimodalCSRPool."""
 

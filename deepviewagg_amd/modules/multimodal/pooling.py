@@ -256,7 +256,8 @@ class HeuristicBimodalCSRPool(nn.Module, _SaveLast):
             sel = x_mod.row_idx.long()[arg_idx.clamp(min=0)] if x_mod.row_idx.shape[0] else arg_idx.clamp(min=0)
             x_pool = ops.gather_rows(x_mod.rows, sel.to(torch.int32)) if x_mod.row_idx.shape[0] else \
                 x_mod.rows.new_zeros((arg_idx.shape[0], x_mod.rows.shape[1]))
-            return x_pool * seen.unsqueeze(1).to(x_pool.dtype)
+            # unseen points: exact zeros whatever the (unrelated) gathered row holds -- 0 * Inf would be NaN
+            return torch.where(seen.unsqueeze(1), x_pool, torch.zeros((), dtype=x_pool.dtype, device=x_pool.device))
         x_mod = _materialize(x_mod)
         # arg of the per-group extremum of the heuristic feature (first row on ties, -1 if unseen)
         _, arg_idx = ops.segment_csr_arg(x_map[:, self._feat].float(), csr_idx, reduce=self._mode)
@@ -465,20 +466,29 @@ class QKVBimodalCSRPool(nn.Module, _SaveLast):
             # on the N point rows through the row kernels (split-K weight gradients: the library's are skinny GEMMs)
             x_main = _mlp_rows(self.E_main, x_main)
             x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0]))
-            if fused_chain.QKV_ONE_KERNEL and x_mod.rows.shape[1] in (32, 64, 128, 256, 512):
-                # keys, compatibilities, softmax, weighted sum and gate in ONE view kernel (dva_chain_attn_fwd_keys)
-                return fused_chain.qkv_pool(self, x_main, x_mod, x_map, csr_idx)
-            compatibilities = fused_chain.qkv_compatibilities(self, x_main, x_map, csr_idx)
-            x_pool, _, _ = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
-            return x_pool
-        x_main = self.E_main(x_main)
+            # the rows the view kernel is handed are E_mod's OUTPUT: check those again (ADVICE r4 -- E_mod's torch
+            # fallback may return fp32 rows, which the bf16 kernel would reinterpret), as GroupBimodalCSRPool does
+            if fused_chain.keys_rows_ok(self, x_mod):
+                if fused_chain.QKV_ONE_KERNEL and x_mod.rows.shape[1] in (32, 64, 128, 256, 512):
+                    # keys, compatibilities, softmax, weighted sum and gate in ONE view kernel (dva_chain_attn_fwd_keys)
+                    return fused_chain.qkv_pool(self, x_main, x_mod, x_map, csr_idx)
+                compatibilities = fused_chain.qkv_compatibilities(self, x_main, x_map, csr_idx)
+                x_pool, _, _ = _pool_with_attention(self, x_mod, compatibilities, csr_idx)
+                return x_pool
+            encoded = True                  # generic composition below, E_main / E_mod already applied
+        else:
+            encoded = False
+        if not encoded:
+            x_main = self.E_main(x_main)
         fused_keys = (not self.use_mod_k and not self.save_last and not self.debug
                       and fused_deepset.applicable(self.E_map, self.K, x_map))
         if fused_keys:
             keys = fused_deepset.deepset_linear(self.E_map, self.K, x_map, csr_idx)
         else:
             x_map = self.E_map(x_map, csr_idx)
-        if isinstance(x_mod, ops.GatheredFeatures) and not (self.use_mod_k or self.use_mod_q or self.debug):
+        if encoded:
+            pass
+        elif isinstance(x_mod, ops.GatheredFeatures) and not (self.use_mod_k or self.use_mod_q or self.debug):
             x_mod = x_mod.with_rows(mlp_on_gathered_rows(self.E_mod, x_mod.rows, x_mod.counts, x_mod.shape[0]))
         else:
             x_mod = _mlp_rows(self.E_mod, _materialize(x_mod))

@@ -735,19 +735,23 @@ class _GatherSegmentMax(torch.autograd.Function):
 
 # A/B: fp32 atomics instead of the segmented reduction over the atoms' row plan (tests)
 SEGMENT_MAX_ATOMICS = False
-_ATOMS_OK = {}
 
 
 def _atoms_per_view_ok(atom_ptr):
-    """True when no view owns more than 65534 atoms (the uint16 arg offsets of the fused max pool); one device
-    synchronisation per mapping tensor, cached."""
-    key = (atom_ptr.data_ptr(), atom_ptr.shape[0], atom_ptr._version)
-    if key not in _ATOMS_OK:
-        if len(_ATOMS_OK) > 64:
-            _ATOMS_OK.clear()
-        n = atom_ptr.shape[0] - 1
-        _ATOMS_OK[key] = n == 0 or int((atom_ptr[1:] - atom_ptr[:-1]).max()) <= 0xfffe
-    return _ATOMS_OK[key]
+    """True when no view owns more than 65534 atoms (the uint16 arg offsets of the fused max pool).  One device
+    synchronisation per mapping tensor; the verdict is remembered ON the tensor object together with its version
+    counter (not under its address: the caching allocator hands the same address to the next mapping), so a
+    new or modified pointer tensor is always measured again."""
+    memo = getattr(atom_ptr, "_dva_atoms_ok", None)
+    if memo is not None and memo[0] == atom_ptr._version:
+        return memo[1]
+    n = atom_ptr.shape[0] - 1
+    ok = n == 0 or int((atom_ptr[1:] - atom_ptr[:-1]).max()) <= 0xfffe
+    try:
+        atom_ptr._dva_atoms_ok = (atom_ptr._version, ok)
+    except AttributeError:       # a tensor subclass without a __dict__: measure every time
+        pass
+    return ok
 
 
 LAZY_NONEXACT = os.environ.get("DVA_LAZY_NONEXACT", "1") == "1"
@@ -757,8 +761,12 @@ def gather_segment_max_applicable(x_mod, atom_ptr):
     if not (LAZY_NONEXACT and isinstance(x_mod, GatheredFeatures)):
         return False
     C, es = x_mod.rows.shape[1], x_mod.rows.element_size()
+    # 16-byte alignment of the row base: a contiguous slice of a feature map with a storage offset that is not a
+    # multiple of 16 bytes takes the materialised route instead of DVA_ERR_UNSUPPORTED; non-contiguous
+    # rows are copied by the op (fresh, aligned allocation)
     return (x_mod.rows.dtype in (torch.float32, torch.bfloat16) and C % (16 // es) == 0 and C > 0
-            and x_mod.rows.is_cuda and _atoms_per_view_ok(atom_ptr))
+            and x_mod.rows.is_cuda and (not x_mod.rows.is_contiguous() or x_mod.rows.data_ptr() % 16 == 0)
+            and _atoms_per_view_ok(atom_ptr))
 
 
 def gather_segment_max(x_mod, atom_ptr):
