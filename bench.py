@@ -169,15 +169,30 @@ PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pro
 
 
 def pmc_traffic(timer_name, default_workload):
-    """HBM bytes per launch of the kernel from the committed rocprofv3 PMC passes of this same command
+    """(HBM bytes per launch, reason) of the kernel from the committed rocprofv3 PMC passes of this same command
     (separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes;
-    tools/gpu_evidence.sh + profiles/summarize_pmc.py).  Counters cannot be read from inside the process,
-    so this is only reported for the default workload the passes were taken on; None otherwise."""
-    if not default_workload or timer_name not in KERNEL_SYMBOL or not os.path.exists(PMC_TRAFFIC_FILE):
-        return None
+    tools/gpu_evidence.sh + profiles/summarize_pmc.py).  Counters cannot be read from inside the process, so the
+    value is only reported for the default workload the passes were taken on AND only when the file's stamp (sha256 of
+    the kernel sources at the time of the passes) equals the hash of the sources this run is built from; otherwise
+    (None, why)."""
+    from deepviewagg_amd import _lib
+    if not default_workload:
+        return None, "not the workload the PMC passes were taken on"
+    if timer_name not in KERNEL_SYMBOL or not os.path.exists(PMC_TRAFFIC_FILE):
+        return None, "no PMC pass for this kernel"
     table = json.load(open(PMC_TRAFFIC_FILE))
-    entry = table.get(KERNEL_SYMBOL[timer_name])
-    return None if entry is None else entry["hbm_bytes"]
+    stamp = (table.get("_stamp") or {}).get("csrc_sha256")
+    if stamp != _lib.source_sha256():
+        return None, ("profiles/pmc_traffic_latest.json was taken on other kernel sources (stamp "
+                      f"{str(stamp)[:12]} != {_lib.source_sha256()[:12]}): re-run tools/gpu_evidence.sh")
+    sym = KERNEL_SYMBOL[timer_name]
+    entry = table.get(sym)
+    if entry is None:            # template arguments appended since the table of symbols was written: prefix match
+        hits = [v for k, v in table.items() if k.startswith(sym.rstrip(">")) and isinstance(v, dict) and "hbm_bytes" in v]
+        entry = max(hits, key=lambda v: v["hbm_bytes"]) if hits else None
+    if entry is None:
+        return None, f"kernel {sym} not in the PMC passes"
+    return entry["hbm_bytes"], None
 
 
 def step(scene, packed, mods, dtype, lazy=True, before_backward=None, interpolate=False):
@@ -290,10 +305,22 @@ def cpu_gather_attention_twin(log2_points, views, C, G=4):
                                     "view_gather_rows_grad + row_plan (kernels table) minus the encoder recompute")
 
 
+def _host_mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_full_path_twin(log2_points, views, C, G=4):
-    """C + OpenMP twin of the WHOLE pooling step on all host cores: the mapping-feature encoder (DeepSetFeat + E_score,
-    train-mode BatchNorm: oracle/deepset_oracle.c) feeding the view gather + attention tail (oracle/attention_oracle.c),
-    forward + backward incl. the rows scatter-add and every parameter gradient.  Bounded sample of S1."""
+    """C + OpenMP twin of the WHOLE pooling step on all host cores (the build's own CPU restatement):
+    E_mod on the map rows (count-weighted train-mode BatchNorm: oracle/deepset_oracle.c `oracle_wblock_*`), the
+    mapping-feature encoder (DeepSetFeat + E_score, train-mode BatchNorm) feeding the view gather + attention tail
+    (oracle/attention_oracle.c), the fusion concat; forward + backward incl. the rows scatter-add, E_mod's backward on the
+    map rows and every parameter gradient.  Bounded sample of S1 (same shapes; N as large as the host memory allows)."""
     import numpy as np
     from oracle import attention_oracle as A
     from oracle import deepset_oracle as DS
@@ -303,30 +330,40 @@ def cpu_full_path_twin(log2_points, views, C, G=4):
     V, R = n * views, 32 * 64 * 128
     csr = np.arange(0, V + 1, views, dtype=np.int64)
     row_idx = rng.integers(0, R, V, dtype=np.int32)
-    rows = rng.standard_normal((R, C), dtype=np.float32)
+    counts = np.bincount(row_idx, minlength=R).astype(np.float32)
+    x_rows = rng.standard_normal((R, C), dtype=np.float32)
     x_map = rng.random((V, 8), dtype=np.float32)
+    x_3d = rng.standard_normal((n, 4), dtype=np.float32)
     gw, gb = np.ones(G, np.float32), np.zeros(G, np.float32)
-    gout = rng.standard_normal((n, C), dtype=np.float32)
+    gfused = rng.standard_normal((n, 4 + C), dtype=np.float32)
     torch.manual_seed(0)
-    e_map, lin = O.DeepSetFeat(8, 32, use_num=True), torch.nn.Linear(32, G)
+    e_map, lin, e_mod = O.DeepSetFeat(8, 32, use_num=True), torch.nn.Linear(32, G), O.MLP([C, C, C], bias=False)
     P = DS.params_from_state_dict({k: v.detach().numpy() for k, v in e_map.state_dict().items()},
                                   lin.weight.detach().numpy(), lin.bias.detach().numpy())
+    P_mod = DS.emod_params_from_state_dict({k: v.detach().numpy() for k, v in e_mod.state_dict().items()})
 
     def one():
+        rows, mod_cache = DS.emod_forward(P_mod, x_rows, counts)
         scores, cache = DS.forward(P, x_map, csr, True)
         out, att, gate, amax = A.forward(rows, row_idx, scores, csr, gw, gb, True)
-        _, g_compat, _, _ = A.backward(gout, rows, row_idx, scores, csr, att, gate, amax, gw, gb, True)
+        fused = DS.fusion_concat_forward(x_3d, out)
+        _, gout = DS.fusion_concat_backward(gfused, 4)
+        g_rows, g_compat, _, _ = A.backward(gout, rows, row_idx, scores, csr, att, gate, amax, gw, gb, True)
         DS.backward(P, cache, g_compat)
+        DS.emod_backward(P_mod, mod_cache, g_rows)
+        return fused
     one()
-    reps, t0 = 2, time.perf_counter()
+    reps, t0 = 1 if log2_points >= 19 else 2, time.perf_counter()
     for _ in range(reps):
         one()
     dt = (time.perf_counter() - t0) / reps
     return dict(value=n / dt, unit="points/s", cores=DS.num_threads(), kind="port",
-                sample=f"oracle/deepset_oracle.c + oracle/attention_oracle.c (C + OpenMP, fp32): DeepSetFeat + E_score "
-                       f"(train-mode BatchNorm) -> view gather + attention, forward + backward, N=2^{log2_points} "
-                       f"points x {views} views, C={C}, G={G}, {reps} steps, {dt:.3f} s/step (E_mod on the map rows "
-                       f"and the fusion are not included: < 1 % of the work)")
+                sample=f"oracle/deepset_oracle.c + oracle/attention_oracle.c (C + OpenMP, fp32, {DS.num_threads()} threads): "
+                       f"E_mod on the {R} map rows -> DeepSetFeat + E_score (train-mode BatchNorm) -> view gather + attention "
+                       f"-> fusion concat, forward + backward with every parameter gradient, S1 shapes at N=2^{log2_points} "
+                       f"points x {views} views (V={V}), C={C}, G={G}, {reps} timed step(s) after one warm-up, "
+                       f"{dt:.3f} s/step; the work is linear in V at fixed views per point, so points/s carries over to "
+                       f"N=2^20 (N chosen by the host memory: ~2.3 KB of fp32 activations per view)")
 
 
 def mapping_build_bench(device, n_images=32, n_points=200_000):
@@ -1004,7 +1041,7 @@ def main():
         default_workload = (args.log2_points == 20 and args.dtype == "bf16" and args.workload == "S1"
                             and args.channels == 64 and args.views == 32 and not args.materialize
                             and not args.strong and not args.interpolate and args.out_channels is None)
-        traffic = pmc_traffic(name, default_workload)
+        traffic, traffic_why = pmc_traffic(name, default_workload)
         chain = "chain_attn_fwd" in kern
         res = {
             "metric": "points/sec fused fwd+bwd (1M pts, 32 views)",
@@ -1028,10 +1065,10 @@ def main():
                                 "(SURVEY.md 8(e)); all-reduced (RCCL) on a side stream under the backward of every step"}},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": None if traffic is None else
-                         "profiles/pmc_traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                         "command, bytes per launch, FETCH_SIZE x2 (gfx950 correction), KiB units calibrated on the "
-                         "copy kernel of the same run",
+                         "traffic_source": traffic_why if traffic is None else
+                         "profiles/pmc_traffic_latest.json (stamp = sha256 of the kernel sources, checked against this "
+                         "build): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, "
+                         "FETCH_SIZE x2 (gfx950 correction), KiB units calibrated on the copy kernel of the same run",
                          "avg_launch_ms": avg_ms, "launches": k["launches"],
                          "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
                          "note": ROOFLINE_NOTES.get(name, ROOFLINE_NOTES["*"]) if chain else None},
@@ -1064,7 +1101,7 @@ def main():
                 "bound": "hbm", "kernel": tname, "achieved": t_ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS, "avg_launch_ms": t_ms, "launches": tk["launches"],
                 "algorithmic_bytes_per_launch": nb, "frac_of_copy_ceiling": t_ach / res["hbm_copy_GBps"],
-                "traffic": pmc_traffic(tname, default_workload),
+                "traffic": pmc_traffic(tname, default_workload)[0],
                 "note": "x_map + value rows in -> pooled features out in ONE kernel (DeepSetFeat scores, softmax, row "
                         "gather, weighted sum, gate); SURVEY.md 8(d) bytes V (C s + 32 + 8) + N (C s + 8), every "
                         "gathered row counted as an HBM read although the rows of this workload come out of a 33 MB "
@@ -1098,13 +1135,21 @@ def main():
                 "nonexact": nonexact_workload(device),
             }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_log2_points, views, C, min(os.cpu_count() or 1, 64))
+            # cpu_baseline.value = the build's own C + OpenMP restatement of the WHOLE step on all host
+            # cores; the PyTorch-CPU op sequence (dispatch-bound, effectively one core) and the
+            # gather + attention-only twin are sub-keys
+            threads = min(os.cpu_count() or 1, 64)
+            mem = _host_mem_available_gb()
+            log2_cpu = min(args.log2_points, 20 if mem > 200 else 19 if mem > 100 else 18 if mem > 40 else 16)
             try:
+                res["cpu_baseline"] = cpu_full_path_twin(log2_cpu, views, C)
+                res["cpu_baseline"]["host"] = {"os_cpu_count": os.cpu_count(), "mem_available_GB": mem,
+                                               "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")}
                 res["cpu_baseline"]["gather_attention_openmp_twin"] = cpu_gather_attention_twin(
                     min(args.log2_points, 18), views, C)
-                res["cpu_baseline"]["full_path_openmp_twin"] = cpu_full_path_twin(min(args.log2_points, 17), views, C)
             except OSError as e:         # the oracle library is built by __graft_entry__.build()
-                res["cpu_baseline"]["gather_attention_openmp_twin"] = {"error": str(e)}
+                res["cpu_baseline"] = {"error": str(e)}
+            res["cpu_baseline"]["pytorch_oracle"] = cpu_baseline(args.cpu_log2_points, views, C, threads)
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.barrier()

@@ -232,6 +232,22 @@ def load():
     return lib
 
 
+def source_sha256():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, csrc/*.h, include/dva.h; names + bytes,
+    sorted): what ties a measurement file (profiles/pmc_traffic_latest.json) to the build it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "dva.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def check(rc, what):
     if rc != 0:
         raise DvaError(f"{what} failed: {_ERRORS.get(rc, rc)}", code=rc)

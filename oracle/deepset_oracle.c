@@ -274,3 +274,148 @@ void oracle_score_bwd(const float* a6, const float* dc, int64_t V, int G, const 
   }
   free(part);
 }
+
+/* ---- E_mod on the MAP rows (the nearest gather of an exact mapping commutes with the row-wise MLP: DESIGN.md "E_mod
+ * hoisting"; reference E_mod = MLP([in_mod, out_mod, out_mod]) applied to the gathered [V, C] rows, pooling.py:245,275)
+ * and the fusion concat (modules/multimodal/fusion.py:33-53).  A map row that cnt[r] views read counts cnt[r] times in
+ * the train-mode batch statistics, so the result equals the per-view evaluation the reference runs (pinned by
+ * tests/test_oracle_deepset_c.py against the per-view PyTorch restatement).  Generic widths K -> O (O <= 512). */
+#define WMAX 512
+void oracle_wblock_fwd(const float* x, const float* cnt, int64_t M, int K, int O, const float* W, const float* gamma,
+                       const float* beta, float eps, float* z, float* a, float* mean, float* invstd) {
+  double s0 = 0.0, s1[WMAX] = {0}, s2[WMAX] = {0};
+#pragma omp parallel
+  {
+    double t0 = 0.0, t1[WMAX] = {0}, t2[WMAX] = {0};
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < M; ++r) {
+      const float* xr = x + r * K;
+      float* zr = z + r * O;
+      const double c = cnt[r];
+      for (int o = 0; o < O; ++o) {
+        const float* w = W + (int64_t)o * K;
+        float acc = 0.f;
+#pragma omp simd reduction(+ : acc)
+        for (int k = 0; k < K; ++k) acc += xr[k] * w[k];
+        zr[o] = acc;
+        t1[o] += c * acc;
+        t2[o] += c * (double)acc * acc;
+      }
+      t0 += c;
+    }
+#pragma omp critical
+    {
+      s0 += t0;
+      for (int o = 0; o < O; ++o) { s1[o] += t1[o]; s2[o] += t2[o]; }
+    }
+  }
+  float g[WMAX], b[WMAX];
+  for (int o = 0; o < O; ++o) {
+    const double mu = s0 > 0 ? s1[o] / s0 : 0.0;
+    double var = s0 > 0 ? s2[o] / s0 - mu * mu : 0.0;
+    if (var < 0) var = 0;
+    mean[o] = (float)mu;
+    invstd[o] = (float)(1.0 / sqrt(var + (double)eps));
+    g[o] = gamma[o] * invstd[o];
+    b[o] = beta[o] - mean[o] * g[o];
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < M; ++r)
+    for (int o = 0; o < O; ++o) {
+      const float y = fmaf(z[r * O + o], g[o], b[o]);
+      a[r * O + o] = y > 0.f ? y : 0.2f * y;
+    }
+}
+
+/* da [M][O] = dL/da of the map rows (already summed over the views of a row) -> dx [M][K] (nullable), dW [O][K], dgamma,
+ * dbeta.  With mu, sigma weighted by cnt:  dz[r] = g (dy[r] - cnt[r]/V S1 - cnt[r]/V zh[r] S2),  S1 = sum dy, S2 = sum dy zh */
+void oracle_wblock_bwd(const float* x, const float* z, const float* da, const float* cnt, int64_t M, int K, int O,
+                       const float* W, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                       float* dx, float* dW, float* dgamma, float* dbeta) {
+  double s0 = 0.0, s1[WMAX] = {0}, s2[WMAX] = {0};
+  float g[WMAX], b[WMAX];
+  for (int o = 0; o < O; ++o) {
+    g[o] = gamma[o] * invstd[o];
+    b[o] = beta[o] - mean[o] * g[o];
+  }
+#pragma omp parallel
+  {
+    double t0 = 0.0, t1[WMAX] = {0}, t2[WMAX] = {0};
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < M; ++r) {
+      for (int o = 0; o < O; ++o) {
+        const float zz = z[r * O + o];
+        const float y = fmaf(zz, g[o], b[o]);
+        const float dy = y > 0.f ? da[r * O + o] : 0.2f * da[r * O + o];
+        t1[o] += dy;
+        t2[o] += (double)dy * ((zz - mean[o]) * invstd[o]);
+      }
+      t0 += cnt[r];
+    }
+#pragma omp critical
+    {
+      s0 += t0;
+      for (int o = 0; o < O; ++o) { s1[o] += t1[o]; s2[o] += t2[o]; }
+    }
+  }
+  float k1[WMAX], k2[WMAX];
+  for (int o = 0; o < O; ++o) {
+    dbeta[o] = (float)s1[o];
+    dgamma[o] = (float)s2[o];
+    k1[o] = s0 > 0 ? (float)(s1[o] / s0) : 0.f;
+    k2[o] = s0 > 0 ? (float)(s2[o] / s0) : 0.f;
+  }
+  const int nt = oracle_deepset_num_threads();
+  double* part = (double*)calloc((size_t)nt * O * K, sizeof(double));        /* [thread][o][k] */
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    double* mine = part + (size_t)omp_get_thread_num() * O * K;
+#else
+    double* mine = part;
+#endif
+    float dz[WMAX];
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < M; ++r) {
+      const float* xr = x + r * K;
+      const float c = cnt[r];
+      for (int o = 0; o < O; ++o) {
+        const float zz = z[r * O + o];
+        const float y = fmaf(zz, g[o], b[o]);
+        const float dy = y > 0.f ? da[r * O + o] : 0.2f * da[r * O + o];
+        const float zh = (zz - mean[o]) * invstd[o];
+        dz[o] = g[o] * (dy - c * k1[o] - c * zh * k2[o]);
+        double* m = mine + (size_t)o * K;
+        for (int k = 0; k < K; ++k) m[k] += (double)dz[o] * xr[k];
+      }
+      if (dx)
+        for (int k = 0; k < K; ++k) {
+          float acc = 0.f;
+          for (int o = 0; o < O; ++o) acc = fmaf(dz[o], W[(int64_t)o * K + k], acc);
+          dx[r * K + k] = acc;
+        }
+    }
+  }
+  for (int i = 0; i < O * K; ++i) {
+    double acc = 0.0;
+    for (int t = 0; t < nt; ++t) acc += part[(size_t)t * O * K + i];
+    dW[i] = (float)acc;
+  }
+  free(part);
+}
+
+/* BimodalFusion('concatenation'): out [N][A + C] = [x_3d | x_pool]; backward = the two column blocks of the gradient */
+void oracle_fusion_concat_fwd(const float* x3d, const float* xpool, int64_t N, int A, int C, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t p = 0; p < N; ++p) {
+    memcpy(out + p * (A + C), x3d + p * A, sizeof(float) * (size_t)A);
+    memcpy(out + p * (A + C) + A, xpool + p * C, sizeof(float) * (size_t)C);
+  }
+}
+void oracle_fusion_concat_bwd(const float* dout, int64_t N, int A, int C, float* dx3d, float* dxpool) {
+#pragma omp parallel for schedule(static)
+  for (int64_t p = 0; p < N; ++p) {
+    memcpy(dx3d + p * A, dout + p * (A + C), sizeof(float) * (size_t)A);
+    memcpy(dxpool + p * C, dout + p * (A + C) + A, sizeof(float) * (size_t)C);
+  }
+}

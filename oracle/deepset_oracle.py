@@ -27,7 +27,11 @@ def lib():
                            ("oracle_concat_fwd", [vp, vp, vp, i64, vp]),
                            ("oracle_concat_bwd", [vp, vp, i64, vp, vp]),
                            ("oracle_score_fwd", [vp, i64, i32, vp, vp, vp]),
-                           ("oracle_score_bwd", [vp, vp, i64, i32, vp, vp, vp, vp])):
+                           ("oracle_score_bwd", [vp, vp, i64, i32, vp, vp, vp, vp]),
+                           ("oracle_wblock_fwd", [vp, vp, i64, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]),
+                           ("oracle_wblock_bwd", [vp, vp, vp, vp, i64, i32, i32] + [vp] * 9),
+                           ("oracle_fusion_concat_fwd", [vp, vp, i64, i32, i32, vp]),
+                           ("oracle_fusion_concat_bwd", [vp, i64, i32, i32, vp, vp])):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = args
         _lib = L
@@ -127,3 +131,56 @@ def backward(P, cache, dscores):
     da1, out["mlp_elt_1.1"] = _block_bwd(da2, P["mlp_elt_1.1"], s2)
     _, out["mlp_elt_1.0"] = _block_bwd(da1, P["mlp_elt_1.0"], s1, need_dx=False)
     return out
+
+
+# ---- E_mod on the map rows + fusion concat (the rest of the pooling step around DeepSetFeat + attention)
+def emod_params_from_state_dict(sd):
+    """[(W, gamma, beta)] * 2 from the state dict of E_mod = MLP([in_mod, out_mod, out_mod], bias=False)."""
+    return [(_f(sd[f"{i}.0.weight"]), _f(sd[f"{i}.1.batch_norm.weight"]), _f(sd[f"{i}.1.batch_norm.bias"]))
+            for i in range(2)]
+
+
+def emod_forward(P_mod, rows, counts, eps=1e-5):
+    """E_mod(rows) on the R map rows, train-mode batch statistics weighted by ``counts`` (views per row)."""
+    x, cnt = _f(rows), _f(counts)
+    saved = []
+    for W, g, b in P_mod:
+        M, K, O = x.shape[0], x.shape[1], W.shape[0]
+        z, a = np.empty((M, O), np.float32), np.empty((M, O), np.float32)
+        mean, inv = np.empty(O, np.float32), np.empty(O, np.float32)
+        lib().oracle_wblock_fwd(_p(x), _p(cnt), M, K, O, _p(W), _p(g), _p(b), eps, _p(z), _p(a), _p(mean), _p(inv))
+        saved.append((x, z, mean, inv))
+        x = a
+    return x, dict(saved=saved, cnt=cnt)
+
+
+def emod_backward(P_mod, cache, drows_out, need_dx=True):
+    """Gradients [(dW, dgamma, dbeta)] * 2 and d(rows) [R, C_in] from the gradient of E_mod's output rows."""
+    da, cnt, grads = _f(drows_out), cache["cnt"], [None, None]
+    for i in (1, 0):
+        W, g, b = P_mod[i]
+        x, z, mean, inv = cache["saved"][i]
+        M, K, O = x.shape[0], x.shape[1], W.shape[0]
+        dx = np.empty((M, K), np.float32) if (i > 0 or need_dx) else None
+        dW, dg, db = np.empty((O, K), np.float32), np.empty(O, np.float32), np.empty(O, np.float32)
+        lib().oracle_wblock_bwd(_p(x), _p(z), _p(da), _p(cnt), M, K, O, _p(W), _p(g), _p(b), _p(mean), _p(inv), _p(dx),
+                                _p(dW), _p(dg), _p(db))
+        grads[i] = (dW, dg, db)
+        da = dx
+    return grads, da
+
+
+def fusion_concat_forward(x3d, xpool):
+    x3d, xpool = _f(x3d), _f(xpool)
+    N, A, C = x3d.shape[0], x3d.shape[1], xpool.shape[1]
+    out = np.empty((N, A + C), np.float32)
+    lib().oracle_fusion_concat_fwd(_p(x3d), _p(xpool), N, A, C, _p(out))
+    return out
+
+
+def fusion_concat_backward(dout, A):
+    dout = _f(dout)
+    N, C = dout.shape[0], dout.shape[1] - A
+    dx3d, dxpool = np.empty((N, A), np.float32), np.empty((N, C), np.float32)
+    lib().oracle_fusion_concat_bwd(_p(dout), N, A, C, _p(dx3d), _p(dxpool))
+    return dx3d, dxpool

@@ -876,6 +876,10 @@ def gen_neighborhood():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    # bit-reproducible files: one thread and deterministic CPU algorithms -- the multi-threaded
+    # index_add / scatter-add of the reference's backward sums in a run-dependent order (1 ulp in grad_x)
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
     torch.manual_seed(0)
     np.random.seed(0)
     only = set(sys.argv[1:])

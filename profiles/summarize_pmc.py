@@ -43,6 +43,10 @@ def main(src, dst):
         res["_calibration"] = {"kernel": "copy_kernel", "known_read_bytes": COPY_BYTES, "known_write_bytes": COPY_BYTES,
                                "read_measured_over_known": c["fetch_bytes_corrected"] / COPY_BYTES,
                                "write_measured_over_known": c["write_bytes"] / COPY_BYTES}
+    # what build these counters belong to (bench.py prints traffic only when the sources it runs hash to the same value)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepviewagg_amd import _lib
+    res["_stamp"] = {"csrc_sha256": _lib.source_sha256()}
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
         if k.startswith("_"):
