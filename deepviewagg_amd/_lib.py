@@ -157,12 +157,14 @@ SIGNATURES = {
     "dva_emod_bwd": (ctypes.c_int, [_i32] + [_vp] * 16 + [_i64, _i64, _i64, _i32, _i32, _vp]),
     "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_copy_ceiling": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
+    "dva_zero_unseen_rows": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "dva_chain_bn_consts": (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                            _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dva_concat_cast_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dva_concat_cast_bwd": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "dva_mapping_row_index": (ctypes.c_int, [_vp, _vp, _vp, _i32, ctypes.c_double, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dva_view_gather_rows_grad_rec16": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "dva_view_gather_rows_grad_rec16_to": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp]),
     "dva_chain_tile_chunks": (ctypes.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "dva_chain_tile_offsets": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "dva_bn_bwd_consts": (ctypes.c_int, [_vp, _vp, ctypes.c_double, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -972,12 +972,14 @@ static int bwd_impl(const void* gout, const void* val, const int32_t* row_idx, f
 // ------------------------------------------------------------------------------------------------
 // REC16: rec holds packed 16-byte records {int32 point, 4 x bf16 gate * attention, 4 bytes unused} (G <= 4) instead of
 // fp32 records of stride rs.
-template <typename T, bool REC16 = false>
+// TO = float: fp32 rows out; TO = T (bf16 grad_out, REC16 callers whose map is bf16): the row is rounded where it is
+// summed -- no fp32 [R, C] tensor and no conversion pass behind the kernel (round 5: 64 us of a 3.3 ms step at C = 512)
+template <typename T, bool REC16 = false, typename TO = float>
 __global__ __launch_bounds__(256) void rows_grad_team_kernel(
     const T* __restrict__ gout, const float* __restrict__ att, const float* __restrict__ gate,
     const int32_t* __restrict__ vp, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ row_ptr, const float* __restrict__ rec, int rs,
-    float* __restrict__ grows, int64_t R, int C, int G, int lpr, int lpg, int c0 = 0) {
+    TO* __restrict__ grows, int64_t R, int C, int G, int lpr, int lpg, int c0 = 0) {
   // C = row stride in elements; a launch covers the channels [c0, c0 + lpr * VEC) of every row (c0 = 0, lpr * VEC = C:
   // whole rows; channel slabs: dva_view_gather_rows_grad_rec16)
   constexpr int VEC = Vec16<T>::N;
@@ -1052,22 +1054,26 @@ __global__ __launch_bounds__(256) void rows_grad_team_kernel(
       for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off);
     }
     if (slot == 0) {
-      float* dst = grows + r * C + col;
+      if constexpr (sizeof(TO) == 4) {
+        float* dst = reinterpret_cast<float*>(grows) + r * C + col;
 #pragma unroll
-      for (int k = 0; k < VEC; k += 4)
-        *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+        for (int k = 0; k < VEC; k += 4)
+          *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+      } else {
+        *reinterpret_cast<raw_t*>(reinterpret_cast<T*>(grows) + r * C + col) = Vec16<T>::pack(acc);
+      }
     }
   }
 }
 
 // Sparse row plans (at most ~2 views per row: the identity gather of a view-level tensor, ops.gather_segment_max): one
 // lane team per ROW instead of one wavefront per row -- 64 / lpr rows per wavefront, no cross-slot reduction.
-template <typename T>
+template <typename T, typename TO = float>
 __global__ __launch_bounds__(256) void rows_grad_short_rec16_kernel(const T* __restrict__ gout,
                                                                      const int32_t* __restrict__ perm,
                                                                      const int32_t* __restrict__ row_ptr,
                                                                      const uint32_t* __restrict__ rec,
-                                                                     float* __restrict__ grows, int64_t R, int C, int lpr,
+                                                                     TO* __restrict__ grows, int64_t R, int C, int lpr,
                                                                      int lpg) {
   constexpr int VEC = Vec16<T>::N;
   typedef typename Vec16<T>::raw raw_t;
@@ -1093,10 +1099,14 @@ __global__ __launch_bounds__(256) void rows_grad_short_rec16_kernel(const T* __r
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] = fmaf(f[k], sc, acc[k]);
     }
-    float* dst = grows + r * C + col;
+    if constexpr (sizeof(TO) == 4) {
+      float* dst = reinterpret_cast<float*>(grows) + r * C + col;
 #pragma unroll
-    for (int k = 0; k < VEC; k += 4)
-      *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+      for (int k = 0; k < VEC; k += 4)
+        *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+    } else {
+      *reinterpret_cast<raw_t*>(reinterpret_cast<T*>(grows) + r * C + col) = Vec16<T>::pack(acc);
+    }
   }
 }
 
@@ -1513,10 +1523,11 @@ int dva_view_gather_attention_bwd(const void* grad_out, const void* rows, const 
                              n_views, C, G, scaling, dtype, algo, stream);
 }
 
-int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
-                                    const void* view_rec16, float* grad_rows, int64_t n_rows, int64_t n_views,
-                                    int32_t C, int32_t G, int32_t dtype, void* stream) {
+static int rows_grad_rec16_impl(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                                const void* view_rec16, void* grad_rows, int32_t out_dtype, int64_t n_rows,
+                                int64_t n_views, int32_t C, int32_t G, int32_t dtype, void* stream) {
   if (n_rows < 0 || n_views < 0 || C <= 0 || G <= 0 || G > 4 || (G & (G - 1))) return DVA_ERR_INVALID;
+  if (out_dtype != DVA_F32 && out_dtype != DVA_BF16) return DVA_ERR_INVALID;
   if (n_views > 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
   if (n_rows == 0) return DVA_OK;
   if (!row_ptr || !grad_rows) return DVA_ERR_INVALID;
@@ -1532,23 +1543,49 @@ int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, c
   int slab = slab_env;
   if (slab <= 0 || slab >= C || (slab % 8) || !is_pow2(slab / 8) || (C % slab)) slab = C;
   const int lpr_s = slab / 8;
+  const bool to_bf16 = out_dtype == DVA_BF16;
   if (n_views <= 2 * n_rows && lpr < 64) {
     // sparse plan (view-level identity gathers): a lane team per row
     const int64_t waves = (n_rows + (64 / lpr) - 1) / (64 / lpr);
-    hipLaunchKernelGGL((rows_grad_short_rec16_kernel<bf16_t>), dim3(grid_cap((waves + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)grad_out, perm, row_ptr, (const uint32_t*)view_rec16, grad_rows,
-                       n_rows, (int)C, lpr, lpr / G);
+    if (to_bf16)
+      hipLaunchKernelGGL((rows_grad_short_rec16_kernel<bf16_t, bf16_t>), dim3(grid_cap((waves + 3) / 4)), dim3(256), 0,
+                         (hipStream_t)stream, (const bf16_t*)grad_out, perm, row_ptr, (const uint32_t*)view_rec16,
+                         (bf16_t*)grad_rows, n_rows, (int)C, lpr, lpr / G);
+    else
+      hipLaunchKernelGGL((rows_grad_short_rec16_kernel<bf16_t>), dim3(grid_cap((waves + 3) / 4)), dim3(256), 0,
+                         (hipStream_t)stream, (const bf16_t*)grad_out, perm, row_ptr, (const uint32_t*)view_rec16,
+                         (float*)grad_rows, n_rows, (int)C, lpr, lpr / G);
     DVA_CHECK_LAUNCH();
     return DVA_OK;
   }
   for (int c0 = 0; c0 < C; c0 += slab) {
-    hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true>), dim3(grid_cap((n_rows + 3) / 4)),
-                       dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr,
-                       (const float*)nullptr, (const int32_t*)nullptr, perm, row_ptr, (const float*)view_rec16, 4,
-                       grad_rows, n_rows, (int)C, (int)G, lpr_s, lpr / G, c0);
+    if (to_bf16)
+      hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true, bf16_t>), dim3(grid_cap((n_rows + 3) / 4)),
+                         dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr,
+                         (const float*)nullptr, (const int32_t*)nullptr, perm, row_ptr, (const float*)view_rec16, 4,
+                         (bf16_t*)grad_rows, n_rows, (int)C, (int)G, lpr_s, lpr / G, c0);
+    else
+      hipLaunchKernelGGL((rows_grad_team_kernel<bf16_t, true>), dim3(grid_cap((n_rows + 3) / 4)),
+                         dim3(256), 0, (hipStream_t)stream, (const bf16_t*)grad_out, (const float*)nullptr,
+                         (const float*)nullptr, (const int32_t*)nullptr, perm, row_ptr, (const float*)view_rec16, 4,
+                         (float*)grad_rows, n_rows, (int)C, (int)G, lpr_s, lpr / G, c0);
   }
   DVA_CHECK_LAUNCH();
   return DVA_OK;
+}
+
+int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                                    const void* view_rec16, float* grad_rows, int64_t n_rows, int64_t n_views,
+                                    int32_t C, int32_t G, int32_t dtype, void* stream) {
+  return rows_grad_rec16_impl(grad_out, perm, row_ptr, view_rec16, grad_rows, DVA_F32, n_rows, n_views, C, G, dtype,
+                              stream);
+}
+
+int dva_view_gather_rows_grad_rec16_to(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                                       const void* view_rec16, void* grad_rows, int32_t out_dtype, int64_t n_rows,
+                                       int64_t n_views, int32_t C, int32_t G, int32_t dtype, void* stream) {
+  return rows_grad_rec16_impl(grad_out, perm, row_ptr, view_rec16, grad_rows, out_dtype, n_rows, n_views, C, G, dtype,
+                              stream);
 }
 
 int dva_view_gather_rows_grad(const void* grad_out, const float* att, const float* gate,

@@ -75,14 +75,29 @@ __global__ __launch_bounds__(256, 2) void set_kernel(
   const int64_t tiles = (N + 31) / 32;
   const int64_t wave = rfl((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // The passes are latency-bound (32 k tiles over ~2 k resident wavefronts, every tile a dependent load -> six to
+  // fifteen products): the rows of the NEXT tile of the wavefront (pooled, du, the CSR pair of the set size) are
+  // requested before the current tile is computed (round 5).  Rows beyond N read zeros through the buffer bounds.
+  float xn[16], dn[16];
+  int64_t cnt_n = 0;
+  auto request = [&](int64_t t) {
+    const int64_t p = t * 32 + j;
+    const bool ok = p < N;
+    load_rows16(PL, ok, (uint32_t)p, h, xn);
+    if (DIR == 1) load_rows16(DU, ok, (uint32_t)p, h, dn);
+    cnt_n = (w33 && ok) ? ptr[p + 1] - ptr[p] : 0;
+  };
+  request(wave);
   for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t p = t * 32 + j;
     const bool ok = p < N;
     const uint32_t keep = ok ? 0xffffffffu : 0u, row = (uint32_t)p;
-    float x[16], w3[16];
-    load_rows16(PL, ok, row, h, x);
+    float x[16], d[16], w3[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = xn[r]; d[r] = dn[r]; }
     float num = 0.f;
-    if (w33 && ok) num = sqrtf(1.f / ((float)(ptr[p + 1] - ptr[p]) + 1e-3f));
+    if (w33 && ok) num = sqrtf(1.f / ((float)cnt_n + 1e-3f));
+    request(t + n_waves);
     tab16(s_w33, 0, h, w3);
     // ---- forward: s1 = Wsa [pooled | num], a1 = act(BN(s1)), s2 = Wsb a1, a2 = act(BN(s2)), u = WcB a2
     const Split xs = split16(x, keep);
@@ -109,8 +124,7 @@ __global__ __launch_bounds__(256, 2) void set_kernel(
       continue;
     }
     // ---- backward
-    float d[16], dz[16], unused_st[2][16];
-    load_rows16(DU, ok, row, h, d);
+    float dz[16], unused_st[2][16];
     const Split ds = split16(d, keep);
     const f32x16 da2 = mm3(s_ops, SO_WCBT, lane, ds, zero);
     if (STAGE == 1) {
@@ -197,7 +211,8 @@ int dva_chain_set_fwd(int32_t stage, const float* pooled, const int64_t* ptr, co
     return DVA_ERR_INVALID;
   if (n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const int64_t tiles = (n_points + 31) / 32;
-  const int cap = chain_grid(2);
+  static const int bpc = tune_int("DVA_SET_FWD_BPC", 2);       // blocks per CU of the grid (read once)
+  const int cap = chain_grid(bpc);
   const dim3 grid((int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const float *b1 = bn_s1, *b2 = bn_s2;
@@ -224,7 +239,8 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
     return DVA_ERR_INVALID;
   if (n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const int64_t tiles = (n_points + 31) / 32;
-  const int cap = chain_grid(2);
+  static const int bpc = tune_int("DVA_SET_BWD_BPC", 2);       // blocks per CU of the grid (read once)
+  const int cap = chain_grid(bpc);
   const dim3 grid((int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define DVA_SET_BWD(ST_)                                                                                          \

@@ -94,29 +94,42 @@ static int key_bits(int64_t n_rows) {
 
 // Row keys of 17 / 18 bits (e.g. 32 feature maps of 64 x 128): two onesweep passes of 9 bits instead of the library's
 // 8 + 8 + 2 (one pass over the 33 M (row, view) pairs less).
-typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
-                                                                       rocprim::kernel_config<1024, 8>, 9,
-                                                                       rocprim::block_radix_rank_algorithm::match>>
-    PlanSort9;
+// Below 2^20 keys the library switches to a merge sort (block sort + 2 kernels per doubling: 21 launches of 6-13 us =
+// 0.15 ms for the 8.8e5 views of the reference's own S3DIS batch, profiles/r04x_s3dis_kernel_stats.csv): the plan sorts
+// carry their own limit (MERGE_LIMIT) and, under 4 M keys, smaller onesweep blocks (4096 keys instead of 8192: twice
+// the blocks for the same keys -- a plan of 1 M keys is only 128 of the large ones on 256 CUs) (round 5).
+constexpr size_t MERGE_LIMIT = 1 << 15;
+template <int BITS, int BLOCK>
+using PlanSortCfg =
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                               rocprim::radix_sort_onesweep_config<rocprim::kernel_config<BLOCK, 8>,
+                                                                   rocprim::kernel_config<BLOCK, 8>, BITS,
+                                                                   rocprim::block_radix_rank_algorithm::match>,
+                               MERGE_LIMIT>;
+typedef PlanSortCfg<9, 1024> PlanSort9;
+typedef PlanSortCfg<9, 512> PlanSort9s;
 static inline bool plan_wide_digits(int bits) { return bits == 17 || bits == 18; }
 // 19 / 20 bits (the anchor plan of the bilinear backward: 32 x 65 x 129 padded cells): two passes of 10 bits
-typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>,
-                                                                       rocprim::kernel_config<1024, 8>, 10,
-                                                                       rocprim::block_radix_rank_algorithm::match>>
-    PlanSort10;
+typedef PlanSortCfg<10, 1024> PlanSort10;
+typedef PlanSortCfg<10, 512> PlanSort10s;
 static inline bool plan_wider_digits(int bits) { return bits == 19 || bits == 20; }
+// everything else: the library's own (architecture-tuned) onesweep configuration with the plan's merge limit
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, MERGE_LIMIT>
+    PlanSortLib;
+constexpr size_t SMALL_PLAN = (size_t)1 << 22;
 
 // values in = the view numbers 0 .. n-1 as a counting iterator (no iota array is written or read)
 static hipError_t plan_sort(void* temp, size_t& tmp, const uint32_t* kin, uint32_t* kout, int32_t* vout, size_t n,
                             int bits, hipStream_t s) {
   rocprim::counting_iterator<int32_t> vin(0);
+  const bool small = n < SMALL_PLAN;
   if (plan_wide_digits(bits))
-    return rocprim::radix_sort_pairs<PlanSort9>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
+    return small ? rocprim::radix_sort_pairs<PlanSort9s>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s)
+                 : rocprim::radix_sort_pairs<PlanSort9>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
   if (plan_wider_digits(bits))
-    return rocprim::radix_sort_pairs<PlanSort10>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
-  return rocprim::radix_sort_pairs(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
+    return small ? rocprim::radix_sort_pairs<PlanSort10s>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s)
+                 : rocprim::radix_sort_pairs<PlanSort10>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
+  return rocprim::radix_sort_pairs<PlanSortLib>(temp, tmp, kin, kout, vin, vout, n, 0, bits, s);
 }
 
 static int plan_layout(int64_t n, int bits, PlanLayout* L) {

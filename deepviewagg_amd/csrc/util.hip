@@ -1,7 +1,21 @@
-// Measurement helpers of the C ABI (not on the product path).
+// Small helpers of the C ABI: the copy-ceiling measurement and the zero rows of points without views.
 #include "dva_common.h"
 
 namespace dva {
+// Pooled rows of points WITHOUT views are exact zeros (torch_scatter's empty-segment convention, reference
+// modules/multimodal/pooling.py:870): the view kernels only write points that have views, so the rows of the others are
+// cleared here -- 16-byte stores to those rows only (a tenth of the points on ragged scenes, none on the headline scene)
+// instead of a fill of the whole [N, C] tensor in front of the view kernel (round 5).
+__global__ __launch_bounds__(256) void zero_unseen_rows_kernel(const int64_t* __restrict__ ptr,
+                                                               uint4* __restrict__ out, int64_t N, int chunks) {
+  // `chunks` 16-byte pieces per row; a thread owns one piece of one point
+  const int64_t total = N * chunks;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / chunks;
+    if (ptr[p + 1] == ptr[p]) out[t] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 // Device copy (read + write): the practical HBM ceiling the roofline fractions are quoted beside.  One contiguous chunk of
 // 4 x 256 x 16 bytes per block, blocks sweeping the buffer in launch order, 4 non-temporal loads in flight per thread
 // before the first (non-temporal) store: 6.35 TB/s on MI355X (MI355X_MICROARCH.md: 6.29 for this pattern; 8 TB/s spec).
@@ -35,6 +49,19 @@ extern "C" int dva_copy_ceiling(const void* src, void* dst, int64_t nbytes, void
   if (blocks > 0x7fffffffll) return DVA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(dva::copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (const dva::copy_u4*)src, (dva::copy_u4*)dst, n);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+extern "C" int dva_zero_unseen_rows(const int64_t* ptr, void* out, int64_t n_points, int64_t row_bytes, void* stream) {
+  if (n_points < 0 || row_bytes <= 0 || (row_bytes & 15) || row_bytes > (1 << 20)) return DVA_ERR_INVALID;
+  if (n_points == 0) return DVA_OK;
+  if (!ptr || !out || ((uintptr_t)out & 15)) return DVA_ERR_INVALID;
+  const int chunks = (int)(row_bytes / 16);
+  int64_t blocks = (n_points * chunks + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dva::zero_unseen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ptr,
+                     (uint4*)out, n_points, chunks);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

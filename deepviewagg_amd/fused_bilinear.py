@@ -135,7 +135,7 @@ class _EmodPool(torch.autograd.Function):
             return s
         tab_a = ops.bn_table(stats(1, None), float(max(V, 1)), bn_a, training)
         tab_b = ops.bn_table(stats(2, tab_a), float(max(V, 1)), bn_b, training)
-        out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
+        out = fused_chain.pooled_output(csr_idx, N, C, dev)
         need_bwd = any(ctx.needs_input_grad)
         scores = torch.empty((V, 4), dtype=torch.float32, device=dev) if need_bwd else None
         # per view: z_a (train) or 4 taps of Y (C s each) + tap record 32 (eval), x_map 32, view -> point index 4

@@ -52,6 +52,15 @@ def applicable(module, x_mod, x_map, csr_idx=None):
     return V * 64 < (1 << 32) - 16 and R * C * 2 < (1 << 32) - 16 and N * max(C * 2, 128) < (1 << 32) - 16
 
 
+def pooled_output(csr_idx, N, C, dev):
+    """The bf16 [N, C] tensor the view kernel pools into: the rows of points WITHOUT views are cleared here (exact
+    zeros, pooling.py:870), the kernel writes every other row -- no fill of the whole tensor (round 5)."""
+    lib = _lib.load()
+    out = torch.empty((N, C), dtype=torch.bfloat16, device=dev)
+    check(lib.dva_zero_unseen_rows(ptr(csr_idx), ptr(out), N, C * 2, stream_of(out)), "dva_zero_unseen_rows")
+    return out
+
+
 def build_tiles(csr_idx, V):
     """Tile table of a CSR pointer array: (tiles int32 [T_max, 2], n_tiles int32 [1]), no host sync."""
     lib = _lib.load()
@@ -243,7 +252,7 @@ class _ChainPool(torch.autograd.Function):
         st = stream_of(x_map)
         S = chain_prologue(module, x_map, csr_idx)
         # ---- the fused view kernel
-        out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
+        out = pooled_output(csr_idx, N, C, dev)
         # a backward will follow: the scores of every view stay (16 bytes per view) -- the attention backward starts from
         # them instead of evaluating the chain once more
         need_bwd = any(ctx.needs_input_grad)
@@ -359,7 +368,7 @@ class _ChainQKVPool(torch.autograd.Function):
         groups, scale = qk
         st = stream_of(x_map)
         S = chain_prologue(module, x_map, csr_idx)
-        out = torch.zeros((N, C), dtype=torch.bfloat16, device=dev)
+        out = pooled_output(csr_idx, N, C, dev)
         need_bwd = any(ctx.needs_input_grad)
         scores = torch.empty((V, 4), dtype=torch.float32, device=dev) if need_bwd else None
         keys = torch.empty((V, D), dtype=torch.bfloat16, device=dev) if need_bwd else None

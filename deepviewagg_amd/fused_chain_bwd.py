@@ -206,12 +206,14 @@ def backward(ctx, gout):
         perm, row_ptr = plan
 
         def rows_grad(stream):
-            g = torch.empty((R, C), dtype=torch.float32, device=dev)
-            with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
-                check(lib.dva_view_gather_rows_grad_rec16(ptr(gout), None if planrec else ptr(perm), ptr(row_ptr),
-                                                          ptr(rec), ptr(g), R, V, C, G, _lib.DVA_BF16, stream),
-                      "dva_view_gather_rows_grad_rec16")
-            return g.to(rows.dtype)
+            # the row is rounded to the map's dtype where it is summed (round 5): no fp32 [R, C] tensor + conversion pass
+            g = torch.empty((R, C), dtype=rows.dtype, device=dev)
+            with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 2 + 4)):
+                check(lib.dva_view_gather_rows_grad_rec16_to(ptr(gout), None if planrec else ptr(perm), ptr(row_ptr),
+                                                             ptr(rec), ptr(g), _lib.dtype_code(g), R, V, C, G,
+                                                             _lib.DVA_BF16, stream),
+                      "dva_view_gather_rows_grad_rec16_to")
+            return g
         if OVERLAP_ROWS_GRAD:
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)

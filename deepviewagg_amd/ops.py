@@ -32,10 +32,16 @@ class KernelTimer:
     ``ops.TIMER = KernelTimer()``): records an event pair around every C-ABI launch together with the
     algorithmic bytes of that launch; ``summary()`` synchronises once and aggregates."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        # ``only``: names to time; every other launch goes out without events.  An event pair costs the stream ~6 us of
+        # bubble per launch on this part (rocprofv3 trace, round 5: 43 pairs = 0.27 ms of an 11.2 ms step), so a region
+        # whose WALL time matters times only the kernel(s) it reports on
         self.records = []
+        self.only = None if only is None else set(only)
 
     def launch(self, name, nbytes):
+        if self.only is not None and name not in self.only:
+            return _NO_TIMER
         return _TimedLaunch(self, name, nbytes)
 
     def summary(self):
@@ -972,15 +978,15 @@ class _ViewGatherAttention(torch.autograd.Function):
                     ptr(rec), ptr(gwb), N, V, R, C, G, scaling, ctx.eps, stream_of(rows)), "dva_chain_attn_bwd")
             plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
             perm, row_ptr = plan
-            grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
-            with _timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 4 + 4)):
-                check(lib.dva_view_gather_rows_grad_rec16(
-                    ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), R, V, C, G, dtype_code(rows),
-                    stream_of(rows)), "dva_view_gather_rows_grad_rec16")
+            grows = torch.empty((R, C), dtype=rows.dtype, device=rows.device)      # bf16: rounded where it is summed
+            with _timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 2 + 4)):
+                check(lib.dva_view_gather_rows_grad_rec16_to(
+                    ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), dtype_code(grows), R, V, C, G,
+                    dtype_code(rows), stream_of(rows)), "dva_view_gather_rows_grad_rec16_to")
             g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
             g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
             gcompat = dc if G == 4 else dc[:, :G].contiguous()
-            return grows.to(rows.dtype), None, gcompat, None, g_w, g_b, None, None, None
+            return grows, None, gcompat, None, g_w, g_b, None, None, None
         if need_rows and not use_plan:
             grows = torch.zeros((R, C), dtype=torch.float32, device=rows.device)
         else:
@@ -1041,7 +1047,7 @@ def _xty_splitk(a, b, splits=64):
     if R < 8192 or R % splits:
         return a.float().t() @ b.float()
     part = torch.bmm(a.view(splits, R // splits, -1).transpose(1, 2), b.view(splits, R // splits, -1))
-    return part.float().sum(0)
+    return part.sum(0, dtype=torch.float32)        # one reduction kernel (fp32 accumulation), no fp32 copy of `part`
 
 
 class _TallLinear(torch.autograd.Function):

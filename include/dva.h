@@ -222,6 +222,12 @@ int dva_view_gather_rows_grad(const void* grad_out, const float* att, const floa
 int dva_view_gather_rows_grad_rec16(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
                                     const void* view_rec16, float* grad_rows, int64_t n_rows, int64_t n_views,
                                     int32_t C, int32_t G, int32_t dtype, void* stream);
+/* The same with the output dtype chosen by the caller: out_dtype = DVA_F32 (as above) or DVA_BF16 -- the summed row is
+ * rounded once where it is summed, for maps that are bf16 anyway (the gradient autograd hands on has the map's dtype:
+ * core/multimodal/image.py:1262-1287 is an index_add in the map's dtype); no fp32 [n_rows, C] tensor, no conversion pass. */
+int dva_view_gather_rows_grad_rec16_to(const void* grad_out, const int32_t* perm, const int32_t* row_ptr,
+                                       const void* view_rec16, void* grad_rows, int32_t out_dtype, int64_t n_rows,
+                                       int64_t n_views, int32_t C, int32_t G, int32_t dtype, void* stream);
 
 /* Backward of a gather over the row plan (dva_row_plan): grad_rows[r, :] = sum over the plan entries e of row r
  * of weights[e] * grad_out[e >> atom_shift, :]  (fp32 [n_rows, C], written, not accumulated; deterministic).
@@ -729,6 +735,11 @@ int dva_concat_cast_bwd(const float* grad_out, float* grad_main, void* grad_mod,
 /* Measurement helper (bench.py): float4 grid-stride device copy of nbytes (multiple of 16) -- the practical HBM
  * ceiling (read + write) beside which the roofline fractions are quoted. */
 int dva_copy_ceiling(const void* src, void* dst, int64_t nbytes, void* stream);
+/* out[p, :] = 0 for every point p without views (ptr[p + 1] == ptr[p]); rows of the other points are not touched.
+ * out: n_points rows of row_bytes bytes (multiple of 16, 16-byte aligned).  The pooled features of unseen points are exact
+ * zeros (reference modules/multimodal/pooling.py:870, torch_scatter's empty segments); the view kernels write only the
+ * points that have views. */
+int dva_zero_unseen_rows(const int64_t* ptr, void* out, int64_t n_points, int64_t row_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * Voxel parent index after a strided sparse 3D convolution.  Replaces the torchsparse (v1.1.0, not in the

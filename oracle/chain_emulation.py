@@ -88,3 +88,31 @@ def emulated_chain(ref, vals, x_map, csr, dev_invstd=None, dev_scores=None, retu
         compat.retain_grad()
     out, _, _ = O.attention_tail(vals, compat, csr, ref.G, ref.num_groups, ref.out_mod, ref.group_scaling)
     return (out, compat if dev_scores is None else own) if return_scores else out
+
+
+def emulated_emod(ref, x, images, pixels, mapping_size):
+    """E_mod of the fused BILINEAR path with the roundings of csrc/chain_emod.hip made explicit (round 5; VERDICT r4
+    item 7): the per-view values ``E_mod(sparse_interpolation(x))`` [V, C_o] that ``emulated_chain`` takes as ``vals``.
+
+    Reference: sparse_interpolation (core/multimodal/image.py:105-170) -> E_mod = [Linear_a, BN_a, LeakyReLU, Linear_b,
+    BN_b, LeakyReLU] per view (modules/multimodal/pooling.py:245, :275).  Device arithmetic (fused_bilinear.py):
+      * Linear_a commutes with the interpolation: Y = x_rows . bf16(W_a)^T on the MAP rows (fp32 accumulation), stored as
+        bf16 -- the rounding the layer's output has under autocast;
+      * z_a[v] = sum_k w_k Y[tap_k(v)] in fp32 from the bf16 rows; TRAIN mode keeps it as bf16 [V, C_o] (every later pass
+        reads the stored row) and BatchNorm_a's batch statistics are those of the STORED values; eval mode uses the fp32
+        value (one kernel, nothing stored);
+      * y_a = leaky(BN_a(z_a)) enters Linear_b as a bf16 operand against bf16(W_b), fp32 accumulation;
+      * BatchNorm_b (not folded into the operand), LeakyReLU and the attention-weighted sum stay fp32.
+    ``x`` fp32 [B, C_in, H, W] with values on the bf16 grid (the feature maps are bf16 on the device)."""
+    lin_a, bn_a = ref.E_mod[0][0], ref.E_mod[0][1]
+    lin_b, bn_b = ref.E_mod[1][0], ref.E_mod[1][1]
+    B, C_in, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C_in)
+    Y = _bf(rows @ _bf(lin_a.weight).t())                                   # [R, C_o] map rows of Linear_a
+    y_map = Y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+    z_a = O.gather_bilinear(y_map, images, pixels, mapping_size)            # fp32 interpolation of the bf16 rows
+    if bn_a.batch_norm.training:
+        z_a = _bf(z_a)                                                      # the stored row; its statistics
+    y_a = F.leaky_relu(bn_a(z_a), 0.2)
+    z_b = _bf(y_a) @ _bf(lin_b.weight).t()
+    return F.leaky_relu(bn_b(z_b), 0.2)

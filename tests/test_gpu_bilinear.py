@@ -410,3 +410,81 @@ def test_anchor_scatter_workspace_chunks_and_gram_form():
                 ops.ANCHOR_WS_BYTES = None
             outs.append(g_)
         assert torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tight parity of the fused bilinear path, the WIDE levels included (round 5): the bf16-emulation oracle
+# of the recompute chain (oracle/chain_emulation.py, tests/test_gpu_chain.py) extended by E_mod's roundings -- Y = Linear_a
+# on the map rows stored as bf16, z_a stored as bf16 in train mode with BatchNorm_a's statistics taken from the stored
+# values, bf16 operands of Linear_b -- and held to the FIXED tolerances of test_gpu_chain.EMU_TOL (relative L2 per tensor)
+# instead of the autocast-relative gate above.  As there, the discrete decisions (rounding of the chain's folded
+# operands, arg-max views / gate branches) are shared with the device: dev_invstd, dev_scores.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sizes_fn,N,C_in,C_out,G,train", [
+    (ragged_long, 1200, 256, 128, 4, True),     # KITTI-360 pyramid level 256 -> 128 (block-by-block kernels)
+    (full32, 512, 64, 128, 1, True),
+    (ragged_long, 900, 160, 256, 4, True),      # level 512 -> 256 shape class (dz_b hand-off, cooperative dW_b)
+    (full32, 512, 64, 256, 4, True),
+    (ragged_long, 1200, 96, 256, 4, False),
+    (ragged, 3000, 64, 64, 4, True),            # the register-resident widths for comparison
+    (ragged_long, 1500, 128, 32, 4, True),
+])
+def test_fused_bilinear_matches_bf16_emulation(sizes_fn, N, C_in, C_out, G, train):
+    from deepviewagg_amd import ops
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    from oracle.chain_emulation import emulated_chain, emulated_emod
+    from test_gpu_chain import EMU_TOL
+    case = make_case(33, N, C_in, sizes_fn)
+    w = torch.randn(N, C_out, generator=case["gen"])
+    ref, m = build(case, C_out, G, train)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    V, csr = case["V"], case["csr"]
+    # ---- device: forward, the saved BatchNorm tables / scores, then the gradients
+    xd = case["x"].to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    atom_ptr = torch.arange(V + 1, device=DEV)
+    packed = ops.pack_gather_index(case["images"].to(DEV), atom_ptr, case["pixels"].to(DEV))
+    res = torch.tensor([case["msize"]], dtype=torch.float32, device=DEV)
+    coords = (case["pixels"].to(DEV) / (res - 1))[:, [1, 0]]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lazy = ops.lazy_gather_bilinear(xd, packed, coords, exact=True)
+        lazy = P.BimodalCSRPool(mode='max')(None, lazy, None, atom_ptr)
+        out = m(None, lazy, case["x_map"].to(DEV), csr.to(DEV))
+    assert type(out.grad_fn).__name__ == "_EmodPoolBackward", "the fused bilinear path must be the one that ran"
+    saved = out.grad_fn.saved_tensors          # fused_bilinear._EmodPool.forward: ... bn1 [13], bn2, bn5, bn6, out, scores [18]
+    dev_invstd = {1: saved[13][1].cpu(), 2: saved[14][1].cpu(), 6: saved[16][1].cpu()}
+    dev_scores = saved[18].cpu()[:, :G]
+    g = torch.autograd.grad((out.float() * w.to(DEV)).sum(), [xd] + list(m.parameters()), allow_unused=True)
+    # ---- emulation: own forward (output, scores), then the gradient leg at the device's scores
+    names = ["x"] + [n for n, _ in ref.named_parameters()]
+    with torch.no_grad():
+        vals = emulated_emod(ref, case["x"], case["images"], case["pixels"], case["msize"])
+        out_own, sc_own = emulated_chain(ref, vals, case["x_map"], csr, dev_invstd=dev_invstd, return_scores=True)
+    ref.load_state_dict(sd)
+    xr = case["x"].clone().requires_grad_()
+    vals = emulated_emod(ref, xr, case["images"], case["pixels"], case["msize"])
+    out_ref = emulated_chain(ref, vals, case["x_map"], csr, dev_invstd=dev_invstd, dev_scores=dev_scores)
+    g_ref = torch.autograd.grad((out_ref * w).sum(), [xr] + list(ref.parameters()), allow_unused=True)
+    r_out, r_sc = rel(out, out_own), rel(dev_scores, sc_own)
+    report, bad, par = [("out", round(r_out, 5)), ("scores", round(r_sc, 5))], [], []
+    for n, a, b in zip(names, g, g_ref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0, n
+            continue
+        assert a is not None, n
+        r = rel(a, b)
+        report.append((n, round(r, 5)))
+        if n != "x":
+            par.append(r)
+        if r > (EMU_TOL["rows"] if n == "x" else EMU_TOL["param_train" if train else "param_eval"]):
+            bad.append((n, r))
+    print("fused bilinear vs bf16 emulation, rel L2:", report)
+    import os
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/emu_report_bilinear_r5.txt", "a") as f:
+            f.write(f"{sizes_fn.__name__} N={N} C_in={C_in} C_out={C_out} G={G} train={train} {report}\n")
+    assert r_out < EMU_TOL["out"], report
+    assert r_sc < EMU_TOL["scores"], report
+    assert rel(out, out_ref) < EMU_TOL["out"], report
+    assert not bad, (bad, report)
+    if train:
+        assert sorted(par)[len(par) // 2] < EMU_TOL["param_train_median"], report

@@ -4,8 +4,9 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("ms/step", round(d["ms_per_step"], 3), " value", round(d["value"] / 1e6, 2), "M points/s")
 tot = 0
 for k, v in d["kernels"].items():
-    tot += v["avg_ms"] * v["launches"] / d["steps"]
-    print(f"{k:32s} {v['avg_ms']:.3f} ms  {v['GBps']:7.0f} GB/s  x{v['launches'] / d['steps']:.0f}/step")
+    per = v["launches_per_step"] if "launches_per_step" in v else v["launches"] / d["steps"]
+    tot += v["avg_ms"] * per
+    print(f"{k:32s} {v['avg_ms']:.3f} ms  {v['GBps']:7.0f} GB/s  x{per:.0f}/step")
 print("sum of timed kernels per step:", round(tot, 3), "ms")
 for k in ("roofline", "roofline_view_gather_attention"):
     if k in d:
