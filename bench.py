@@ -1001,7 +1001,7 @@ def main():
             standin.finish()
         return fused
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + 3):       # + 3: clock ramp / allocator growth of a fresh process, whatever W is
         one_step()
     # per-kernel table: PROFILE_STEPS more UNTIMED steps with HIP events around every launch.  The timed region below
     # carries events only around the kernels its roofline objects report on (the dominant kernel found here and the fused
@@ -1016,12 +1016,25 @@ def main():
     target_name = "chain_attn_fwd" if "chain_attn_fwd" in kern else "view_gather_attention_fwd"
     barrier()
     ops.TIMER = ops.KernelTimer(only={dom_name, target_name})
+    # one event per step boundary (6 us per step): the device-side duration of every timed step goes into the JSON line,
+    # so that a one-off stall (a 33 ms hiccup was seen once in twenty runs) is visible next to the wall-clock value
+    marks, host = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
+        host.append(time.perf_counter())
         fused = one_step()
+    end_mark = torch.cuda.Event(enable_timing=True)
+    end_mark.record()
+    marks.append(end_mark)
+    host.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    per_step_device_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+    per_step_host_ms = [(b - a) * 1e3 for a, b in zip(host[:-1], host[1:])]
     collective = None
     if use_dist:
         # what the collectives of the LAST step cost: duration on the side stream, and the part the main stream had to
@@ -1099,6 +1112,9 @@ def main():
             "kernels_source": f"{PROFILE_STEPS} untimed steps after the warm-up with HIP events around every launch; the "
                               f"timed region times only '{dom_name}' and '{target_name}' (an event pair costs ~6 us of "
                               "stream bubble per launch)",
+            "per_step_ms_device": [round(v, 3) for v in per_step_device_ms],
+            "per_step_ms_device_median": sorted(per_step_device_ms)[len(per_step_device_ms) // 2],
+            "host_enqueue_ms_per_step_median": sorted(per_step_host_ms)[len(per_step_host_ms) // 2],
             "step_algorithmic_GB": sum(v["bytes"] for v in kern.values()) / PROFILE_STEPS / 1e9,
             "hbm_copy_GBps": None,
             "gather_GBps": None,

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void set_prep_kernel(const float* __restrict__ 
 
 // w33 [32]: the set-size column of Wsa (use_num), nullptr otherwise.  DIR = 0 forward, 1 backward.
 template <int DIR, int STAGE>
-__global__ __launch_bounds__(256, 2) void set_kernel(
+__global__ __launch_bounds__(256, DIR == 0 ? 4 : 3) void set_kernel(
     const float* __restrict__ pooled, const int64_t* __restrict__ ptr, const float* __restrict__ w33,
     const uint4* __restrict__ ops, const float* __restrict__ bn_s1, const float* __restrict__ bn_s2,
     const float* __restrict__ sm_s1, const float* __restrict__ sm_s2, const float* __restrict__ du,
@@ -75,29 +75,19 @@ __global__ __launch_bounds__(256, 2) void set_kernel(
   const int64_t tiles = (N + 31) / 32;
   const int64_t wave = rfl((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  // The passes are latency-bound (32 k tiles over ~2 k resident wavefronts, every tile a dependent load -> six to
-  // fifteen products): the rows of the NEXT tile of the wavefront (pooled, du, the CSR pair of the set size) are
-  // requested before the current tile is computed (round 5).  Rows beyond N read zeros through the buffer bounds.
-  float xn[16], dn[16];
-  int64_t cnt_n = 0;
-  auto request = [&](int64_t t) {
-    const int64_t p = t * 32 + j;
-    const bool ok = p < N;
-    load_rows16(PL, ok, (uint32_t)p, h, xn);
-    if (DIR == 1) load_rows16(DU, ok, (uint32_t)p, h, dn);
-    cnt_n = (w33 && ok) ? ptr[p + 1] - ptr[p] : 0;
-  };
-  request(wave);
+  // (round 5, measured: requesting the rows of the wavefront's NEXT tile before the current one is computed changes
+  //  nothing -- 40 / 46 / 49 us forward, 129 / 105 / 99 us backward at 2^20 points either way -- and costs 32 registers,
+  //  i.e. the third wavefront per SIMD of the backward stages; SQ counters: the vector unit is busy 0.28 of a wave's
+  //  cycles at two wavefronts per SIMD, like the view passes at three: the passes are instruction-bound, so what pays is
+  //  residency -- grids of 4 (forward) / 3 (backward) blocks per CU instead of 2)
   for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t p = t * 32 + j;
     const bool ok = p < N;
     const uint32_t keep = ok ? 0xffffffffu : 0u, row = (uint32_t)p;
-    float x[16], d[16], w3[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = xn[r]; d[r] = dn[r]; }
+    float x[16], w3[16];
+    load_rows16(PL, ok, row, h, x);
     float num = 0.f;
-    if (w33 && ok) num = sqrtf(1.f / ((float)cnt_n + 1e-3f));
-    request(t + n_waves);
+    if (w33 && ok) num = sqrtf(1.f / ((float)(ptr[p + 1] - ptr[p]) + 1e-3f));
     tab16(s_w33, 0, h, w3);
     // ---- forward: s1 = Wsa [pooled | num], a1 = act(BN(s1)), s2 = Wsb a1, a2 = act(BN(s2)), u = WcB a2
     const Split xs = split16(x, keep);
@@ -124,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void set_kernel(
       continue;
     }
     // ---- backward
-    float dz[16], unused_st[2][16];
+    float d[16], dz[16], unused_st[2][16];
+    load_rows16(DU, ok, row, h, d);
     const Split ds = split16(d, keep);
     const f32x16 da2 = mm3(s_ops, SO_WCBT, lane, ds, zero);
     if (STAGE == 1) {
@@ -211,7 +202,7 @@ int dva_chain_set_fwd(int32_t stage, const float* pooled, const int64_t* ptr, co
     return DVA_ERR_INVALID;
   if (n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const int64_t tiles = (n_points + 31) / 32;
-  static const int bpc = tune_int("DVA_SET_FWD_BPC", 2);       // blocks per CU of the grid (read once)
+  static const int bpc = tune_int("DVA_SET_FWD_BPC", 4);       // blocks per CU of the grid (read once)
   const int cap = chain_grid(bpc);
   const dim3 grid((int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap)), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -239,7 +230,7 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
     return DVA_ERR_INVALID;
   if (n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const int64_t tiles = (n_points + 31) / 32;
-  static const int bpc = tune_int("DVA_SET_BWD_BPC", 2);       // blocks per CU of the grid (read once)
+  static const int bpc = tune_int("DVA_SET_BWD_BPC", 3);       // blocks per CU of the grid (read once)
   const int cap = chain_grid(bpc);
   const dim3 grid((int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap)), block(256);
   hipStream_t s = (hipStream_t)stream;

@@ -8,14 +8,22 @@ namespace dva {
 // instead of a fill of the whole [N, C] tensor in front of the view kernel (round 5).
 __global__ __launch_bounds__(256) void zero_unseen_rows_kernel(const int64_t* __restrict__ ptr,
                                                                uint4* __restrict__ out, int64_t N, int chunks) {
-  // `chunks` 16-byte pieces per row; a thread owns one piece of one point
-  const int64_t total = N * chunks;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = t / chunks;
-    if (ptr[p + 1] == ptr[p]) out[t] = make_uint4(0u, 0u, 0u, 0u);
+  // a wavefront looks at 64 points (one pointer pair per lane), then clears the rows of those without views with all its
+  // lanes: `chunks` 16-byte pieces per row, coalesced
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p0 = wave * 64; p0 < N; p0 += n_waves * 64) {
+    const int64_t p = p0 + lane;
+    unsigned long long m = __ballot(p < N && ptr[p + 1] == ptr[p]);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      uint4* row = out + (p0 + b) * chunks;
+      for (int c = lane; c < chunks; c += 64) row[c] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
-
 // Device copy (read + write): the practical HBM ceiling the roofline fractions are quoted beside.  One contiguous chunk of
 // 4 x 256 x 16 bytes per block, blocks sweeping the buffer in launch order, 4 non-temporal loads in flight per thread
 // before the first (non-temporal) store: 6.35 TB/s on MI355X (MI355X_MICROARCH.md: 6.29 for this pattern; 8 TB/s spec).
@@ -58,8 +66,8 @@ extern "C" int dva_zero_unseen_rows(const int64_t* ptr, void* out, int64_t n_poi
   if (n_points == 0) return DVA_OK;
   if (!ptr || !out || ((uintptr_t)out & 15)) return DVA_ERR_INVALID;
   const int chunks = (int)(row_bytes / 16);
-  int64_t blocks = (n_points * chunks + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
+  int64_t blocks = (n_points + 255) / 256;        // 64 points per wavefront and iteration
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(dva::zero_unseen_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ptr,
                      (uint4*)out, n_points, chunks);
   DVA_CHECK_LAUNCH();

@@ -123,7 +123,7 @@ class _EmodPool(torch.autograd.Function):
         plan = ops.anchor_plan(anchors, *bhw) if (training and ANCHOR_ORDER_STATS and C >= 64) else None
 
         def stats(layer, tab_a):
-            s = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            s = ops.zeros_small(2 * C, torch.float64, dev)
             if training and layer == 1 and plan is not None:
                 with ops._timed("emod_stats1", V * (4 + 32 + C * 2)):
                     check(lib.dva_emod_stats1_plan(ptr(Y), ptr(rows4), ptr(w4), ptr(plan[0]), ptr(s), ptr(za), V, R, C,
@@ -195,7 +195,7 @@ class _EmodPool(torch.autograd.Function):
         dc = torch.empty((V, 4), dtype=torch.float32, device=dev)
         rec = torch.empty((V, 4), dtype=torch.int32, device=dev)
         gwb = arena.take(2 * G) if gate is not None else None
-        stats_b = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        stats_b = ops.zeros_small(2 * C, torch.float64, dev)
         with ops._timed("emod_attn_bwd", za_bytes + V * (16 + 4 + 16 + 16) + N * (C * 2 + 8)):
             check(lib.dva_emod_attn_bwd(ptr(scores), ptr(vp), ptr(tiles), ptr(n_tiles), None, None, None,
                                         ptr(eops), ptr(tab_a), ptr(tab_b), ptr(csr_idx), ptr(gw), ptr(gb), ptr(gout),
@@ -206,7 +206,7 @@ class _EmodPool(torch.autograd.Function):
         # ---- E_mod backward: dW_b, dy_a handed over as bf16 [V, C], S of BatchNorm_a; then dz_a in place
         da = torch.empty((V, C), dtype=torch.bfloat16, device=dev)
         dWb = arena.take(C, C)
-        stats_a = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        stats_a = ops.zeros_small(2 * C, torch.float64, dev)
         def emod_bwd(stage, name, nbytes):
             with ops._timed(name, nbytes):
                 check(lib.dva_emod_bwd(stage, None, None, None, ptr(tiles), ptr(n_tiles), ptr(eops), ptr(tab_a),

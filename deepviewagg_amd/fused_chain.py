@@ -186,7 +186,7 @@ def chain_prologue(module, x_map, csr_idx):
     gw = gate.weight.detach().reshape(-1).float().contiguous() if gate is not None else None
     gb = gate.bias.detach().reshape(-1).float().contiguous() if gate is not None else None
 
-    zpool = iter(torch.zeros((10, 3 * D), dtype=torch.float64, device=dev))   # sum | sum of squares | input sums
+    zpool = iter(ops.zeros_small((11, 3 * D), torch.float64, dev))   # sum | sum of squares | input sums (+ moments)
 
     def zstats():
         return next(zpool)
@@ -200,7 +200,7 @@ def chain_prologue(module, x_map, csr_idx):
           "dva_chain_prep")
     # ---- layer 1: statistics from the moments of x_map
     s1 = zstats()
-    mom = torch.zeros(44, dtype=torch.float64, device=dev)
+    mom = zstats()[:44]
     if training:
         with ops._timed("chain_moments", V * 32):
             check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), 0, ptr(mom), ptr(s1), st), "dva_chain_moments")

@@ -15,7 +15,7 @@ class Arena:
     backward cost one fill launch instead of one each."""
 
     def __init__(self, device, n_floats=1 << 15):
-        self.buf = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        self.buf = ops.zeros_small(n_floats, torch.float32, device)
         self.used = 0
 
     def take(self, *shape):
@@ -53,7 +53,7 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
     bn1, bn2, bn5, bn6 = S.bn1, S.bn2, S.bn5, S.bn6
     st = stream_of(x_map)
     m_rows = float(max(V, 1))
-    zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
+    zpool = iter(ops.zeros_small((10, 2 * D), torch.float64, dev))
 
     def zstats():
         return next(zpool)

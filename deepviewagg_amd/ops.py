@@ -81,6 +81,39 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 TIMER = None
 
+# ---------------------------------------------------------------------------------------------
+# small zero-filled tensors (statistics accumulators, gradient arenas) without a fill launch each
+# ---------------------------------------------------------------------------------------------
+_ZERO_POOLS = {}
+_ZERO_POOL_BYTES = 4 << 20
+
+
+def zeros_small(shape, dtype, device):
+    """``torch.zeros(shape, dtype=dtype, device=device)`` for the small accumulators of a step (fp64 statistics of a
+    BatchNorm layer, the fp32 arena of a backward): a piece of a 4 MiB zero-filled pool per (device, stream) that only
+    moves forward -- a piece is handed out once, so it is zero when the kernel that accumulates into it runs, and the
+    pool is replaced (one fill) when it is used up.  A step of the pooling path asks for ~10 such tensors; each used to
+    be its own 4-5 us fill kernel (round 5).  Large requests and requests during a HIP-graph capture (a captured fill is
+    replayed, the pool's fill is not) take the plain ``torch.zeros``."""
+    device = torch.device(device)
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    if (device.type != "cuda" or nbytes == 0 or nbytes > _ZERO_POOL_BYTES // 4
+            or torch.cuda.is_current_stream_capturing()):
+        return torch.zeros(shape, dtype=dtype, device=device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    pool = _ZERO_POOLS.get(key)
+    step = (nbytes + 255) & ~255
+    if pool is None or pool[1] + step > _ZERO_POOL_BYTES:
+        pool = [torch.zeros(_ZERO_POOL_BYTES, dtype=torch.uint8, device=device), 0]
+        _ZERO_POOLS[key] = pool
+    off = pool[1]
+    pool[1] = off + step
+    return pool[0][off:off + nbytes].view(dtype).view(shape)
+
 
 def _timed(name, nbytes):
     return TIMER.launch(name, int(nbytes)) if TIMER is not None else _NO_TIMER
@@ -1109,7 +1142,7 @@ class _RowBNAct(torch.autograd.Function):
         n, batch_stats, slope, has_g, has_b = ctx.meta
         R, C = y.shape
         gout = gout.contiguous().to(y.dtype)
-        sums = torch.zeros(2 * C, dtype=torch.float64, device=y.device)
+        sums = zeros_small(2 * C, torch.float64, y.device)
         with _timed("rowbn_bwd_stats", R * C * 2 * y.element_size()):
             check(lib.dva_rowbn_bwd_stats(ptr(gout), ptr(y), ptr(bn), ptr(sums), R, C, slope, dtype_code(y),
                                           stream_of(y)), "dva_rowbn_bwd_stats")
@@ -1130,7 +1163,7 @@ def rowbn_sums(y, counts):
     require_device(y)
     y = y.contiguous()
     R, C = y.shape
-    sums = torch.zeros(2 * C, dtype=torch.float64, device=y.device)
+    sums = zeros_small(2 * C, torch.float64, y.device)
     with _timed("rowbn_stats", R * (C * y.element_size() + 4)):
         check(lib.dva_rowbn_stats(ptr(y), ptr(counts), ptr(sums), R, C, dtype_code(y), stream_of(y)),
               "dva_rowbn_stats")

@@ -90,7 +90,7 @@ def emulated_chain(ref, vals, x_map, csr, dev_invstd=None, dev_scores=None, retu
     return (out, compat if dev_scores is None else own) if return_scores else out
 
 
-def emulated_emod(ref, x, images, pixels, mapping_size):
+def emulated_emod(ref, x, images, pixels, mapping_size, stored_za=None):
     """E_mod of the fused BILINEAR path with the roundings of csrc/chain_emod.hip made explicit (round 5; VERDICT r4
     item 7): the per-view values ``E_mod(sparse_interpolation(x))`` [V, C_o] that ``emulated_chain`` takes as ``vals``.
 
@@ -103,7 +103,11 @@ def emulated_emod(ref, x, images, pixels, mapping_size):
         value (one kernel, nothing stored);
       * y_a = leaky(BN_a(z_a)) enters Linear_b as a bf16 operand against bf16(W_b), fp32 accumulation;
       * BatchNorm_b (not folded into the operand), LeakyReLU and the attention-weighted sum stay fp32.
-    ``x`` fp32 [B, C_in, H, W] with values on the bf16 grid (the feature maps are bf16 on the device)."""
+    ``x`` fp32 [B, C_in, H, W] with values on the bf16 grid (the feature maps are bf16 on the device).
+    ``stored_za``: evaluate from the bf16 z_a (default: train mode).  A BACKWARD behind an eval-mode forward builds the
+    stored row first and differentiates the evaluation from it (fused_bilinear._EmodPool.backward), so its gradients are
+    those of ``stored_za=True`` although the eval forward itself used the fp32 row -- 2-3 % apart on the feature-map and
+    E_mod gradients (leaky' flips of the values the rounding moves across zero; measured, tests/test_gpu_bilinear.py)."""
     lin_a, bn_a = ref.E_mod[0][0], ref.E_mod[0][1]
     lin_b, bn_b = ref.E_mod[1][0], ref.E_mod[1][1]
     B, C_in, H, W = x.shape
@@ -111,7 +115,7 @@ def emulated_emod(ref, x, images, pixels, mapping_size):
     Y = _bf(rows @ _bf(lin_a.weight).t())                                   # [R, C_o] map rows of Linear_a
     y_map = Y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
     z_a = O.gather_bilinear(y_map, images, pixels, mapping_size)            # fp32 interpolation of the bf16 rows
-    if bn_a.batch_norm.training:
+    if bn_a.batch_norm.training if stored_za is None else stored_za:
         z_a = _bf(z_a)                                                      # the stored row; its statistics
     y_a = F.leaky_relu(bn_a(z_a), 0.2)
     z_b = _bf(y_a) @ _bf(lin_b.weight).t()

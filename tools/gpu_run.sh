@@ -28,8 +28,8 @@ for JOB in "$@"; do
   echo "== $JOB"
   case $KIND in
     tests)
-      timeout 1200 python -m pytest ${REST:-tests} -m gpu -x -q --tb=short 2>&1 | tail -15 > $OUT/pytest_gpu.log
-      tail -4 $OUT/pytest_gpu.log ;;
+      timeout 1500 python -m pytest ${REST:-tests} -m gpu -q --tb=short 2>&1 | tail -40 > $OUT/pytest_gpu.log
+      grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | tail -12 ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     bench)
