@@ -201,6 +201,8 @@ SIGNATURES = {
     "dva_visibility": (ctypes.c_int,
                        [_vp, _i64, ctypes.POINTER(DvaCamera), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                         _vp, _i64, _vp]),
+    "dva_camera_projection": (ctypes.c_int,
+                              [_vp, _i64, ctypes.POINTER(DvaCamera), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_visibility_batch_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(DvaCamera), _i64, _i32]),
     "dva_visibility_batch": (ctypes.c_int,
                              [_vp, _i64, ctypes.POINTER(DvaCamera), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

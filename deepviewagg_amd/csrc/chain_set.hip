@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256, DIR == 0 ? 4 : 3) void set_kernel(
   // (round 5, measured: requesting the rows of the wavefront's NEXT tile before the current one is computed changes
   //  nothing -- 40 / 46 / 49 us forward, 129 / 105 / 99 us backward at 2^20 points either way -- and costs 32 registers,
   //  i.e. the third wavefront per SIMD of the backward stages; SQ counters: the vector unit is busy 0.28 of a wave's
-  //  cycles at two wavefronts per SIMD, like the view passes at three: the passes are instruction-bound, so what pays is
-  //  residency -- grids of 4 (forward) / 3 (backward) blocks per CU instead of 2)
+  //  cycles at two wavefronts per SIMD, like the view passes at three.  Grids of 4 (forward) / 3 (backward) blocks per CU
+  //  instead of 2 -- the registers allow them -- measured SLOWER on the reference-sized batch (78 -> 97 us forward,
+  //  168 -> 191 us backward for 3e5 points: every block pays the 24 KB operand table and the flush): 2 stays)
   for (int64_t t = wave; t < tiles; t += n_waves) {
     const int64_t p = t * 32 + j;
     const bool ok = p < N;
@@ -202,7 +203,7 @@ int dva_chain_set_fwd(int32_t stage, const float* pooled, const int64_t* ptr, co
     return DVA_ERR_INVALID;
   if (n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const int64_t tiles = (n_points + 31) / 32;
-  static const int bpc = tune_int("DVA_SET_FWD_BPC", 4);       // blocks per CU of the grid (read once)
+  static const int bpc = tune_int("DVA_SET_FWD_BPC", 2);       // blocks per CU of the grid (read once)
   const int cap = chain_grid(bpc);
   const dim3 grid((int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap)), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -230,7 +231,7 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
     return DVA_ERR_INVALID;
   if (n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const int64_t tiles = (n_points + 31) / 32;
-  static const int bpc = tune_int("DVA_SET_BWD_BPC", 3);       // blocks per CU of the grid (read once)
+  static const int bpc = tune_int("DVA_SET_BWD_BPC", 2);       // blocks per CU of the grid (read once)
   const int cap = chain_grid(bpc);
   const dim3 grid((int)((tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap)), block(256);
   hipStream_t s = (hipStream_t)stream;

@@ -17,7 +17,7 @@
 namespace dva {
 
 constexpr int KNN_TPB = 64;      // one wavefront per block: the candidate lists live in LDS, [slot][thread]
-constexpr int KNN_KMAX = 64;
+constexpr int KNN_KMAX = 128;     // k <= 64: 32 KB of candidate lists per block; k <= 128 (BiasuttiVisibility, k = 75): 64 KB
 constexpr int CELL_BITS = 21;
 constexpr int64_t CELL_BIAS = 1 << 20;
 
@@ -79,13 +79,14 @@ __device__ __forceinline__ int cell_start(const uint64_t* __restrict__ tkeys, co
   }
 }
 
+template <int KCAP>
 __global__ __launch_bounds__(KNN_TPB) void knn_query_kernel(
     const float4* __restrict__ pts, const uint64_t* __restrict__ keys_sorted, int64_t n,
     const float* __restrict__ bbox, float cell, const uint64_t* __restrict__ tkeys,
     const int32_t* __restrict__ tvals, uint32_t mask, int k, int max_shell, uint8_t* __restrict__ done,
     int32_t* __restrict__ nbr, float* __restrict__ d2_out) {
-  __shared__ float s_d[KNN_KMAX][KNN_TPB];
-  __shared__ int32_t s_i[KNN_KMAX][KNN_TPB];
+  __shared__ float s_d[KCAP][KNN_TPB];
+  __shared__ int32_t s_i[KCAP][KNN_TPB];
   const int t = threadIdx.x;
   const float inv_cell = 1.f / cell;
   const float ext = fmaxf(fmaxf(bbox[3] - bbox[0], bbox[4] - bbox[1]), bbox[5] - bbox[2]);
@@ -278,8 +279,12 @@ int dva_knn(const float* xyz, int64_t n, const float* bbox, float cell, int32_t 
                      tvals, (uint32_t)(L.cap - 1));
   int64_t qb = (n + KNN_TPB - 1) / KNN_TPB;
   if (qb > 256 * 32) qb = 256 * 32;
-  hipLaunchKernelGGL(knn_query_kernel, dim3((int)qb), dim3(KNN_TPB), 0, s, pts, keys_sorted, n, bbox, cell, tkeys,
-                     tvals, (uint32_t)(L.cap - 1), k, max_shell, done, neighbors, dist2);
+  if (k <= 64)
+    hipLaunchKernelGGL(knn_query_kernel<64>, dim3((int)qb), dim3(KNN_TPB), 0, s, pts, keys_sorted, n, bbox, cell, tkeys,
+                       tvals, (uint32_t)(L.cap - 1), k, max_shell, done, neighbors, dist2);
+  else
+    hipLaunchKernelGGL(knn_query_kernel<128>, dim3((int)qb), dim3(KNN_TPB), 0, s, pts, keys_sorted, n, bbox, cell, tkeys,
+                       tvals, (uint32_t)(L.cap - 1), k, max_shell, done, neighbors, dist2);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

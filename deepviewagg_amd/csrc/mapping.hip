@@ -902,11 +902,69 @@ static int vis_batch_layout(const dva_camera* c, int64_t n, int64_t B, VisBatchL
   return DVA_OK;
 }
 
+// survivors of the projection to the caller's arrays (dva_camera_projection): int64 indices, count
+__global__ __launch_bounds__(256) void projection_out_kernel(int64_t n, const int32_t* __restrict__ flag,
+                                                              const int32_t* __restrict__ pos,
+                                                              const float* __restrict__ dist_u,
+                                                              const double* __restrict__ xp_u,
+                                                              const double* __restrict__ yp_u,
+                                                              int64_t* __restrict__ idx, float* __restrict__ dist,
+                                                              double* __restrict__ xp, double* __restrict__ yp,
+                                                              int64_t* __restrict__ n_out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (flag[i]) {
+      const int32_t j = pos[i];
+      idx[j] = i;
+      dist[j] = dist_u[i];
+      xp[j] = xp_u[i];
+      yp[j] = yp_u[i];
+    }
+    if (i == n - 1) *n_out = (int64_t)pos[i] + flag[i];
+  }
+}
+
 }  // namespace dva
 
 using namespace dva;
 
 extern "C" {
+
+// camera_projection alone (reference core/multimodal/visibility.py:478-538): range / field-of-view / crop / mask cull and
+// the float projection of the survivors, in candidate order -- what the visibility models other than the splatting one
+// start from (DepthBasedVisibility, BiasuttiVisibility: visibility.py:1356-1496).  Workspace: dva_visibility_workspace_bytes.
+int dva_camera_projection(const float* xyz, int64_t n, const dva_camera* cam, const uint8_t* mask, int64_t* idx,
+                          float* depth, double* x_proj, double* y_proj, int64_t* n_out_dev, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+  if (!cam || n < 0 || !n_out_dev) return DVA_ERR_INVALID;
+  if (cam->model < DVA_CAM_EQUIRECT || cam->model > DVA_CAM_FISHEYE_KITTI) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), s) != hipSuccess) return DVA_ERR_LAUNCH;
+    return DVA_OK;
+  }
+  if (n > 0x7fffffff) return DVA_ERR_UNSUPPORTED;
+  if (!xyz || !idx || !depth || !x_proj || !y_proj || !workspace) return DVA_ERR_INVALID;
+  VisLayout L;
+  int rc = vis_layout(cam, n, &L);
+  if (rc) return rc;
+  if ((int64_t)L.total > workspace_bytes) return DVA_ERR_INVALID;
+  char* ws = (char*)workspace;
+  int32_t* flag = (int32_t*)(ws + L.flag);
+  int32_t* pos = (int32_t*)(ws + L.pos);
+  float* dist_u = (float*)(ws + L.dist_u);
+  double* xp_u = (double*)(ws + L.xp_u);
+  double* yp_u = (double*)(ws + L.yp_u);
+  const dva_camera c = *cam;
+  hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(256), 0, s, xyz, n, c, mask, flag, dist_u, xp_u, yp_u);
+  size_t tmp = L.temp_bytes;
+  if (rocprim::exclusive_scan(ws + L.temp, tmp, flag, pos, 0, (size_t)n, rocprim::plus<int32_t>(), s) != hipSuccess)
+    return DVA_ERR_LAUNCH;
+  hipLaunchKernelGGL(projection_out_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, flag, pos, dist_u, xp_u, yp_u, idx,
+                     depth, x_proj, y_proj, n_out_dev);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
 
 int64_t dva_visibility_workspace_bytes(const dva_camera* cam, int64_t n) {
   if (!cam || n < 0) return DVA_ERR_INVALID;

@@ -320,7 +320,7 @@ int dva_rowbn_stats(const void* y, const int32_t* counts, double* sums, int64_t 
   if (dtype == DVA_F32 ? rv_ok<float>(C, y, y, y) : rv_ok<bf16_t>(C, y, y, y)) {
     const int rpb = 256 / (C / (dtype == DVA_F32 ? 4 : 8));
     int64_t b = (R + 4 * rpb - 1) / (4 * rpb);      // four rows per thread and iteration
-    if (b > 256 * 4) b = 256 * 4;
+    if (b > 256 * 2) b = 256 * 2;      // every block ends with 2 C fp64 atomics: more blocks measured slower
     if (dtype == DVA_F32)
       hipLaunchKernelGGL((rowbn_sums_vec_kernel<float, 0>), dim3((int)b), dim3(256), lds, (hipStream_t)stream,
                          (const float*)y, (const float*)nullptr, counts, (const float*)nullptr, sums, R, C, 0.f);
@@ -381,7 +381,7 @@ int dva_rowbn_bwd_stats(const void* grad_out, const void* y, const float* bn, do
   if (dtype == DVA_F32 ? rv_ok<float>(C, y, grad_out, y) : rv_ok<bf16_t>(C, y, grad_out, y)) {
     const int rpb = 256 / (C / (dtype == DVA_F32 ? 4 : 8));
     int64_t b = (R + 4 * rpb - 1) / (4 * rpb);      // four rows per thread and iteration
-    if (b > 256 * 4) b = 256 * 4;
+    if (b > 256 * 2) b = 256 * 2;      // every block ends with 2 C fp64 atomics: more blocks measured slower
     if (dtype == DVA_F32)
       hipLaunchKernelGGL((rowbn_sums_vec_kernel<float, 1>), dim3((int)b), dim3(256), lds, (hipStream_t)stream,
                          (const float*)y, (const float*)grad_out, (const int32_t*)nullptr, bn, sums, R, C, slope);

@@ -1349,7 +1349,7 @@ def knn(xyz, k, cell=None):
     require_device(xyz)
     xyz = xyz.float().contiguous()
     n = xyz.shape[0]
-    assert xyz.dim() == 2 and xyz.shape[1] == 3 and 0 < k <= 64
+    assert xyz.dim() == 2 and xyz.shape[1] == 3 and 0 < k <= 128
     nbr = torch.empty((n, k), dtype=torch.int32, device=xyz.device)
     d2 = torch.empty((n, k), dtype=torch.float32, device=xyz.device)
     if n == 0:

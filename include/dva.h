@@ -792,7 +792,7 @@ int dva_sparse_conv_wgrad(const void* x, const int32_t* nbr, const void* grad_ou
  * neighbours of every point among all points (replaces KeOps `((x_i - x_j)**2).sum(2).argKmin(k, dim=1)`,
  * :506-507; pykeops 1.4.2 is not in the reference tree) and the per-view occlusion counts (:560-599).
  * ------------------------------------------------------------------------------------------ */
-/* neighbors int32 [n, k] (k <= 64), dist2 fp32 [n, k] (nullable): ascending by (d2, index) with
+/* neighbors int32 [n, k] (k <= 128), dist2 fp32 [n, k] (nullable): ascending by (d2, index) with
  * d2 = ((dx*dx + dy*dy) + dz*dz) in fp32; the point itself is its own first neighbour; -1 / inf when
  * n < k.  bbox = fp32[6] device array (min xyz | max xyz of the cloud); cell = grid cell size;
  * (max - min) / cell must stay below 2^20 per axis.  One call searches at most max_shell Chebyshev shells
@@ -868,6 +868,14 @@ int dva_visibility(const float* xyz, int64_t n, const dva_camera* cam, const uin
                    int64_t* idx, int64_t* x_pix, int64_t* y_pix, float* depth, double* x_proj,
                    double* y_proj, int64_t* n_out_dev, void* workspace, int64_t workspace_bytes,
                    void* stream);
+
+/* camera_projection alone (reference core/multimodal/visibility.py:478-538: range, field-of-view / crop / mask cull,
+ * float projection), survivors in candidate order: idx int64[m], depth fp32[m], x_proj / y_proj fp64[m] (capacity n),
+ * *n_out_dev = m.  The start of the visibility models other than the splatting one (DepthBasedVisibility,
+ * BiasuttiVisibility: visibility.py:1356-1496, :1779-1803).  Workspace: dva_visibility_workspace_bytes(cam, n). */
+int dva_camera_projection(const float* xyz, int64_t n, const dva_camera* cam, const uint8_t* mask, int64_t* idx,
+                          float* depth, double* x_proj, double* y_proj, int64_t* n_out_dev, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* B images of ONE setting in one set of launches (reference core/data_transform/multimodal/image.py:192-428 loops
  * over the images; core/multimodal/visibility.py:1073-1195 per image).  cam0 (host) = the camera of image 0: projection

@@ -70,12 +70,13 @@ for JOB in "$@"; do
       head -40 $OUT/sq_counters.txt | cut -c1-170 ;;
     trace)
       # ordered kernel list of the LAST step of a workload: trace:<name>:<steps>
-      IFS=: read -r NAME STEPS <<< "$REST"
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $OUT/trace_$NAME -o t --output-format csv -- \
-          python $ROOT/tools/workload_once.py $NAME ${STEPS:-3} > $OUT/${NAME}_trace.out 2> $OUT/${NAME}_trace.err)
-      python tools/last_step_trace.py $(find $OUT/trace_$NAME -name "*kernel_trace.csv" | head -1) ${STEPS:-3} > $OUT/${NAME}_last_step.txt 2>&1
-      rm -rf $OUT/trace_$NAME
-      tail -5 $OUT/${NAME}_last_step.txt ;;
+      IFS=: read -r NAME STEPS ENVS <<< "$REST"
+      FN=${NAME}$(echo "${ENVS:+_$ENVS}" | tr -c 'A-Za-z0-9_=\n' '_')
+      (cd /tmp && env $(envs "$ENVS") timeout 900 rocprofv3 --kernel-trace -d $OUT/trace_$FN -o t --output-format csv -- \
+          python $ROOT/tools/workload_once.py $NAME ${STEPS:-3} > $OUT/${FN}_trace.out 2> $OUT/${FN}_trace.err)
+      python tools/last_step_trace.py $(find $OUT/trace_$FN -name "*kernel_trace.csv" | head -1) ${STEPS:-3} > $OUT/${FN}_last_step.txt 2>&1
+      rm -rf $OUT/trace_$FN
+      python tools/last_step_trace.py --sum $OUT/${FN}_last_step.txt | head -${TRACE_TOP:-12} ;;
     py)
       IFS=: read -r SCRIPT ARGS <<< "$REST"
       timeout 900 python $SCRIPT $ARGS > $OUT/py_$(basename $SCRIPT .py).log 2>&1

@@ -4,6 +4,22 @@ the launches after the last but one occurrence of the step's first kernel.  Prin
 import csv
 import sys
 
+if sys.argv[1] == "--sum":
+    # per-kernel totals of a *_last_step.txt written by this script
+    import collections
+    import re
+    tot, cnt = collections.Counter(), collections.Counter()
+    for line in open(sys.argv[2]):
+        m = re.match(r"\s*([\d.]+) us\s+gap\s+\S+\s+(.*)", line)
+        if m:
+            name = re.sub(r"\(.*", "", m.group(2)).replace("void ", "")[:70]
+            tot[name] += float(m.group(1))
+            cnt[name] += 1
+        elif "launches" in line:
+            print(line.strip())
+    for name, t in tot.most_common():
+        print(f"{t:9.1f} us  x{cnt[name]:<3d} {name}")
+    sys.exit(0)
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
