@@ -310,3 +310,174 @@ class SplattingVisibility(VisibilityModel):
         self.k_swell = k_swell
         self.d_swell = d_swell
         self.exact = exact
+
+
+class _ProjectionVisibility(VisibilityModel):
+    """Visibility models that decide per PROJECTED point (no splatting): the reference's ``VisibilityModel.__call__``
+    (visibility.py:1699-1757) with ``camera_projection`` on the device (``dva_camera_projection``), a subclass
+    ``_visibility(x_proj, y_proj, dist)`` -> (indices into the projected points, x_pix, y_pix) and the mapping features of
+    the kept points (``dva_mapping_features``).  ``x`` / ``y`` of the result are what the reference returns for these
+    models: the FLOAT projections of the kept points (visibility.py:1381, :1496), not integer pixels."""
+
+    def _visibility(self, x_proj, y_proj, dist, **kwargs):
+        raise NotImplementedError
+
+    def batch(self, xyz, img_xyz, linearity=None, planarity=None, scattering=None, normals=None, img_opk=None,
+              img_intrinsic_pinhole=None, img_intrinsic_fisheye=None, img_extrinsic=None, img_mask=None, **kwargs):
+        """The ``batch`` contract of ``VisibilityModel`` (rows of all images concatenated, ``image``, ``row_ptr``) as a
+        loop over the images, like the reference's MapImages (core/data_transform/multimodal/image.py:238-353): these
+        models have no batched kernels."""
+        B = torch.as_tensor(img_xyz).reshape(-1, 3).shape[0]
+
+        def one(a, b):
+            return None if a is None else torch.as_tensor(a)[b]
+        outs = [self(xyz, torch.as_tensor(img_xyz).reshape(-1, 3)[b], linearity=linearity, planarity=planarity,
+                     scattering=scattering, normals=normals, img_opk=one(img_opk, b),
+                     img_intrinsic_pinhole=one(img_intrinsic_pinhole, b),
+                     img_intrinsic_fisheye=one(img_intrinsic_fisheye, b), img_extrinsic=one(img_extrinsic, b),
+                     img_mask=img_mask, **kwargs) for b in range(B)]
+        counts = torch.tensor([o['idx'].shape[0] for o in outs], dtype=torch.long)
+        row_ptr = torch.cat((torch.zeros(1, dtype=torch.long), counts.cumsum(0))).to(xyz.device)
+        keep = [o for o in outs if o['idx'].shape[0] > 0]
+        res = {k: (torch.cat([o[k] for o in keep]) if keep else outs[0][k]) for k in ('idx', 'x', 'y', 'depth', 'features')}
+        res['image'] = torch.repeat_interleave(torch.arange(B), counts).to(xyz.device)
+        res['row_ptr'] = row_ptr
+        return res
+
+    def __call__(self, xyz, img_xyz, linearity=None, planarity=None, scattering=None, normals=None,
+                 img_opk=None, img_intrinsic_pinhole=None, img_intrinsic_fisheye=None, img_extrinsic=None,
+                 img_mask=None, **kwargs):
+        lib = _lib.load()
+        in_device = xyz.device
+        if not torch.cuda.is_available():
+            raise _lib.DvaError("the mapping build runs on a HIP device; none is visible "
+                                "(deepviewagg_amd has no CPU fallback)")
+        dev = in_device if xyz.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        assert img_mask is None or tuple(img_mask.shape) == tuple(self.img_size)
+        cam = self._camera_struct(img_xyz, img_opk, img_intrinsic_pinhole, img_intrinsic_fisheye, img_extrinsic)
+        xyz_d = xyz.detach().to(dev, torch.float32).contiguous()
+        n = xyz_d.shape[0]
+        mask_d = None if img_mask is None else img_mask.to(dev).to(torch.uint8).contiguous()
+        cap = max(n, 1)
+        idx1 = torch.empty(cap, dtype=torch.int64, device=dev)
+        dist = torch.empty(cap, dtype=torch.float32, device=dev)
+        x_proj = torch.empty(cap, dtype=torch.float64, device=dev)
+        y_proj = torch.empty(cap, dtype=torch.float64, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws_bytes = lib.dva_visibility_workspace_bytes(ctypes.byref(cam), n)
+        if ws_bytes < 0:
+            check(int(ws_bytes), "dva_visibility_workspace_bytes")
+        ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
+        st = stream_of(xyz_d)
+        check(lib.dva_camera_projection(ptr(xyz_d), n, ctypes.byref(cam), ptr(mask_d), ptr(idx1), ptr(dist),
+                                        ptr(x_proj), ptr(y_proj), ptr(n_out), ptr(ws), int(ws_bytes), st),
+              "dva_camera_projection")
+        m = int(n_out.item())
+        del ws
+        out = {}
+        if m == 0:          # visibility.py:1721-1729
+            for k, dt in (('idx', torch.long), ('x', torch.long), ('y', torch.long), ('depth', torch.float),
+                          ('features', torch.float)):
+                out[k] = torch.empty((0,), dtype=dt, device=in_device)
+            return out
+        idx1, dist, x_proj, y_proj = idx1[:m], dist[:m], x_proj[:m], y_proj[:m]
+        idx2, x_pix, y_pix = self._visibility(x_proj, y_proj, dist, **kwargs)
+        idx = idx1[idx2].contiguous()
+        dist, y_kept = dist[idx2].contiguous(), y_proj[idx2].contiguous()
+        q = idx.shape[0]
+
+        def dev32(a):
+            return None if a is None else a.detach().to(dev, torch.float32).contiguous()
+        lin, pla, sca, nrm = dev32(linearity), dev32(planarity), dev32(scattering), dev32(normals)
+        ncol = 2 + sum(a is not None for a in (lin, pla, sca, nrm))
+        feats = torch.empty((q, ncol), dtype=torch.float32, device=dev)
+        if q > 0:
+            got = ctypes.c_int32(0)
+            check(lib.dva_mapping_features(ptr(xyz_d), ptr(idx), ptr(dist), ptr(y_kept), ptr(lin), ptr(pla), ptr(sca),
+                                           ptr(nrm), ctypes.byref(cam), q, ptr(feats), ctypes.byref(got), st),
+                  "dva_mapping_features")
+            assert got.value == ncol
+        out['idx'], out['x'], out['y'] = idx.to(in_device), x_pix.to(in_device), y_pix.to(in_device)
+        out['depth'], out['features'] = dist.to(in_device), feats.to(in_device)
+        return out
+
+
+def read_s3dis_depth_map(path, img_size=None, empty=-1):
+    """S3DIS depth panorama (16-bit PNG, 1/512 m, 2^16 - 1 = missing) as a float [W, H] tensor in metres
+    (visibility.py:1326-1355)."""
+    from PIL import Image
+    im = Image.open(path)
+    if img_size is not None:
+        im = im.resize(tuple(int(v) for v in img_size), resample=Image.NEAREST)
+    im = torch.from_numpy(np.array(im).astype(np.int32)).t()
+    empty_mask = im == 2 ** 16 - 1
+    im = im / 512
+    im[empty_mask] = empty
+    return im
+
+
+class DepthBasedVisibility(_ProjectionVisibility):
+    """A projected point is visible when its distance lies within ``depth_threshold`` of the depth map's value at its
+    pixel (visibility.py:1356-1383, :1779-1787).  The map comes from ``depth_map_path`` (S3DIS format, as in the reference)
+    or, already loaded, as ``depth_map`` float [W, H]."""
+
+    def __init__(self, depth_threshold=0.05, **kwargs):
+        super().__init__(**kwargs)
+        self.depth_threshold = depth_threshold
+
+    def _visibility(self, x_proj, y_proj, dist, depth_map_path=None, depth_map=None, **kwargs):
+        if depth_map is None:
+            assert depth_map_path is not None, 'Please provide depth_map_path.'      # visibility.py:1374
+            depth_map = read_s3dis_depth_map(depth_map_path, img_size=self.img_size, empty=-1)
+        depth_map = depth_map.to(x_proj.device)
+        dist_real = depth_map[x_proj.long(), y_proj.long()]
+        indices = torch.where((dist_real - dist).abs() <= self.depth_threshold)[0]
+        return indices, x_proj[indices], y_proj[indices]
+
+
+class BiasuttiVisibility(_ProjectionVisibility):
+    """Biasutti et al., "Visibility estimation in point clouds with variable density" (visibility.py:1390-1496, :1790-1803):
+    alpha = exp(-((d - d_min) / (d_max - d_min))^2) over the k nearest projected points in IMAGE coordinates (wrapped in x
+    by ``margin`` pixels for panoramas), visible when alpha >= ``threshold`` (default: the mean alpha).  The neighbour
+    search is the exact hash-grid K-NN of ``dva_knn`` on (x, y, 0) -- the reference's KeOps argKmin over all pairs, fp32
+    squared distances, ties to the lower index."""
+
+    def __init__(self, k=75, margin=None, threshold=None, **kwargs):
+        super().__init__(**kwargs)
+        self.k = k
+        self.margin = margin
+        self.threshold = threshold
+
+    def _neighbors(self, x_proj, y_proj):
+        from ... import ops
+        n = x_proj.shape[0]
+        xy = torch.stack((x_proj.float(), y_proj.float())).t()
+        x_width, x_margin = self.img_size[0], self.margin
+        wrap = x_margin is not None and x_margin > 0 and x_width is not None and x_width > 0
+        if wrap:
+            off = torch.tensor([[float(x_width), 0.0]], device=xy.device)
+            idx_left = torch.where(x_proj <= x_margin)[0]
+            idx_right = torch.where(x_proj >= (x_width - x_margin))[0]
+            search = torch.cat((xy, xy[idx_left] + off, xy[idx_right] - off))
+        else:
+            search = xy
+        k = min(int(self.k), search.shape[0])
+        pts = torch.cat((search, torch.zeros((search.shape[0], 1), device=xy.device)), 1).contiguous()
+        nbr, _ = ops.knn(pts, k)                        # self-search over the search set; the queries are its first n rows
+        nbr = nbr[:n].long()
+        if wrap:
+            n_left = idx_left.shape[0]
+            is_left = (nbr >= n) & (nbr < n + n_left)
+            nbr[is_left] = idx_left[nbr[is_left] - n]
+            is_right = nbr >= n + n_left
+            nbr[is_right] = idx_right[nbr[is_right] - n - n_left]
+        return nbr
+
+    def _visibility(self, x_proj, y_proj, dist, **kwargs):
+        neighbors = self._neighbors(x_proj, y_proj)
+        dist_nn = dist[neighbors]
+        dist_min, dist_max = dist_nn.min(dim=1).values, dist_nn.max(dim=1).values
+        alpha = torch.exp(-((dist - dist_min) / (dist_max - dist_min)) ** 2)
+        threshold = alpha.mean() if self.threshold is None else self.threshold
+        indices = torch.where(alpha >= threshold)[0]
+        return indices, x_proj[indices], y_proj[indices]

@@ -521,6 +521,52 @@ def gen_visibility():
                    gen, True, size, extra=dict(img_opk=torch.zeros(3)))
 
 
+def gen_visibility_models():
+    """BiasuttiVisibility / DepthBasedVisibility of the reference (visibility.py:1356-1496, :1779-1803) on the room cloud:
+    the reference's own classes, KeOps through oracle/shims/pykeops, the S3DIS depth PNG written here with PIL."""
+    print("BiasuttiVisibility, DepthBasedVisibility (reference classes)")
+    import tempfile
+    from PIL import Image
+    patch_numba_promotion()
+    gen = torch.Generator().manual_seed(16)
+    xyz = room_cloud(3000, gen)
+    cam = torch.tensor([2.0, 1.7, 1.2])
+    size = (256, 128)
+    n = xyz.shape[0]
+    lin, pla, sca = (torch.rand(n, generator=gen) for _ in range(3))
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1)
+    base = dict(img_size=size, crop_top=0, crop_bottom=0, r_max=np.float64(10.0), r_min=np.float64(0.2),
+                camera='s3dis_equirectangular')
+    kw = dict(img_opk=torch.tensor([0.1, -0.05, 0.7]), img_intrinsic_pinhole=None, img_intrinsic_fisheye=None,
+              img_extrinsic=None, img_mask=None)
+    common = dict(xyz=xyz, img_xyz=cam, img_size=np.array(size), r_min=np.array(0.2), r_max=np.array(10.0),
+                  linearity=lin, planarity=pla, scattering=sca, normals=nrm, img_opk=kw['img_opk'])
+    for name, k, margin, thr in (("vis_biasutti", 20, None, None), ("vis_biasutti_wrap", 12, 20, 0.5)):
+        model = ref_vis.BiasuttiVisibility(k=k, margin=margin, threshold=thr, **base)
+        idx_1, dist, x_proj, y_proj = model._camera_projection(xyz, cam, **kw)
+        nbr = ref_vis.k_nn_image_system(x_proj, y_proj, k=k, x_margin=margin, x_width=size[0])
+        out = model(xyz, cam, linearity=lin, planarity=pla, scattering=sca, normals=nrm, **kw)
+        save(name, k=np.array(k), margin=np.array(-1 if margin is None else margin),
+             threshold=np.array(-1.0 if thr is None else thr), proj_idx=idx_1, proj_dist=dist, proj_x=x_proj,
+             proj_y=y_proj, neighbors=nbr, idx=out['idx'], x=out['x'], y=out['y'], depth=out['depth'],
+             features=out['features'], **common)
+    # depth map: the true distance of the closest projected point per pixel + noise, a block of missing pixels
+    model = ref_vis.DepthBasedVisibility(depth_threshold=0.05, **base)
+    idx_1, dist, x_proj, y_proj = model._camera_projection(xyz, cam, **kw)
+    dm = np.full(size, 65535, dtype=np.uint16)
+    order = np.argsort(-dist.numpy(), kind='stable')            # the closest point of a pixel is written last
+    dm[x_proj.long().numpy()[order], y_proj.long().numpy()[order]] = np.round(dist.numpy()[order] * 512).astype(np.uint16)
+    dm[40:60, 30:50] = 65535
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "depth.png")
+        Image.fromarray(dm.T).save(path)                          # read_s3dis_depth_map transposes back
+        out = model(xyz, cam, linearity=lin, planarity=pla, scattering=sca, normals=nrm, depth_map_path=path, **kw)
+        depth_m = ref_vis.read_s3dis_depth_map(path, img_size=size, empty=-1)
+    save("vis_depth_map", depth_threshold=np.array(0.05), depth_png_u16=dm, depth_map=depth_m, proj_idx=idx_1,
+         proj_dist=dist, proj_x=x_proj, proj_y=y_proj, idx=out['idx'], x=out['x'], y=out['y'], depth=out['depth'],
+         features=out['features'], **common)
+
+
 def gen_lex_and_csr():
     print("lexargsort / lexargunique / lexunique and CSR ops")
     gen = torch.Generator().manual_seed(7)
@@ -888,7 +934,7 @@ if __name__ == "__main__":
                 gather=gen_gather,
                 branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
                 transforms=gen_transforms, cylinder=gen_mapping_cylinder,
-                neighborhood=gen_neighborhood)
+                neighborhood=gen_neighborhood, visibility_models=gen_visibility_models)
     for name, fn in jobs.items():
         if not only or name in only:
             fn()
