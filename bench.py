@@ -1016,6 +1016,14 @@ def main():
     target_name = "chain_attn_fwd" if "chain_attn_fwd" in kern else "view_gather_attention_fwd"
     barrier()
     ops.TIMER = ops.KernelTimer(only={dom_name, target_name})
+    # A one-off host stall inside the timed region (one step of 47 ms among nineteen of 11.2 ms, twice in six runs on the
+    # GPU box) is the host, not the path: the collector of Python cycles is switched off for the K timed steps (a full
+    # collection over the module / autograd objects takes tens of ms), and the caching allocator's device allocations
+    # during the region are counted and reported (a hipMalloc of a new segment is the other candidate)
+    import gc
+    gc.collect()
+    gc.disable()
+    mem0 = torch.cuda.memory_stats(device)
     # one event per step boundary (6 us per step): the device-side duration of every timed step goes into the JSON line,
     # so that a one-off stall (a 33 ms hiccup was seen once in twenty runs) is visible next to the wall-clock value
     marks, host = [], []
@@ -1032,6 +1040,10 @@ def main():
     host.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    mem1 = torch.cuda.memory_stats(device)
+    alloc_in_region = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in
+                       ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")}
     timer, ops.TIMER = ops.TIMER, None
     per_step_device_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
     per_step_host_ms = [(b - a) * 1e3 for a, b in zip(host[:-1], host[1:])]
@@ -1115,6 +1127,8 @@ def main():
             "per_step_ms_device": [round(v, 3) for v in per_step_device_ms],
             "per_step_ms_device_median": sorted(per_step_device_ms)[len(per_step_device_ms) // 2],
             "host_enqueue_ms_per_step_median": sorted(per_step_host_ms)[len(per_step_host_ms) // 2],
+            "host_enqueue_ms_per_step_max": max(per_step_host_ms),
+            "allocator_in_timed_region": alloc_in_region,
             "step_algorithmic_GB": sum(v["bytes"] for v in kern.values()) / PROFILE_STEPS / 1e9,
             "hbm_copy_GBps": None,
             "gather_GBps": None,
