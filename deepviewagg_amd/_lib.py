@@ -155,6 +155,9 @@ SIGNATURES = {
     "dva_emod_attn_bwd": (ctypes.c_int, [_vp] * 20 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_emod_stats1_plan": (ctypes.c_int, [_vp] * 6 + [_i64, _i64, _i32, _vp]),
     "dva_emod_bwd": (ctypes.c_int, [_i32] + [_vp] * 16 + [_i64, _i64, _i64, _i32, _i32, _vp]),
+    "dva_chain_score_l6_stats": (ctypes.c_int, [_vp] * 16 + [_i32, _i64, _i64, _vp]),
+    "dva_chain_l6_consts": (ctypes.c_int, [_vp] * 7),
+    "dva_chain_bwd_layer5_merged": (ctypes.c_int, [_vp] * 18 + [_i32, _i64, _i64, _vp]),
     "dva_chain_route_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_copy_ceiling": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "dva_zero_unseen_rows": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp]),

@@ -520,6 +520,204 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Merged backward (round 5): the score pass ALSO produces what stage 6 existed for -- the statistics S5 of the
+// BatchNorm-5 backward -- so that stage 6 disappears and stage 5 starts from the score gradients.
+//   dz6 = G6 dy6 - K1 - K2 z6 is linear in the two constants this very pass is still summing (K1, K2 per channel from
+//   S6), so S5 = sum_v dy5 | sum_v dy5 z5 with dy5 = m5 (W6^T dz6), m5 = leaky'(y5) in {1, 0.2}, splits into
+//     S5a[c] = e1[c] - n5[c] sum_j W6[j][c] K1[j] - sum_j W6[j][c] K2[j] P2[c][j]
+//     S5b[c] = e2[c] - q5[c] sum_j W6[j][c] K1[j] - sum_j W6[j][c] K2[j] Q2[c][j]
+//   with the sums this kernel accumulates per view from quantities it has in registers anyway:
+//     e = W6^T (G6 dy6)  (one more product),  e1 = sum m5 e,  e2 = sum (m5 z5) e,  n5 = sum m5,  q5 = sum m5 z5  (vectors),
+//     P2[c][j] = sum_v m5[c] z6[j],  Q2[c][j] = sum_v (m5 z5)[c] z6[j]   (two 32 x 32 products over natural LDS tiles).
+//   l6_consts_kernel finishes S5 once S6 is complete.  Stage 5 (layer_bwd_kernel<5, ., false, true>) then evaluates
+//   dy6 -> dz6 -> da5 -> dy5 itself (three more products on idle matrix cores; it reads 16 bytes of score gradients per
+//   view instead of the 64-byte dy5 row) and takes dW6 along.  Gone: one chain evaluation, the [V, 32] bf16 dy5 tensor
+//   (2.1 GB written + read), one launch.  Roundings: the operands of the new products are bf16 like every other
+//   weight-gradient operand (sums over all views: unbiased, they average out); S5 is no longer the sum of the very dy5
+//   values stage 5 uses but of the same expression before its bf16 operand rounding -- a difference of 2^-9 / sqrt(V)
+//   relative in the subtracted means.
+// acc5 fp32 [2][32][32] = P2 | Q2 (channel indices, caller-zeroed), vec5 fp64 [4][32] = e1 | e2 | n5 | q5 (caller-zeroed).
+// LDS operand table: chain positions 0..6 (W1', W2', W5, W6), 7..8 = W6' (folded), 9 = Ws^T, 10..11 = W6^T.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void score_l6_kernel(
+    const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
+    const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
+    const float* __restrict__ bn6, const float* __restrict__ dc, double* __restrict__ stats6,
+    float* __restrict__ dWs, float* __restrict__ dbs, float* __restrict__ acc5, double* __restrict__ vec5, int G,
+    int64_t V, int64_t N) {
+  constexpr int L_W6F = 7, L_WST = 9, L_W6T = 10, NOPS = 12;
+  __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
+  // natural tiles: a6 (score-weight gradient), m5, m5 z5, z6; a 4-row transposed score-gradient tile (+ one zero row)
+  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_tm[4][32 * TSB], s_tq[4][32 * TSB],
+      s_tz[4][32 * TSB], s_td[4][5 * TSB];
+  float* s_red = reinterpret_cast<float*>(&s_tc[0][0]);        // epilogue only
+  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
+  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * 4 * 4 * D, "statistics buffer");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < 4 * 5 * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) s_ops[OP_W5 * 64 + i] = ops[OP_W5 * 64 + i];   // W5, W6
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_ops[L_WST * 64 + i] = ops[OP_WST * 64 + i];
+  for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L_W6T * 64 + i] = ops[OP_W6T * 64 + i];
+  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  fold_ops(s_ops, L_W6F, ops, OP_W6, 2, bn6);
+  stage_tab(s_tab[0], bn1, nullptr);
+  stage_tab(s_tab[1], bn2, nullptr);
+  stage_tab(s_tab[2], bn5, nullptr);
+  stage_tab(s_tab[3], bn6, nullptr);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16);
+  bf16_t* tc = s_tc[wv];
+  bf16_t* tm = s_tm[wv];
+  bf16_t* tq = s_tq[wv];
+  bf16_t* tz = s_tz[wv];
+  bf16_t* td = s_td[wv];
+  f32x16 accS = {0}, accP = {0}, accQ = {0};
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float st[2][16], sv[4][16];          // S6; e1 | e2 | n5 | q5
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    st[0][r] = st[1][r] = 0.f;
+    sv[0][r] = sv[1][r] = sv[2][r] = sv[3][r] = 0.f;
+  }
+  const int n_tiles = n_tiles_dev[0];
+  int ta, tb;
+  wave_tile_range(tiles, n_tiles, ta, tb);
+  struct Pre {
+    TileInfo ti;
+    float4 x, dc;
+    int vpj;
+  };
+  run_tiles_single<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
+    Pre p;
+    p.ti = ti;
+    const bool ok = j < p.ti.nv;
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
+    p.dc = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+    return p;
+  }, [&](const Pre& p) {
+    const bool ok = j < p.ti.nv;
+    const uint32_t keep = ok ? 0xffffffffu : 0u;
+    const f32x16 uacc = load_u(U, ok, p.vpj, h);
+    ChainKeep k;
+    chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};      // zeros in the lanes without a view and for h = 1
+    tileN_put_packed(tc, j, h, k.a6);
+    if (h == 0) {
+      const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
+      td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
+      td[1 * TSB + j] = (bf16_t)(d01 >> 16);
+      td[2 * TSB + j] = (bf16_t)(d23 & 0xffffu);
+      td[3 * TSB + j] = (bf16_t)(d23 >> 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dbsum[g] += dc4[g];
+    }
+    f32x16 dy6 = score_bwd<L_WST>(s_ops, lane, dc4, h);
+    dleaky_mul(k.t6, dy6);
+    bn_bwd_stats(k.z6, dy6, st);
+    // ---- the linear pieces of S5
+    {
+      // z6 tile (bf16, zeros for lanes without a view: a5 is masked, so z6 is 0 there)
+      float t16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t16[r] = k.z6[r];
+      bf16x8 zp[2];
+      pack16(t16, 0xffffffffu, zp);
+      tileN_put_packed(tz, j, h, zp);
+      // e = W6^T (G6 dy6)
+      float g6[16];
+      asm volatile("" ::: "memory");
+      tab16(s_tab[3], T_G, h, g6);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t16[r] = dy6[r] * g6[r];
+      bf16x8 gp[2];
+      pack16(t16, 0xffffffffu, gp);
+      const f32x16 zero = {0};
+      const f32x16 e = mm32_lds(s_ops, L_W6T, lane, gp, zero);
+      // m5 = leaky'(y5) (layer 5 is evaluated plain: sign of G5 z5 + B5), 0 for lanes without a view
+      float g5[16], b5[16], m5[16], mz[16];
+      asm volatile("" ::: "memory");
+      tab16(s_tab[2], T_G, h, g5);
+      tab16(s_tab[2], T_B, h, b5);
+      const float one = ok ? 1.f : 0.f, low = ok ? SLOPE : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y5 = __builtin_fmaf(k.z5[r], g5[r], b5[r]);
+        m5[r] = y5 > 0.f ? one : low;
+        mz[r] = m5[r] * k.z5[r];
+        sv[0][r] = __builtin_fmaf(m5[r], e[r], sv[0][r]);
+        sv[1][r] = __builtin_fmaf(mz[r], e[r], sv[1][r]);
+        sv[2][r] += m5[r];
+        sv[3][r] += mz[r];
+      }
+      bf16x8 mp[2], qp[2];
+      pack16(m5, 0xffffffffu, mp);
+      pack16(mz, 0xffffffffu, qp);
+      tileN_put_packed(tm, j, h, mp);
+      tileN_put_packed(tq, j, h, qp);
+    }
+    wave_sync();
+    accS = wgradN_T(tc, td, lane, j, 4, h, accS);
+    {
+      const bf16x8 z0 = tileN_get(tz, lane, 0), z1 = tileN_get(tz, lane, 1);
+      accP = CH_MFMA(tileN_get(tm, lane, 0), z0, accP);       // P2[c][j] = sum_v m5[v][c] z6[v][j]
+      accP = CH_MFMA(tileN_get(tm, lane, 1), z1, accP);
+      accQ = CH_MFMA(tileN_get(tq, lane, 0), z0, accQ);       // Q2[c][j] = sum_v (m5 z5)[v][c] z6[v][j]
+      accQ = CH_MFMA(tileN_get(tq, lane, 1), z1, accQ);
+    }
+    wave_sync();
+  });
+  flush_matrix_nat(accS, dWs, D, G, true, s_red, false);
+  flush_matrix_nat(accP, acc5, D, D, false, s_red, true);
+  flush_matrix_nat(accQ, acc5 + D * D, D, D, false, s_red, true);
+  flush_stats<2>(st, stats6, s_red);
+  flush_stats<4>(sv, vec5, s_red);
+  __syncthreads();       // dbs: one atomic per block and group (see the attention backward)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v = dbsum[g];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    if (lane == 0) s_red[wv * 4 + g] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) atomicAdd(&dbs[threadIdx.x], (s_red[threadIdx.x] + s_red[4 + threadIdx.x]) +
+                                                           (s_red[8 + threadIdx.x] + s_red[12 + threadIdx.x]));
+}
+
+// S5 (fp64 [64] = sum dy5 | sum dy5 z5, the form the layer passes accumulate) from the sums of score_l6_kernel once S6 is
+// complete: sm6 fp32 [64] = S1/M | S2_hat/M of layer 6 (dva_bn_bwd_consts), bn6 [4+][32], W6 fp32 [32][32] (rounded to
+// bf16 here like the operand of the W6^T product), acc5 = P2 | Q2, vec5 = e1 | e2 | n5 | q5.  One block of 32 threads.
+__global__ void l6_consts_kernel(const float* __restrict__ sm6, const float* __restrict__ bn6,
+                                 const float* __restrict__ W6, const float* __restrict__ acc5,
+                                 const double* __restrict__ vec5, double* __restrict__ s5) {
+  __shared__ double k1[D], k2[D];
+  const int c = threadIdx.x;
+  if (c < D) {
+    const double mean = bn6[c], inv = bn6[D + c], g = (double)bn6[2 * D + c] * inv;
+    const double s1 = sm6[c], s2 = sm6[D + c];
+    k1[c] = g * (s1 - mean * inv * s2);          // dz = G dy - K1 - K2 z (stage_tab)
+    k2[c] = g * inv * s2;
+  }
+  __syncthreads();
+  if (c >= D) return;
+  double t1 = 0.0, tp = 0.0, tq = 0.0;
+  for (int jj = 0; jj < D; ++jj) {
+    const double w = (double)bf2f(f2bf(W6[jj * D + c]));
+    t1 += w * k1[jj];
+    tp += w * k2[jj] * (double)acc5[c * D + jj];
+    tq += w * k2[jj] * (double)acc5[D * D + c * D + jj];
+  }
+  s5[c] = vec5[c] - vec5[2 * D + c] * t1 - tp;
+  s5[D + c] = vec5[D + c] - vec5[3 * D + c] * t1 - tq;
+}
+
+// ------------------------------------------------------------------------------------------------
 // layer passes.  STAGE 6: dz6 -> dW6, S5; hands dy5 = leaky'(y5) da5 (bf16 [V, 32]) to the next pass.
 // STAGE 5: dy5 -> dz5 -> dW5, du, S2 (view part); hands dy2 = leaky'(t2) da2 to the next pass.
 // STAGE 2: dy2 + set-pooling gradient -> dz2 -> dW2, dz1 statistics S1, P = sum dy1 x^T.
@@ -550,7 +748,10 @@ __device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
   return d;
 }
 
-template <int STAGE, int OCC, bool KEYS = false>
+// MERGED (STAGE 5 only, round 5): no stage 6 ran -- the pass starts from the score gradients dc [V, 4] and the constants
+// of the BatchNorm-6 backward (sm6), evaluates dy6 -> dz6 -> da5 -> dy5 itself and takes dW6 along (written to `Pm`);
+// S5 came from score_l6_kernel + l6_consts_kernel.
+template <int STAGE, int OCC, bool KEYS = false, bool MERGED = false>
 __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
@@ -579,8 +780,11 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   // place, W2 as a second operand (the raw z2 feeds the statistics) -> local 7, 8; stage 2: W1 as a second operand
   // -> local 5
   // stage 6: W1' W2' W5 W6 at their table positions 0..6, then W6T -> 7, 8; WST -> 9; W6' (folded) -> 10, 11
-  constexpr int NOPS = STAGE == 6 ? (KEYS ? 13 : 12) : (STAGE == 5 ? 9 : 6);      // (KEYS: W_k^T takes two blocks at L6_WST, the folded W6 moves up one)
+  static_assert(!MERGED || STAGE == 5, "the merged form is a stage-5 instance");
+  constexpr int NOPS = STAGE == 6 ? (KEYS ? 13 : 12) : (STAGE == 5 ? (MERGED ? 16 : 9) : 6);      // (KEYS: W_k^T takes two blocks at L6_WST, the folded W6 moves up one)
   constexpr int L_W5T = 5, L_W2T = 3, L_W2F = 7, L_W1F = 5, L6_W6T = 7, L6_WST = 9, L6_W6F = KEYS ? 11 : 10;
+  // merged stage 5: W6 -> 9, 10; W6' (folded) -> 11, 12; W6^T -> 13, 14; Ws^T -> 15
+  constexpr int L5_W6 = 9, L5_W6F = 11, L5_W6T = 13, L5_WST = 15;
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   if (STAGE == 6) {
@@ -604,10 +808,19 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       if (STAGE == 2 && op >= 3) op = OP_W2T + (op - 3);
       s_ops[i] = ops[op * 64 + (i & 63)];
     }
+    if (MERGED) {
+      for (int i = threadIdx.x; i < 5 * 64; i += blockDim.x) {
+        const int blk = i >> 6, l = i & 63;
+        if (blk < 2) s_ops[(L5_W6 + blk) * 64 + l] = ops[(OP_W6 + blk) * 64 + l];
+        else if (blk < 4) s_ops[(L5_W6T + blk - 2) * 64 + l] = ops[(OP_W6T + blk - 2) * 64 + l];
+        else s_ops[L5_WST * 64 + l] = ops[OP_WST * 64 + l];
+      }
+    }
     __syncthreads();
     if (STAGE == 5) {
       fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
       fold_ops(s_ops, L_W2F, ops, OP_W2, 2, bn2);
+      if (MERGED) fold_ops(s_ops, L5_W6F, ops, OP_W6, 2, bn6);
     } else {
       fold_ops(s_ops, L_W1F, ops, OP_W1, 1, bn1);
     }
@@ -615,7 +828,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   stage_tab(s_tab[0], bn1, nullptr);
   stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr);
   stage_tab(s_tab[2], bn5, STAGE == 5 ? sm5 : nullptr);
-  stage_tab(s_tab[3], bn6, STAGE == 6 ? sm6 : nullptr);
+  stage_tab(s_tab[3], bn6, (STAGE == 6 || MERGED) ? sm6 : nullptr);
   // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
   for (int i = threadIdx.x; i < 4 * 32 * TSB; i += blockDim.x) {
     if (STAGE == 2) {
@@ -632,7 +845,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
-  f32x16 accW = {0}, accS = {0};      // layer weight gradient; P (STAGE 2)
+  f32x16 accW = {0}, accS = {0};      // layer weight gradient; P (STAGE 2) / dW6 (merged stage 5)
   bf16_t* ta = s_ta[wv];
   bf16_t* tb_ = s_tb[wv];
   bf16_t* tc = s_tc[STAGE == 2 ? wv : 0];
@@ -717,7 +930,14 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       wave_sync();
     } else if constexpr (STAGE == 5) {
       f32x16 uacc = load_u(U, ok, p.vpj, h);
-      const u32x4 dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB), dhi = ld128(DI, ok ? view * 64u + 32u * h + 16u : OOB);
+      u32x4 dlo = {0, 0, 0, 0}, dhi = {0, 0, 0, 0};
+      float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (MERGED) {
+        dcv = as_f4(ld128(DC, ok && h == 0 ? view * 16u : OOB));
+      } else {
+        dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB);
+        dhi = ld128(DI, ok ? view * 64u + 32u * h + 16u : OOB);
+      }
       // forward up to layer 5
       bf16x8 a1[2], a2[2];
       asm volatile("" ::: "memory");
@@ -729,7 +949,41 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       }
       {
         const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
-        const f32x16 dy5 = unpack_da(dlo, dhi);           // stage 6 hands leaky'(y5) da5
+        f32x16 dy5;
+        if constexpr (MERGED) {
+          // what stage 6 did for this view: dy6 = leaky'(t6) Ws^T dc, dz6 = BatchNorm-6 backward, da5 = W6^T dz6,
+          // dy5 = leaky'(y5) da5 (fp32: no bf16 row in between); dW6 from the two natural tiles
+          bf16x8 a5[2];
+          act_pack(z5, s_tab[2], h, keep, a5);
+          const float dc4[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+          f32x16 dy6 = score_bwd<L5_WST>(s_ops, lane, dc4, h);
+          {
+            const f32x16 t6 = mm32_lds(s_ops, L5_W6F, lane, a5, bias_acc(s_tab[3], T_B6, h));
+            dleaky_mul(t6, dy6);
+          }
+          float dz6[16];
+          {
+            const f32x16 z6 = mm32_lds(s_ops, L5_W6, lane, a5, zero);
+            bn_bwd_apply(z6, dy6, s_tab[3], h, dz6);
+          }
+          bf16x8 dzp6[2];
+          pack16(dz6, keep, dzp6);
+          tileN_put_packed(ta, j, h, dzp6);
+          tileN_put_packed(tb_, j, h, a5);
+          const f32x16 da5 = mm32_lds(s_ops, L5_W6T, lane, dzp6, zero);
+          float g5[16], b5[16];
+          asm volatile("" ::: "memory");
+          tab16(s_tab[2], T_G, h, g5);
+          tab16(s_tab[2], T_B, h, b5);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dy5[r] = __builtin_fmaf(z5[r], g5[r], b5[r]) > 0.f ? da5[r] : SLOPE * da5[r];
+          wave_sync();
+          accS = wgradN(ta, tb_, lane, accS);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
+          wave_sync();
+        } else {
+          dy5 = unpack_da(dlo, dhi);           // stage 6 hands leaky'(y5) da5
+        }
         bn_bwd_apply(z5, dy5, s_tab[2], h, dz);
       }
       pack16(dz, keep, dzp);
@@ -852,6 +1106,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     }
   });
   flush_matrix_nat(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red, true);
+  if (MERGED) flush_matrix_nat(accS, Pm, D, D, false, s_red, true);          // dW6
   if (STAGE == 2) flush_matrix_nat(accS, Pm, 20, 17, false, s_red, false);
   else flush_stats<2>(st, stats, s_red);
 }
@@ -1155,6 +1410,61 @@ int dva_chain_bwd_layer(int32_t stage, const float* x_map, const int32_t* view_p
   else if (stage == 5) DVA_LAYER_BWD(5, 3);
   else DVA_LAYER_BWD(2, 3);
 #undef DVA_LAYER_BWD
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// Merged backward (round 5): score layer + the linear pieces of S5 in one pass (score_l6_kernel), S5 from them
+// (l6_consts_kernel), stage 5 from the score gradients (layer_bwd_kernel<5, ., false, true>): no stage 6, no dy5 tensor.
+int dva_chain_score_l6_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                             const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                             const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
+                             float* dbs, float* acc5, double* vec5, int32_t G, int64_t n_views, int64_t n_points,
+                             void* stream) {
+  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !grad_scores ||
+      !stats6 || !dWs || !dbs || !acc5 || !vec5)
+    return DVA_ERR_INVALID;
+  if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(score_l6_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
+                     (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores, stats6, dWs, dbs,
+                     acc5, vec5, (int)G, n_views, n_points);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_l6_consts(const float* sm6, const float* bn6, const float* W6, const float* acc5, const double* vec5,
+                        double* stats5, void* stream) {
+  if (!sm6 || !bn6 || !W6 || !acc5 || !vec5 || !stats5) return DVA_ERR_INVALID;
+  hipLaunchKernelGGL(l6_consts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sm6, bn6, W6, acc5, vec5, stats5);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_chain_bwd_layer5_merged(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                                const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                                const float* bn5, const float* bn6, const float* sm5, const float* sm6,
+                                const float* grad_scores, void* da_out, float* dW5, float* dW6, float* du, double* stats2,
+                                int32_t G, int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !bn5 || !bn6 || !sm5 || !sm6 ||
+      !grad_scores || !da_out || !dW5 || !dW6 || !du || !stats2)
+    return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  const dim3 block(256);
+  hipStream_t s = (hipStream_t)stream;
+  static const int occ = tune_int("DVA_STAGE5M_OCC", 2);
+#define DVA_LAYER5M(OCC_)                                                                                        \
+  hipLaunchKernelGGL((layer_bwd_kernel<5, OCC_, false, true>), dim3(chain_grid(OCC_)), block, 0, s, x_map,        \
+                     view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6,           \
+                     (const float*)nullptr, sm5, sm6, grad_scores, (const int32_t*)nullptr, (const float*)nullptr, \
+                     (const bf16_t*)nullptr, (bf16_t*)da_out, dW5, du, dW6, stats2, (int)G, n_views, n_points,    \
+                     (const float*)nullptr, 0.f)
+  if (occ == 3) DVA_LAYER5M(3);
+  else DVA_LAYER5M(2);
+#undef DVA_LAYER5M
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

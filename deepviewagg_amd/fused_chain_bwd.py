@@ -37,6 +37,12 @@ def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=Tru
     return sm, dg, db
 
 
+# Merged backward (round 5): the score pass also sums what the statistics of the BatchNorm-5 backward are linear in, stage 6
+# disappears and stage 5 starts from the score gradients (csrc/chain_bwd.hip score_l6_kernel).  DVA_CHAIN_MERGE=0: the
+# three-pass form of rounds 3-4 (kept as the A/B and for the key layer of QKVBimodalCSRPool).
+MERGE_STAGE6 = os.environ.get("DVA_CHAIN_MERGE", "1") == "1"
+
+
 def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, keys=None):
     """Everything of a chain backward behind the attention backward (which is specific to how the values are
     produced): score layer + BatchNorm-6 statistics, the three layer passes, the per-point set branch, layer 1.
@@ -66,8 +72,16 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
     # ---- score layer: dWs, dbs, and the statistics of the BatchNorm-6 backward (one chain evaluation)
     s6 = zstats()
     dWs, dbs = arena.take(G, D), arena.take(G)
+    merged = MERGE_STAGE6 and keys is None
     with ops._timed("chain_score_stats", V * (32 + 4 + 16) + N * (128 if keys is None else 256)):
-        if keys is None:
+        if merged:
+            # + the sums the statistics of the BatchNorm-5 backward are linear in: P2 | Q2 [2, 32, 32], e1 | e2 | n5 | q5
+            acc5 = arena.take(2, D, D)
+            vec5 = ops.zeros_small(4 * D, torch.float64, dev)
+            check(lib.dva_chain_score_l6_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                               ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs),
+                                               ptr(dbs), ptr(acc5), ptr(vec5), G, V, N, st), "dva_chain_score_l6_stats")
+        elif keys is None:
             check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                             ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
                                             G, V, N, st), "dva_chain_score_stats")
@@ -96,16 +110,30 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
     sm6, g6, b6 = consts(s6, bn6)
     dW6 = arena.take(D, D)
     s5 = zstats()
-    da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
-    layer(6, None, None, sm6, None, None, None, da5, dW6, None, None, s5, "chain_bwd_l6",
-          V * (32 + 4 + 16 + 64) + N * 128)
+    if merged:
+        W6 = module.E_map.mlp_elt_2[1][0].weight.detach().float().contiguous()
+        check(lib.dva_chain_l6_consts(ptr(sm6), ptr(bn6), ptr(W6), ptr(acc5), ptr(vec5), ptr(s5), st),
+              "dva_chain_l6_consts")
+        da5 = None
+    else:
+        da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
+        layer(6, None, None, sm6, None, None, None, da5, dW6, None, None, s5, "chain_bwd_l6",
+              V * (32 + 4 + 16 + 64) + N * 128)
     sm5, g5, b5 = consts(s5, bn5)
     dW5 = arena.take(D, 2 * D)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
     s2 = zstats()
     da2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
-    layer(5, None, sm5, None, None, None, da5, da2, dW5, du, None, s2, "chain_bwd_l5",
-          V * (32 + 4 + 64 + 64) + N * 256)
+    if merged:
+        # per view: x_map 32 + view -> point 4 + score gradients 16 in, the 64-byte dy2 row out
+        with ops._timed("chain_bwd_l5", V * (32 + 4 + 16 + 64) + N * 256):
+            check(lib.dva_chain_bwd_layer5_merged(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                                  ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm5), ptr(sm6), ptr(dc),
+                                                  ptr(da2), ptr(dW5), ptr(dW6), ptr(du), ptr(s2), min(G, 4), V, N, st),
+                  "dva_chain_bwd_layer5_merged")
+    else:
+        layer(5, None, sm5, None, None, None, da5, da2, dW5, du, None, s2, "chain_bwd_l5",
+              V * (32 + 4 + 64 + 64) + N * 256)
     del da5
     # ---- per-point set branch
     dpooled, d_set = _set_branch_backward(set_saved, du, dW5, training, zstats, arena)

@@ -583,6 +583,28 @@ int dva_chain_set_bwd(int32_t stage, const float* pooled, const int64_t* ptr, co
                       const float* bn_s1, const float* bn_s2, const float* sm_s1, const float* sm_s2,
                       const float* du, float* dpooled, float* dW, int32_t ld_dw, float* dw33, double* stats,
                       int64_t n_points, void* stream);
+/* Merged chain backward (round 5; autograd of modules/multimodal/pooling.py:263-315, :658-669 as the entries around it): the
+ * score pass also accumulates the pieces the statistics of the BatchNorm-5 backward are linear in (dz6 = G6 dy6 - K1 - K2 z6
+ * is linear in the constants K1, K2 the same pass is still summing), so that stage 6 -- one chain evaluation, the bf16
+ * [V][32] dy5 tensor, one launch -- disappears:
+ *   dva_chain_score_l6_stats   dva_chain_score_stats + acc5 fp32 [2][32][32] = P2 | Q2 and vec5 fp64 [4][32] = e1 | e2 | n5 | q5
+ *                              (both caller-zeroed; see csrc/chain_bwd.hip score_l6_kernel)
+ *   dva_chain_l6_consts        stats5 fp64 [64] = sum dy5 | sum dy5 z5 from them, sm6 (dva_bn_bwd_consts of stats6), bn6 and
+ *                              the fp32 weight W6 [32][32]
+ *   dva_chain_bwd_layer5_merged  stage 5 of dva_chain_bwd_layer starting from grad_scores [V][4] and sm6 instead of the dy5
+ *                              row: also writes dW6 [32][32] (caller-zeroed) */
+int dva_chain_score_l6_stats(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                             const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                             const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
+                             float* dbs, float* acc5, double* vec5, int32_t G, int64_t n_views, int64_t n_points,
+                             void* stream);
+int dva_chain_l6_consts(const float* sm6, const float* bn6, const float* W6, const float* acc5, const double* vec5,
+                        double* stats5, void* stream);
+int dva_chain_bwd_layer5_merged(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,
+                                const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
+                                const float* bn5, const float* bn6, const float* sm5, const float* sm6,
+                                const float* grad_scores, void* da_out, float* dW5, float* dW6, float* du, double* stats2,
+                                int32_t G, int64_t n_views, int64_t n_points, void* stream);
 /* Backward of the softmax / weighted sum / gate of dva_chain_attn_fwd from the scores it left (scores fp32 [V][4]):
  * no chain evaluation.  grad_out / out bf16 [N][C] (out = the forward result; only read for points with more than 32
  * views).  Outputs: grad_scores fp32 [V][4] (columns >= G zero), view_rec = V packed 16-byte records {int32 point id |
