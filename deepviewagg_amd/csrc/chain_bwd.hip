@@ -622,42 +622,51 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
     bn_bwd_stats(k.z6, dy6, st);
     // ---- the linear pieces of S5
     {
-      // z6 tile (bf16, zeros for lanes without a view: a5 is masked, so z6 is 0 there)
-      float t16[16];
+      // z6 tile (bf16, zeros for lanes without a view: a5 is masked, so z6 is 0 there) and G6 dy6 as the operand of
+      // e = W6^T (G6 dy6); constants four channels at a time (a few float4 live instead of 48 registers)
+      float t16[16], gd[16];
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t16[r] = k.z6[r];
-      bf16x8 zp[2];
+      for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(s_tab[3] + T_G * D + 16 * h + 4 * q);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          t16[4 * q + e] = k.z6[4 * q + e];
+          gd[4 * q + e] = dy6[4 * q + e] * g[e];
+        }
+      }
+      bf16x8 zp[2], gp[2];
       pack16(t16, 0xffffffffu, zp);
       tileN_put_packed(tz, j, h, zp);
-      // e = W6^T (G6 dy6)
-      float g6[16];
-      asm volatile("" ::: "memory");
-      tab16(s_tab[3], T_G, h, g6);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t16[r] = dy6[r] * g6[r];
-      bf16x8 gp[2];
-      pack16(t16, 0xffffffffu, gp);
+      pack16(gd, 0xffffffffu, gp);
       const f32x16 zero = {0};
       const f32x16 e = mm32_lds(s_ops, L_W6T, lane, gp, zero);
       // m5 = leaky'(y5) (layer 5 is evaluated plain: sign of G5 z5 + B5), 0 for lanes without a view
-      float g5[16], b5[16], m5[16], mz[16];
-      asm volatile("" ::: "memory");
-      tab16(s_tab[2], T_G, h, g5);
-      tab16(s_tab[2], T_B, h, b5);
       const float one = ok ? 1.f : 0.f, low = ok ? SLOPE : 0.f;
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float y5 = __builtin_fmaf(k.z5[r], g5[r], b5[r]);
-        m5[r] = y5 > 0.f ? one : low;
-        mz[r] = m5[r] * k.z5[r];
-        sv[0][r] = __builtin_fmaf(m5[r], e[r], sv[0][r]);
-        sv[1][r] = __builtin_fmaf(mz[r], e[r], sv[1][r]);
-        sv[2][r] += m5[r];
-        sv[3][r] += mz[r];
+      for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(s_tab[2] + T_G * D + 16 * h + 4 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_tab[2] + T_B * D + 16 * h + 4 * q);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int r = 4 * q + e4;
+          const float y5 = __builtin_fmaf(k.z5[r], g[e4], b[e4]);
+          const float m = y5 > 0.f ? one : low;
+          const float mzv = m * k.z5[r];
+          t16[r] = m;
+          gd[r] = mzv;
+          sv[0][r] = __builtin_fmaf(m, e[r], sv[0][r]);
+          sv[1][r] = __builtin_fmaf(mzv, e[r], sv[1][r]);
+          sv[2][r] += m;
+          sv[3][r] += mzv;
+        }
       }
       bf16x8 mp[2], qp[2];
-      pack16(m5, 0xffffffffu, mp);
-      pack16(mz, 0xffffffffu, qp);
+      pack16(t16, 0xffffffffu, mp);
+      pack16(gd, 0xffffffffu, qp);
       tileN_put_packed(tm, j, h, mp);
       tileN_put_packed(tq, j, h, qp);
     }
@@ -971,13 +980,18 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
           tileN_put_packed(ta, j, h, dzp6);
           tileN_put_packed(tb_, j, h, a5);
           const f32x16 da5 = mm32_lds(s_ops, L5_W6T, lane, dzp6, zero);
-          float g5[16], b5[16];
           asm volatile("" ::: "memory");
-          tab16(s_tab[2], T_G, h, g5);
-          tab16(s_tab[2], T_B, h, b5);
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            dy5[r] = __builtin_fmaf(z5[r], g5[r], b5[r]) > 0.f ? da5[r] : SLOPE * da5[r];
+          for (int q = 0; q < 4; ++q) {        // four channels at a time: two float4 of constants live
+            const float4 g4 = *reinterpret_cast<const float4*>(s_tab[2] + T_G * D + 16 * h + 4 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(s_tab[2] + T_B * D + 16 * h + 4 * q);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * q + e;
+              dy5[r] = __builtin_fmaf(z5[r], g[e], b[e]) > 0.f ? da5[r] : SLOPE * da5[r];
+            }
+          }
           wave_sync();
           accS = wgradN(ta, tb_, lane, accS);      // dW6[n][k] = sum_v dz6[v][n] a5[v][k]
           wave_sync();

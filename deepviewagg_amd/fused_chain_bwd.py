@@ -37,10 +37,13 @@ def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=Tru
     return sm, dg, db
 
 
-# Merged backward (round 5): the score pass also sums what the statistics of the BatchNorm-5 backward are linear in, stage 6
-# disappears and stage 5 starts from the score gradients (csrc/chain_bwd.hip score_l6_kernel).  DVA_CHAIN_MERGE=0: the
-# three-pass form of rounds 3-4 (kept as the A/B and for the key layer of QKVBimodalCSRPool).
-MERGE_STAGE6 = os.environ.get("DVA_CHAIN_MERGE", "1") == "1"
+# DVA_CHAIN_MERGE=1 -- merged backward (round 5): the score pass also sums what the statistics of the
+# BatchNorm-5 backward are linear in, stage 6 disappears and stage 5 starts from the score gradients (csrc/chain_bwd.hip
+# score_l6_kernel).  Built, parity-green (tests/test_gpu_chain.py::test_merged_backward_matches_three_pass and the whole
+# chain / bilinear / full-size suites under the switch) and measured: the step does not move (11.02 against 11.01 ms:
+# profiles/r05_chain_merge_ab.json) -- the accumulators the merged passes carry cost both their third wavefront per SIMD
+# (score pass 0.78 -> 1.50 ms, stage 5 1.21 -> 1.83 ms, against the 1.14 ms of stage 6).  Off by default.
+MERGE_STAGE6 = os.environ.get("DVA_CHAIN_MERGE", "0") == "1"
 
 
 def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, keys=None):
