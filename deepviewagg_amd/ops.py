@@ -85,12 +85,13 @@ TIMER = None
 # small zero-filled tensors (statistics accumulators, gradient arenas) without a fill launch each
 # ---------------------------------------------------------------------------------------------
 _ZERO_POOLS = {}
-_ZERO_POOL_BYTES = 4 << 20
+_ZERO_POOL_BYTES = 32 << 20
+_ZERO_SMALL_BYTES = 1 << 20
 
 
 def zeros_small(shape, dtype, device):
     """``torch.zeros(shape, dtype=dtype, device=device)`` for the small accumulators of a step (fp64 statistics of a
-    BatchNorm layer, the fp32 arena of a backward): a piece of a 4 MiB zero-filled pool per (device, stream) that only
+    BatchNorm layer, the fp32 arena of a backward): a piece of a 32 MiB zero-filled pool per (device, stream) that only
     moves forward -- a piece is handed out once, so it is zero when the kernel that accumulates into it runs, and the
     pool is replaced (one fill) when it is used up.  A step of the pooling path asks for ~10 such tensors; each used to
     be its own 4-5 us fill kernel (round 5).  Large requests and requests during a HIP-graph capture (a captured fill is
@@ -100,7 +101,7 @@ def zeros_small(shape, dtype, device):
     for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
         n *= int(d)
     nbytes = n * torch.empty((), dtype=dtype).element_size()
-    if (device.type != "cuda" or nbytes == 0 or nbytes > _ZERO_POOL_BYTES // 4
+    if (device.type != "cuda" or nbytes == 0 or nbytes > _ZERO_SMALL_BYTES
             or torch.cuda.is_current_stream_capturing()):
         return torch.zeros(shape, dtype=dtype, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(),
@@ -110,7 +111,7 @@ def zeros_small(shape, dtype, device):
     if pool is None or pool[1] + step > _ZERO_POOL_BYTES:
         # the pieces of a used-up pool are still alive when its successor is allocated: the first pool reserves the
         # second block as well (held while the first is allocated, then handed back to the caching allocator), so that
-        # no hipMalloc lands in a later step (1.3 ms once every ~27 steps, seen in the bench's per-step times)
+        # no hipMalloc lands in a later step (a pool lasts ~200 steps of the headline workload)
         spare = torch.empty(_ZERO_POOL_BYTES, dtype=torch.uint8, device=device) if pool is None else None
         pool = [torch.zeros(_ZERO_POOL_BYTES, dtype=torch.uint8, device=device), 0]
         del spare
