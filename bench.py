@@ -1014,6 +1014,8 @@ def main():
     kern = prof_timer.summary()
     dom_name = max(kern.items(), key=lambda kv: kv[1]["ms"])[0]
     target_name = "chain_attn_fwd" if "chain_attn_fwd" in kern else "view_gather_attention_fwd"
+    for _ in range(2):          # settle: the allocator's block pattern of steps WITHOUT per-launch events (the first such
+        one_step()              # step after the profile steps was seen 1.4 ms slow with one device allocation)
     barrier()
     ops.TIMER = ops.KernelTimer(only={dom_name, target_name})
     # A one-off host stall inside the timed region (one step of 47 ms among nineteen of 11.2 ms, twice in six runs on the
