@@ -1014,17 +1014,18 @@ def main():
     kern = prof_timer.summary()
     dom_name = max(kern.items(), key=lambda kv: kv[1]["ms"])[0]
     target_name = "chain_attn_fwd" if "chain_attn_fwd" in kern else "view_gather_attention_fwd"
-    for _ in range(2):          # settle: the allocator's block pattern of steps WITHOUT per-launch events (the first such
-        one_step()              # step after the profile steps was seen 1.4 ms slow with one device allocation)
-    barrier()
-    ops.TIMER = ops.KernelTimer(only={dom_name, target_name})
     # A one-off host stall inside the timed region (one step of 47 ms among nineteen of 11.2 ms, twice in six runs on the
     # GPU box) is the host, not the path: the collector of Python cycles is switched off for the K timed steps (a full
     # collection over the module / autograd objects takes tens of ms), and the caching allocator's device allocations
-    # during the region are counted and reported (a hipMalloc of a new segment is the other candidate)
+    # during the region are counted and reported.  Two settle steps in the same regime first: the step right after a
+    # collection was seen 1.4 ms slow with one device allocation (freed cycles change the allocator's block pattern).
     import gc
     gc.collect()
     gc.disable()
+    for _ in range(2):
+        one_step()
+    barrier()
+    ops.TIMER = ops.KernelTimer(only={dom_name, target_name})
     mem0 = torch.cuda.memory_stats(device)
     # one event per step boundary (6 us per step): the device-side duration of every timed step goes into the JSON line,
     # so that a one-off stall (a 33 ms hiccup was seen once in twenty runs) is visible next to the wall-clock value
