@@ -17,6 +17,8 @@ All ops require tensors on a HIP device and raise otherwise (no CPU fallback).
 """
 import os
 
+import threading
+
 import torch
 
 from . import _lib
@@ -85,6 +87,7 @@ TIMER = None
 # small zero-filled tensors (statistics accumulators, gradient arenas) without a fill launch each
 # ---------------------------------------------------------------------------------------------
 _ZERO_POOLS = {}
+_ZERO_LOCK = threading.Lock()
 _ZERO_POOL_BYTES = 32 << 20
 _ZERO_SMALL_BYTES = 1 << 20
 
@@ -106,8 +109,13 @@ def zeros_small(shape, dtype, device):
         return torch.zeros(shape, dtype=dtype, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
-    pool = _ZERO_POOLS.get(key)
     step = (nbytes + 255) & ~255
+    with _ZERO_LOCK:        # the autograd thread and the caller's thread may both ask (never the same piece twice)
+        return _zero_piece(key, step, nbytes, shape, dtype, device)
+
+
+def _zero_piece(key, step, nbytes, shape, dtype, device):
+    pool = _ZERO_POOLS.get(key)
     if pool is None or pool[1] + step > _ZERO_POOL_BYTES:
         # the pieces of a used-up pool are still alive when its successor is allocated: the first pool reserves the
         # second block as well (held while the first is allocated, then handed back to the caching allocator), so that
