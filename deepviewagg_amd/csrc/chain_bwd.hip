@@ -519,6 +519,47 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
                                                            (s_red[8 + threadIdx.x] + s_red[12 + threadIdx.x]));
 }
 
+// column sums of natural tiles this wavefront has just written: lane (n, hh) receives 16 of the 32 views of image column
+// n through the transpose read; two registers per statistic pair instead of 32 per-lane accumulators (merged stage 5)
+__device__ __forceinline__ void col_sums_xy(const bf16_t* tx, const bf16_t* ty, int lane, float& sx, float& sxy) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float x[8], y[8];
+    unpack8(tileN_get(tx, lane, m), x);
+    unpack8(tileN_get(ty, lane, m), y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sx += x[i];
+      sxy = __builtin_fmaf(x[i], y[i], sxy);
+    }
+  }
+}
+// the two halves of the column sums (lanes n and n + 32) -> fp64 atomics in a fixed per-block order; column n of a
+// natural tile = channel cperm(n).  s_red: 4 x 2 x 32 floats.
+__device__ __forceinline__ void flush_col_stats(float v0, float v1, double* __restrict__ out, float* s_red) {
+  const int wv = threadIdx.x >> 6, n = threadIdx.x & 31;
+  {
+    uint32_t a = __float_as_uint(v0), b = a;
+    swap_halves(a, b);
+    v0 += __uint_as_float((threadIdx.x & 32) ? a : b);
+    uint32_t c = __float_as_uint(v1), d = c;
+    swap_halves(c, d);
+    v1 += __uint_as_float((threadIdx.x & 32) ? c : d);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 32) == 0) {
+    s_red[(wv * 2 + 0) * 32 + n] = v0;
+    s_red[(wv * 2 + 1) * 32 + n] = v1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    double acc = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) acc += (double)s_red[(w * 2 + which) * 32 + n];
+    atomicAdd(&out[which * D + cperm(n)], acc);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Merged backward (round 5): the score pass ALSO produces what stage 6 existed for -- the statistics S5 of the
 // BatchNorm-5 backward -- so that stage 6 disappears and stage 5 starts from the score gradients.
@@ -539,7 +580,7 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
 // acc5 fp32 [2][32][32] = P2 | Q2 (channel indices, caller-zeroed), vec5 fp64 [4][32] = e1 | e2 | n5 | q5 (caller-zeroed).
 // LDS operand table: chain positions 0..6 (W1', W2', W5, W6), 7..8 = W6' (folded), 9 = Ws^T, 10..11 = W6^T.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void score_l6_kernel(
+__global__ __launch_bounds__(256, 3) void score_l6_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
@@ -549,12 +590,12 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
   constexpr int L_W6F = 7, L_WST = 9, L_W6T = 10, NOPS = 12;
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
-  // natural tiles: a6 (score-weight gradient), m5, m5 z5, z6; a 4-row transposed score-gradient tile (+ one zero row)
-  __shared__ __attribute__((aligned(16))) bf16_t s_tc[4][32 * TSB], s_tm[4][32 * TSB], s_tq[4][32 * TSB],
-      s_tz[4][32 * TSB], s_td[4][5 * TSB];
-  float* s_red = reinterpret_cast<float*>(&s_tc[0][0]);        // epilogue only
+  // THREE natural tile buffers per wavefront, used in turn (the LDS budget of three blocks per CU), and the 4-row
+  // transposed score-gradient tile (+ one zero row).  Every vector statistic is a column sum of such tiles (two registers
+  // per pair, col_sums_xy) instead of 16 per-lane accumulators: the register budget of three wavefronts per SIMD.
+  __shared__ __attribute__((aligned(16))) bf16_t s_t0[4][32 * TSB], s_t1[4][32 * TSB], s_t2[4][32 * TSB], s_td[4][5 * TSB];
+  float* s_red = reinterpret_cast<float*>(&s_t0[0][0]);        // epilogue only
   static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * D * D, "epilogue buffer");
-  static_assert(sizeof(bf16_t) * 4 * 32 * TSB >= sizeof(float) * 4 * 4 * D, "statistics buffer");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < 4 * 5 * TSB; i += blockDim.x) (&s_td[0][0])[i] = 0;
   for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) s_ops[OP_W5 * 64 + i] = ops[OP_W5 * 64 + i];   // W5, W6
@@ -570,19 +611,13 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
   __syncthreads();
   const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16);
-  bf16_t* tc = s_tc[wv];
-  bf16_t* tm = s_tm[wv];
-  bf16_t* tq = s_tq[wv];
-  bf16_t* tz = s_tz[wv];
+  bf16_t* b0 = s_t0[wv];
+  bf16_t* b1 = s_t1[wv];
+  bf16_t* b2 = s_t2[wv];
   bf16_t* td = s_td[wv];
   f32x16 accS = {0}, accP = {0}, accQ = {0};
   float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
-  float st[2][16], sv[4][16];          // S6; e1 | e2 | n5 | q5
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    st[0][r] = st[1][r] = 0.f;
-    sv[0][r] = sv[1][r] = sv[2][r] = sv[3][r] = 0.f;
-  }
+  float s6a = 0.f, s6b = 0.f, n5 = 0.f, e1 = 0.f, q5 = 0.f, e2 = 0.f;       // column sums (lane = image column, half)
   const int n_tiles = n_tiles_dev[0];
   int ta, tb;
   wave_tile_range(tiles, n_tiles, ta, tb);
@@ -607,7 +642,8 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
     ChainKeep k;
     chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
     const float dc4[4] = {p.dc.x, p.dc.y, p.dc.z, p.dc.w};      // zeros in the lanes without a view and for h = 1
-    tileN_put_packed(tc, j, h, k.a6);
+    // ---- phase 1: b0 = a6, td = dc (score-weight gradient); b1 = z6, b2 = dy6 (S6 as column sums of the rounded values)
+    tileN_put_packed(b0, j, h, k.a6);
     if (h == 0) {
       const uint32_t d01 = pack_bf16x2(dc4[0], dc4[1]), d23 = pack_bf16x2(dc4[2], dc4[3]);
       td[0 * TSB + j] = (bf16_t)(d01 & 0xffffu);
@@ -619,11 +655,10 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
     }
     f32x16 dy6 = score_bwd<L_WST>(s_ops, lane, dc4, h);
     dleaky_mul(k.t6, dy6);
-    bn_bwd_stats(k.z6, dy6, st);
-    // ---- the linear pieces of S5
+    f32x16 e;
     {
-      // z6 tile (bf16, zeros for lanes without a view: a5 is masked, so z6 is 0 there) and G6 dy6 as the operand of
-      // e = W6^T (G6 dy6); constants four channels at a time (a few float4 live instead of 48 registers)
+      // z6 and dy6 tiles (zeros for lanes without a view: a5 is masked and dc reads 0); G6 dy6 as the operand of
+      // e = W6^T (G6 dy6); constants four channels at a time
       float t16[16], gd[16];
       asm volatile("" ::: "memory");
 #pragma unroll
@@ -631,19 +666,30 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
         const float4 g4 = *reinterpret_cast<const float4*>(s_tab[3] + T_G * D + 16 * h + 4 * q);
         const float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          t16[4 * q + e] = k.z6[4 * q + e];
-          gd[4 * q + e] = dy6[4 * q + e] * g[e];
+        for (int c = 0; c < 4; ++c) {
+          t16[4 * q + c] = dy6[4 * q + c];
+          gd[4 * q + c] = dy6[4 * q + c] * g[c];
         }
       }
-      bf16x8 zp[2], gp[2];
-      pack16(t16, 0xffffffffu, zp);
-      tileN_put_packed(tz, j, h, zp);
-      pack16(gd, 0xffffffffu, gp);
+      bf16x8 pk[2];
+      pack16(t16, 0xffffffffu, pk);
+      tileN_put_packed(b2, j, h, pk);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t16[r] = k.z6[r];
+      pack16(t16, 0xffffffffu, pk);
+      tileN_put_packed(b1, j, h, pk);
+      pack16(gd, 0xffffffffu, pk);
       const f32x16 zero = {0};
-      const f32x16 e = mm32_lds(s_ops, L_W6T, lane, gp, zero);
-      // m5 = leaky'(y5) (layer 5 is evaluated plain: sign of G5 z5 + B5), 0 for lanes without a view
+      e = mm32_lds(s_ops, L_W6T, lane, pk, zero);
+    }
+    wave_sync();
+    accS = wgradN_T(b0, td, lane, j, 4, h, accS);
+    col_sums_xy(b2, b1, lane, s6a, s6b);                        // sum dy6 | sum dy6 z6
+    wave_sync();
+    // ---- phase 2: b0 = m5, b2 = m5 z5 (b1 = z6 stays): P2, Q2
+    {
       const float one = ok ? 1.f : 0.f, low = ok ? SLOPE : 0.f;
+      float m16[16], q16[16];
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -651,41 +697,48 @@ __global__ __launch_bounds__(256, 2) void score_l6_kernel(
         const float4 b4 = *reinterpret_cast<const float4*>(s_tab[2] + T_B * D + 16 * h + 4 * q);
         const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          const int r = 4 * q + e4;
-          const float y5 = __builtin_fmaf(k.z5[r], g[e4], b[e4]);
-          const float m = y5 > 0.f ? one : low;
-          const float mzv = m * k.z5[r];
-          t16[r] = m;
-          gd[r] = mzv;
-          sv[0][r] = __builtin_fmaf(m, e[r], sv[0][r]);
-          sv[1][r] = __builtin_fmaf(mzv, e[r], sv[1][r]);
-          sv[2][r] += m;
-          sv[3][r] += mzv;
+        for (int c = 0; c < 4; ++c) {
+          const int r = 4 * q + c;
+          const float y5 = __builtin_fmaf(k.z5[r], g[c], b[c]);      // layer 5 is evaluated plain: sign of G5 z5 + B5
+          m16[r] = y5 > 0.f ? one : low;
+          q16[r] = m16[r] * k.z5[r];
         }
       }
       bf16x8 mp[2], qp[2];
-      pack16(t16, 0xffffffffu, mp);
-      pack16(gd, 0xffffffffu, qp);
-      tileN_put_packed(tm, j, h, mp);
-      tileN_put_packed(tq, j, h, qp);
+      pack16(m16, 0xffffffffu, mp);
+      pack16(q16, 0xffffffffu, qp);
+      tileN_put_packed(b0, j, h, mp);
+      tileN_put_packed(b2, j, h, qp);
     }
     wave_sync();
-    accS = wgradN_T(tc, td, lane, j, 4, h, accS);
     {
-      const bf16x8 z0 = tileN_get(tz, lane, 0), z1 = tileN_get(tz, lane, 1);
-      accP = CH_MFMA(tileN_get(tm, lane, 0), z0, accP);       // P2[c][j] = sum_v m5[v][c] z6[v][j]
-      accP = CH_MFMA(tileN_get(tm, lane, 1), z1, accP);
-      accQ = CH_MFMA(tileN_get(tq, lane, 0), z0, accQ);       // Q2[c][j] = sum_v (m5 z5)[v][c] z6[v][j]
-      accQ = CH_MFMA(tileN_get(tq, lane, 1), z1, accQ);
+      const bf16x8 z0 = tileN_get(b1, lane, 0), z1 = tileN_get(b1, lane, 1);
+      accP = CH_MFMA(tileN_get(b0, lane, 0), z0, accP);       // P2[c][j] = sum_v m5[v][c] z6[v][j]
+      accP = CH_MFMA(tileN_get(b0, lane, 1), z1, accP);
+      accQ = CH_MFMA(tileN_get(b2, lane, 0), z0, accQ);       // Q2[c][j] = sum_v (m5 z5)[v][c] z6[v][j]
+      accQ = CH_MFMA(tileN_get(b2, lane, 1), z1, accQ);
     }
+    wave_sync();
+    // ---- phase 3: b1 = e: n5 | e1 = sum m5 | sum m5 e,  q5 | e2 = sum m5 z5 | sum (m5 z5) e
+    {
+      float t16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t16[r] = e[r];
+      bf16x8 ep[2];
+      pack16(t16, 0xffffffffu, ep);
+      tileN_put_packed(b1, j, h, ep);
+    }
+    wave_sync();
+    col_sums_xy(b0, b1, lane, n5, e1);
+    col_sums_xy(b2, b1, lane, q5, e2);
     wave_sync();
   });
   flush_matrix_nat(accS, dWs, D, G, true, s_red, false);
   flush_matrix_nat(accP, acc5, D, D, false, s_red, true);
   flush_matrix_nat(accQ, acc5 + D * D, D, D, false, s_red, true);
-  flush_stats<2>(st, stats6, s_red);
-  flush_stats<4>(sv, vec5, s_red);
+  flush_col_stats(s6a, s6b, stats6, s_red);
+  flush_col_stats(e1, e2, vec5, s_red);
+  flush_col_stats(n5, q5, vec5 + 2 * D, s_red);
   __syncthreads();       // dbs: one atomic per block and group (see the attention backward)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -854,6 +907,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
+  float cs1 = 0.f, cs2 = 0.f;         // merged stage 5: S2 (view part) as column sums of natural tiles
   f32x16 accW = {0}, accS = {0};      // layer weight gradient; P (STAGE 2) / dW6 (merged stage 5)
   bf16_t* ta = s_ta[wv];
   bf16_t* tb_ = s_tb[wv];
@@ -871,7 +925,11 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     u32x4 dlo, dhi;
     int vpj;
   };
-  run_tiles<Pre>(tiles, t0, t1, [&](const TileInfo& ti, int t) {
+  auto loop = [&](auto&& load, auto&& body) {
+    if constexpr (MERGED) run_tiles_single<Pre>(tiles, t0, t1, load, body);      // one register set: the occupancy step
+    else run_tiles<Pre>(tiles, t0, t1, load, body);
+  };
+  loop([&](const TileInfo& ti, int t) {
     Pre p;
     p.ti = ti;
     const bool ok = j < p.ti.nv;
@@ -1002,7 +1060,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       }
       pack16(dz, keep, dzp);
       tileN_put_packed(ta, j, h, dzp);
-      tileN_put_packed(tb_, j, h, a2);
+      if constexpr (!MERGED) tileN_put_packed(tb_, j, h, a2);      // (merged: a2 is packed again below, see there)
       // du[p][c] = sum of dz5 over the views of point p = dz5^T . indicator: one more product on the matrix cores
       // (operands: the transposed dz5 tile and a [local point][view] indicator tile of 1.0 / 0)
       const int prv = shfl(p.vpj, lane - 1);
@@ -1019,9 +1077,15 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
         // layer 2 was evaluated folded: leaky' follows the sign of t2 (evaluated again here: a1 is 8 registers, t2 16)
         const f32x16 t2 = mm32_lds(s_ops, L_W2F, lane, a1, bias_acc(s_tab[1], T_B6, h));
         dleaky_mul(t2, dy2);
+        if constexpr (MERGED) {
+          // the a2 operand of the dW5 product from the same t2: 8 registers that do not live across the layer-6 block
+          bf16x8 a2b[2];
+          act_fold(t2, keep, a2b);
+          tileN_put_packed(tb_, j, h, a2b);
+        }
       }
-      store_da(DO, ok, view, h, dy2);
-      {
+      if constexpr (!MERGED) {
+        store_da(DO, ok, view, h, dy2);
         const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);     // the raw output: sum dy2 z2
         bn_bwd_stats(z2, dy2, st);
       }
@@ -1030,6 +1094,31 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       const int frag = p.ti.frag;
       const f32x16 accU = wgradN_T(ta, ind, lane, j, 32, h, zero);      // du[image column][local point j] of this tile
       if (h == 0 && ok) ind[lpj * TSB + j] = 0;           // leave the indicator tile clean for the next tile
+      if constexpr (MERGED) {
+        // the row that is handed over (bf16) and the raw z2 as natural tiles in the buffers the products have just read:
+        // S2 = sum dy2 | sum dy2 z2 through column sums -- two registers instead of the 32 per-lane accumulators
+        // (the third wavefront per SIMD of this instance); statistics of the rounded values
+        wave_sync();
+        float t16[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t16[r] = dy2[r];
+        bf16x8 dyp[2];
+        pack16(t16, keep, dyp);
+        const uint32_t off = ok ? view * 64u + 32u * h : OOB;
+        st128(DO, off, __builtin_bit_cast(u32x4, dyp[0]));
+        st128(DO, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, dyp[1]));
+        tileN_put_packed(ta, j, h, dyp);
+        {
+          const f32x16 z2 = mm32_lds(s_ops, OP_W2, lane, a1, zero);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t16[r] = z2[r];
+          bf16x8 zp[2];
+          pack16(t16, keep, zp);
+          tileN_put_packed(tb_, j, h, zp);
+        }
+        wave_sync();
+        col_sums_xy(ta, tb_, lane, cs1, cs2);
+      }
       {
         const bool wr = j < nseg;
         const uint32_t pt = wr ? (uint32_t)plp[j] : 0u;
@@ -1122,6 +1211,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
   flush_matrix_nat(accW, dW, STAGE == 5 ? 2 * D : D, D, false, s_red, true);
   if (MERGED) flush_matrix_nat(accS, Pm, D, D, false, s_red, true);          // dW6
   if (STAGE == 2) flush_matrix_nat(accS, Pm, 20, 17, false, s_red, false);
+  else if (MERGED) flush_col_stats(cs1, cs2, stats, s_red);
   else flush_stats<2>(st, stats, s_red);
 }
 
@@ -1441,7 +1531,7 @@ int dva_chain_score_l6_stats(const float* x_map, const int32_t* view_point, cons
       !stats6 || !dWs || !dbs || !acc5 || !vec5)
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(score_l6_kernel, dim3(chain_grid(2)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
+  hipLaunchKernelGGL(score_l6_kernel, dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map, view_point, u,
                      (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores, stats6, dWs, dbs,
                      acc5, vec5, (int)G, n_views, n_points);
   DVA_CHECK_LAUNCH();
@@ -1469,7 +1559,7 @@ int dva_chain_bwd_layer5_merged(const float* x_map, const int32_t* view_point, c
   if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   const dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
-  static const int occ = tune_int("DVA_STAGE5M_OCC", 2);
+  static const int occ = tune_int("DVA_STAGE5M_OCC", 3);
 #define DVA_LAYER5M(OCC_)                                                                                        \
   hipLaunchKernelGGL((layer_bwd_kernel<5, OCC_, false, true>), dim3(chain_grid(OCC_)), block, 0, s, x_map,        \
                      view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6,           \
