@@ -522,15 +522,17 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
 // column sums of natural tiles this wavefront has just written: lane (n, hh) receives 16 of the 32 views of image column
 // n through the transpose read; two registers per statistic pair instead of 32 per-lane accumulators (merged stage 5)
 __device__ __forceinline__ void col_sums_xy(const bf16_t* tx, const bf16_t* ty, int lane, float& sx, float& sxy) {
+  // packed bf16 pairs straight into v_dot2c_f32_bf16 (fp32 accumulation): four dot products per eight values for
+  // sum x y, four against a pair of ones for sum x -- no unpacking
+  const uint32_t ones = 0x3f803f80u;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    float x[8], y[8];
-    unpack8(tileN_get(tx, lane, m), x);
-    unpack8(tileN_get(ty, lane, m), y);
+    const u32x4 x = __builtin_bit_cast(u32x4, tileN_get(tx, lane, m)), y = __builtin_bit_cast(u32x4, tileN_get(ty, lane, m));
+    const uint32_t xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sx += x[i];
-      sxy = __builtin_fmaf(x[i], y[i], sxy);
+    for (int i = 0; i < 4; ++i) {
+      sx = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xx[i]), __builtin_bit_cast(bf16x2_t, ones), sx, false);
+      sxy = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xx[i]), __builtin_bit_cast(bf16x2_t, yy[i]), sxy, false);
     }
   }
 }

@@ -40,9 +40,10 @@ def bn_bwd_consts(lib, arena, stats, bn, m_rows, training, st, hat=True, out=Tru
 # DVA_CHAIN_MERGE=1 -- merged backward (round 5): the score pass also sums what the statistics of the
 # BatchNorm-5 backward are linear in, stage 6 disappears and stage 5 starts from the score gradients (csrc/chain_bwd.hip
 # score_l6_kernel).  Built, parity-green (tests/test_gpu_chain.py::test_merged_backward_matches_three_pass and the whole
-# chain / bilinear / full-size suites under the switch) and measured: the step does not move (11.02 against 11.01 ms:
-# profiles/r05_chain_merge_ab.json) -- the accumulators the merged passes carry cost both their third wavefront per SIMD
-# (score pass 0.78 -> 1.50 ms, stage 5 1.21 -> 1.83 ms, against the 1.14 ms of stage 6).  Off by default.
+# chain / bilinear / pooling / full-size suites under the switch), put on a register diet until both merged passes ran at
+# three wavefronts per SIMD, and measured: the step does not get faster (11.01 against 10.92 - 10.95 ms on one box:
+# profiles/r05_chain_merge_ab.json) -- the per-tile bookkeeping of the merge costs as many vector instructions as the chain
+# evaluation of stage 6 it removes.  Off by default.
 MERGE_STAGE6 = os.environ.get("DVA_CHAIN_MERGE", "0") == "1"
 
 
