@@ -268,28 +268,33 @@ __device__ __forceinline__ void act_a_rows(const ZaRows<NB>& z, const float (*ta
 // of half h, i.e. channel cperm(column)) and reads it back through the transpose read: lane (n, hh) receives the views
 // 8 hh .. 8 hh + 7 and 16 + 8 hh .. of column n -- 16 in-lane additions; the two half-waves hold the two halves of the
 // column sum (added at the flush).  x, y: values as stored (bf16).
+// (round 5: the packed bf16 pairs go straight into v_dot2c_f32_bf16 -- four dot products per eight values and statistic,
+//  fp32 accumulation, no unpacking: a third of the vector instructions of the unpack + add + fma form)
+typedef __bf16 bf16x2e_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2e_t, a), __builtin_bit_cast(bf16x2e_t, b), c, false);
+}
 __device__ __forceinline__ void col_sums(const bf16_t* tx, int lane, float& s, float& ss) {        // sum x | sum x^2
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    float x[8];
-    unpack8(tileN_get(tx, lane, m), x);
+    const u32x4 x = __builtin_bit_cast(u32x4, tileN_get(tx, lane, m));
+    const uint32_t xx[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      s += x[i];
-      ss = __builtin_fmaf(x[i], x[i], ss);
+    for (int i = 0; i < 4; ++i) {
+      s = dot2bf(xx[i], 0x3f803f80u, s);
+      ss = dot2bf(xx[i], xx[i], ss);
     }
   }
 }
 __device__ __forceinline__ void col_sums2(const bf16_t* tx, const bf16_t* ty, int lane, float& sx, float& sxy) {   // sum x | sum x y
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    float x[8], y[8];
-    unpack8(tileN_get(tx, lane, m), x);
-    unpack8(tileN_get(ty, lane, m), y);
+    const u32x4 x = __builtin_bit_cast(u32x4, tileN_get(tx, lane, m)), y = __builtin_bit_cast(u32x4, tileN_get(ty, lane, m));
+    const uint32_t xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sx += x[i];
-      sxy = __builtin_fmaf(x[i], y[i], sxy);
+    for (int i = 0; i < 4; ++i) {
+      sx = dot2bf(xx[i], 0x3f803f80u, sx);
+      sxy = dot2bf(xx[i], yy[i], sxy);
     }
   }
 }
