@@ -379,8 +379,11 @@ def test_rows_grad_plan_equals_atomics(C, G, gating, dtype):
     for x, y in zip(b[3:], c[3:]):      # gate parameters: fp32 sums accumulated atomically (order varies)
         close(x, y, rtol=1e-4, atol=1e-4)
     tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
-    for x, y in zip(a, b):
+    for x, y in zip(a[:3], b[:3]):
         close(x, y, **tol)
+    ptol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else tol
+    for x, y in zip(a[3:], b[3:]):      # gate parameters: atomically accumulated fp32 sums in both runs
+        close(x, y, **ptol)
     assert float(b[1][R - 20:].abs().max()) == 0.0
     # torch reference on the materialised gather
     rr = rows.float().requires_grad_()
