@@ -1,0 +1,391 @@
+// Split row plan (round 5): the row plan of the rows gradient as a two-pass MSD radix partition whose OFFSETS are built
+// before the forward (from the row keys alone: per-row view counts and CSR pointers -- all the forward needs) and whose
+// two scatter passes run in the backward ON THE 16-BYTE VIEW RECORDS themselves.  The rows gradient then streams its
+// records in plan order instead of fetching one random 128-byte line per view for 16 bytes of payload (PMC: 4.3 GB of the
+// kernel's 9.0 GB), and no permutation is ever written or read.
+//
+//   build (keys only):  hist_hi -> scan_tiles -> bucket_starts -> scatter<LOWS> (9-bit low digits, bucket order)
+//                       -> hist_lo -> scan_rows  => counts[R], row_ptr[R + 1], offA[tile][bucket], offB[tile][digit]
+//   sort  (records):    scatter<REC_A> (view order -> bucket order) -> scatter<REC_B> (bucket order -> plan order)
+//
+// Both passes are stable (wave-striped tiles, per-wavefront digit counters advanced in item order, match-any ranking),
+// so the views of a row stay in view order: the sums of the rows gradient are those of the permutation plan, bit for
+// bit.  A tile is 8192 entries of one workgroup (1024 threads x 8): with 512 buckets a tile leaves 16-entry = 256-byte
+// runs per bucket, staged through LDS (128 KB of the CU's 160) so that every run is written by consecutive lanes.
+// Row keys: 512 < n_rows <= 2^18 (high digit = key >> 9 in at most 512 buckets); anything else keeps dva_row_plan.
+#include "dva_common.h"
+
+namespace dva {
+namespace ps {
+
+constexpr int TILE = 8192;
+constexpr int THREADS = 1024;
+constexpr int IPT = TILE / THREADS;
+constexpr int WAVES = THREADS / 64;
+constexpr int BINS = 512;
+constexpr int LO_BITS = 9;
+constexpr int HEAD_INTS = 2048;   // tot[512] | bucket_start[513] | tile_start[513] (padded)
+
+struct Layout {
+  int64_t nt, nb, ntb;
+  size_t off_tot, off_bstart, off_tstart, off_a, off_b, total;
+};
+
+static inline bool eligible(int64_t n_views, int64_t n_rows) {
+  return n_views > 0 && n_views <= 0x7fffffffLL && n_rows > BINS && n_rows <= (int64_t)BINS * BINS;
+}
+
+static inline Layout layout(int64_t n, int64_t n_rows) {
+  Layout L;
+  L.nt = (n + TILE - 1) / TILE;
+  L.nb = (n_rows + BINS - 1) / BINS;
+  L.ntb = L.nt + L.nb;
+  L.off_tot = 0;
+  L.off_bstart = 512 * 4;
+  L.off_tstart = (512 + 520) * 4;
+  L.off_a = HEAD_INTS * 4;
+  L.off_b = L.off_a + (size_t)L.nt * BINS * 4;
+  L.total = L.off_b + (size_t)L.ntb * BINS * 4;
+  return L;
+}
+
+// exclusive scan of one int per thread over the block (NT threads, a multiple of 64); s_w: NT / 64 ints
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(int v, int* s_w, int* total = nullptr) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();                       // s_w may still be read by a previous scan
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) {
+    const int t = s_w[i];
+    before += i < w ? t : 0;
+    all += t;
+  }
+  if (total) *total = all;
+  return before + inc - v;
+}
+
+__device__ __forceinline__ int hi_digit(uint32_t key, int nb) {
+  const int d = (int)(key >> LO_BITS);
+  return d < nb ? d : nb - 1;            // keys >= n_rows are out of contract: they stay inside the tables
+}
+
+// ---- build -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void hist_hi_kernel(const uint32_t* __restrict__ keys, int64_t n, int nb,
+                                                          int32_t* __restrict__ offA) {
+  __shared__ int h[BINS];
+  if (threadIdx.x < BINS) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int64_t e = base + k * THREADS + threadIdx.x;
+    if (e < n) atomicAdd(&h[hi_digit(keys[e], nb)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < BINS) offA[(int64_t)blockIdx.x * BINS + threadIdx.x] = h[threadIdx.x];
+}
+
+// column d of off[nt][BINS]: counts -> exclusive prefix over the tiles (in place); tot[d] = column sum
+__global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t* __restrict__ off, int64_t nt, int32_t* __restrict__ tot) {
+  __shared__ int s_w[4];
+  const int d = blockIdx.x;
+  const int64_t per = (nt + 255) / 256, t0 = threadIdx.x * per;
+  int sum = 0;
+  for (int64_t j = 0; j < per; ++j) {
+    const int64_t t = t0 + j;
+    if (t < nt) sum += off[t * BINS + d];
+  }
+  int all;
+  int run = block_excl_scan<256>(sum, s_w, &all);
+  for (int64_t j = 0; j < per; ++j) {
+    const int64_t t = t0 + j;
+    if (t < nt) {
+      const int v = off[t * BINS + d];
+      off[t * BINS + d] = run;
+      run += v;
+    }
+  }
+  if (threadIdx.x == 0) tot[d] = all;
+}
+
+// bucket_start[0 .. BINS], tile_start[0 .. BINS] (B tiles: every bucket is cut into its own tiles of TILE entries)
+__global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __restrict__ tot, int nb,
+                                                             int32_t* __restrict__ bucket_start,
+                                                             int32_t* __restrict__ tile_start) {
+  __shared__ int s_w[BINS / 64];
+  const int d = threadIdx.x;
+  const int v = d < nb ? tot[d] : 0;
+  int all;
+  const int bs = block_excl_scan<BINS>(v, s_w, &all);
+  bucket_start[d] = bs;
+  if (d == BINS - 1) bucket_start[BINS] = all;
+  int allt;
+  const int ts = block_excl_scan<BINS>((v + TILE - 1) / TILE, s_w, &allt);
+  tile_start[d] = ts;
+  if (d == BINS - 1) tile_start[BINS] = allt;
+}
+
+// geometry of B tile `tb`: its bucket, first entry and entry count (false: no such tile)
+__device__ __forceinline__ bool tile_b(const int32_t* __restrict__ bucket_start, const int32_t* __restrict__ tile_start,
+                                       int nb, int tb, int& b, int64_t& start, int& count) {
+  if (tb >= tile_start[nb]) return false;
+  int lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= tb) lo = mid; else hi = mid;
+  }
+  b = lo;
+  start = (int64_t)bucket_start[b] + (int64_t)(tb - tile_start[b]) * TILE;
+  const int64_t left = (int64_t)bucket_start[b + 1] - start;
+  count = (int)(left < TILE ? left : TILE);
+  return true;
+}
+
+__global__ __launch_bounds__(THREADS) void hist_lo_kernel(const uint16_t* __restrict__ lows, int nb,
+                                                          const int32_t* __restrict__ bucket_start,
+                                                          const int32_t* __restrict__ tile_start,
+                                                          int32_t* __restrict__ offB) {
+  __shared__ int h[BINS];
+  int b, count;
+  int64_t start;
+  if (!tile_b(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
+  if (threadIdx.x < BINS) h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int i = k * THREADS + threadIdx.x;
+    if (i < count) atomicAdd(&h[lows[start + i]], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < BINS) offB[(int64_t)blockIdx.x * BINS + threadIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup per bucket, one thread per low digit = per row: prefix over the bucket's tiles (in place), row counts,
+// CSR pointers over ALL rows (rows nobody maps to get empty segments)
+__global__ __launch_bounds__(BINS) void scan_rows_kernel(int32_t* __restrict__ offB, const int32_t* __restrict__ bucket_start,
+                                                         const int32_t* __restrict__ tile_start, int64_t n_rows,
+                                                         int64_t n_views, int32_t* __restrict__ row_ptr,
+                                                         int32_t* __restrict__ counts) {
+  __shared__ int s_w[BINS / 64];
+  const int b = blockIdx.x, d = threadIdx.x;
+  const int tb0 = tile_start[b], tb1 = tile_start[b + 1];
+  int run = 0;
+  for (int tb = tb0; tb < tb1; ++tb) {
+    const int v = offB[(int64_t)tb * BINS + d];
+    offB[(int64_t)tb * BINS + d] = run;
+    run += v;
+  }
+  const int64_t r = (int64_t)b * BINS + d;
+  if (counts && r < n_rows) counts[r] = run;
+  const int excl = block_excl_scan<BINS>(run, s_w);
+  if (r <= n_rows) row_ptr[r] = bucket_start[b] + excl;
+  if (r + 1 == n_rows && d == BINS - 1) row_ptr[n_rows] = (int32_t)n_views;
+}
+
+// ---- the stable scatter of one tile ------------------------------------------------------------------------------
+enum { MODE_LOWS = 0, MODE_REC_A = 1, MODE_REC_B = 2 };
+template <int MODE> struct Elem { typedef uint4 type; };
+template <> struct Elem<MODE_LOWS> { typedef uint32_t type; };
+__device__ __forceinline__ uint32_t key_of(const uint4& e) { return e.w; }
+__device__ __forceinline__ uint32_t key_of(uint32_t e) { return e; }
+
+// lanes of the wavefront whose (valid) 9-bit digit equals this lane's
+__device__ __forceinline__ uint64_t match_digit(int d, bool valid) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < LO_BITS; ++bit) {
+    const bool one = (d >> bit) & 1;
+    const uint64_t m = __ballot(one);
+    peers &= one ? m : ~m;
+  }
+  return peers;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __restrict__ keys, const uint4* __restrict__ src,
+                                                          void* __restrict__ dst, int64_t n, int nb, int64_t n_rows,
+                                                          const int32_t* __restrict__ bucket_start,
+                                                          const int32_t* __restrict__ tile_start,
+                                                          const int32_t* __restrict__ off,
+                                                          const int32_t* __restrict__ row_ptr) {
+  typedef typename Elem<MODE>::type E;
+  __shared__ E s_stage[TILE];
+  __shared__ uint16_t s_cnt[WAVES][BINS];
+  __shared__ int s_lstart[BINS];
+  __shared__ int s_base[BINS];
+  __shared__ int s_w[WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int b = 0, count;
+  int64_t start;
+  if (MODE == MODE_REC_B) {
+    if (!tile_b(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
+  } else {
+    start = (int64_t)blockIdx.x * TILE;
+    const int64_t left = n - start;
+    count = (int)(left < TILE ? left : TILE);
+  }
+  // ---- loads first (8 independent requests per lane), tables while they fly
+  uint32_t kk[IPT], p0[IPT], p1[IPT], p2[IPT];     // key | the three payload words of a record (scalars: no scratch)
+  bool ok[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int idx = w * (64 * IPT) + i * 64 + lane;
+    ok[i] = idx < count;
+    const int64_t g = start + (ok[i] ? idx : 0);
+    if constexpr (MODE == MODE_LOWS) {
+      kk[i] = keys[g];
+      p0[i] = p1[i] = p2[i] = 0u;
+    } else {
+      const uint4 r = src[g];
+      p0[i] = r.x, p1[i] = r.y, p2[i] = r.z;
+      if constexpr (MODE == MODE_REC_A) kk[i] = keys[g]; else kk[i] = r.w;
+    }
+  }
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);
+#pragma unroll
+    for (int k = 0; k < WAVES * BINS / 2 / THREADS; ++k) z[k * THREADS + tid] = 0u;
+  }
+  if (tid < BINS) {
+    int base;
+    if (MODE == MODE_REC_B) {
+      const int64_t r = (int64_t)b * BINS + tid;
+      base = (r <= n_rows ? row_ptr[r] : 0) + off[(int64_t)blockIdx.x * BINS + tid];
+    } else {
+      base = tid < nb ? bucket_start[tid] + off[(int64_t)blockIdx.x * BINS + tid] : 0;
+    }
+    s_base[tid] = base;
+  }
+  __syncthreads();
+  // ---- stable rank inside the wavefront's 512 entries: counter of the digit before this item + lanes below
+  int dg[IPT], rank[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const uint32_t key = kk[i];
+    dg[i] = MODE == MODE_REC_B ? (int)(key & (BINS - 1)) : hi_digit(key, nb);
+    const uint64_t peers = match_digit(dg[i], ok[i]);
+    const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+    const int prev = s_cnt[w][dg[i]];
+    if (ok[i] && below == 0) s_cnt[w][dg[i]] = (uint16_t)(prev + __popcll(peers));
+    rank[i] = prev + below;
+  }
+  __syncthreads();
+  // ---- counters -> prefix over the wavefronts; digit starts inside the tile
+  int run = 0;
+  if (tid < BINS) {
+#pragma unroll
+    for (int k = 0; k < WAVES; ++k) {
+      const int t = s_cnt[k][tid];
+      s_cnt[k][tid] = (uint16_t)run;
+      run += t;
+    }
+  }
+  const int ls = block_excl_scan<THREADS>(tid < BINS ? run : 0, s_w);
+  if (tid < BINS) s_lstart[tid] = ls;
+  __syncthreads();
+  // ---- stage in tile order of the digits
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    if (ok[i]) {
+      const int pos = s_lstart[dg[i]] + s_cnt[w][dg[i]] + rank[i];
+      if constexpr (MODE == MODE_LOWS) s_stage[pos] = kk[i]; else s_stage[pos] = make_uint4(p0[i], p1[i], p2[i], kk[i]);
+    }
+  }
+  __syncthreads();
+  // ---- runs of one digit leave through consecutive lanes
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int j = k * THREADS + tid;
+    if (j < count) {
+      const E v = s_stage[j];
+      const uint32_t key = key_of(v);
+      const int d = MODE == MODE_REC_B ? (int)(key & (BINS - 1)) : hi_digit(key, nb);
+      int64_t g = (int64_t)s_base[d] + (j - s_lstart[d]);
+      g = g < n ? g : n - 1;
+      if constexpr (MODE == MODE_LOWS)
+        reinterpret_cast<uint16_t*>(dst)[g] = (uint16_t)(key & (BINS - 1));
+      else
+        reinterpret_cast<uint4*>(dst)[g] = v;
+    }
+  }
+}
+
+}  // namespace ps
+}  // namespace dva
+
+using namespace dva;
+
+extern "C" {
+
+int64_t dva_plan_split_table_bytes(int64_t n_views, int64_t n_rows) {
+  if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
+  if (!ps::eligible(n_views, n_rows)) return DVA_ERR_UNSUPPORTED;
+  return (int64_t)ps::layout(n_views, n_rows).total;
+}
+
+int dva_plan_split_build(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_t* row_ptr, int32_t* counts,
+                         void* tables, int64_t tables_bytes, void* scratch, int64_t scratch_bytes, void* stream) {
+  if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
+  if (!ps::eligible(n_views, n_rows)) return DVA_ERR_UNSUPPORTED;
+  if (!row_idx || !row_ptr || !tables || !scratch) return DVA_ERR_INVALID;
+  const ps::Layout L = ps::layout(n_views, n_rows);
+  if ((int64_t)L.total > tables_bytes || scratch_bytes < n_views * 2) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  char* tb = (char*)tables;
+  int32_t* tot = (int32_t*)(tb + L.off_tot);
+  int32_t* bstart = (int32_t*)(tb + L.off_bstart);
+  int32_t* tstart = (int32_t*)(tb + L.off_tstart);
+  int32_t* offA = (int32_t*)(tb + L.off_a);
+  int32_t* offB = (int32_t*)(tb + L.off_b);
+  const uint32_t* keys = (const uint32_t*)row_idx;
+  const int nb = (int)L.nb;
+  hipLaunchKernelGGL(ps::hist_hi_kernel, dim3((unsigned)L.nt), dim3(ps::THREADS), 0, s, keys, n_views, nb, offA);
+  hipLaunchKernelGGL(ps::scan_tiles_kernel, dim3(nb), dim3(256), 0, s, offA, L.nt, tot);
+  hipLaunchKernelGGL(ps::bucket_starts_kernel, dim3(1), dim3(ps::BINS), 0, s, tot, nb, bstart, tstart);
+  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_LOWS>), dim3((unsigned)L.nt), dim3(ps::THREADS), 0, s, keys,
+                     (const uint4*)nullptr, scratch, n_views, nb, n_rows, bstart, tstart, offA, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(ps::hist_lo_kernel, dim3((unsigned)L.ntb), dim3(ps::THREADS), 0, s, (const uint16_t*)scratch, nb,
+                     bstart, tstart, offB);
+  hipLaunchKernelGGL(ps::scan_rows_kernel, dim3(nb), dim3(ps::BINS), 0, s, offB, bstart, tstart, n_rows, n_views,
+                     row_ptr, counts);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t n_views, int64_t n_rows,
+                                const int32_t* row_ptr, const void* tables, int64_t tables_bytes, void* buf,
+                                void* rec_sorted, void* stream) {
+  if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
+  if (!ps::eligible(n_views, n_rows)) return DVA_ERR_UNSUPPORTED;
+  if (!row_idx || !rec || !row_ptr || !tables || !buf || !rec_sorted || buf == rec || buf == rec_sorted)
+    return DVA_ERR_INVALID;
+  if (((uintptr_t)rec % 16) || ((uintptr_t)buf % 16) || ((uintptr_t)rec_sorted % 16)) return DVA_ERR_UNSUPPORTED;
+  const ps::Layout L = ps::layout(n_views, n_rows);
+  if ((int64_t)L.total > tables_bytes) return DVA_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const char* tb = (const char*)tables;
+  const int32_t* bstart = (const int32_t*)(tb + L.off_bstart);
+  const int32_t* tstart = (const int32_t*)(tb + L.off_tstart);
+  const int32_t* offA = (const int32_t*)(tb + L.off_a);
+  const int32_t* offB = (const int32_t*)(tb + L.off_b);
+  const int nb = (int)L.nb;
+  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_REC_A>), dim3((unsigned)L.nt), dim3(ps::THREADS), 0, s,
+                     (const uint32_t*)row_idx, (const uint4*)rec, buf, n_views, nb, n_rows, bstart, tstart, offA,
+                     (const int32_t*)nullptr);
+  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_REC_B>), dim3((unsigned)L.ntb), dim3(ps::THREADS), 0, s,
+                     (const uint32_t*)nullptr, (const uint4*)buf, rec_sorted, n_views, nb, n_rows, bstart, tstart, offB,
+                     row_ptr);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+}  // extern "C"

@@ -214,7 +214,7 @@ def backward(ctx, gout):
     plan = None
     if ctx.needs_input_grad[0]:
         plan = ctx.plan if ctx.plan is not None else ops.row_plan(row_idx, R, with_counts=False)[0]
-    planrec = PLAN_ORDER_RECORDS and plan is not None
+    planrec = PLAN_ORDER_RECORDS and plan is not None and not isinstance(plan, ops.SplitPlan)
     if planrec:
         # A/B (round 4): records written in plan order through the inverse of the plan permutation
         inv = torch.empty(V, dtype=torch.int32, device=dev)
@@ -235,10 +235,13 @@ def backward(ctx, gout):
     grows = None
     side = None
     if ctx.needs_input_grad[0]:
-        perm, row_ptr = plan
+        split = isinstance(plan, ops.SplitPlan)
+        perm, row_ptr = (None, plan.row_ptr) if split else plan
 
         def rows_grad(stream):
             # the row is rounded to the map's dtype where it is summed (round 5): no fp32 [R, C] tensor + conversion pass
+            if split:     # the records themselves go through the plan's two scatter passes, then stream in plan order
+                return ops.rows_grad_rec16(gout, plan, rec, R, C, G, rows.dtype, stream)
             g = torch.empty((R, C), dtype=rows.dtype, device=dev)
             with ops._timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 2 + 4)):
                 check(lib.dva_view_gather_rows_grad_rec16_to(ptr(gout), None if planrec else ptr(perm), ptr(row_ptr),
@@ -252,7 +255,7 @@ def backward(ctx, gout):
             side.wait_stream(main)                       # records of the attention backward
             with torch.cuda.stream(side):
                 grows = rows_grad(stream_of(x_map))
-            for t_ in (gout, perm, row_ptr, rec):
+            for t_ in (gout, row_ptr, rec) + (() if perm is None else (perm,)):
                 t_.record_stream(side)
         else:
             grows = rows_grad(st)

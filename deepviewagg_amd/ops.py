@@ -593,12 +593,16 @@ def gather_bilinear(x, packed_idx, coords):
 # lazy view gather + fused gather-attention  (DESIGN.md "E_mod hoisting")
 # ---------------------------------------------------------------------------------------------
 
-def row_plan(row_idx, n_rows, with_counts=True):
-    """Views grouped by the feature-map row they read: ``(perm, row_ptr)`` int32 (+ ``counts`` int32
-    [n_rows]).  Stable, so the order of the views inside a row (and with it every sum over them) is
-    deterministic."""
+# The split plan (round 5, csrc/plan_split.hip): from 4 M views on (and 512 < rows <= 2^18) ``row_plan`` builds only the
+# offset tables of a two-pass radix partition -- row_ptr and counts come out of them -- and the backward runs the two
+# scatter passes on the 16-byte view records themselves, so the rows gradient streams its records in plan order.
+# DVA_SPLIT_PLAN=0: the permutation plan everywhere (the A/B).
+SPLIT_PLAN = os.environ.get("DVA_SPLIT_PLAN", "1") == "1"
+SPLIT_PLAN_MIN_VIEWS = 1 << 22
+
+
+def _legacy_row_plan(row_idx, n_rows, with_counts):
     lib = _lib.load()
-    require_device(row_idx)
     V, dev = row_idx.shape[0], row_idx.device
     perm = torch.empty(V, dtype=torch.int32, device=dev)
     row_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
@@ -611,6 +615,84 @@ def row_plan(row_idx, n_rows, with_counts=True):
         check(lib.dva_row_plan(ptr(row_idx), V, n_rows, ptr(perm), ptr(row_ptr), ptr(counts), ptr(ws),
                                int(nbytes), stream_of(row_idx)), "dva_row_plan")
     return (perm, row_ptr), counts
+
+
+class SplitPlan:
+    """A row plan without its permutation: ``row_ptr`` and the offset tables of the two scatter passes
+    (``dva_plan_split_build``).  ``sort_records`` brings the 16-byte view records of a backward into plan order;
+    callers that want ``(perm, row_ptr)`` (unpacking, ``plan[0]``) get the permutation from ``dva_row_plan`` on first
+    use -- correct, but it pays the sort the split plan exists to avoid."""
+
+    def __init__(self, row_idx, n_rows, row_ptr, tables):
+        self.row_idx, self.n_rows, self.row_ptr, self.tables = row_idx, int(n_rows), row_ptr, tables
+        self._perm = None
+
+    @property
+    def perm(self):
+        if self._perm is None:
+            self._perm = _legacy_row_plan(self.row_idx, self.n_rows, False)[0][0]
+        return self._perm
+
+    def __iter__(self):
+        yield self.perm
+        yield self.row_ptr
+
+    def __getitem__(self, i):
+        return (self.perm, self.row_ptr)[i] if i in (0, -2) else (None, self.row_ptr)[i]
+
+    def __len__(self):
+        return 2
+
+    def sort_records(self, rec):
+        """rec int32 [V, 4] in view order -> the same storage in plan order (word 3 of a record = its row key)."""
+        lib = _lib.load()
+        V = self.row_idx.shape[0]
+        assert rec.shape == (V, 4) and rec.dtype == torch.int32 and rec.is_contiguous()
+        buf = torch.empty_like(rec)
+        with _timed("plan_sort_records", V * 68):
+            check(lib.dva_plan_split_sort_records(ptr(self.row_idx), ptr(rec), V, self.n_rows, ptr(self.row_ptr),
+                                                  ptr(self.tables), self.tables.numel(), ptr(buf), ptr(rec),
+                                                  stream_of(rec)), "dva_plan_split_sort_records")
+        return rec
+
+
+def row_plan(row_idx, n_rows, with_counts=True):
+    """Views grouped by the feature-map row they read: ``(perm, row_ptr)`` int32 (+ ``counts`` int32
+    [n_rows]).  Stable, so the order of the views inside a row (and with it every sum over them) is
+    deterministic.  Large plans come back as a ``SplitPlan`` (same ``row_ptr`` / ``counts``, no permutation)."""
+    lib = _lib.load()
+    require_device(row_idx)
+    V, dev = row_idx.shape[0], row_idx.device
+    if SPLIT_PLAN and V >= SPLIT_PLAN_MIN_VIEWS and row_idx.is_contiguous():
+        nbytes = int(lib.dva_plan_split_table_bytes(V, n_rows))
+        if nbytes > 0:
+            row_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+            counts = torch.empty(n_rows, dtype=torch.int32, device=dev) if with_counts else None
+            tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            lows = torch.empty(V, dtype=torch.int16, device=dev)
+            with _timed("row_plan", V * 10):      # keys read twice, 2-byte digits written + read
+                check(lib.dva_plan_split_build(ptr(row_idx), V, n_rows, ptr(row_ptr), ptr(counts), ptr(tables), nbytes,
+                                               ptr(lows), V * 2, stream_of(row_idx)), "dva_plan_split_build")
+            return SplitPlan(row_idx, n_rows, row_ptr, tables), counts
+    return _legacy_row_plan(row_idx, n_rows, with_counts)
+
+
+def rows_grad_rec16(gout, plan, rec, R, C, G, out_dtype, stream):
+    """Rows gradient from the 16-byte view records of ``dva_chain_attn_bwd`` (``rec`` int32 [V, 4], view order; consumed):
+    over the permutation plan, or -- ``SplitPlan`` -- after the records themselves went through the plan's two passes."""
+    lib = _lib.load()
+    V = rec.shape[0]
+    g = torch.empty((R, C), dtype=out_dtype, device=gout.device)
+    if isinstance(plan, SplitPlan):
+        rec = plan.sort_records(rec)
+        perm, row_ptr = None, plan.row_ptr
+    else:
+        perm, row_ptr = plan
+    with _timed("view_gather_rows_grad", V * ((4 if perm is not None else 0) + 16 + C * 2) + R * (C * 2 + 4)):
+        check(lib.dva_view_gather_rows_grad_rec16_to(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(g), dtype_code(g),
+                                                     R, V, C, G, _lib.DVA_BF16, stream),
+              "dva_view_gather_rows_grad_rec16_to")
+    return g
 
 
 def csr_expand(csr_idx, n_views):
@@ -1024,12 +1106,8 @@ class _ViewGatherAttention(torch.autograd.Function):
                     ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(gout), ptr(out), ptr(dc),
                     ptr(rec), ptr(gwb), N, V, R, C, G, scaling, ctx.eps, stream_of(rows)), "dva_chain_attn_bwd")
             plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
-            perm, row_ptr = plan
-            grows = torch.empty((R, C), dtype=rows.dtype, device=rows.device)      # bf16: rounded where it is summed
-            with _timed("view_gather_rows_grad", V * (4 + 16 + C * 2) + R * (C * 2 + 4)):
-                check(lib.dva_view_gather_rows_grad_rec16_to(
-                    ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(grows), dtype_code(grows), R, V, C, G,
-                    dtype_code(rows), stream_of(rows)), "dva_view_gather_rows_grad_rec16_to")
+            # bf16: rounded where it is summed
+            grows = rows_grad_rec16(gout, plan, rec, R, C, G, rows.dtype, stream_of(rows))
             g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
             g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
             gcompat = dc if G == 4 else dc[:, :G].contiguous()

@@ -205,6 +205,22 @@ int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_
                  int32_t* row_ptr, int32_t* counts, void* workspace, int64_t workspace_bytes,
                  void* stream);
 
+/* The row plan SPLIT in two (round 5; 512 < n_rows <= 2^18, otherwise DVA_ERR_UNSUPPORTED and the caller keeps dva_row_plan):
+ * a two-pass stable MSD radix partition (digits key >> 9 | key & 511, tiles of 8192 views) whose offset tables are built
+ * from the row keys alone -- dva_plan_split_build: row_ptr int32 [n_rows + 1], counts int32 [n_rows] (nullable), identical to
+ * dva_row_plan's, and `tables` (dva_plan_split_table_bytes; kept by the caller until the backward); scratch: 2 n_views bytes,
+ * free afterwards -- and whose two scatter passes move the 16-BYTE VIEW RECORDS of the attention backward themselves --
+ * dva_plan_split_sort_records: rec [n_views][16] in view order -> rec_sorted in plan order (record i = plan entry i, views of
+ * a row in view order, word 3 of a record = its row key), through buf [n_views][16]; rec_sorted may be rec.  The rows gradient
+ * (dva_view_gather_rows_grad_rec16* with perm = NULL) then streams its records: no permutation exists, no random 16-byte
+ * fetch per view.  Replaces the index_add of core/multimodal/image.py:1262-1287's backward like dva_row_plan. */
+int64_t dva_plan_split_table_bytes(int64_t n_views, int64_t n_rows);
+int dva_plan_split_build(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_t* row_ptr, int32_t* counts,
+                         void* tables, int64_t tables_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t n_views, int64_t n_rows,
+                                const int32_t* row_ptr, const void* tables, int64_t tables_bytes, void* buf,
+                                void* rec_sorted, void* stream);
+
 /* grad_rows[r, c] = sum over the views v of row r of grad_out[p(v), c] * gate[p(v), g(c)] *
  * att[v, g(c)]  (written, not accumulated; fp32 [n_rows, C]).  view_point int32 [n_views] = point of
  * every view (dva_csr_expand); gate nullable (no gating); grad_out [n_points, C] in dtype.

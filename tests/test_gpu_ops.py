@@ -340,6 +340,93 @@ def test_row_plan_is_a_stable_sort(V, R):
     assert torch.equal(row_ptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), ref_counts.cumsum(0)]))
 
 
+# the split plan (csrc/plan_split.hip): offsets from the keys, the two scatter passes on the 16-byte records themselves
+@pytest.mark.parametrize("V,R,how", [(1, 513, "uniform"), (8192, 1000, "uniform"), (8193, 4097, "uniform"),
+                                     (70001, 600, "uniform"), (250000, 1 << 18, "uniform"),
+                                     (250000, (1 << 18) - 511, "uniform"), (200000, 3000, "one_row"),
+                                     (300000, 70000, "few_rows"), (300000, 131072, "one_bucket"),
+                                     (5000000, 1 << 18, "uniform"), (4500000, (1 << 17) + 5, "skewed")])
+def test_split_plan_equals_row_plan(V, R, how):
+    """row_ptr / counts of the split plan = those of the permutation plan (and of torch); records brought into plan order
+    by the two scatter passes = rec[perm] bit for bit, word 3 = the row key; both passes stable."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(V + R)
+    if how == "uniform":
+        row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    elif how == "one_row":
+        row_idx = torch.full((V,), R - 2, dtype=torch.int32)
+    elif how == "few_rows":
+        row_idx = torch.tensor([5, 512, 513, R - 1, 40000], dtype=torch.int32)[torch.randint(0, 5, (V,), generator=gen)]
+    elif how == "one_bucket":
+        row_idx = (torch.randint(0, 512, (V,), generator=gen) + 512 * 100).to(torch.int32)
+    else:   # half of the views in 64 rows, the rest uniform
+        hot = torch.randint(0, R, (64,), generator=gen)
+        row_idx = torch.where(torch.rand(V, generator=gen) < 0.5, hot[torch.randint(0, 64, (V,), generator=gen)],
+                              torch.randint(0, R, (V,), generator=gen)).to(torch.int32)
+    if V > 10 and how == "uniform":
+        row_idx[row_idx == 3] = 4                     # an empty row in the middle
+    rd = row_idx.to(DEV)
+    old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS
+    try:
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = True, 0
+        plan, counts = ops.row_plan(rd, R)
+        assert isinstance(plan, ops.SplitPlan)
+        ops.SPLIT_PLAN = False
+        (perm, row_ptr), counts_ref = ops.row_plan(rd, R)
+    finally:
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = old
+    ref_counts = torch.bincount(row_idx.long(), minlength=R)
+    assert torch.equal(counts.cpu().long(), ref_counts) and torch.equal(counts, counts_ref)
+    assert torch.equal(plan.row_ptr, row_ptr)
+    assert torch.equal(perm.cpu().long(), torch.sort(row_idx.long(), stable=True).indices)
+    rec = torch.randint(-2 ** 31, 2 ** 31 - 1, (V, 4), generator=gen, dtype=torch.int64).to(torch.int32).to(DEV)
+    want = rec[perm.long()].clone()
+    want[:, 3] = rd[perm.long()]
+    got = plan.sort_records(rec.clone())
+    assert torch.equal(got, want)
+    assert torch.equal(plan.perm, perm) and torch.equal(plan[1], row_ptr)      # the lazy permutation of other callers
+
+
+@pytest.mark.parametrize("C,G,gating", [(64, 4, True), (32, 2, False), (128, 1, True)])
+def test_rows_grad_split_plan_equals_permutation_plan(C, G, gating):
+    """view_gather_attention (bf16, the lean backward) over the split plan = over the permutation plan, bit for bit
+    (the same records summed in the same order), with and without a plan handed in."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C + G)
+    N, R = 6000, 700
+    sizes = torch.randint(0, 9, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    row_idx = torch.randint(0, R - 20, (V,), generator=gen, dtype=torch.int32).to(DEV)
+    rows = torch.randn(R, C, generator=gen).to(torch.bfloat16)
+    compat = torch.randn(V, G, generator=gen)
+    gw = torch.randn(G, generator=gen) if gating else None
+    gb = torch.randn(G, generator=gen) if gating else None
+    w = torch.randn(N, C, generator=gen).to(DEV)
+
+    def run(split, with_plan):
+        old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = split, 0
+        try:
+            plan = ops.row_plan(row_idx, R, with_counts=False)[0] if with_plan else None
+            assert plan is None or isinstance(plan, ops.SplitPlan) == split
+            rd = rows.to(DEV).requires_grad_()
+            cd = compat.to(DEV).requires_grad_()
+            gwd = gw.to(DEV).requires_grad_() if gating else None
+            gbd = gb.to(DEV).requires_grad_() if gating else None
+            out, _, _ = ops.view_gather_attention(rd, row_idx, cd, csr, gwd, gbd, plan=plan)
+            return [out] + list(torch.autograd.grad((out.float() * w).sum(), [rd, cd]))
+        finally:
+            ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = old
+
+    a = run(False, True)
+    for split, with_plan in ((True, True), (True, False)):
+        b = run(split, with_plan)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert float(a[1][R - 20:].abs().max()) == 0.0 and float(a[1].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,G,gating", [(64, 4, True), (32, 1, False), (24, 3, True), (128, 8, True)])
 def test_rows_grad_plan_equals_atomics(C, G, gating, dtype):
