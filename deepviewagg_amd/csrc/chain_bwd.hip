@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && LPR <= 8) ? 4 : 3) void att
       st128(RC, wr ? vg * 32u : OOB, r0);
       st128(RC, wr ? vg * 32u + 16u : OOB, r1);
     } else {   // 16-byte record: the rows gradient is rounded to bf16 anyway, its weights travel as bf16
-      const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), 0u};
+      // word 3 = the view's row key: the split plan (plan_split.hip) sorts the records themselves by it
+      const u32x4 r = {(uint32_t)p.vpj, pack_bf16x2(ga4[0], ga4[1]), pack_bf16x2(ga4[2], ga4[3]), (uint32_t)p.rij};
       uint32_t slot = vg;
       if (rec_pos) slot = wr ? (uint32_t)rec_pos[vg] : 0u;       // (uniform branch: a kernel argument)
       st128(RC, wr ? slot * 16u : OOB, r);

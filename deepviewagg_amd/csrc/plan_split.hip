@@ -18,13 +18,17 @@
 namespace dva {
 namespace ps {
 
-constexpr int TILE = 8192;
-constexpr int THREADS = 1024;
-constexpr int IPT = TILE / THREADS;
-constexpr int WAVES = THREADS / 64;
+constexpr int IPT = 8;             // entries per thread: a tile of TILE entries is one workgroup of TILE / 8 threads
 constexpr int BINS = 512;
 constexpr int LO_BITS = 9;
 constexpr int HEAD_INTS = 2048;   // tot[512] | bucket_start[513] | tile_start[513] (padded)
+
+// DVA_PLAN_TILE = 8192 (default: 1024 threads, 148 KB of LDS, one workgroup per CU, 256-byte runs) or 4096 (512 threads,
+// 76 KB, two workgroups per CU, 128-byte runs); read once, build and sort of a plan must agree
+static inline int tile_size() {
+  static const int t = tune_int("DVA_PLAN_TILE", 8192) == 4096 ? 4096 : 8192;
+  return t;
+}
 
 struct Layout {
   int64_t nt, nb, ntb;
@@ -37,6 +41,7 @@ static inline bool eligible(int64_t n_views, int64_t n_rows) {
 
 static inline Layout layout(int64_t n, int64_t n_rows) {
   Layout L;
+  const int TILE = tile_size();
   L.nt = (n + TILE - 1) / TILE;
   L.nb = (n_rows + BINS - 1) / BINS;
   L.ntb = L.nt + L.nb;
@@ -79,10 +84,13 @@ __device__ __forceinline__ int hi_digit(uint32_t key, int nb) {
 }
 
 // ---- build -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS) void hist_hi_kernel(const uint32_t* __restrict__ keys, int64_t n, int nb,
-                                                          int32_t* __restrict__ offA) {
+// offA is bucket-major, offA[d][tile]: the scan over the tiles of a bucket reads one contiguous row
+template <int TILE>
+__global__ __launch_bounds__(TILE / IPT) void hist_hi_kernel(const uint32_t* __restrict__ keys, int64_t n, int nb,
+                                                             int64_t nt, int32_t* __restrict__ offA) {
+  constexpr int THREADS = TILE / IPT;
   __shared__ int h[BINS];
-  if (threadIdx.x < BINS) h[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < BINS; i += THREADS) h[i] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * TILE;
 #pragma unroll
@@ -91,34 +99,27 @@ __global__ __launch_bounds__(THREADS) void hist_hi_kernel(const uint32_t* __rest
     if (e < n) atomicAdd(&h[hi_digit(keys[e], nb)], 1);
   }
   __syncthreads();
-  if (threadIdx.x < BINS) offA[(int64_t)blockIdx.x * BINS + threadIdx.x] = h[threadIdx.x];
+  for (int i = threadIdx.x; i < nb; i += THREADS) offA[(int64_t)i * nt + blockIdx.x] = h[i];
 }
 
-// column d of off[nt][BINS]: counts -> exclusive prefix over the tiles (in place); tot[d] = column sum
+// row d of offA[nb][nt]: counts -> exclusive prefix over the tiles (in place, chunks of 256 tiles); tot[d] = row sum
 __global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t* __restrict__ off, int64_t nt, int32_t* __restrict__ tot) {
   __shared__ int s_w[4];
-  const int d = blockIdx.x;
-  const int64_t per = (nt + 255) / 256, t0 = threadIdx.x * per;
-  int sum = 0;
-  for (int64_t j = 0; j < per; ++j) {
-    const int64_t t = t0 + j;
-    if (t < nt) sum += off[t * BINS + d];
+  int32_t* row = off + (int64_t)blockIdx.x * nt;
+  int carry = 0;
+  for (int64_t t0 = 0; t0 < nt; t0 += 256) {
+    const int64_t t = t0 + threadIdx.x;
+    const int v = t < nt ? row[t] : 0;
+    int all;
+    const int ex = block_excl_scan<256>(v, s_w, &all);
+    if (t < nt) row[t] = carry + ex;
+    carry += all;
   }
-  int all;
-  int run = block_excl_scan<256>(sum, s_w, &all);
-  for (int64_t j = 0; j < per; ++j) {
-    const int64_t t = t0 + j;
-    if (t < nt) {
-      const int v = off[t * BINS + d];
-      off[t * BINS + d] = run;
-      run += v;
-    }
-  }
-  if (threadIdx.x == 0) tot[d] = all;
+  if (threadIdx.x == 0) tot[blockIdx.x] = carry;
 }
 
 // bucket_start[0 .. BINS], tile_start[0 .. BINS] (B tiles: every bucket is cut into its own tiles of TILE entries)
-__global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __restrict__ tot, int nb,
+__global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __restrict__ tot, int nb, int TILE,
                                                              int32_t* __restrict__ bucket_start,
                                                              int32_t* __restrict__ tile_start) {
   __shared__ int s_w[BINS / 64];
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __re
 }
 
 // geometry of B tile `tb`: its bucket, first entry and entry count (false: no such tile)
+template <int TILE>
 __device__ __forceinline__ bool tile_b(const int32_t* __restrict__ bucket_start, const int32_t* __restrict__ tile_start,
                                        int nb, int tb, int& b, int64_t& start, int& count) {
   if (tb >= tile_start[nb]) return false;
@@ -150,15 +152,17 @@ __device__ __forceinline__ bool tile_b(const int32_t* __restrict__ bucket_start,
   return true;
 }
 
-__global__ __launch_bounds__(THREADS) void hist_lo_kernel(const uint16_t* __restrict__ lows, int nb,
-                                                          const int32_t* __restrict__ bucket_start,
-                                                          const int32_t* __restrict__ tile_start,
-                                                          int32_t* __restrict__ offB) {
+template <int TILE>
+__global__ __launch_bounds__(TILE / IPT) void hist_lo_kernel(const uint16_t* __restrict__ lows, int nb,
+                                                             const int32_t* __restrict__ bucket_start,
+                                                             const int32_t* __restrict__ tile_start,
+                                                             int32_t* __restrict__ offB) {
+  constexpr int THREADS = TILE / IPT;
   __shared__ int h[BINS];
   int b, count;
   int64_t start;
-  if (!tile_b(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
-  if (threadIdx.x < BINS) h[threadIdx.x] = 0;
+  if (!tile_b<TILE>(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
+  for (int i = threadIdx.x; i < BINS; i += THREADS) h[i] = 0;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(THREADS) void hist_lo_kernel(const uint16_t* __rest
     if (i < count) atomicAdd(&h[lows[start + i]], 1);
   }
   __syncthreads();
-  if (threadIdx.x < BINS) offB[(int64_t)blockIdx.x * BINS + threadIdx.x] = h[threadIdx.x];
+  for (int i = threadIdx.x; i < BINS; i += THREADS) offB[(int64_t)blockIdx.x * BINS + i] = h[i];
 }
 
 // one workgroup per bucket, one thread per low digit = per row: prefix over the bucket's tiles (in place), row counts,
@@ -210,13 +214,15 @@ __device__ __forceinline__ uint64_t match_digit(int d, bool valid) {
   return peers;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __restrict__ keys, const uint4* __restrict__ src,
-                                                          void* __restrict__ dst, int64_t n, int nb, int64_t n_rows,
-                                                          const int32_t* __restrict__ bucket_start,
-                                                          const int32_t* __restrict__ tile_start,
-                                                          const int32_t* __restrict__ off,
-                                                          const int32_t* __restrict__ row_ptr) {
+// keys NULL (REC_A): word 3 of the records already is the row key (dva_chain_attn_bwd writes it)
+template <int MODE, int TILE>
+__global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __restrict__ keys, const uint4* __restrict__ src,
+                                                             void* __restrict__ dst, int64_t n, int nb, int64_t n_rows,
+                                                             int64_t nt, const int32_t* __restrict__ bucket_start,
+                                                             const int32_t* __restrict__ tile_start,
+                                                             const int32_t* __restrict__ off,
+                                                             const int32_t* __restrict__ row_ptr) {
+  constexpr int THREADS = TILE / IPT, WAVES = THREADS / 64;
   typedef typename Elem<MODE>::type E;
   __shared__ E s_stage[TILE];
   __shared__ uint16_t s_cnt[WAVES][BINS];
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __rest
   int b = 0, count;
   int64_t start;
   if (MODE == MODE_REC_B) {
-    if (!tile_b(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
+    if (!tile_b<TILE>(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
   } else {
     start = (int64_t)blockIdx.x * TILE;
     const int64_t left = n - start;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __rest
     } else {
       const uint4 r = src[g];
       p0[i] = r.x, p1[i] = r.y, p2[i] = r.z;
-      if constexpr (MODE == MODE_REC_A) kk[i] = keys[g]; else kk[i] = r.w;
+      kk[i] = (MODE == MODE_REC_A && keys) ? keys[g] : r.w;      // (uniform: a kernel argument)
     }
   }
   {
@@ -255,15 +261,15 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __rest
 #pragma unroll
     for (int k = 0; k < WAVES * BINS / 2 / THREADS; ++k) z[k * THREADS + tid] = 0u;
   }
-  if (tid < BINS) {
+  for (int d = tid; d < BINS; d += THREADS) {
     int base;
     if (MODE == MODE_REC_B) {
-      const int64_t r = (int64_t)b * BINS + tid;
-      base = (r <= n_rows ? row_ptr[r] : 0) + off[(int64_t)blockIdx.x * BINS + tid];
+      const int64_t r = (int64_t)b * BINS + d;
+      base = (r <= n_rows ? row_ptr[r] : 0) + off[(int64_t)blockIdx.x * BINS + d];
     } else {
-      base = tid < nb ? bucket_start[tid] + off[(int64_t)blockIdx.x * BINS + tid] : 0;
+      base = d < nb ? bucket_start[d] + off[(int64_t)d * nt + blockIdx.x] : 0;
     }
-    s_base[tid] = base;
+    s_base[d] = base;
   }
   __syncthreads();
   // ---- stable rank inside the wavefront's 512 entries: counter of the digit before this item + lanes below
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __rest
   }
   __syncthreads();
   // ---- counters -> prefix over the wavefronts; digit starts inside the tile
+  static_assert(THREADS >= BINS, "one thread per digit in the scan over the wavefronts");
   int run = 0;
   if (tid < BINS) {
 #pragma unroll
@@ -322,6 +329,47 @@ __global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t* __rest
 }  // namespace ps
 }  // namespace dva
 
+namespace dva {
+namespace ps {
+struct Tables {
+  int32_t *tot, *bstart, *tstart, *offA, *offB;
+};
+static inline Tables tables_of(void* tables, const Layout& L) {
+  char* tb = (char*)tables;
+  return {(int32_t*)(tb + L.off_tot), (int32_t*)(tb + L.off_bstart), (int32_t*)(tb + L.off_tstart),
+          (int32_t*)(tb + L.off_a), (int32_t*)(tb + L.off_b)};
+}
+
+template <int TILE>
+static void build(const uint32_t* keys, int64_t n, int64_t n_rows, int32_t* row_ptr, int32_t* counts, const Layout& L,
+                  const Tables& T, void* scratch, hipStream_t s) {
+  constexpr int THREADS = TILE / IPT;
+  const int nb = (int)L.nb;
+  hipLaunchKernelGGL(hist_hi_kernel<TILE>, dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys, n, nb, L.nt, T.offA);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(nb), dim3(256), 0, s, T.offA, L.nt, T.tot);
+  hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(BINS), 0, s, T.tot, nb, TILE, T.bstart, T.tstart);
+  hipLaunchKernelGGL((scatter_kernel<MODE_LOWS, TILE>), dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys,
+                     (const uint4*)nullptr, scratch, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.offA,
+                     (const int32_t*)nullptr);
+  hipLaunchKernelGGL(hist_lo_kernel<TILE>, dim3((unsigned)L.ntb), dim3(THREADS), 0, s, (const uint16_t*)scratch, nb,
+                     T.bstart, T.tstart, T.offB);
+  hipLaunchKernelGGL(scan_rows_kernel, dim3(nb), dim3(BINS), 0, s, T.offB, T.bstart, T.tstart, n_rows, n, row_ptr, counts);
+}
+
+template <int TILE>
+static void sort_records(const uint32_t* keys, const uint4* rec, int64_t n, int64_t n_rows, const int32_t* row_ptr,
+                         const Layout& L, const Tables& T, void* buf, void* out, hipStream_t s) {
+  constexpr int THREADS = TILE / IPT;
+  const int nb = (int)L.nb;
+  hipLaunchKernelGGL((scatter_kernel<MODE_REC_A, TILE>), dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys, rec, buf, n, nb,
+                     n_rows, L.nt, T.bstart, T.tstart, T.offA, (const int32_t*)nullptr);
+  hipLaunchKernelGGL((scatter_kernel<MODE_REC_B, TILE>), dim3((unsigned)L.ntb), dim3(THREADS), 0, s,
+                     (const uint32_t*)nullptr, (const uint4*)buf, out, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.offB,
+                     row_ptr);
+}
+}  // namespace ps
+}  // namespace dva
+
 using namespace dva;
 
 extern "C" {
@@ -339,24 +387,11 @@ int dva_plan_split_build(const int32_t* row_idx, int64_t n_views, int64_t n_rows
   if (!row_idx || !row_ptr || !tables || !scratch) return DVA_ERR_INVALID;
   const ps::Layout L = ps::layout(n_views, n_rows);
   if ((int64_t)L.total > tables_bytes || scratch_bytes < n_views * 2) return DVA_ERR_INVALID;
-  hipStream_t s = (hipStream_t)stream;
-  char* tb = (char*)tables;
-  int32_t* tot = (int32_t*)(tb + L.off_tot);
-  int32_t* bstart = (int32_t*)(tb + L.off_bstart);
-  int32_t* tstart = (int32_t*)(tb + L.off_tstart);
-  int32_t* offA = (int32_t*)(tb + L.off_a);
-  int32_t* offB = (int32_t*)(tb + L.off_b);
-  const uint32_t* keys = (const uint32_t*)row_idx;
-  const int nb = (int)L.nb;
-  hipLaunchKernelGGL(ps::hist_hi_kernel, dim3((unsigned)L.nt), dim3(ps::THREADS), 0, s, keys, n_views, nb, offA);
-  hipLaunchKernelGGL(ps::scan_tiles_kernel, dim3(nb), dim3(256), 0, s, offA, L.nt, tot);
-  hipLaunchKernelGGL(ps::bucket_starts_kernel, dim3(1), dim3(ps::BINS), 0, s, tot, nb, bstart, tstart);
-  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_LOWS>), dim3((unsigned)L.nt), dim3(ps::THREADS), 0, s, keys,
-                     (const uint4*)nullptr, scratch, n_views, nb, n_rows, bstart, tstart, offA, (const int32_t*)nullptr);
-  hipLaunchKernelGGL(ps::hist_lo_kernel, dim3((unsigned)L.ntb), dim3(ps::THREADS), 0, s, (const uint16_t*)scratch, nb,
-                     bstart, tstart, offB);
-  hipLaunchKernelGGL(ps::scan_rows_kernel, dim3(nb), dim3(ps::BINS), 0, s, offB, bstart, tstart, n_rows, n_views,
-                     row_ptr, counts);
+  const ps::Tables T = ps::tables_of(tables, L);
+  if (ps::tile_size() == 4096)
+    ps::build<4096>((const uint32_t*)row_idx, n_views, n_rows, row_ptr, counts, L, T, scratch, (hipStream_t)stream);
+  else
+    ps::build<8192>((const uint32_t*)row_idx, n_views, n_rows, row_ptr, counts, L, T, scratch, (hipStream_t)stream);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
@@ -366,24 +401,17 @@ int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t
                                 void* rec_sorted, void* stream) {
   if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
   if (!ps::eligible(n_views, n_rows)) return DVA_ERR_UNSUPPORTED;
-  if (!row_idx || !rec || !row_ptr || !tables || !buf || !rec_sorted || buf == rec || buf == rec_sorted)
-    return DVA_ERR_INVALID;
+  if (!rec || !row_ptr || !tables || !buf || !rec_sorted || buf == rec || buf == rec_sorted) return DVA_ERR_INVALID;
   if (((uintptr_t)rec % 16) || ((uintptr_t)buf % 16) || ((uintptr_t)rec_sorted % 16)) return DVA_ERR_UNSUPPORTED;
   const ps::Layout L = ps::layout(n_views, n_rows);
   if ((int64_t)L.total > tables_bytes) return DVA_ERR_INVALID;
-  hipStream_t s = (hipStream_t)stream;
-  const char* tb = (const char*)tables;
-  const int32_t* bstart = (const int32_t*)(tb + L.off_bstart);
-  const int32_t* tstart = (const int32_t*)(tb + L.off_tstart);
-  const int32_t* offA = (const int32_t*)(tb + L.off_a);
-  const int32_t* offB = (const int32_t*)(tb + L.off_b);
-  const int nb = (int)L.nb;
-  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_REC_A>), dim3((unsigned)L.nt), dim3(ps::THREADS), 0, s,
-                     (const uint32_t*)row_idx, (const uint4*)rec, buf, n_views, nb, n_rows, bstart, tstart, offA,
-                     (const int32_t*)nullptr);
-  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_REC_B>), dim3((unsigned)L.ntb), dim3(ps::THREADS), 0, s,
-                     (const uint32_t*)nullptr, (const uint4*)buf, rec_sorted, n_views, nb, n_rows, bstart, tstart, offB,
-                     row_ptr);
+  const ps::Tables T = ps::tables_of(const_cast<void*>(tables), L);
+  if (ps::tile_size() == 4096)
+    ps::sort_records<4096>((const uint32_t*)row_idx, (const uint4*)rec, n_views, n_rows, row_ptr, L, T, buf, rec_sorted,
+                           (hipStream_t)stream);
+  else
+    ps::sort_records<8192>((const uint32_t*)row_idx, (const uint4*)rec, n_views, n_rows, row_ptr, L, T, buf, rec_sorted,
+                           (hipStream_t)stream);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -643,14 +643,16 @@ class SplitPlan:
     def __len__(self):
         return 2
 
-    def sort_records(self, rec):
-        """rec int32 [V, 4] in view order -> the same storage in plan order (word 3 of a record = its row key)."""
+    def sort_records(self, rec, keyed=False):
+        """rec int32 [V, 4] in view order -> the same storage in plan order (word 3 of a record = its row key).
+        ``keyed``: word 3 already holds the row key (the records of ``dva_chain_attn_bwd``)."""
         lib = _lib.load()
         V = self.row_idx.shape[0]
         assert rec.shape == (V, 4) and rec.dtype == torch.int32 and rec.is_contiguous()
         buf = torch.empty_like(rec)
-        with _timed("plan_sort_records", V * 68):
-            check(lib.dva_plan_split_sort_records(ptr(self.row_idx), ptr(rec), V, self.n_rows, ptr(self.row_ptr),
+        with _timed("plan_sort_records", V * (64 if keyed else 68)):
+            check(lib.dva_plan_split_sort_records(None if keyed else ptr(self.row_idx), ptr(rec), V, self.n_rows,
+                                                  ptr(self.row_ptr),
                                                   ptr(self.tables), self.tables.numel(), ptr(buf), ptr(rec),
                                                   stream_of(rec)), "dva_plan_split_sort_records")
         return rec
@@ -684,7 +686,7 @@ def rows_grad_rec16(gout, plan, rec, R, C, G, out_dtype, stream):
     V = rec.shape[0]
     g = torch.empty((R, C), dtype=out_dtype, device=gout.device)
     if isinstance(plan, SplitPlan):
-        rec = plan.sort_records(rec)
+        rec = plan.sort_records(rec, keyed=True)
         perm, row_ptr = None, plan.row_ptr
     else:
         perm, row_ptr = plan

@@ -211,7 +211,8 @@ int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_
  * dva_row_plan's, and `tables` (dva_plan_split_table_bytes; kept by the caller until the backward); scratch: 2 n_views bytes,
  * free afterwards -- and whose two scatter passes move the 16-BYTE VIEW RECORDS of the attention backward themselves --
  * dva_plan_split_sort_records: rec [n_views][16] in view order -> rec_sorted in plan order (record i = plan entry i, views of
- * a row in view order, word 3 of a record = its row key), through buf [n_views][16]; rec_sorted may be rec.  The rows gradient
+ * a row in view order, word 3 of a record = its row key), through buf [n_views][16]; rec_sorted may be rec; row_idx NULL: word 3
+ * of the records already holds the row key (dva_chain_attn_bwd writes it there).  The rows gradient
  * (dva_view_gather_rows_grad_rec16* with perm = NULL) then streams its records: no permutation exists, no random 16-byte
  * fetch per view.  Replaces the index_add of core/multimodal/image.py:1262-1287's backward like dva_row_plan. */
 int64_t dva_plan_split_table_bytes(int64_t n_views, int64_t n_rows);

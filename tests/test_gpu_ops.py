@@ -384,6 +384,9 @@ def test_split_plan_equals_row_plan(V, R, how):
     want[:, 3] = rd[perm.long()]
     got = plan.sort_records(rec.clone())
     assert torch.equal(got, want)
+    keyed = rec.clone()
+    keyed[:, 3] = rd                                   # records that carry their key (dva_chain_attn_bwd)
+    assert torch.equal(plan.sort_records(keyed, keyed=True), want)
     assert torch.equal(plan.perm, perm) and torch.equal(plan[1], row_ptr)      # the lazy permutation of other callers
 
 
