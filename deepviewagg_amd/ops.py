@@ -430,7 +430,7 @@ class _GatherNearest(torch.autograd.Function):
         P = packed.shape[0]
         if ROWS_GRAD_ALGO == 0:
             # deterministic segmented reduction over the row plan (sorted atoms) instead of fp32 atomics
-            row_idx, _, (perm, row_ptr) = gather_row_index(packed, B, H, W, with_counts=False, with_plan=True)
+            row_idx, _, (perm, row_ptr) = gather_row_index(packed, B, H, W, with_counts=False, with_plan=True, split=False)
             gx = torch.empty((B, H, W, C), dtype=torch.float32, device=gout.device)
             with _timed("gather_nearest_bwd", P * (C * gout.element_size() + 12) + B * H * W * C * 4):
                 check(lib.dva_gather_rows_sum(ptr(gout), ptr(perm), ptr(row_ptr), None, 0, ptr(gx), B * H * W, P, C,
@@ -474,7 +474,7 @@ def _anchor_chunk_images(B, bytes_per_image, device):
 def anchor_plan(anchors, B, H, W):
     """The row plan over the ANCHORS of the views (``dva_gather_bilinear_taps_anchor``): ``(perm, row_ptr)`` with
     B (H + 1) (W + 1) + 1 anchors (the last one = views without the 2 x 2 tap structure)."""
-    return row_plan(anchors, B * (H + 1) * (W + 1) + 1, with_counts=False)[0]
+    return row_plan(anchors, B * (H + 1) * (W + 1) + 1, with_counts=False, split=False)[0]
 
 
 def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=None, plan=None):
@@ -569,7 +569,7 @@ class _GatherBilinear(torch.autograd.Function):
                 # grouped by anchor instead: P keys to sort, every gradient row read once (bilinear_scatter)
                 gx = bilinear_scatter(gout, rows4, w4, anchors, B, H, W).view(B, H, W, C)
                 return gx.permute(0, 3, 1, 2).to(dt), None, None
-            (perm, row_ptr), _ = row_plan(rows4, B * H * W, with_counts=False)
+            (perm, row_ptr), _ = row_plan(rows4, B * H * W, with_counts=False, split=False)
             gx = torch.empty((B, H, W, C), dtype=torch.float32, device=gout.device)
             with _timed("gather_bilinear_bwd", 4 * P * (C * gout.element_size() + 12) + B * H * W * C * 4):
                 check(lib.dva_gather_rows_sum(ptr(gout), ptr(perm), ptr(row_ptr), ptr(w4), 2, ptr(gx), B * H * W,
@@ -658,14 +658,15 @@ class SplitPlan:
         return rec
 
 
-def row_plan(row_idx, n_rows, with_counts=True):
+def row_plan(row_idx, n_rows, with_counts=True, split=True):
     """Views grouped by the feature-map row they read: ``(perm, row_ptr)`` int32 (+ ``counts`` int32
     [n_rows]).  Stable, so the order of the views inside a row (and with it every sum over them) is
-    deterministic.  Large plans come back as a ``SplitPlan`` (same ``row_ptr`` / ``counts``, no permutation)."""
+    deterministic.  Large plans come back as a ``SplitPlan`` (same ``row_ptr`` / ``counts``, no permutation) unless the
+    caller knows its consumer wants the permutation (``split=False``: fp32 maps, several atoms per view)."""
     lib = _lib.load()
     require_device(row_idx)
     V, dev = row_idx.shape[0], row_idx.device
-    if SPLIT_PLAN and V >= SPLIT_PLAN_MIN_VIEWS and row_idx.is_contiguous():
+    if split and SPLIT_PLAN and V >= SPLIT_PLAN_MIN_VIEWS and row_idx.is_contiguous():
         nbytes = int(lib.dva_plan_split_table_bytes(V, n_rows))
         if nbytes > 0:
             row_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
@@ -707,7 +708,7 @@ def csr_expand(csr_idx, n_views):
     return vp
 
 
-def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True, with_plan=False):
+def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True, with_plan=False, split=True):
     """Flat row index of every atom into the [B*H*W, C] view of a channels-last map, and the number
     of atoms per row (int32 [B*H*W]) if ``with_counts``.  ``with_plan``: also return the row plan
     (``row_plan``); the counts then come from the plan instead of a histogram with atomics."""
@@ -722,12 +723,12 @@ def gather_row_index(packed_idx, B, H, W, row_offset=0, with_counts=True, with_p
                                        ptr(counts), stream_of(packed_idx)), "dva_gather_row_index")
     if with_plan:
         assert row_offset == 0, "a plan is built over the rows of one map"
-        plan, counts = row_plan(row_idx, B * H * W, with_counts)
+        plan, counts = row_plan(row_idx, B * H * W, with_counts, split)
         return row_idx, counts, plan
     return row_idx, counts
 
 
-def mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W, with_counts=True, with_plan=True):
+def mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W, with_counts=True, with_plan=True, split=True):
     """``gather_row_index(pack_gather_index(images, atom_ptr, pixels, ratio), B, H, W)`` in one pass (no packed index):
     (row_idx, counts, plan) with the counts taken from the row plan."""
     lib = _lib.load()
@@ -744,7 +745,7 @@ def mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W, with_counts=True
                                         V, P, B, H, W, ptr(row_idx), stream_of(pixels)), "dva_mapping_row_index")
     if not with_plan:
         return row_idx, None, None
-    plan, counts = row_plan(row_idx, B * H * W, with_counts)
+    plan, counts = row_plan(row_idx, B * H * W, with_counts, split)
     return row_idx, counts, plan
 
 
@@ -810,7 +811,9 @@ def lazy_gather_nearest(x, packed_idx, exact):
     assert x.dim() == 4
     B, C, H, W = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
-    row_idx, counts, plan = gather_row_index(packed_idx, B, H, W, with_plan=True)
+    # the split plan serves the 16-byte-record rows gradient: bf16 maps, one atom per view
+    row_idx, counts, plan = gather_row_index(packed_idx, B, H, W, with_plan=True,
+                                             split=bool(exact) and x.dtype == torch.bfloat16)
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
 
 
@@ -819,7 +822,8 @@ def lazy_gather_nearest_mapping(x, images, atom_ptr, pixels, ratio, exact):
     assert x.dim() == 4
     B, C, H, W = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
-    row_idx, counts, plan = mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W)
+    row_idx, counts, plan = mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W,
+                                              split=bool(exact) and x.dtype == torch.bfloat16)
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
 
 
@@ -860,7 +864,7 @@ class _GatherSegmentMax(torch.autograd.Function):
                                                      ptr(grows), V, P, R, C, dtype_code(gout), stream_of(gout)),
                       "dva_gather_segment_max_bwd")
             return grows.to(dt), None, None, None
-        perm, row_ptr = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
+        perm, row_ptr = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False, split=False)[0]
         voa = csr_expand(atom_ptr, P)
         grows = torch.empty((R, C), dtype=torch.float32, device=gout.device)
         with _timed("gather_segment_max_bwd", P * (16 + C * (es + 2)) + R * (C * 4 + 4)):
@@ -1075,7 +1079,7 @@ class _ViewGatherAttention(torch.autograd.Function):
                     ptr(compat), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx), ptr(csr_idx),
                     ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(gout), ptr(out), ptr(gcompat),
                     ptr(rec), ptr(gwb), N, V, R, C, G, scaling, ctx.eps, stream_of(rows)), "dva_chain_attn_bwd_f32")
-            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
+            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False, split=False)[0]
             perm, row_ptr = plan
             grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
             with _timed("view_gather_rows_grad", V * (4 + 32 + C * es) + R * (C * 4 + 4)):
@@ -1134,7 +1138,7 @@ class _ViewGatherAttention(torch.autograd.Function):
                 ptr(gcompat), ptr(gwb), ptr(rec), rs, N, V, C, G, scaling, dtype_code(rows), ATTENTION_ALGO,
                 stream_of(rows)), "dva_view_gather_attention_bwd")
         if use_plan:
-            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False)[0]
+            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False, split=False)[0]
             perm, row_ptr = plan
             vp = csr_expand(csr_idx, V) if rec is None else None
             grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
