@@ -32,7 +32,7 @@ static inline int tile_size() {
 
 struct Layout {
   int64_t nt, nb, ntb;
-  size_t off_tot, off_bstart, off_tstart, off_a, off_b, total;
+  size_t off_tot, off_bstart, off_tstart, off_a, off_b, off_desc, total;
 };
 
 static inline bool eligible(int64_t n_views, int64_t n_rows) {
@@ -50,7 +50,8 @@ static inline Layout layout(int64_t n, int64_t n_rows) {
   L.off_tstart = (512 + 520) * 4;
   L.off_a = HEAD_INTS * 4;
   L.off_b = L.off_a + (size_t)L.nt * BINS * 4;
-  L.total = L.off_b + (size_t)L.ntb * BINS * 4;
+  L.off_desc = L.off_b + (size_t)L.ntb * BINS * 4;      // int4 {bucket, first entry, entries, 0} per B tile
+  L.total = L.off_desc + (size_t)L.ntb * 16;
   return L;
 }
 
@@ -77,6 +78,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* s_w, int* total = nul
   if (total) *total = all;
   return before + inc - v;
 }
+
+__device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ int hi_digit(uint32_t key, int nb) {
   const int d = (int)(key >> LO_BITS);
@@ -118,10 +121,11 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t* __restrict__ o
   if (threadIdx.x == 0) tot[blockIdx.x] = carry;
 }
 
-// bucket_start[0 .. BINS], tile_start[0 .. BINS] (B tiles: every bucket is cut into its own tiles of TILE entries)
+// bucket_start[0 .. BINS], tile_start[0 .. BINS] (B tiles: every bucket is cut into its own tiles of TILE entries) and the
+// descriptor {bucket, first entry, entries} of every B tile (one load per tile in the passes instead of a search)
 __global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __restrict__ tot, int nb, int TILE,
                                                              int32_t* __restrict__ bucket_start,
-                                                             int32_t* __restrict__ tile_start) {
+                                                             int32_t* __restrict__ tile_start, int4* __restrict__ desc) {
   __shared__ int s_w[BINS / 64];
   const int d = threadIdx.x;
   const int v = d < nb ? tot[d] : 0;
@@ -130,38 +134,34 @@ __global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __re
   bucket_start[d] = bs;
   if (d == BINS - 1) bucket_start[BINS] = all;
   int allt;
-  const int ts = block_excl_scan<BINS>((v + TILE - 1) / TILE, s_w, &allt);
+  const int nt_b = (v + TILE - 1) / TILE;
+  const int ts = block_excl_scan<BINS>(nt_b, s_w, &allt);
   tile_start[d] = ts;
   if (d == BINS - 1) tile_start[BINS] = allt;
+  for (int j = 0; j < nt_b; ++j) {
+    const int left = v - j * TILE;
+    desc[ts + j] = make_int4(d, bs + j * TILE, left < TILE ? left : TILE, 0);
+  }
 }
 
-// geometry of B tile `tb`: its bucket, first entry and entry count (false: no such tile)
-template <int TILE>
-__device__ __forceinline__ bool tile_b(const int32_t* __restrict__ bucket_start, const int32_t* __restrict__ tile_start,
-                                       int nb, int tb, int& b, int64_t& start, int& count) {
-  if (tb >= tile_start[nb]) return false;
-  int lo = 0, hi = nb;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (tile_start[mid] <= tb) lo = mid; else hi = mid;
-  }
-  b = lo;
-  start = (int64_t)bucket_start[b] + (int64_t)(tb - tile_start[b]) * TILE;
-  const int64_t left = (int64_t)bucket_start[b + 1] - start;
-  count = (int)(left < TILE ? left : TILE);
-  return true;
+// geometry of B tile `tb`: its bucket, first entry and entry count
+__device__ __forceinline__ void tile_b(const int4* __restrict__ desc, int tb, int& b, int64_t& start, int& count) {
+  const int4 d = desc[tb];
+  b = rfl_i(d.x);
+  start = (int64_t)rfl_i(d.y);
+  count = rfl_i(d.z);
 }
 
 template <int TILE>
 __global__ __launch_bounds__(TILE / IPT) void hist_lo_kernel(const uint16_t* __restrict__ lows, int nb,
-                                                             const int32_t* __restrict__ bucket_start,
                                                              const int32_t* __restrict__ tile_start,
-                                                             int32_t* __restrict__ offB) {
+                                                             const int4* __restrict__ desc, int32_t* __restrict__ offB) {
   constexpr int THREADS = TILE / IPT;
   __shared__ int h[BINS];
+  if ((int)blockIdx.x >= tile_start[nb]) return;
   int b, count;
   int64_t start;
-  if (!tile_b<TILE>(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
+  tile_b(desc, blockIdx.x, b, start, count);
   for (int i = threadIdx.x; i < BINS; i += THREADS) h[i] = 0;
   __syncthreads();
 #pragma unroll
@@ -214,14 +214,21 @@ __device__ __forceinline__ uint64_t match_digit(int d, bool valid) {
   return peers;
 }
 
-// keys NULL (REC_A): word 3 of the records already is the row key (dva_chain_attn_bwd writes it)
+// keys NULL (REC_A): word 3 of the records already is the row key (dva_chain_attn_bwd writes it).
+// One workgroup per tile, in an XCD-aware order (xcd_order, gridDim.x a multiple of 8): workgroup i runs on XCD i % 8, so
+// XCD x takes the x-th eighth of the tiles and its CUs hold NEIGHBOURING tiles at any time -- the two halves of a 128-byte
+// line shared by the runs of two neighbouring tiles then meet in one L2 instead of leaving two partial writes (0.66 ->
+// 0.56 ms for the two record passes).  Persistent workgroups that request the next tile's entries under the write-out of
+// the current one were measured slower (0.60 ms: 119 registers, and the tiles of a CU no longer neighbour those of the
+// other CUs of its XCD in time).
 template <int MODE, int TILE>
 __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __restrict__ keys, const uint4* __restrict__ src,
                                                              void* __restrict__ dst, int64_t n, int nb, int64_t n_rows,
                                                              int64_t nt, const int32_t* __restrict__ bucket_start,
                                                              const int32_t* __restrict__ tile_start,
+                                                             const int4* __restrict__ desc,
                                                              const int32_t* __restrict__ off,
-                                                             const int32_t* __restrict__ row_ptr) {
+                                                             const int32_t* __restrict__ row_ptr, int xcd_order) {
   constexpr int THREADS = TILE / IPT, WAVES = THREADS / 64;
   typedef typename Elem<MODE>::type E;
   __shared__ E s_stage[TILE];
@@ -229,13 +236,17 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
   __shared__ int s_lstart[BINS];
   __shared__ int s_base[BINS];
   __shared__ int s_w[WAVES];
+  static_assert(THREADS >= BINS, "one thread per digit in the scan over the wavefronts");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n_tiles = MODE == MODE_REC_B ? tile_start[nb] : (int)nt;
+  const int tile = xcd_order ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= n_tiles) return;
   int b = 0, count;
   int64_t start;
   if (MODE == MODE_REC_B) {
-    if (!tile_b<TILE>(bucket_start, tile_start, nb, blockIdx.x, b, start, count)) return;
+    tile_b(desc, tile, b, start, count);
   } else {
-    start = (int64_t)blockIdx.x * TILE;
+    start = (int64_t)tile * TILE;
     const int64_t left = n - start;
     count = (int)(left < TILE ? left : TILE);
   }
@@ -261,15 +272,15 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
 #pragma unroll
     for (int k = 0; k < WAVES * BINS / 2 / THREADS; ++k) z[k * THREADS + tid] = 0u;
   }
-  for (int d = tid; d < BINS; d += THREADS) {
+  if (tid < BINS) {
     int base;
     if (MODE == MODE_REC_B) {
-      const int64_t r = (int64_t)b * BINS + d;
-      base = (r <= n_rows ? row_ptr[r] : 0) + off[(int64_t)blockIdx.x * BINS + d];
+      const int64_t r = (int64_t)b * BINS + tid;
+      base = (r <= n_rows ? row_ptr[r] : 0) + off[(int64_t)tile * BINS + tid];
     } else {
-      base = d < nb ? bucket_start[d] + off[(int64_t)d * nt + blockIdx.x] : 0;
+      base = tid < nb ? bucket_start[tid] + off[(int64_t)tid * nt + tile] : 0;
     }
-    s_base[d] = base;
+    s_base[tid] = base;
   }
   __syncthreads();
   // ---- stable rank inside the wavefront's 512 entries: counter of the digit before this item + lanes below
@@ -286,14 +297,13 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
   }
   __syncthreads();
   // ---- counters -> prefix over the wavefronts; digit starts inside the tile
-  static_assert(THREADS >= BINS, "one thread per digit in the scan over the wavefronts");
   int run = 0;
   if (tid < BINS) {
 #pragma unroll
     for (int k = 0; k < WAVES; ++k) {
-      const int t = s_cnt[k][tid];
+      const int c = s_cnt[k][tid];
       s_cnt[k][tid] = (uint16_t)run;
-      run += t;
+      run += c;
     }
   }
   const int ls = block_excl_scan<THREADS>(tid < BINS ? run : 0, s_w);
@@ -333,12 +343,21 @@ namespace dva {
 namespace ps {
 struct Tables {
   int32_t *tot, *bstart, *tstart, *offA, *offB;
+  int4* desc;
 };
 static inline Tables tables_of(void* tables, const Layout& L) {
   char* tb = (char*)tables;
   return {(int32_t*)(tb + L.off_tot), (int32_t*)(tb + L.off_bstart), (int32_t*)(tb + L.off_tstart),
-          (int32_t*)(tb + L.off_a), (int32_t*)(tb + L.off_b)};
+          (int32_t*)(tb + L.off_a), (int32_t*)(tb + L.off_b), (int4*)(tb + L.off_desc)};
 }
+
+// grid of a scatter pass: its tiles rounded up to a multiple of 8 for the XCD-aware order (the extra workgroups exit);
+// DVA_PLAN_XCD=0: plain order, the A/B
+static inline bool xcd_on() {
+  static const int on = tune_int("DVA_PLAN_XCD", 1);
+  return on != 0;
+}
+static inline unsigned scatter_grid(int64_t tiles) { return (unsigned)(xcd_on() ? (tiles + 7) / 8 * 8 : tiles); }
 
 template <int TILE>
 static void build(const uint32_t* keys, int64_t n, int64_t n_rows, int32_t* row_ptr, int32_t* counts, const Layout& L,
@@ -347,12 +366,12 @@ static void build(const uint32_t* keys, int64_t n, int64_t n_rows, int32_t* row_
   const int nb = (int)L.nb;
   hipLaunchKernelGGL(hist_hi_kernel<TILE>, dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys, n, nb, L.nt, T.offA);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(nb), dim3(256), 0, s, T.offA, L.nt, T.tot);
-  hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(BINS), 0, s, T.tot, nb, TILE, T.bstart, T.tstart);
-  hipLaunchKernelGGL((scatter_kernel<MODE_LOWS, TILE>), dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys,
-                     (const uint4*)nullptr, scratch, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.offA,
-                     (const int32_t*)nullptr);
+  hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(BINS), 0, s, T.tot, nb, TILE, T.bstart, T.tstart, T.desc);
+  hipLaunchKernelGGL((scatter_kernel<MODE_LOWS, TILE>), dim3(scatter_grid(L.nt)), dim3(THREADS), 0, s, keys,
+                     (const uint4*)nullptr, scratch, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.desc, T.offA,
+                     (const int32_t*)nullptr, (int)xcd_on());
   hipLaunchKernelGGL(hist_lo_kernel<TILE>, dim3((unsigned)L.ntb), dim3(THREADS), 0, s, (const uint16_t*)scratch, nb,
-                     T.bstart, T.tstart, T.offB);
+                     T.tstart, T.desc, T.offB);
   hipLaunchKernelGGL(scan_rows_kernel, dim3(nb), dim3(BINS), 0, s, T.offB, T.bstart, T.tstart, n_rows, n, row_ptr, counts);
 }
 
@@ -361,11 +380,12 @@ static void sort_records(const uint32_t* keys, const uint4* rec, int64_t n, int6
                          const Layout& L, const Tables& T, void* buf, void* out, hipStream_t s) {
   constexpr int THREADS = TILE / IPT;
   const int nb = (int)L.nb;
-  hipLaunchKernelGGL((scatter_kernel<MODE_REC_A, TILE>), dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys, rec, buf, n, nb,
-                     n_rows, L.nt, T.bstart, T.tstart, T.offA, (const int32_t*)nullptr);
-  hipLaunchKernelGGL((scatter_kernel<MODE_REC_B, TILE>), dim3((unsigned)L.ntb), dim3(THREADS), 0, s,
-                     (const uint32_t*)nullptr, (const uint4*)buf, out, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.offB,
-                     row_ptr);
+  hipLaunchKernelGGL((scatter_kernel<MODE_REC_A, TILE>), dim3(scatter_grid(L.nt)), dim3(THREADS), 0, s, keys, rec,
+                     buf, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.desc, T.offA, (const int32_t*)nullptr,
+                     (int)xcd_on());
+  hipLaunchKernelGGL((scatter_kernel<MODE_REC_B, TILE>), dim3(scatter_grid(L.ntb)), dim3(THREADS), 0, s,
+                     (const uint32_t*)nullptr, (const uint4*)buf, out, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.desc,
+                     T.offB, row_ptr, (int)xcd_on());
 }
 }  // namespace ps
 }  // namespace dva
