@@ -153,12 +153,14 @@ KERNEL_SYMBOL = {
 }
 # what bounds the kernel the roofline object is about (SQ counters: profiles/*sq_counters*)
 ROOFLINE_NOTES = {
-    "view_gather_rows_grad": "rows gradient = segmented reduction over the row plan (deterministic, no atomics): per view "
-                             "a 4-byte plan entry, a 16-byte record and the 128-byte grad_out row of its point, all at "
-                             "random addresses; the records cost a whole cache line each (PMC traffic 1.8 x the "
-                             "algorithmic bytes): bound by random-access throughput of the memory system",
-    "chain_bwd_l5": "layer-5 backward pass (x_map 32 + index 4 + gradient row in 64 + out 64 bytes per view, per-point "
-                    "rows): 166 VGPRs -> 3 wavefronts per SIMD since round 3",
+    "view_gather_rows_grad": "rows gradient = segmented reduction over the row plan (deterministic, no atomics); since "
+                             "round 5 its 16-byte view records arrive in plan order (split plan: the records themselves go "
+                             "through the two radix scatter passes, timer plan_sort_records), so per view it streams 16 bytes "
+                             "and fetches the 128-byte grad_out row of the point at a random address: bound by the fabric's "
+                             "rate for one random line per view",
+    "chain_bwd_l5": "layer-5 backward pass of the recompute chain (x_map 32 + index 4 + gradient row in 64 + out 64 bytes per "
+                    "view, per-point rows): 166 VGPRs -> 3 wavefronts per SIMD; the one chain pass whose PMC traffic equals "
+                    "its algorithmic bytes and whose vector unit is only ~0.5 busy: HBM-bound at 3 wavefronts per SIMD",
     "chain_attn_bwd": "attention backward from the stored scores (softmax / gate backward, score gradients, view "
                       "records; no chain evaluation): 107 VGPRs -> 4 wavefronts per SIMD; the value rows it re-gathers "
                       "(128 of its ~184 bytes per view) come out of the cache hierarchy",

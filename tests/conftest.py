@@ -36,6 +36,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _poison_freed_device_memory(request):
+    """DVA_TEST_POISON=1: before every GPU test, fill 2 GiB of the caching allocator's free list with 0xFF bytes (NaN as
+    fp32 / bf16, -1 as an index), so that a kernel reading memory it was supposed to write first fails loudly instead of
+    passing on whatever the previous test left there."""
+    if os.environ.get("DVA_TEST_POISON") == "1" and "gpu" in request.keywords and torch.cuda.is_available():
+        big = torch.empty(1 << 31, dtype=torch.uint8, device="cuda:0").fill_(0xFF)
+        small = [torch.empty(1 << 16, dtype=torch.uint8, device="cuda:0").fill_(0xFF) for _ in range(64)]
+        del big, small
+    yield
+
+
 def load_golden(name):
     """Committed golden vector produced by oracle/gen_golden.py from the reference's own source."""
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:

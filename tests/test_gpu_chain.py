@@ -472,7 +472,7 @@ def test_chain_against_reference_fixture(name):
     print(f"chain vs reference fixture {name}: out {r:.4f} (oracle under autocast {r_amp:.4f})")
     assert r < max(2e-2, 1.5 * r_amp), (r, r_amp)
     unseen = csr[1:] == csr[:-1]
-    assert float(out.float().cpu()[unseen].abs().max()) == 0.0
+    assert float(out.detach().float().cpu()[unseen].abs().max()) == 0.0
     names = ["x_mod"] + [n for n, _ in m.named_parameters()]
     refs = [t(g["grad_x_mod"])] + [t(g["gp/" + n]) for n in names[1:]]
     amps = sorted(rel(c, b) for n, b, c in zip(names, refs, g_amp) if c is not None and n.startswith("E_map"))
