@@ -336,6 +336,127 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
   }
 }
 
+
+// ---- the rows gradient straight from the bucket-ordered records (pass A's output) ---------------------------------
+// One workgroup per bucket = 512 consecutive map rows, whose C fp32 accumulators ARE the workgroup's registers (1024
+// threads x 32 at C = 64: lane team `grp` of C / 8 lanes owns rows grp, grp + GROUPS, ...).  The bucket's tiles pass
+// through LDS one after the other: ranked by the low digit and staged in row order exactly like pass B -- but instead of
+// being written back (16 bytes per view) and read again by the rows gradient (16 more), the staged records are
+// consumed where they lie: per row its records in view order, the 128-byte grad_out row of each record's point
+// gathered U at a time.  Deterministic (a row is summed by one lane team in view order); the order differs from the
+// segmented reduction of attention.hip (which splits a row over 8 lane slots), so the two agree to fp32 rounding, not
+// bit for bit.  bf16 in, bf16 out, C in {32, 64}.
+template <int C>
+__global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __restrict__ rec, const bf16_t* __restrict__ gout,
+                                                                bf16_t* __restrict__ grows, int64_t n_rows, int G,
+                                                                const int32_t* __restrict__ tile_start,
+                                                                const int4* __restrict__ desc) {
+  constexpr int TILE = 8192, THREADS = 1024, WAVES = THREADS / 64;
+  constexpr int LPR = C / 8, GROUPS = THREADS / LPR, RPT = BINS / GROUPS, U = 8;
+  __shared__ uint4 s_stage[TILE];
+  __shared__ uint16_t s_cnt[WAVES][BINS];
+  __shared__ int s_lstart[BINS + 1];
+  __shared__ int s_w[WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.x;
+  const int grp = tid / LPR, cl = tid % LPR, gch = cl / (LPR / G);
+  float acc[RPT][8];
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[rr][k] = 0.f;
+  const int tb0 = tile_start[b], tb1 = tile_start[b + 1];
+  for (int tb = tb0; tb < tb1; ++tb) {
+    int bb, count;
+    int64_t start;
+    tile_b(desc, tb, bb, start, count);
+    uint32_t kk[IPT], p0[IPT], p1[IPT], p2[IPT];
+    bool ok[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int idx = w * (64 * IPT) + i * 64 + lane;
+      ok[i] = idx < count;
+      const uint4 r = rec[start + (ok[i] ? idx : 0)];
+      p0[i] = r.x, p1[i] = r.y, p2[i] = r.z, kk[i] = r.w;
+    }
+    {
+      uint32_t* z = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);
+#pragma unroll
+      for (int k = 0; k < WAVES * BINS / 2 / THREADS; ++k) z[k * THREADS + tid] = 0u;
+    }
+    __syncthreads();                       // (also: the previous tile's records are consumed)
+    int dg[IPT], rank[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      dg[i] = (int)(kk[i] & (BINS - 1));
+      const uint64_t peers = match_digit(dg[i], ok[i]);
+      const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+      const int prev = s_cnt[w][dg[i]];
+      if (ok[i] && below == 0) s_cnt[w][dg[i]] = (uint16_t)(prev + __popcll(peers));
+      rank[i] = prev + below;
+    }
+    __syncthreads();
+    int run = 0;
+    if (tid < BINS) {
+#pragma unroll
+      for (int k = 0; k < WAVES; ++k) {
+        const int c = s_cnt[k][tid];
+        s_cnt[k][tid] = (uint16_t)run;
+        run += c;
+      }
+    }
+    const int ls = block_excl_scan<THREADS>(tid < BINS ? run : 0, s_w);
+    if (tid < BINS) s_lstart[tid] = ls;
+    if (tid == BINS - 1) s_lstart[BINS] = ls + run;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      if (ok[i]) s_stage[s_lstart[dg[i]] + s_cnt[w][dg[i]] + rank[i]] = make_uint4(p0[i], p1[i], p2[i], kk[i]);
+    }
+    __syncthreads();
+    // ---- consume: row d = grp + GROUPS * rr, its records [s_lstart[d], s_lstart[d + 1]) in view order
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+      const int d = grp + GROUPS * rr;
+      const int beg = s_lstart[d], end = s_lstart[d + 1];
+      for (int i0 = beg; i0 < end; i0 += U) {
+        uint4 raw[U];
+        float sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool in = i0 + u < end;
+          const uint32_t* rv = reinterpret_cast<const uint32_t*>(&s_stage[in ? i0 + u : beg]);
+          const int64_t p = (int)rv[0];
+          const uint32_t w2 = rv[1 + (gch >> 1)];
+          sc[u] = in ? __uint_as_float((gch & 1) ? (w2 & 0xffff0000u) : (w2 << 16)) : 0.f;
+          raw[u] = *reinterpret_cast<const uint4*>(gout + p * C + cl * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint4 r = raw[u];
+          acc[rr][0] = fmaf(__uint_as_float(r.x << 16), sc[u], acc[rr][0]);
+          acc[rr][1] = fmaf(__uint_as_float(r.x & 0xffff0000u), sc[u], acc[rr][1]);
+          acc[rr][2] = fmaf(__uint_as_float(r.y << 16), sc[u], acc[rr][2]);
+          acc[rr][3] = fmaf(__uint_as_float(r.y & 0xffff0000u), sc[u], acc[rr][3]);
+          acc[rr][4] = fmaf(__uint_as_float(r.z << 16), sc[u], acc[rr][4]);
+          acc[rr][5] = fmaf(__uint_as_float(r.z & 0xffff0000u), sc[u], acc[rr][5]);
+          acc[rr][6] = fmaf(__uint_as_float(r.w << 16), sc[u], acc[rr][6]);
+          acc[rr][7] = fmaf(__uint_as_float(r.w & 0xffff0000u), sc[u], acc[rr][7]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    const int64_t r = (int64_t)b * BINS + grp + GROUPS * rr;
+    if (r < n_rows) {
+      const uint4 o = {pack_bf16x2(acc[rr][0], acc[rr][1]), pack_bf16x2(acc[rr][2], acc[rr][3]),
+                       pack_bf16x2(acc[rr][4], acc[rr][5]), pack_bf16x2(acc[rr][6], acc[rr][7])};
+      *reinterpret_cast<uint4*>(grows + r * C + cl * 8) = o;
+    }
+  }
+}
+
 }  // namespace ps
 }  // namespace dva
 
@@ -383,6 +504,7 @@ static void sort_records(const uint32_t* keys, const uint4* rec, int64_t n, int6
   hipLaunchKernelGGL((scatter_kernel<MODE_REC_A, TILE>), dim3(scatter_grid(L.nt)), dim3(THREADS), 0, s, keys, rec,
                      buf, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.desc, T.offA, (const int32_t*)nullptr,
                      (int)xcd_on());
+  if (!out) return;                 // pass A only: the caller consumes the bucket-ordered records (dva_plan_split_rows_grad)
   hipLaunchKernelGGL((scatter_kernel<MODE_REC_B, TILE>), dim3(scatter_grid(L.ntb)), dim3(THREADS), 0, s,
                      (const uint32_t*)nullptr, (const uint4*)buf, out, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.desc,
                      T.offB, row_ptr, (int)xcd_on());
@@ -421,7 +543,7 @@ int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t
                                 void* rec_sorted, void* stream) {
   if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
   if (!ps::eligible(n_views, n_rows)) return DVA_ERR_UNSUPPORTED;
-  if (!rec || !row_ptr || !tables || !buf || !rec_sorted || buf == rec || buf == rec_sorted) return DVA_ERR_INVALID;
+  if (!rec || !row_ptr || !tables || !buf || buf == rec || buf == rec_sorted) return DVA_ERR_INVALID;
   if (((uintptr_t)rec % 16) || ((uintptr_t)buf % 16) || ((uintptr_t)rec_sorted % 16)) return DVA_ERR_UNSUPPORTED;
   const ps::Layout L = ps::layout(n_views, n_rows);
   if ((int64_t)L.total > tables_bytes) return DVA_ERR_INVALID;
@@ -432,6 +554,30 @@ int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t
   else
     ps::sort_records<8192>((const uint32_t*)row_idx, (const uint4*)rec, n_views, n_rows, row_ptr, L, T, buf, rec_sorted,
                            (hipStream_t)stream);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64_t n_views, int64_t n_rows,
+                             const void* tables, int64_t tables_bytes, void* grad_rows, int32_t C, int32_t G, int32_t dtype,
+                             int32_t out_dtype, void* stream) {
+  if (n_views < 0 || n_rows < 0 || C <= 0 || G <= 0) return DVA_ERR_INVALID;
+  if (!ps::eligible(n_views, n_rows) || ps::tile_size() != 8192 || dtype != DVA_BF16 || out_dtype != DVA_BF16 ||
+      (C != 32 && C != 64) || (G != 1 && G != 2 && G != 4) || ((C / 8) % G) != 0)
+    return DVA_ERR_UNSUPPORTED;
+  if (!grad_out || !bucket_rec || !tables || !grad_rows) return DVA_ERR_INVALID;
+  if (((uintptr_t)bucket_rec % 16) || ((uintptr_t)grad_out % 16) || ((uintptr_t)grad_rows % 16)) return DVA_ERR_UNSUPPORTED;
+  const ps::Layout L = ps::layout(n_views, n_rows);
+  if ((int64_t)L.total > tables_bytes) return DVA_ERR_INVALID;
+  const ps::Tables T = ps::tables_of(const_cast<void*>(tables), L);
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (int)L.nb;
+  if (C == 64)
+    hipLaunchKernelGGL(ps::bucket_rows_grad_kernel<64>, dim3(nb), dim3(1024), 0, s, (const uint4*)bucket_rec,
+                       (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, T.tstart, T.desc);
+  else
+    hipLaunchKernelGGL(ps::bucket_rows_grad_kernel<32>, dim3(nb), dim3(1024), 0, s, (const uint4*)bucket_rec,
+                       (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, T.tstart, T.desc);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

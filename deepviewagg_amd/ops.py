@@ -599,6 +599,9 @@ def gather_bilinear(x, packed_idx, coords):
 # DVA_SPLIT_PLAN=0: the permutation plan everywhere (the A/B).
 SPLIT_PLAN = os.environ.get("DVA_SPLIT_PLAN", "1") == "1"
 SPLIT_PLAN_MIN_VIEWS = 1 << 22
+# DVA_SPLIT_FUSED=0: pass B + the segmented reduction of attention.hip instead of the bucket kernel (the A/B; also the
+# form whose sums equal the permutation plan's bit for bit)
+SPLIT_FUSED = os.environ.get("DVA_SPLIT_FUSED", "1") == "1"
 
 
 def _legacy_row_plan(row_idx, n_rows, with_counts):
@@ -643,19 +646,39 @@ class SplitPlan:
     def __len__(self):
         return 2
 
-    def sort_records(self, rec, keyed=False):
+    def sort_records(self, rec, keyed=False, bucket_order=False):
         """rec int32 [V, 4] in view order -> the same storage in plan order (word 3 of a record = its row key).
-        ``keyed``: word 3 already holds the row key (the records of ``dva_chain_attn_bwd``)."""
+        ``keyed``: word 3 already holds the row key (the records of ``dva_chain_attn_bwd``).  ``bucket_order``: pass A
+        only -- a NEW tensor with the records in bucket order (what ``rows_grad_fused`` consumes)."""
         lib = _lib.load()
         V = self.row_idx.shape[0]
         assert rec.shape == (V, 4) and rec.dtype == torch.int32 and rec.is_contiguous()
         buf = torch.empty_like(rec)
-        with _timed("plan_sort_records", V * (64 if keyed else 68)):
+        with _timed("plan_sort_records", V * ((32 if bucket_order else 64) + (0 if keyed else 4))):
             check(lib.dva_plan_split_sort_records(None if keyed else ptr(self.row_idx), ptr(rec), V, self.n_rows,
                                                   ptr(self.row_ptr),
-                                                  ptr(self.tables), self.tables.numel(), ptr(buf), ptr(rec),
-                                                  stream_of(rec)), "dva_plan_split_sort_records")
-        return rec
+                                                  ptr(self.tables), self.tables.numel(), ptr(buf),
+                                                  None if bucket_order else ptr(rec), stream_of(rec)),
+                  "dva_plan_split_sort_records")
+        return buf if bucket_order else rec
+
+    def rows_grad_fused(self, gout, rec, C, G, stream):
+        """bf16 [R, C] rows gradient from KEYED view-order records through pass A + the bucket kernel
+        (``dva_plan_split_rows_grad``: no pass B, no plan-order records), or None where that kernel does not apply."""
+        lib = _lib.load()
+        V, R = self.row_idx.shape[0], self.n_rows
+        if gout.dtype != torch.bfloat16 or C not in (32, 64) or G not in (1, 2, 4) or (C // 8) % G:
+            return None
+        g = torch.empty((R, C), dtype=torch.bfloat16, device=gout.device)
+        # probe with the cheap call first: the entry refuses what it does not implement before any launch
+        brec = self.sort_records(rec, keyed=True, bucket_order=True)
+        with _timed("view_gather_rows_grad", V * (16 + C * 2) + R * C * 2):
+            rc = lib.dva_plan_split_rows_grad(ptr(gout), ptr(brec), V, R, ptr(self.tables), self.tables.numel(), ptr(g),
+                                              C, G, _lib.DVA_BF16, _lib.DVA_BF16, stream)
+        if rc == -2:        # DVA_ERR_UNSUPPORTED (e.g. DVA_PLAN_TILE=4096)
+            return None
+        check(rc, "dva_plan_split_rows_grad")
+        return g
 
 
 def row_plan(row_idx, n_rows, with_counts=True, split=True):
@@ -687,6 +710,10 @@ def rows_grad_rec16(gout, plan, rec, R, C, G, out_dtype, stream):
     V = rec.shape[0]
     g = torch.empty((R, C), dtype=out_dtype, device=gout.device)
     if isinstance(plan, SplitPlan):
+        if SPLIT_FUSED and out_dtype == torch.bfloat16:
+            fused = plan.rows_grad_fused(gout, rec, C, G, stream)
+            if fused is not None:
+                return fused
         rec = plan.sort_records(rec, keyed=True)
         perm, row_ptr = None, plan.row_ptr
     else:

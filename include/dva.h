@@ -211,7 +211,7 @@ int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_
  * dva_row_plan's, and `tables` (dva_plan_split_table_bytes; kept by the caller until the backward); scratch: 2 n_views bytes,
  * free afterwards -- and whose two scatter passes move the 16-BYTE VIEW RECORDS of the attention backward themselves --
  * dva_plan_split_sort_records: rec [n_views][16] in view order -> rec_sorted in plan order (record i = plan entry i, views of
- * a row in view order, word 3 of a record = its row key), through buf [n_views][16]; rec_sorted may be rec; row_idx NULL: word 3
+ * a row in view order, word 3 of a record = its row key), through buf [n_views][16]; rec_sorted may be rec (or NULL: pass A only, see dva_plan_split_rows_grad); row_idx NULL: word 3
  * of the records already holds the row key (dva_chain_attn_bwd writes it there).  The rows gradient
  * (dva_view_gather_rows_grad_rec16* with perm = NULL) then streams its records: no permutation exists, no random 16-byte
  * fetch per view.  Replaces the index_add of core/multimodal/image.py:1262-1287's backward like dva_row_plan. */
@@ -221,6 +221,16 @@ int dva_plan_split_build(const int32_t* row_idx, int64_t n_views, int64_t n_rows
 int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t n_views, int64_t n_rows,
                                 const int32_t* row_ptr, const void* tables, int64_t tables_bytes, void* buf,
                                 void* rec_sorted, void* stream);
+/* The rows gradient straight from BUCKET-ordered records, without pass B: dva_plan_split_sort_records with rec_sorted =
+ * NULL runs pass A only (view order -> bucket order, into buf); then ONE workgroup per bucket of 512 map rows keeps their C
+ * fp32 sums in its registers, ranks and stages the bucket's tiles in LDS like pass B and consumes the staged records where
+ * they lie (the 16 bytes per view pass B writes and the rows gradient reads again never exist).  grad_rows [n_rows][C]
+ * bf16, written; deterministic; a row is summed by one lane team in view order (dva_view_gather_rows_grad_rec16* splits
+ * it over 8 lane slots: the two agree to fp32 rounding).  bf16 / bf16, C in {32, 64}, G in {1, 2, 4}; otherwise
+ * DVA_ERR_UNSUPPORTED (the caller runs pass B and dva_view_gather_rows_grad_rec16_to). */
+int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64_t n_views, int64_t n_rows,
+                             const void* tables, int64_t tables_bytes, void* grad_rows, int32_t C, int32_t G, int32_t dtype,
+                             int32_t out_dtype, void* stream);
 
 /* grad_rows[r, c] = sum over the views v of row r of grad_out[p(v), c] * gate[p(v), g(c)] *
  * att[v, g(c)]  (written, not accumulated; fp32 [n_rows, C]).  view_point int32 [n_views] = point of

@@ -390,6 +390,56 @@ def test_split_plan_equals_row_plan(V, R, how):
     assert torch.equal(plan.perm, perm) and torch.equal(plan[1], row_ptr)      # the lazy permutation of other callers
 
 
+@pytest.mark.parametrize("V,R,C,G,how", [(9000, 600, 64, 4, "uniform"), (300000, 5000, 32, 2, "uniform"),
+                                         (4300000, 1 << 18, 64, 4, "uniform"), (600000, 70000, 64, 1, "skewed"),
+                                         (100000, 2000, 32, 4, "one_row")])
+def test_bucket_rows_grad_equals_segmented_reduction(V, R, C, G, how):
+    """dva_plan_split_rows_grad (pass A + one workgroup per bucket, records consumed from LDS) against pass B + the
+    segmented reduction over plan-order records, and against an fp64 index_add of the same products."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(V + R + C)
+    N = max(V // 8, 4)
+    if how == "uniform":
+        row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    elif how == "one_row":
+        row_idx = torch.full((V,), R - 3, dtype=torch.int32)
+    else:
+        hot = torch.randint(0, R, (16,), generator=gen)
+        row_idx = torch.where(torch.rand(V, generator=gen) < 0.5, hot[torch.randint(0, 16, (V,), generator=gen)],
+                              torch.randint(0, R, (V,), generator=gen)).to(torch.int32)
+    point = torch.randint(0, N, (V,), generator=gen, dtype=torch.int32)
+    wts = torch.randn(V, 4, generator=gen).to(torch.bfloat16)
+    rec = torch.empty(V, 4, dtype=torch.int32)
+    rec[:, 0] = point
+    rec[:, 1:3] = wts.view(torch.int32)
+    rec[:, 3] = row_idx
+    gout = torch.randn(N, C, generator=gen).to(torch.bfloat16).to(DEV)
+    rd, recd = row_idx.to(DEV), rec.to(DEV)
+    old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED
+    try:
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = True, 0
+        plan = ops.row_plan(rd, R, with_counts=False)[0]
+        ops.SPLIT_FUSED = False
+        a = ops.rows_grad_rec16(gout, plan, recd.clone(), R, C, G, torch.bfloat16, torch.cuda.current_stream().cuda_stream)
+        ops.SPLIT_FUSED = True
+        b = ops.rows_grad_rec16(gout, plan, recd.clone(), R, C, G, torch.bfloat16, torch.cuda.current_stream().cuda_stream)
+        b2 = ops.rows_grad_rec16(gout, plan, recd.clone(), R, C, G, torch.bfloat16, torch.cuda.current_stream().cuda_stream)
+    finally:
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED = old
+    assert torch.equal(b, b2)                                       # deterministic
+    if V <= 600000:
+        ch_group = torch.arange(C) // (C // G)
+        prod = gout.cpu().double()[point.long()] * wts.double()[:, ch_group]
+        ref = torch.zeros(R, C, dtype=torch.float64).index_add_(0, row_idx.long(), prod)
+        scale = float(ref.abs().max()) + 1e-9
+        for got in (a, b):
+            assert float((got.cpu().double() - ref).abs().max()) <= scale * 2 ** -7
+    # the two device paths: same records, another order of the fp32 additions, one bf16 rounding each
+    d = (a.float() - b.float()).abs()
+    assert float(d.max()) <= float(a.float().abs().max()) * 2 ** -6
+    assert float((d > 0).float().mean()) < 0.2
+
+
 @pytest.mark.parametrize("C,G,gating", [(64, 4, True), (32, 2, False), (128, 1, True)])
 def test_rows_grad_split_plan_equals_permutation_plan(C, G, gating):
     """view_gather_attention (bf16, the lean backward) over the split plan = over the permutation plan, bit for bit
@@ -407,9 +457,9 @@ def test_rows_grad_split_plan_equals_permutation_plan(C, G, gating):
     gb = torch.randn(G, generator=gen) if gating else None
     w = torch.randn(N, C, generator=gen).to(DEV)
 
-    def run(split, with_plan):
-        old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS
-        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = split, 0
+    def run(split, with_plan, fused=False):
+        old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED = split, 0, fused
         try:
             plan = ops.row_plan(row_idx, R, with_counts=False)[0] if with_plan else None
             assert plan is None or isinstance(plan, ops.SplitPlan) == split
@@ -420,7 +470,7 @@ def test_rows_grad_split_plan_equals_permutation_plan(C, G, gating):
             out, _, _ = ops.view_gather_attention(rd, row_idx, cd, csr, gwd, gbd, plan=plan)
             return [out] + list(torch.autograd.grad((out.float() * w).sum(), [rd, cd]))
         finally:
-            ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = old
+            ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED = old
 
     a = run(False, True)
     for split, with_plan in ((True, True), (True, False)):
@@ -428,6 +478,18 @@ def test_rows_grad_split_plan_equals_permutation_plan(C, G, gating):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert float(a[1][R - 20:].abs().max()) == 0.0 and float(a[1].abs().max()) > 0.0
+    # the bucket kernel (no pass B; C <= 64): one lane team sums a row in view order -- same records, another order of the
+    # fp32 additions: the bf16 rows agree to one rounding, and the kernel is deterministic
+    f1, f2 = run(True, True, fused=True), run(True, False, fused=True)
+    for x, y in zip(f1, f2):
+        assert torch.equal(x, y)
+    assert torch.equal(f1[0], a[0]) and torch.equal(f1[2], a[2])
+    if C <= 64:
+        assert not torch.equal(f1[1], a[1]) or True      # (may or may not differ in the last bit)
+        close(f1[1].float(), a[1].float(), rtol=2 ** -7, atol=1e-3)
+        assert float(f1[1][R - 20:].abs().max()) == 0.0
+    else:
+        assert torch.equal(f1[1], a[1])                   # C = 128: the bucket kernel declines, pass B runs
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
