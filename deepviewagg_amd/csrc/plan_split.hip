@@ -346,14 +346,17 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
 // gathered U at a time.  Deterministic (a row is summed by one lane team in view order); the order differs from the
 // segmented reduction of attention.hip (which splits a row over 8 lane slots), so the two agree to fp32 rounding, not
 // bit for bit.  bf16 in, bf16 out, C in {32, 64}.
-template <int C>
+template <int C, int BT>
 __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __restrict__ rec, const bf16_t* __restrict__ gout,
                                                                 bf16_t* __restrict__ grows, int64_t n_rows, int G,
-                                                                const int32_t* __restrict__ tile_start,
-                                                                const int4* __restrict__ desc) {
-  constexpr int TILE = 8192, THREADS = 1024, WAVES = THREADS / 64;
-  constexpr int LPR = C / 8, GROUPS = THREADS / LPR, RPT = BINS / GROUPS, U = 8;
-  __shared__ uint4 s_stage[TILE];
+                                                                const int32_t* __restrict__ bucket_start) {
+  // BT = records ranked + staged at a time (the kernel's own tile: the bucket is one contiguous, view-ordered range).
+  // The 256 workgroups in flight walk their buckets side by side, so at any time they all gather grad_out rows of the
+  // same window of points -- BT / 65536 of them at the headline's bucket size: a smaller BT narrows the window towards
+  // what an L2 holds (and leaves LDS for nothing else: one workgroup per CU is set by the 128 registers anyway).
+  constexpr int THREADS = 1024, WAVES = THREADS / 64, IPB = BT / THREADS;
+  constexpr int LPR = C / 8, GROUPS = THREADS / LPR, RPT = BINS / GROUPS, U = BT >= 8192 ? 8 : 4;
+  __shared__ uint4 s_stage[BT];
   __shared__ uint16_t s_cnt[WAVES][BINS];
   __shared__ int s_lstart[BINS + 1];
   __shared__ int s_w[WAVES];
@@ -365,16 +368,14 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
   for (int rr = 0; rr < RPT; ++rr)
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[rr][k] = 0.f;
-  const int tb0 = tile_start[b], tb1 = tile_start[b + 1];
-  for (int tb = tb0; tb < tb1; ++tb) {
-    int bb, count;
-    int64_t start;
-    tile_b(desc, tb, bb, start, count);
-    uint32_t kk[IPT], p0[IPT], p1[IPT], p2[IPT];
-    bool ok[IPT];
+  const int64_t b0 = bucket_start[b], b1 = bucket_start[b + 1];
+  for (int64_t start = b0; start < b1; start += BT) {
+    const int count = (int)(b1 - start < BT ? b1 - start : BT);
+    uint32_t kk[IPB], p0[IPB], p1[IPB], p2[IPB];
+    bool ok[IPB];
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int idx = w * (64 * IPT) + i * 64 + lane;
+    for (int i = 0; i < IPB; ++i) {
+      const int idx = w * (64 * IPB) + i * 64 + lane;
       ok[i] = idx < count;
       const uint4 r = rec[start + (ok[i] ? idx : 0)];
       p0[i] = r.x, p1[i] = r.y, p2[i] = r.z, kk[i] = r.w;
@@ -385,9 +386,9 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
       for (int k = 0; k < WAVES * BINS / 2 / THREADS; ++k) z[k * THREADS + tid] = 0u;
     }
     __syncthreads();                       // (also: the previous tile's records are consumed)
-    int dg[IPT], rank[IPT];
+    int dg[IPB], rank[IPB];
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) {
+    for (int i = 0; i < IPB; ++i) {
       dg[i] = (int)(kk[i] & (BINS - 1));
       const uint64_t peers = match_digit(dg[i], ok[i]);
       const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
     if (tid == BINS - 1) s_lstart[BINS] = ls + run;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) {
+    for (int i = 0; i < IPB; ++i) {
       if (ok[i]) s_stage[s_lstart[dg[i]] + s_cnt[w][dg[i]] + rank[i]] = make_uint4(p0[i], p1[i], p2[i], kk[i]);
     }
     __syncthreads();
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
           const int64_t p = (int)rv[0];
           const uint32_t w2 = rv[1 + (gch >> 1)];
           sc[u] = in ? __uint_as_float((gch & 1) ? (w2 & 0xffff0000u) : (w2 << 16)) : 0.f;
-          raw[u] = *reinterpret_cast<const uint4*>(gout + p * C + cl * 8);
+          raw[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (in) raw[u] = *reinterpret_cast<const uint4*>(gout + p * C + cl * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -455,6 +457,18 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
       *reinterpret_cast<uint4*>(grows + r * C + cl * 8) = o;
     }
   }
+}
+
+template <int C>
+static void bucket_rows_grad(const uint4* rec, const bf16_t* gout, bf16_t* grows, int64_t n_rows, int G, int nb,
+                             const int32_t* bstart, hipStream_t s) {
+  static const int bt = tune_int("DVA_PLAN_BT", 8192);
+  if (bt == 2048)
+    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 2048>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart);
+  else if (bt == 4096)
+    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 4096>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart);
+  else
+    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 8192>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart);
 }
 
 }  // namespace ps
@@ -562,7 +576,7 @@ int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64
                              const void* tables, int64_t tables_bytes, void* grad_rows, int32_t C, int32_t G, int32_t dtype,
                              int32_t out_dtype, void* stream) {
   if (n_views < 0 || n_rows < 0 || C <= 0 || G <= 0) return DVA_ERR_INVALID;
-  if (!ps::eligible(n_views, n_rows) || ps::tile_size() != 8192 || dtype != DVA_BF16 || out_dtype != DVA_BF16 ||
+  if (!ps::eligible(n_views, n_rows) || dtype != DVA_BF16 || out_dtype != DVA_BF16 ||
       (C != 32 && C != 64) || (G != 1 && G != 2 && G != 4) || ((C / 8) % G) != 0)
     return DVA_ERR_UNSUPPORTED;
   if (!grad_out || !bucket_rec || !tables || !grad_rows) return DVA_ERR_INVALID;
@@ -573,11 +587,11 @@ int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64
   hipStream_t s = (hipStream_t)stream;
   const int nb = (int)L.nb;
   if (C == 64)
-    hipLaunchKernelGGL(ps::bucket_rows_grad_kernel<64>, dim3(nb), dim3(1024), 0, s, (const uint4*)bucket_rec,
-                       (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, T.tstart, T.desc);
+    ps::bucket_rows_grad<64>((const uint4*)bucket_rec, (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, nb,
+                             T.bstart, s);
   else
-    hipLaunchKernelGGL(ps::bucket_rows_grad_kernel<32>, dim3(nb), dim3(1024), 0, s, (const uint4*)bucket_rec,
-                       (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, T.tstart, T.desc);
+    ps::bucket_rows_grad<32>((const uint4*)bucket_rec, (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, nb,
+                             T.bstart, s);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
