@@ -149,15 +149,15 @@ KERNEL_SYMBOL = {
     "chain_stats5": "chain::stats_mid_kernel<5>",
     "chain_stats6": "chain::stats_mid_kernel<6>",
     "chain_moments": "chain::moments_kernel",
-    "view_gather_rows_grad": "rows_grad_team_kernel<unsigned short, true>",
+    "view_gather_rows_grad": "ps::bucket_rows_grad_kernel<64, 8192>",
 }
 # what bounds the kernel the roofline object is about (SQ counters: profiles/*sq_counters*)
 ROOFLINE_NOTES = {
-    "view_gather_rows_grad": "rows gradient = segmented reduction over the row plan (deterministic, no atomics); since "
-                             "round 5 its 16-byte view records arrive in plan order (split plan: the records themselves go "
-                             "through the two radix scatter passes, timer plan_sort_records), so per view it streams 16 bytes "
-                             "and fetches the 128-byte grad_out row of the point at a random address: bound by the fabric's "
-                             "rate for one random line per view",
+    "view_gather_rows_grad": "rows gradient (deterministic, no atomics); since round 5 the 16-byte view records go through "
+                             "pass A of the split plan (timer plan_sort_records) and ONE workgroup per bucket of 512 map rows "
+                             "keeps the rows' sums in registers and consumes the bucket's records from LDS: per view 16 "
+                             "streamed bytes and the 128-byte grad_out row of the point at a random address; bound by the "
+                             "fabric's rate for one random line per view",
     "chain_bwd_l5": "layer-5 backward pass of the recompute chain (x_map 32 + index 4 + gradient row in 64 + out 64 bytes per "
                     "view, per-point rows): 166 VGPRs -> 3 wavefronts per SIMD; the one chain pass whose PMC traffic equals "
                     "its algorithmic bytes and whose vector unit is only ~0.5 busy: HBM-bound at 3 wavefronts per SIMD",
