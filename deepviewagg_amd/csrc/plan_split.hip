@@ -1,17 +1,20 @@
-// Split row plan (round 5): the row plan of the rows gradient as a two-pass MSD radix partition whose OFFSETS are built
-// before the forward (from the row keys alone: per-row view counts and CSR pointers -- all the forward needs) and whose
-// two scatter passes run in the backward ON THE 16-BYTE VIEW RECORDS themselves.  The rows gradient then streams its
-// records in plan order instead of fetching one random 128-byte line per view for 16 bytes of payload (PMC: 4.3 GB of the
-// kernel's 9.0 GB), and no permutation is ever written or read.
+// Split row plan (round 5): the row plan of the rows gradient as a two-pass MSD radix partition (digits row >> 9 | row & 511)
+// whose OFFSETS are built before the forward -- from the row keys alone: per-row view counts and CSR pointers, all the
+// forward needs -- and whose passes run in the backward ON THE 16-BYTE VIEW RECORDS themselves.  No permutation is ever
+// written or read, and the rows gradient no longer fetches one random 128-byte line per view for 16 bytes of payload (PMC:
+// 4.3 GB of the 9.0 GB of the permutation form).
 //
 //   build (keys only):  hist_hi -> scan_tiles -> bucket_starts -> scatter<LOWS> (9-bit low digits, bucket order)
-//                       -> hist_lo -> scan_rows  => counts[R], row_ptr[R + 1], offA[tile][bucket], offB[tile][digit]
-//   sort  (records):    scatter<REC_A> (view order -> bucket order) -> scatter<REC_B> (bucket order -> plan order)
+//                       -> hist_lo -> scan_rows  => counts[R], row_ptr[R + 1], offA[bucket][tile], offB[tile][digit]
+//   records:            scatter<REC_A> (view order -> bucket order), then either
+//                         bucket_rows_grad (C <= 64): one workgroup per bucket of 512 rows ranks + stages the bucket's
+//                           records in LDS like a second pass and CONSUMES them there (sums in registers), or
+//                         scatter<REC_B> (bucket order -> plan order) + the segmented reduction of attention.hip (perm = NULL)
 //
-// Both passes are stable (wave-striped tiles, per-wavefront digit counters advanced in item order, match-any ranking),
-// so the views of a row stay in view order: the sums of the rows gradient are those of the permutation plan, bit for
-// bit.  A tile is 8192 entries of one workgroup (1024 threads x 8): with 512 buckets a tile leaves 16-entry = 256-byte
-// runs per bucket, staged through LDS (128 KB of the CU's 160) so that every run is written by consecutive lanes.
+// All passes are stable (wave-striped tiles, per-wavefront digit counters advanced in item order, match-any ranking), so
+// the views of a row stay in view order: deterministic sums (the REC_B form: those of the permutation plan, bit for bit).
+// A tile is 4096 entries of one workgroup (512 threads x 8): with 512 buckets a tile leaves 8-entry = 128-byte runs per
+// bucket, staged through LDS (64 KB; two workgroups per CU) so that every run is written by consecutive lanes.
 // Row keys: 512 < n_rows <= 2^18 (high digit = key >> 9 in at most 512 buckets); anything else keeps dva_row_plan.
 #include "dva_common.h"
 
@@ -23,10 +26,12 @@ constexpr int BINS = 512;
 constexpr int LO_BITS = 9;
 constexpr int HEAD_INTS = 2048;   // tot[512] | bucket_start[513] | tile_start[513] (padded)
 
-// DVA_PLAN_TILE = 8192 (default: 1024 threads, 148 KB of LDS, one workgroup per CU, 256-byte runs) or 4096 (512 threads,
-// 76 KB, two workgroups per CU, 128-byte runs); read once, build and sort of a plan must agree
+// DVA_PLAN_TILE = 4096 (default: 512 threads, 76 KB of LDS, two workgroups per CU whose load and write-out phases overlap,
+// 128-byte runs that the XCD-aware tile order below pairs up in one L2) or 8192 (1024 threads, 148 KB, one workgroup per
+// CU, 256-byte runs: pass A 0.29 against 0.23 ms, the build 0.24 against 0.26 ms; before the XCD-aware order the larger
+// tile was the faster one); read once, build and record passes of a plan must agree
 static inline int tile_size() {
-  static const int t = tune_int("DVA_PLAN_TILE", 8192) == 4096 ? 4096 : 8192;
+  static const int t = tune_int("DVA_PLAN_TILE", 4096) == 8192 ? 8192 : 4096;
   return t;
 }
 
