@@ -24,7 +24,7 @@ namespace ps {
 constexpr int IPT = 8;             // entries per thread: a tile of TILE entries is one workgroup of TILE / 8 threads
 constexpr int BINS = 512;
 constexpr int LO_BITS = 9;
-constexpr int HEAD_INTS = 2048;   // tot[512] | bucket_start[513] | tile_start[513] (padded)
+constexpr int HEAD_INTS = 4096;   // tot[512] | bucket_start[513] | tile_start[513] (padded) | order[512] at 2048
 
 // DVA_PLAN_TILE = 4096 (default: 512 threads, 76 KB of LDS, two workgroups per CU whose load and write-out phases overlap,
 // 128-byte runs that the XCD-aware tile order below pairs up in one L2) or 8192 (1024 threads, 148 KB, one workgroup per
@@ -37,7 +37,7 @@ static inline int tile_size() {
 
 struct Layout {
   int64_t nt, nb, ntb;
-  size_t off_tot, off_bstart, off_tstart, off_a, off_b, off_desc, total;
+  size_t off_tot, off_bstart, off_tstart, off_order, off_a, off_b, off_desc, total;
 };
 
 static inline bool eligible(int64_t n_views, int64_t n_rows) {
@@ -53,6 +53,7 @@ static inline Layout layout(int64_t n, int64_t n_rows) {
   L.off_tot = 0;
   L.off_bstart = 512 * 4;
   L.off_tstart = (512 + 520) * 4;
+  L.off_order = 2048 * 4;
   L.off_a = HEAD_INTS * 4;
   L.off_b = L.off_a + (size_t)L.nt * BINS * 4;
   L.off_desc = L.off_b + (size_t)L.ntb * BINS * 4;      // int4 {bucket, first entry, entries, 0} per B tile
@@ -130,10 +131,24 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t* __restrict__ o
 // descriptor {bucket, first entry, entries} of every B tile (one load per tile in the passes instead of a search)
 __global__ __launch_bounds__(BINS) void bucket_starts_kernel(const int32_t* __restrict__ tot, int nb, int TILE,
                                                              int32_t* __restrict__ bucket_start,
-                                                             int32_t* __restrict__ tile_start, int4* __restrict__ desc) {
+                                                             int32_t* __restrict__ tile_start, int4* __restrict__ desc,
+                                                             int32_t* __restrict__ order) {
   __shared__ int s_w[BINS / 64];
+  __shared__ int s_tot[BINS];
   const int d = threadIdx.x;
   const int v = d < nb ? tot[d] : 0;
+  // buckets by decreasing size (ties: by index): the bucket rows gradient hands its workgroups out largest first, so that
+  // a mapping whose views crowd into a few buckets does not leave one of them for the end
+  s_tot[d] = d < nb ? v : -1;
+  __syncthreads();
+  if (d < nb) {
+    int before = 0;
+    for (int j = 0; j < nb; ++j) {
+      const int t = s_tot[j];
+      before += (t > v || (t == v && j < d)) ? 1 : 0;
+    }
+    order[before] = d;
+  }
   int all;
   const int bs = block_excl_scan<BINS>(v, s_w, &all);
   bucket_start[d] = bs;
@@ -354,7 +369,8 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
 template <int C, int BT>
 __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __restrict__ rec, const bf16_t* __restrict__ gout,
                                                                 bf16_t* __restrict__ grows, int64_t n_rows, int G,
-                                                                const int32_t* __restrict__ bucket_start) {
+                                                                const int32_t* __restrict__ bucket_start,
+                                                                const int32_t* __restrict__ order) {
   // BT = records ranked + staged at a time (the kernel's own tile: the bucket is one contiguous, view-ordered range).
   // The 256 workgroups in flight walk their buckets side by side, so at any time they all gather grad_out rows of the
   // same window of points -- BT / 65536 of them at the headline's bucket size: a smaller BT narrows the window towards
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
   __shared__ int s_lstart[BINS + 1];
   __shared__ int s_w[WAVES];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = order[blockIdx.x];          // largest bucket first
   const int grp = tid / LPR, cl = tid % LPR, gch = cl / (LPR / G);
   float acc[RPT][8];
 #pragma unroll
@@ -466,14 +482,14 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
 
 template <int C>
 static void bucket_rows_grad(const uint4* rec, const bf16_t* gout, bf16_t* grows, int64_t n_rows, int G, int nb,
-                             const int32_t* bstart, hipStream_t s) {
+                             const int32_t* bstart, const int32_t* order, hipStream_t s) {
   static const int bt = tune_int("DVA_PLAN_BT", 8192);
   if (bt == 2048)
-    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 2048>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart);
+    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 2048>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart, order);
   else if (bt == 4096)
-    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 4096>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart);
+    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 4096>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart, order);
   else
-    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 8192>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart);
+    hipLaunchKernelGGL((bucket_rows_grad_kernel<C, 8192>), dim3(nb), dim3(1024), 0, s, rec, gout, grows, n_rows, G, bstart, order);
 }
 
 }  // namespace ps
@@ -482,13 +498,13 @@ static void bucket_rows_grad(const uint4* rec, const bf16_t* gout, bf16_t* grows
 namespace dva {
 namespace ps {
 struct Tables {
-  int32_t *tot, *bstart, *tstart, *offA, *offB;
+  int32_t *tot, *bstart, *tstart, *order, *offA, *offB;
   int4* desc;
 };
 static inline Tables tables_of(void* tables, const Layout& L) {
   char* tb = (char*)tables;
   return {(int32_t*)(tb + L.off_tot), (int32_t*)(tb + L.off_bstart), (int32_t*)(tb + L.off_tstart),
-          (int32_t*)(tb + L.off_a), (int32_t*)(tb + L.off_b), (int4*)(tb + L.off_desc)};
+          (int32_t*)(tb + L.off_order), (int32_t*)(tb + L.off_a), (int32_t*)(tb + L.off_b), (int4*)(tb + L.off_desc)};
 }
 
 // grid of a scatter pass: its tiles rounded up to a multiple of 8 for the XCD-aware order (the extra workgroups exit);
@@ -506,7 +522,7 @@ static void build(const uint32_t* keys, int64_t n, int64_t n_rows, int32_t* row_
   const int nb = (int)L.nb;
   hipLaunchKernelGGL(hist_hi_kernel<TILE>, dim3((unsigned)L.nt), dim3(THREADS), 0, s, keys, n, nb, L.nt, T.offA);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(nb), dim3(256), 0, s, T.offA, L.nt, T.tot);
-  hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(BINS), 0, s, T.tot, nb, TILE, T.bstart, T.tstart, T.desc);
+  hipLaunchKernelGGL(bucket_starts_kernel, dim3(1), dim3(BINS), 0, s, T.tot, nb, TILE, T.bstart, T.tstart, T.desc, T.order);
   hipLaunchKernelGGL((scatter_kernel<MODE_LOWS, TILE>), dim3(scatter_grid(L.nt)), dim3(THREADS), 0, s, keys,
                      (const uint4*)nullptr, scratch, n, nb, n_rows, L.nt, T.bstart, T.tstart, T.desc, T.offA,
                      (const int32_t*)nullptr, (int)xcd_on());
@@ -593,10 +609,10 @@ int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64
   const int nb = (int)L.nb;
   if (C == 64)
     ps::bucket_rows_grad<64>((const uint4*)bucket_rec, (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, nb,
-                             T.bstart, s);
+                             T.bstart, T.order, s);
   else
     ps::bucket_rows_grad<32>((const uint4*)bucket_rec, (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, nb,
-                             T.bstart, s);
+                             T.bstart, T.order, s);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }
