@@ -593,12 +593,20 @@ def gather_bilinear(x, packed_idx, coords):
 # lazy view gather + fused gather-attention  (DESIGN.md "E_mod hoisting")
 # ---------------------------------------------------------------------------------------------
 
-# The split plan (round 5, csrc/plan_split.hip): from 4 M views on (and 512 < rows <= 2^18) ``row_plan`` builds only the
+# The split plan (round 5, csrc/plan_split.hip): from 1 - 2 M views on (and 512 < rows <= 2^18) ``row_plan`` builds only the
 # offset tables of a two-pass radix partition -- row_ptr and counts come out of them -- and the backward runs the two
 # scatter passes on the 16-byte view records themselves, so the rows gradient streams its records in plan order.
 # DVA_SPLIT_PLAN=0: the permutation plan everywhere (the A/B).
 SPLIT_PLAN = os.environ.get("DVA_SPLIT_PLAN", "1") == "1"
-SPLIT_PLAN_MIN_VIEWS = 1 << 22
+# measured crossover (tools/split_threshold.py, profiles/r05_split_threshold.json: plan + rows gradient at C = 64): the split
+# form wins from 2 M views on for any row count (0.13 against 0.17 - 0.23 ms) and from 1 M views on maps of >= 2^17 rows
+# (0.10 against 0.19 ms); at 0.5 M views its eight launches cost what the records' lines do
+SPLIT_PLAN_MIN_VIEWS = 1 << 20
+
+
+def _split_plan_pays(n_views, n_rows):
+    return n_views >= SPLIT_PLAN_MIN_VIEWS and (n_views >= 2 * SPLIT_PLAN_MIN_VIEWS or n_rows >= (1 << 17))
+
 # DVA_SPLIT_FUSED=0: pass B + the segmented reduction of attention.hip instead of the bucket kernel (the A/B; also the
 # form whose sums equal the permutation plan's bit for bit)
 SPLIT_FUSED = os.environ.get("DVA_SPLIT_FUSED", "1") == "1"
@@ -689,7 +697,7 @@ def row_plan(row_idx, n_rows, with_counts=True, split=True):
     lib = _lib.load()
     require_device(row_idx)
     V, dev = row_idx.shape[0], row_idx.device
-    if split and SPLIT_PLAN and V >= SPLIT_PLAN_MIN_VIEWS and row_idx.is_contiguous():
+    if split and SPLIT_PLAN and _split_plan_pays(V, n_rows) and row_idx.is_contiguous():
         nbytes = int(lib.dva_plan_split_table_bytes(V, n_rows))
         if nbytes > 0:
             row_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
