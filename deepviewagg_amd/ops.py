@@ -629,7 +629,9 @@ def _legacy_row_plan(row_idx, n_rows, with_counts):
 
 
 class SplitPlan:
-    """A row plan without its permutation: ``row_ptr`` and the offset tables of the two scatter passes
+    """The backward of the row gather (reference ``core/multimodal/image.py:1262-1287``: ``x[idx]`` in the forward, an
+    ``index_add`` of the views' gradients in the backward) for large mappings.
+    A row plan without its permutation: ``row_ptr`` and the offset tables of the two scatter passes
     (``dva_plan_split_build``).  ``sort_records`` brings the 16-byte view records of a backward into plan order;
     callers that want ``(perm, row_ptr)`` (unpacking, ``plan[0]``) get the permutation from ``dva_row_plan`` on first
     use -- correct, but it pays the sort the split plan exists to avoid."""
