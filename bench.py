@@ -13,10 +13,11 @@ The 2D encoder and the 3D backbone are outside the path.
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  Every rank owns
 its own scene (tile) -> weak scaling (--strong: one 2^20-point scene cut into N slabs); the collectives are the
 all-reduce of the pooling module's parameter gradients and of a stand-in 112 MB fp32 bucket (--standin-mb: the rest of
-the model's gradients), both on a side stream under the backward.  Rank 0 prints ONE JSON line:
-the contract fields + `roofline` (dominant kernel), `roofline_view_gather_attention` (the fused kernel the north star
-names), `cpu_baseline` (PyTorch-CPU oracle of the whole path + the C/OpenMP twin of gather + attention), `workloads`
-(S2 ragged, F-L C = 512), `mapping_build`, `gather`, per-kernel HIP-event timings.
+the model's gradients), both on a side stream under the backward.  Rank 0 prints ONE compact JSON line
+(< 4 KB; the driver keeps an 8 KB tail of stdout): the contract fields + `roofline` (dominant kernel),
+`roofline_view_gather_attention` (the fused kernel the north star names), `cpu_baseline` (C + OpenMP twin of the whole
+step), one ms figure per secondary workload and the top-8 kernels.  The full record (`workloads`, every kernel,
+`mapping_build`, `gather`, per-step arrays, notes) goes to `bench_detail.json` (`compact_line` / `emit`).
 """
 import argparse
 import json
@@ -68,6 +69,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help=argparse.SUPPRESS)   # launcher + process group + rank/device census only, no HIP work
     ap.add_argument("--no-standin", action="store_true", help="N > 1: no stand-in bucket (same as --standin-mb 0)")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the full record goes (default: bench_detail.json in the repo root and in gpurun_out/)")
     ap.add_argument("--workload", default="S1", choices=["S1", "S2", "S1c"],
                     help="S1: every point seen by --views images (headline); S2: ragged view counts "
                          "min(views, 1 + Geom(0.2)), 10 %% of the points unseen (SURVEY.md 8(d))")
@@ -360,7 +363,9 @@ def cpu_full_path_twin(log2_points, views, C, G=4):
         one()
     dt = (time.perf_counter() - t0) / reps
     return dict(value=n / dt, unit="points/s", cores=DS.num_threads(), kind="port",
-                sample=f"oracle/deepset_oracle.c + oracle/attention_oracle.c (C + OpenMP, fp32, {DS.num_threads()} threads): "
+                sample=f"whole step fwd+bwd, C+OpenMP fp32 twin (oracle/deepset_oracle.c + attention_oracle.c), S1 shapes "
+                       f"N=2^{log2_points} x {views} views, C={C}, {reps} step(s) after 1 warm-up, {dt:.2f} s/step",
+                sample_long=f"oracle/deepset_oracle.c + oracle/attention_oracle.c (C + OpenMP, fp32, {DS.num_threads()} threads): "
                        f"E_mod on the {R} map rows -> DeepSetFeat + E_score (train-mode BatchNorm) -> view gather + attention "
                        f"-> fusion concat, forward + backward with every parameter gradient, S1 shapes at N=2^{log2_points} "
                        f"points x {views} views (V={V}), C={C}, G={G}, {reps} timed step(s) after one warm-up, "
@@ -900,6 +905,106 @@ def rank_census(world, rank, local_rank, device, backend):
     return ranks_devices
 
 
+DETAIL_FILE = "bench_detail.json"
+LINE_HARD_CAP = 8192      # the driver keeps an 8 KB tail of stdout: a longer line cannot be parsed (BENCH_r05: parsed = null)
+LINE_TARGET = 4096
+
+
+def _sig(v, digits=5):
+    """Floats at `digits` significant digits (a measurement record, not a dump of doubles)."""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return v
+
+
+def _clip(s, n):
+    return s if s is None or len(s) <= n else s[: n - 3] + "..."
+
+
+def _roofline_compact(r):
+    if not r:
+        return None
+    keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
+            "algorithmic_bytes_per_launch", "frac_of_copy_ceiling")
+    out = {k: r[k] for k in keys if k in r}
+    if "traffic_source" in r:
+        out["traffic_source"] = _clip(r["traffic_source"], 120)
+    return out
+
+
+def _workload_ms(w):
+    for k in ("ms_per_step", "ms_all_levels", "ms_per_step_eager"):
+        if isinstance(w, dict) and k in w:
+            v = w[k]
+            return v.get("lazy") if isinstance(v, dict) else v
+    return None
+
+
+def compact_line(res, detail_file=DETAIL_FILE):
+    """The ONE stdout line: the contract fields, the two roofline objects, cpu_baseline and one number per secondary
+    measurement.  Everything else (`workloads`, the full per-kernel table, per-step arrays, mapping build detail, prose
+    notes) lives in `detail_file`.  tests/test_bench_line.py holds the size cap."""
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+    line = {k: res.get(k) for k in contract}
+    cfg = dict(res.get("config") or {})
+    cfg["workload"] = _clip(cfg.get("workload"), 420)
+    ga = cfg.get("gradient_allreduce")
+    if ga:
+        cfg["gradient_allreduce"] = {k: v for k, v in ga.items() if k != "note"}
+    line["config"] = cfg
+    line["roofline"] = _roofline_compact(res.get("roofline"))
+    line["roofline_view_gather_attention"] = _roofline_compact(res.get("roofline_view_gather_attention"))
+    cb = res.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = ({"error": _clip(cb["error"], 200)} if "error" in cb else
+                                {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                 "kind": cb.get("kind"), "sample": _clip(cb.get("sample"), 200)})
+    for k in ("gather_GBps", "hbm_copy_GBps", "per_step_ms_device_median", "host_enqueue_ms_per_step_median",
+              "step_algorithmic_GB", "step_algorithmic_GBps", "allreduce_ms", "exposed_ms"):
+        if res.get(k) is not None:
+            line[k] = res[k]
+    kern = res.get("kernels") or {}
+    top = sorted(kern.items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1].get("launches_per_step", 1))[:8]
+    line["kernels_ms_per_step"] = {n: v["avg_ms"] * v.get("launches_per_step", 1) for n, v in top}
+    if res.get("workloads"):
+        line["workloads_ms"] = {n: _workload_ms(w) for n, w in res["workloads"].items()}
+    mb = res.get("mapping_build")
+    if mb and "images_per_s" in mb:
+        line["mapping_build_images_per_s"] = mb["images_per_s"]
+    col = res.get("collective")
+    if col:
+        line["collective"] = {k: col[k] for k in ("per_rank_ms_per_step", "ranks_devices") if k in col}
+    line["detail_file"] = detail_file
+    line = _sig(line)
+    # the cap is a property of the record, not of luck: optional keys go first if a future field overgrows it
+    for k in ("collective", "workloads_ms", "kernels_ms_per_step", "host_enqueue_ms_per_step_median",
+              "step_algorithmic_GBps"):
+        if len(json.dumps(line)) < LINE_TARGET + 2048:
+            break
+        line.pop(k, None)
+    assert len(json.dumps(line)) < LINE_HARD_CAP, "bench line over the driver's 8 KB stdout tail"
+    return line
+
+
+def emit(res, json_fd, detail_file=None):
+    """Full record -> bench_detail.json (repo root, and gpurun_out/ when it exists so that it travels back from the GPU
+    box; or --detail-file); compact record -> the one stdout line."""
+    paths = [detail_file] if detail_file else [os.path.join(d, DETAIL_FILE) for d in (ROOT, os.path.join(ROOT, "gpurun_out"))
+                                               if os.path.isdir(d)]
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(res, f)
+        except OSError as e:
+            print(f"bench.py: could not write {p}: {e}", file=sys.stderr)
+    os.write(json_fd, (json.dumps(compact_line(res, os.path.basename(paths[0]) if paths else DETAIL_FILE)) + "\n").encode())
+
+
 def dry_run(args, world, rank, local_rank, json_fd):
     """Hidden `--dry-run` (tests/test_bench_launcher.py): everything bench.py does to become N ranks -- launcher,
     rendezvous, process group, rank / device census, the gradient bucket's all-reduce, max-over-ranks timing -- with
@@ -1209,7 +1314,7 @@ def main():
             except OSError as e:         # the oracle library is built by __graft_entry__.build()
                 res["cpu_baseline"] = {"error": str(e)}
             res["cpu_baseline"]["pytorch_oracle"] = cpu_baseline(args.cpu_log2_points, views, C, threads)
-        os.write(json_fd, (json.dumps(res) + "\n").encode())
+        emit(res, json_fd, args.detail_file)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,13 +25,13 @@ done
 python profiles/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
 python tools/pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1) > $OUT/sq_counters.txt 2>&1
 cp $OUT/pmc_traffic.json $ROOT/profiles/pmc_traffic_latest.json
-( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
+( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file $OUT/bench.detail.json > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
 python tools/show_bench.py $OUT/bench.json | head -3
 HEAD="--steps 20 --warmup 5 --no-cpu-baseline --no-mapping-build --no-secondary"
-timeout 600 python bench.py --gpus 1 $HEAD > $OUT/bench_plain.json 2> /dev/null
+timeout 600 python bench.py --gpus 1 $HEAD --detail-file $OUT/bench_plain.detail.json > $OUT/bench_plain.json 2> /dev/null
 for V in "" "--no-standin"; do
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
-      bench.py --gpus 1 $HEAD $V > $OUT/bench_torchrun1$(echo $V | tr -d ' ' | tr - _).json 2> $OUT/bench_torchrun1.err
+      bench.py --gpus 1 $HEAD $V --detail-file $OUT/bench_torchrun1$(echo $V | tr -d ' ' | tr - _).detail.json > $OUT/bench_torchrun1$(echo $V | tr -d ' ' | tr - _).json 2> $OUT/bench_torchrun1.err
 done
 python - <<PY
 import json
@@ -45,7 +45,7 @@ PY
 timeout 300 python bench.py --gpus 2 --steps 1 --warmup 0 > $OUT/bench_gpus2.out 2> $OUT/bench_gpus2.err; echo "bench.py --gpus 2 on this box: rc=$?" | tee $OUT/bench_gpus2.rc
 grep -E "launching 2 ranks|has no HIP device" $OUT/bench_gpus2.err | head -3 | tee -a $OUT/bench_gpus2.rc
 # A/B on the same box: the permutation plan (rounds 1-4) against the split plan
-timeout 600 env DVA_SPLIT_PLAN=0 python bench.py --gpus 1 $HEAD > $OUT/bench_plain_permutation_plan.json 2> /dev/null
+timeout 600 env DVA_SPLIT_PLAN=0 python bench.py --gpus 1 $HEAD --detail-file $OUT/bench_plain_permutation_plan.detail.json > $OUT/bench_plain_permutation_plan.json 2> /dev/null
 python tools/show_bench.py $OUT/bench_plain_permutation_plan.json | head -1
 # keep the merged output small: raw traces are large
 rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq

@@ -33,20 +33,20 @@ for JOB in "$@"; do
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     bench)
-      ( time timeout 1200 python bench.py $REST > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
+      ( time timeout 1200 python bench.py $REST --detail-file $OUT/bench.detail.json > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
       python tools/show_bench.py $OUT/bench.json | head -4 ;;
     headline)
       NAME=headline_$(echo "${REST:-base}" | tr -c 'A-Za-z0-9_=\n' '_')
-      env $(envs "$REST") timeout 600 python bench.py $HEAD > $OUT/$NAME.json 2> $OUT/$NAME.err
+      env $(envs "$REST") timeout 600 python bench.py $HEAD --detail-file $OUT/$NAME.detail.json > $OUT/$NAME.json 2> $OUT/$NAME.err
       python tools/show_bench.py $OUT/$NAME.json | head -2 ;;
     torchrun1)
       NAME=torchrun1_$(echo "${REST:-base}" | tr -c 'A-Za-z0-9_=\n' '_')
       timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
-          --master-port 29517 bench.py --gpus 1 $HEAD $REST > $OUT/$NAME.json 2> $OUT/$NAME.err
+          --master-port 29517 bench.py --gpus 1 $HEAD $REST --detail-file $OUT/$NAME.detail.json > $OUT/$NAME.json 2> $OUT/$NAME.err
       python tools/show_bench.py $OUT/$NAME.json | head -1 ;;
     prof)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- \
-          python $ROOT/bench.py --no-secondary --no-cpu-baseline --no-mapping-build $REST > $OUT/bench_prof.json 2> $OUT/prof.err)
+          python $ROOT/bench.py --no-secondary --no-cpu-baseline --no-mapping-build $REST --detail-file $OUT/bench_prof.detail.json > $OUT/bench_prof.json 2> $OUT/prof.err)
       find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; ; rm -rf $OUT/prof
       head -14 $OUT/kernel_stats.csv | cut -c1-150 ;;
     workload)
