@@ -126,7 +126,13 @@ def _zero_piece(key, step, nbytes, shape, dtype, device):
         _ZERO_POOLS[key] = pool
     off = pool[1]
     pool[1] = off + step
-    return pool[0][off:off + nbytes].view(dtype).view(shape)
+    # NOT a view of the pool tensor: views share the base's autograd version counter, so an in-place update of one piece
+    # (AccumulateGrad's `grad += new` on a parameter gradient that lives in a piece) would invalidate every other piece
+    # saved for backward ("modified by an inplace operation").  A fresh tensor set_ onto the pool's storage
+    # has its own counter; `off` is a multiple of 256 bytes, so it is a whole number of elements of any dtype.
+    piece = torch.empty(0, dtype=dtype, device=device)
+    size = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+    return piece.set_(pool[0].untyped_storage(), off // piece.element_size(), size)
 
 
 def _timed(name, nbytes):
@@ -640,9 +646,18 @@ class SplitPlan:
         self.row_idx, self.n_rows, self.row_ptr, self.tables = row_idx, int(n_rows), row_ptr, tables
         self._perm = None
 
+    LAZY_PERMS = 0      # how often a consumer asked a split plan for its permutation (each one = a full dva_row_plan sort)
+
     @property
     def perm(self):
         if self._perm is None:
+            if SplitPlan.LAZY_PERMS == 0:
+                import warnings
+                warnings.warn("SplitPlan.perm: a consumer wants (perm, row_ptr) from a split plan -- the permutation is "
+                              "being built by a full dva_row_plan sort on top of the split build (correct, but slower "
+                              "than asking row_plan(..., split=False) up front); counted in ops.SplitPlan.LAZY_PERMS",
+                              RuntimeWarning, stacklevel=3)
+            SplitPlan.LAZY_PERMS += 1
             self._perm = _legacy_row_plan(self.row_idx, self.n_rows, False)[0][0]
         return self._perm
 
@@ -677,17 +692,16 @@ class SplitPlan:
         (``dva_plan_split_rows_grad``: no pass B, no plan-order records), or None where that kernel does not apply."""
         lib = _lib.load()
         V, R = self.row_idx.shape[0], self.n_rows
-        if gout.dtype != torch.bfloat16 or C not in (32, 64) or G not in (1, 2, 4) or (C // 8) % G:
+        # everything dva_plan_split_rows_grad refuses (DVA_ERR_UNSUPPORTED: dtype, C, G, 16-byte alignment of the
+        # gradient rows; the records and the output are fresh allocations) is decided here, BEFORE pass A is launched
+        if (gout.dtype != torch.bfloat16 or C not in (32, 64) or G not in (1, 2, 4) or (C // 8) % G
+                or gout.data_ptr() % 16 or not gout.is_contiguous()):
             return None
-        g = torch.empty((R, C), dtype=torch.bfloat16, device=gout.device)
-        # probe with the cheap call first: the entry refuses what it does not implement before any launch
         brec = self.sort_records(rec, keyed=True, bucket_order=True)
+        g = torch.empty((R, C), dtype=torch.bfloat16, device=gout.device)
         with _timed("view_gather_rows_grad", V * (16 + C * 2) + R * C * 2):
-            rc = lib.dva_plan_split_rows_grad(ptr(gout), ptr(brec), V, R, ptr(self.tables), self.tables.numel(), ptr(g),
-                                              C, G, _lib.DVA_BF16, _lib.DVA_BF16, stream)
-        if rc == -2:        # DVA_ERR_UNSUPPORTED (e.g. DVA_PLAN_TILE=4096)
-            return None
-        check(rc, "dva_plan_split_rows_grad")
+            check(lib.dva_plan_split_rows_grad(ptr(gout), ptr(brec), V, R, ptr(self.tables), self.tables.numel(), ptr(g),
+                                               C, G, _lib.DVA_BF16, _lib.DVA_BF16, stream), "dva_plan_split_rows_grad")
         return g
 
 
@@ -718,7 +732,6 @@ def rows_grad_rec16(gout, plan, rec, R, C, G, out_dtype, stream):
     over the permutation plan, or -- ``SplitPlan`` -- after the records themselves went through the plan's two passes."""
     lib = _lib.load()
     V = rec.shape[0]
-    g = torch.empty((R, C), dtype=out_dtype, device=gout.device)
     if isinstance(plan, SplitPlan):
         if SPLIT_FUSED and out_dtype == torch.bfloat16:
             fused = plan.rows_grad_fused(gout, rec, C, G, stream)
@@ -728,6 +741,7 @@ def rows_grad_rec16(gout, plan, rec, R, C, G, out_dtype, stream):
         perm, row_ptr = None, plan.row_ptr
     else:
         perm, row_ptr = plan
+    g = torch.empty((R, C), dtype=out_dtype, device=gout.device)
     with _timed("view_gather_rows_grad", V * ((4 if perm is not None else 0) + 16 + C * 2) + R * (C * 2 + 4)):
         check(lib.dva_view_gather_rows_grad_rec16_to(ptr(gout), ptr(perm), ptr(row_ptr), ptr(rec), ptr(g), dtype_code(g),
                                                      R, V, C, G, _lib.DVA_BF16, stream),

@@ -19,6 +19,46 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
+@pytest.fixture(params=["permutation_plan", "split_plan"])
+def plan_kind(request):
+    """The whole-chain oracle tests run twice: over the permutation plan + `rows_grad_team_kernel`
+    (what V < ops.SPLIT_PLAN_MIN_VIEWS = 2^20 selects by itself) and -- threshold forced to 0 -- over the split plan +
+    `bucket_rows_grad_kernel` / the two record passes, the code path the 33.5 M-view headline runs.  Yields a call
+    counter; `check_plan_kind` asserts that the split path really was the one that ran."""
+    from deepviewagg_amd import ops
+    calls = {"kind": request.param, "fused": 0, "sorted": 0}
+    if request.param == "permutation_plan":
+        yield calls
+        return
+    old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED
+    orig_fused, orig_sort = ops.SplitPlan.rows_grad_fused, ops.SplitPlan.sort_records
+
+    def fused(self, *a, **k):
+        r = orig_fused(self, *a, **k)
+        calls["fused"] += r is not None
+        return r
+
+    def sort(self, *a, **k):
+        calls["sorted"] += 1
+        return orig_sort(self, *a, **k)
+    ops.SplitPlan.rows_grad_fused, ops.SplitPlan.sort_records = fused, sort
+    ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED = True, 0, True
+    try:
+        yield calls
+    finally:
+        ops.SplitPlan.rows_grad_fused, ops.SplitPlan.sort_records = orig_fused, orig_sort
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS, ops.SPLIT_FUSED = old
+
+
+def check_plan_kind(calls, C):
+    if calls["kind"] == "split_plan":
+        assert calls["sorted"] >= 1, "the split plan's record pass did not run"
+        if C in (32, 64):
+            assert calls["fused"] >= 1, "bucket_rows_grad_kernel did not run"       # the headline's rows-gradient kernel
+    else:
+        assert calls["sorted"] == 0 and calls["fused"] == 0
+
+
 def make_case(seed, N, C, sizes_fn, B=3, H=12, W=20):
     gen = torch.Generator().manual_seed(seed)
     sizes = sizes_fn(N, gen)
@@ -183,7 +223,7 @@ def _oracle_grads(case, ref, autocast):
     (ragged, 3000, 128, 4, True, True),
     (ragged_long, 700, 512, 4, True, True),
 ])
-def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
+def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating, plan_kind):
     """Gradients w.r.t. the feature maps and every parameter against the fp32 oracle; yardstick = the error of
     the reference maths itself under torch.autocast(bfloat16): per tensor, relative L2 error
     <= max(2 x reference-autocast error, 5e-2) (4 x for the gate / score parameters; for the encoder's parameters the
@@ -195,6 +235,7 @@ def test_chain_backward_matches_oracle(sizes_fn, N, C, G, train, gating):
     ref.load_state_dict(sd)
     _, g_amp = _oracle_grads(case, ref, autocast=True)
     out, g = run_dev(case, m, chain=True)
+    check_plan_kind(plan_kind, C)
     ref.load_state_dict(sd)
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
         out_amp = ref(None, O.gather_nearest(case["x"], case["images"], case["pixels"]), case["x_map"], case["csr"])
@@ -323,7 +364,7 @@ from oracle.chain_emulation import emulated_chain, _bf      # noqa: E402  (the b
     (ragged_long, 700, 512, 4, True, True, True),
     (ragged_long, 900, 256, 2, False, True, True),
 ])
-def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling):
+def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling, plan_kind):
     from deepviewagg_amd import ops, fused_chain
     case = make_case(13, N, C, sizes_fn)
     gen = case["gen"]
@@ -369,6 +410,7 @@ def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling)
     sens_out = rel(out_ref, out_fp.detach())
     dev_params = [p for n, p in m.named_parameters() if not n.startswith("E_mod")]
     g = torch.autograd.grad((out.float() * case["w"].to(DEV)).sum(), [rows_d] + dev_params, allow_unused=True)
+    check_plan_kind(plan_kind, C)
     r_out, r_sc = rel(out, out_plain), rel(dev_scores, sc_own)
     report = [("out", round(r_out, 5)), ("scores", round(r_sc, 5))]
     bad, par = [], []
@@ -439,7 +481,7 @@ def test_chain_matches_bf16_emulation(sizes_fn, N, C, G, train, gating, scaling)
 # chain runs in bf16 on values that lie on the bf16 grid; yardstick = the oracle under torch.autocast(bfloat16).
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["pool_group_c64_train", "pool_group_c64_eval"])
-def test_chain_against_reference_fixture(name):
+def test_chain_against_reference_fixture(name, plan_kind):
     import ast
     from conftest import load_golden, t, state_dict_from
     from deepviewagg_amd import ops
@@ -460,6 +502,7 @@ def test_chain_against_reference_fixture(name):
         out = m(None, gf, x_map.to(DEV), csr.to(DEV))
     assert out.dtype == torch.bfloat16, "the recompute chain must be the path that ran"
     grads = torch.autograd.grad((out.float() * w.to(DEV)).sum(), [rows] + list(m.parameters()), allow_unused=True)
+    check_plan_kind(plan_kind, rows.shape[1])
     # yardstick: the oracle under autocast against the same fixture
     ref = O.GroupBimodalCSRPool(**kwargs)
     ref.load_state_dict(state_dict_from(g), strict=True)
@@ -496,3 +539,46 @@ def test_chain_against_reference_fixture(name):
         for k, v in m.state_dict().items():
             if "running" in k:
                 torch.testing.assert_close(v.cpu(), t(g["sd_after/" + k]), rtol=2e-2, atol=2e-3)
+
+
+def test_two_fused_pool_nodes_two_backwards_without_zero_grad():
+    """the small zero-filled accumulators of a step are pieces of one pool (ops.zeros_small); pieces
+    are saved for backward (BatchNorm moments) and returned as parameter gradients.  As views of the pool tensor they
+    shared ONE autograd version counter: AccumulateGrad's in-place `grad += new` after the first fused node (second
+    backward, .grad already defined) invalidated the saved pieces of the next node in the same graph ("modified by an
+    inplace operation").  Two fused pooling nodes in one graph, two backward passes, no zero_grad in between."""
+    from deepviewagg_amd import ops, fused_chain
+    from deepviewagg_amd.modules.multimodal import pooling as P
+    case = make_case(17, 2500, 64, ragged)
+    _, m = build(case, 4, True)
+    V = case["V"]
+    xd = case["x"].to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    packed = ops.pack_gather_index(case["images"].to(DEV), torch.arange(V + 1, device=DEV), case["pixels"].to(DEV))
+    x_map2 = torch.rand(V, 8, generator=case["gen"]).to(DEV)
+    fused_chain.FORCE = True
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lazy = ops.lazy_gather_nearest(xd, packed, exact=True)
+            lazy = P.BimodalCSRPool(mode='max')(None, lazy, None, torch.arange(V + 1, device=DEV))
+            out1 = m(None, lazy, case["x_map"].to(DEV), case["csr"].to(DEV))
+            out2 = m(None, lazy, x_map2, case["csr"].to(DEV))
+        loss = ((out1.float() + 0.5 * out2.float()) * case["w"].to(DEV)).sum()
+        loss.backward(retain_graph=True)
+        first = [p.grad.clone() for p in m.parameters() if p.grad is not None] + [xd.grad.clone()]
+        loss.backward()                                  # .grad defined: AccumulateGrad adds in place
+    finally:
+        fused_chain.FORCE = None
+    second = [p.grad for p in m.parameters() if p.grad is not None] + [xd.grad]
+    for a, b in zip(first, second):
+        assert rel(b, 2 * a.float()) < 2e-3              # the same gradients once more (bf16 / atomics reorder only)
+
+
+def test_zero_pool_pieces_have_their_own_version_counter():
+    from deepviewagg_amd import ops
+    a = ops.zeros_small(40, torch.float64, DEV)
+    b = ops.zeros_small((3, 5), torch.float32, DEV)
+    assert a._base is None and b._base is None and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    va, vb = a._version, b._version
+    a.add_(1.0)
+    assert a._version == va + 1 and b._version == vb
+    assert float(b.abs().max()) == 0.0 and float(a.sum()) == 40.0 and b.shape == (3, 5) and b.is_contiguous()

@@ -77,6 +77,43 @@ def test_rows_gradient_is_deterministic_and_conserves_mass(scene):
     assert torch.isfinite(s_c).all()
 
 
+def test_split_plan_rows_gradient_full_size_equals_index_add(scene):
+    """The headline's rows-gradient path -- split plan (`dva_plan_split_build`), pass A on the 16-byte view records,
+    `bucket_rows_grad_kernel<64>` (`dva_plan_split_rows_grad`) -- at V = 33.5 M views / R = 2^18 rows against an
+    INDEPENDENT sum: the reference's backward of the row gather is an ``index_add`` of the views'
+    gradients (core/multimodal/image.py:1262-1287), so an 8-channel slice (two channels of every group) is summed by
+    ``torch.index_add_`` in fp32 on the device.  Tolerance 2^-7 of the largest entry: one bf16 rounding of a sum of
+    ~128 products (2^-9 relative) plus the fp32 atomics' order."""
+    from deepviewagg_amd import ops
+    s = scene
+    V, R = s["V"], s["R"]
+    g = torch.Generator(device=DEV).manual_seed(21)
+    point = torch.arange(V, device=DEV, dtype=torch.int32) // VIEWS
+    wts = torch.randn(V, 4, generator=g, device=DEV).bfloat16()
+    rec = torch.empty(V, 4, dtype=torch.int32, device=DEV)
+    rec[:, 0] = point
+    rec[:, 1:3] = wts.view(torch.int32)
+    rec[:, 3] = s["row_idx"]
+    gout = torch.randn(N, C, generator=g, device=DEV).bfloat16()
+    assert ops._split_plan_pays(V, R)                       # the threshold selects the split plan by itself here
+    plan = ops.row_plan(s["row_idx"], R, with_counts=False)[0]
+    assert isinstance(plan, ops.SplitPlan)
+    got = plan.rows_grad_fused(gout, rec, C, G, torch.cuda.current_stream().cuda_stream)
+    assert got is not None and got.dtype == torch.bfloat16 and got.shape == (R, C)
+    chs = torch.tensor([0, 9, 17, 26, 35, 44, 52, 63], device=DEV)
+    grp = chs // (C // G)
+    ref = torch.zeros(R, chs.numel(), dtype=torch.float32, device=DEV)
+    step = V // 8
+    for lo in range(0, V, step):                            # 8 chunks of 4.2 M views: 134 MB of products each
+        sl = slice(lo, lo + step)
+        prod = gout[point[sl].long()][:, chs].float() * wts[sl][:, grp].float()
+        ref.index_add_(0, s["row_idx"][sl].long(), prod)
+    scale = float(ref.abs().max())
+    err = float((got[:, chs].float() - ref).abs().max())
+    assert err <= scale * 2 ** -7, (err, scale)
+    assert float(ref.abs().max()) > 1.0                      # the sums are not trivially small
+
+
 def test_deepset_scores_are_equivariant_to_view_permutations():
     """DeepSetFeat pools with a max over the views of a point: permuting the views inside every point permutes
     the scores the same way (fused kernels, bf16 storage, full size)."""

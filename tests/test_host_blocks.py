@@ -77,3 +77,45 @@ def test_multimodal_input_builds_the_block_dictionary():
     assert torch.equal(x.C[:, 3], data.batch.int()) and torch.equal(x.C[:, :3], data.coords.int())
     assert torch.equal(x.F, data.x) and x.coord_maps[1] is x.C
     assert _is_voxel_tensor(multimodal_input(data, "cpu", is_multimodal=False))
+
+
+def test_zero_pool_pieces_do_not_share_a_version_counter():
+    """ops._zero_piece (the allocator behind ops.zeros_small) on a CPU pool: pieces share the pool's storage but each has
+    its own autograd version counter, so an in-place update of one (AccumulateGrad on a stolen gradient) does not
+    invalidate another that a fused node saved for backward.  Reproduces the failure mode with two
+    autograd Functions saving / returning pieces."""
+    import torch
+    from deepviewagg_amd import ops
+    dev = torch.device("cpu")
+    key = ("test-pool", 0)
+    ops._ZERO_POOLS.pop(key, None)
+
+    def piece(n):
+        return ops._zero_piece(key, (n * 4 + 255) & ~255, n * 4, (n,), torch.float32, dev)
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            saved = piece(4)            # e.g. BatchNorm moments written by a kernel
+            ctx.save_for_backward(saved)
+            return x * w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            (saved,) = ctx.saved_tensors        # raises if the shared counter moved
+            gw = piece(3)                       # parameter gradient handed out of the pool
+            gw += g.sum()
+            return g, gw
+
+    x = torch.ones(5, requires_grad=True)
+    w = torch.nn.Parameter(torch.ones(3))
+    y = Node.apply(Node.apply(x, w), w).sum()
+    y.backward(retain_graph=True)
+    y.backward()                                # .grad defined: in-place accumulation into a stolen pool piece
+    assert torch.allclose(w.grad, torch.full((3,), 20.0))
+    a, b = piece(8), piece(8)
+    assert a._base is None and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    v = b._version
+    a.add_(1)
+    assert b._version == v and float(b.sum()) == 0.0
+    ops._ZERO_POOLS.pop(key, None)
