@@ -511,6 +511,21 @@ def timed_steps(scene, mods, dtype, steps, warmup, lazy=True, interpolate=False)
     return ms, kern
 
 
+def timed_steps_guarded(scene, mods, dtype, steps, warmup, interpolate=False):
+    """timed_steps, timed once more when the wall time is far above the sum of the timed kernels: a warm-up artefact
+    (allocator growth after the previous workload's buffers were released was seen to double a C = 512 step once; a 3 s
+    host stall inside one 5-step region was seen once in round 6: kitti 128 -> 64 at 636 ms/step instead of 22)."""
+    ms, kern = timed_steps(scene, mods, dtype, steps, warmup, interpolate=interpolate)
+    sanity = kern.pop("__sanity__")
+    retimed = False
+    if ms > 1.25 * sum(v["ms"] for v in kern.values()) / PROFILE_STEPS + 3.0:
+        ms2, kern2 = timed_steps(scene, mods, dtype, steps, 0, interpolate=interpolate)
+        kern2.pop("__sanity__")
+        if ms2 < ms:
+            ms, kern, retimed = ms2, kern2, True
+    return ms, kern, sanity, retimed
+
+
 def sanity_values(out, x_grad):
     """What the last timed step computed (a timing of an unverified computation is not a measurement):
     mean |.| and finiteness of the fused features and of the feature-map gradient, outside the timed region."""
@@ -540,16 +555,7 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=10, war
     N = 1 << log2_points
     scene = make_scene(N, views, 32, C, 64, 128, dtype, device, seed=4321, workload=wl, upscale=8 if interpolate else 1)
     mods = build_modules(C, device, C_out, pool="qkv" if name == "qkv" else "group")
-    ms, kern = timed_steps(scene, mods, dtype, steps, warmup, interpolate=interpolate)
-    sanity = kern.pop("__sanity__")
-    retimed = False
-    if ms > 1.25 * sum(v["ms"] for v in kern.values()) / PROFILE_STEPS + 3.0:
-        # wall time far above the sum of the timed kernels: a warm-up artefact (allocator growth after the previous
-        # workload's buffers were released was seen to double a C = 512 step once) -- time the same steps again
-        ms2, kern2 = timed_steps(scene, mods, dtype, steps, 0, interpolate=interpolate)
-        kern2.pop("__sanity__")
-        if ms2 < ms:
-            ms, kern, retimed = ms2, kern2, True
+    ms, kern, sanity, retimed = timed_steps_guarded(scene, mods, dtype, steps, warmup, interpolate=interpolate)
     if interpolate:
         # the fused bilinear path against the reference's materialised [V, C] dataflow on the same scene (same
         # parameters: its sanity values are the yardstick of the fused path's)
@@ -781,10 +787,9 @@ def kitti360_pyramid_train(device, log2_points, views, steps=5):
     for C, Co in ((128, 32), (64, 32), (128, 64), (256, 128), (512, 256)):
         scene = make_scene(N, views, 32, C, 64, 128, torch.bfloat16, device, seed=4321, workload="S1", upscale=8)
         mods = build_modules(C, device, Co)
-        ms, kern = timed_steps(scene, mods, torch.bfloat16, steps, 2, interpolate=True)
-        sanity = kern.pop("__sanity__")
+        ms, kern, sanity, retimed = timed_steps_guarded(scene, mods, torch.bfloat16, steps, 2, interpolate=True)
         top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]
-        lvl = {"ms_per_step": ms, "fused_path": "emod_attn_fwd" in kern, "steps": steps, "sanity": sanity,
+        lvl = {"ms_per_step": ms, "fused_path": "emod_attn_fwd" in kern, "steps": steps, "sanity": sanity, "retimed": retimed,
                "top_kernels_ms": {n: v["ms"] / v["launches"] for n, v in top}}
         if Co >= 128:
             ms_mat, kern_mat = timed_steps(scene, mods, torch.bfloat16, 2, 1, lazy=False, interpolate=True)
