@@ -126,6 +126,9 @@ SIGNATURES = {
     "dva_chain_stats2": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_pooled": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "dva_chain_stats": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "dva_chain_stats_a2": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "dva_chain_score_stats_a2": (ctypes.c_int, [_vp] * 12 + [_i32, _i64, _i64, _vp]),
+    "dva_chain_bwd_layer6_a2": (ctypes.c_int, [_vp] * 13 + [_i32, _i64, _i64, _vp]),
     "dva_chain_attn_fwd": (ctypes.c_int, [_vp] * 18 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),
     "dva_chain_attn_bwd_f32": (ctypes.c_int, [_vp] * 14 + [_i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp]),

@@ -27,16 +27,20 @@ struct ChainKeep {
 // the raw output z6 (BatchNorm backward, statistics) and the folded product t6 = 0.6 y6 (block W6F) whose sign the
 // forward's activation saw and whose activation a6 feeds the score layer.  tabs[0..3] = layers 1, 2, 5, 6.
 // L6: 0 = z6 only, 1 = + t6, 2 = + t6 and a6.
-template <int W6F, int L6>
+// A2IN (round 6, the stored-a2 hybrid): k.a2 already holds the layer-2 activation row the forward stored
+// (stats_mid_kernel<5, 1>: the very operand computed below): layers 1 and 2 are skipped, x is not read.
+template <int W6F, int L6, bool A2IN = false>
 __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
                                               uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
   const f32x16 zero = {0};
-  bf16x8 a1[2];
-  asm volatile("" ::: "memory");
-  const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(x), bias_acc(tabs[0], T_B6, h));
-  act_fold(t1, keep, a1);
-  const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(tabs[1], T_B6, h));
-  act_fold(t2, keep, k.a2);
+  if constexpr (!A2IN) {
+    bf16x8 a1[2];
+    asm volatile("" ::: "memory");
+    const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(x), bias_acc(tabs[0], T_B6, h));
+    act_fold(t1, keep, a1);
+    const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(tabs[1], T_B6, h));
+    act_fold(t2, keep, k.a2);
+  }
   k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
   act_pack(k.z5, tabs[2], h, keep, k.a5);
   k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
@@ -394,14 +398,14 @@ __device__ __forceinline__ void dkeys_operand(const float4& dcv, __amdgpu_buffer
   dkp[1] = pack8(&d[8]);
 }
 
-template <bool KEYS>
+template <bool KEYS, bool A2IN = false>
 __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
     const float* __restrict__ bn6, const float* __restrict__ dc, double* __restrict__ stats6,
     float* __restrict__ dWs, float* __restrict__ dbs, int G, int64_t V, int64_t N, const float* __restrict__ qp,
-    float qscale) {
+    float qscale, const bf16_t* __restrict__ a2buf = nullptr) {
   constexpr int L_W6F = 7, L_WST = 9, NOPS = KEYS ? 11 : 10;
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) uint4 s_ops[NOPS * 64];
@@ -414,17 +418,22 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
   for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) s_ops[OP_W5 * 64 + i] = ops[OP_W5 * 64 + i];   // W5, W6
   for (int i = threadIdx.x; i < (KEYS ? 128 : 64); i += blockDim.x)
     s_ops[L_WST * 64 + i] = ops[(KEYS ? OP_WKT : OP_WST) * 64 + i];
-  fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
-  fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  if (!A2IN) {
+    fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+    fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+  }
   fold_ops(s_ops, L_W6F, ops, OP_W6, 2, bn6);
-  stage_tab(s_tab[0], bn1, nullptr);
-  stage_tab(s_tab[1], bn2, nullptr);
+  if (!A2IN) {
+    stage_tab(s_tab[0], bn1, nullptr);
+    stage_tab(s_tab[1], bn2, nullptr);
+  }
   stage_tab(s_tab[2], bn5, nullptr);
   stage_tab(s_tab[3], bn6, nullptr);
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, A2IN ? 0 : (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16),
-                               QP = make_rsrc(qp, KEYS ? (uint64_t)N * 128 : 0);
+                               QP = make_rsrc(qp, KEYS ? (uint64_t)N * 128 : 0),
+                               A2 = make_rsrc(a2buf, A2IN ? (uint64_t)V * 64 : 0);
   bf16_t* tc = s_tc[wv];
   bf16_t* td = s_td[wv];
   f32x16 accS = {0};
@@ -438,6 +447,7 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
   struct Pre {
     TileInfo ti;
     float4 x, dc;
+    u32x4 alo, ahi;
     int vpj;
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
@@ -445,7 +455,12 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     p.ti = ti;
     const bool ok = j < p.ti.nv;
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
-    p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    if constexpr (A2IN) {
+      p.alo = ld128(A2, ok ? view * 64u + 32u * h : OOB);
+      p.ahi = ld128(A2, ok ? view * 64u + 32u * h + 16u : OOB);
+    } else {
+      p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    }
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
     p.dc = as_f4(ld128(DC, ok && (KEYS || h == 0) ? view * 16u : OOB));      // KEYS: both halves need the four groups
     return p;
@@ -454,7 +469,11 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
     const uint32_t keep = ok ? 0xffffffffu : 0u;
     const f32x16 uacc = load_u(U, ok, p.vpj, h);
     ChainKeep k;
-    chain_forward<L_W6F, 2>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    if constexpr (A2IN) {
+      k.a2[0] = __builtin_bit_cast(bf16x8, p.alo);
+      k.a2[1] = __builtin_bit_cast(bf16x8, p.ahi);
+    }
+    chain_forward<L_W6F, 2, A2IN>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
     if constexpr (KEYS) {
       // dK of the view as the packed B operand (zeros for lanes without a view)
       bf16x8 dkp[2];
@@ -816,7 +835,7 @@ __device__ __forceinline__ f32x16 unpack_da(const u32x4& lo, const u32x4& hi) {
 // MERGED (STAGE 5 only, round 5): no stage 6 ran -- the pass starts from the score gradients dc [V, 4] and the constants
 // of the BatchNorm-6 backward (sm6), evaluates dy6 -> dz6 -> da5 -> dy5 itself and takes dW6 along (written to `Pm`);
 // S5 came from score_l6_kernel + l6_consts_kernel.
-template <int STAGE, int OCC, bool KEYS = false, bool MERGED = false>
+template <int STAGE, int OCC, bool KEYS = false, bool MERGED = false, bool A2IN = false>
 __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
@@ -826,7 +845,9 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     const float* __restrict__ dpooled, const bf16_t* __restrict__ da_in, bf16_t* __restrict__ da_out,
     float* __restrict__ dW,
     float* __restrict__ du, float* __restrict__ Pm, double* __restrict__ stats, int G, int64_t V, int64_t N,
-    const float* __restrict__ qp, float qscale) {
+    const float* __restrict__ qp, float qscale, const bf16_t* __restrict__ a2buf = nullptr) {
+  static_assert(!A2IN || STAGE == 6, "the stored a2 row replaces x_map in stage 6 only (stages 5, 2 need layers 1-2)");
+  constexpr bool A2_PREFETCH = false;     // the row is loaded in the body: a second prefetch set of it spills (56 bytes of scratch)
   __shared__ __attribute__((aligned(16))) float s_tab[4][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[4][32 * TSB], s_tb[4][32 * TSB];
   // second operand tile of the small products: 4 (score gradients) / 17 (x_map hi | lo | ones) rows + one shared zero row
@@ -863,8 +884,10 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_WST * 64 + i] = ops[OP_WKT * 64 + i];
     }
     for (int i = threadIdx.x; i < 2 * 64; i += blockDim.x) s_ops[L6_W6T * 64 + i] = ops[OP_W6T * 64 + i];
-    fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
-    fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+    if (!A2IN) {
+      fold_ops(s_ops, OP_W1, ops, OP_W1, 1, bn1);
+      fold_ops(s_ops, OP_W2, ops, OP_W2, 2, bn2);
+    }
     fold_ops(s_ops, L6_W6F, ops, OP_W6, 2, bn6);
   } else {
     for (int i = threadIdx.x; i < (STAGE == 5 ? 7 : 5) * 64; i += blockDim.x) {
@@ -890,8 +913,10 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       fold_ops(s_ops, L_W1F, ops, OP_W1, 1, bn1);
     }
   }
-  stage_tab(s_tab[0], bn1, nullptr);
-  stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr);
+  if (!A2IN) {
+    stage_tab(s_tab[0], bn1, nullptr);
+    stage_tab(s_tab[1], bn2, STAGE == 2 ? sm2 : nullptr);
+  }
   stage_tab(s_tab[2], bn5, STAGE == 5 ? sm5 : nullptr);
   stage_tab(s_tab[3], bn6, (STAGE == 6 || MERGED) ? sm6 : nullptr);
   // second operand tiles hold rows that are never rewritten (score gradients: rows >= 4, x_map: rows >= 8)
@@ -903,10 +928,11 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     }
   }
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, A2IN ? 0 : (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
                                U = make_rsrc(u, (uint64_t)N * 128), DC = make_rsrc(dc, (uint64_t)V * 16), QP = make_rsrc(qp, KEYS ? (uint64_t)N * 128 : 0),
                                AR = make_rsrc(arg, (uint64_t)N * 128), DP = make_rsrc(dpooled, (uint64_t)N * 128),
-                               DI = make_rsrc(da_in, (uint64_t)V * 64), DO = make_rsrc(da_out, (uint64_t)V * 64);
+                               DI = make_rsrc(da_in, (uint64_t)V * 64), DO = make_rsrc(da_out, (uint64_t)V * 64),
+                               A2 = make_rsrc(a2buf, A2IN ? (uint64_t)V * 64 : 0);
   float st[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = 0.f;
@@ -937,7 +963,14 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
     p.ti = ti;
     const bool ok = j < p.ti.nv;
     const uint32_t view = (uint32_t)(p.ti.v0 + j);
-    p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    if constexpr (A2IN) {      // the stored layer-2 activation row instead of x_map
+      if constexpr (A2_PREFETCH) {      // (dlo | dhi are free in stage 6)
+        p.dlo = ld128(A2, ok ? view * 64u + 32u * h : OOB);
+        p.dhi = ld128(A2, ok ? view * 64u + 32u * h + 16u : OOB);
+      }
+    } else {
+      p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    }
     p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
     if (STAGE == 2) {
       p.dlo = ld128(DI, ok ? view * 64u + 32u * h : OOB);
@@ -963,10 +996,18 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       {
         bf16x8 a1[2], a2[2];
         asm volatile("" ::: "memory");
-        const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
-        act_fold(t1, keep, a1);
-        const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(s_tab[1], T_B6, h));
-        act_fold(t2, keep, a2);
+        if constexpr (A2IN && A2_PREFETCH) {
+          a2[0] = __builtin_bit_cast(bf16x8, p.dlo);
+          a2[1] = __builtin_bit_cast(bf16x8, p.dhi);
+        } else if constexpr (A2IN) {
+          a2[0] = __builtin_bit_cast(bf16x8, ld128(A2, ok ? view * 64u + 32u * h : OOB));
+          a2[1] = __builtin_bit_cast(bf16x8, ld128(A2, ok ? view * 64u + 32u * h + 16u : OOB));
+        } else {
+          const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
+          act_fold(t1, keep, a1);
+          const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(s_tab[1], T_B6, h));
+          act_fold(t2, keep, a2);
+        }
         z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
         act_pack(z5, s_tab[2], h, keep, a5);
       }
@@ -1465,6 +1506,48 @@ int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const f
   hipLaunchKernelGGL((score_stats_kernel<false>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream, x_map,
                      view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops, bn1, bn2, bn5, bn6, grad_scores,
                      stats6, dWs, dbs, (int)G, n_views, n_points, (const float*)nullptr, 0.f);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// The stored-a2 hybrid (round 6): the same pass starting from the layer-2 activation row the forward stored
+// (dva_chain_stats_a2(5): bf16 [V, 32], accumulator order) instead of x_map -- 64 instead of 32 bytes per view in, layers 1
+// and 2 not evaluated.  Same results bit for bit (the row IS the operand layer 5 consumes).
+int dva_chain_score_stats_a2(const void* a2, const int32_t* view_point, const float* u, const void* tiles,
+                             const int32_t* n_tiles, const void* ops, const float* bn5, const float* bn6,
+                             const float* grad_scores, double* stats6, float* dWs, float* dbs, int32_t G,
+                             int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!a2 || !view_point || !u || !tiles || !n_tiles || !ops || !bn5 || !bn6 || !grad_scores || !stats6 || !dWs ||
+      !dbs || ((uintptr_t)a2 & 15))
+    return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((score_stats_kernel<false, true>), dim3(chain_grid(3)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)nullptr, view_point, u, (const int2*)tiles, n_tiles, (const uint4*)ops,
+                     (const float*)nullptr, (const float*)nullptr, bn5, bn6, grad_scores, stats6, dWs, dbs, (int)G,
+                     n_views, n_points, (const float*)nullptr, 0.f, (const bf16_t*)a2);
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+// stage 6 of dva_chain_bwd_layer from the stored a2 row: dW6, dy5 (da_out bf16 [V, 32]), S of layer 5
+int dva_chain_bwd_layer6_a2(const void* a2, const int32_t* view_point, const float* u, const void* tiles,
+                            const int32_t* n_tiles, const void* ops, const float* bn5, const float* bn6,
+                            const float* sm6, const float* grad_scores, void* da_out, float* dW, double* stats,
+                            int32_t G, int64_t n_views, int64_t n_points, void* stream) {
+  if (n_views < 0 || n_points < 0 || G < 1 || G > 4) return DVA_ERR_INVALID;
+  if (n_views == 0) return DVA_OK;
+  if (!a2 || !view_point || !u || !tiles || !n_tiles || !ops || !bn5 || !bn6 || !sm6 || !grad_scores || !da_out ||
+      !dW || !stats || ((uintptr_t)a2 & 15))
+    return DVA_ERR_INVALID;
+  if (n_views * 64 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((layer_bwd_kernel<6, 3, false, false, true>), dim3(chain_grid(3)), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)nullptr, view_point, u, (const int2*)tiles, n_tiles,
+                     (const uint4*)ops, (const float*)nullptr, (const float*)nullptr, bn5, bn6, (const float*)nullptr,
+                     (const float*)nullptr, sm6, grad_scores, (const int32_t*)nullptr, (const float*)nullptr,
+                     (const bf16_t*)nullptr, (bf16_t*)da_out, dW, (float*)nullptr, (float*)nullptr, stats, (int)G,
+                     n_views, n_points, (const float*)nullptr, 0.f, (const bf16_t*)a2);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

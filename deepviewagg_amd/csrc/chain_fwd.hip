@@ -417,25 +417,38 @@ __global__ __launch_bounds__(256) void pooled_kernel(const float* __restrict__ z
 // ------------------------------------------------------------------------------------------------
 // statistics of layer 5 (z5 = W5a a2 + u[point]) or layer 6 (train mode)
 // ------------------------------------------------------------------------------------------------
-template <int L>
+// A2 (round 6, the stored-a2 hybrid: DVA_CHAIN_A2=1): 0 = everything from x_map; 1 (L == 5) = the pass also WRITES the
+// layer-2 activation a2 as one bf16 row per view ([V, 32] in accumulator order: the 32 bytes a lane holds are
+// contiguous, position 16 h + r = channel chan(r, h)) -- exactly the packed B operand layer 5 consumes, so a pass that
+// starts from the row evaluates the same numbers; 2 (L == 6) = the pass READS that row instead of x_map and skips
+// layers 1 and 2 (the hi | lo split, three MFMAs, two bias / activation / pack sequences per view).
+template <int L, int A2 = 0>
 __global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
     const float* __restrict__ x_map, const int32_t* __restrict__ vp, const float* __restrict__ u,
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ ops,
     const float* __restrict__ bn1, const float* __restrict__ bn2, const float* __restrict__ bn5,
-    double* __restrict__ stats, int64_t V, int64_t N) {
+    double* __restrict__ stats, int64_t V, int64_t N, bf16_t* __restrict__ a2buf) {
+  static_assert(A2 == 0 || (A2 == 1 && L == 5) || (A2 == 2 && L == 6), "a2 is written by stats5 and read by stats6");
   __shared__ __attribute__((aligned(16))) float s_tab[3][TAB_FLOATS];
   __shared__ float s_red[STATS_RED_FLOATS];
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  stage_tab(s_tab[0], bn1, nullptr);
-  stage_tab(s_tab[1], bn2, nullptr);
+  if (A2 != 2) {
+    stage_tab(s_tab[0], bn1, nullptr);
+    stage_tab(s_tab[1], bn2, nullptr);
+  }
   if (L == 6) stage_tab(s_tab[2], bn5, nullptr);
   __syncthreads();
-  const bf16x8 w1 = load_op_fold(ops, OP_W1, lane, bn1);     // layers 1, 2: BatchNorm inside the product
-  const WOp w2 = load_wop_fold(ops, OP_W2, lane, bn2), w5 = load_wop(ops, OP_W5, lane);
+  bf16x8 w1;
+  WOp w2;
+  if (A2 != 2) {
+    w1 = load_op_fold(ops, OP_W1, lane, bn1);     // layers 1, 2: BatchNorm inside the product
+    w2 = load_wop_fold(ops, OP_W2, lane, bn2);
+  }
+  const WOp w5 = load_wop(ops, OP_W5, lane);
   WOp w6;
   if (L == 6) w6 = load_wop(ops, OP_W6, lane);
-  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
-                               U = make_rsrc(u, (uint64_t)N * 128);
+  const __amdgpu_buffer_rsrc_t X = make_rsrc(x_map, A2 == 2 ? 0 : (uint64_t)V * 32), P = make_rsrc(vp, (uint64_t)V * 4),
+                               U = make_rsrc(u, (uint64_t)N * 128), A = make_rsrc(a2buf, A2 ? (uint64_t)V * 64 : 0);
   float st[3][16];      // sum z | sum z^2 | (L == 6) sum a5
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[0][r] = st[1][r] = st[2][r] = 0.f;
@@ -445,14 +458,21 @@ __global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
   struct Pre {
     TileInfo ti;
     float4 x;
+    u32x4 alo, ahi;
     int vpj;
   };
   run_tiles<Pre>(tiles, ta, tb, [&](const TileInfo& ti, int t) {
     Pre p;
     p.ti = ti;
     const bool ok = j < p.ti.nv;
-    p.x = as_f4(ld128(X, ok ? (uint32_t)(p.ti.v0 + j) * 32u + 16u * h : OOB));
-    p.vpj = (int)ld32(P, ok ? (uint32_t)(p.ti.v0 + j) * 4u : OOB);
+    const uint32_t view = (uint32_t)(p.ti.v0 + j);
+    if (A2 == 2) {
+      p.alo = ld128(A, ok ? view * 64u + 32u * h : OOB);
+      p.ahi = ld128(A, ok ? view * 64u + 32u * h + 16u : OOB);
+    } else {
+      p.x = as_f4(ld128(X, ok ? view * 32u + 16u * h : OOB));
+    }
+    p.vpj = (int)ld32(P, ok ? view * 4u : OOB);
     return p;
   }, [&](const Pre& p) {
     const bool ok = j < p.ti.nv;
@@ -464,11 +484,22 @@ __global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
       uacc[4 * q] = v.x; uacc[4 * q + 1] = v.y; uacc[4 * q + 2] = v.z; uacc[4 * q + 3] = v.w;
     }
     const f32x16 zero = {0};
-    const f32x16 t1 = CH_MFMA(w1, pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
-    bf16x8 a1[2], a2[2];
-    act_fold(t1, keep, a1);
-    const f32x16 t2 = mm32(w2, a1, bias_acc(s_tab[1], T_B6, h));
-    act_fold(t2, keep, a2);
+    bf16x8 a2[2];
+    if (A2 == 2) {
+      a2[0] = __builtin_bit_cast(bf16x8, p.alo);      // lanes without a view loaded zeros (OOB): the masked operand
+      a2[1] = __builtin_bit_cast(bf16x8, p.ahi);
+    } else {
+      const f32x16 t1 = CH_MFMA(w1, pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
+      bf16x8 a1[2];
+      act_fold(t1, keep, a1);
+      const f32x16 t2 = mm32(w2, a1, bias_acc(s_tab[1], T_B6, h));
+      act_fold(t2, keep, a2);
+      if (A2 == 1) {
+        const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 64u + 32u * h : OOB;
+        st128(A, off, __builtin_bit_cast(u32x4, a2[0]));
+        st128(A, ok ? off + 16u : OOB, __builtin_bit_cast(u32x4, a2[1]));
+      }
+    }
     f32x16 z = mm32(w5, a2, uacc);
     if (L == 6) {
       bf16x8 a5[2];
@@ -1144,28 +1175,51 @@ int dva_chain_pooled(const float* zstar, const float* bn2, const int64_t* ptr, f
   return DVA_OK;
 }
 
-int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
-                    const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
-                    const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
-                    void* stream) {
+static int chain_stats_impl(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
+                            const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                            const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
+                            void* a2, void* stream) {
   if (n_views < 0 || (layer != 5 && layer != 6)) return DVA_ERR_INVALID;
   if (n_views == 0) return DVA_OK;
-  if (!x_map || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !stats ||
-      (layer == 6 && !bn5))
+  const bool from_a2 = a2 && layer == 6;
+  if ((!x_map && !from_a2) || !view_point || !u || !tiles || !n_tiles || !ops || !bn1 || !bn2 || !stats ||
+      (layer == 6 && !bn5) || ((uintptr_t)a2 & 15))
     return DVA_ERR_INVALID;
   if (n_views * 32 > 0xfffffff0ll || n_points * 128 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
+  if (a2 && n_views * 64 > 0xfffffff0ll) return DVA_ERR_UNSUPPORTED;
   // layer 5 fits 116 VGPRs: four blocks per CU; layer 6 (150) three
   static const int bpc5 = tune_int("DVA_STATS5_BPC", 4);      // read once
   const dim3 grid(chain_grid(layer == 5 ? bpc5 : 3)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (layer == 5)
-    hipLaunchKernelGGL((stats_mid_kernel<5>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
-                       n_tiles, (const uint4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
-  else
-    hipLaunchKernelGGL((stats_mid_kernel<6>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles,
-                       n_tiles, (const uint4*)ops, bn1, bn2, bn5, stats, n_views, n_points);
+#define DVA_STATS_MID(L_, A_)                                                                                         \
+  hipLaunchKernelGGL((stats_mid_kernel<L_, A_>), grid, block, 0, s, x_map, view_point, u, (const int2*)tiles, n_tiles, \
+                     (const uint4*)ops, bn1, bn2, bn5, stats, n_views, n_points, (bf16_t*)a2)
+  if (layer == 5 && a2) DVA_STATS_MID(5, 1);
+  else if (layer == 5) DVA_STATS_MID(5, 0);
+  else if (a2) DVA_STATS_MID(6, 2);
+  else DVA_STATS_MID(6, 0);
+#undef DVA_STATS_MID
   DVA_CHECK_LAUNCH();
   return DVA_OK;
+}
+
+int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
+                    const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                    const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
+                    void* stream) {
+  return chain_stats_impl(layer, x_map, view_point, u, tiles, n_tiles, ops, bn1, bn2, bn5, stats, n_views, n_points,
+                          nullptr, stream);
+}
+
+// The stored-a2 hybrid (round 6): layer 5 = dva_chain_stats(5) that also WRITES a2 bf16 [V, 32] (accumulator order);
+// layer 6 = dva_chain_stats(6) starting from that row instead of x_map (x_map may be null).
+int dva_chain_stats_a2(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
+                       const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                       const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
+                       void* a2, void* stream) {
+  if (!a2) return DVA_ERR_INVALID;
+  return chain_stats_impl(layer, x_map, view_point, u, tiles, n_tiles, ops, bn1, bn2, bn5, stats, n_views, n_points, a2,
+                          stream);
 }
 
 static int chain_keys_impl(const float* x_map, const int32_t* view_point, const float* u, const void* tiles,

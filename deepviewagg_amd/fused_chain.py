@@ -164,7 +164,14 @@ def _set_branch_backward(saved, dt, dWc, training, zstats, arena):
     return dpooled, [dWsa, g1, b1, dWsb, g2, b2]
 
 
-def chain_prologue(module, x_map, csr_idx):
+# DVA_CHAIN_A2=1 -- the stored-a2 hybrid (round 6, VERDICT r5 item 3: bytes for instructions): the layer-5 statistics pass
+# also writes the layer-2 activation as a bf16 [V, 32] row (+64 bytes per view written once); the layer-6 statistics pass,
+# the score pass and stage 6 of the backward start from that row (64 instead of 32 bytes per view read, layers 1 and 2 not
+# evaluated).  Same numbers bit for bit: the row is the operand layer 5 consumes.  A/B: profiles/r06_hybrid_ab.json.
+CHAIN_A2 = os.environ.get("DVA_CHAIN_A2", "0") == "1"
+
+
+def chain_prologue(module, x_map, csr_idx, store_a2=False):
     """Everything of a chain forward that does not depend on the values: tile table, view -> point index, weight
     operands, the statistics passes of the four BatchNorm layers of DeepSetFeat (train mode), the set branch.
     Returns a namespace with the tensors the fused view kernel and the backward need (shared by the nearest path
@@ -219,19 +226,30 @@ def chain_prologue(module, x_map, csr_idx):
     t_add, set_saved = _set_branch_forward(e_map, pooled, csr_idx, training, zstats)
     # ---- layers 5, 6: statistics (train mode)
     s5, s6 = zstats(), zstats()
+    a2 = None
+    if training and store_a2 and V * 64 <= 0xfffffff0:
+        a2 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
     if training:
-        with ops._timed("chain_stats5", V * 36 + N * 128):
-            check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                      ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
+        with ops._timed("chain_stats5", V * (36 + (64 if a2 is not None else 0)) + N * 128):
+            if a2 is not None:
+                check(lib.dva_chain_stats_a2(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                             ptr(bn1), ptr(bn2), None, ptr(s5), V, N, ptr(a2), st), "dva_chain_stats_a2")
+            else:
+                check(lib.dva_chain_stats(5, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                          ptr(bn1), ptr(bn2), None, ptr(s5), V, N, st), "dva_chain_stats")
     bn5 = _chain_bn(s5, V, bns[2], training)                       # layer 5 is not folded
     if training:
-        with ops._timed("chain_stats6", V * 36 + N * 128):
-            check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
-                                      ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
+        with ops._timed("chain_stats6", V * (68 if a2 is not None else 36) + N * 128):
+            if a2 is not None:
+                check(lib.dva_chain_stats_a2(6, None, ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                             ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, ptr(a2), st), "dva_chain_stats_a2")
+            else:
+                check(lib.dva_chain_stats(6, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                          ptr(bn1), ptr(bn2), ptr(bn5), ptr(s6), V, N, st), "dva_chain_stats")
     bn6 = _chain_bn(s6, V, bns[3], training, W6, D, s6[2 * D:])
     return SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
                            bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, bs=bs, gw=gw, gb=gb, W1=W1, G=G, training=training,
-                           set_saved=set_saved)
+                           set_saved=set_saved, a2=a2)
 
 
 # order of the chain's tensors in ctx.saved_tensors (after the path's own): tests/test_gpu_chain.py reads bn1 ..., scores
@@ -250,12 +268,12 @@ class _ChainPool(torch.autograd.Function):
         dev, V, N = x_map.device, x_map.shape[0], csr_idx.shape[0] - 1
         R, C = rows.shape
         st = stream_of(x_map)
-        S = chain_prologue(module, x_map, csr_idx)
+        need_bwd = any(ctx.needs_input_grad)
+        S = chain_prologue(module, x_map, csr_idx, store_a2=CHAIN_A2 and need_bwd)
         # ---- the fused view kernel
         out = pooled_output(csr_idx, N, C, dev)
         # a backward will follow: the scores of every view stay (16 bytes per view) -- the attention backward starts from
         # them instead of evaluating the chain once more
-        need_bwd = any(ctx.needs_input_grad)
         scores = torch.empty((V, 4), dtype=torch.float32, device=dev) if need_bwd else None
         # SURVEY.md 8(d) fused view-gather + attention: V (C s + F_map 4 + idx) + N (C s + ptr); idx = view->point
         # index + row index (4 + 4), per point the set-branch row (128) on top (+ 16 bytes per view of scores out in training)
@@ -269,6 +287,7 @@ class _ChainPool(torch.autograd.Function):
         ctx.plan = plan
         ctx.module = module
         ctx.set_saved = S.set_saved
+        ctx.a2 = S.a2          # a workspace of this step (like set_saved): released by the backward
         ctx.training = S.training
         ctx.meta = (int(scaling), float(eps))
         return out

@@ -77,7 +77,9 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
     s6 = zstats()
     dWs, dbs = arena.take(G, D), arena.take(G)
     merged = MERGE_STAGE6 and keys is None
-    with ops._timed("chain_score_stats", V * (32 + 4 + 16) + N * (128 if keys is None else 256)):
+    a2 = getattr(S, "a2", None) if (keys is None and not merged) else None      # the stored-a2 hybrid (fused_chain.CHAIN_A2)
+    xb = 64 if a2 is not None else 32          # bytes per view of the pass's chain input
+    with ops._timed("chain_score_stats", V * (xb + 4 + 16) + N * (128 if keys is None else 256)):
         if merged:
             # + the sums the statistics of the BatchNorm-5 backward are linear in: P2 | Q2 [2, 32, 32], e1 | e2 | n5 | q5
             acc5 = arena.take(2, D, D)
@@ -85,6 +87,10 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
             check(lib.dva_chain_score_l6_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                                ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs),
                                                ptr(dbs), ptr(acc5), ptr(vec5), G, V, N, st), "dva_chain_score_l6_stats")
+        elif keys is None and a2 is not None:
+            check(lib.dva_chain_score_stats_a2(ptr(a2), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops), ptr(bn5),
+                                               ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs), G, V, N, st),
+                  "dva_chain_score_stats_a2")
         elif keys is None:
             check(lib.dva_chain_score_stats(ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                             ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(dc), ptr(s6), ptr(dWs), ptr(dbs),
@@ -104,6 +110,11 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
                                                     ptr(da_out), ptr(dW), ptr(stats), keys[1], keys[2], V, N, st),
                       "dva_chain_bwd_layer6_keys")
                 return
+            if stage == 6 and a2 is not None:
+                check(lib.dva_chain_bwd_layer6_a2(ptr(a2), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
+                                                  ptr(bn5), ptr(bn6), ptr(sm6), ptr(dc), ptr(da_out), ptr(dW), ptr(stats),
+                                                  min(G, 4), V, N, st), "dva_chain_bwd_layer6_a2")
+                return
             check(lib.dva_chain_bwd_layer(stage, ptr(x_map), ptr(vp), ptr(t_add), ptr(tiles), ptr(n_tiles), ptr(wops),
                                           ptr(bn1), ptr(bn2), ptr(bn5), ptr(bn6), ptr(sm2), ptr(sm5), ptr(sm6),
                                           ptr(dc), ptr(arg_), ptr(dpooled_), ptr(da_in), ptr(da_out), ptr(dW),
@@ -122,7 +133,8 @@ def chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, set_saved, ke
     else:
         da5 = torch.empty((V, D), dtype=torch.bfloat16, device=dev)
         layer(6, None, None, sm6, None, None, None, da5, dW6, None, None, s5, "chain_bwd_l6",
-              V * (32 + 4 + 16 + 64) + N * 128)
+              V * (xb + 4 + 16 + 64) + N * 128)
+        del a2
     sm5, g5, b5 = consts(s5, bn5)
     dW5 = arena.take(D, 2 * D)
     du = torch.zeros((N, D), dtype=torch.float32, device=dev)
@@ -203,7 +215,9 @@ def backward(ctx, gout):
     st = stream_of(x_map)
     gout = gout.contiguous().to(torch.bfloat16)
     S = SimpleNamespace(vp=vp, tiles=tiles, n_tiles=n_tiles, wops=wops, t_add=t_add, zstar=zstar, arg=arg, mom=mom,
-                        bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G if qk is None else D, training=training)
+                        bn1=bn1, bn2=bn2, bn5=bn5, bn6=bn6, W1=W1, G=G if qk is None else D, training=training,
+                        a2=getattr(ctx, "a2", None))
+    ctx.a2 = None
     arena = Arena(dev)          # every small fp32 accumulator / gradient of this backward: one zero fill
     # ---- attention + gate backward from the scores the forward left: score gradients, view records (no chain)
     dc = torch.empty((V, 4), dtype=torch.float32, device=dev)

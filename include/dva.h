@@ -479,6 +479,14 @@ int dva_chain_stats(int32_t layer, const float* x_map, const int32_t* view_point
                     const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
                     const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
                     void* stream);
+/* The stored-a2 hybrid (round 6; reference maths unchanged: modules/multimodal/pooling.py:658-669, DeepSetFeat.forward):
+ * layer = 5: dva_chain_stats(5) that also WRITES a2 bf16 [V][32] = the layer-2 activation leaky(BN2(W2 a1)) of every view in
+ * ACCUMULATOR order (position 16 h + r = channel (r & 3) + 8 (r >> 2) + 4 h), i.e. the packed operand layer 5 consumes;
+ * layer = 6: dva_chain_stats(6) starting from that row instead of x_map (x_map may be NULL).  a2 16-byte aligned. */
+int dva_chain_stats_a2(int32_t layer, const float* x_map, const int32_t* view_point, const float* u,
+                       const void* tiles, const int32_t* n_tiles, const void* ops, const float* bn1,
+                       const float* bn2, const float* bn5, double* stats, int64_t n_views, int64_t n_points,
+                       void* a2, void* stream);
 /* Key layer of QKVBimodalCSRPool on the recompute chain (round 4; reference modules/multimodal/pooling.py:454-547:
  * keys = K(E_map(x_map))): ops prepared by dva_chain_prep with Ws = K.weight [32][32], G = 32.  keys bf16 [V][32] in
  * ACCUMULATOR order: position 16 h + r holds key channel (r & 3) + 8 (r >> 2) + 4 h (the layout of the rows the chain's
@@ -681,6 +689,16 @@ int dva_chain_score_stats(const float* x_map, const int32_t* view_point, const f
                           const int32_t* n_tiles, const void* ops, const float* bn1, const float* bn2,
                           const float* bn5, const float* bn6, const float* grad_scores, double* stats6, float* dWs,
                           float* dbs, int32_t G, int64_t n_views, int64_t n_points, void* stream);
+/* dva_chain_score_stats / stage 6 of dva_chain_bwd_layer starting from the a2 row of dva_chain_stats_a2 instead of x_map
+ * (64 instead of 32 bytes per view read, layers 1 and 2 not evaluated; same results bit for bit). */
+int dva_chain_score_stats_a2(const void* a2, const int32_t* view_point, const float* u, const void* tiles,
+                             const int32_t* n_tiles, const void* ops, const float* bn5, const float* bn6,
+                             const float* grad_scores, double* stats6, float* dWs, float* dbs, int32_t G,
+                             int64_t n_views, int64_t n_points, void* stream);
+int dva_chain_bwd_layer6_a2(const void* a2, const int32_t* view_point, const float* u, const void* tiles,
+                            const int32_t* n_tiles, const void* ops, const float* bn5, const float* bn6,
+                            const float* sm6, const float* grad_scores, void* da_out, float* dW, double* stats,
+                            int32_t G, int64_t n_views, int64_t n_points, void* stream);
 /* The same pass below the KEY layer of QKVBimodalCSRPool (ops prepared with G = 32): the gradient of a view's key row is
  * built in registers, dK'[v][i] = scale grad_compat[v][g(i)] queries[point(v)][i] (grad_compat fp32 [V][4], queries fp32
  * [N][32] in position order, G in {1, 2, 4} query-key groups); dWk fp32 [32][32] / dbk fp32 [32] (caller-zeroed) += the

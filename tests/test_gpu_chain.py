@@ -583,3 +583,36 @@ def test_zero_pool_pieces_have_their_own_version_counter():
     a.add_(1.0)
     assert a._version == va + 1 and b._version == vb
     assert float(b.abs().max()) == 0.0 and float(a.sum()) == 40.0 and b.shape == (3, 5) and b.is_contiguous()
+
+
+@pytest.mark.parametrize("sizes_fn,N,C,G", [(ragged_long, 2000, 64, 4), (full32, 4096, 64, 4), (ragged, 3000, 128, 2)])
+def test_stored_a2_hybrid_equals_recompute(sizes_fn, N, C, G):
+    """DVA_CHAIN_A2=1 (round 6 A/B): stats5 writes the layer-2 activation row, stats6 / the score pass /
+    stage 6 start from it.  The row is the very bf16 operand layer 5 consumes, so forward and feature-map gradient are
+    identical; the parameter gradients differ by the order of their fp32 atomics only."""
+    from deepviewagg_amd import fused_chain
+    case = make_case(19, N, C, sizes_fn)
+    _, m = build(case, G, True)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    res = {}
+    old = fused_chain.CHAIN_A2
+    calls = []
+    try:
+        for a2 in (False, True):
+            fused_chain.CHAIN_A2 = a2
+            m.load_state_dict(sd)
+            res[a2] = run_dev(case, m, chain=True)
+            calls.append({k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    finally:
+        fused_chain.CHAIN_A2 = old
+    (out_a, g_a), (out_b, g_b) = res[False], res[True]
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(g_a[0], g_b[0])                          # feature maps: the rows gradient does not pass the chain
+    for (k, a), b in zip(calls[0].items(), calls[1].values()):
+        assert torch.equal(a, b), k                             # BatchNorm running statistics: same sums
+    names = [n for n, _ in m.named_parameters()]
+    for n, a, b in zip(names, g_a[1:], g_b[1:]):
+        if a is None:
+            assert b is None, n
+            continue
+        assert rel(b, a) < 2e-5, (n, rel(b, a))
