@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdva_hip.so")
+# DVA_LIB_PATH: another build of the same sources (compile-time A/B variants, csrc/Makefile LIB= / EXTRA=) -- tools only
+LIB_PATH = os.environ.get("DVA_LIB_PATH") or os.path.join(_HERE, "csrc", "libdva_hip.so")
 
 DVA_F32, DVA_BF16 = 0, 1
 DVA_SUM, DVA_MEAN, DVA_MAX, DVA_MIN = 0, 1, 2, 3

@@ -29,7 +29,9 @@ struct ChainKeep {
 // L6: 0 = z6 only, 1 = + t6, 2 = + t6 and a6.
 // A2IN (round 6, the stored-a2 hybrid): k.a2 already holds the layer-2 activation row the forward stored
 // (stats_mid_kernel<5, 1>: the very operand computed below): layers 1 and 2 are skipped, x is not read.
-template <int W6F, int L6, bool A2IN = false>
+// MASK = false: activations of lanes without a view are not zeroed (chain_common.h act_pack) -- for passes whose every sum
+// over views is guarded on the gradient side (score gradients of such a lane are zero, gradient rows go through pack16).
+template <int W6F, int L6, bool A2IN = false, bool MASK = true>
 __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, const float (*tabs)[TAB_FLOATS], int h,
                                               uint32_t keep, const float4& x, const f32x16& uacc, ChainKeep& k) {
   const f32x16 zero = {0};
@@ -37,15 +39,15 @@ __device__ __forceinline__ void chain_forward(const uint4* s_ops, int lane, cons
     bf16x8 a1[2];
     asm volatile("" ::: "memory");
     const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(x), bias_acc(tabs[0], T_B6, h));
-    act_fold(t1, keep, a1);
+    act_fold<MASK>(t1, keep, a1);
     const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(tabs[1], T_B6, h));
-    act_fold(t2, keep, k.a2);
+    act_fold<MASK>(t2, keep, k.a2);
   }
   k.z5 = mm32_lds(s_ops, OP_W5, lane, k.a2, uacc);
-  act_pack(k.z5, tabs[2], h, keep, k.a5);
+  act_pack<MASK>(k.z5, tabs[2], h, keep, k.a5);
   k.z6 = mm32_lds(s_ops, OP_W6, lane, k.a5, zero);
   if (L6 >= 1) k.t6 = mm32_lds(s_ops, W6F, lane, k.a5, bias_acc(tabs[3], T_B6, h));
-  if (L6 >= 2) act_fold(k.t6, keep, k.a6);
+  if (L6 >= 2) act_fold<MASK>(k.t6, keep, k.a6);
 }
 __device__ __forceinline__ f32x16 load_u(__amdgpu_buffer_rsrc_t U, bool ok, int vpj, int h) {
   f32x16 uacc;
@@ -473,7 +475,9 @@ __global__ __launch_bounds__(256, 3) void score_stats_kernel(
       k.a2[0] = __builtin_bit_cast(bf16x8, p.alo);
       k.a2[1] = __builtin_bit_cast(bf16x8, p.ahi);
     }
-    chain_forward<L_W6F, 2, A2IN>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
+    // unmasked activations: the score gradients (KEYS: the dK operand) of a lane without a view are zero, so dy6 is, and
+    // the a6 / z6 garbage of such a lane meets a zero in every product and sum below
+    chain_forward<L_W6F, 2, A2IN, false>(s_ops, lane, s_tab, h, keep, p.x, uacc, k);
     if constexpr (KEYS) {
       // dK of the view as the packed B operand (zeros for lanes without a view)
       bf16x8 dkp[2];
@@ -1004,12 +1008,12 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
           a2[1] = __builtin_bit_cast(bf16x8, ld128(A2, ok ? view * 64u + 32u * h + 16u : OOB));
         } else {
           const f32x16 t1 = CH_MFMA(lds_op(s_ops, OP_W1, lane), pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
-          act_fold(t1, keep, a1);
+          act_fold<false>(t1, keep, a1);
           const f32x16 t2 = mm32_lds(s_ops, OP_W2, lane, a1, bias_acc(s_tab[1], T_B6, h));
-          act_fold(t2, keep, a2);
+          act_fold<false>(t2, keep, a2);
         }
         z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
-        act_pack(z5, s_tab[2], h, keep, a5);
+        act_pack<false>(z5, s_tab[2], h, keep, a5);      // unmasked: dz6 below is (pack16), so da5 = dy5 = 0 without a view
       }
       tileN_put_packed(tb_, j, h, a5);
       const float dc4[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
@@ -1056,7 +1060,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       act_fold(t1, 0xffffffffu, a1);
       {
         const f32x16 t2 = mm32_lds(s_ops, L_W2F, lane, a1, bias_acc(s_tab[1], T_B6, h));
-        act_fold(t2, keep, a2);
+        act_fold<MERGED>(t2, keep, a2);      // unmasked: dz5 is masked (pack16) before it meets a2 in the dW5 product
       }
       {
         const f32x16 z5 = mm32_lds(s_ops, OP_W5, lane, a2, uacc);
@@ -1196,7 +1200,7 @@ __global__ __launch_bounds__(256, OCC) void layer_bwd_kernel(
       const bf16x8 xp = pack_x(p.x);
       {
         const f32x16 t1 = CH_MFMA(lds_op(s_ops, L_W1F, lane), xp, bias_acc(s_tab[0], T_B6, h));
-        act_fold(t1, keep, a1);
+        act_fold<false>(t1, keep, a1);       // unmasked: dz2 is masked (pack16) before the dW2 product and da1
       }
       // dy2 of the view path (stage 5) + the gradient of the max-pooled set features, which goes to the arg view of
       // each channel; dpooled arrives as leaky'(y*) dpooled (dva_chain_route_stats: the set pooling saw the plain y2)

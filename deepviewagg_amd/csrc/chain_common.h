@@ -300,6 +300,15 @@ __device__ __forceinline__ void stage_tab_fwd(float* tab, const float* __restric
 //   t = z * (0.6 G) + 0.6 B = 0.6 y;   leaky(y) = 0.6 y + 0.4 |y| = t + (2/3) |t|   (one fma with an |.| modifier)
 // keep = 0 zeroes the operand of a lane without a view.  The LDS reads stay inside the tile loop (asm barrier):
 // hoisting 32 constants per layer into registers costs an occupancy step.
+// MASK = false (round 6): the operand of a lane without a view is NOT zeroed.  A column of the B operand only reaches the
+// same column of the product, so the garbage (finite: such a lane loaded zeros) stays in lanes that own no view; what has
+// to be exact is every REDUCTION OVER VIEWS, and each of those is guarded where it happens (statistics under `if (ok)`,
+// gradient rows masked by pack16 before the weight-gradient products).  v_cndmask costs two issue slots (tools/ubench):
+// the eight per layer and tile were a quarter of the vector time of a statistics pass.
+#ifndef DVA_MASK_ACT
+#define DVA_MASK_ACT 0      // 1: the A/B build (csrc/Makefile EXTRA=-DDVA_MASK_ACT=1) keeps every activation mask
+#endif
+template <bool MASK_ = true>
 __device__ __forceinline__ void act_pack(const f32x16& z, const float* tab, int h, uint32_t keep, bf16x8 (&a)[2],
                                          int rg = T_G6, int rb = T_B6, float* sum = nullptr) {
   asm volatile("" ::: "memory");
@@ -315,8 +324,9 @@ __device__ __forceinline__ void act_pack(const f32x16& z, const float* tab, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) sum[r] += av[r];
   }
-  a[0] = mask8(pack8(&av[0]), keep);
-  a[1] = mask8(pack8(&av[8]), keep);
+  constexpr bool MASK = MASK_ || DVA_MASK_ACT;
+  a[0] = MASK ? mask8(pack8(&av[0]), keep) : pack8(&av[0]);
+  a[1] = MASK ? mask8(pack8(&av[8]), keep) : pack8(&av[8]);
 }
 
 // ---- BatchNorm folded into the weight operand ---------------------------------------------------------------------
@@ -367,6 +377,7 @@ __device__ __forceinline__ f32x16 bias_acc(const float* tab, int row, int h) {
   return c;
 }
 // activation of a folded layer (t = 0.6 y from the product) + bf16 packing as the next B operand
+template <bool MASK_ = true>
 __device__ __forceinline__ void act_fold(const f32x16& t, uint32_t keep, bf16x8 (&a)[2], float* sum = nullptr) {
   float av[16];
 #pragma unroll
@@ -375,8 +386,9 @@ __device__ __forceinline__ void act_fold(const f32x16& t, uint32_t keep, bf16x8 
 #pragma unroll
     for (int r = 0; r < 16; ++r) sum[r] += av[r];
   }
-  a[0] = mask8(pack8(&av[0]), keep);
-  a[1] = mask8(pack8(&av[8]), keep);
+  constexpr bool MASK = MASK_ || DVA_MASK_ACT;
+  a[0] = MASK ? mask8(pack8(&av[0]), keep) : pack8(&av[0]);
+  a[1] = MASK ? mask8(pack8(&av[8]), keep) : pack8(&av[8]);
 }
 
 // ---- statistics ------------------------------------------------------------------------------------------------

@@ -314,12 +314,14 @@ __global__ __launch_bounds__(256, 3) void stats2_kernel(
     const f32x16 zero = {0};
     const f32x16 t1 = CH_MFMA(w1, pack_x(p.x), bias_acc(s_tab, T_B6, h));
     bf16x8 a1[2];
-    act_fold(t1, keep, a1, st[2]);
+    act_fold<false>(t1, keep, a1, st[2]);
     const f32x16 z2 = mm32(w2, a1, zero);
+    if (keep) {      // lanes without a view hold an unmasked a1: their z2 stays out of the sums (and of the walk below)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[0][r] += z2[r];
-      st[1][r] = __builtin_fmaf(z2[r], z2[r], st[1][r]);
+      for (int r = 0; r < 16; ++r) {
+        st[0][r] += z2[r];
+        st[1][r] = __builtin_fmaf(z2[r], z2[r], st[1][r]);
+      }
     }
     // tile -> LDS [view][channel]; lane c then walks the views of its channel in order
 #pragma unroll
@@ -491,9 +493,9 @@ __global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
     } else {
       const f32x16 t1 = CH_MFMA(w1, pack_x(p.x), bias_acc(s_tab[0], T_B6, h));
       bf16x8 a1[2];
-      act_fold(t1, keep, a1);
+      act_fold<false>(t1, keep, a1);
       const f32x16 t2 = mm32(w2, a1, bias_acc(s_tab[1], T_B6, h));
-      act_fold(t2, keep, a2);
+      act_fold<false>(t2, keep, a2);         // (the a2 row of a lane without a view is never stored: `ok` below)
       if (A2 == 1) {
         const uint32_t off = ok ? (uint32_t)(p.ti.v0 + j) * 64u + 32u * h : OOB;
         st128(A, off, __builtin_bit_cast(u32x4, a2[0]));
@@ -503,13 +505,15 @@ __global__ __launch_bounds__(256, L == 5 ? 4 : 3) void stats_mid_kernel(
     f32x16 z = mm32(w5, a2, uacc);
     if (L == 6) {
       bf16x8 a5[2];
-      act_pack(z, s_tab[2], h, keep, a5, T_G6, T_B6, st[2]);
+      act_pack<false>(z, s_tab[2], h, keep, a5, T_G6, T_B6, st[2]);
       z = mm32(w6, a5, zero);
     }
+    if (keep) {      // unmasked operands: the sums take the lanes that own a view
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[0][r] += z[r];
-      st[1][r] = __builtin_fmaf(z[r], z[r], st[1][r]);
+      for (int r = 0; r < 16; ++r) {
+        st[0][r] += z[r];
+        st[1][r] = __builtin_fmaf(z[r], z[r], st[1][r]);
+      }
     }
   });
   flush_stats<3>(st, stats, s_red);      // L == 5: the third row stays zero
