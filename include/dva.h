@@ -206,7 +206,7 @@ int dva_row_plan(const int32_t* row_idx, int64_t n_views, int64_t n_rows, int32_
                  void* stream);
 
 /* The row plan SPLIT in two (round 5; 512 < n_rows <= 2^18, otherwise DVA_ERR_UNSUPPORTED and the caller keeps dva_row_plan):
- * a two-pass stable MSD radix partition (digits key >> 9 | key & 511, tiles of 8192 views) whose offset tables are built
+ * a two-pass stable MSD radix partition (digits key >> 9 | key & 511, tiles of 4096 views -- DVA_PLAN_TILE=8192: 8192) whose offset tables are built
  * from the row keys alone -- dva_plan_split_build: row_ptr int32 [n_rows + 1], counts int32 [n_rows] (nullable), identical to
  * dva_row_plan's, and `tables` (dva_plan_split_table_bytes; kept by the caller until the backward); scratch: 2 n_views bytes,
  * free afterwards -- and whose two scatter passes move the 16-BYTE VIEW RECORDS of the attention backward themselves --
