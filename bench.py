@@ -595,6 +595,82 @@ def secondary_workload(name, device, dtype, log2_points, views, C, steps=10, war
     return out
 
 
+def two_setting_bilinear_workload(device, log2_points=20, views=32, C=64, steps=5, warmup=2):
+    """A multi-setting batch on the bilinear path: ImageData = two settings with different map sizes
+    (16 maps [C, 64, 128] and 16 maps [C, 32, 64]); every point is seen by views / 2 images of each, the views of the two
+    settings are concatenated and brought into point order (the reference's view_cat_sorting, core/multimodal/image.py:
+    1549-1588).  Lazy: ONE concatenated tap gather through fused_bilinear (ops.InterpolatedFeatures.cat); materialised:
+    the reference's dataflow (two [V_s, C] gathers, cat, index)."""
+    from deepviewagg_amd import ops
+    N, k = 1 << log2_points, views // 2
+    g = torch.Generator(device=device).manual_seed(2468)
+    geo = [(16, 64, 128), (16, 32, 64)]
+    up = 8
+    xs, packs, coords = [], [], []
+    for B, H, W in geo:
+        Vs = N * k
+        images = torch.arange(B, device=device)[:k].repeat(N) if k <= B else None
+        pixels = torch.stack([torch.randint(0, W * up, (Vs,), generator=g, device=device),
+                              torch.randint(0, H * up, (Vs,), generator=g, device=device)], 1).to(torch.int16)
+        xs.append(torch.randn(B, C, H, W, generator=g, device=device).bfloat16().contiguous(memory_format=torch.channels_last))
+        packs.append(ops.pack_gather_index(images.long(), torch.arange(Vs + 1, device=device), pixels, ratio=1.0))
+        res = torch.tensor([[W * up, H * up]], dtype=torch.float32, device=device)
+        coords.append((pixels / (res - 1))[:, [1, 0]].contiguous())
+    V = 2 * N * k
+    pt = torch.arange(N, device=device).view(-1, 1)
+    j = torch.arange(k, device=device).view(1, -1)
+    order = torch.cat([pt * k + j, N * k + pt * k + j], dim=1).reshape(-1)        # point order: setting A's views, then B's
+    csr = torch.arange(0, V + 1, 2 * k, dtype=torch.int64, device=device)
+    x_map = torch.rand(V, 8, generator=g, device=device)
+    x_3d = torch.randn(N, 4, generator=g, device=device)
+    atomic_pool, view_pool, fusion = build_modules(C, device)
+    grad_out = None
+
+    def one(lazy):
+        nonlocal grad_out
+        for x in xs:
+            x.requires_grad_(True)
+            x.grad = None
+        for p_ in view_pool.parameters():
+            p_.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            parts = [ops.lazy_gather_bilinear(x, pk, co, True) for x, pk, co in zip(xs, packs, coords)]
+            if lazy:
+                x_mod = ops.InterpolatedFeatures.cat(parts, order=order)
+            else:
+                x_mod = torch.cat([p_.materialize() for p_ in parts], dim=0)[order]
+            out = fusion(x_3d, view_pool(x_3d, x_mod, x_map, csr))
+        if grad_out is None:
+            grad_out = torch.randn(out.shape, device=device, dtype=out.dtype,
+                                   generator=torch.Generator(device=device).manual_seed(99)) / out.shape[0]
+        out.backward(grad_out)
+        return out.detach()
+
+    def timed(lazy, n, w):
+        for _ in range(w):
+            one(lazy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = one(lazy)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, sanity_values(out, xs[0].grad)
+    ms, sanity = timed(True, steps, warmup)
+    ops.TIMER = ops.KernelTimer()
+    one(True)
+    timer, ops.TIMER = ops.TIMER, None
+    kern = timer.summary()
+    ms_mat, sanity_mat = timed(False, 2, 1)
+    top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:6]
+    out = {"points": N, "views": V, "settings": [list(g_) for g_ in geo], "channels": C, "ms_per_step": ms,
+           "points_per_s": N / (ms * 1e-3), "fused_path": "emod_attn_fwd" in kern, "materialised_ms_per_step": ms_mat,
+           "speedup_vs_materialised": ms_mat / ms, "steps": steps, "sanity": sanity, "sanity_materialised": sanity_mat,
+           "top_kernels_ms": {n: v["ms"] / v["launches"] for n, v in top}}
+    del xs, packs, coords, x_map
+    torch.cuda.empty_cache()
+    return out
+
+
 def make_s3dis_batch_scene(device, dtype=torch.bfloat16, samples=4, points_per_sample=75_000, images_per_sample=4,
                            C=512, H=64, W=128, seed=77):
     """A batch the size the reference actually trains S3DIS on (BASELINE config 1): `batch_size: 4` spheres
@@ -1302,6 +1378,8 @@ def main():
                 "kitti360_pyramid_train": kitti360_pyramid_train(device, args.log2_points, views),
                 "s3dis_batch": s3dis_batch_workload(device),
                 "nonexact": nonexact_workload(device),
+                # a multi-setting batch (two map sizes) on the fused bilinear path (round 6)
+                "bilinear_two_settings": two_setting_bilinear_workload(device, args.log2_points, views),
             }
         if world == 1 and not args.no_cpu_baseline:
             # cpu_baseline.value = the build's own C + OpenMP restatement of the WHOLE step on all host

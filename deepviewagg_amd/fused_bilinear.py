@@ -120,7 +120,7 @@ class _EmodPool(torch.autograd.Function):
         # train mode: the first statistics pass walks the views in ANCHOR order (the plan the backward scatters through,
         # built here once): neighbouring lanes then read the same four rows of Y and the tap gathers become cache hits
         # (C_out = 32: one block per view, nothing to overlap the random record reads with -- 2.4 against 1.9 ms in view order)
-        plan = ops.anchor_plan(anchors, *bhw) if (training and ANCHOR_ORDER_STATS and C >= 64) else None
+        plan = ops.anchor_plan(anchors, bhw) if (training and ANCHOR_ORDER_STATS and C >= 64) else None
 
         def stats(layer, tab_a):
             s = ops.zeros_small(2 * C, torch.float64, dev)
@@ -226,7 +226,7 @@ class _EmodPool(torch.autograd.Function):
         #      backward is applied to the rows as they are read: no in-place pass over [V, C])
         dY = None
         if ctx.needs_input_grad[0]:
-            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, *ctx.bhw, plan=ctx.anchor_plan,
+            dY = ops.bilinear_scatter(da, rows4, w4, ctx.anchors, ctx.bhw, plan=ctx.anchor_plan,
                                       bn_backward=(za, tab_a, sm_a, Y if ANCHOR_GRAM else None)).to(Y.dtype)
         del da, za
         grads = chain_epilogue(lib, arena, S, module, x_map, csr_idx, dc, gwb, ctx.set_saved)
@@ -242,8 +242,9 @@ def pool(module, x_mod, x_map, csr_idx):
     # Linear_a on the map rows, its output channels in the kernels' position order (autograd: index + GEMM)
     Y = ops.tall_linear(x_mod.rows, lin_a.weight[kappa])
     csr_idx = ops._check_ptr(csr_idx)
-    B, _, H, W = x_mod.x.shape
-    return _EmodPool.apply(Y, x_mod.tap_rows, x_mod.tap_weights, x_mod.anchors, (B, H, W), x_map, csr_idx, module,
+    # (one (B, H, W) per setting: a multi-setting batch -- ops.InterpolatedFeatures.cat -- is one gather over stacked rows)
+    return _EmodPool.apply(Y, x_mod.tap_rows, x_mod.tap_weights, x_mod.anchors, tuple(x_mod.geometry), x_map, csr_idx,
+                           module,
                            module.group_scaling, 1e-12,
                            bn_a.weight, bn_a.bias, lin_b.weight, bn_b.weight, bn_b.bias,
                            *fused_chain.chain_params(module))

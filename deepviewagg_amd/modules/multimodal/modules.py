@@ -253,6 +253,10 @@ class UnimodalBranch(nn.Module):
             order = mod_data.view_cat_sorting
             if all(isinstance(x, ops.GatheredFeatures) for x in x_mod):
                 x_mod = ops.GatheredFeatures.cat(x_mod, order=order)
+            elif all(isinstance(x, ops.InterpolatedFeatures) for x in x_mod):
+                # bilinear gather of a multi-setting batch (round 6): the settings' taps as ONE lazy gather over the
+                # stacked map rows, so the view pooling keeps its fused path (fused_bilinear) instead of [V, C]
+                x_mod = ops.InterpolatedFeatures.cat(x_mod, order=order)
             else:
                 x_mod = torch.cat([x.materialize() if isinstance(x, ops.LAZY_TYPES) else x
                                    for x in x_mod], dim=0)[order]

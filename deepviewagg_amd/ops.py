@@ -477,13 +477,25 @@ def _anchor_chunk_images(B, bytes_per_image, device):
     return max(1, min(B, budget // max(bytes_per_image, 1)))
 
 
-def anchor_plan(anchors, B, H, W):
+def _geometry(B, H=None, W=None):
+    """[(B, H, W), ...] of the feature maps behind a bilinear gather: one triple, or one per SETTING of a multi-setting
+    batch (``InterpolatedFeatures.cat``: map rows and anchors of the settings are numbered one after the other)."""
+    return [(int(B), int(H), int(W))] if H is not None else [tuple(int(v) for v in g) for g in B]
+
+
+def n_anchors(geometry):
+    """Anchors of a geometry, WITHOUT the dummy anchor (which is the next id)."""
+    return sum(b * (h + 1) * (w + 1) for b, h, w in geometry)
+
+
+def anchor_plan(anchors, B, H=None, W=None):
     """The row plan over the ANCHORS of the views (``dva_gather_bilinear_taps_anchor``): ``(perm, row_ptr)`` with
-    B (H + 1) (W + 1) + 1 anchors (the last one = views without the 2 x 2 tap structure)."""
-    return row_plan(anchors, B * (H + 1) * (W + 1) + 1, with_counts=False, split=False)[0]
+    sum B (H + 1) (W + 1) + 1 anchors (the last one = views without the 2 x 2 tap structure).  ``B`` may be a list of
+    (B, H, W) triples (several settings)."""
+    return row_plan(anchors, n_anchors(_geometry(B, H, W)) + 1, with_counts=False, split=False)[0]
 
 
-def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=None, plan=None):
+def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H=None, W=None, bn_backward=None, plan=None):
     """Transpose of the bilinear gather: fp32 [B*H*W, C] = sum over the views and their 4 taps of weight x grad row.
     Views are grouped by ANCHOR (the padded cell of their top-left tap, ``dva_gather_bilinear_taps_anchor``): one
     sort of P keys, every gradient row read once into four per-anchor sums, then a 2 x 2 stencil on the map
@@ -495,9 +507,10 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
     lib = _lib.load()
     grad = grad.contiguous()
     P, C = grad.shape
-    per_image = (H + 1) * (W + 1)
-    n_anchor = B * per_image + 1                    # + the dummy anchor of views without the 2 x 2 structure
-    perm, row_ptr = plan if plan is not None else anchor_plan(anchors, B, H, W)
+    geometry = _geometry(B, H, W)                   # several settings: rows and anchors numbered setting after setting
+    n_rows = sum(b * h * w for b, h, w in geometry)
+    dummy = n_anchors(geometry)                     # the anchor of views without the 2 x 2 structure
+    perm, row_ptr = plan if plan is not None else anchor_plan(anchors, geometry)
     st = stream_of(grad)
     es = grad.element_size()
     if bn_backward is not None:
@@ -513,30 +526,40 @@ def bilinear_scatter(grad, tap_rows, tap_weights, anchors, B, H, W, bn_backward=
     # The per-anchor sums S [anchors, 4, C] fp32 are 4 x the map gradient: bounded workspace, the images
     # go through in chunks when it would exceed the budget (anchors are image-major, so a chunk of images is a
     # contiguous range of the plan; the dummy anchor's views are added tap by tap by the fix-up below)
-    imgs = _anchor_chunk_images(B, per_image * 4 * C * 4, grad.device)
-    out = torch.empty((B * H * W, C), dtype=torch.float32, device=grad.device)
-    S = torch.empty((min(imgs, B) * per_image + 1, 4, C), dtype=torch.float32, device=grad.device)
-    for b0 in range(0, B, imgs):
-        nb = min(imgs, B - b0)
-        a0, na = b0 * per_image, nb * per_image
-        rp = row_ptr[a0:a0 + na + 1]
-        with _timed("bilinear_anchor_sum", P * (C * es * (2 if two_rows else 1) + 20) * nb // B + na * 4 * C * 4):
-            if bn_backward is None:
-                check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(rp), ptr(tap_weights), ptr(S), na, P, C,
-                                              dtype_code(grad), st), "dva_anchor_rows_sum")
-            else:
-                check(lib.dva_anchor_rows_sum_bn(ptr(grad), None if Y is not None else ptr(z_a), ptr(bn_a), ptr(sm_a),
-                                                 ptr(perm), ptr(rp), ptr(tap_weights),
-                                                 ptr(tap_rows) if Y is not None else None, ptr(Y), ptr(S), na, P, C,
-                                                 st), "dva_anchor_rows_sum_bn")
-        with _timed("bilinear_anchor_combine", na * 4 * C * 4 + nb * H * W * C * 4):
-            check(lib.dva_anchor_combine(ptr(S), ptr(out[b0 * H * W:]), nb, H, W, C, st), "dva_anchor_combine")
+    out = torch.empty((n_rows, C), dtype=torch.float32, device=grad.device)
+    chunks = [_anchor_chunk_images(b, (h + 1) * (w + 1) * 4 * C * 4, grad.device) for b, h, w in geometry]
+    S = torch.empty((max(min(i, b) * (h + 1) * (w + 1) for i, (b, h, w) in zip(chunks, geometry)) + 1, 4, C),
+                    dtype=torch.float32, device=grad.device)
+    n_views_anchored = max(dummy, 1)
+    a_off = r_off = 0
+    for imgs, (Bs, Hs, Ws) in zip(chunks, geometry):
+        per_image = (Hs + 1) * (Ws + 1)
+        for b0 in range(0, Bs, imgs):
+            nb = min(imgs, Bs - b0)
+            a0, na = a_off + b0 * per_image, nb * per_image
+            rp = row_ptr[a0:a0 + na + 1]
+            with _timed("bilinear_anchor_sum",
+                        P * (C * es * (2 if two_rows else 1) + 20) * na // n_views_anchored + na * 4 * C * 4):
+                if bn_backward is None:
+                    check(lib.dva_anchor_rows_sum(ptr(grad), ptr(perm), ptr(rp), ptr(tap_weights), ptr(S), na, P, C,
+                                                  dtype_code(grad), st), "dva_anchor_rows_sum")
+                else:
+                    check(lib.dva_anchor_rows_sum_bn(ptr(grad), None if Y is not None else ptr(z_a), ptr(bn_a),
+                                                     ptr(sm_a), ptr(perm), ptr(rp), ptr(tap_weights),
+                                                     ptr(tap_rows) if Y is not None else None, ptr(Y), ptr(S), na, P, C,
+                                                     st), "dva_anchor_rows_sum_bn")
+            with _timed("bilinear_anchor_combine", na * 4 * C * 4 + nb * Hs * Ws * C * 4):
+                check(lib.dva_anchor_combine(ptr(S), ptr(out[r_off + b0 * Hs * Ws:]), nb, Hs, Ws, C, st),
+                      "dva_anchor_combine")
+        a_off += Bs * per_image
+        r_off += Bs * Hs * Ws
+    # views of the dummy anchor, tap by tap: the entries only take the dummy id from (B, H, W) = B (H + 1) (W + 1)
     if bn_backward is None:
-        check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, B, H, W, C,
+        check(lib.dva_anchor_fixup(ptr(grad), ptr(tap_rows), ptr(tap_weights), ptr(anchors), ptr(out), P, dummy, 0, 0, C,
                                    dtype_code(grad), st), "dva_anchor_fixup")
     else:
         check(lib.dva_anchor_fixup_bn(ptr(grad), ptr(z_a), ptr(bn_a), ptr(sm_a), ptr(tap_rows), ptr(tap_weights),
-                                      ptr(anchors), ptr(out), P, B, H, W, C, st), "dva_anchor_fixup_bn")
+                                      ptr(anchors), ptr(out), P, dummy, 0, 0, C, st), "dva_anchor_fixup_bn")
     return out
 
 
@@ -989,6 +1012,40 @@ class InterpolatedFeatures:
         self.tap_rows, self.tap_weights, self.anchors = tap_rows, tap_weights, anchors
         B, C, H, W = x.shape
         self.rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)      # view when x is channels_last
+        self.geometry = [(B, H, W)]     # one (B, H, W) per setting: rows / anchors are numbered setting after setting
+        self.parts = self.order = None  # cat(): the per-setting gathers and the view order (materialize goes through them)
+
+    @staticmethod
+    def cat(items, order=None):
+        """The views of several SETTINGS (feature maps of different sizes, ``ImageData`` = list of
+        ``SameSettingImageData``) as one lazy gather, optionally permuted into point order (reference
+        modules/multimodal/modules.py:514-525 + core/multimodal/image.py:1549-1588 ``view_cat_sorting``: the reference
+        concatenates the materialised [V_s, C] tensors and indexes the result).  The map rows of the settings are stacked
+        ([sum R_s, C], differentiable), tap rows and anchors offset into the stacked numbering, so a consumer of taps
+        (fused_bilinear) sees one gather; ``materialize()`` still evaluates setting by setting."""
+        if len(items) == 1 and order is None:
+            return items[0]
+        assert all(isinstance(it, InterpolatedFeatures) and it.parts is None for it in items)
+        out = InterpolatedFeatures.__new__(InterpolatedFeatures)
+        out.x = out.packed_idx = out.coords = None
+        out.parts, out.order = list(items), order
+        out.exact = all(it.exact for it in items)
+        out.geometry = [g for it in items for g in it.geometry]
+        out.rows = torch.cat([it.rows for it in items], dim=0)
+        dummy = n_anchors(out.geometry)
+        r_off = a_off = 0
+        rows4, anchors = [], []
+        for it in items:
+            na = n_anchors(it.geometry)
+            rows4.append(it.tap_rows + r_off)
+            anchors.append(torch.where(it.anchors == na, torch.full_like(it.anchors, dummy), it.anchors + a_off))
+            r_off += it.rows.shape[0]
+            a_off += na
+        rows4, w4, anchors = torch.cat(rows4), torch.cat([it.tap_weights for it in items]), torch.cat(anchors)
+        if order is not None:
+            rows4, w4, anchors = rows4[order], w4[order], anchors[order]
+        out.tap_rows, out.tap_weights, out.anchors = rows4.contiguous(), w4.contiguous(), anchors.contiguous()
+        return out
 
     @property
     def shape(self):
@@ -1008,6 +1065,10 @@ class InterpolatedFeatures:
     def materialize(self, rows=None):
         """The reference's [P, C] tensor; ``rows`` [R, C']: the same interpolation of another per-row tensor (a linear
         function of the map rows, e.g. the hoisted first Linear of E_mod)."""
+        if self.parts is not None:      # several settings: setting by setting, then the view order of cat()
+            splits = [None] * len(self.parts) if rows is None else torch.split(rows, [p.rows.shape[0] for p in self.parts])
+            out = torch.cat([p.materialize(rows=r) for p, r in zip(self.parts, splits)], dim=0)
+            return out if self.order is None else out[self.order]
         if rows is None:
             return gather_bilinear(self.x, self.packed_idx, self.coords)
         B, _, H, W = self.x.shape

@@ -422,6 +422,69 @@ def gen_branch():
         save(f"branch_{'bilinear' if interp else 'nearest'}", **res, **sd_conv, **sd_pool)
 
 
+def gen_branch_fused():
+    """The two-setting UnimodalBranch of gen_branch at the width the product's fused bilinear path starts at (out_mod = 32,
+    interpolate=True): ImageData with two settings of different map sizes, view_cat_sorting into point order
+    (core/multimodal/image.py:1549-1588, modules/multimodal/modules.py:514-525).  Inputs and the 2D encoder's weights lie on
+    the bf16 grid (the product runs this under autocast).  Own generator: gen_branch's files do not change."""
+    print("UnimodalBranch, two settings, interpolate=True, out_mod = 32 (the fused bilinear path's multi-setting case)")
+    gen = torch.Generator().manual_seed(55)
+    N, C3d, C_in, C = 600, 5, 6, 32
+    settings = [dict(B=3, ref=(32, 16), hw=(16, 32)), dict(B=2, ref=(64, 32), hw=(32, 64))]
+
+    def dense(B, ref):
+        pts, imgs = [], []
+        for p in range(N):
+            k = int(torch.randint(0, B + 1, (1,), generator=gen))
+            pts += [p] * k
+            imgs += torch.randperm(B, generator=gen)[:k].tolist()
+        pts, imgs = torch.LongTensor(pts), torch.LongTensor(imgs)
+        pix = torch.stack([torch.randint(0, ref[0], (len(pts),), generator=gen),
+                           torch.randint(0, ref[1], (len(pts),), generator=gen)], dim=1).short()
+        return pts, imgs, pix, torch.rand(len(pts), 8, generator=gen)
+
+    data = [dense(s['B'], s['ref']) for s in settings]
+    sds, xs = [], []
+    for s, (pts, imgs, pix, feats) in zip(settings, data):
+        mapping = ref_image.ImageMapping.from_dense(pts, imgs, pix, feats, num_points=N)
+        sd = ref_image.SameSettingImageData(
+            path=np.array([f'img_{i}' for i in range(s['B'])]), pos=torch.zeros(s['B'], 3),
+            opk=torch.zeros(s['B'], 3), ref_size=s['ref'], proj_upscale=1, mappings=mapping)
+        x = torch.randn(s['B'], C_in, *s['hw'], generator=gen).bfloat16().float().requires_grad_()
+        sd.x = x
+        sds.append(sd)
+        xs.append(x)
+    conv = _RefConv(C_in, C)
+    view_pool = ref_pooling.GroupBimodalCSRPool(in_map=8, in_mod=C, num_groups=4, use_num=True)
+    randomize(conv, gen)
+    randomize(view_pool, gen)
+    with torch.no_grad():
+        for p_ in conv.parameters():
+            p_.copy_(p_.bfloat16().float())
+    branch = ref_modules.UnimodalBranch(
+        conv, ref_pooling.BimodalCSRPool(mode='max'), view_pool,
+        ref_fusion.BimodalFusion(mode='concatenation'), interpolate=True)
+    branch.train()
+    sd_conv, sd_pool = state(conv, 'sd_conv/'), state(view_pool, 'sd_pool/')
+    x_3d = torch.randn(N, C3d, generator=gen, requires_grad=True)
+    mm = {'x_3d': x_3d, 'x_seen': None, 'modalities': {'image': ref_image.ImageData(sds)}}
+    out = branch(mm, 'image')
+    y = out['x_3d']
+    w = torch.randn(y.shape, generator=gen)
+    params = list(view_pool.parameters())
+    grads = torch.autograd.grad((y * w).sum(), xs + [x_3d] + params)
+    res = dict(x_3d=x_3d, out=y, x_seen=out['x_seen'], w=w, grad_x_3d=grads[len(xs)], n_settings=np.array(len(settings)))
+    for (n, _), g in zip(view_pool.named_parameters(), grads[len(xs) + 1:]):
+        res['gp/' + n] = g
+    for i, (s, (pts, imgs, pix, feats), sd) in enumerate(zip(settings, data, sds)):
+        m = sd.mappings
+        res.update({f's{i}_x_img': xs[i], f's{i}_grad_x_img': grads[i], f's{i}_point_ids': pts,
+                    f's{i}_image_ids': imgs, f's{i}_pixels_dense': pix,
+                    f's{i}_map_features_dense': feats, f's{i}_pointers': m.pointers,
+                    f's{i}_ref_size': np.array(s['ref'])})
+    save("branch_bilinear_c32", **res, **sd_conv, **sd_pool)
+
+
 # ------------------------------------------------------------------------------------------------
 def room_cloud(n, gen, size=(4.0, 4.0, 2.5)):
     """Points on the six faces of a room box + small noise (notebook cell 4 of
@@ -932,7 +995,7 @@ if __name__ == "__main__":
     jobs = dict(softmax=gen_softmax, segment=gen_segment, pools=gen_pools, pools_headline=gen_pools_headline,
                 pools_bilinear=gen_pools_bilinear,
                 gather=gen_gather,
-                branch=gen_branch, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
+                branch=gen_branch, branch_fused=gen_branch_fused, visibility=gen_visibility, lex=gen_lex_and_csr, mapping=gen_mapping,
                 transforms=gen_transforms, cylinder=gen_mapping_cylinder,
                 neighborhood=gen_neighborhood, visibility_models=gen_visibility_models)
     for name, fn in jobs.items():

@@ -34,6 +34,8 @@ elif name == "s3dis_eager":
     r = bench.s3dis_batch_workload(dev, steps=steps, warmup=0, graph=False)
 elif name == "nonexact":
     r = bench.nonexact_workload(dev, steps=steps)
+elif name == "two_settings":
+    r = bench.two_setting_bilinear_workload(dev, 20, 32, steps=steps)
 elif name == "pyramid_eval":
     r = bench.kitti360_pyramid_eval(dev, 20, 32, steps=steps)
 elif name == "pyramid_train":
