@@ -152,6 +152,7 @@ SIGNATURES = {
     "dva_chain_score_stats": (ctypes.c_int, [_vp] * 14 + [_i32, _i64, _i64, _vp]),
     "dva_chain_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i32, _i64, _i64, _vp]),
     "dva_gather_bilinear_taps_anchor": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "dva_bilinear_taps_cat": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dva_anchor_rows_sum": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "dva_anchor_combine": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dva_anchor_fixup": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -287,6 +287,40 @@ __global__ __launch_bounds__(256) void bilinear_taps_kernel(const PackedIdx* __r
   }
 }
 
+// The taps of several SETTINGS (feature maps of different sizes) as one gather over the stacked map rows, in a given view
+// order (reference core/multimodal/image.py:1549-1588 view_cat_sorting applied to the concatenated [V_s, C] tensors,
+// modules/multimodal/modules.py:514-525): view i of the result = view order[i] of the concatenation; its tap rows move by the
+// row offset of its setting, its anchor by the anchor offset (the per-setting dummy anchor becomes the common one).
+constexpr int TAPS_CAT_MAX = 8;
+struct TapsCatArgs {
+  const int4* rows[TAPS_CAT_MAX];
+  const float4* weights[TAPS_CAT_MAX];
+  const int32_t* anchors[TAPS_CAT_MAX];
+  int64_t v_end[TAPS_CAT_MAX];       // exclusive prefix ends of the settings' view ranges in the concatenation
+  int32_t row_off[TAPS_CAT_MAX], anchor_off[TAPS_CAT_MAX], n_anchor[TAPS_CAT_MAX];
+  int32_t n, dummy;
+};
+__global__ __launch_bounds__(256) void taps_cat_kernel(TapsCatArgs a, const int64_t* __restrict__ order, int64_t V,
+                                                       int4* __restrict__ rows_out, float4* __restrict__ w_out,
+                                                       int32_t* __restrict__ anchors_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = order ? order[i] : i;
+    int s = 0;
+    int64_t base = 0;
+#pragma unroll
+    for (int k = 0; k < TAPS_CAT_MAX - 1; ++k)
+      if (k + 1 < a.n && src >= a.v_end[k]) { s = k + 1; base = a.v_end[k]; }
+    const int64_t l = src - base;
+    int4 r = a.rows[s][l];
+    const int32_t ro = a.row_off[s];
+    r.x += ro; r.y += ro; r.z += ro; r.w += ro;
+    rows_out[i] = r;
+    w_out[i] = a.weights[s][l];
+    const int32_t an = a.anchors[s][l];
+    anchors_out[i] = an == a.n_anchor[s] ? a.dummy : an + a.anchor_off[s];
+  }
+}
+
 // dY[r][c] (fp32, written) from the per-anchor sums S[a][k][c] of dva_anchor_rows_sum: row (b, y, x) collects the padded
 // cells that replicate it -- (py, px) with clamp(py - 1) = y, clamp(px - 1) = x -- and a padded cell collects tap k of
 // the anchors it is tap k of: S0[py][px] + S1[py][px - 1] + S2[py - 1][px] + S3[py - 1][px - 1].
@@ -737,6 +771,40 @@ int dva_gather_bilinear_taps_anchor(const void* packed_idx, const float* coords,
   hipLaunchKernelGGL(bilinear_taps_kernel, dim3(grid_for(n_atoms)), dim3(256), 0, (hipStream_t)stream,
                      (const PackedIdx*)packed_idx, coords, n_atoms, H, W, rows, weights, anchors,
                      (int32_t)((int64_t)B * (H + 1) * (W + 1)));
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
+int dva_bilinear_taps_cat(int32_t n_settings, const void* const* tap_rows, const void* const* tap_weights,
+                          const void* const* anchors, const int64_t* n_views, const int64_t* n_rows,
+                          const int64_t* n_anchors, const int64_t* order, int64_t n_views_total, int32_t* rows_out,
+                          float* weights_out, int32_t* anchors_out, void* stream) {
+  if (n_settings < 1 || n_views_total < 0 || !tap_rows || !tap_weights || !anchors || !n_views || !n_rows || !n_anchors)
+    return DVA_ERR_INVALID;
+  if (n_settings > TAPS_CAT_MAX) return DVA_ERR_UNSUPPORTED;
+  TapsCatArgs a;
+  int64_t v = 0, r = 0, an = 0;
+  for (int s = 0; s < TAPS_CAT_MAX; ++s) {
+    const bool on = s < n_settings;
+    if (on && (n_views[s] < 0 || n_rows[s] < 0 || n_anchors[s] < 0)) return DVA_ERR_INVALID;
+    if (on && n_views[s] > 0 && (!tap_rows[s] || !tap_weights[s] || !anchors[s])) return DVA_ERR_INVALID;
+    a.rows[s] = on ? (const int4*)tap_rows[s] : nullptr;
+    a.weights[s] = on ? (const float4*)tap_weights[s] : nullptr;
+    a.anchors[s] = on ? (const int32_t*)anchors[s] : nullptr;
+    a.row_off[s] = (int32_t)r;
+    a.anchor_off[s] = (int32_t)an;
+    a.n_anchor[s] = on ? (int32_t)n_anchors[s] : 0;
+    if (on) { v += n_views[s]; r += n_rows[s]; an += n_anchors[s]; }
+    a.v_end[s] = v;
+  }
+  if (v != n_views_total) return DVA_ERR_INVALID;
+  if (r >= 0x7fffffffLL || an >= 0x7fffffffLL) return DVA_ERR_UNSUPPORTED;
+  if (n_views_total == 0) return DVA_OK;
+  if (!rows_out || !weights_out || !anchors_out) return DVA_ERR_INVALID;
+  a.n = n_settings;
+  a.dummy = (int32_t)an;
+  hipLaunchKernelGGL(taps_cat_kernel, dim3(grid_for(n_views_total)), dim3(256), 0, (hipStream_t)stream, a, order,
+                     n_views_total, (int4*)rows_out, (float4*)weights_out, anchors_out);
   DVA_CHECK_LAUNCH();
   return DVA_OK;
 }

@@ -1032,19 +1032,27 @@ class InterpolatedFeatures:
         out.exact = all(it.exact for it in items)
         out.geometry = [g for it in items for g in it.geometry]
         out.rows = torch.cat([it.rows for it in items], dim=0)
-        dummy = n_anchors(out.geometry)
-        r_off = a_off = 0
-        rows4, anchors = [], []
-        for it in items:
-            na = n_anchors(it.geometry)
-            rows4.append(it.tap_rows + r_off)
-            anchors.append(torch.where(it.anchors == na, torch.full_like(it.anchors, dummy), it.anchors + a_off))
-            r_off += it.rows.shape[0]
-            a_off += na
-        rows4, w4, anchors = torch.cat(rows4), torch.cat([it.tap_weights for it in items]), torch.cat(anchors)
+        # one pass (dva_bilinear_taps_cat): concatenate, offset rows / anchors into the stacked numbering, permute
+        import ctypes
+        lib = _lib.load()
+        S = len(items)
+        dev = items[0].tap_rows.device
+        V = sum(it.tap_rows.shape[0] for it in items)
         if order is not None:
-            rows4, w4, anchors = rows4[order], w4[order], anchors[order]
-        out.tap_rows, out.tap_weights, out.anchors = rows4.contiguous(), w4.contiguous(), anchors.contiguous()
+            order = order.to(torch.int64).contiguous()
+            assert order.shape[0] == V
+        keep = [(it.tap_rows.contiguous(), it.tap_weights.contiguous(), it.anchors.contiguous()) for it in items]
+        arr = lambda k: (ctypes.c_void_p * S)(*[t[k].data_ptr() for t in keep])
+        i64 = lambda vals: (ctypes.c_int64 * S)(*vals)
+        rows4 = torch.empty((V, 4), dtype=torch.int32, device=dev)
+        w4 = torch.empty((V, 4), dtype=torch.float32, device=dev)
+        anchors = torch.empty(V, dtype=torch.int32, device=dev)
+        with _timed("bilinear_taps_cat", V * (8 + 2 * 36)):
+            check(lib.dva_bilinear_taps_cat(S, arr(0), arr(1), arr(2), i64([t[0].shape[0] for t in keep]),
+                                            i64([it.rows.shape[0] for it in items]),
+                                            i64([n_anchors(it.geometry) for it in items]), ptr(order), V, ptr(rows4),
+                                            ptr(w4), ptr(anchors), stream_of(rows4)), "dva_bilinear_taps_cat")
+        out.tap_rows, out.tap_weights, out.anchors = rows4, w4, anchors
         return out
 
     @property

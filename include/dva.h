@@ -274,6 +274,18 @@ int dva_gather_rows_sum(const void* grad_out, const int32_t* perm, const int32_t
 int dva_gather_bilinear_taps_anchor(const void* packed_idx, const float* coords, int64_t n_atoms, int32_t B,
                                     int32_t H, int32_t W, int32_t* rows, float* weights, int32_t* anchors,
                                     void* stream);
+/* The taps of n_settings <= 8 SETTINGS (feature maps of different sizes; the outputs of dva_gather_bilinear_taps_anchor per
+ * setting) as ONE gather over the stacked map rows, in a given view order -- the reference concatenates the materialised
+ * [V_s, C] tensors of the settings and indexes the result with view_cat_sorting (core/multimodal/image.py:1549-1588,
+ * modules/multimodal/modules.py:514-525); here the taps are concatenated instead and no [V, C] tensor exists.
+ * tap_rows / tap_weights / anchors: HOST arrays of n_settings device pointers; n_views / n_rows / n_anchors: HOST arrays
+ * (views, map rows B H W, anchors B (H + 1) (W + 1) of every setting).  order int64 [n_views_total] (device, nullable =
+ * identity): view i of the result = view order[i] of the concatenation.  Tap rows are offset by the rows of the settings
+ * before, anchors by their anchors; a setting's dummy anchor (= its n_anchors) becomes the common one (= sum n_anchors). */
+int dva_bilinear_taps_cat(int32_t n_settings, const void* const* tap_rows, const void* const* tap_weights,
+                          const void* const* anchors, const int64_t* n_views, const int64_t* n_rows,
+                          const int64_t* n_anchors, const int64_t* order, int64_t n_views_total, int32_t* rows_out,
+                          float* weights_out, int32_t* anchors_out, void* stream);
 int dva_anchor_rows_sum(const void* grad_out, const int32_t* perm, const int32_t* row_ptr, const float* weights,
                         float* S, int64_t n_anchors, int64_t n_views, int32_t C, int32_t dtype, void* stream);
 int dva_anchor_combine(const float* S, float* grad_rows, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);

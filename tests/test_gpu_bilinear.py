@@ -499,3 +499,46 @@ def test_fused_bilinear_matches_bf16_emulation(sizes_fn, N, C_in, C_out, G, trai
     assert not bad, (bad, report)
     if train:
         assert sorted(par)[len(par) // 2] < EMU_TOL["param_train_median"], report
+
+
+def test_interpolated_features_cat_equals_torch_composition():
+    """ops.InterpolatedFeatures.cat (dva_bilinear_taps_cat): the taps of three settings concatenated, offset into the stacked
+    row / anchor numbering and permuted -- against the same thing spelled with torch ops; materialize() of the result =
+    the reference's dataflow (cat of the settings' [V_s, C] gathers, indexed by the order)."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    geo = [(3, 12, 20), (2, 7, 9), (4, 16, 8)]
+    items = []
+    for (B, H, W), P in zip(geo, (5000, 1, 3000)):
+        x = torch.randn(B, 16, H, W, generator=gen).to(DEV)
+        images = torch.randint(0, B, (P,), generator=gen)
+        pixels = torch.stack([torch.randint(0, 4 * W, (P,), generator=gen), torch.randint(0, 4 * H, (P,), generator=gen)], 1)
+        packed = ops.pack_gather_index(images.to(DEV), torch.arange(P + 1, device=DEV), pixels.short().to(DEV), ratio=1.0)
+        res = torch.tensor([[4 * W, 4 * H]], dtype=torch.float32)
+        coords = (pixels / (res - 1))[:, [1, 0]].contiguous().to(DEV)
+        # (q + 1 rounding across an integer: a few views get the dummy anchor)
+        items.append(ops.lazy_gather_bilinear(x, packed, coords, True))
+    V = sum(it.shape[0] for it in items)
+    order = torch.randperm(V, generator=gen).to(DEV)
+    for od in (order, None):
+        cat = ops.InterpolatedFeatures.cat(items, order=od)
+        dummy = ops.n_anchors(geo)
+        r_off = a_off = 0
+        rows4, anchors = [], []
+        for it, g in zip(items, geo):
+            na = ops.n_anchors([g])
+            rows4.append(it.tap_rows + r_off)
+            anchors.append(torch.where(it.anchors == na, torch.full_like(it.anchors, dummy), it.anchors + a_off))
+            r_off += it.rows.shape[0]
+            a_off += na
+        rows4, w4, anchors = torch.cat(rows4), torch.cat([it.tap_weights for it in items]), torch.cat(anchors)
+        if od is not None:
+            rows4, w4, anchors = rows4[od], w4[od], anchors[od]
+        assert torch.equal(cat.tap_rows, rows4) and torch.equal(cat.tap_weights, w4) and torch.equal(cat.anchors, anchors)
+        assert cat.geometry == [tuple(g) for g in geo] and cat.rows.shape[0] == r_off and cat.shape == (V, 16)
+        want = torch.cat([it.materialize() for it in items])
+        assert torch.equal(cat.materialize(), want if od is None else want[od])
+        # the taps reproduce the gather on the stacked rows
+        via_taps = (cat.rows[cat.tap_rows.long()].float() * cat.tap_weights.unsqueeze(-1)).sum(1)
+        torch.testing.assert_close(via_taps, cat.materialize().float(), rtol=1e-5, atol=1e-5)
+    assert ops.InterpolatedFeatures.cat(items[:1]) is items[0]
