@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help=argparse.SUPPRESS)   # launcher + process group + rank/device census only, no HIP work
     ap.add_argument("--no-standin", action="store_true", help="N > 1: no stand-in bucket (same as --standin-mb 0)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (the "
+                         "stamped file of the last evidence pass is used instead)")
     ap.add_argument("--detail-file", default=None,
                     help="where the full record goes (default: bench_detail.json in the repo root and in gpurun_out/)")
     ap.add_argument("--workload", default="S1", choices=["S1", "S2", "S1c"],
@@ -143,7 +146,7 @@ def build_modules(C, device, C_out=None, pool="group"):
 # HIP-event timer name -> kernel symbol in the rocprofv3 outputs (bf16 headline workload)
 KERNEL_SYMBOL = {
     "chain_attn_fwd": "chain::attn_fwd_kernel<8, 4, 4>",
-    "chain_attn_bwd": "chain::attn_bwd_kernel<8, 4>",
+    "chain_attn_bwd": "chain::attn_bwd_kernel<unsigned short, 8, 4>",
     "chain_score_stats": "chain::score_stats_kernel",
     "chain_bwd_l6": "chain::layer_bwd_kernel<6, 3>",
     "chain_bwd_l5": "chain::layer_bwd_kernel<5, 3>",
@@ -173,6 +176,68 @@ ROOFLINE_NOTES = {
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 
 
+_LIVE_PMC = {"table": None, "why": "not run"}
+
+
+def live_pmc_passes(timeout_s=240):
+    """HBM traffic MEASURED IN THIS RUN: two child runs of this same script on the default workload
+    (1 step after 1 warm-up, no secondary work) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes
+    with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes (the two counters do not fit one pass) --
+    summarised by profiles/summarize_pmc.py (KiB units, FETCH_SIZE x 2 on gfx950, calibration on the copy kernel).  Fills
+    _LIVE_PMC; on any failure (no rocprofv3, time-out, empty output) the stamped file of the last evidence pass stays
+    the source and `why` says so."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        _LIVE_PMC["why"] = "rocprofv3 not found"
+        return
+    work = tempfile.mkdtemp(prefix="dva_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    child = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-mapping-build", "--no-secondary",
+             "--no-pmc", "--steps", "1", "--warmup", "1", "--detail-file", os.path.join(work, "child_detail.json")]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, f"pmc_{counter}")
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--output-format", "csv",
+                                "--"] + child, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            hits = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not hits:
+                _LIVE_PMC["why"] = f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+                return
+            want = os.path.join(out, "pmc_counter_collection.csv")
+            if os.path.abspath(hits[0]) != want:
+                shutil.copy(hits[0], want)
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import summarize_pmc
+        import contextlib
+        import io
+        dst = os.path.join(work, "pmc_traffic.json")
+        with contextlib.redirect_stdout(io.StringIO()):
+            summarize_pmc.main(work, dst)
+        _LIVE_PMC["table"] = json.load(open(dst))
+        _LIVE_PMC["why"] = None
+        gout = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(gout):
+            shutil.copy(dst, os.path.join(gout, "pmc_traffic_live.json"))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        _LIVE_PMC["why"] = f"live PMC passes failed: {type(e).__name__}: {str(e)[:160]}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def _pmc_lookup(table, timer_name):
+    sym = KERNEL_SYMBOL[timer_name]
+    entry = table.get(sym)
+    if entry is None:            # template arguments appended since the table of symbols was written: prefix match
+        hits = [v for k, v in table.items() if k.startswith(sym.rstrip(">")) and isinstance(v, dict) and "hbm_bytes" in v]
+        entry = max(hits, key=lambda v: v["hbm_bytes"]) if hits else None
+    return entry
+
+
 def pmc_traffic(timer_name, default_workload):
     """(HBM bytes per launch, reason) of the kernel from the committed rocprofv3 PMC passes of this same command
     (separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes;
@@ -183,20 +248,20 @@ def pmc_traffic(timer_name, default_workload):
     from deepviewagg_amd import _lib
     if not default_workload:
         return None, "not the workload the PMC passes were taken on"
+    if timer_name in KERNEL_SYMBOL and _LIVE_PMC["table"] is not None:
+        entry = _pmc_lookup(_LIVE_PMC["table"], timer_name)
+        if entry is not None:
+            return entry["hbm_bytes"], "live"
     if timer_name not in KERNEL_SYMBOL or not os.path.exists(PMC_TRAFFIC_FILE):
         return None, "no PMC pass for this kernel"
     table = json.load(open(PMC_TRAFFIC_FILE))
     stamp = (table.get("_stamp") or {}).get("csrc_sha256")
     if stamp != _lib.source_sha256():
-        return None, ("profiles/pmc_traffic_latest.json was taken on other kernel sources (stamp "
-                      f"{str(stamp)[:12]} != {_lib.source_sha256()[:12]}): re-run tools/gpu_evidence.sh")
-    sym = KERNEL_SYMBOL[timer_name]
-    entry = table.get(sym)
-    if entry is None:            # template arguments appended since the table of symbols was written: prefix match
-        hits = [v for k, v in table.items() if k.startswith(sym.rstrip(">")) and isinstance(v, dict) and "hbm_bytes" in v]
-        entry = max(hits, key=lambda v: v["hbm_bytes"]) if hits else None
+        return None, (f"live passes: {_LIVE_PMC['why']}; profiles/pmc_traffic_latest.json is of other kernel sources "
+                      f"(stamp {str(stamp)[:12]} != {_lib.source_sha256()[:12]})")
+    entry = _pmc_lookup(table, timer_name)
     if entry is None:
-        return None, f"kernel {sym} not in the PMC passes"
+        return None, f"kernel {KERNEL_SYMBOL[timer_name]} not in the PMC passes"
     return entry["hbm_bytes"], None
 
 
@@ -1278,6 +1343,8 @@ def main():
         default_workload = (args.log2_points == 20 and args.dtype == "bf16" and args.workload == "S1"
                             and args.channels == 64 and args.views == 32 and not args.materialize
                             and not args.strong and not args.interpolate and args.out_channels is None)
+        if default_workload and world == 1 and not args.no_pmc:
+            live_pmc_passes()
         traffic, traffic_why = pmc_traffic(name, default_workload)
         chain = "chain_attn_fwd" in kern
         res = {
@@ -1303,9 +1370,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_why if traffic is None else
-                         "profiles/pmc_traffic_latest.json (stamp = sha256 of the kernel sources, checked against this "
-                         "build): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, "
-                         "FETCH_SIZE x2 (gfx950 correction), KiB units calibrated on the copy kernel of the same run",
+                         ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (1 step), "
+                          "FETCH_SIZE x2 (gfx950)" if traffic_why == "live" else
+                          "profiles/pmc_traffic_latest.json (stamp = sha256 of the kernel sources, checked against this "
+                          "build; live passes: " + str(_LIVE_PMC["why"]) + ")"),
                          "avg_launch_ms": avg_ms, "launches": k["launches"],
                          "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
                          "note": ROOFLINE_NOTES.get(name, ROOFLINE_NOTES["*"]) if chain else None},
@@ -1326,6 +1394,12 @@ def main():
             "fused_abs_mean": float(fused.float().abs().mean().item()),
         }
         res["step_algorithmic_GBps"] = res["step_algorithmic_GB"] / (ms_per_step * 1e-3)
+        if _LIVE_PMC["table"] is not None:
+            res["pmc_live"] = {"calibration_on_copy_kernel": _LIVE_PMC["table"].get("_calibration"),
+                               "hbm_bytes_per_launch": {t: (_pmc_lookup(_LIVE_PMC["table"], t) or {}).get("hbm_bytes")
+                                                        for t in KERNEL_SYMBOL}}
+        else:
+            res["pmc_live"] = {"skipped": _LIVE_PMC["why"]}
         if collective is not None:
             res["allreduce_ms"] = max(collective["standin_allreduce_ms"])
             res["exposed_ms"] = max(a + b for a, b in zip(collective["standin_exposed_ms"],

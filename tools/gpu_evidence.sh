@@ -14,7 +14,7 @@ tail -2 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.log
 # profiler passes first: the PMC table of THIS build is in place (profiles/pmc_traffic_latest.json of the box's copy)
 # when the bench lines are taken, so that their roofline objects carry `traffic`
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-mapping-build --no-secondary"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-mapping-build --no-secondary --no-pmc"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG --output-format csv -- $BENCH > $OUT/bench_prof.json 2> $OUT/prof.err)
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -27,7 +27,7 @@ python tools/pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head
 cp $OUT/pmc_traffic.json $ROOT/profiles/pmc_traffic_latest.json
 ( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file $OUT/bench.detail.json > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
 python tools/show_bench.py $OUT/bench.json | head -3
-HEAD="--steps 20 --warmup 5 --no-cpu-baseline --no-mapping-build --no-secondary"
+HEAD="--steps 20 --warmup 5 --no-cpu-baseline --no-mapping-build --no-secondary --no-pmc"
 timeout 600 python bench.py --gpus 1 $HEAD --detail-file $OUT/bench_plain.detail.json > $OUT/bench_plain.json 2> /dev/null
 for V in "" "--no-standin"; do
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \

@@ -21,7 +21,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-HEAD="--no-secondary --no-cpu-baseline --no-mapping-build --steps 20 --warmup 5"
+HEAD="--no-secondary --no-cpu-baseline --no-mapping-build --no-pmc --steps 20 --warmup 5"
 envs() { echo "$1" | tr ',' ' '; }
 for JOB in "$@"; do
   KIND=${JOB%%:*}; REST=""; [ "$JOB" != "$KIND" ] && REST=${JOB#*:}
@@ -46,7 +46,7 @@ for JOB in "$@"; do
       python tools/show_bench.py $OUT/$NAME.json | head -1 ;;
     prof)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- \
-          python $ROOT/bench.py --no-secondary --no-cpu-baseline --no-mapping-build $REST --detail-file $OUT/bench_prof.detail.json > $OUT/bench_prof.json 2> $OUT/prof.err)
+          python $ROOT/bench.py --no-secondary --no-cpu-baseline --no-mapping-build --no-pmc $REST --detail-file $OUT/bench_prof.detail.json > $OUT/bench_prof.json 2> $OUT/prof.err)
       find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \; ; rm -rf $OUT/prof
       head -14 $OUT/kernel_stats.csv | cut -c1-150 ;;
     workload)
@@ -64,7 +64,7 @@ for JOB in "$@"; do
       # SQ counters of the headline (one step): VALU / LDS / wait shares per kernel -> sq_counters.txt
       (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES \
           --kernel-trace -d $OUT/pmc_sq -o sq --output-format csv -- python $ROOT/bench.py --no-secondary --no-cpu-baseline \
-          --no-mapping-build --steps 1 --warmup 1 $REST > /dev/null 2> $OUT/pmc_sq.err)
+          --no-mapping-build --no-pmc --steps 1 --warmup 1 $REST > /dev/null 2> $OUT/pmc_sq.err)
       python tools/pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1) > $OUT/sq_counters.txt 2>&1
       rm -rf $OUT/pmc_sq
       head -40 $OUT/sq_counters.txt | cut -c1-170 ;;
