@@ -1751,10 +1751,19 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 512, 1) void emodw_bwd_kernel(
 // block w of z_a and of dz_b, applies BatchNorm_a + LeakyReLU, writes both as natural LDS tiles, and owns the rows of
 // dW_b of output block w (NB accumulator blocks = 128 registers at C_o = 256): after the block barrier it reads its own
 // dz_b tile and the y_a tiles of all input blocks through the transpose read.  No weight operands in LDS at all.
-template <int CO>
+// DYA (round 6, C_o = 256): the same launch also turns the stored dz_b into dy_a IN PLACE -- what emodw_bwd MODE 4 did in a
+// pass of its own (z_a + dz_b read once more, 1 KB per view).  Wavefront w keeps its 32 x CO slice of W_b^T in registers
+// (weight-stationary: 64 VGPRs at C_o = 256; the 128 KB of the whole orientation do not fit LDS next to the tiles), the
+// dz_b tiles of ALL blocks are in LDS anyway (natural tiles: what a lane stored is the packed B operand of its view), so
+// da[block w] = sum_mb W_b^T[w][mb] dz_b[mb] is 2 NB more matrix instructions per wavefront and tile, dy_a = leaky'(y_a) da
+// goes back over the wavefront's own 32 bytes of the view's dz_b row (every reader of the row takes it from LDS), and S of
+// BatchNorm_a are column sums through the wavefront's slot of the idle tile buffer, exactly as MODE 4 took them
+// (statistics of the stored, rounded values).
+template <int CO, bool DYA>
 __global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
     const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const float* __restrict__ bna,
-    const bf16_t* __restrict__ dzst, const bf16_t* __restrict__ zst, float* __restrict__ dWb) {
+    bf16_t* __restrict__ dzst, const bf16_t* __restrict__ zst, float* __restrict__ dWb, const uint4* __restrict__ eops,
+    double* __restrict__ stats_a) {
   constexpr int NB = CO / 32;
   __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS];
   __shared__ __attribute__((aligned(16))) bf16_t s_ta[2][NB][32 * TSB], s_tb[2][NB][32 * TSB];     // double-buffered tiles
@@ -1768,10 +1777,22 @@ __global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
     const f32x16 zero = {0};
     accW[b] = zero;
   }
+  // the wavefront's slice of W_b^T: the first k-half of every block in registers (32 VGPRs), the second in LDS (64 KB for
+  // the eight wavefronts: all 64 VGPRs next to the 128 accumulators of dW_b spilled)
+  __shared__ __attribute__((aligned(16))) uint4 s_wt[DYA ? NB : 1][DYA ? NB : 1][DYA ? 64 : 1];
+  bf16x8 wT[DYA ? NB : 1];
+  if constexpr (DYA) {
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+      wT[mb] = load_op(eops, op_bwd<NB>(w, mb, 0), lane);
+      s_wt[w][mb][lane] = eops[op_bwd<NB>(w, mb, 1) * 64 + lane];
+    }
+  }
+  float sa1 = 0.f, sa2 = 0.f;
   const int n_tiles = n_tiles_dev[0];
   const int t0 = (int)((int64_t)n_tiles * blockIdx.x / gridDim.x), t1 = (int)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
-  auto fetch = [&](int t, u32x4 (&z)[2], u32x4 (&d)[2], bool& ok) {
-    const TileInfo ti = get_tile(tiles, t);
+  auto fetch = [&](int t, u32x4 (&z)[2], u32x4 (&d)[2], bool& ok, TileInfo& ti) {
+    ti = get_tile(tiles, t);
     ok = j < ti.nv;
     const __amdgpu_buffer_rsrc_t Z = make_rsrc(zst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2),
                                  DZ = make_rsrc(dzst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
@@ -1783,9 +1804,14 @@ __global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
   };
   u32x4 zq[2], dq[2];
   bool ok = false;
-  if (t0 < t1) fetch(t0, zq, dq, ok);
+  TileInfo ti_next;
+  ti_next.v0 = ti_next.nv = ti_next.frag = 0;
+  if (t0 < t1) fetch(t0, zq, dq, ok, ti_next);
   for (int t = t0; t < t1; ++t) {
     const int buf = (t - t0) & 1;
+    const bool ok_cur = ok;
+    const TileInfo ti = ti_next;
+    const u32x4 zk0 = zq[0], zk1 = zq[1];      // the z_a block of this tile (dy_a below needs the sign of y_a)
     {
       // this wavefront's block of the tile: y_a = leaky(BatchNorm_a(z_a)) (0 for lanes without a view), dz_b as stored
       f32x16 za;
@@ -1801,10 +1827,57 @@ __global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
       tileN_put_packed(s_tb[buf][w], j, h, a);
       tileN_put_packed(s_ta[buf][w], j, h, dzk);
     }
-    if (t + 1 < t1) fetch(t + 1, zq, dq, ok);       // the next tile's loads fly during the products
+    if (t + 1 < t1) fetch(t + 1, zq, dq, ok, ti_next);       // the next tile's loads fly during the products
     __syncthreads();       // tiles of all blocks written (the other buffer is free: its readers passed this barrier once more)
 #pragma unroll
     for (int b = 0; b < NB; ++b) accW[b] = wgradN(s_ta[buf][w], s_tb[buf][b], lane, accW[b]);      // dW_b[32 w ..][32 b ..]
+    if constexpr (DYA) {
+      f32x16 dya = {0};
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const bf16_t* row = s_ta[buf][mb] + j * TSB + 16 * h;        // the packed dz_b operand of view j, block mb
+        dya = CH_MFMA(wT[mb], *reinterpret_cast<const bf16x8*>(row), dya);
+        dya = CH_MFMA(__builtin_bit_cast(bf16x8, s_wt[w][mb][lane]), *reinterpret_cast<const bf16x8*>(row + 8), dya);
+      }
+      const uint32_t zv[8] = {zk0.x, zk0.y, zk0.z, zk0.w, zk1.x, zk1.y, zk1.z, zk1.w};
+      float tt[16], zaf[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {        // four channels at a time: two float4 of constants live
+        const float4 g4 = *reinterpret_cast<const float4*>(s_taba[w] + T_G * D + 16 * h + 4 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_taba[w] + T_B * D + 16 * h + 4 * q);
+        const float g_[4] = {g4.x, g4.y, g4.z, g4.w}, b_[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          zaf[r] = (r & 1) ? __uint_as_float(zv[r >> 1] & 0xffff0000u) : __uint_as_float(zv[r >> 1] << 16);
+          tt[r] = __builtin_fmaf(zaf[r], g_[e], b_[e]) > 0.f ? dya[r] : SLOPE * dya[r];
+        }
+      }
+      bf16x8 pk[2] = {pack8(&tt[0]), pack8(&tt[8])};     // lanes without a view: dz_b = 0 -> dy_a = 0
+      {
+        const __amdgpu_buffer_rsrc_t DA = make_rsrc(dzst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
+        const uint32_t off = ok_cur ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * w + 16 * h) * 2u : OOB;
+        st128(DA, off, __builtin_bit_cast(u32x4, pk[0]));
+        st128(DA, ok_cur ? off + 16u : OOB, __builtin_bit_cast(u32x4, pk[1]));
+      }
+      // S of BatchNorm_a: column sums of the stored dy_a and of dy_a z_a (rounded once more for the tile, as MODE 4 did)
+      // through this wavefront's slot of the OTHER buffer: nobody reads it before this wavefront refills it
+      bf16_t* tdy = s_ta[buf ^ 1][w];
+      tileN_put_packed(tdy, j, h, pk);
+      wave_sync();
+      col_sum1(tdy, lane, sa1);
+      wave_sync();
+      float dyr[16], pr[16];
+      unpack8(pk[0], reinterpret_cast<float(&)[8]>(dyr[0]));
+      unpack8(pk[1], reinterpret_cast<float(&)[8]>(dyr[8]));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = dyr[r] * zaf[r];
+      bf16x8 pp[2] = {pack8(&pr[0]), pack8(&pr[8])};
+      tileN_put_packed(tdy, j, h, pp);
+      wave_sync();
+      col_sum1(tdy, lane, sa2);
+      wave_sync();
+    }
   }
   // rows of the accumulator = image columns of the dz_b tile, columns = image columns of the y_a tile (cperm)
 #pragma unroll
@@ -1812,6 +1885,13 @@ __global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       atomicAdd(&dWb[(size_t)(32 * w + cperm(chan(r, h))) * CO + 32 * b + cperm(j)], accW[b][r]);
+  }
+  if constexpr (DYA) {
+    const float a0 = sa1 + other_half(sa1), a1 = sa2 + other_half(sa2);
+    if (h == 0) {          // lane n of the first half-wave: image column n of block w = channel 32 w + cperm(n)
+      atomicAdd(&stats_a[32 * w + cperm(j)], (double)a0);
+      atomicAdd(&stats_a[CO + 32 * w + cperm(j)], (double)a1);
+    }
   }
 }
 
@@ -2053,8 +2133,19 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
         hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 3>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
                            (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
                            (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
-        hipLaunchKernelGGL((emodw_wgrad_coop_kernel<256>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
-                           bn_a, (const bf16_t*)da, (const bf16_t*)z_a, dWb);
+        {
+          // round 6: dW_b AND dy_a (in place) + S of BatchNorm_a from the stored dz_b in ONE launch (weight-stationary W_b^T
+          // slices); DVA_EMOD_COOP_DYA=0: the round-4 pair (emodw_wgrad_coop + emodw_bwd MODE 4), the A/B
+          static const int coop_dya = tune_int("DVA_EMOD_COOP_DYA", 1);
+          if (coop_dya) {
+            hipLaunchKernelGGL((emodw_wgrad_coop_kernel<256, true>), dim3(chain_grid(1)), dim3(512), 0, s,
+                               (const int2*)tiles, n_tiles, bn_a, (bf16_t*)da, (const bf16_t*)z_a, dWb, (const uint4*)eops,
+                               stats_a);
+            break;
+          }
+        }
+        hipLaunchKernelGGL((emodw_wgrad_coop_kernel<256, false>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles,
+                           n_tiles, bn_a, (bf16_t*)da, (const bf16_t*)z_a, dWb, (const uint4*)eops, stats_a);
         hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 4>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
                            (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
                            (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
