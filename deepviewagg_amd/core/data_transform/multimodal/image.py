@@ -80,16 +80,28 @@ class MapImages:
         n_img = images.num_views
         step = self._batch_size(visi_model, xyz.shape[0], n_img, device=xyz.device)
 
+        # DepthBasedVisibility reads one depth map per image: '<...>/depth/<name>_depth.png' next to '<...>/<dir>/<name>_rgb.png'
+        # (the S3DIS layout, derived from image.path exactly as the reference does: image.py:262-265)
+        extra = {}
+        if self.method == 'DepthBasedVisibility' and 'depth_map' not in self.kwargs:
+            import os.path as osp
+
+            def depth_paths(sel):
+                return [osp.join(osp.dirname(osp.dirname(str(p))), 'depth',
+                                 osp.basename(str(p)).replace('_rgb.png', '_depth.png')) for p in images.path[sel]]
+            extra['depth_map_path'] = depth_paths
+
         def run_batch(sel):
             def part(attr):
                 return attr[sel].float() if attr is not None else None
+            kw = {k: f(sel) for k, f in extra.items()}
             return visi_model.batch(
                 xyz, images.pos[sel].float(),
                 img_opk=part(images.opk) if images.has_opk else None,
                 img_intrinsic_pinhole=images.intrinsic_pinhole[sel].float() if images.is_pinhole else None,
                 img_intrinsic_fisheye=images.intrinsic_fisheye[sel].float() if images.is_fisheye else None,
                 img_extrinsic=part(images.extrinsic) if images.has_extrinsic else None,
-                img_mask=mask, linearity=lin, planarity=pla, scattering=sca, normals=nrm)
+                img_mask=mask, linearity=lin, planarity=pla, scattering=sca, normals=nrm, **kw)
         i0 = 0
         while i0 < n_img:
             sel = slice(i0, min(i0 + step, n_img))

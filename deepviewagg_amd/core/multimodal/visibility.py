@@ -331,11 +331,17 @@ class _ProjectionVisibility(VisibilityModel):
 
         def one(a, b):
             return None if a is None else torch.as_tensor(a)[b]
+
+        def per_image(b):
+            # per-image keyword arguments arrive as lists (depth_map_path / depth_map of DepthBasedVisibility: one file
+            # per image, reference core/data_transform/multimodal/image.py:262-285); anything else is shared
+            return {k: (v[b] if isinstance(v, (list, tuple)) and len(v) == B and k in ('depth_map_path', 'depth_map') else v)
+                    for k, v in kwargs.items()}
         outs = [self(xyz, torch.as_tensor(img_xyz).reshape(-1, 3)[b], linearity=linearity, planarity=planarity,
                      scattering=scattering, normals=normals, img_opk=one(img_opk, b),
                      img_intrinsic_pinhole=one(img_intrinsic_pinhole, b),
                      img_intrinsic_fisheye=one(img_intrinsic_fisheye, b), img_extrinsic=one(img_extrinsic, b),
-                     img_mask=img_mask, **kwargs) for b in range(B)]
+                     img_mask=img_mask, **per_image(b)) for b in range(B)]
         counts = torch.tensor([o['idx'].shape[0] for o in outs], dtype=torch.long)
         row_ptr = torch.cat((torch.zeros(1, dtype=torch.long), counts.cumsum(0))).to(xyz.device)
         keep = [o for o in outs if o['idx'].shape[0] > 0]

@@ -1567,7 +1567,10 @@ def knn(xyz, k, cell=None):
     require_device(xyz)
     xyz = xyz.float().contiguous()
     n = xyz.shape[0]
-    assert xyz.dim() == 2 and xyz.shape[1] == 3 and 0 < k <= 128
+    assert xyz.dim() == 2 and xyz.shape[1] == 3
+    if not 0 < k <= 128:
+        raise ValueError(f"ops.knn: k = {k} neighbours requested, the kernel keeps at most 128 candidates per query "
+                         f"(csrc/knn.hip); the reference's settings are k <= 75")
     nbr = torch.empty((n, k), dtype=torch.int32, device=xyz.device)
     d2 = torch.empty((n, k), dtype=torch.float32, device=xyz.device)
     if n == 0:
@@ -1577,8 +1580,17 @@ def knn(xyz, k, cell=None):
     ext = float((hi - lo).max())                   # host sync: this is a preprocessing transform
     if cell is None:
         # a cell that holds a few points of a surface-like cloud: mean spacing x (k/4)^(1/3)
-        vol = float((hi - lo).clamp(min=1e-6).prod())
-        cell = (vol / n) ** (1 / 3) * max(1.0, (k / 4) ** (1 / 3))
+        dims = (hi - lo) > 1e-6 * max(ext, 1e-30)
+        nd = int(dims.sum())
+        if nd in (1, 2):
+            # a PLANAR (or collinear) cloud -- BiasuttiVisibility searches image-plane points (x, y, 0): the volume rule
+            # would give a cell far below the point spacing (z extent clamped to 1e-6) and every query would be retried
+            # on coarser grids (4 - 6 full launches): mean spacing in the occupied dimensions x (k/4)^(1/nd)
+            area = float((hi - lo)[dims].prod())
+            cell = (area / n) ** (1 / nd) * max(1.0, (k / 4) ** (1 / nd))
+        else:
+            vol = float((hi - lo).clamp(min=1e-6).prod())
+            cell = (vol / n) ** (1 / 3) * max(1.0, (k / 4) ** (1 / 3))
     cell = max(float(cell), ext / (1 << 19), 1e-12)
     nbytes = lib.dva_knn_workspace_bytes(n)
     if nbytes < 0:
