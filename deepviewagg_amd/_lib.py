@@ -148,6 +148,7 @@ SIGNATURES = {
     "dva_plan_split_table_bytes": (ctypes.c_int64, [_i64, _i64]),
     "dva_plan_split_build": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "dva_plan_split_sort_records": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dva_plan_split_sort_records32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "dva_plan_split_rows_grad": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "dva_chain_score_stats": (ctypes.c_int, [_vp] * 14 + [_i32, _i64, _i64, _vp]),
     "dva_chain_bwd_layer": (ctypes.c_int, [_i32] + [_vp] * 22 + [_i32, _i64, _i64, _vp]),

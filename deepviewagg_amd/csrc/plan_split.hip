@@ -241,7 +241,10 @@ __device__ __forceinline__ uint64_t match_digit(int d, bool valid) {
 // 0.56 ms for the two record passes).  Persistent workgroups that request the next tile's entries under the write-out of
 // the current one were measured slower (0.60 ms: 119 registers, and the tiles of a CU no longer neighbour those of the
 // other CUs of its XCD in time).
-template <int MODE, int TILE>
+// RW = 8 (round 6, MODE_REC_A only): the 32-byte records of the fp32 attention backward {point | 4 fp32 weights | 3 pad
+// words}: five payload words travel, the row key (from `keys`) is written into word 7 of the record on the way, so that
+// the bucket kernel finds it where the 16-byte records carry theirs (the last word).  Two 16-byte LDS planes.
+template <int MODE, int TILE, int RW = 4>
 __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __restrict__ keys, const uint4* __restrict__ src,
                                                              void* __restrict__ dst, int64_t n, int nb, int64_t n_rows,
                                                              int64_t nt, const int32_t* __restrict__ bucket_start,
@@ -251,7 +254,9 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
                                                              const int32_t* __restrict__ row_ptr, int xcd_order) {
   constexpr int THREADS = TILE / IPT, WAVES = THREADS / 64;
   typedef typename Elem<MODE>::type E;
+  static_assert(RW == 4 || (RW == 8 && MODE == MODE_REC_A), "32-byte records only go through pass A");
   __shared__ E s_stage[TILE];
+  __shared__ uint4 s_stage_hi[RW == 8 ? TILE : 1];
   __shared__ uint16_t s_cnt[WAVES][BINS];
   __shared__ int s_lstart[BINS];
   __shared__ int s_base[BINS];
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
   }
   // ---- loads first (8 independent requests per lane), tables while they fly
   uint32_t kk[IPT], p0[IPT], p1[IPT], p2[IPT];     // key | the three payload words of a record (scalars: no scratch)
+  uint32_t p3[RW == 8 ? IPT : 1], p4[RW == 8 ? IPT : 1];
   bool ok[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
@@ -281,6 +287,11 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
     if constexpr (MODE == MODE_LOWS) {
       kk[i] = keys[g];
       p0[i] = p1[i] = p2[i] = 0u;
+    } else if constexpr (RW == 8) {
+      const uint4 r = src[2 * g];
+      p0[i] = r.x, p1[i] = r.y, p2[i] = r.z, p3[i] = r.w;
+      p4[i] = src[2 * g + 1].x;
+      kk[i] = keys[g];
     } else {
       const uint4 r = src[g];
       p0[i] = r.x, p1[i] = r.y, p2[i] = r.z;
@@ -334,7 +345,14 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
   for (int i = 0; i < IPT; ++i) {
     if (ok[i]) {
       const int pos = s_lstart[dg[i]] + s_cnt[w][dg[i]] + rank[i];
-      if constexpr (MODE == MODE_LOWS) s_stage[pos] = kk[i]; else s_stage[pos] = make_uint4(p0[i], p1[i], p2[i], kk[i]);
+      if constexpr (MODE == MODE_LOWS) {
+        s_stage[pos] = kk[i];
+      } else if constexpr (RW == 8) {
+        s_stage[pos] = make_uint4(p0[i], p1[i], p2[i], p3[i]);
+        s_stage_hi[pos] = make_uint4(p4[i], 0u, 0u, kk[i]);
+      } else {
+        s_stage[pos] = make_uint4(p0[i], p1[i], p2[i], kk[i]);
+      }
     }
   }
   __syncthreads();
@@ -344,14 +362,20 @@ __global__ __launch_bounds__(TILE / IPT) void scatter_kernel(const uint32_t* __r
     const int j = k * THREADS + tid;
     if (j < count) {
       const E v = s_stage[j];
-      const uint32_t key = key_of(v);
+      uint4 vh = make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (RW == 8) vh = s_stage_hi[j];
+      const uint32_t key = RW == 8 ? vh.w : key_of(v);
       const int d = MODE == MODE_REC_B ? (int)(key & (BINS - 1)) : hi_digit(key, nb);
       int64_t g = (int64_t)s_base[d] + (j - s_lstart[d]);
       g = g < n ? g : n - 1;
-      if constexpr (MODE == MODE_LOWS)
+      if constexpr (MODE == MODE_LOWS) {
         reinterpret_cast<uint16_t*>(dst)[g] = (uint16_t)(key & (BINS - 1));
-      else
+      } else if constexpr (RW == 8) {
+        reinterpret_cast<uint4*>(dst)[2 * g] = v;
+        reinterpret_cast<uint4*>(dst)[2 * g + 1] = vh;
+      } else {
         reinterpret_cast<uint4*>(dst)[g] = v;
+      }
     }
   }
 }
@@ -480,6 +504,117 @@ __global__ __launch_bounds__(1024) void bucket_rows_grad_kernel(const uint4* __r
   }
 }
 
+// The fp32 twin (round 6; the reference's default arithmetic, no autocast): 32-byte records in bucket order (pass A with
+// RW = 8: {point | w0 w1 w2 | w3 0 0 key}), fp32 grad_out rows (256 bytes at C = 64: a lane team of C / 4 lanes, four
+// channels per lane), fp32 rows out.  Same structure as the bf16 kernel: ranked by the low digit, staged in row order in
+// two 16-byte LDS planes, consumed in view order by the team that owns the row (deterministic).
+template <int C, int BT>
+__global__ __launch_bounds__(1024) void bucket_rows_grad_f32_kernel(const uint4* __restrict__ rec, const float* __restrict__ gout,
+                                                                    float* __restrict__ grows, int64_t n_rows, int G,
+                                                                    const int32_t* __restrict__ bucket_start,
+                                                                    const int32_t* __restrict__ order) {
+  constexpr int THREADS = 1024, WAVES = THREADS / 64, IPB = BT / THREADS;
+  constexpr int LPR = C / 4, GROUPS = THREADS / LPR, RPT = BINS / GROUPS, U = 4;
+  __shared__ uint4 s_lo[BT], s_hi[BT];
+  __shared__ uint16_t s_cnt[WAVES][BINS];
+  __shared__ int s_lstart[BINS + 1];
+  __shared__ int s_w[WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = order[blockIdx.x];          // largest bucket first
+  const int grp = tid / LPR, cl = tid % LPR, gch = cl / (LPR / G);
+  float acc[RPT][4];
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[rr][k] = 0.f;
+  const int64_t b0 = bucket_start[b], b1 = bucket_start[b + 1];
+  for (int64_t start = b0; start < b1; start += BT) {
+    const int count = (int)(b1 - start < BT ? b1 - start : BT);
+    uint32_t kk[IPB], p0[IPB], p1[IPB], p2[IPB], p3[IPB], p4[IPB];
+    bool ok[IPB];
+#pragma unroll
+    for (int i = 0; i < IPB; ++i) {
+      const int idx = w * (64 * IPB) + i * 64 + lane;
+      ok[i] = idx < count;
+      const int64_t g = start + (ok[i] ? idx : 0);
+      const uint4 r = rec[2 * g], rh = rec[2 * g + 1];
+      p0[i] = r.x, p1[i] = r.y, p2[i] = r.z, p3[i] = r.w, p4[i] = rh.x, kk[i] = rh.w;
+    }
+    {
+      uint32_t* z = reinterpret_cast<uint32_t*>(&s_cnt[0][0]);
+#pragma unroll
+      for (int k = 0; k < WAVES * BINS / 2 / THREADS; ++k) z[k * THREADS + tid] = 0u;
+    }
+    __syncthreads();                       // (also: the previous tile's records are consumed)
+    int dg[IPB], rank[IPB];
+#pragma unroll
+    for (int i = 0; i < IPB; ++i) {
+      dg[i] = (int)(kk[i] & (BINS - 1));
+      const uint64_t peers = match_digit(dg[i], ok[i]);
+      const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+      const int prev = s_cnt[w][dg[i]];
+      if (ok[i] && below == 0) s_cnt[w][dg[i]] = (uint16_t)(prev + __popcll(peers));
+      rank[i] = prev + below;
+    }
+    __syncthreads();
+    int run = 0;
+    if (tid < BINS) {
+#pragma unroll
+      for (int k = 0; k < WAVES; ++k) {
+        const int c = s_cnt[k][tid];
+        s_cnt[k][tid] = (uint16_t)run;
+        run += c;
+      }
+    }
+    const int ls = block_excl_scan<THREADS>(tid < BINS ? run : 0, s_w);
+    if (tid < BINS) s_lstart[tid] = ls;
+    if (tid == BINS - 1) s_lstart[BINS] = ls + run;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPB; ++i) {
+      if (ok[i]) {
+        const int pos = s_lstart[dg[i]] + s_cnt[w][dg[i]] + rank[i];
+        s_lo[pos] = make_uint4(p0[i], p1[i], p2[i], p3[i]);
+        s_hi[pos] = make_uint4(p4[i], 0u, 0u, kk[i]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+      const int d = grp + GROUPS * rr;
+      const int beg = s_lstart[d], end = s_lstart[d + 1];
+      for (int i0 = beg; i0 < end; i0 += U) {
+        float4 raw[U];
+        float sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool in = i0 + u < end;
+          const int at = in ? i0 + u : beg;
+          const uint32_t* lo = reinterpret_cast<const uint32_t*>(&s_lo[at]);
+          const int64_t p = (int)lo[0];
+          const uint32_t wb = gch < 3 ? lo[1 + gch] : reinterpret_cast<const uint32_t*>(&s_hi[at])[0];
+          sc[u] = in ? __uint_as_float(wb) : 0.f;
+          raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (in) raw[u] = *reinterpret_cast<const float4*>(gout + p * C + cl * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc[rr][0] = fmaf(raw[u].x, sc[u], acc[rr][0]);
+          acc[rr][1] = fmaf(raw[u].y, sc[u], acc[rr][1]);
+          acc[rr][2] = fmaf(raw[u].z, sc[u], acc[rr][2]);
+          acc[rr][3] = fmaf(raw[u].w, sc[u], acc[rr][3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    const int64_t r = (int64_t)b * BINS + grp + GROUPS * rr;
+    if (r < n_rows)
+      *reinterpret_cast<float4*>(grows + r * C + cl * 4) = make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
+  }
+}
+
 template <int C>
 static void bucket_rows_grad(const uint4* rec, const bf16_t* gout, bf16_t* grows, int64_t n_rows, int G, int nb,
                              const int32_t* bstart, const int32_t* order, hipStream_t s) {
@@ -593,12 +728,32 @@ int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t
   return DVA_OK;
 }
 
+// Pass A on the 32-BYTE records of the fp32 attention backward (dva_chain_attn_bwd_f32: {point | 4 fp32 weights | 3 pad
+// words}, view order) -> bucket order in `buf` [n_views][32], the row key (row_idx, required) written into word 7.
+int dva_plan_split_sort_records32(const int32_t* row_idx, const void* rec, int64_t n_views, int64_t n_rows,
+                                  const void* tables, int64_t tables_bytes, void* buf, void* stream) {
+  if (n_views < 0 || n_rows < 0) return DVA_ERR_INVALID;
+  if (!ps::eligible(n_views, n_rows) || ps::tile_size() != 4096) return DVA_ERR_UNSUPPORTED;      // (two LDS planes of a tile)
+  if (!row_idx || !rec || !tables || !buf || buf == rec) return DVA_ERR_INVALID;
+  if (((uintptr_t)rec % 16) || ((uintptr_t)buf % 16)) return DVA_ERR_UNSUPPORTED;
+  const ps::Layout L = ps::layout(n_views, n_rows);
+  if ((int64_t)L.total > tables_bytes) return DVA_ERR_INVALID;
+  const ps::Tables T = ps::tables_of(const_cast<void*>(tables), L);
+  constexpr int TILE = 4096, THREADS = TILE / ps::IPT;
+  hipLaunchKernelGGL((ps::scatter_kernel<ps::MODE_REC_A, TILE, 8>), dim3(ps::scatter_grid(L.nt)), dim3(THREADS), 0,
+                     (hipStream_t)stream, (const uint32_t*)row_idx, (const uint4*)rec, buf, n_views, (int)L.nb, n_rows,
+                     L.nt, T.bstart, T.tstart, T.desc, T.offA, (const int32_t*)nullptr, (int)ps::xcd_on());
+  DVA_CHECK_LAUNCH();
+  return DVA_OK;
+}
+
 int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64_t n_views, int64_t n_rows,
                              const void* tables, int64_t tables_bytes, void* grad_rows, int32_t C, int32_t G, int32_t dtype,
                              int32_t out_dtype, void* stream) {
   if (n_views < 0 || n_rows < 0 || C <= 0 || G <= 0) return DVA_ERR_INVALID;
-  if (!ps::eligible(n_views, n_rows) || dtype != DVA_BF16 || out_dtype != DVA_BF16 ||
-      (C != 32 && C != 64) || (G != 1 && G != 2 && G != 4) || ((C / 8) % G) != 0)
+  const bool f32 = dtype == DVA_F32 && out_dtype == DVA_F32;       // 32-byte records (dva_plan_split_sort_records32)
+  if (!ps::eligible(n_views, n_rows) || (!f32 && (dtype != DVA_BF16 || out_dtype != DVA_BF16)) ||
+      (C != 32 && C != 64) || (G != 1 && G != 2 && G != 4) || ((C / (f32 ? 4 : 8)) % G) != 0)
     return DVA_ERR_UNSUPPORTED;
   if (!grad_out || !bucket_rec || !tables || !grad_rows) return DVA_ERR_INVALID;
   if (((uintptr_t)bucket_rec % 16) || ((uintptr_t)grad_out % 16) || ((uintptr_t)grad_rows % 16)) return DVA_ERR_UNSUPPORTED;
@@ -607,6 +762,16 @@ int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64
   const ps::Tables T = ps::tables_of(const_cast<void*>(tables), L);
   hipStream_t s = (hipStream_t)stream;
   const int nb = (int)L.nb;
+  if (f32) {
+    if (C == 64)
+      hipLaunchKernelGGL((ps::bucket_rows_grad_f32_kernel<64, 4096>), dim3(nb), dim3(1024), 0, s, (const uint4*)bucket_rec,
+                         (const float*)grad_out, (float*)grad_rows, n_rows, (int)G, T.bstart, T.order);
+    else
+      hipLaunchKernelGGL((ps::bucket_rows_grad_f32_kernel<32, 4096>), dim3(nb), dim3(1024), 0, s, (const uint4*)bucket_rec,
+                         (const float*)grad_out, (float*)grad_rows, n_rows, (int)G, T.bstart, T.order);
+    DVA_CHECK_LAUNCH();
+    return DVA_OK;
+  }
   if (C == 64)
     ps::bucket_rows_grad<64>((const uint4*)bucket_rec, (const bf16_t*)grad_out, (bf16_t*)grad_rows, n_rows, (int)G, nb,
                              T.bstart, T.order, s);

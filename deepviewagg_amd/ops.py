@@ -633,6 +633,13 @@ SPLIT_PLAN = os.environ.get("DVA_SPLIT_PLAN", "1") == "1"
 SPLIT_PLAN_MIN_VIEWS = 1 << 20
 
 
+def split_plan_serves(dtype, C):
+    """Does a consumer of [R, C] value rows of this dtype take its rows gradient over a SplitPlan?  bf16: the 16-byte
+    records of the chain (any C: bucket kernel at C in {32, 64}, the two record passes otherwise); fp32: the 32-byte
+    records of the lean attention backward at C in {32, 64} (round 6).  Everything else wants the permutation."""
+    return dtype == torch.bfloat16 or (dtype == torch.float32 and C in (32, 64))
+
+
 def _split_plan_pays(n_views, n_rows):
     return n_views >= SPLIT_PLAN_MIN_VIEWS and (n_views >= 2 * SPLIT_PLAN_MIN_VIEWS or n_rows >= (1 << 17))
 
@@ -709,6 +716,25 @@ class SplitPlan:
                                                   None if bucket_order else ptr(rec), stream_of(rec)),
                   "dva_plan_split_sort_records")
         return buf if bucket_order else rec
+
+    def rows_grad_f32(self, gout, rec, C, G, stream):
+        """fp32 [R, C] rows gradient from the 32-byte view records of ``dva_chain_attn_bwd_f32`` (``rec`` fp32 [V, 8], view
+        order) through pass A on those records + the fp32 bucket kernel (round 6), or None where it does not apply."""
+        lib = _lib.load()
+        V, R = self.row_idx.shape[0], self.n_rows
+        if (gout.dtype != torch.float32 or C not in (32, 64) or G not in (1, 2, 4) or (C // 4) % G
+                or gout.data_ptr() % 16 or not gout.is_contiguous() or os.environ.get("DVA_PLAN_TILE", "4096") != "4096"):
+            return None
+        assert rec.shape == (V, 8) and rec.dtype == torch.float32 and rec.is_contiguous()
+        brec = torch.empty_like(rec)
+        with _timed("plan_sort_records", V * (64 + 4)):
+            check(lib.dva_plan_split_sort_records32(ptr(self.row_idx), ptr(rec), V, R, ptr(self.tables),
+                                                    self.tables.numel(), ptr(brec), stream), "dva_plan_split_sort_records32")
+        g = torch.empty((R, C), dtype=torch.float32, device=gout.device)
+        with _timed("view_gather_rows_grad", V * (32 + C * 4) + R * C * 4):
+            check(lib.dva_plan_split_rows_grad(ptr(gout), ptr(brec), V, R, ptr(self.tables), self.tables.numel(), ptr(g),
+                                               C, G, _lib.DVA_F32, _lib.DVA_F32, stream), "dva_plan_split_rows_grad")
+        return g
 
     def rows_grad_fused(self, gout, rec, C, G, stream):
         """bf16 [R, C] rows gradient from KEYED view-order records through pass A + the bucket kernel
@@ -841,7 +867,10 @@ class GatheredFeatures:
     def with_rows(self, rows):
         """Same gather applied to another [R, C'] row tensor (e.g. E_mod(rows))."""
         assert rows.shape[0] == self.rows.shape[0]
-        return GatheredFeatures(rows, self.row_idx, self.counts, self.exact, self.plan)
+        plan = self.plan
+        if isinstance(plan, SplitPlan) and not split_plan_serves(rows.dtype, rows.shape[1]):
+            plan = None      # the consumer of these rows wants a permutation: built in its backward (ADVICE r5)
+        return GatheredFeatures(rows, self.row_idx, self.counts, self.exact, plan)
 
     @property
     def shape(self):
@@ -887,7 +916,7 @@ def lazy_gather_nearest(x, packed_idx, exact):
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
     # the split plan serves the 16-byte-record rows gradient: bf16 maps, one atom per view
     row_idx, counts, plan = gather_row_index(packed_idx, B, H, W, with_plan=True,
-                                             split=bool(exact) and x.dtype == torch.bfloat16)
+                                             split=bool(exact) and split_plan_serves(x.dtype, C))
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
 
 
@@ -897,7 +926,7 @@ def lazy_gather_nearest_mapping(x, images, atom_ptr, pixels, ratio, exact):
     B, C, H, W = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C)   # view when x is channels_last
     row_idx, counts, plan = mapping_row_index(images, atom_ptr, pixels, ratio, B, H, W,
-                                              split=bool(exact) and x.dtype == torch.bfloat16)
+                                              split=bool(exact) and split_plan_serves(x.dtype, C))
     return GatheredFeatures(rows, row_idx, counts, exact, plan)
 
 
@@ -1199,13 +1228,19 @@ class _ViewGatherAttention(torch.autograd.Function):
                     ptr(compat), ptr(vp), ptr(tiles), ptr(n_tiles), ptr(rows), ptr(row_idx), ptr(csr_idx),
                     ptr(gw) if has_gate else None, ptr(gb) if has_gate else None, ptr(gout), ptr(out), ptr(gcompat),
                     ptr(rec), ptr(gwb), N, V, R, C, G, scaling, ctx.eps, stream_of(rows)), "dva_chain_attn_bwd_f32")
-            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False, split=False)[0]
-            perm, row_ptr = plan
-            grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
-            with _timed("view_gather_rows_grad", V * (4 + 32 + C * es) + R * (C * 4 + 4)):
-                check(lib.dva_view_gather_rows_grad(
-                    ptr(gout), ptr(att), ptr(gate) if has_gate else None, None, ptr(perm), ptr(row_ptr), ptr(rec), 8,
-                    ptr(grows), R, V, C, G, dtype_code(rows), stream_of(rows)), "dva_view_gather_rows_grad")
+            plan = ctx.plan if ctx.plan is not None else row_plan(row_idx, R, with_counts=False,
+                                                                  split=split_plan_serves(rows.dtype, C))[0]
+            grows = None
+            if isinstance(plan, SplitPlan) and SPLIT_FUSED:
+                # round 6: the 32-byte records through pass A of the split plan + the fp32 bucket kernel
+                grows = plan.rows_grad_f32(gout, rec, C, G, stream_of(rows))
+            if grows is None:
+                perm, row_ptr = plan
+                grows = torch.empty((R, C), dtype=torch.float32, device=rows.device)
+                with _timed("view_gather_rows_grad", V * (4 + 32 + C * es) + R * (C * 4 + 4)):
+                    check(lib.dva_view_gather_rows_grad(
+                        ptr(gout), ptr(att), ptr(gate) if has_gate else None, None, ptr(perm), ptr(row_ptr), ptr(rec), 8,
+                        ptr(grows), R, V, C, G, dtype_code(rows), stream_of(rows)), "dva_view_gather_rows_grad")
             g_w = gwb[:G].reshape(w_shape) if (has_gate and w_shape is not None) else None
             g_b = gwb[G:].reshape(b_shape) if (has_gate and b_shape is not None) else None
             return grows, None, gcompat, None, g_w, g_b, None, None, None

@@ -227,7 +227,13 @@ int dva_plan_split_sort_records(const int32_t* row_idx, const void* rec, int64_t
  * they lie (the 16 bytes per view pass B writes and the rows gradient reads again never exist).  grad_rows [n_rows][C]
  * bf16, written; deterministic; a row is summed by one lane team in view order (dva_view_gather_rows_grad_rec16* splits
  * it over 8 lane slots: the two agree to fp32 rounding).  bf16 / bf16, C in {32, 64}, G in {1, 2, 4}; otherwise
- * DVA_ERR_UNSUPPORTED (the caller runs pass B and dva_view_gather_rows_grad_rec16_to). */
+ * DVA_ERR_UNSUPPORTED (the caller runs pass B and dva_view_gather_rows_grad_rec16_to).
+ * fp32 / fp32 (round 6; the reference's default arithmetic, models/base_model.py:244,381): bucket_rec = the 32-BYTE records
+ * of dva_chain_attn_bwd_f32 in bucket order, from dva_plan_split_sort_records32 -- pass A on {point | 4 fp32 weights | 3 pad
+ * words} records, row_idx required, the row key written into word 7 of every record; buf [n_views][32] -- grad_out fp32
+ * [N][C], grad_rows fp32 [n_rows][C]; C in {32, 64}. */
+int dva_plan_split_sort_records32(const int32_t* row_idx, const void* rec, int64_t n_views, int64_t n_rows,
+                                  const void* tables, int64_t tables_bytes, void* buf, void* stream);
 int dva_plan_split_rows_grad(const void* grad_out, const void* bucket_rec, int64_t n_views, int64_t n_rows,
                              const void* tables, int64_t tables_bytes, void* grad_rows, int32_t C, int32_t G, int32_t dtype,
                              int32_t out_dtype, void* stream);

@@ -903,3 +903,108 @@ def test_gather_bilinear_forward_is_bitwise_the_reference_expression(dtype, C):
     acc = acc + w4[:, 2:3] * rows[r4[:, 2]]
     acc = acc + w4[:, 3:4] * rows[r4[:, 3]]
     assert torch.equal(out, acc.to(dtype))
+
+
+@pytest.mark.parametrize("V,R,C,G,how", [(9000, 600, 64, 4, "uniform"), (300000, 5000, 32, 2, "uniform"),
+                                         (2000000, 1 << 18, 64, 4, "uniform"), (500000, 70000, 64, 1, "skewed"),
+                                         (100000, 2000, 32, 4, "one_row")])
+def test_bucket_rows_grad_f32_equals_index_add(V, R, C, G, how):
+    """The fp32 twin of the bucket rows gradient (round 6: dva_plan_split_sort_records32 + dva_plan_split_rows_grad with
+    fp32 / fp32): the 32-byte records of the fp32 attention backward {point | 4 fp32 weights | pad} against an fp64
+    ``index_add`` of the same products (the reference's backward of the row gather, core/multimodal/image.py:1262-1287),
+    and against the segmented reduction over the permutation plan (dva_view_gather_rows_grad) it replaces."""
+    from deepviewagg_amd import ops, _lib
+    from deepviewagg_amd._lib import ptr, check
+    gen = torch.Generator().manual_seed(V + R + C + 1)
+    N = max(V // 8, 4)
+    if how == "uniform":
+        row_idx = torch.randint(0, R, (V,), generator=gen, dtype=torch.int32)
+    elif how == "one_row":
+        row_idx = torch.full((V,), R - 3, dtype=torch.int32)
+    else:
+        hot = torch.randint(0, R, (16,), generator=gen)
+        row_idx = torch.where(torch.rand(V, generator=gen) < 0.5, hot[torch.randint(0, 16, (V,), generator=gen)],
+                              torch.randint(0, R, (V,), generator=gen)).to(torch.int32)
+    point = torch.randint(0, N, (V,), generator=gen, dtype=torch.int32)
+    wts = torch.randn(V, 4, generator=gen)
+    rec = torch.zeros(V, 8, dtype=torch.float32)
+    rec[:, 0] = point.view(torch.float32)
+    rec[:, 1:5] = wts
+    rec[:, 5:] = float("nan")                              # the pad words must not matter
+    gout = torch.randn(N, C, generator=gen).to(DEV)
+    rd, recd = row_idx.to(DEV), rec.to(DEV)
+    old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS
+    try:
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = True, 0
+        plan = ops.row_plan(rd, R, with_counts=False)[0]
+        assert isinstance(plan, ops.SplitPlan)
+        st = torch.cuda.current_stream().cuda_stream
+        a = plan.rows_grad_f32(gout, recd.clone(), C, G, st)
+        a2 = plan.rows_grad_f32(gout, recd.clone(), C, G, st)
+    finally:
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = old
+    assert a is not None and a.dtype == torch.float32 and a.shape == (R, C)
+    assert torch.equal(a, a2)                                       # deterministic
+    ch_group = torch.arange(C) // (C // G)
+    ref = torch.zeros(R, C, dtype=torch.float64)
+    for lo in range(0, V, 500000):
+        sl = slice(lo, lo + 500000)
+        ref.index_add_(0, row_idx[sl].long(), gout.cpu().double()[point[sl].long()] * wts[sl].double()[:, ch_group])
+    scale = float(ref.abs().max()) + 1e-9
+    assert float((a.cpu().double() - ref).abs().max()) <= scale * 2e-5        # fp32 sums of up to ~10^5 terms (one_row)
+    # the permutation-plan kernel on the same records
+    (perm, row_ptr), _ = ops.row_plan(rd, R, with_counts=False, split=False)
+    b = torch.empty((R, C), dtype=torch.float32, device=DEV)
+    lib = _lib.load()
+    check(lib.dva_view_gather_rows_grad(ptr(gout), None, None, None, ptr(perm), ptr(row_ptr), ptr(recd), 8, ptr(b), R, V, C,
+                                        G, _lib.DVA_F32, st), "dva_view_gather_rows_grad")
+    assert float((a - b).abs().max()) <= scale * 2e-5
+
+
+@pytest.mark.parametrize("C,gating", [(64, True), (32, False)])
+def test_view_gather_attention_f32_split_plan_equals_permutation_plan(C, gating):
+    """ops.view_gather_attention on fp32 rows (the lean fp32 backward, G = 4) over the split plan (32-byte records through
+    pass A + the fp32 bucket kernel) = over the permutation plan, to fp32 rounding."""
+    from deepviewagg_amd import ops
+    gen = torch.Generator().manual_seed(C + 7)
+    N, R, G = 6000, 700, 4
+    sizes = torch.randint(0, 9, (N,), generator=gen)
+    csr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(DEV)
+    V = int(csr[-1])
+    row_idx = torch.randint(0, R - 20, (V,), generator=gen, dtype=torch.int32).to(DEV)
+    rows = torch.randn(R, C, generator=gen)
+    compat = torch.randn(V, G, generator=gen)
+    gw = torch.randn(G, generator=gen) if gating else None
+    gb = torch.randn(G, generator=gen) if gating else None
+    w = torch.randn(N, C, generator=gen).to(DEV)
+
+    def run(split):
+        old = ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS
+        ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = split, 0
+        calls = {"f32": 0}
+        orig = ops.SplitPlan.rows_grad_f32
+
+        def counted(self, *a, **k):
+            r = orig(self, *a, **k)
+            calls["f32"] += r is not None
+            return r
+        ops.SplitPlan.rows_grad_f32 = counted
+        try:
+            plan = ops.row_plan(row_idx, R, with_counts=False, split=split)[0]
+            assert isinstance(plan, ops.SplitPlan) == split
+            rd = rows.to(DEV).requires_grad_()
+            cd = compat.to(DEV).requires_grad_()
+            gwd = gw.to(DEV).requires_grad_() if gating else None
+            gbd = gb.to(DEV).requires_grad_() if gating else None
+            out, _, _ = ops.view_gather_attention(rd, row_idx, cd, csr, gwd, gbd, plan=plan)
+            res = [out] + list(torch.autograd.grad((out * w).sum(), [rd, cd]))
+        finally:
+            ops.SPLIT_PLAN, ops.SPLIT_PLAN_MIN_VIEWS = old
+            ops.SplitPlan.rows_grad_f32 = orig
+        assert calls["f32"] == (1 if split else 0)
+        return res
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    torch.testing.assert_close(b[1], a[1], rtol=1e-5, atol=1e-5 * float(a[1].abs().max()))
+    assert float(b[1][R - 20:].abs().max()) == 0.0 and float(b[1].abs().max()) > 0.0
