@@ -3,7 +3,7 @@
 # 1-GPU box, rocprofv3 kernel stats, PMC traffic (stamped with the kernel-source hash), SQ counters.
 # Usage: tools/gpu_evidence.sh <tag>   (writes gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>_*)
 exec < /dev/null
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -44,9 +44,6 @@ PY
 # the launcher on a box with ONE device: two ranks start, the second has no device, the run fails loudly
 timeout 300 python bench.py --gpus 2 --steps 1 --warmup 0 > $OUT/bench_gpus2.out 2> $OUT/bench_gpus2.err; echo "bench.py --gpus 2 on this box: rc=$?" | tee $OUT/bench_gpus2.rc
 grep -E "launching 2 ranks|has no HIP device" $OUT/bench_gpus2.err | head -3 | tee -a $OUT/bench_gpus2.rc
-# A/B on the same box: the permutation plan (rounds 1-4) against the split plan
-timeout 600 env DVA_SPLIT_PLAN=0 python bench.py --gpus 1 $HEAD --detail-file $OUT/bench_plain_permutation_plan.detail.json > $OUT/bench_plain_permutation_plan.json 2> /dev/null
-python tools/show_bench.py $OUT/bench_plain_permutation_plan.json | head -1
 # keep the merged output small: raw traces are large
 rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq
 grep -E "rows_grad|attn_fwd|_stamp|calibration" $OUT/pmc_traffic.txt | head -8
