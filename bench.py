@@ -179,7 +179,7 @@ PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pro
 _LIVE_PMC = {"table": None, "why": "not run"}
 
 
-def live_pmc_passes(timeout_s=240):
+def live_pmc_passes(timeout_s=150):
     """HBM traffic MEASURED IN THIS RUN: two child runs of this same script on the default workload
     (1 step after 1 warm-up, no secondary work) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes
     with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes (the two counters do not fit one pass) --
