@@ -242,15 +242,10 @@ __device__ __forceinline__ bf16x8 pack8(const float* x) {
                    pack_bf16x2(x[6], x[7])};
   return __builtin_bit_cast(bf16x8, v);
 }
-// plain v_and_b32 (one issue slot): hipcc turns `v & (ok ? ~0 : 0)` into v_cndmask, which costs two (tools/ubench)
-__device__ __forceinline__ uint32_t vand(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 __device__ __forceinline__ bf16x8 mask8(bf16x8 a, uint32_t keep) {  // keep = 0 or ~0
   u32x4 v = __builtin_bit_cast(u32x4, a);
-  v.x = vand(v.x, keep); v.y = vand(v.y, keep); v.z = vand(v.z, keep); v.w = vand(v.w, keep);
+  v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;      // (compiled to v_cndmask; a v_and_b32 forced through inline asm
+                                                          //  broke tests/test_gpu_fullsize.py::test_fused_bilinear_full_size_slice)
   return __builtin_bit_cast(bf16x8, v);
 }
 // 4 features per lane as the 8 k-slots of its half: hi(x) | lo(x) = x - hi(x): the first layer sees x to 16 bits
