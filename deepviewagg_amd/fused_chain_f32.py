@@ -55,7 +55,7 @@ class _ChainScores(torch.autograd.Function):
         G = Ws.shape[0]
         bns = [_bn_of(e_map.mlp_elt_1[0]), _bn_of(e_map.mlp_elt_1[1]),
                _bn_of(e_map.mlp_elt_2[0]), _bn_of(e_map.mlp_elt_2[1])]
-        zpool = iter(torch.zeros((10, 3 * D), dtype=torch.float64, device=dev))
+        zpool = iter(ops.zeros_small((10, 3 * D), torch.float64, dev))
 
         def zstats():
             return next(zpool)
@@ -69,7 +69,7 @@ class _ChainScores(torch.autograd.Function):
               "dva_chain3_prep")
         # ---- layer 1: statistics from the moments of x_map (z1 = W1 x is linear in x)
         s1 = zstats()
-        mom = torch.zeros(44, dtype=torch.float64, device=dev)
+        mom = ops.zeros_small(44, torch.float64, dev)
         if training:
             with ops._timed("chain_moments", V * 32):
                 check(lib.dva_chain_moments(ptr(x_map), V, ptr(W1), 1, ptr(mom), ptr(s1), st), "dva_chain_moments")
@@ -129,7 +129,7 @@ class _ChainScores(torch.autograd.Function):
             dc = torch.nn.functional.pad(dc, (0, 4 - G))
         arena = Arena(dev)
         m_rows = float(max(V, 1))
-        zpool = iter(torch.zeros((10, 2 * D), dtype=torch.float64, device=dev))
+        zpool = iter(ops.zeros_small((10, 2 * D), torch.float64, dev))
 
         def zstats():
             return next(zpool)
