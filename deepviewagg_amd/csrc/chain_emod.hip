@@ -1895,6 +1895,209 @@ __global__ __launch_bounds__(CO * 2, 1) void emodw_wgrad_coop_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// C_o = 256 backward WITHOUT the dz_b hand-off (round 6): two cooperative kernels that each evaluate dz_b of a 32-view
+// tile themselves -- the eight wavefronts of a block own one output block each and share the tile through LDS --
+//   WGRAD = false:  z_a -> y_a tiles | barrier | z_b[w] = W_b[w][:] y_a, dz_b[w] (BatchNorm_b backward of the attention's
+//                   value gradient) -> dz_b tiles | barrier | dy_a[w] = leaky'(y_a) W_b^T[w][:] dz_b -> bf16 [V][CO] (written
+//                   once), S of BatchNorm_a (column sums);
+//   WGRAD = true:   the same up to the dz_b tiles | barrier | dW_b[32 w ..][:] += dz_b[w]^T y_a (128 accumulator registers).
+// Both keep their W_b slice weight-stationary (WGRAD = false: W_b and W_b^T slices in 128 VGPRs; WGRAD = true: the first
+// k-halves of W_b in 32 VGPRs, the second in 64 KB of LDS next to the accumulators).  Against MODE 3 + the merged
+// cooperative kernel: 1 KB per view less (dz_b is never written or read: 512 + 512 B), 128 matrix instructions per tile
+// more (dz_b evaluated twice).  MEASURED (round 6): 25.9 against 23.3 ms for the pair it replaces -- 51 GB in 25.9 ms is
+// 2 TB/s and the matrix pipe is ~30 % busy: the eight wavefronts run in lockstep through two block barriers per tile and
+// one block per CU (233 / 246 VGPRs) leaves nothing to overlap them with.  Opt-in (DVA_EMOD_COOP2=1), kept for the A/B.  The bf16 rounding of dz_b is the stored one's (pack16), so the results are those of
+// the three-kernel form up to the order of the fp32 atomics.  One tile buffer per kind suffices: two barriers per tile.
+template <int CO, int G, bool WGRAD>
+__global__ __launch_bounds__(CO * 2, 1) void emodw_coop2_kernel(
+    const int2* __restrict__ tiles, const int32_t* __restrict__ n_tiles_dev, const uint4* __restrict__ eops,
+    const float* __restrict__ bna, const float* __restrict__ bnb, const float* __restrict__ smb,
+    const uint32_t* __restrict__ rec, const bf16_t* __restrict__ gout, bf16_t* __restrict__ da, float* __restrict__ dWb,
+    double* __restrict__ stats_a, const bf16_t* __restrict__ zst, int64_t V, int64_t N) {
+  constexpr int NB = CO / 32, GS = CO / G;
+  __shared__ __attribute__((aligned(16))) float s_taba[NB][TAB_FLOATS], s_tabb[NB][TAB_FLOATS];
+  __shared__ __attribute__((aligned(16))) bf16_t s_ta[NB][32 * TSB], s_tb[NB][32 * TSB];     // dz_b tiles | y_a tiles
+  __shared__ __attribute__((aligned(16))) uint4 s_wb[WGRAD ? NB : 1][WGRAD ? NB : 1][WGRAD ? 64 : 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    stage_tab_c(s_taba[b], bna, CO, 32 * b, nullptr);
+    stage_tab_c(s_tabb[b], bnb, CO, 32 * b, smb);
+  }
+  // weight-stationary slices of this wavefront's output block
+  bf16x8 wB0[NB], wB1[WGRAD ? 1 : NB], wT[WGRAD ? 1 : NB][2];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    wB0[b] = load_op(eops, op_fwd<NB>(w, b, 0), lane);
+    if constexpr (WGRAD) {
+      s_wb[w][b][lane] = eops[op_fwd<NB>(w, b, 1) * 64 + lane];
+    } else {
+      wB1[b] = load_op(eops, op_fwd<NB>(w, b, 1), lane);
+      wT[b][0] = load_op(eops, op_bwd<NB>(w, b, 0), lane);
+      wT[b][1] = load_op(eops, op_bwd<NB>(w, b, 1), lane);
+    }
+  }
+  __syncthreads();
+  f32x16 accW[WGRAD ? NB : 1];
+#pragma unroll
+  for (int b = 0; b < (WGRAD ? NB : 1); ++b) {
+    const f32x16 zero = {0};
+    accW[b] = zero;
+  }
+  float sa1 = 0.f, sa2 = 0.f;
+  const __amdgpu_buffer_rsrc_t RC = make_rsrc(rec, (uint64_t)V * 16), GO = make_rsrc(gout, (uint64_t)N * CO * 2);
+  const int n_tiles = n_tiles_dev[0];
+  const int t0 = (int)((int64_t)n_tiles * blockIdx.x / gridDim.x), t1 = (int)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  auto fetch = [&](int t, u32x4 (&z)[2], u32x4& rc, bool& ok, TileInfo& ti) {
+    ti = get_tile(tiles, t);
+    ok = j < ti.nv;
+    const __amdgpu_buffer_rsrc_t Z = make_rsrc(zst + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
+    const uint32_t off = ok ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * w + 16 * h) * 2u : OOB;
+    z[0] = ld128(Z, off);
+    z[1] = ld128(Z, ok ? off + 16u : OOB);
+    rc = ld128(RC, ok ? (uint32_t)(ti.v0 + j) * 16u : OOB);
+  };
+  u32x4 zq[2], rq;
+  bool ok = false;
+  TileInfo ti_next;
+  ti_next.v0 = ti_next.nv = ti_next.frag = 0;
+  if (t0 < t1) fetch(t0, zq, rq, ok, ti_next);
+  for (int t = t0; t < t1; ++t) {
+    const bool ok_cur = ok;
+    const uint32_t keep = ok_cur ? 0xffffffffu : 0u;
+    const TileInfo ti = ti_next;
+    const u32x4 zk0 = zq[0], zk1 = zq[1], rc = rq;
+    {
+      // this wavefront's block of y_a = leaky(BatchNorm_a(z_a)) (0 for lanes without a view) -> its tile
+      f32x16 za;
+      const uint32_t v[8] = {zk0.x, zk0.y, zk0.z, zk0.w, zk1.x, zk1.y, zk1.z, zk1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        za[2 * i] = __uint_as_float(v[i] << 16);
+        za[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+      }
+      bf16x8 a[2];
+      act_pack(za, s_taba[w], h, keep, a);
+      tileN_put_packed(s_tb[w], j, h, a);
+    }
+    // the value gradient of this block, requested before the first barrier: (gate attention)[g] grad_out[point][ch]
+    u32x2 gv[4];
+    {
+      const uint32_t pid = rc.x;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        gv[q] = ld64(GO, ok_cur ? pid * (uint32_t)(CO * 2) + (uint32_t)(32 * w + 8 * q + 4 * h) * 2u : OOB);
+    }
+    if (t + 1 < t1) fetch(t + 1, zq, rq, ok, ti_next);       // the next tile's loads fly during the products
+    __syncthreads();       // y_a tiles of all blocks written (and: the dz_b tiles of the previous tile are consumed)
+    // ---- z_b[w] = sum_b W_b[w][b] y_a[b]
+    f32x16 zb = {0};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bf16_t* row = s_tb[b] + j * TSB + 16 * h;          // the packed y_a operand of view j, block b
+      zb = CH_MFMA(wB0[b], *reinterpret_cast<const bf16x8*>(row), zb);
+      if constexpr (WGRAD) zb = CH_MFMA(__builtin_bit_cast(bf16x8, s_wb[w][b][lane]), *reinterpret_cast<const bf16x8*>(row + 8), zb);
+      else zb = CH_MFMA(wB1[b], *reinterpret_cast<const bf16x8*>(row + 8), zb);
+    }
+    // ---- dz_b[w]: dy_b = leaky'(y_b) d value, dz_b = G_b dy_b - K1 - K2 z_b (as emodw_bwd MODE 3)
+    {
+      const float ga4[4] = {__uint_as_float(rc.y << 16), __uint_as_float(rc.y & 0xffff0000u),
+                            __uint_as_float(rc.z << 16), __uint_as_float(rc.z & 0xffff0000u)};
+      const float gg = ga4[G == 1 ? 0 : (32 * w) / GS];      // a 32-channel block lies inside one group (GS >= 32)
+      static_assert(GS % 32 == 0, "a block inside one channel group");
+      float dz[16];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {        // four channels at a time: sixteen constants live instead of 64 (register budget)
+        const float dy[4] = {gg * __uint_as_float(gv[q].x << 16), gg * __uint_as_float(gv[q].x & 0xffff0000u),
+                             gg * __uint_as_float(gv[q].y << 16), gg * __uint_as_float(gv[q].y & 0xffff0000u)};
+        const int o = 16 * h + 4 * q;
+        const float4 g4 = *reinterpret_cast<const float4*>(s_tabb[w] + T_G * D + o);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_tabb[w] + T_B * D + o);
+        const float4 a4 = *reinterpret_cast<const float4*>(s_tabb[w] + T_K1 * D + o);
+        const float4 c4 = *reinterpret_cast<const float4*>(s_tabb[w] + T_K2 * D + o);
+        const float g_[4] = {g4.x, g4.y, g4.z, g4.w}, b_[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float k1[4] = {a4.x, a4.y, a4.z, a4.w}, k2[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float dyb = __builtin_fmaf(zb[r], g_[e], b_[e]) > 0.f ? dy[e] : SLOPE * dy[e];
+          dz[r] = __builtin_fmaf(-k2[e], zb[r], __builtin_fmaf(g_[e], dyb, -k1[e]));       // = bn_bwd_apply
+        }
+      }
+      bf16x8 t2[2];
+      pack16(dz, keep, t2);
+      tileN_put_packed(s_ta[w], j, h, t2);
+    }
+    __syncthreads();       // dz_b tiles of all blocks written (and: the y_a tiles are consumed by the products above)
+    if constexpr (WGRAD) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) accW[b] = wgradN(s_ta[w], s_tb[b], lane, accW[b]);      // dW_b[32 w ..][32 b ..]
+    } else {
+      f32x16 dya = {0};
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+        const bf16_t* row = s_ta[mb] + j * TSB + 16 * h;        // the packed dz_b operand of view j, block mb
+        dya = CH_MFMA(wT[mb][0], *reinterpret_cast<const bf16x8*>(row), dya);
+        dya = CH_MFMA(wT[mb][1], *reinterpret_cast<const bf16x8*>(row + 8), dya);
+      }
+      const uint32_t zv[8] = {zk0.x, zk0.y, zk0.z, zk0.w, zk1.x, zk1.y, zk1.z, zk1.w};
+      float tt[16], zaf[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(s_taba[w] + T_G * D + 16 * h + 4 * q);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_taba[w] + T_B * D + 16 * h + 4 * q);
+        const float g_[4] = {g4.x, g4.y, g4.z, g4.w}, b_[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          zaf[r] = (r & 1) ? __uint_as_float(zv[r >> 1] & 0xffff0000u) : __uint_as_float(zv[r >> 1] << 16);
+          tt[r] = __builtin_fmaf(zaf[r], g_[e], b_[e]) > 0.f ? dya[r] : SLOPE * dya[r];
+        }
+      }
+      bf16x8 pk[2] = {pack8(&tt[0]), pack8(&tt[8])};     // lanes without a view: dz_b = 0 -> dy_a = 0
+      {
+        const __amdgpu_buffer_rsrc_t DA = make_rsrc(da + (int64_t)ti.v0 * CO, (uint64_t)ti.nv * CO * 2);
+        const uint32_t off = ok_cur ? (uint32_t)j * (uint32_t)(CO * 2) + (uint32_t)(32 * w + 16 * h) * 2u : OOB;
+        st128(DA, off, __builtin_bit_cast(u32x4, pk[0]));
+        st128(DA, ok_cur ? off + 16u : OOB, __builtin_bit_cast(u32x4, pk[1]));
+      }
+      // S of BatchNorm_a through this wavefront's own y_a tile: every reader passed the second barrier, and this
+      // wavefront refills the tile before the next first barrier
+      bf16_t* tdy = s_tb[w];
+      tileN_put_packed(tdy, j, h, pk);
+      wave_sync();
+      col_sum1(tdy, lane, sa1);
+      wave_sync();
+      float dyr[16], pr[16];
+      unpack8(pk[0], reinterpret_cast<float(&)[8]>(dyr[0]));
+      unpack8(pk[1], reinterpret_cast<float(&)[8]>(dyr[8]));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = dyr[r] * zaf[r];
+      bf16x8 pp[2] = {pack8(&pr[0]), pack8(&pr[8])};
+      tileN_put_packed(tdy, j, h, pp);
+      wave_sync();
+      col_sum1(tdy, lane, sa2);
+      wave_sync();
+    }
+  }
+  if constexpr (WGRAD) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomicAdd(&dWb[(size_t)(32 * w + cperm(chan(r, h))) * CO + 32 * b + cperm(j)], accW[b][r]);
+    }
+  } else {
+    const float a0 = sa1 + other_half(sa1), a1 = sa2 + other_half(sa2);
+    if (h == 0) {
+      atomicAdd(&stats_a[32 * w + cperm(j)], (double)a0);
+      atomicAdd(&stats_a[CO + 32 * w + cperm(j)], (double)a1);
+    }
+  }
+}
+
 }  // namespace emod
 }  // namespace dva
 
@@ -2129,6 +2332,22 @@ int dva_emod_bwd(int32_t stage, const void* Y, const int32_t* tap_rows, const fl
       case 128 * 8 + 4: DVA_EMODW(4); break;
 #undef DVA_EMODW
       case 256 * 8 + 4:
+        {
+          // round 6 (second form, A/B): no dz_b hand-off at all -- two cooperative kernels that each evaluate dz_b themselves
+          // (emodw_coop2_kernel).  Parity-green and SLOWER (25.9 against 23.3 ms, profiles/r06_emod_coop2_ab.json): with one
+          // 512-thread block per CU nothing overlaps its two barriers per tile.  DVA_EMOD_COOP2=1 selects it; default:
+          // MODE 3 + the merged cooperative kernel below
+          static const int coop2 = tune_int("DVA_EMOD_COOP2", 0);
+          if (coop2) {
+            hipLaunchKernelGGL((emodw_coop2_kernel<256, 4, false>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles,
+                               n_tiles, (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec,
+                               (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
+            hipLaunchKernelGGL((emodw_coop2_kernel<256, 4, true>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles,
+                               n_tiles, (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec,
+                               (const bf16_t*)grad_out, (bf16_t*)da, dWb, stats_a, (const bf16_t*)z_a, n_views, n_points);
+            break;
+          }
+        }
         // W_b (128 KB per orientation) does not fit LDS twice: dz_b -> `da`, dW_b from the stored dz_b, dy_a in place
         hipLaunchKernelGGL((emodw_bwd_kernel<256, 4, 3>), dim3(chain_grid(1)), dim3(512), 0, s, (const int2*)tiles, n_tiles,
                            (const uint4*)eops, bn_a, bn_b, sm_b, (const uint32_t*)view_rec, (const bf16_t*)grad_out,
