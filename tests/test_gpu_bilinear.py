@@ -542,3 +542,22 @@ def test_interpolated_features_cat_equals_torch_composition():
         via_taps = (cat.rows[cat.tap_rows.long()].float() * cat.tap_weights.unsqueeze(-1)).sum(1)
         torch.testing.assert_close(via_taps, cat.materialize().float(), rtol=1e-5, atol=1e-5)
     assert ops.InterpolatedFeatures.cat(items[:1]) is items[0]
+
+
+@pytest.mark.parametrize("env", [{"DVA_EMOD_COOP2": "1"}, {"DVA_EMOD_COOP_DYA": "0"}])
+def test_c256_backward_variants_stay_green(env):
+    """The A/B forms of the C_o = 256 E_mod backward (round 6: `emodw_coop2_kernel` = no dz_b hand-off; the round-4 pair
+    emodw_wgrad_coop + MODE 4) are selected by switches the library reads once per process: the C_o = 256 oracle /
+    emulation cases of this file run again in a child process under each switch."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DVA_BILINEAR_VARIANT_CHILD") == "1":
+        pytest.skip("child process")
+    e = dict(os.environ, DVA_BILINEAR_VARIANT_CHILD="1", **env)
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-k", "256 and not variants"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
