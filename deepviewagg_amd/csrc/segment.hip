@@ -312,7 +312,7 @@ using namespace dva;
 
 extern "C" {
 
-int dva_version(void) { return 301; }
+int dva_version(void) { return 306; }
 
 int dva_device_count(void) {
   int n = 0;
